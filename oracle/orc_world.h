@@ -1,0 +1,210 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.  Nothing under evomotion_amd/ may include, link or call this.
+//
+// Scalar CPU restatement of the reference's robot_walk environment:
+//   Environment::do_step / reset            evo_motion_model/src/environment.cpp:33-48
+//   RobotWalk ctor / compute_step / reset   evo_motion_model/src/env/robot_walk.cpp:17-104
+//   Skeleton body / constraint / state order evo_motion_model/src/robot/skeleton.cpp:77-160
+//   RigidBodyItem                           evo_motion_model/src/item.cpp:17-86
+//   Hinge / Fixed constraints               evo_motion_model/src/robot/constraint.cpp:52-69,137-150
+//   Muscle (slider + 2 p2p)                 evo_motion_model/src/robot/muscle.cpp:14-85
+//   Proprioception states                   evo_motion_model/src/robot/proprioception_state.cpp:21-129
+// plus the third-party algorithm those files delegate to: Bullet3's btDiscreteDynamicsWorld::stepSimulation
+// with the sequential-impulse solver [UPSTREAM — Bullet3 is an un-vendored, un-pinned system dependency
+// (evo_motion_model/CMakeLists.txt:14); its algorithm is restated here from the published bullet3 3.x
+// sources as remembered, it could not be compiled or run in this image].
+//
+// PARITY STATUS: *parity unpinned* for the physics half.  The reference holds no test, golden vector or
+// fixture for evo_motion_model, and Bullet3 is unavailable, so this restatement is pinned
+// only by (a) analytic invariants (tests/test_oracle_physics.py) and (b) the independently verifiable
+// constants of SURVEY.md App. D (RNG stream, step counters, dimensions).
+//
+// Deliberate deviation (stated in DESIGN.md): collision detection is hull-vs-floor-plane only
+// (deepest hull vertex per step fed into a Bullet-style 4-point persistent manifold); member-vs-member
+// self collision, which Bullet would also run (GJK/EPA), is not modelled.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "orc_math.h"
+
+namespace orc {
+
+struct ShapeDef {
+    std::string name;
+    std::vector<V3> pts;  // unique hull points, first-occurrence order
+};
+struct MemberDef {
+    std::string name;
+    int shape;
+    float mass, friction;
+    V3 t;
+    float qw, qx, qy, qz;
+    V3 scale;
+    int ignore_collision;
+};
+struct ConstraintDef {
+    int type;  // 0 hinge, 1 fixed
+    std::string name;
+    int parent, child;
+    // hinge
+    V3 pivot_p, pivot_c, axis_p, axis_c;
+    float lim_lo, lim_hi;
+    // fixed
+    V3 tp, tc;
+    float qp[4], qc[4];  // w x y z
+};
+struct MuscleDef {
+    std::string name;
+    int a, b;
+    float attach_mass;
+    V3 attach_scale, pos_a, pos_b;
+    float force, speed;
+};
+struct SkeletonDef {
+    std::string robot_name, root_name;
+    std::vector<MemberDef> members;
+    std::vector<ConstraintDef> constraints;
+    std::vector<MuscleDef> muscles;
+    std::vector<ShapeDef> shapes;
+    int shape_index(const std::string &n) const;
+    int member_index(const std::string &n) const;
+};
+bool load_skeleton(const char *path, SkeletonDef &out, std::string &err);
+
+struct EnvParams {
+    float initial_remaining_seconds = 1.f;  // evo_motion_model/src/env/env_factory.cpp:80-82
+    float max_episode_seconds = 30.f;
+    float target_velocity = 0.5f;
+    float minimal_velocity = 0.1f;
+    int reset_frames = 30;
+};
+
+struct ManifoldPoint {
+    V3 localA, localB;  // A = floor (static), B = member
+    V3 posA, posB, normalB;
+    float dist;
+    float applied, applied_lat;
+    V3 latdir;
+};
+struct Manifold {
+    int n = 0;
+    ManifoldPoint p[4];
+};
+
+struct Body {
+    // constants
+    float mass = 0, inv_mass = 0;
+    V3 inv_inertia_local;
+    float friction = 0.5f;
+    int shape = 0;
+    V3 scale;
+    bool is_member = false;
+    bool contact_response = true;
+    float break_thr = 0.02f;
+    Xf first_model;
+    V3 gravity_force;
+    // state
+    Xf xf;
+    Q q;  // quaternion whose matFromQuat() is xf.b (valid unless the env is in the reset-pending state)
+    V3 lin, ang;
+    M3 iinv_world;
+    V3 ms_origin;  // btDefaultMotionState origin (lags one step)
+    // solver scratch
+    V3 dlin, dang, push, turn, extF, extT;
+};
+
+struct Hinge {
+    int a, b;
+    Xf frameA, frameB;
+    float center, half_range, bias, relaxation;
+    // per-step
+    float angle, correction;
+    bool solve_limit;
+    float applied;
+};
+struct Fixed {
+    int a, b;
+    Xf frameA, frameB;
+    float applied;
+};
+struct Slider {
+    int a, b;
+    float upper_lin;  // lower = 0; ang limits 0,0
+    float max_force, max_speed;
+    bool powered;
+    float target_vel;
+    // per-step
+    float lin_pos, depth0, ang_depth;
+    bool solve_lin, solve_ang;
+    float applied;
+};
+struct P2P {
+    int a, b;
+    V3 pivotA, pivotB;
+    float applied;
+};
+struct WorldConstraint {
+    int type;  // 0 hinge 1 fixed 2 slider 3 p2p
+    int idx;
+};
+
+struct Row {
+    int a, b;  // body index, -1 = static
+    V3 n1, c1, n2, c2, angA, angB;
+    float jd, rhs, rhs_pen, cfm, lo, hi, applied, applied_push, friction;
+    int fric_of;  // for friction rows: index of the normal row
+    int owner;    // constraint index (joint rows) or manifold slot (contact rows)
+};
+
+class World {
+public:
+    SkeletonDef skel;
+    EnvParams prm;
+    std::vector<Body> bodies;  // members, then per muscle attach_a, attach_b  (skeleton.cpp:92-103)
+    std::vector<Hinge> hinges;
+    std::vector<Fixed> fixeds;
+    std::vector<Slider> sliders;
+    std::vector<P2P> p2ps;
+    std::vector<WorldConstraint> order;  // skeleton.cpp:77-90
+    std::vector<Manifold> manifolds;     // one per member (vs floor)
+    int root = 0;
+    std::vector<int> state_members;  // root first, then non-root members in array order (skeleton.cpp:140-160)
+    std::vector<V3> last_lin, last_ang;
+    float floor_top_y = -1.f, floor_friction = 0.5f;
+    Xf floor_xf;
+    MT19937 rng;
+    int rng_draws = 0;
+    int curr_step = 0, max_steps = 0, remaining_steps = 0;
+    bool reset_pending = false;  // world transforms are E*M0 (non-orthonormal) until the next integrate
+    M3 reset_E;
+    // diagnostics of the last step
+    int last_num_contacts = 0, last_num_joint_rows = 0;
+    float last_residual = 0;
+
+    bool init(const SkeletonDef &s, int seed, const EnvParams &p, std::string &err);
+    int nb() const { return (int) bodies.size(); }
+    int nmember() const { return (int) skel.members.size(); }
+    int nmuscle() const { return (int) skel.muscles.size(); }
+    int obs_dim() const { return 19 * nmember() + 4 * nmuscle(); }
+    int act_dim() const { return nmuscle(); }
+
+    void apply_action(const float *action);  // controllers: muscle_controller.cpp:10-12, muscle.cpp:82-85
+    void physics_step();                     // Environment::step_world -> stepSimulation(1/60, n, 1/60)
+    void compute_step(float *obs, float *reward, int *done);
+    void reset_begin();  // RobotWalk::reset_engine up to (not including) the settle steps
+    void reset(float *obs, float *reward, int *done);
+    void do_step(const float *action, float *obs, float *reward, int *done);
+
+    // canonical state blob shared with the HIP implementation (layout: include/evomotion.h)
+    int state_size() const;
+    void get_state(float *out) const;
+    void set_state(const float *in);
+    void get_poses(float *out) const;  // nb x (px py pz qx qy qz qw)
+
+private:
+    void collide();
+    void solve();
+    void integrate();
+};
+
+}  // namespace orc
