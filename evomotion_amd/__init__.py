@@ -1,0 +1,7 @@
+"""evomotion_amd — MI355X-native vectorised robot_walk environment + PPO rollout path.
+
+Product code: HIP kernels and the C ABI in csrc/ (libevomotion_hip.so), host mirrors of the reference's
+Environment / Agent interfaces in env.py / agent.py.  The CPU oracle under /oracle is test infrastructure
+and is never imported from here."""
+from ._lib import DEFAULT_SKELETON, EvmError, LIB_PATH  # noqa: F401
+from .env import RolloutStep, Step, VecRobotWalk  # noqa: F401

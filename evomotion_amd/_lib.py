@@ -1,0 +1,69 @@
+"""ctypes binding of libevomotion_hip.so (the C ABI declared in include/evomotion.h).
+
+The HIP library is the product; there is no CPU or PyTorch fallback.  Importing this module when the
+library has not been built raises ImportError with the build instruction."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libevomotion_hip.so")
+DEFAULT_SKELETON = os.path.join(_HERE, "data", "robot_walk_spider.skel")
+
+EVM_OK = 0
+
+
+class EvmEnvParams(ctypes.Structure):
+    _fields_ = [
+        ("initial_remaining_seconds", ctypes.c_float),
+        ("max_episode_seconds", ctypes.c_float),
+        ("target_velocity", ctypes.c_float),
+        ("minimal_velocity", ctypes.c_float),
+        ("reset_frames", ctypes.c_int),
+    ]
+
+
+class EvmError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C evomotion_amd/csrc`). evomotion_amd has no CPU fallback."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, cp, fp = ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_float)
+    ip = ctypes.POINTER(ctypes.c_int)
+    lib.evm_last_error.restype = cp
+    lib.evm_env_default_params.argtypes = [ctypes.POINTER(EvmEnvParams)]
+    lib.evm_env_create.argtypes = [cp, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, ctypes.POINTER(EvmEnvParams), ctypes.POINTER(vp)]
+    lib.evm_env_destroy.argtypes = [vp]
+    lib.evm_env_destroy.restype = None
+    lib.evm_env_spaces.argtypes = [vp, ip, ip]
+    lib.evm_env_counts.argtypes = [vp, ip, ip, ip, ip]
+    lib.evm_env_reset.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.evm_env_step.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.evm_env_step_autoreset.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    lib.evm_env_get_body_poses.argtypes = [vp, vp, vp]
+    lib.evm_env_state_size.argtypes = [vp]
+    lib.evm_env_get_state.argtypes = [vp, fp]
+    lib.evm_env_set_state.argtypes = [vp, fp]
+    lib.evm_env_debug_reset_begin.argtypes = [vp, vp]
+    lib.evm_env_debug_physics_steps.argtypes = [vp, ctypes.c_int, vp]
+    lib.evm_env_get_body_constants.argtypes = [vp, fp]
+    lib.evm_env_get_diagnostics.argtypes = [vp, vp, vp]
+    lib.evm_env_timing_begin.argtypes = [vp, vp]
+    lib.evm_env_timing_end.argtypes = [vp, vp, fp, ip]
+    return lib
+
+
+lib = _load()
+
+
+def check(rc):
+    if rc != EVM_OK:
+        msg = lib.evm_last_error().decode("utf-8", "replace")
+        if rc == -1:
+            raise ValueError(msg)  # std::invalid_argument in the reference
+        raise EvmError(f"evomotion error {rc}: {msg}")

@@ -1,0 +1,39 @@
+// Device-side view of the vectorised environment state (struct-of-arrays, [field][env], env padded to 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "skel_const.h"
+
+namespace evm {
+
+#define EVM_FLAG_POWERED 1  // Muscle::contract has been called at least once (muscle.cpp:82-85)
+#define EVM_FLAG_PENDING 2  // reset() re-posed the bodies; transforms are E*M0 until the next integrate
+#define EVM_FLAG_DONE 4     // rollout form: the last emitted transition was terminal
+
+struct EnvDev {
+    int n;       // padded env count (multiple of 64)
+    int n_real;  // env count
+    float *pos, *quat, *lin, *ang;  // [nb*3|4][n]
+    float *hist;                    // [nm*6][n]  last_lin, last_ang (proprioception_state.cpp:33-34)
+    int *mfn;                       // [nm][n]    persistent manifold point counts
+    float *mfp;                     // [nm*4*9][n] localA3 localB3 dist applied applied_lateral
+    float *target;                  // [nmus][n]  slider target velocity
+    int *flags, *curr_step, *remaining, *settle_left;  // [n]
+    float *E;                       // [9][n]     reset rotation (rows)
+    float *iinv_stale;              // [nb*6][n]  world inverse inertia used by the first step after reset()
+    uint32_t *mt;                   // [624][n]   std::mt19937 state
+    int *mt_idx;                    // [n]
+    float *scratch;                 // [sc_total][n] per-step constraint data
+    float *diag;                    // [2][n]
+};
+
+hipError_t upload_skeleton(const EvmSkelC *h, hipStream_t s);
+size_t step_lds_bytes(int nb);
+hipError_t launch_step(const EnvDev &d, int nb, int mode, const float *action, float *obs, float *reward,
+                       uint8_t *done, uint8_t *valid, const uint8_t *mask, hipStream_t s);
+hipError_t launch_repose(const EnvDev &d, const uint8_t *mask, hipStream_t s);
+hipError_t launch_init(const EnvDev &d, uint64_t seed, hipStream_t s);
+hipError_t launch_poses(const EnvDev &d, float *out, hipStream_t s);
+
+}  // namespace evm

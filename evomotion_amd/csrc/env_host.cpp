@@ -1,0 +1,369 @@
+// C ABI (include/evomotion.h) for the vectorised robot_walk environment: allocation, launch sequencing,
+// state import/export.  All arithmetic of the hot path lives in env_kernels.hip; there is no CPU fallback.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/evomotion.h"
+#include "env_dev.h"
+#include "skeleton_host.h"
+
+namespace {
+thread_local std::string g_err;
+int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(EVM_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+}  // namespace
+
+struct EvmEnv {
+    EvmSkelC skel;
+    evm::EnvDev d;
+    EvmEnvParams prm;
+    int device;
+    void *arena;
+    size_t arena_bytes;
+    hipEvent_t ev0, ev1;
+    int timed_launches;
+    bool timing;
+};
+
+static const EvmEnv *g_skel_owner = nullptr;
+
+static int ensure_skeleton(EvmEnv *env, hipStream_t s) {
+    if (g_skel_owner != env) {
+        HIP_TRY(evm::upload_skeleton(&env->skel, s));
+        g_skel_owner = env;
+    }
+    return EVM_OK;
+}
+
+extern "C" {
+
+const char *evm_last_error(void) { return g_err.c_str(); }
+
+void evm_env_default_params(EvmEnvParams *p) {
+    p->initial_remaining_seconds = 1.f;
+    p->max_episode_seconds = 30.f;
+    p->target_velocity = 0.5f;
+    p->minimal_velocity = 0.1f;
+    p->reset_frames = 30;
+}
+
+int evm_env_create(const char *skeleton_path, int n_envs, int device, uint64_t seed, const EvmEnvParams *params,
+                   EvmEnv **out) {
+    if (!out) return fail(EVM_E_INVALID, "out is null");
+    *out = nullptr;
+    if (n_envs < 1) return fail(EVM_E_INVALID, "n_envs must be >= 1");
+    EvmEnvParams prm;
+    evm_env_default_params(&prm);
+    if (params) prm = *params;
+    EvmEnv *env = new EvmEnv();
+    memset(&env->d, 0, sizeof(env->d));
+    env->prm = prm;
+    env->device = device;
+    env->arena = nullptr;
+    env->timing = false;
+    env->timed_launches = 0;
+    std::string err;
+    int rc = evm::load_skeleton_constants(skeleton_path, prm, env->skel, err);
+    if (rc != EVM_OK) { delete env; return fail(rc, err); }
+    const EvmSkelC &S = env->skel;
+    if (evm::step_lds_bytes(S.nb) > 160 * 1024) { delete env; return fail(EVM_E_UNSUPPORTED, "skeleton has too many bodies for the LDS tile"); }
+    hipError_t he = hipSetDevice(device);
+    if (he != hipSuccess) { delete env; return fail(EVM_E_HIP, std::string("hipSetDevice: ") + hipGetErrorString(he)); }
+
+    const size_t n = ((size_t) n_envs + 63) / 64 * 64;
+    env->d.n = (int) n;
+    env->d.n_real = n_envs;
+    struct Seg { void **p; size_t count; };
+    std::vector<Seg> segs = {
+        {(void **) &env->d.pos, 3u * S.nb}, {(void **) &env->d.quat, 4u * S.nb}, {(void **) &env->d.lin, 3u * S.nb},
+        {(void **) &env->d.ang, 3u * S.nb}, {(void **) &env->d.hist, 6u * S.nm}, {(void **) &env->d.mfn, 1u * S.nm},
+        {(void **) &env->d.mfp, 36u * S.nm}, {(void **) &env->d.target, (size_t) (S.nmus > 0 ? S.nmus : 1)},
+        {(void **) &env->d.flags, 1}, {(void **) &env->d.curr_step, 1}, {(void **) &env->d.remaining, 1},
+        {(void **) &env->d.settle_left, 1}, {(void **) &env->d.E, 9}, {(void **) &env->d.iinv_stale, 6u * S.nb},
+        {(void **) &env->d.mt, 624}, {(void **) &env->d.mt_idx, 1}, {(void **) &env->d.scratch, (size_t) S.sc_total},
+        {(void **) &env->d.diag, 2}};
+    size_t total = 0;
+    for (auto &s : segs) total += s.count * n * 4;
+    he = hipMalloc(&env->arena, total);
+    if (he != hipSuccess) { delete env; return fail(EVM_E_HIP, std::string("hipMalloc: ") + hipGetErrorString(he)); }
+    env->arena_bytes = total;
+    hipMemset(env->arena, 0, total);
+    char *base = (char *) env->arena;
+    for (auto &s : segs) { *s.p = base; base += s.count * n * 4; }
+    hipEventCreate(&env->ev0);
+    hipEventCreate(&env->ev1);
+    g_skel_owner = nullptr;
+    rc = ensure_skeleton(env, 0);
+    if (rc != EVM_OK) { evm_env_destroy(env); return rc; }
+    he = evm::launch_init(env->d, seed, 0);
+    if (he == hipSuccess) he = hipDeviceSynchronize();
+    if (he != hipSuccess) { evm_env_destroy(env); return fail(EVM_E_HIP, std::string("init: ") + hipGetErrorString(he)); }
+    *out = env;
+    return EVM_OK;
+}
+
+void evm_env_destroy(EvmEnv *env) {
+    if (!env) return;
+    if (g_skel_owner == env) g_skel_owner = nullptr;
+    if (env->arena) hipFree(env->arena);
+    hipEventDestroy(env->ev0);
+    hipEventDestroy(env->ev1);
+    delete env;
+}
+
+int evm_env_spaces(const EvmEnv *env, int *state_dim, int *action_dim) {
+    if (!env) return fail(EVM_E_INVALID, "env is null");
+    if (state_dim) *state_dim = env->skel.obs_dim;
+    if (action_dim) *action_dim = env->skel.act_dim;
+    return EVM_OK;
+}
+int evm_env_counts(const EvmEnv *env, int *n_envs, int *n_bodies, int *n_members, int *n_muscles) {
+    if (!env) return fail(EVM_E_INVALID, "env is null");
+    if (n_envs) *n_envs = env->d.n_real;
+    if (n_bodies) *n_bodies = env->skel.nb;
+    if (n_members) *n_members = env->skel.nm;
+    if (n_muscles) *n_muscles = env->skel.nmus;
+    return EVM_OK;
+}
+
+static int step_launch(EvmEnv *env, int mode, const float *a, float *obs, float *rew, uint8_t *done, uint8_t *valid,
+                       const uint8_t *mask, hipStream_t s) {
+    int rc = ensure_skeleton(env, s);
+    if (rc != EVM_OK) return rc;
+    HIP_TRY(evm::launch_step(env->d, env->skel.nb, mode, a, obs, rew, done, valid, mask, s));
+    if (env->timing) env->timed_launches++;
+    return EVM_OK;
+}
+
+int evm_env_reset(EvmEnv *env, const uint8_t *d_mask, float *d_obs, float *d_reward, uint8_t *d_done, void *stream) {
+    if (!env || !d_obs || !d_reward || !d_done) return fail(EVM_E_INVALID, "null argument");
+    hipStream_t s = (hipStream_t) stream;
+    int rc = ensure_skeleton(env, s);
+    if (rc != EVM_OK) return rc;
+    HIP_TRY(evm::launch_repose(env->d, d_mask, s));
+    const int settle = 2 * env->prm.reset_frames;
+    for (int i = 0; i < settle; i++) {
+        const bool last = i == settle - 1;
+        rc = step_launch(env, last ? 2 : 0, nullptr, d_obs, d_reward, d_done, nullptr, d_mask, s);
+        if (rc != EVM_OK) return rc;
+    }
+    if (settle == 0) return fail(EVM_E_UNSUPPORTED, "reset_frames == 0 is not supported");
+    return EVM_OK;
+}
+
+int evm_env_step(EvmEnv *env, const float *d_action, float *d_obs, float *d_reward, uint8_t *d_done, void *stream) {
+    if (!env || !d_action || !d_obs || !d_reward || !d_done) return fail(EVM_E_INVALID, "null argument");
+    return step_launch(env, 3, d_action, d_obs, d_reward, d_done, nullptr, nullptr, (hipStream_t) stream);
+}
+
+int evm_env_step_autoreset(EvmEnv *env, const float *d_action, float *d_obs, float *d_reward, uint8_t *d_done,
+                           uint8_t *d_valid, void *stream) {
+    if (!env || !d_action || !d_obs || !d_reward || !d_done || !d_valid) return fail(EVM_E_INVALID, "null argument");
+    return step_launch(env, 7, d_action, d_obs, d_reward, d_done, d_valid, nullptr, (hipStream_t) stream);
+}
+
+int evm_env_get_body_poses(const EvmEnv *env, float *d_pose, void *stream) {
+    if (!env || !d_pose) return fail(EVM_E_INVALID, "null argument");
+    int rc = ensure_skeleton(const_cast<EvmEnv *>(env), (hipStream_t) stream);
+    if (rc != EVM_OK) return rc;
+    HIP_TRY(evm::launch_poses(env->d, d_pose, (hipStream_t) stream));
+    return EVM_OK;
+}
+
+int evm_env_debug_reset_begin(EvmEnv *env, const uint8_t *d_mask) {
+    if (!env) return fail(EVM_E_INVALID, "env is null");
+    int rc = ensure_skeleton(env, 0);
+    if (rc != EVM_OK) return rc;
+    HIP_TRY(evm::launch_repose(env->d, d_mask, 0));
+    HIP_TRY(hipDeviceSynchronize());
+    return EVM_OK;
+}
+int evm_env_debug_physics_steps(EvmEnv *env, int n_steps, const uint8_t *d_mask) {
+    if (!env) return fail(EVM_E_INVALID, "env is null");
+    for (int i = 0; i < n_steps; i++) {
+        int rc = step_launch(env, 0, nullptr, nullptr, nullptr, nullptr, nullptr, d_mask, 0);
+        if (rc != EVM_OK) return rc;
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    return EVM_OK;
+}
+
+int evm_env_get_body_constants(const EvmEnv *env, float *out) {
+    if (!env || !out) return fail(EVM_E_INVALID, "null argument");
+    const EvmSkelC &S = env->skel;
+    int k = 0;
+    for (int b = 0; b < S.nb; b++) {
+        const EvmBodyC &B = S.body[b];
+        out[k++] = B.mass; out[k++] = B.inv_mass;
+        out[k++] = B.inv_inertia[0]; out[k++] = B.inv_inertia[1]; out[k++] = B.inv_inertia[2];
+        out[k++] = B.friction;
+        out[k++] = b < S.nm ? S.member[b].break_thr : 0.f;
+        for (int i = 0; i < 9; i++) out[k++] = B.m0[i];
+        for (int i = 0; i < 3; i++) out[k++] = B.t0[i];
+    }
+    return EVM_OK;
+}
+
+int evm_env_get_diagnostics(const EvmEnv *env, float *d_out, void *stream) {
+    if (!env || !d_out) return fail(EVM_E_INVALID, "null argument");
+    // diag is [2][n] field-major on the device; hand it out as [n_envs, 2]
+    std::vector<float> h(2 * (size_t) env->d.n), o(2 * (size_t) env->d.n_real);
+    HIP_TRY(hipStreamSynchronize((hipStream_t) stream));
+    HIP_TRY(hipMemcpy(h.data(), env->d.diag, h.size() * 4, hipMemcpyDeviceToHost));
+    for (int e = 0; e < env->d.n_real; e++) { o[2 * e] = h[e]; o[2 * e + 1] = h[(size_t) env->d.n + e]; }
+    HIP_TRY(hipMemcpy(d_out, o.data(), o.size() * 4, hipMemcpyHostToDevice));
+    return EVM_OK;
+}
+
+// ---- canonical state blob -------------------------------------------------------------------
+int evm_env_state_size(const EvmEnv *env) {
+    if (!env) return fail(EVM_E_INVALID, "env is null");
+    const EvmSkelC &S = env->skel;
+    return 13 * S.nb + 1 + 9 + 6 * S.nb + 3 * S.nm + 6 * S.nm + 37 * S.nm + S.nmus + 1 + 2;
+}
+
+namespace {
+struct HostMirror {
+    std::vector<float> pos, quat, lin, ang, hist, mfp, target, E, iinv, scratch_ms;
+    std::vector<int> mfn, flags, curr, rem;
+};
+}
+
+int evm_env_get_state(EvmEnv *env, float *h_state) {
+    if (!env || !h_state) return fail(EVM_E_INVALID, "null argument");
+    const EvmSkelC &S = env->skel;
+    const size_t n = env->d.n;
+    HIP_TRY(hipDeviceSynchronize());
+    auto dl = [&](const void *src, size_t count, std::vector<float> &dst) {
+        dst.resize(count * n);
+        return hipMemcpy(dst.data(), src, count * n * 4, hipMemcpyDeviceToHost);
+    };
+    auto dli = [&](const void *src, size_t count, std::vector<int> &dst) {
+        dst.resize(count * n);
+        return hipMemcpy(dst.data(), src, count * n * 4, hipMemcpyDeviceToHost);
+    };
+    HostMirror m;
+    HIP_TRY(dl(env->d.pos, 3 * S.nb, m.pos)); HIP_TRY(dl(env->d.quat, 4 * S.nb, m.quat));
+    HIP_TRY(dl(env->d.lin, 3 * S.nb, m.lin)); HIP_TRY(dl(env->d.ang, 3 * S.nb, m.ang));
+    HIP_TRY(dl(env->d.hist, 6 * S.nm, m.hist)); HIP_TRY(dl(env->d.mfp, 36 * S.nm, m.mfp));
+    HIP_TRY(dl(env->d.target, S.nmus > 0 ? S.nmus : 1, m.target)); HIP_TRY(dl(env->d.E, 9, m.E));
+    HIP_TRY(dl(env->d.iinv_stale, 6 * S.nb, m.iinv));
+    HIP_TRY(dl(env->d.scratch + (size_t) S.sc_ms * n, 3 * S.nm, m.scratch_ms));
+    HIP_TRY(dli(env->d.mfn, S.nm, m.mfn)); HIP_TRY(dli(env->d.flags, 1, m.flags));
+    HIP_TRY(dli(env->d.curr_step, 1, m.curr)); HIP_TRY(dli(env->d.remaining, 1, m.rem));
+    const int ss = evm_env_state_size(env);
+    for (int e = 0; e < env->d.n_real; e++) {
+        float *o = h_state + (size_t) e * ss;
+        int k = 0;
+        const bool pending = (m.flags[e] & EVM_FLAG_PENDING) != 0;
+        for (int b = 0; b < S.nb; b++) {
+            for (int a = 0; a < 3; a++) o[k++] = m.pos[(size_t) (3 * b + a) * n + e];
+            if (pending) { o[k++] = 0.f; o[k++] = 0.f; o[k++] = 0.f; o[k++] = 1.f; }
+            else for (int a = 0; a < 4; a++) o[k++] = m.quat[(size_t) (4 * b + a) * n + e];
+            for (int a = 0; a < 3; a++) o[k++] = m.lin[(size_t) (3 * b + a) * n + e];
+            for (int a = 0; a < 3; a++) o[k++] = m.ang[(size_t) (3 * b + a) * n + e];
+        }
+        o[k++] = pending ? 1.f : 0.f;
+        for (int a = 0; a < 9; a++) o[k++] = m.E[(size_t) a * n + e];
+        for (int a = 0; a < 6 * S.nb; a++) o[k++] = m.iinv[(size_t) a * n + e];
+        for (int a = 0; a < 3 * S.nm; a++) o[k++] = m.scratch_ms[(size_t) a * n + e];
+        for (int a = 0; a < 6 * S.nm; a++) o[k++] = m.hist[(size_t) a * n + e];
+        for (int mm = 0; mm < S.nm; mm++) {
+            const int cnt = m.mfn[(size_t) mm * n + e];
+            o[k++] = (float) cnt;
+            for (int j = 0; j < 4; j++)
+                for (int f = 0; f < 9; f++) o[k++] = j < cnt ? m.mfp[(size_t) ((mm * 4 + j) * 9 + f) * n + e] : 0.f;
+        }
+        for (int a = 0; a < S.nmus; a++) o[k++] = m.target[(size_t) a * n + e];
+        o[k++] = (m.flags[e] & EVM_FLAG_POWERED) ? 1.f : 0.f;
+        o[k++] = (float) m.curr[e];
+        o[k++] = (float) m.rem[e];
+    }
+    return EVM_OK;
+}
+
+int evm_env_set_state(EvmEnv *env, const float *h_state) {
+    if (!env || !h_state) return fail(EVM_E_INVALID, "null argument");
+    const EvmSkelC &S = env->skel;
+    const size_t n = env->d.n;
+    HIP_TRY(hipDeviceSynchronize());
+    HostMirror m;
+    m.pos.assign(3 * S.nb * n, 0.f); m.quat.assign(4 * S.nb * n, 0.f); m.lin.assign(3 * S.nb * n, 0.f);
+    m.ang.assign(3 * S.nb * n, 0.f); m.hist.assign(6 * S.nm * n, 0.f); m.mfp.assign(36 * S.nm * n, 0.f);
+    m.target.assign((S.nmus > 0 ? S.nmus : 1) * n, 0.f); m.E.assign(9 * n, 0.f); m.iinv.assign(6 * S.nb * n, 0.f);
+    m.scratch_ms.assign(3 * S.nm * n, 0.f);
+    m.mfn.assign(S.nm * n, 0); m.flags.assign(n, 0); m.curr.assign(n, 0); m.rem.assign(n, 0);
+    // keep the rollout flag and whatever the padded lanes hold
+    HIP_TRY(hipMemcpy(m.flags.data(), env->d.flags, n * 4, hipMemcpyDeviceToHost));
+    const int ss = evm_env_state_size(env);
+    for (int e = 0; e < env->d.n_real; e++) {
+        const float *in = h_state + (size_t) e * ss;
+        int k = 0;
+        for (int b = 0; b < S.nb; b++) {
+            for (int a = 0; a < 3; a++) m.pos[(size_t) (3 * b + a) * n + e] = in[k++];
+            for (int a = 0; a < 4; a++) m.quat[(size_t) (4 * b + a) * n + e] = in[k++];
+            for (int a = 0; a < 3; a++) m.lin[(size_t) (3 * b + a) * n + e] = in[k++];
+            for (int a = 0; a < 3; a++) m.ang[(size_t) (3 * b + a) * n + e] = in[k++];
+        }
+        const bool pending = in[k++] != 0.f;
+        for (int a = 0; a < 9; a++) m.E[(size_t) a * n + e] = in[k++];
+        for (int a = 0; a < 6 * S.nb; a++) m.iinv[(size_t) a * n + e] = in[k++];
+        for (int a = 0; a < 3 * S.nm; a++) m.scratch_ms[(size_t) a * n + e] = in[k++];
+        for (int a = 0; a < 6 * S.nm; a++) m.hist[(size_t) a * n + e] = in[k++];
+        for (int mm = 0; mm < S.nm; mm++) {
+            m.mfn[(size_t) mm * n + e] = (int) in[k++];
+            for (int j = 0; j < 4; j++)
+                for (int f = 0; f < 9; f++) m.mfp[(size_t) ((mm * 4 + j) * 9 + f) * n + e] = in[k++];
+        }
+        for (int a = 0; a < S.nmus; a++) m.target[(size_t) a * n + e] = in[k++];
+        const bool powered = in[k++] != 0.f;
+        m.curr[e] = (int) in[k++];
+        m.rem[e] = (int) in[k++];
+        int f = m.flags[e] & ~(EVM_FLAG_PENDING | EVM_FLAG_POWERED);
+        if (pending) f |= EVM_FLAG_PENDING;
+        if (powered) f |= EVM_FLAG_POWERED;
+        m.flags[e] = f;
+    }
+    auto ul = [&](void *dst, const std::vector<float> &src) { return hipMemcpy(dst, src.data(), src.size() * 4, hipMemcpyHostToDevice); };
+    auto uli = [&](void *dst, const std::vector<int> &src) { return hipMemcpy(dst, src.data(), src.size() * 4, hipMemcpyHostToDevice); };
+    HIP_TRY(ul(env->d.pos, m.pos)); HIP_TRY(ul(env->d.quat, m.quat)); HIP_TRY(ul(env->d.lin, m.lin));
+    HIP_TRY(ul(env->d.ang, m.ang)); HIP_TRY(ul(env->d.hist, m.hist)); HIP_TRY(ul(env->d.mfp, m.mfp));
+    HIP_TRY(ul(env->d.target, m.target)); HIP_TRY(ul(env->d.E, m.E)); HIP_TRY(ul(env->d.iinv_stale, m.iinv));
+    HIP_TRY(ul(env->d.scratch + (size_t) S.sc_ms * n, m.scratch_ms));
+    HIP_TRY(uli(env->d.mfn, m.mfn)); HIP_TRY(uli(env->d.flags, m.flags));
+    HIP_TRY(uli(env->d.curr_step, m.curr)); HIP_TRY(uli(env->d.remaining, m.rem));
+    return EVM_OK;
+}
+
+// ---- timing ------------------------------------------------------------------------------------
+int evm_env_timing_begin(EvmEnv *env, void *stream) {
+    if (!env) return fail(EVM_E_INVALID, "env is null");
+    env->timing = true;
+    env->timed_launches = 0;
+    HIP_TRY(hipEventRecord(env->ev0, (hipStream_t) stream));
+    return EVM_OK;
+}
+int evm_env_timing_end(EvmEnv *env, void *stream, float *ms_total, int *n_launches) {
+    if (!env) return fail(EVM_E_INVALID, "env is null");
+    HIP_TRY(hipEventRecord(env->ev1, (hipStream_t) stream));
+    HIP_TRY(hipEventSynchronize(env->ev1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, env->ev0, env->ev1));
+    env->timing = false;
+    if (ms_total) *ms_total = ms;
+    if (n_launches) *n_launches = env->timed_launches;
+    return EVM_OK;
+}
+
+}  // extern "C"

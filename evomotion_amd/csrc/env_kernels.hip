@@ -1,0 +1,1250 @@
+// robot_walk dynamics for MI355X (gfx950): one environment per lane, one wavefront per workgroup.
+//
+// What this file replaces (reference, paths relative to its repo root):
+//   Environment::do_step / step_world / reset      evo_motion_model/src/environment.cpp:33-48
+//   RobotWalk::compute_step / reset_engine         evo_motion_model/src/env/robot_walk.cpp:56-104
+//   MuscleController::on_input, Muscle::contract   src/controller/muscle_controller.cpp:10-12, src/robot/muscle.cpp:82-85
+//   proprioception states                          src/robot/proprioception_state.cpp:23-129
+//   and Bullet3's stepSimulation (sequential-impulse solver) that those call into.
+//
+// Layout:
+//   HBM   struct-of-arrays state, field-major [field][env]: lane i of a wave touches env 64*w+i, so every
+//         load/store instruction is one coalesced 256-byte line per field.
+//   LDS   per-body solver velocity deltas (6 floats) and world inverse-inertia tiles (6 floats),
+//         [slot][lane] (bank = lane, conflict-free).  41 bodies -> 492 slots x 256 B = 123 KiB per wave.
+//   SGPR  the skeleton (frames, pivots, masses, hull points) is wave-uniform and sits in __constant__ memory.
+//   PGS   the Gauss-Seidel sweep keeps Bullet's row order; rows are rebuilt from compact per-constraint
+//         geometry (axes + lever arms) each sweep instead of streaming ~20 floats/row, so one sweep reads
+//         ~1.4 K floats/env of scratch instead of ~7.5 K.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "dev_math.h"
+#include "env_dev.h"
+#include "skel_const.h"
+
+namespace evm {
+
+__constant__ EvmSkelC c_skel;
+
+#define DT_F (1.f / 60.f)
+#define FPS_F (1.f / DT_F)
+#define MARGIN_F 0.04f
+#define ERP_F 0.2f
+#define WARM_F 0.85f
+#define SPLIT_THR_F (-0.04f)
+#define SPLIT_TURN_ERP_F 0.1f
+#define NUM_ITER 10
+
+struct Ctx {
+    EnvDev d;
+    int env, lane;
+    float *lds;
+};
+
+#define GS(arr, k) (c.d.arr[(size_t) (k) * (size_t) c.d.n + (size_t) c.env])
+#define SC(k) (c.d.scratch[(size_t) (k) * (size_t) c.d.n + (size_t) c.env])
+#define LDV(b, k) (c.lds[(((b) * 6 + (k)) << 6) + c.lane])
+#define LII(b, k) (c.lds[(((c_skel.nb + (b)) * 6 + (k)) << 6) + c.lane])
+
+DEV F3 gs3(const float *base, size_t n, size_t env, int k) {
+    return f3(base[(size_t) k * n + env], base[(size_t) (k + 1) * n + env], base[(size_t) (k + 2) * n + env]);
+}
+DEV void ss3(float *base, size_t n, size_t env, int k, F3 v) {
+    base[(size_t) k * n + env] = v.x; base[(size_t) (k + 1) * n + env] = v.y; base[(size_t) (k + 2) * n + env] = v.z;
+}
+#define G3(arr, k) gs3(c.d.arr, c.d.n, c.env, (k))
+#define S3(arr, k, v) ss3(c.d.arr, c.d.n, c.env, (k), (v))
+#define SC3(k) gs3(c.d.scratch, c.d.n, c.env, (k))
+#define SSC3(k, v) ss3(c.d.scratch, c.d.n, c.env, (k), (v))
+
+// ---------------------------------------------------------------------------------------------
+// body views
+// ---------------------------------------------------------------------------------------------
+struct BodyK {  // kinematic snapshot used while building rows
+    F3 o;
+    M33 R;
+    F3 v, w;     // lin + externalForceImpulse, ang + externalTorqueImpulse
+    F3 w_raw;    // ang
+    S33 I;
+    float im;
+};
+struct BodyD {  // what a Gauss-Seidel row needs
+    F3 dl, da;
+    S33 I;
+    float im;
+};
+
+DEV S33 lds_inertia(const Ctx &c, int b) {
+    S33 s;
+    s.xx = LII(b, 0); s.xy = LII(b, 1); s.xz = LII(b, 2); s.yy = LII(b, 3); s.yz = LII(b, 4); s.zz = LII(b, 5);
+    return s;
+}
+DEV BodyK load_bodyk(const Ctx &c, int b) {
+    BodyK k;
+    k.o = G3(pos, 3 * b);
+    k.R = m33(SC3(c_skel.sc_r + 9 * b), SC3(c_skel.sc_r + 9 * b + 3), SC3(c_skel.sc_r + 9 * b + 6));
+    const F3 lin = G3(lin, 3 * b);
+    k.w_raw = G3(ang, 3 * b);
+    const F3 ext = SC3(c_skel.sc_ext + 3 * b);
+    k.v = lin + f3(0.f, c_skel.body[b].ext_force_y, 0.f);
+    k.w = k.w_raw + ext;
+    k.I = lds_inertia(c, b);
+    k.im = c_skel.body[b].inv_mass;
+    return k;
+}
+DEV BodyD load_bodyd(const Ctx &c, int b) {
+    BodyD k;
+    k.dl = f3(LDV(b, 0), LDV(b, 1), LDV(b, 2));
+    k.da = f3(LDV(b, 3), LDV(b, 4), LDV(b, 5));
+    k.I = lds_inertia(c, b);
+    k.im = c_skel.body[b].inv_mass;
+    return k;
+}
+DEV void store_bodyd(const Ctx &c, int b, const BodyD &k) {
+    LDV(b, 0) = k.dl.x; LDV(b, 1) = k.dl.y; LDV(b, 2) = k.dl.z;
+    LDV(b, 3) = k.da.x; LDV(b, 4) = k.da.y; LDV(b, 5) = k.da.z;
+}
+
+// ---------------------------------------------------------------------------------------------
+// generic two-body rows: linear (n, relA x n, -(relB x n)) or angular (0, a, -a)
+// ---------------------------------------------------------------------------------------------
+template <bool LIN>
+DEV void row_setup(F3 ax, F3 relA, F3 relB, const BodyK &A, const BodyK &B, float err, float &jd, float &rhs) {
+    F3 c1, c2;
+    float sum, rel_vel;
+    if (LIN) {
+        c1 = cross(relA, ax);
+        c2 = -cross(relB, ax);
+        sum = dot(ax * A.im, ax);
+        sum += dot(mul(A.I, c1), c1);
+        sum += dot(ax * B.im, ax);
+        sum += dot(mul(B.I, c2), c2);
+        rel_vel = (dot(ax, A.v) + dot(c1, A.w)) + (-dot(ax, B.v) + dot(c2, B.w));
+    } else {
+        c1 = ax;
+        c2 = -ax;
+        sum = dot(mul(A.I, c1), c1);
+        sum += dot(mul(B.I, c2), c2);
+        rel_vel = dot(c1, A.w) + dot(c2, B.w);
+    }
+    jd = fabsf(sum) > EVM_EPS ? 1.0f / sum : 0.f;
+    rhs = err * jd + (0.f - rel_vel) * jd;
+}
+
+template <bool LIN>
+DEV float row_iter(F3 ax, F3 relA, F3 relB, BodyD &A, BodyD &B, float jd, float rhs, float lo, float hi,
+                   float &applied) {
+    F3 c1, c2;
+    float d1, d2;
+    if (LIN) {
+        c1 = cross(relA, ax);
+        c2 = -cross(relB, ax);
+        d1 = dot(ax, A.dl) + dot(c1, A.da);
+        d2 = -dot(ax, B.dl) + dot(c2, B.da);
+    } else {
+        c1 = ax;
+        c2 = -ax;
+        d1 = dot(c1, A.da);
+        d2 = dot(c2, B.da);
+    }
+    const F3 angA = mul(A.I, c1), angB = mul(B.I, c2);
+    float dI = rhs;
+    dI -= d1 * jd;
+    dI -= d2 * jd;
+    const float sum = applied + dI;
+    if (sum < lo) { dI = lo - applied; applied = lo; }
+    else if (sum > hi) { dI = hi - applied; applied = hi; }
+    else applied = sum;
+    if (LIN) {
+        A.dl = A.dl + (ax * A.im) * dI;
+        B.dl = B.dl + ((-ax) * B.im) * dI;
+    }
+    A.da = A.da + angA * dI;
+    B.da = B.da + angB * dI;
+    return dI;
+}
+
+// ---------------------------------------------------------------------------------------------
+// hinge  (btHingeConstraint::getInfo2InternalUsingFrameOffset)
+// scratch: relA3 relB3 p3 q3 ax3 | jd6 | rhs6 | lo hi | applied6
+// ---------------------------------------------------------------------------------------------
+DEV void hinge_setup(const Ctx &c, int hi) {
+    const EvmHingeC &H = c_skel.hinge[hi];
+    const BodyK A = load_bodyk(c, H.a), B = load_bodyk(c, H.b);
+    const M33 fa = load_m33(H.fa), fb = load_m33(H.fb);
+    const F3 A0 = mul(A.R, col0(fa)), A1 = mul(A.R, col1(fa)), A2 = mul(A.R, col2(fa));
+    const F3 B1 = mul(B.R, col1(fb)), B2 = mul(B.R, col2(fb));
+    const F3 trAo = mul(A.R, load_f3(H.fao)) + A.o;
+    const F3 trBo = mul(B.R, load_f3(H.fbo)) + B.o;
+    // testLimit (btAngularLimit::test)
+    const float angle = atan2f(dot(B1, A0), dot(B1, A1));
+    float correction = 0.f;
+    bool solve_limit = false;
+    if (H.half_range >= 0.f) {
+        const float dev = norm_angle(angle - H.center);
+        if (dev < -H.half_range) { solve_limit = true; correction = -(dev + H.half_range); }
+        else if (dev > H.half_range) { solve_limit = true; correction = H.half_range - dev; }
+    }
+    const F3 ofs = trBo - trAo;
+    float factA = H.factA, factB = H.factB;
+    F3 ax1 = A2 * factA + B2 * factB;
+    if (len2(ax1) < EVM_EPS) { factA = 0.f; factB = 1.f; ax1 = A2 * factA + B2 * factB; }
+    ax1 = normalize(ax1);
+    F3 relB = trBo - B.o;
+    const F3 projB = ax1 * dot(relB, ax1);
+    const F3 orthoB = relB - projB;
+    F3 relA = trAo - A.o;
+    const F3 projA = ax1 * dot(relA, ax1);
+    const F3 orthoA = relA - projA;
+    const F3 totalDist = projA - projB;
+    relA = orthoA + totalDist * factA;
+    relB = orthoB - totalDist * factB;
+    F3 p = orthoB * factA + orthoA * factB;
+    const float l2 = len2(p);
+    if (l2 > EVM_EPS) p = p * (1.0f / sqrtf(l2)); else p = A1;
+    const F3 q = cross(ax1, p);
+    const float k = FPS_F * ERP_F;
+    const F3 u = cross(A2, B2);
+    float jd[6], rhs[6];
+    row_setup<true>(p, relA, relB, A, B, k * dot(p, ofs), jd[0], rhs[0]);
+    row_setup<true>(q, relA, relB, A, B, k * dot(q, ofs), jd[1], rhs[1]);
+    row_setup<true>(ax1, relA, relB, A, B, k * dot(ax1, ofs), jd[2], rhs[2]);
+    row_setup<false>(p, relA, relB, A, B, k * dot(u, p), jd[3], rhs[3]);
+    row_setup<false>(q, relA, relB, A, B, k * dot(u, q), jd[4], rhs[4]);
+    float lo = 0.f, hi_ = 0.f;
+    jd[5] = 0.f; rhs[5] = 0.f;
+    if (solve_limit) {
+        const float limit_err = correction;
+        const bool low = limit_err > 0.f;
+        float err = 0.f;
+        err += k * limit_err;
+        if (low) { lo = 0.f; hi_ = EVM_INF; } else { lo = -EVM_INF; hi_ = 0.f; }
+        const float bounce = H.relaxation;
+        if (bounce > 0.f) {
+            float vel = dot(A.w_raw, ax1);
+            vel -= dot(B.w_raw, ax1);
+            if (low) { if (vel < 0.f) { const float nc = -bounce * vel; if (nc > err) err = nc; } }
+            else { if (vel > 0.f) { const float nc = -bounce * vel; if (nc < err) err = nc; } }
+        }
+        err *= H.bias;
+        row_setup<false>(ax1, relA, relB, A, B, err, jd[5], rhs[5]);
+    }
+    const int s = c_skel.sc_h + EVM_H_STRIDE * hi;
+    SSC3(s + 0, relA); SSC3(s + 3, relB); SSC3(s + 6, p); SSC3(s + 9, q); SSC3(s + 12, ax1);
+#pragma unroll
+    for (int r = 0; r < 6; r++) { SC(s + 15 + r) = jd[r]; SC(s + 21 + r) = rhs[r]; SC(s + 29 + r) = 0.f; }
+    SC(s + 27) = lo; SC(s + 28) = hi_;
+}
+DEV float hinge_iter(const Ctx &c, int hi) {
+    const EvmHingeC &H = c_skel.hinge[hi];
+    const int s = c_skel.sc_h + EVM_H_STRIDE * hi;
+    const F3 relA = SC3(s + 0), relB = SC3(s + 3), p = SC3(s + 6), q = SC3(s + 9), ax1 = SC3(s + 12);
+    float jd[6], rhs[6], ap[6];
+#pragma unroll
+    for (int r = 0; r < 6; r++) { jd[r] = SC(s + 15 + r); rhs[r] = SC(s + 21 + r); ap[r] = SC(s + 29 + r); }
+    const float lo = SC(s + 27), hi_ = SC(s + 28);
+    BodyD A = load_bodyd(c, H.a), B = load_bodyd(c, H.b);
+    float res = 0.f;
+    res = fmaxf(res, fabsf(row_iter<true>(p, relA, relB, A, B, jd[0], rhs[0], -EVM_INF, EVM_INF, ap[0])));
+    res = fmaxf(res, fabsf(row_iter<true>(q, relA, relB, A, B, jd[1], rhs[1], -EVM_INF, EVM_INF, ap[1])));
+    res = fmaxf(res, fabsf(row_iter<true>(ax1, relA, relB, A, B, jd[2], rhs[2], -EVM_INF, EVM_INF, ap[2])));
+    res = fmaxf(res, fabsf(row_iter<false>(p, relA, relB, A, B, jd[3], rhs[3], -EVM_INF, EVM_INF, ap[3])));
+    res = fmaxf(res, fabsf(row_iter<false>(q, relA, relB, A, B, jd[4], rhs[4], -EVM_INF, EVM_INF, ap[4])));
+    if (jd[5] != 0.f) res = fmaxf(res, fabsf(row_iter<false>(ax1, relA, relB, A, B, jd[5], rhs[5], lo, hi_, ap[5])));
+    store_bodyd(c, H.a, A); store_bodyd(c, H.b, B);
+#pragma unroll
+    for (int r = 0; r < 6; r++) SC(s + 29 + r) = ap[r];
+    return res;
+}
+
+// ---------------------------------------------------------------------------------------------
+// fixed = btGeneric6DofSpring2Constraint with every axis locked (RO_XYZ): 3 angular rows then 3 linear rows
+// scratch: relA3 relB3 angax9 linax9 | jd6 | rhs6 | applied6
+// ---------------------------------------------------------------------------------------------
+DEV M33 inverse33(const M33 &m) {
+    const float co0 = m.r1.y * m.r2.z - m.r1.z * m.r2.y;
+    const float co1 = m.r1.z * m.r2.x - m.r1.x * m.r2.z;
+    const float co2 = m.r1.x * m.r2.y - m.r1.y * m.r2.x;
+    const float det = m.r0.x * co0 + m.r0.y * co1 + m.r0.z * co2;
+    const float s = 1.0f / det;
+    return m33(f3(co0 * s, (m.r0.z * m.r2.y - m.r0.y * m.r2.z) * s, (m.r0.y * m.r1.z - m.r0.z * m.r1.y) * s),
+               f3(co1 * s, (m.r0.x * m.r2.z - m.r0.z * m.r2.x) * s, (m.r0.z * m.r1.x - m.r0.x * m.r1.z) * s),
+               f3(co2 * s, (m.r0.y * m.r2.x - m.r0.x * m.r2.y) * s, (m.r0.x * m.r1.y - m.r0.y * m.r1.x) * s));
+}
+DEV void fixed_setup(const Ctx &c, int fi) {
+    const EvmFixedC &X = c_skel.fixed[fi];
+    const BodyK A = load_bodyk(c, X.a), B = load_bodyk(c, X.b);
+    const M33 cA = mul(A.R, load_m33(X.fa)), cB = mul(B.R, load_m33(X.fb));
+    const F3 cAo = mul(A.R, load_f3(X.fao)) + A.o;
+    const F3 cBo = mul(B.R, load_f3(X.fbo)) + B.o;
+    const M33 invA = inverse33(cA);
+    const F3 linDiff = mul(invA, cBo - cAo);
+    const M33 rel = mul(invA, cB);
+    F3 ang;
+    const float fi_ = rel.r2.x;
+    if (fi_ < 1.0f) {
+        if (fi_ > -1.0f) {
+            ang.x = atan2f(-rel.r2.y, rel.r2.z);
+            ang.y = asinf(rel.r2.x);
+            ang.z = atan2f(-rel.r1.x, rel.r0.x);
+        } else {
+            ang.x = -atan2f(rel.r0.y, rel.r1.y); ang.y = -EVM_PI * 0.5f; ang.z = 0.f;
+        }
+    } else {
+        ang.x = atan2f(rel.r0.y, rel.r1.y); ang.y = EVM_PI * 0.5f; ang.z = 0.f;
+    }
+    const F3 axis0 = col0(cB), axis2 = col2(cA);
+    F3 a1 = cross(axis2, axis0);
+    F3 a0 = cross(a1, axis2);
+    F3 a2 = cross(axis0, a1);
+    a0 = normalize(a0); a1 = normalize(a1); a2 = normalize(a2);
+    const F3 relB = cBo - B.o, relA = cAo - A.o;
+    const F3 l0 = col0(cA), l1 = col1(cA), l2 = col2(cA);
+    const float k = FPS_F * ERP_F;
+    float jd[6], rhs[6];
+    row_setup<false>(a0, relA, relB, A, B, k * ang.x * -1.f, jd[0], rhs[0]);
+    row_setup<false>(a1, relA, relB, A, B, k * ang.y * -1.f, jd[1], rhs[1]);
+    row_setup<false>(a2, relA, relB, A, B, k * ang.z * -1.f, jd[2], rhs[2]);
+    row_setup<true>(l0, relA, relB, A, B, k * linDiff.x * 1.f, jd[3], rhs[3]);
+    row_setup<true>(l1, relA, relB, A, B, k * linDiff.y * 1.f, jd[4], rhs[4]);
+    row_setup<true>(l2, relA, relB, A, B, k * linDiff.z * 1.f, jd[5], rhs[5]);
+    const int s = c_skel.sc_f + EVM_F_STRIDE * fi;
+    SSC3(s + 0, relA); SSC3(s + 3, relB);
+    SSC3(s + 6, a0); SSC3(s + 9, a1); SSC3(s + 12, a2);
+    SSC3(s + 15, l0); SSC3(s + 18, l1); SSC3(s + 21, l2);
+#pragma unroll
+    for (int r = 0; r < 6; r++) { SC(s + 24 + r) = jd[r]; SC(s + 30 + r) = rhs[r]; SC(s + 36 + r) = 0.f; }
+}
+DEV float fixed_iter(const Ctx &c, int fi) {
+    const EvmFixedC &X = c_skel.fixed[fi];
+    const int s = c_skel.sc_f + EVM_F_STRIDE * fi;
+    const F3 relA = SC3(s + 0), relB = SC3(s + 3);
+    float jd[6], rhs[6], ap[6];
+#pragma unroll
+    for (int r = 0; r < 6; r++) { jd[r] = SC(s + 24 + r); rhs[r] = SC(s + 30 + r); ap[r] = SC(s + 36 + r); }
+    BodyD A = load_bodyd(c, X.a), B = load_bodyd(c, X.b);
+    float res = 0.f;
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+        res = fmaxf(res, fabsf(row_iter<false>(SC3(s + 6 + 3 * r), relA, relB, A, B, jd[r], rhs[r], -EVM_INF, EVM_INF, ap[r])));
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+        res = fmaxf(res, fabsf(row_iter<true>(SC3(s + 15 + 3 * r), relA, relB, A, B, jd[3 + r], rhs[3 + r], -EVM_INF, EVM_INF, ap[3 + r])));
+    store_bodyd(c, X.a, A); store_bodyd(c, X.b, B);
+#pragma unroll
+    for (int r = 0; r < 6; r++) SC(s + 36 + r) = ap[r];
+    return res;
+}
+
+// ---------------------------------------------------------------------------------------------
+// muscle slider (btSliderConstraint::getInfo2NonVirtual, identity frames, useLinearReferenceFrameA)
+// scratch: p3 q3 ax3 p2_3 q2_3 relA3 relB3 | jd6 | rhs6 | lo hi | applied6
+// rows: 0,1 angular(p,q)  2,3 linear(p2,q2)  4 linear(ax1) motor/limit  5 angular(ax1) limit
+// ---------------------------------------------------------------------------------------------
+DEV float motor_factor(float pos, float lowLim, float uppLim, float vel, float timeFact) {
+    if (lowLim > uppLim) return 1.0f;
+    if (lowLim == uppLim) return 0.0f;
+    float lim_fact = 1.0f;
+    const float delta_max = vel / timeFact;
+    if (delta_max < 0.0f) {
+        if ((pos >= lowLim) && (pos < (lowLim - delta_max))) lim_fact = (lowLim - pos) / delta_max;
+        else if (pos < lowLim) lim_fact = 0.0f;
+        else lim_fact = 1.0f;
+    } else if (delta_max > 0.0f) {
+        if ((pos <= uppLim) && (pos > (uppLim - delta_max))) lim_fact = (uppLim - pos) / delta_max;
+        else if (pos > uppLim) lim_fact = 0.0f;
+        else lim_fact = 1.0f;
+    } else lim_fact = 0.0f;
+    return lim_fact;
+}
+DEV void slider_setup(const Ctx &c, int mi, bool powered_in, float target_vel) {
+    const EvmMuscleC &M = c_skel.muscle[mi];
+    const BodyK A = load_bodyk(c, M.sa), B = load_bodyk(c, M.sb);
+    const F3 ax1A = col0(A.R), ax1B = col0(B.R);
+    const F3 delta = B.o - A.o;
+    float depth0 = dot(delta, col0(A.R));
+    // testAngLimits (lower == upper == 0)
+    float ang_depth = 0.f;
+    bool solve_ang = false;
+    {
+        // the limit is [0,0]: this row exists iff rot != 0, and rot hovers at rounding level (see DESIGN.md,
+        // "ill-conditioned decisions"), so evaluate it without contraction
+        const F3 axisA0 = col1(A.R), axisA1 = col2(A.R), axisB0 = col1(B.R);
+        const float rot = atan2f(xdot(axisB0, axisA1), xdot(axisB0, axisA0));
+        if (rot < 0.f) { ang_depth = rot; solve_ang = true; }
+        else if (rot > 0.f) { ang_depth = rot; solve_ang = true; }
+    }
+    // testLinLimits (lower 0, upper = 2 * L0)
+    bool solve_lin = false;
+    const float lin_pos = depth0;
+    const float upper = M.upper_lin;
+    if (0.f <= upper) {
+        if (depth0 > upper) { depth0 -= upper; solve_lin = true; }
+        else if (depth0 < 0.f) { depth0 -= 0.f; solve_lin = true; }
+        else depth0 = 0.f;
+    } else depth0 = 0.f;
+    const F3 ofs = B.o - A.o;
+    const float factA = M.factA, factB = M.factB;
+    F3 ax1 = normalize(ax1A * factA + ax1B * factB);
+    F3 p, q;
+    plane_space(ax1, p, q);
+    float k = FPS_F * (1.0f * ERP_F);
+    const F3 u = cross(ax1A, ax1B);
+    float jd[6], rhs[6];
+    F3 relB = f3(0.f, 0.f, 0.f) + (B.o - B.o);
+    F3 relA = A.o - A.o;
+    row_setup<false>(p, relA, relB, A, B, k * dot(u, p), jd[0], rhs[0]);
+    row_setup<false>(q, relA, relB, A, B, k * dot(u, q), jd[1], rhs[1]);
+    const F3 projB = ax1 * dot(relB, ax1);
+    const F3 orthoB = relB - projB;
+    const F3 projA = ax1 * dot(relA, ax1);
+    const F3 orthoA = relA - projA;
+    const float sliderOffs = lin_pos - depth0;
+    const F3 totalDist = projA + ax1 * sliderOffs - projB;
+    relA = orthoA + totalDist * factA;
+    relB = orthoB - totalDist * factB;
+    F3 p2 = orthoB * factA + orthoA * factB;
+    const float l2 = len2(p2);
+    if (l2 > EVM_EPS) p2 = p2 * (1.0f / sqrtf(l2)); else p2 = col1(A.R);
+    const F3 q2 = cross(ax1, p2);
+    k = FPS_F * (1.0f * ERP_F);
+    row_setup<true>(p2, relA, relB, A, B, k * dot(p2, ofs), jd[2], rhs[2]);
+    row_setup<true>(q2, relA, relB, A, B, k * dot(q2, ofs), jd[3], rhs[3]);
+    // linear limit / motor row
+    float lo = 0.f, hi_ = 0.f;
+    jd[4] = 0.f; rhs[4] = 0.f;
+    {
+        float limit_err = 0.f;
+        int limit = 0;
+        if (solve_lin) { limit_err = depth0; limit = limit_err > 0.f ? 2 : 1; }
+        bool powered = powered_in;
+        if (limit || powered) {
+            const float lostop = 0.f, histop = upper;
+            if (limit && (lostop == histop)) powered = false;
+            float err = 0.f;
+            if (powered) {
+                const float mot = motor_factor(lin_pos, lostop, histop, target_vel, FPS_F * ERP_F);
+                err -= 1.0f * mot * target_vel;
+                lo += -M.max_impulse;
+                hi_ += M.max_impulse;
+            }
+            if (limit) {
+                k = FPS_F * ERP_F;
+                err += k * limit_err;
+                if (lostop == histop) { lo = -EVM_INF; hi_ = EVM_INF; }
+                else if (limit == 1) { lo = -EVM_INF; hi_ = 0.f; }
+                else { lo = 0.f; hi_ = EVM_INF; }
+                err *= 1.0f;
+            }
+            row_setup<true>(ax1, relA, relB, A, B, err, jd[4], rhs[4]);
+        }
+    }
+    // angular limit row
+    jd[5] = 0.f; rhs[5] = 0.f;
+    if (solve_ang) {
+        float err = 0.f;
+        err += (FPS_F * ERP_F) * ang_depth;
+        err *= 1.0f;
+        row_setup<false>(ax1, relA, relB, A, B, err, jd[5], rhs[5]);
+    }
+    const int s = c_skel.sc_s + EVM_S_STRIDE * mi;
+    SSC3(s + 0, p); SSC3(s + 3, q); SSC3(s + 6, ax1); SSC3(s + 9, p2); SSC3(s + 12, q2);
+    SSC3(s + 15, relA); SSC3(s + 18, relB);
+#pragma unroll
+    for (int r = 0; r < 6; r++) { SC(s + 21 + r) = jd[r]; SC(s + 27 + r) = rhs[r]; SC(s + 35 + r) = 0.f; }
+    SC(s + 33) = lo; SC(s + 34) = hi_;
+    SC(c_skel.sc_mobs + 4 * mi) = lin_pos;  // btSliderConstraint::getLinearPos(), MuscleState
+}
+DEV float slider_iter(const Ctx &c, int mi) {
+    const EvmMuscleC &M = c_skel.muscle[mi];
+    const int s = c_skel.sc_s + EVM_S_STRIDE * mi;
+    const F3 p = SC3(s + 0), q = SC3(s + 3), ax1 = SC3(s + 6), p2 = SC3(s + 9), q2 = SC3(s + 12);
+    const F3 relA = SC3(s + 15), relB = SC3(s + 18);
+    float jd[6], rhs[6], ap[6];
+#pragma unroll
+    for (int r = 0; r < 6; r++) { jd[r] = SC(s + 21 + r); rhs[r] = SC(s + 27 + r); ap[r] = SC(s + 35 + r); }
+    const float lo = SC(s + 33), hi_ = SC(s + 34);
+    BodyD A = load_bodyd(c, M.sa), B = load_bodyd(c, M.sb);
+    float res = 0.f;
+    res = fmaxf(res, fabsf(row_iter<false>(p, relA, relB, A, B, jd[0], rhs[0], -EVM_INF, EVM_INF, ap[0])));
+    res = fmaxf(res, fabsf(row_iter<false>(q, relA, relB, A, B, jd[1], rhs[1], -EVM_INF, EVM_INF, ap[1])));
+    res = fmaxf(res, fabsf(row_iter<true>(p2, relA, relB, A, B, jd[2], rhs[2], -EVM_INF, EVM_INF, ap[2])));
+    res = fmaxf(res, fabsf(row_iter<true>(q2, relA, relB, A, B, jd[3], rhs[3], -EVM_INF, EVM_INF, ap[3])));
+    if (jd[4] != 0.f) res = fmaxf(res, fabsf(row_iter<true>(ax1, relA, relB, A, B, jd[4], rhs[4], lo, hi_, ap[4])));
+    if (jd[5] != 0.f) res = fmaxf(res, fabsf(row_iter<false>(ax1, relA, relB, A, B, jd[5], rhs[5], -EVM_INF, EVM_INF, ap[5])));
+    store_bodyd(c, M.sa, A); store_bodyd(c, M.sb, B);
+#pragma unroll
+    for (int r = 0; r < 6; r++) SC(s + 35 + r) = ap[r];
+    return res;
+}
+
+// ---------------------------------------------------------------------------------------------
+// point-to-point (btPoint2PointConstraint::getInfo2NonVirtual); which = 0: member A - sphere A, 1: B side
+// scratch: a1_3 a2_3 | jd3 | rhs3 | applied3
+// ---------------------------------------------------------------------------------------------
+DEV void p2p_setup(const Ctx &c, int mi, int which) {
+    const EvmMuscleC &M = c_skel.muscle[mi];
+    const int ba = which ? M.mb : M.ma, bb = which ? M.sb : M.sa;
+    const BodyK A = load_bodyk(c, ba), B = load_bodyk(c, bb);
+    const F3 a1 = mul(A.R, load_f3(which ? M.piv_b : M.piv_a));
+    const F3 a2 = mul(B.R, f3(0.f, 0.f, 0.f));
+    const float k = FPS_F * ERP_F;
+    const int s = c_skel.sc_p + EVM_P_STRIDE * (2 * mi + which);
+    float jd, rhs;
+    row_setup<true>(f3(1.f, 0.f, 0.f), a1, a2, A, B, k * (a2.x + B.o.x - a1.x - A.o.x), jd, rhs);
+    SC(s + 6) = jd; SC(s + 9) = rhs;
+    row_setup<true>(f3(0.f, 1.f, 0.f), a1, a2, A, B, k * (a2.y + B.o.y - a1.y - A.o.y), jd, rhs);
+    SC(s + 7) = jd; SC(s + 10) = rhs;
+    row_setup<true>(f3(0.f, 0.f, 1.f), a1, a2, A, B, k * (a2.z + B.o.z - a1.z - A.o.z), jd, rhs);
+    SC(s + 8) = jd; SC(s + 11) = rhs;
+    SSC3(s + 0, a1); SSC3(s + 3, a2);
+    SC(s + 12) = 0.f; SC(s + 13) = 0.f; SC(s + 14) = 0.f;
+}
+DEV float p2p_iter(const Ctx &c, int mi, int which) {
+    const EvmMuscleC &M = c_skel.muscle[mi];
+    const int ba = which ? M.mb : M.ma, bb = which ? M.sb : M.sa;
+    const int s = c_skel.sc_p + EVM_P_STRIDE * (2 * mi + which);
+    const F3 a1 = SC3(s + 0), a2 = SC3(s + 3);
+    float jd[3], rhs[3], ap[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) { jd[r] = SC(s + 6 + r); rhs[r] = SC(s + 9 + r); ap[r] = SC(s + 12 + r); }
+    BodyD A = load_bodyd(c, ba), B = load_bodyd(c, bb);
+    float res = 0.f;
+    res = fmaxf(res, fabsf(row_iter<true>(f3(1.f, 0.f, 0.f), a1, a2, A, B, jd[0], rhs[0], -EVM_INF, EVM_INF, ap[0])));
+    res = fmaxf(res, fabsf(row_iter<true>(f3(0.f, 1.f, 0.f), a1, a2, A, B, jd[1], rhs[1], -EVM_INF, EVM_INF, ap[1])));
+    res = fmaxf(res, fabsf(row_iter<true>(f3(0.f, 0.f, 1.f), a1, a2, A, B, jd[2], rhs[2], -EVM_INF, EVM_INF, ap[2])));
+    store_bodyd(c, ba, A); store_bodyd(c, bb, B);
+#pragma unroll
+    for (int r = 0; r < 3; r++) SC(s + 12 + r) = ap[r];
+    return res;
+}
+
+// ---------------------------------------------------------------------------------------------
+// contacts: member hull vs floor plane, Bullet-style persistent manifold (A = floor/static, B = member)
+// manifold point fields: 0..2 localA, 3..5 localB, 6 dist, 7 applied, 8 applied_lateral
+// ---------------------------------------------------------------------------------------------
+#define MFP(m, slot, f) GS(mfp, ((m) * 4 + (slot)) * 9 + (f))
+
+struct MPoint {
+    F3 la, lb;
+    float dist, ap, apl;
+};
+DEV MPoint sel(bool cnd, const MPoint &a, const MPoint &b) {
+    MPoint r;
+    r.la = f3(cnd ? a.la.x : b.la.x, cnd ? a.la.y : b.la.y, cnd ? a.la.z : b.la.z);
+    r.lb = f3(cnd ? a.lb.x : b.lb.x, cnd ? a.lb.y : b.lb.y, cnd ? a.lb.z : b.lb.z);
+    r.dist = cnd ? a.dist : b.dist; r.ap = cnd ? a.ap : b.ap; r.apl = cnd ? a.apl : b.apl;
+    return r;
+}
+DEV MPoint load_mp(const Ctx &c, int m, int slot) {
+    MPoint p;
+    p.la = f3(MFP(m, slot, 0), MFP(m, slot, 1), MFP(m, slot, 2));
+    p.lb = f3(MFP(m, slot, 3), MFP(m, slot, 4), MFP(m, slot, 5));
+    p.dist = MFP(m, slot, 6); p.ap = MFP(m, slot, 7); p.apl = MFP(m, slot, 8);
+    return p;
+}
+DEV void store_mp(const Ctx &c, int m, int slot, const MPoint &p) {
+    MFP(m, slot, 0) = p.la.x; MFP(m, slot, 1) = p.la.y; MFP(m, slot, 2) = p.la.z;
+    MFP(m, slot, 3) = p.lb.x; MFP(m, slot, 4) = p.lb.y; MFP(m, slot, 5) = p.lb.z;
+    MFP(m, slot, 6) = p.dist; MFP(m, slot, 7) = p.ap; MFP(m, slot, 8) = p.apl;
+}
+
+// collision + manifold maintenance for member m; returns the number of cached points afterwards
+DEV int contact_update(const Ctx &c, int m) {
+    const EvmMemberC &MB = c_skel.member[m];
+    const F3 o = G3(pos, 3 * m);
+    const M33 R = m33(SC3(c_skel.sc_r + 9 * m), SC3(c_skel.sc_r + 9 * m + 3), SC3(c_skel.sc_r + 9 * m + 6));
+    // deepest hull vertex: first strict minimum of world y, evaluated without fma contraction so that the
+    // discrete choice follows the same rounding as a plain multiply/add sequence
+    float best = EVM_INF;
+    int bi = 0;
+    const float *hp = c_skel.hull + 3 * MB.hull_off;
+    for (int i = 0; i < MB.hull_n; i++) {
+        const float px = hp[3 * i], py = hp[3 * i + 1], pz = hp[3 * i + 2];
+        const float wy = xa(xa(xa(xm(R.r1.x, px), xm(R.r1.y, py)), xm(R.r1.z, pz)), o.y);
+        if (wy < best) { best = wy; bi = i; }
+    }
+    int n = GS(mfn, m);
+    const float thr = MB.break_thr;
+    const float depth = (best - c_skel.floor_top_y) - (MARGIN_F + MARGIN_F);
+    const bool add = !(depth > thr);
+    if (!__any(add || n > 0)) return 0;
+
+    MPoint p0 = load_mp(c, m, 0), p1 = load_mp(c, m, 1), p2 = load_mp(c, m, 2), p3 = load_mp(c, m, 3);
+    const F3 fo = load_f3(c_skel.floor_o);
+    if (add) {
+        const F3 ps = f3(hp[3 * bi], hp[3 * bi + 1], hp[3 * bi + 2]);
+        const F3 w = f3(xa(xa(xa(xm(R.r0.x, ps.x), xm(R.r0.y, ps.y)), xm(R.r0.z, ps.z)), o.x),
+                        best,
+                        xa(xa(xa(xm(R.r2.x, ps.x), xm(R.r2.y, ps.y)), xm(R.r2.z, ps.z)), o.z));
+        const F3 pointOnB = f3(w.x, w.y - MARGIN_F, w.z);
+        const F3 pointA = pointOnB + f3(0.f, -1.f, 0.f) * depth;
+        MPoint np;
+        np.la = pointA - fo;                  // floor basis is the identity
+        np.lb = tmul(R, pointOnB - o);        // btTransform::invXform
+        np.dist = depth; np.ap = 0.f; np.apl = 0.f;
+        // getCacheEntry
+        float shortest = thr * thr;
+        int nearest = -1;
+        { const F3 d = p0.la - np.la; const float dd = dot(d, d); if (0 < n && dd < shortest) { shortest = dd; nearest = 0; } }
+        { const F3 d = p1.la - np.la; const float dd = dot(d, d); if (1 < n && dd < shortest) { shortest = dd; nearest = 1; } }
+        { const F3 d = p2.la - np.la; const float dd = dot(d, d); if (2 < n && dd < shortest) { shortest = dd; nearest = 2; } }
+        { const F3 d = p3.la - np.la; const float dd = dot(d, d); if (3 < n && dd < shortest) { shortest = dd; nearest = 3; } }
+        int ins;
+        if (nearest >= 0) {
+            ins = nearest;
+            const MPoint old = sel(ins == 0, p0, sel(ins == 1, p1, sel(ins == 2, p2, p3)));
+            np.ap = old.ap; np.apl = old.apl;
+        } else if (n == 4) {
+            // sortCachedPoints: keep the deepest, maximise the area
+            int maxPen = -1;
+            float mp = np.dist;
+            if (p0.dist < mp) { maxPen = 0; mp = p0.dist; }
+            if (p1.dist < mp) { maxPen = 1; mp = p1.dist; }
+            if (p2.dist < mp) { maxPen = 2; mp = p2.dist; }
+            if (p3.dist < mp) { maxPen = 3; mp = p3.dist; }
+            float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f;
+            if (maxPen != 0) r0 = len2(cross(np.la - p1.la, p3.la - p2.la));
+            if (maxPen != 1) r1 = len2(cross(np.la - p0.la, p3.la - p2.la));
+            if (maxPen != 2) r2 = len2(cross(np.la - p0.la, p3.la - p1.la));
+            if (maxPen != 3) r3 = len2(cross(np.la - p0.la, p2.la - p1.la));
+            ins = -1;
+            float mv = -1e18f;
+            if (fabsf(r0) > mv) { ins = 0; mv = fabsf(r0); }
+            if (fabsf(r1) > mv) { ins = 1; mv = fabsf(r1); }
+            if (fabsf(r2) > mv) { ins = 2; mv = fabsf(r2); }
+            if (fabsf(r3) > mv) { ins = 3; mv = fabsf(r3); }
+            if (ins < 0) ins = 0;
+        } else {
+            ins = n;
+            n++;
+        }
+        p0 = sel(ins == 0, np, p0); p1 = sel(ins == 1, np, p1); p2 = sel(ins == 2, np, p2); p3 = sel(ins == 3, np, p3);
+    }
+    // refreshContactPoints: distances first, then removal from the last slot down (swap-with-last)
+#define REFRESH_DIST(P)                                       \
+    {                                                         \
+        const F3 posA_ = P.la + fo;                           \
+        const F3 posB_ = mul(R, P.lb) + o;                    \
+        P.dist = -(posA_.y - posB_.y); /* dot(posA - posB, (0,-1,0)) */ \
+    }
+    REFRESH_DIST(p3) REFRESH_DIST(p2) REFRESH_DIST(p1) REFRESH_DIST(p0)
+#undef REFRESH_DIST
+#define REFRESH_SLOT(I, P)                                                                         \
+    if (I < n) {                                                                                   \
+        const F3 posA = P.la + fo;                                                                 \
+        const F3 posB = mul(R, P.lb) + o;                                                          \
+        bool rm = !(P.dist <= thr);                                                                \
+        if (!rm) {                                                                                 \
+            const F3 projected = posA - f3(0.f, -1.f, 0.f) * P.dist;                               \
+            const F3 diff = posB - projected;                                                      \
+            rm = dot(diff, diff) > thr * thr;                                                      \
+        }                                                                                          \
+        if (rm) {                                                                                  \
+            const int last = n - 1;                                                                \
+            const MPoint lp = sel(last == 0, p0, sel(last == 1, p1, sel(last == 2, p2, p3)));      \
+            P = lp;                                                                                \
+            n--;                                                                                   \
+        }                                                                                          \
+    }
+    REFRESH_SLOT(3, p3)
+    REFRESH_SLOT(2, p2)
+    REFRESH_SLOT(1, p1)
+    REFRESH_SLOT(0, p0)
+#undef REFRESH_SLOT
+    store_mp(c, m, 0, p0); store_mp(c, m, 1, p1); store_mp(c, m, 2, p2); store_mp(c, m, 3, p3);
+    GS(mfn, m) = n;
+    return n;
+}
+
+// contact rows of member m: setup, warm start, split-impulse recovery (all of it touches body m only)
+DEV void contact_setup(const Ctx &c, int m, int n) {
+    const EvmMemberC &MB = c_skel.member[m];
+    const BodyK B = load_bodyk(c, m);
+    BodyD D = load_bodyd(c, m);
+    const F3 nrm = f3(0.f, -1.f, 0.f);
+    const float invdt = 1.f / DT_F;
+    F3 push = f3(0.f, 0.f, 0.f), turn = f3(0.f, 0.f, 0.f);
+    // split-impulse bookkeeping for up to 4 points
+    F3 pc2[4], pang[4];
+    float pjd[4], prhs[4], ppush[4];
+    bool any_pen = false;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        pjd[j] = 0.f; prhs[j] = 0.f; ppush[j] = 0.f; pc2[j] = f3(0, 0, 0); pang[j] = f3(0, 0, 0);
+        if (j < n) {
+            const F3 lb = f3(MFP(m, j, 3), MFP(m, j, 4), MFP(m, j, 5));
+            const float dist = MFP(m, j, 6);
+            const F3 posB = mul(B.R, lb) + B.o;
+            const F3 rel = posB - B.o;
+            // convertContact: relative velocity of the contact point (static body A contributes 0)
+            const F3 vel2 = B.v + cross(B.w, rel);
+            const F3 vel = f3(0.f, 0.f, 0.f) - vel2;
+            const float rel_vel = dot(nrm, vel);
+            // normal row
+            const F3 tq = cross(rel, nrm);
+            const F3 c2 = -tq;
+            const F3 angB = mul(B.I, c2);
+            const F3 vec = cross(-angB, rel);
+            const float denom1 = B.im + dot(nrm, vec);
+            const float jd = 1.0f / (0.f + denom1 + 0.f);
+            const F3 n2 = -nrm;
+            const float applied = MFP(m, j, 7) * WARM_F;
+            // warm start: internalApplyImpulse(-n2 * invMass, -angB, -applied)
+            D.dl = D.dl + ((-n2) * B.im) * (-applied);
+            D.da = D.da + (-angB) * (-applied);
+            const float vel2Dotn = dot(n2, B.v) + dot(c2, B.w);
+            const float rv = 0.f + vel2Dotn;
+            float positionalError = 0.f;
+            float velocityError = 0.f - rv;
+            const float penetration = dist + 0.f;
+            if (penetration > 0.f) velocityError -= penetration * invdt;
+            else positionalError = -penetration * ERP_F * invdt;
+            const float penImp = positionalError * jd, velImp = velocityError * jd;
+            float rhs, rhs_pen;
+            if (penetration > SPLIT_THR_F) { rhs = penImp + velImp; rhs_pen = 0.f; }
+            else { rhs = velImp; rhs_pen = penImp; }
+            // friction direction
+            F3 lat = vel - nrm * rel_vel;
+            const float lat2 = len2(lat);
+            if (lat2 > EVM_EPS) lat = lat * (1.f / sqrtf(lat2));
+            else { F3 d2; plane_space(nrm, lat, d2); }
+            const F3 fn2 = -lat;
+            const F3 fc2 = cross(rel, fn2);
+            const F3 fangB = mul(B.I, fc2);
+            const F3 fvec = cross(-fangB, rel);
+            const float fjd = 1.0f / (0.f + (B.im + dot(lat, fvec)));
+            const float fv2 = dot(fn2, B.v) + dot(fc2, B.w_raw);  // no external torque impulse here
+            const float frhs = (0.f - (0.f + fv2)) * fjd;
+            const float fapplied = MFP(m, j, 8) * WARM_F;
+            D.dl = D.dl + ((-fn2) * B.im) * (-fapplied);
+            D.da = D.da + (-fangB) * (-fapplied);
+            const int s = c_skel.sc_c + EVM_C_STRIDE * (4 * m + j);
+            SSC3(s + 0, rel); SSC3(s + 3, lat);
+            SC(s + 6) = jd; SC(s + 7) = rhs; SC(s + 8) = fjd; SC(s + 9) = frhs;
+            MFP(m, j, 7) = applied; MFP(m, j, 8) = fapplied;
+            pjd[j] = jd; prhs[j] = rhs_pen; pc2[j] = c2; pang[j] = angB;
+            any_pen = any_pen || (rhs_pen != 0.f);
+        }
+    }
+    store_bodyd(c, m, D);
+    if (__any(any_pen)) {
+        for (int it = 0; it < NUM_ITER; it++) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (prhs[j] != 0.f) {
+                    float dI = prhs[j];
+                    const float d2 = dot(f3(0.f, 1.f, 0.f), push) + dot(pc2[j], turn);
+                    dI -= d2 * pjd[j];
+                    const float sum = ppush[j] + dI;
+                    if (sum < 0.f) { dI = 0.f - ppush[j]; ppush[j] = 0.f; } else ppush[j] = sum;
+                    push = push + (f3(0.f, 1.f, 0.f) * B.im) * dI;
+                    turn = turn + pang[j] * dI;
+                }
+            }
+        }
+    }
+    SSC3(c_skel.sc_pt + 6 * m, push); SSC3(c_skel.sc_pt + 6 * m + 3, turn);
+}
+
+DEV float contact_iter(const Ctx &c, int m, int n) {
+    const EvmMemberC &MB = c_skel.member[m];
+    BodyD D = load_bodyd(c, m);
+    float res = 0.f;
+    float apn[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        apn[j] = 0.f;
+        if (j < n) {  // resolveSingleConstraintRowLowerLimit
+            const int s = c_skel.sc_c + EVM_C_STRIDE * (4 * m + j);
+            const F3 rel = SC3(s + 0);
+            const float jd = SC(s + 6), rhs = SC(s + 7);
+            const F3 c2 = -cross(rel, f3(0.f, -1.f, 0.f));
+            const F3 angB = mul(D.I, c2);
+            float ap = MFP(m, j, 7);
+            float dI = rhs;
+            const float d2 = D.dl.y + dot(c2, D.da);
+            dI -= d2 * jd;
+            const float sum = ap + dI;
+            if (sum < 0.f) { dI = 0.f - ap; ap = 0.f; } else ap = sum;
+            D.dl = D.dl + (f3(0.f, 1.f, 0.f) * D.im) * dI;
+            D.da = D.da + angB * dI;
+            MFP(m, j, 7) = ap;
+            apn[j] = ap;
+            res = fmaxf(res, fabsf(dI));
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (j < n && apn[j] > 0.f) {  // friction row with limits +-mu * normal impulse
+            const int s = c_skel.sc_c + EVM_C_STRIDE * (4 * m + j);
+            const F3 rel = SC3(s + 0), lat = SC3(s + 3);
+            const float jd = SC(s + 8), rhs = SC(s + 9);
+            const F3 n2 = -lat;
+            const F3 c2 = cross(rel, n2);
+            const F3 angB = mul(D.I, c2);
+            const float lim = MB.mu * apn[j];
+            float ap = MFP(m, j, 8);
+            float dI = rhs;
+            const float d2 = dot(n2, D.dl) + dot(c2, D.da);
+            dI -= d2 * jd;
+            const float sum = ap + dI;
+            if (sum < -lim) { dI = -lim - ap; ap = -lim; }
+            else if (sum > lim) { dI = lim - ap; ap = lim; }
+            else ap = sum;
+            D.dl = D.dl + (n2 * D.im) * dI;
+            D.da = D.da + angB * dI;
+            MFP(m, j, 8) = ap;
+            res = fmaxf(res, fabsf(dI));
+        }
+    }
+    store_bodyd(c, m, D);
+    return res;
+}
+
+// ---------------------------------------------------------------------------------------------
+// MT19937 stream per env (std::mt19937 + libstdc++ uniform_real_distribution<float>, robot_walk.h:34-35)
+// ---------------------------------------------------------------------------------------------
+DEV float mt_uniform01(const Ctx &c) {
+    int idx = c.d.mt_idx[c.env];
+    const size_t n = c.d.n, e = c.env;
+    uint32_t *mt = c.d.mt;
+    if (idx >= 624) {
+        for (int i = 0; i < 624; i++) {
+            const uint32_t a = mt[(size_t) i * n + e], b = mt[(size_t) ((i + 1) % 624) * n + e];
+            const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+            mt[(size_t) i * n + e] = mt[(size_t) ((i + 397) % 624) * n + e] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        idx = 0;
+    }
+    uint32_t y = mt[(size_t) idx * n + e];
+    c.d.mt_idx[c.env] = idx + 1;
+    y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+    float r = xm((float) y, 2.3283064365386963e-10f);
+    if (r >= 1.0f) r = 0.99999994f;
+    return r;
+}
+
+// RobotWalk::reset_engine up to the settle steps (robot_walk.cpp:76-96, item.cpp:77-86)
+DEV void repose(const Ctx &c) {
+    const float angle_limit = (float) 3.14159265358979323846 * 2.f / 3.f;
+    const float half = angle_limit / 2.f;
+    const float yaw = xs_(xm(mt_uniform01(c), angle_limit), half);
+    const float roll = xs_(xm(mt_uniform01(c), angle_limit), half);
+    const float pitch = xs_(xm(mt_uniform01(c), angle_limit), half);
+    // sin/cos through fp64 so that the fp32 results are the correctly rounded ones (what glibc returns for
+    // all but a handful of arguments); 6 evaluations per reset.
+    const float ch = (float) cos((double) yaw), sh = (float) sin((double) yaw), cp = (float) cos((double) pitch),
+                sp = (float) sin((double) pitch), cb = (float) cos((double) roll), sb = (float) sin((double) roll);
+    // glm::eulerAngleYXZ(yaw, pitch, roll), stored as rows, every operation individually rounded
+    const M33 E = m33(f3(xa(xm(ch, cb), xm(xm(sh, sp), sb)), xa(xm(-ch, sb), xm(xm(sh, sp), cb)), xm(sh, cp)),
+                      f3(xm(sb, cp), xm(cb, cp), -sp),
+                      f3(xa(xm(-sh, cb), xm(xm(ch, sp), sb)), xa(xm(sb, sh), xm(xm(ch, sp), cb)), xm(ch, cp)));
+    const int flags = c.d.flags[c.env];
+    const bool was_pending = (flags & EVM_FLAG_PENDING) != 0;
+    const F3 e0 = col0(E), e1 = col1(E), e2 = col2(E);
+    for (int b = 0; b < c_skel.nb; b++) {
+        if (!was_pending) {  // the world inverse inertia tensor stays that of the last integrated transform
+            const Q4 q = q4(GS(quat, 4 * b), GS(quat, 4 * b + 1), GS(quat, 4 * b + 2), GS(quat, 4 * b + 3));
+            const S33 I = inertia_world(mat_from_quat(q), load_f3(c_skel.body[b].inv_inertia));
+            GS(iinv_stale, 6 * b) = I.xx; GS(iinv_stale, 6 * b + 1) = I.xy; GS(iinv_stale, 6 * b + 2) = I.xz;
+            GS(iinv_stale, 6 * b + 3) = I.yy; GS(iinv_stale, 6 * b + 4) = I.yz; GS(iinv_stale, 6 * b + 5) = I.zz;
+        }
+        const F3 t0 = load_f3(c_skel.body[b].t0);
+        const F3 rp = load_f3(c_skel.root_pos);
+        const F3 o = f3(xa(xa(xa(xm(e0.x, t0.x), xm(e1.x, t0.y)), xm(e2.x, t0.z)), rp.x),
+                        xa(xa(xa(xm(e0.y, t0.x), xm(e1.y, t0.y)), xm(e2.y, t0.z)), rp.y),
+                        xa(xa(xa(xm(e0.z, t0.x), xm(e1.z, t0.y)), xm(e2.z, t0.z)), rp.z));
+        S3(pos, 3 * b, o);
+        S3(lin, 3 * b, f3(0.f, 0.f, 0.f));
+        S3(ang, 3 * b, f3(0.f, 0.f, 0.f));
+        if (b < c_skel.nm) SSC3(c_skel.sc_ms + 3 * b, o);  // motion state := new transform (item.cpp:81)
+    }
+    for (int m = 0; m < c_skel.nm; m++) GS(mfn, m) = 0;
+    GS(E, 0) = E.r0.x; GS(E, 1) = E.r0.y; GS(E, 2) = E.r0.z;
+    GS(E, 3) = E.r1.x; GS(E, 4) = E.r1.y; GS(E, 5) = E.r1.z;
+    GS(E, 6) = E.r2.x; GS(E, 7) = E.r2.y; GS(E, 8) = E.r2.z;
+    c.d.flags[c.env] = flags | EVM_FLAG_PENDING;
+    c.d.curr_step[c.env] = 0;                       // robot_walk.cpp:100-101 (nothing reads them in between)
+    c.d.remaining[c.env] = c_skel.init_remaining;
+}
+
+// ---------------------------------------------------------------------------------------------
+// observation + reward + termination (robot_walk.cpp:56-74; proprioception_state.cpp)
+// ---------------------------------------------------------------------------------------------
+DEV void euler_zyx(Q4 q, float &yaw, float &pitch, float &roll) {
+    const float sqx = q.x * q.x, sqy = q.y * q.y, sqz = q.z * q.z, squ = q.w * q.w;
+    const float sarg = -2.0f * (q.x * q.z - q.w * q.y);
+    if (sarg <= -0.99999f) { pitch = -0.5f * EVM_PI; roll = 0.f; yaw = 2.0f * atan2f(q.x, -q.y); }
+    else if (sarg >= 0.99999f) { pitch = 0.5f * EVM_PI; roll = 0.f; yaw = 2.0f * atan2f(-q.x, q.y); }
+    else {
+        pitch = asinf(sarg);
+        roll = atan2f(2.0f * (q.y * q.z + q.w * q.x), squ - sqx - sqy + sqz);
+        yaw = atan2f(2.0f * (q.x * q.y + q.w * q.z), squ + sqx - sqy - sqz);
+    }
+}
+
+DEV void observe(const Ctx &c, float *obs, float *reward, uint8_t *done) {
+    float *o = obs + (size_t) c.env * c_skel.obs_dim;
+    const float PI_F = (float) 3.14159265358979323846;
+    const int root = c_skel.root;
+    const F3 root_ms = SC3(c_skel.sc_ms + 3 * root);
+    int k = 0;
+    for (int si = 0; si < c_skel.nm; si++) {
+        const int m = c_skel.state_member[si];
+        const Q4 qs = q4(GS(quat, 4 * m), GS(quat, 4 * m + 1), GS(quat, 4 * m + 2), GS(quat, 4 * m + 3));
+        const Q4 q = quat_from_mat(mat_from_quat(qs));  // getWorldTransform().getRotation()
+        float yaw, pitch, roll;
+        euler_zyx(q, yaw, pitch, roll);
+        const F3 lv = G3(lin, 3 * m), av = G3(ang, 3 * m);
+        const F3 ll = G3(hist, 6 * m), la = G3(hist, 6 * m + 3);
+        const F3 dl = ll - lv, da = la - av;
+        S3(hist, 6 * m, lv); S3(hist, 6 * m + 3, av);
+        o[k + 0] = yaw / PI_F; o[k + 1] = pitch / PI_F; o[k + 2] = roll / PI_F;
+        o[k + 3] = lv.x; o[k + 4] = lv.y; o[k + 5] = lv.z;
+        o[k + 6] = av.x / PI_F; o[k + 7] = av.y / PI_F; o[k + 8] = av.z / PI_F;
+        o[k + 9] = dl.x; o[k + 10] = dl.y; o[k + 11] = dl.z;
+        o[k + 12] = da.x / PI_F; o[k + 13] = da.y / PI_F; o[k + 14] = da.z / PI_F;
+        o[k + 15] = 0.f;  // floor_touched is never raised after construction (proprioception_state.cpp:18,39-40)
+        if (m == root) {
+            const F3 p = G3(pos, 3 * m);
+            o[k + 16] = logf(sqrtf(dot(p, p)) + 1.f);
+            o[k + 17] = p.y;
+            o[k + 18] = atan2f(p.z, p.x);
+        } else {
+            const F3 d = SC3(c_skel.sc_ms + 3 * m) - root_ms;
+            o[k + 16] = d.x; o[k + 17] = d.y; o[k + 18] = d.z;
+        }
+        k += 19;
+    }
+    for (int mi = 0; mi < c_skel.nmus; mi++) {
+        o[k + 0] = SC(c_skel.sc_mobs + 4 * mi + 0);
+        o[k + 1] = SC(c_skel.sc_mobs + 4 * mi + 1);
+        o[k + 2] = SC(c_skel.sc_mobs + 4 * mi + 2);
+        o[k + 3] = SC(c_skel.sc_mobs + 4 * mi + 3);
+        k += 4;
+    }
+    const float vz = GS(lin, 3 * root + 2);
+    int remaining = c.d.remaining[c.env], cs = c.d.curr_step[c.env];
+    if (vz < c_skel.min_vel) remaining -= 1;
+    else if (vz >= c_skel.target_vel) remaining += 1;
+    const bool win = cs >= c_skel.max_steps;
+    const bool fail = remaining <= 0;
+    c.d.remaining[c.env] = remaining;
+    c.d.curr_step[c.env] = cs + 1;
+    reward[c.env] = vz;
+    done[c.env] = (win | fail) ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// one stepSimulation(1/60) for this lane's env
+// ---------------------------------------------------------------------------------------------
+DEV void physics_step(const Ctx &c, int flags) {
+    const bool pending = (flags & EVM_FLAG_PENDING) != 0;
+    const bool powered = (flags & EVM_FLAG_POWERED) != 0;
+    const bool any_pending = __any(pending);
+    M33 E;
+    if (any_pending)
+        E = m33(f3(GS(E, 0), GS(E, 1), GS(E, 2)), f3(GS(E, 3), GS(E, 4), GS(E, 5)), f3(GS(E, 6), GS(E, 7), GS(E, 8)));
+
+    // ---- bodies: world basis, inverse inertia tile -> LDS, implicit gyroscopic impulse, zero deltas ----
+    for (int b = 0; b < c_skel.nb; b++) {
+        const EvmBodyC &BC = c_skel.body[b];
+        const Q4 q0 = q4(GS(quat, 4 * b), GS(quat, 4 * b + 1), GS(quat, 4 * b + 2), GS(quat, 4 * b + 3));
+        M33 R = mat_from_quat(q0);
+        const F3 invI = load_f3(BC.inv_inertia);
+        S33 I = inertia_world(R, invI);
+        if (any_pending) {
+            // first step after reset(): transform = E * M0 (non-orthonormal) and the inverse
+            // inertia tensor is still the one of the last integrated transform
+            const M33 Rp = glm_mul_basis(E, load_m33(BC.m0));
+            S33 Ip;
+            Ip.xx = GS(iinv_stale, 6 * b); Ip.xy = GS(iinv_stale, 6 * b + 1); Ip.xz = GS(iinv_stale, 6 * b + 2);
+            Ip.yy = GS(iinv_stale, 6 * b + 3); Ip.yz = GS(iinv_stale, 6 * b + 4); Ip.zz = GS(iinv_stale, 6 * b + 5);
+            if (pending) { R = Rp; I = Ip; }
+        }
+        SSC3(c_skel.sc_r + 9 * b, R.r0); SSC3(c_skel.sc_r + 9 * b + 3, R.r1); SSC3(c_skel.sc_r + 9 * b + 6, R.r2);
+        LII(b, 0) = I.xx; LII(b, 1) = I.xy; LII(b, 2) = I.xz; LII(b, 3) = I.yy; LII(b, 4) = I.yz; LII(b, 5) = I.zz;
+#pragma unroll
+        for (int k = 0; k < 6; k++) LDV(b, k) = 0.f;
+        // btRigidBody::computeGyroscopicImpulseImplicit_Body
+        const F3 omega1 = G3(ang, 3 * b);
+        const F3 idl = f3(1.f / invI.x, 1.f / invI.y, 1.f / invI.z);
+        const Q4 q = quat_from_mat(R);
+        F3 ob = quat_rotate(qinv(q), omega1);
+        const F3 ibo = f3(idl.x * ob.x, idl.y * ob.y, idl.z * ob.z);
+        const F3 f = cross(ob, ibo) * DT_F;
+        // J = Ib + (skew(ob) * Ib - skew(Ib ob)) * dt
+        const M33 s0 = m33(f3(0.f, -ob.z, ob.y), f3(ob.z, 0.f, -ob.x), f3(-ob.y, ob.x, 0.f));
+        const M33 s1 = m33(f3(0.f, -ibo.z, ibo.y), f3(ibo.z, 0.f, -ibo.x), f3(-ibo.y, ibo.x, 0.f));
+        M33 J;
+        J.r0 = f3(idl.x, 0.f, 0.f) + (f3(s0.r0.x * idl.x, s0.r0.y * idl.y, s0.r0.z * idl.z) - s1.r0) * DT_F;
+        J.r1 = f3(0.f, idl.y, 0.f) + (f3(s0.r1.x * idl.x, s0.r1.y * idl.y, s0.r1.z * idl.z) - s1.r1) * DT_F;
+        J.r2 = f3(0.f, 0.f, idl.z) + (f3(s0.r2.x * idl.x, s0.r2.y * idl.y, s0.r2.z * idl.z) - s1.r2) * DT_F;
+        const F3 c1 = col0(J), c2 = col1(J), c3 = col2(J);
+        const float det = dot(c1, cross(c2, c3));
+        F3 od = f3(0.f, 0.f, 0.f);
+        if (fabsf(det) > EVM_EPS)
+            od = f3(dot(f, cross(c2, c3)) / det, dot(c1, cross(f, c3)) / det, dot(c1, cross(c2, f)) / det);
+        ob = ob - od;
+        const F3 omega2 = quat_rotate(q, ob);
+        SSC3(c_skel.sc_ext + 3 * b, omega2 - omega1);
+    }
+
+    // ---- collision: hull vs floor plane, persistent manifolds ----
+    int ncontact = 0;
+    unsigned cmask = 0;  // wave-uniform: members with a cached point in any lane
+    for (int m = 0; m < c_skel.nm; m++) {
+        int n = 0;
+        if (c_skel.member[m].contact_response) n = contact_update(c, m);
+        ncontact += n;
+        if (__any(n > 0)) cmask |= 1u << m;
+    }
+
+    // ---- joint rows (Bullet order: skeleton constraints in file order, then slider, p2p_a, p2p_b per muscle) ----
+    for (int ci = 0; ci < c_skel.ncon; ci++) {
+        if (c_skel.con_type[ci] == 0) hinge_setup(c, c_skel.con_idx[ci]);
+        else fixed_setup(c, c_skel.con_idx[ci]);
+    }
+    for (int mi = 0; mi < c_skel.nmus; mi++) {
+        slider_setup(c, mi, powered, GS(target, mi));
+        p2p_setup(c, mi, 0);
+        p2p_setup(c, mi, 1);
+    }
+    // ---- contact rows: setup + warm start + split impulse ----
+    for (int m = 0; m < c_skel.nm; m++) {
+        if (cmask & (1u << m)) contact_setup(c, m, GS(mfn, m));
+        else { SSC3(c_skel.sc_pt + 6 * m, f3(0.f, 0.f, 0.f)); SSC3(c_skel.sc_pt + 6 * m + 3, f3(0.f, 0.f, 0.f)); }
+    }
+
+    // ---- projected Gauss-Seidel sweeps ----
+    float res = 0.f;
+    for (int it = 0; it < NUM_ITER; it++) {
+        res = 0.f;
+        for (int ci = 0; ci < c_skel.ncon; ci++) {
+            if (c_skel.con_type[ci] == 0) res = fmaxf(res, hinge_iter(c, c_skel.con_idx[ci]));
+            else res = fmaxf(res, fixed_iter(c, c_skel.con_idx[ci]));
+        }
+        for (int mi = 0; mi < c_skel.nmus; mi++) {
+            res = fmaxf(res, slider_iter(c, mi));
+            res = fmaxf(res, p2p_iter(c, mi, 0));
+            res = fmaxf(res, p2p_iter(c, mi, 1));
+        }
+        for (int m = 0; m < c_skel.nm; m++)
+            if (cmask & (1u << m)) res = fmaxf(res, contact_iter(c, m, GS(mfn, m)));
+    }
+    GS(diag, 0) = res;
+    GS(diag, 1) = (float) ncontact;
+
+    // ---- muscle readbacks: getAppliedImpulse() = impulse of the last row written back ----
+    for (int mi = 0; mi < c_skel.nmus; mi++) {
+        const int s = c_skel.sc_s + EVM_S_STRIDE * mi;
+        const float jd4 = SC(s + 25), jd5 = SC(s + 26);
+        const float a3 = SC(s + 38), a4 = SC(s + 39), a5 = SC(s + 40);
+        SC(c_skel.sc_mobs + 4 * mi + 1) = jd5 != 0.f ? a5 : (jd4 != 0.f ? a4 : a3);
+        SC(c_skel.sc_mobs + 4 * mi + 2) = SC(c_skel.sc_p + EVM_P_STRIDE * (2 * mi) + 14);
+        SC(c_skel.sc_mobs + 4 * mi + 3) = SC(c_skel.sc_p + EVM_P_STRIDE * (2 * mi + 1) + 14);
+    }
+
+    // ---- write back velocities, split-impulse pose correction, integrate transforms ----
+    for (int b = 0; b < c_skel.nb; b++) {
+        F3 o = G3(pos, 3 * b);
+        M33 R = m33(SC3(c_skel.sc_r + 9 * b), SC3(c_skel.sc_r + 9 * b + 3), SC3(c_skel.sc_r + 9 * b + 6));
+        const F3 dl = f3(LDV(b, 0), LDV(b, 1), LDV(b, 2)), da = f3(LDV(b, 3), LDV(b, 4), LDV(b, 5));
+        F3 lin = G3(lin, 3 * b) + dl;
+        F3 ang = G3(ang, 3 * b) + da;
+        if (b < c_skel.nm) {
+            const F3 push = SC3(c_skel.sc_pt + 6 * b), turn = SC3(c_skel.sc_pt + 6 * b + 3);
+            const bool nz = push.x != 0.f || push.y != 0.f || push.z != 0.f || turn.x != 0.f || turn.y != 0.f || turn.z != 0.f;
+            if (__any(nz)) {
+                F3 o2; Q4 q2;
+                integrate_transform(o, R, push, turn * SPLIT_TURN_ERP_F, DT_F, o2, q2);
+                if (nz) { o = o2; R = mat_from_quat(q2); }
+            }
+        }
+        lin = lin + f3(0.f, c_skel.body[b].ext_force_y, 0.f);
+        ang = ang + SC3(c_skel.sc_ext + 3 * b);
+        F3 o2; Q4 q2;
+        integrate_transform(o, R, lin, ang, DT_F, o2, q2);
+        S3(pos, 3 * b, o2);
+        GS(quat, 4 * b) = q2.x; GS(quat, 4 * b + 1) = q2.y; GS(quat, 4 * b + 2) = q2.z; GS(quat, 4 * b + 3) = q2.w;
+        S3(lin, 3 * b, lin);
+        S3(ang, 3 * b, ang);
+        if (b < c_skel.nm) SSC3(c_skel.sc_ms + 3 * b, o2 + lin * (0.f - DT_F));  // btDefaultMotionState, one step behind
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------
+// MODE bits: 1 apply action, 2 observe, 4 auto-reset rollout form
+template <int MODE>
+__global__ __launch_bounds__(64) void k_env_step(EnvDev d, const float *__restrict__ action, float *obs, float *reward,
+                                                 uint8_t *done, uint8_t *valid, const uint8_t *__restrict__ mask) {
+    extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
+    Ctx c;
+    c.d = d;
+    c.lane = threadIdx.x;
+    c.env = blockIdx.x * 64 + threadIdx.x;
+    c.lds = lds_dyn;
+    if (c.env >= d.n_real) return;
+    if (mask && !mask[c.env]) return;
+    int flags = d.flags[c.env];
+    bool settling = false;
+    if (MODE & 4) {
+        if (flags & EVM_FLAG_DONE) {
+            repose(c);
+            flags = d.flags[c.env] & ~EVM_FLAG_DONE;
+            d.flags[c.env] = flags;
+            d.settle_left[c.env] = 2 * c_skel.reset_frames;
+        }
+        settling = d.settle_left[c.env] > 0;
+    }
+    if ((MODE & 1) && !settling) {  // MuscleController::on_input -> Muscle::contract
+        for (int mi = 0; mi < c_skel.nmus; mi++)
+            GS(target, mi) = action[(size_t) c.env * c_skel.nmus + mi] * c_skel.muscle[mi].speed;
+        flags |= EVM_FLAG_POWERED;
+    }
+    physics_step(c, flags);
+    flags &= ~EVM_FLAG_PENDING;
+    bool do_observe = (MODE & 2) != 0;
+    if (MODE & 4) {
+        if (settling) {
+            const int left = d.settle_left[c.env] - 1;
+            d.settle_left[c.env] = left;
+            do_observe = left == 0;
+        }
+        valid[c.env] = do_observe ? 1 : 0;
+    }
+    if (do_observe) {
+        observe(c, obs, reward, done);
+        if ((MODE & 4) && done[c.env]) flags |= EVM_FLAG_DONE;
+    }
+    d.flags[c.env] = flags;
+}
+
+__global__ __launch_bounds__(64) void k_env_repose(EnvDev d, const uint8_t *__restrict__ mask) {
+    Ctx c;
+    c.d = d;
+    c.lane = threadIdx.x;
+    c.env = blockIdx.x * 64 + threadIdx.x;
+    c.lds = nullptr;
+    if (c.env >= d.n_real) return;
+    if (mask && !mask[c.env]) return;
+    repose(c);
+    d.flags[c.env] &= ~EVM_FLAG_DONE;
+    d.settle_left[c.env] = 0;
+}
+
+// creation state: world transform = first_model_matrix (E = identity, reset-pending), MT19937 seeded
+__global__ __launch_bounds__(64) void k_env_init(EnvDev d, uint64_t seed) {
+    Ctx c;
+    c.d = d;
+    c.lane = threadIdx.x;
+    c.env = blockIdx.x * 64 + threadIdx.x;
+    c.lds = nullptr;
+    if (c.env >= d.n) return;
+    const size_t n = d.n, e = c.env;
+    uint32_t x = (uint32_t) (seed + (uint64_t) c.env);
+    d.mt[e] = x;
+    for (int i = 1; i < 624; i++) {
+        x = 1812433253u * (x ^ (x >> 30)) + (uint32_t) i;
+        d.mt[(size_t) i * n + e] = x;
+    }
+    d.mt_idx[e] = 624;
+    for (int b = 0; b < c_skel.nb; b++) {
+        const EvmBodyC &BC = c_skel.body[b];
+        const M33 M0 = load_m33(BC.m0);
+        const S33 I = inertia_world(M0, load_f3(BC.inv_inertia));
+        GS(iinv_stale, 6 * b) = I.xx; GS(iinv_stale, 6 * b + 1) = I.xy; GS(iinv_stale, 6 * b + 2) = I.xz;
+        GS(iinv_stale, 6 * b + 3) = I.yy; GS(iinv_stale, 6 * b + 4) = I.yz; GS(iinv_stale, 6 * b + 5) = I.zz;
+        S3(pos, 3 * b, load_f3(BC.t0));
+        const Q4 q = quat_from_mat(M0);
+        GS(quat, 4 * b) = q.x; GS(quat, 4 * b + 1) = q.y; GS(quat, 4 * b + 2) = q.z; GS(quat, 4 * b + 3) = q.w;
+        S3(lin, 3 * b, f3(0.f, 0.f, 0.f));
+        S3(ang, 3 * b, f3(0.f, 0.f, 0.f));
+    }
+    for (int m = 0; m < c_skel.nm; m++) {
+        GS(mfn, m) = 0;
+        S3(hist, 6 * m, f3(0.f, 0.f, 0.f)); S3(hist, 6 * m + 3, f3(0.f, 0.f, 0.f));
+        SSC3(c_skel.sc_ms + 3 * m, load_f3(c_skel.body[m].t0));
+        for (int k = 0; k < 36; k++) GS(mfp, m * 36 + k) = 0.f;
+    }
+    for (int mi = 0; mi < c_skel.nmus; mi++) {
+        GS(target, mi) = 0.f;
+        for (int k = 0; k < 4; k++) SC(c_skel.sc_mobs + 4 * mi + k) = 0.f;
+    }
+    for (int k = 0; k < 9; k++) GS(E, k) = (k % 4 == 0) ? 1.f : 0.f;
+    d.flags[e] = EVM_FLAG_PENDING;
+    d.curr_step[e] = 0;
+    d.remaining[e] = c_skel.init_remaining;
+    d.settle_left[e] = 0;
+    GS(diag, 0) = 0.f; GS(diag, 1) = 0.f;
+}
+
+__global__ __launch_bounds__(64) void k_env_poses(EnvDev d, float *out) {
+    Ctx c;
+    c.d = d;
+    c.lane = threadIdx.x;
+    c.env = blockIdx.x * 64 + threadIdx.x;
+    if (c.env >= d.n_real) return;
+    const bool pending = (d.flags[c.env] & EVM_FLAG_PENDING) != 0;
+    M33 E = m33(f3(GS(E, 0), GS(E, 1), GS(E, 2)), f3(GS(E, 3), GS(E, 4), GS(E, 5)), f3(GS(E, 6), GS(E, 7), GS(E, 8)));
+    for (int b = 0; b < c_skel.nb; b++) {
+        float *o = out + ((size_t) c.env * c_skel.nb + b) * 7;
+        const F3 p = G3(pos, 3 * b);
+        Q4 q = q4(GS(quat, 4 * b), GS(quat, 4 * b + 1), GS(quat, 4 * b + 2), GS(quat, 4 * b + 3));
+        if (pending) {
+            q = quat_from_mat(glm_mul_basis(E, load_m33(c_skel.body[b].m0)));
+        }
+        o[0] = p.x; o[1] = p.y; o[2] = p.z; o[3] = q.x; o[4] = q.y; o[5] = q.z; o[6] = q.w;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-callable launchers (used by env_host.cpp)
+// ---------------------------------------------------------------------------------------------
+hipError_t upload_skeleton(const EvmSkelC *h, hipStream_t s) {
+    return hipMemcpyToSymbolAsync(HIP_SYMBOL(c_skel), h, sizeof(EvmSkelC), 0, hipMemcpyHostToDevice, s);
+}
+size_t step_lds_bytes(int nb) { return (size_t) nb * 12 * 64 * sizeof(float); }
+
+template <int MODE>
+static hipError_t launch_mode(const EnvDev &d, int nb, const float *action, float *obs, float *reward, uint8_t *done,
+                              uint8_t *valid, const uint8_t *mask, hipStream_t s) {
+    const size_t lds = step_lds_bytes(nb);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_env_step<MODE>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int) (160 * 1024));
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_env_step<MODE>), dim3(d.n / 64), dim3(64), lds, s, d, action, obs, reward, done, valid, mask);
+    return hipGetLastError();
+}
+hipError_t launch_step(const EnvDev &d, int nb, int mode, const float *action, float *obs, float *reward, uint8_t *done,
+                       uint8_t *valid, const uint8_t *mask, hipStream_t s) {
+    switch (mode) {
+        case 0: return launch_mode<0>(d, nb, action, obs, reward, done, valid, mask, s);
+        case 2: return launch_mode<2>(d, nb, action, obs, reward, done, valid, mask, s);
+        case 3: return launch_mode<3>(d, nb, action, obs, reward, done, valid, mask, s);
+        case 7: return launch_mode<7>(d, nb, action, obs, reward, done, valid, mask, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+hipError_t launch_repose(const EnvDev &d, const uint8_t *mask, hipStream_t s) {
+    hipLaunchKernelGGL(k_env_repose, dim3(d.n / 64), dim3(64), 0, s, d, mask);
+    return hipGetLastError();
+}
+hipError_t launch_init(const EnvDev &d, uint64_t seed, hipStream_t s) {
+    hipLaunchKernelGGL(k_env_init, dim3(d.n / 64), dim3(64), 0, s, d, seed);
+    return hipGetLastError();
+}
+hipError_t launch_poses(const EnvDev &d, float *out, hipStream_t s) {
+    hipLaunchKernelGGL(k_env_poses, dim3(d.n / 64), dim3(64), 0, s, d, out);
+    return hipGetLastError();
+}
+
+}  // namespace evm

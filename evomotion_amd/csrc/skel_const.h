@@ -1,0 +1,72 @@
+// Skeleton constants shared by the host loader (skeleton_host.cpp) and the dynamics kernel (env_kernels.hip).
+// One copy lives in __constant__ memory: every access is wave-uniform, so the compiler reads it through
+// the scalar cache (s_load) and the values occupy SGPRs, not VGPRs.
+#pragma once
+#include <stdint.h>
+
+#define EVM_MAX_BODIES 64
+#define EVM_MAX_MEMBERS 24
+#define EVM_MAX_HINGES 24
+#define EVM_MAX_FIXED 8
+#define EVM_MAX_MUSCLES 20
+#define EVM_MAX_HULL_PTS 1024
+
+// per-constraint scratch strides (floats per env)
+#define EVM_H_STRIDE 35   // hinge : relA3 relB3 p3 q3 ax3 | jd6 | rhs6 | lo hi | applied6
+#define EVM_F_STRIDE 42   // fixed : relA3 relB3 angax9 linax9 | jd6 | rhs6 | applied6
+#define EVM_S_STRIDE 41   // slider: p3 q3 ax3 p2_3 q2_3 relA3 relB3 | jd6 | rhs6 | lo hi | applied6
+#define EVM_P_STRIDE 15   // p2p   : a1_3 a2_3 | jd3 | rhs3 | applied3
+#define EVM_C_STRIDE 10   // contact point: rel3 lat3 | jd_n rhs_n jd_f rhs_f   (applied values live in the manifold)
+
+struct EvmBodyC {
+    float inv_mass;
+    float inv_inertia[3];
+    float ext_force_y;  // (gravity_force * inv_mass) * dt, y component (x = z = 0)
+    float mass, friction;
+    float m0[9];  // first_model_matrix basis, btMatrix3x3 rows (may be non-orthonormal: SURVEY App. A)
+    float t0[3];  // first_model_matrix origin
+};
+struct EvmMemberC {
+    int hull_off, hull_n;  // scaled hull points in hull[]
+    float break_thr;       // relative contact breaking threshold
+    float mu;              // combined friction with the floor
+    int contact_response;
+};
+struct EvmHingeC {
+    int a, b;
+    float fa[9], fao[3], fb[9], fbo[3];  // frames in A / B (basis rows, origin)
+    float factA, factB;
+    float center, half_range, bias, relaxation;
+};
+struct EvmFixedC {
+    int a, b;
+    float fa[9], fao[3], fb[9], fbo[3];
+};
+struct EvmMuscleC {
+    int sa, sb;  // attach sphere bodies (slider A, B)
+    int ma, mb;  // member bodies (p2p_a: ma-sa, p2p_b: mb-sb)
+    float piv_a[3], piv_b[3];
+    float upper_lin, max_impulse, speed;  // max_impulse = max_force / fps
+    float max_force;
+    float factA, factB;
+};
+struct EvmSkelC {
+    int nb, nm, nh, nf, nmus, root;
+    int obs_dim, act_dim;
+    int state_member[EVM_MAX_MEMBERS];  // observation order: root first (skeleton.cpp:140-160)
+    int ncon;                                        // skeleton constraints in file order (skeleton.cpp:77-82)
+    int con_type[EVM_MAX_HINGES + EVM_MAX_FIXED];    // 0 hinge, 1 fixed
+    int con_idx[EVM_MAX_HINGES + EVM_MAX_FIXED];
+    float floor_o[3], floor_top_y;
+    float root_pos[3];
+    float min_vel, target_vel;
+    int max_steps, init_remaining, reset_frames;
+    // scratch layout (offsets in floats-per-env)
+    int sc_r, sc_ext, sc_ms, sc_pt, sc_mobs, sc_h, sc_f, sc_s, sc_p, sc_c, sc_total;
+    EvmBodyC body[EVM_MAX_BODIES];
+    EvmMemberC member[EVM_MAX_MEMBERS];
+    EvmHingeC hinge[EVM_MAX_HINGES];
+    EvmFixedC fixed[EVM_MAX_FIXED];
+    EvmMuscleC muscle[EVM_MAX_MUSCLES];
+    float hull[EVM_MAX_HULL_PTS * 3];
+};

@@ -1,0 +1,390 @@
+#include "skeleton_host.h"
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <vector>
+
+namespace evm {
+namespace {
+
+constexpr float kMargin = 0.04f;        // Bullet CONVEX_DISTANCE_MARGIN
+constexpr float kBreaking = 0.02f;      // Bullet gContactBreakingThreshold
+constexpr float kDt = 1.f / 60.f;       // DELTA_T_MODEL, evo_motion_model/src/constants.h.in:8
+constexpr float kEps = 1.1920928955078125e-7f;
+constexpr float kPi = 3.1415926535897932384626433832795029f;
+
+struct Mat {  // rows of a 3x3 + origin (an affine glm::mat4 / btTransform)
+    float m[3][3];
+    float o[3];
+};
+
+struct RawMember { std::string name, shape; float mass, friction, t[3], q[4], scale[3]; int ignore; };
+struct RawCon { int type; std::string name, parent, child; float v[20]; };
+struct RawMuscle { std::string name, a, b; float mass, scale[3], pa[3], pb[3], force, speed; };
+struct RawShape { std::string name; std::vector<float> pts; };
+
+bool next_float(std::istringstream &ss, float &f) {
+    std::string tok;
+    if (!(ss >> tok)) return false;
+    f = strtof(tok.c_str(), nullptr);
+    return true;
+}
+bool next_floats(std::istringstream &ss, float *dst, int n) {
+    for (int i = 0; i < n; i++)
+        if (!next_float(ss, dst[i])) return false;
+    return true;
+}
+
+// glm::mat3_cast on a possibly non-unit quaternion (w,x,y,z), returned as rows.
+void quat_to_rows(const float q[4], float m[3][3]) {
+    const float w = q[0], x = q[1], y = q[2], z = q[3];
+    const float xx = x * x, yy = y * y, zz = z * z, xz = x * z, xy = x * y, yz = y * z, wx = w * x, wy = w * y, wz = w * z;
+    m[0][0] = 1.f - 2.f * (yy + zz); m[1][0] = 2.f * (xy + wz); m[2][0] = 2.f * (xz - wy);
+    m[0][1] = 2.f * (xy - wz); m[1][1] = 1.f - 2.f * (xx + zz); m[2][1] = 2.f * (yz + wx);
+    m[0][2] = 2.f * (xz + wy); m[1][2] = 2.f * (yz - wx); m[2][2] = 1.f - 2.f * (xx + yy);
+}
+// column c of a row-stored matrix
+inline void colv(const float m[3][3], int c, float out[3]) { out[0] = m[0][c]; out[1] = m[1][c]; out[2] = m[2][c]; }
+inline float dot3(const float a[3], const float b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+inline void cross3(const float a[3], const float b[3], float o[3]) {
+    float r0 = a[1] * b[2] - a[2] * b[1], r1 = a[2] * b[0] - a[0] * b[2], r2 = a[0] * b[1] - a[1] * b[0];
+    o[0] = r0; o[1] = r1; o[2] = r2;
+}
+float norm_angle(float a) {
+    a = fmodf(a, 2.f * kPi);
+    if (a < -kPi) return a + 2.f * kPi;
+    if (a > kPi) return a - 2.f * kPi;
+    return a;
+}
+void plane_space(const float n[3], float p[3], float q[3]) {
+    if (fabsf(n[2]) > 0.7071067811865475244008443621048490f) {
+        float a = n[1] * n[1] + n[2] * n[2], k = 1.f / sqrtf(a);
+        p[0] = 0; p[1] = -n[2] * k; p[2] = n[1] * k;
+        q[0] = a * k; q[1] = -n[0] * p[2]; q[2] = n[0] * p[1];
+    } else {
+        float a = n[0] * n[0] + n[1] * n[1], k = 1.f / sqrtf(a);
+        p[0] = -n[1] * k; p[1] = n[0] * k; p[2] = 0;
+        q[0] = -n[2] * p[1]; q[1] = n[2] * p[0]; q[2] = a * k;
+    }
+}
+// Bullet quatRotate(q, v) with q = (x,y,z,w)
+void quat_rotate(const float q[4], const float v[3], float out[3]) {
+    const float qx = q[0], qy = q[1], qz = q[2], qw = q[3];
+    float tx = qw * v[0] + qy * v[2] - qz * v[1];
+    float ty = qw * v[1] + qz * v[0] - qx * v[2];
+    float tz = qw * v[2] + qx * v[1] - qy * v[0];
+    float tw = -qx * v[0] - qy * v[1] - qz * v[2];
+    const float ix = -qx, iy = -qy, iz = -qz, iw = qw;
+    out[0] = tw * ix + tx * iw + ty * iz - tz * iy;
+    out[1] = tw * iy + ty * iw + tz * ix - tx * iz;
+    out[2] = tw * iz + tz * iw + tx * iy - ty * ix;
+}
+
+// Box-like inertia of the margin-inflated local AABB + the relative contact breaking threshold
+// (btPolyhedralConvexShape::calculateLocalInertia, btCollisionShape::getContactBreakingThreshold).
+void shape_properties(const std::vector<float> &pts, const float scale[3], float mass, float inv_inertia[3],
+                      float &break_thr) {
+    float hi[3] = {-1e18f, -1e18f, -1e18f}, lo[3] = {1e18f, 1e18f, 1e18f};
+    for (size_t i = 0; i + 2 < pts.size(); i += 3)
+        for (int a = 0; a < 3; a++) {
+            float s = pts[i + a] * scale[a];
+            if (s > hi[a]) hi[a] = s;
+            if (s < lo[a]) lo[a] = s;
+        }
+    float amin[3], amax[3];
+    for (int a = 0; a < 3; a++) {
+        float lmax = hi[a] + kMargin, lmin = lo[a] - kMargin;  // cached local AABB
+        float half = 0.5f * (lmax - lmin);
+        half += kMargin;                                       // getAabb adds the margin again
+        float centre = 0.5f * (lmax + lmin);
+        amin[a] = centre - half;
+        amax[a] = centre + half;
+    }
+    float l[3];
+    for (int a = 0; a < 3; a++) l[a] = 2.f * ((amax[a] - amin[a]) * 0.5f + kMargin);
+    const float x2 = l[0] * l[0], y2 = l[1] * l[1], z2 = l[2] * l[2];
+    const float sm = mass * 0.08333333f;
+    const float in[3] = {sm * (y2 + z2), sm * (x2 + z2), sm * (x2 + y2)};
+    for (int a = 0; a < 3; a++) inv_inertia[a] = in[a] != 0.f ? 1.f / in[a] : 0.f;
+    float d[3] = {amax[0] - amin[0], amax[1] - amin[1], amax[2] - amin[2]};
+    float c[3] = {(amin[0] + amax[0]) * 0.5f, (amin[1] + amax[1]) * 0.5f, (amin[2] + amax[2]) * 0.5f};
+    float radius = sqrtf(dot3(d, d)) * 0.5f;
+    break_thr = (radius + sqrtf(dot3(c, c))) * kBreaking;
+}
+
+void copy_rows(const float m[3][3], float out[9]) {
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) out[3 * i + j] = m[i][j];
+}
+
+}  // namespace
+
+int load_skeleton_constants(const char *path, const EvmEnvParams &prm, EvmSkelC &S, std::string &err) {
+    std::ifstream f(path ? path : "");
+    if (!f) { err = std::string("cannot open skeleton fixture: ") + (path ? path : "(null)"); return EVM_E_RUNTIME; }
+    std::string root_name;
+    std::vector<RawMember> members;
+    std::vector<RawCon> cons;
+    std::vector<RawMuscle> muscles;
+    std::vector<RawShape> shapes;
+    std::string line;
+    int pts_left = 0;
+    while (std::getline(f, line)) {
+        if (line.empty() || line[0] == '#') continue;
+        std::istringstream ss(line);
+        if (pts_left > 0) {
+            float p[3];
+            if (!next_floats(ss, p, 3)) { err = "malformed hull point"; return EVM_E_RUNTIME; }
+            shapes.back().pts.insert(shapes.back().pts.end(), p, p + 3);
+            pts_left--;
+            continue;
+        }
+        std::string kw;
+        ss >> kw;
+        if (kw == "skeleton") {
+            std::string robot, r;
+            ss >> robot >> r >> root_name;
+        } else if (kw == "member") {
+            RawMember m;
+            ss >> m.name >> m.shape;
+            bool ok = next_float(ss, m.mass) && next_float(ss, m.friction) && next_floats(ss, m.t, 3) &&
+                      next_floats(ss, m.q, 4) && next_floats(ss, m.scale, 3);
+            if (!ok || !(ss >> m.ignore)) { err = "malformed member line"; return EVM_E_RUNTIME; }
+            members.push_back(m);
+        } else if (kw == "hinge" || kw == "fixed") {
+            RawCon c;
+            c.type = kw == "hinge" ? 0 : 1;
+            ss >> c.name >> c.parent >> c.child;
+            if (!next_floats(ss, c.v, c.type == 0 ? 14 : 14)) { err = "malformed constraint line"; return EVM_E_RUNTIME; }
+            cons.push_back(c);
+        } else if (kw == "muscle") {
+            RawMuscle m;
+            ss >> m.name >> m.a >> m.b;
+            bool ok = next_float(ss, m.mass) && next_floats(ss, m.scale, 3) && next_floats(ss, m.pa, 3) &&
+                      next_floats(ss, m.pb, 3) && next_float(ss, m.force) && next_float(ss, m.speed);
+            if (!ok) { err = "malformed muscle line"; return EVM_E_RUNTIME; }
+            muscles.push_back(m);
+        } else if (kw == "shape") {
+            RawShape s;
+            int n = 0, ndup = 0;
+            ss >> s.name >> n >> ndup;
+            shapes.push_back(s);
+            pts_left = n;
+        } else if (kw == "members" || kw == "constraints" || kw == "muscles" || kw == "shapes") {
+        } else {
+            err = "unknown keyword in skeleton fixture: " + kw;
+            return EVM_E_RUNTIME;
+        }
+    }
+    std::map<std::string, int> member_id, shape_id;
+    for (size_t i = 0; i < members.size(); i++) member_id[members[i].name] = (int) i;
+    for (size_t i = 0; i < shapes.size(); i++) shape_id[shapes[i].name] = (int) i;
+    auto find_member = [&](const std::string &n, int &id) {
+        auto it = member_id.find(n);
+        if (it == member_id.end()) { err = "Member \"" + n + "\"not found"; return false; }  // skeleton.cpp:58
+        id = it->second;
+        return true;
+    };
+
+    const int nm = (int) members.size(), nmus = (int) muscles.size(), nb = nm + 2 * nmus;
+    int nh = 0, nf = 0;
+    for (auto &c : cons) (c.type == 0 ? nh : nf)++;
+    if (nb > EVM_MAX_BODIES || nm > EVM_MAX_MEMBERS || nh > EVM_MAX_HINGES || nf > EVM_MAX_FIXED ||
+        nmus > EVM_MAX_MUSCLES || nm < 1) { err = "skeleton exceeds the compiled capacity"; return EVM_E_UNSUPPORTED; }
+
+    memset(&S, 0, sizeof(S));
+    S.nb = nb; S.nm = nm; S.nh = nh; S.nf = nf; S.nmus = nmus;
+    if (!find_member(root_name, S.root)) return EVM_E_RUNTIME;
+    S.obs_dim = 19 * nm + 4 * nmus;
+    S.act_dim = nmus;
+    {
+        int k = 0;
+        S.state_member[k++] = S.root;
+        for (int i = 0; i < nm; i++)
+            if (i != S.root) S.state_member[k++] = i;
+    }
+    S.floor_o[0] = 0.f; S.floor_o[1] = -2.f; S.floor_o[2] = 2.f;  // robot_walk.cpp:24
+    S.floor_top_y = S.floor_o[1] + 1.0f * 1.f;
+    S.root_pos[0] = 1.f; S.root_pos[1] = 0.25f; S.root_pos[2] = 2.f;  // robot_walk.cpp:78
+    S.min_vel = prm.minimal_velocity; S.target_vel = prm.target_velocity;
+    S.max_steps = (int) (prm.max_episode_seconds / kDt);
+    S.init_remaining = (int) (prm.initial_remaining_seconds / kDt);
+    S.reset_frames = prm.reset_frames;
+
+    // ---- bodies: members, then (attach_a, attach_b) per muscle ----
+    std::vector<Mat> M0(nb);
+    std::vector<int> body_shape(nb);
+    std::vector<const float *> body_scale(nb);
+    int hull_used = 0;
+    std::map<std::pair<int, std::vector<float>>, int> hull_cache;
+    const float floor_friction = 0.5f;  // robot_walk.cpp:33
+    for (int i = 0; i < nm; i++) {
+        const RawMember &m = members[i];
+        auto sit = shape_id.find(m.shape);
+        if (sit == shape_id.end()) { err = "unknown shape " + m.shape; return EVM_E_RUNTIME; }
+        body_shape[i] = sit->second;
+        body_scale[i] = m.scale;
+        quat_to_rows(m.q, M0[i].m);
+        for (int a = 0; a < 3; a++) M0[i].o[a] = m.t[a];
+        S.body[i].mass = m.mass;
+        S.body[i].friction = m.friction;
+        // scaled hull points (btConvexHullShape::getScaledPoint), shared between members of equal shape+scale
+        std::vector<float> key(m.scale, m.scale + 3);
+        auto hk = std::make_pair(sit->second, key);
+        auto hit = hull_cache.find(hk);
+        const std::vector<float> &pts = shapes[sit->second].pts;
+        if (hit == hull_cache.end()) {
+            int n = (int) pts.size() / 3;
+            if (hull_used + n > EVM_MAX_HULL_PTS) { err = "hull table overflow"; return EVM_E_UNSUPPORTED; }
+            for (int p = 0; p < n; p++)
+                for (int a = 0; a < 3; a++) S.hull[3 * (hull_used + p) + a] = pts[3 * p + a] * m.scale[a];
+            hull_cache[hk] = hull_used;
+            S.member[i].hull_off = hull_used;
+            hull_used += n;
+        } else {
+            S.member[i].hull_off = hit->second;
+        }
+        S.member[i].hull_n = (int) pts.size() / 3;
+        S.member[i].contact_response = m.ignore ? 0 : 1;
+        float mu = floor_friction * m.friction;
+        S.member[i].mu = mu < -10.f ? -10.f : (mu > 10.f ? 10.f : mu);
+    }
+    auto sph = shape_id.find("sphere");
+    for (int k = 0; k < nmus; k++) {
+        const RawMuscle &mu = muscles[k];
+        if (sph == shape_id.end()) { err = "sphere shape missing"; return EVM_E_RUNTIME; }
+        int ma, mb;
+        if (!find_member(mu.a, ma) || !find_member(mu.b, mb)) return EVM_E_RUNTIME;
+        for (int side = 0; side < 2; side++) {
+            const int bi = nm + 2 * k + side;
+            const Mat &P = M0[side == 0 ? ma : mb];
+            const float *pos = side == 0 ? mu.pa : mu.pb;
+            // parent.model_matrix_without_scale() * glm::translate(I, pos)   (muscle.cpp:23,27)
+            float c0[3], c1[3], c2[3];
+            colv(P.m, 0, c0); colv(P.m, 1, c1); colv(P.m, 2, c2);
+            for (int r = 0; r < 3; r++)
+                for (int c = 0; c < 3; c++) {
+                    // column c of the product = P0*I[c][0] + P1*I[c][1] + P2*I[c][2]
+                    float e0 = c == 0 ? 1.f : 0.f, e1 = c == 1 ? 1.f : 0.f, e2 = c == 2 ? 1.f : 0.f;
+                    M0[bi].m[r][c] = c0[r] * e0 + c1[r] * e1 + c2[r] * e2;
+                }
+            for (int r = 0; r < 3; r++) M0[bi].o[r] = c0[r] * pos[0] + c1[r] * pos[1] + c2[r] * pos[2] + P.o[r];
+            body_shape[bi] = sph->second;
+            body_scale[bi] = mu.scale;
+            S.body[bi].mass = mu.mass;
+            S.body[bi].friction = 0.5f;
+        }
+    }
+    for (int i = 0; i < nb; i++) {
+        EvmBodyC &b = S.body[i];
+        b.inv_mass = b.mass == 0.f ? 0.f : 1.0f / b.mass;
+        float thr;
+        shape_properties(shapes[body_shape[i]].pts, body_scale[i], b.mass, b.inv_inertia, thr);
+        if (i < nm) S.member[i].break_thr = thr;
+        // applyGravity: m_gravity = g * (1 / invMass); solver: externalForceImpulse = (F * invMass) * dt
+        float gy = b.inv_mass != 0.f ? -9.8f * (1.0f / b.inv_mass) : 0.f;
+        b.ext_force_y = gy * b.inv_mass * kDt;
+        copy_rows(M0[i].m, b.m0);
+        for (int a = 0; a < 3; a++) b.t0[a] = M0[i].o[a];
+    }
+
+    // ---- skeleton constraints ----
+    int hi = 0, fi = 0;
+    S.ncon = (int) cons.size();
+    for (size_t ci = 0; ci < cons.size(); ci++) {
+        const RawCon &c = cons[ci];
+        int pa, ch;
+        if (!find_member(c.parent, pa) || !find_member(c.child, ch)) return EVM_E_RUNTIME;
+        const float miA = S.body[pa].inv_mass, miB = S.body[ch].inv_mass, miS = miA + miB;
+        if (c.type == 0) {
+            EvmHingeC &h = S.hinge[hi];
+            S.con_type[ci] = 0; S.con_idx[ci] = hi++;
+            h.a = pa; h.b = ch;
+            const float *pivA = c.v, *pivB = c.v + 3, *axA = c.v + 6, *axB = c.v + 9;
+            const float lo = c.v[12], up = c.v[13];
+            // btHingeConstraint pivot/axis constructor: frame A from body A's WORLD x axis at construction
+            float a1[3], a2[3];
+            colv(M0[pa].m, 0, a1);
+            float proj = dot3(axA, a1);
+            if (proj >= 1.0f - kEps) {
+                float t[3]; colv(M0[pa].m, 2, t);
+                a1[0] = -t[0]; a1[1] = -t[1]; a1[2] = -t[2];
+                colv(M0[pa].m, 1, a2);
+            } else if (proj <= -1.0f + kEps) {
+                colv(M0[pa].m, 2, a1);
+                colv(M0[pa].m, 1, a2);
+            } else {
+                cross3(axA, a1, a2);
+                cross3(a2, axA, a1);
+            }
+            float FA[3][3] = {{a1[0], a2[0], axA[0]}, {a1[1], a2[1], axA[1]}, {a1[2], a2[2], axA[2]}};
+            // shortestArcQuat(axisInA, axisInB)
+            float cr[3]; cross3(axA, axB, cr);
+            float d = dot3(axA, axB);
+            float q[4];
+            if (d < -1.0f + kEps) {
+                float n[3], u[3]; plane_space(axA, n, u);
+                q[0] = n[0]; q[1] = n[1]; q[2] = n[2]; q[3] = 0.f;
+            } else {
+                float s = sqrtf((1.0f + d) * 2.0f), rs = 1.0f / s;
+                q[0] = cr[0] * rs; q[1] = cr[1] * rs; q[2] = cr[2] * rs; q[3] = s * 0.5f;
+            }
+            float b1[3], b2[3];
+            quat_rotate(q, a1, b1);
+            cross3(axB, b1, b2);
+            float FB[3][3] = {{b1[0], b2[0], axB[0]}, {b1[1], b2[1], axB[1]}, {b1[2], b2[2], axB[2]}};
+            copy_rows(FA, h.fa); copy_rows(FB, h.fb);
+            for (int a = 0; a < 3; a++) { h.fao[a] = pivA[a]; h.fbo[a] = pivB[a]; }
+            h.factA = miS > 0.f ? miB / miS : 0.5f;
+            h.factB = 1.0f - h.factA;
+            h.half_range = (up - lo) / 2.0f;           // btAngularLimit::set
+            h.center = norm_angle(lo + h.half_range);
+            h.bias = 0.3f; h.relaxation = 1.0f;        // setLimit defaults
+        } else {
+            EvmFixedC &x = S.fixed[fi];
+            S.con_type[ci] = 1; S.con_idx[ci] = fi++;
+            x.a = pa; x.b = ch;
+            float FA[3][3], FB[3][3];
+            quat_to_rows(c.v + 3, FA);
+            quat_to_rows(c.v + 10, FB);
+            copy_rows(FA, x.fa); copy_rows(FB, x.fb);
+            for (int a = 0; a < 3; a++) { x.fao[a] = c.v[a]; x.fbo[a] = c.v[7 + a]; }
+        }
+    }
+    for (int k = 0; k < nmus; k++) {
+        const RawMuscle &mu = muscles[k];
+        EvmMuscleC &m = S.muscle[k];
+        find_member(mu.a, m.ma); find_member(mu.b, m.mb);
+        m.sa = nm + 2 * k; m.sb = m.sa + 1;
+        for (int a = 0; a < 3; a++) { m.piv_a[a] = mu.pa[a]; m.piv_b[a] = mu.pb[a]; }
+        float d[3] = {M0[m.sa].o[0] - M0[m.sb].o[0], M0[m.sa].o[1] - M0[m.sb].o[1], M0[m.sa].o[2] - M0[m.sb].o[2]};
+        m.upper_lin = 2.f * sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);  // muscle.cpp:43-49
+        m.max_force = mu.force;
+        m.max_impulse = mu.force / (1.f / kDt);
+        m.speed = mu.speed;
+        const float miA = S.body[m.sa].inv_mass, miB = S.body[m.sb].inv_mass, miS = miA + miB;
+        m.factA = miS > 0.f ? miB / miS : 0.5f;
+        m.factB = 1.0f - m.factA;
+    }
+
+    // ---- scratch layout ----
+    int o = 0;
+    S.sc_r = o; o += 9 * nb;
+    S.sc_ext = o; o += 3 * nb;
+    S.sc_ms = o; o += 3 * nm;
+    S.sc_pt = o; o += 6 * nm;
+    S.sc_mobs = o; o += 4 * nmus;
+    S.sc_h = o; o += EVM_H_STRIDE * nh;
+    S.sc_f = o; o += EVM_F_STRIDE * nf;
+    S.sc_s = o; o += EVM_S_STRIDE * nmus;
+    S.sc_p = o; o += EVM_P_STRIDE * 2 * nmus;
+    S.sc_c = o; o += EVM_C_STRIDE * 4 * nm;
+    S.sc_total = o;
+    return EVM_OK;
+}
+
+}  // namespace evm

@@ -1,0 +1,149 @@
+"""Vectorised robot_walk environment on one MI355X — Python mirror of the reference's Environment API
+(evo_motion_model/include/evo_motion_model/environment.h:35-97) on top of the C ABI.
+
+`VecRobotWalk` keeps the reference's method names (reset / do_step / get_state_space / get_action_space);
+`step` is a (state, reward, done) tuple of device tensors like the reference's `struct step`
+(environment.h:20-24), with a leading env dimension.  torch is used only to own device memory and streams.
+"""
+import ctypes
+from collections import namedtuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import EvmEnvParams, check, lib
+
+Step = namedtuple("Step", ["state", "reward", "done"])
+RolloutStep = namedtuple("RolloutStep", ["state", "reward", "done", "valid"])
+
+# RobotWalkFactory parameter names and defaults (evo_motion_model/src/env/env_factory.cpp:74-83)
+_PARAM_DEFAULTS = {
+    "skeleton_json_path": _lib.DEFAULT_SKELETON,
+    "initial_remaining_seconds": 1.0,
+    "max_episode_seconds": 30.0,
+    "target_velocity": 0.5,
+    "minimal_velocity": 0.1,
+    "reset_frames": 30,
+}
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class VecRobotWalk:
+    def __init__(self, n_envs, seed=1234, device=0, parameters=None):
+        prm = dict(_PARAM_DEFAULTS)
+        for k, v in (parameters or {}).items():
+            if k not in prm:
+                raise ValueError(k)
+            prm[k] = type(_PARAM_DEFAULTS[k])(v)
+        if not torch.cuda.is_available():
+            raise _lib.EvmError("VecRobotWalk needs a HIP device (no CPU fallback)")
+        self.device = torch.device("cuda", device)
+        self.n_envs = int(n_envs)
+        p = EvmEnvParams(prm["initial_remaining_seconds"], prm["max_episode_seconds"], prm["target_velocity"],
+                         prm["minimal_velocity"], prm["reset_frames"])
+        self._h = ctypes.c_void_p()
+        torch.cuda.set_device(self.device)
+        check(lib.evm_env_create(prm["skeleton_json_path"].encode(), self.n_envs, device, seed, ctypes.byref(p),
+                                 ctypes.byref(self._h)))
+        s, a = ctypes.c_int(), ctypes.c_int()
+        check(lib.evm_env_spaces(self._h, ctypes.byref(s), ctypes.byref(a)))
+        self.state_dim, self.action_dim = s.value, a.value
+        c = [ctypes.c_int() for _ in range(4)]
+        check(lib.evm_env_counts(self._h, *[ctypes.byref(x) for x in c]))
+        _, self.n_bodies, self.n_members, self.n_muscles = [x.value for x in c]
+        self.obs = torch.zeros(self.n_envs, self.state_dim, device=self.device)
+        self.reward = torch.zeros(self.n_envs, device=self.device)
+        self.done = torch.zeros(self.n_envs, dtype=torch.uint8, device=self.device)
+        self.valid = torch.zeros(self.n_envs, dtype=torch.uint8, device=self.device)
+
+    def close(self):
+        if self._h:
+            lib.evm_env_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- reference API ---------------------------------------------------------------------------
+    def get_state_space(self):
+        return [self.state_dim]
+
+    def get_action_space(self):
+        return [self.action_dim]
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def reset(self, mask=None):
+        if mask is not None:
+            mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
+        check(lib.evm_env_reset(self._h, _ptr(mask), _ptr(self.obs), _ptr(self.reward), _ptr(self.done), self._stream()))
+        return Step(self.obs, self.reward, self.done)
+
+    def _action(self, action):
+        if action.device != self.device or action.dtype != torch.float32 or not action.is_contiguous():
+            action = action.to(device=self.device, dtype=torch.float32).contiguous()
+        if tuple(action.shape) != (self.n_envs, self.action_dim):
+            raise ValueError(f"action must be [{self.n_envs}, {self.action_dim}]")
+        return action
+
+    def do_step(self, action):
+        action = self._action(action)
+        check(lib.evm_env_step(self._h, _ptr(action), _ptr(self.obs), _ptr(self.reward), _ptr(self.done), self._stream()))
+        return Step(self.obs, self.reward, self.done)
+
+    def step_autoreset(self, action):
+        action = self._action(action)
+        check(lib.evm_env_step_autoreset(self._h, _ptr(action), _ptr(self.obs), _ptr(self.reward), _ptr(self.done),
+                                         _ptr(self.valid), self._stream()))
+        return RolloutStep(self.obs, self.reward, self.done, self.valid)
+
+    # -- parity / checkpoint hooks ---------------------------------------------------------------
+    def body_poses(self):
+        out = torch.empty(self.n_envs, self.n_bodies, 7, device=self.device)
+        check(lib.evm_env_get_body_poses(self._h, _ptr(out), self._stream()))
+        return out
+
+    def state_size(self):
+        return lib.evm_env_state_size(self._h)
+
+    def get_state(self):
+        out = np.zeros((self.n_envs, self.state_size()), np.float32)
+        check(lib.evm_env_get_state(self._h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_float))))
+        return out
+
+    def set_state(self, blob):
+        blob = np.ascontiguousarray(blob, np.float32)
+        assert blob.shape == (self.n_envs, self.state_size())
+        check(lib.evm_env_set_state(self._h, blob.ctypes.data_as(ctypes.POINTER(ctypes.c_float))))
+
+    def debug_reset_begin(self, mask=None):
+        check(lib.evm_env_debug_reset_begin(self._h, _ptr(mask)))
+
+    def debug_physics_steps(self, n, mask=None):
+        check(lib.evm_env_debug_physics_steps(self._h, n, _ptr(mask)))
+
+    def body_constants(self):
+        out = np.zeros((self.n_bodies, 19), np.float32)
+        check(lib.evm_env_get_body_constants(self._h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_float))))
+        return out
+
+    def diagnostics(self):
+        out = torch.empty(self.n_envs, 2, device=self.device)
+        check(lib.evm_env_get_diagnostics(self._h, _ptr(out), self._stream()))
+        return out
+
+    def timing_begin(self):
+        check(lib.evm_env_timing_begin(self._h, self._stream()))
+
+    def timing_end(self):
+        ms, n = ctypes.c_float(), ctypes.c_int()
+        check(lib.evm_env_timing_end(self._h, self._stream(), ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value

@@ -1,0 +1,119 @@
+/*
+ * evomotion.h — C ABI of libevomotion_hip.so (MI355X / gfx950).
+ *
+ * Vectorised drop-in for the reference's two abstract C++ interfaces on the robot_walk hot path.  The
+ * reference has no FFI layer; these entry points are what a binding for that path would call.  Each one
+ * cites the reference interface it replaces (paths relative to the reference repository root).
+ *
+ * Conventions: every function returns 0 on success or a negative EVM_E_* code and records a message
+ * retrievable with evm_last_error(); no C++ exception crosses this boundary.  `d_` pointers are DEVICE
+ * pointers owned by the caller; `h_` pointers are host pointers.  All work is enqueued on the stream given
+ * (a hipStream_t passed as void*; NULL = the default stream) and is asynchronous with respect to the host
+ * unless stated otherwise.  One host thread per GPU; an EvmEnv / EvmPolicy is not re-entrant (like the
+ * reference's Environment: evo_motion_model/include/evo_motion_model/environment.h:35-73).
+ */
+#ifndef EVOMOTION_H
+#define EVOMOTION_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EVM_OK 0
+#define EVM_E_INVALID (-1)    /* std::invalid_argument in the reference (env_factory.cpp:118) */
+#define EVM_E_RUNTIME (-2)    /* std::runtime_error in the reference (skeleton.cpp:46,58) */
+#define EVM_E_HIP (-3)        /* a HIP runtime call failed */
+#define EVM_E_UNSUPPORTED (-4)
+
+typedef struct EvmEnv EvmEnv;
+typedef struct EvmPolicy EvmPolicy;
+
+/* RobotWalkFactory defaults: evo_motion_model/src/env/env_factory.cpp:74-83 */
+typedef struct EvmEnvParams {
+    float initial_remaining_seconds; /* 1.0  */
+    float max_episode_seconds;       /* 30.0 */
+    float target_velocity;           /* 0.5  */
+    float minimal_velocity;          /* 0.1  */
+    int reset_frames;                /* 30   */
+} EvmEnvParams;
+
+const char *evm_last_error(void);
+void evm_env_default_params(EvmEnvParams *out);
+
+/*
+ * Replaces get_environment_factory("robot_walk", params)->get_env(num_threads, seed)
+ * (evo_motion_model/include/evo_motion_model/environment.h:80,96-97; RobotWalk ctor
+ * evo_motion_model/src/env/robot_walk.cpp:17-46) for n_envs independent environments on HIP device
+ * `device`.  Environment i is seeded with seed + i (std::mt19937 stream of robot_walk.h:34).
+ * skeleton_path: the decoded skeleton fixture (evomotion_amd/data/robot_walk_spider.skel).
+ */
+int evm_env_create(const char *skeleton_path, int n_envs, int device, uint64_t seed, const EvmEnvParams *params,
+                   EvmEnv **out);
+void evm_env_destroy(EvmEnv *env);
+
+/* Environment::get_state_space / get_action_space (environment.h:66-67): 371 and 12 for robot_walk. */
+int evm_env_spaces(const EvmEnv *env, int *state_dim, int *action_dim);
+int evm_env_counts(const EvmEnv *env, int *n_envs, int *n_bodies, int *n_members, int *n_muscles);
+
+/*
+ * Environment::reset() (evo_motion_model/src/environment.cpp:45-48 -> RobotWalk::reset_engine,
+ * robot_walk.cpp:76-104) for every env whose d_mask byte is non-zero (NULL = all): 3 RNG draws, rigid
+ * re-pose, 2*reset_frames settle steps, then compute_step().  Outputs are written for the masked envs only.
+ * d_obs [n_envs, state_dim] f32, d_reward [n_envs] f32, d_done [n_envs] u8.
+ */
+int evm_env_reset(EvmEnv *env, const uint8_t *d_mask, float *d_obs, float *d_reward, uint8_t *d_done,
+                  void *stream);
+
+/*
+ * Environment::do_step(action) (evo_motion_model/src/environment.cpp:33-39) for all envs: controllers
+ * (muscle_controller.cpp:10-12), one stepSimulation(1/60), compute_step (robot_walk.cpp:56-74).
+ * d_action [n_envs, action_dim] f32 is borrowed for the call.  No automatic reset.
+ */
+int evm_env_step(EvmEnv *env, const float *d_action, float *d_obs, float *d_reward, uint8_t *d_done, void *stream);
+
+/*
+ * Rollout form of the reference's train loop body (src/train.cpp:61-66): do_step for running envs; an env
+ * whose previous transition was `done` starts reset() instead and spends the next 2*reset_frames calls in
+ * its settle steps, one physics step per call (d_valid = 0, outputs untouched), then emits reset()'s own
+ * step (d_valid = 1).  Every lane does exactly one physics step per call, so the wavefront never diverges
+ * on episode boundaries.  The per-env transition sequence is the reference's.
+ */
+int evm_env_step_autoreset(EvmEnv *env, const float *d_action, float *d_obs, float *d_reward, uint8_t *d_done,
+                           uint8_t *d_valid, void *stream);
+
+/* Parity metric helper: world poses [n_envs, n_bodies, 7] = (px py pz qx qy qz qw), body order of
+ * Skeleton::get_bodies (evo_motion_model/src/robot/skeleton.cpp:92-103). */
+int evm_env_get_body_poses(const EvmEnv *env, float *d_pose, void *stream);
+
+/* Test / checkpoint hooks (synchronous, host buffers).  Canonical per-env state blob, all f32:
+ *   nb x (px py pz qx qy qz qw lx ly lz ax ay az)
+ *   reset_pending, E[9]                      (row-major reset rotation, used while reset_pending)
+ *   nb x inv_inertia_world (xx xy xz yy yz zz) (used by the next step only while reset_pending)
+ *   nm x motion_state_origin[3]
+ *   nm x (last_lin[3], last_ang[3])          (proprioception history, member array order)
+ *   nm x (count, 4 x (localA[3], localB[3], dist, applied, applied_lateral))
+ *   nmuscle x target_velocity, powered, curr_step, remaining_steps
+ */
+int evm_env_state_size(const EvmEnv *env);
+int evm_env_get_state(EvmEnv *env, float *h_state /* [n_envs, state_size] */);
+int evm_env_set_state(EvmEnv *env, const float *h_state);
+/* Low-level pieces of reset()/do_step() for step-by-step parity tests (synchronous). */
+int evm_env_debug_reset_begin(EvmEnv *env, const uint8_t *d_mask);
+int evm_env_debug_physics_steps(EvmEnv *env, int n_steps, const uint8_t *d_mask);
+/* Loader cross-check: per body 19 floats [mass, inv_mass, invI xyz, friction, break_thr, M0 rows(9), t0(3)] */
+int evm_env_get_body_constants(const EvmEnv *env, float *h_out);
+/* Per-env diagnostics of the last physics step: [max |delta impulse| of the last PGS iteration, contacts] */
+int evm_env_get_diagnostics(const EvmEnv *env, float *d_out /* [n_envs, 2] */, void *stream);
+
+/* Last launch statistics: average duration in ms of the dynamics kernel launches bracketed by HIP events
+ * on the env's stream since evm_env_timing_begin(); used by bench.py for the roofline line. */
+int evm_env_timing_begin(EvmEnv *env, void *stream);
+int evm_env_timing_end(EvmEnv *env, void *stream, float *ms_total, int *n_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EVOMOTION_H */
