@@ -1,0 +1,138 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env-steps/sec on robot_walk @4096 envs/GPU (BASELINE.json).
+
+A "step" is one evm_env_step_autoreset call over the whole batch (every lane runs one stepSimulation);
+`value` counts only do_step() transitions delivered to the agent — settle steps inside reset() and the
+reset's own emitted step are NOT counted — divided by the wall time of the K timed calls (max over ranks).
+Actions are pre-generated uniform [-1,1) tensors resident in HBM (config 2: random actions, dynamics only).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALG_BYTES_PER_ENV_STEP = 8300  # SURVEY.md §8(d); breakdown in DESIGN.md
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+VALU_PEAK_TFLOPS = 157.3
+
+
+def cpu_baseline(seconds=12.0):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc
+    L = orc.load()
+    env = orc.OracleEnv(seed=1234, lib=L)
+    n_res = ctypes.c_int()
+    # calibrate, then one bounded sample
+    t = L.orc_bench_env_steps(env.h, 2000, 7, ctypes.byref(n_res))
+    steps = max(2000, int(2000 * seconds / max(t, 1e-6)))
+    t = L.orc_bench_env_steps(env.h, steps, 11, ctypes.byref(n_res))
+    return {
+        "value": steps / t, "unit": "env-steps/s", "cores": 1, "kind": "port",
+        "sample": f"{steps} do_step calls incl. {n_res.value} reset() (60 settle steps each), 1 env, 1 thread, "
+                  f"{t:.1f} s of the scalar CPU restatement (oracle/); Bullet3 itself is not installed on this box",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1024)
+    ap.add_argument("--warmup", type=int, default=256)
+    ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from evomotion_amd import VecRobotWalk
+
+    n = args.envs
+    env = VecRobotWalk(n, seed=1234 + rank * n, device=local_rank)
+    env.reset()
+    # pre-generated action bank, cycled (uniform [-1,1), the reference's RandomAgent: debug_agents.cpp:28-30)
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + rank)
+    bank = 64
+    actions = torch.rand(bank, n, env.action_dim, device=dev, generator=g) * 2.0 - 1.0
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        env.step_autoreset(actions[i % bank])
+    barrier()
+    env.clear_stats()
+    env.timing_begin()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        env.step_autoreset(actions[i % bank])
+    ms_kernel, n_launch = env.timing_end()
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    st = env.stats()
+    tt = torch.tensor([elapsed, float(st["env_steps"]), float(st["resets"])], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = tt.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        elapsed = float(tmax[0].item())
+    env_steps, resets = float(tt[1].item()), float(tt[2].item())
+    if rank == 0:
+        launch_ms = ms_kernel / max(n_launch, 1)
+        phys_per_launch = n  # every lane runs one stepSimulation per launch
+        achieved = ALG_BYTES_PER_ENV_STEP * phys_per_launch / (launch_ms * 1e-3) / 1e9
+        out = {
+            "metric": "env-steps/sec on robot_walk @4096 envs/GPU",
+            "value": env_steps / elapsed,
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "robot_walk, %d envs/GPU on %d MI355X, HIP dynamics only, uniform random actions, "
+                            "rollout form with in-band reset (configs[1])" % (n, world),
+                "envs_per_gpu": n,
+                "physics_steps_per_s": world * n * args.steps / elapsed,
+                "do_step_fraction": env_steps / (world * n * args.steps),
+                "resets_started": resets,
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "k_env_step<7>", "launch_ms": launch_ms,
+                "note": "algorithmic 8300 B per env physics step x %d envs per launch; the kernel is fp32-VALU/latency "
+                        "bound (about 50 FLOP per algorithmic byte), see DESIGN.md" % n,
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

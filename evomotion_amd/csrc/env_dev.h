@@ -26,6 +26,7 @@ struct EnvDev {
     int *mt_idx;                    // [n]
     float *scratch;                 // [sc_total][n] per-step constraint data
     float *diag;                    // [2][n]
+    int *stat;                      // [2][n]     do_step transitions emitted, resets started (rollout form)
 };
 
 hipError_t upload_skeleton(const EvmSkelC *h, hipStream_t s);

@@ -92,7 +92,7 @@ int evm_env_create(const char *skeleton_path, int n_envs, int device, uint64_t s
         {(void **) &env->d.flags, 1}, {(void **) &env->d.curr_step, 1}, {(void **) &env->d.remaining, 1},
         {(void **) &env->d.settle_left, 1}, {(void **) &env->d.E, 9}, {(void **) &env->d.iinv_stale, 6u * S.nb},
         {(void **) &env->d.mt, 624}, {(void **) &env->d.mt_idx, 1}, {(void **) &env->d.scratch, (size_t) S.sc_total},
-        {(void **) &env->d.diag, 2}};
+        {(void **) &env->d.diag, 2}, {(void **) &env->d.stat, 2}};
     size_t total = 0;
     for (auto &s : segs) total += s.count * n * 4;
     he = hipMalloc(&env->arena, total);
@@ -343,6 +343,22 @@ int evm_env_set_state(EvmEnv *env, const float *h_state) {
     HIP_TRY(ul(env->d.scratch + (size_t) S.sc_ms * n, m.scratch_ms));
     HIP_TRY(uli(env->d.mfn, m.mfn)); HIP_TRY(uli(env->d.flags, m.flags));
     HIP_TRY(uli(env->d.curr_step, m.curr)); HIP_TRY(uli(env->d.remaining, m.rem));
+    return EVM_OK;
+}
+
+int evm_env_get_stats(EvmEnv *env, long long *h_out) {
+    if (!env || !h_out) return fail(EVM_E_INVALID, "null argument");
+    std::vector<int> h(2 * (size_t) env->d.n);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(h.data(), env->d.stat, h.size() * 4, hipMemcpyDeviceToHost));
+    h_out[0] = h_out[1] = 0;
+    for (int e = 0; e < env->d.n_real; e++) { h_out[0] += h[e]; h_out[1] += h[(size_t) env->d.n + e]; }
+    return EVM_OK;
+}
+int evm_env_clear_stats(EvmEnv *env) {
+    if (!env) return fail(EVM_E_INVALID, "env is null");
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemset(env->d.stat, 0, 2 * (size_t) env->d.n * 4));
     return EVM_OK;
 }
 

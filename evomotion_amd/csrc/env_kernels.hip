@@ -1098,9 +1098,11 @@ __global__ __launch_bounds__(64) void k_env_step(EnvDev d, const float *__restri
             flags = d.flags[c.env] & ~EVM_FLAG_DONE;
             d.flags[c.env] = flags;
             d.settle_left[c.env] = 2 * c_skel.reset_frames;
+            d.stat[(size_t) d.n + c.env] += 1;
         }
         settling = d.settle_left[c.env] > 0;
     }
+    if ((MODE & 4) && !settling) d.stat[c.env] += 1;
     if ((MODE & 1) && !settling) {  // MuscleController::on_input -> Muscle::contract
         for (int mi = 0; mi < c_skel.nmus; mi++)
             GS(target, mi) = action[(size_t) c.env * c_skel.nmus + mi] * c_skel.muscle[mi].speed;

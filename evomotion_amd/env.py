@@ -140,6 +140,14 @@ class VecRobotWalk:
         check(lib.evm_env_get_diagnostics(self._h, _ptr(out), self._stream()))
         return out
 
+    def stats(self):
+        out = (ctypes.c_longlong * 2)()
+        check(lib.evm_env_get_stats(self._h, out))
+        return dict(env_steps=int(out[0]), resets=int(out[1]))
+
+    def clear_stats(self):
+        check(lib.evm_env_clear_stats(self._h))
+
     def timing_begin(self):
         check(lib.evm_env_timing_begin(self._h, self._stream()))
 

@@ -108,6 +108,11 @@ int evm_env_get_body_constants(const EvmEnv *env, float *h_out);
 /* Per-env diagnostics of the last physics step: [max |delta impulse| of the last PGS iteration, contacts] */
 int evm_env_get_diagnostics(const EvmEnv *env, float *d_out /* [n_envs, 2] */, void *stream);
 
+/* Rollout counters since the last clear, summed over envs: h_out[0] = do_step transitions emitted by
+ * evm_env_step_autoreset (the reset()'s own step and settle calls are not counted), h_out[1] = resets started. */
+int evm_env_get_stats(EvmEnv *env, long long *h_out /* [2] */);
+int evm_env_clear_stats(EvmEnv *env);
+
 /* Last launch statistics: average duration in ms of the dynamics kernel launches bracketed by HIP events
  * on the env's stream since evm_env_timing_begin(); used by bench.py for the roofline line. */
 int evm_env_timing_begin(EvmEnv *env, void *stream);
