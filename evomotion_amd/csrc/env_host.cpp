@@ -199,9 +199,32 @@ int evm_env_debug_physics_steps(EvmEnv *env, int n_steps, const uint8_t *d_mask)
     return EVM_OK;
 }
 
+static void body_constants(const EvmSkelC &S, float *out);
+
+// Host-only: run the skeleton loader (no HIP call) and report what it derived.
+int evm_skeleton_probe(const char *skeleton_path, int *counts /* nb nm nh nf nmus obs act root */, float *out) {
+    EvmEnvParams prm;
+    evm_env_default_params(&prm);
+    EvmSkelC *S = new EvmSkelC();
+    std::string err;
+    int rc = evm::load_skeleton_constants(skeleton_path, prm, *S, err);
+    if (rc != EVM_OK) { delete S; return fail(rc, err); }
+    if (counts) {
+        counts[0] = S->nb; counts[1] = S->nm; counts[2] = S->nh; counts[3] = S->nf; counts[4] = S->nmus;
+        counts[5] = S->obs_dim; counts[6] = S->act_dim; counts[7] = S->root; counts[8] = S->max_steps;
+        counts[9] = S->init_remaining;
+    }
+    if (out) body_constants(*S, out);
+    delete S;
+    return EVM_OK;
+}
+
 int evm_env_get_body_constants(const EvmEnv *env, float *out) {
     if (!env || !out) return fail(EVM_E_INVALID, "null argument");
-    const EvmSkelC &S = env->skel;
+    body_constants(env->skel, out);
+    return EVM_OK;
+}
+static void body_constants(const EvmSkelC &S, float *out) {
     int k = 0;
     for (int b = 0; b < S.nb; b++) {
         const EvmBodyC &B = S.body[b];
@@ -212,7 +235,6 @@ int evm_env_get_body_constants(const EvmEnv *env, float *out) {
         for (int i = 0; i < 9; i++) out[k++] = B.m0[i];
         for (int i = 0; i < 3; i++) out[k++] = B.t0[i];
     }
-    return EVM_OK;
 }
 
 int evm_env_get_diagnostics(const EvmEnv *env, float *d_out, void *stream) {

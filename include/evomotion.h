@@ -103,6 +103,10 @@ int evm_env_set_state(EvmEnv *env, const float *h_state);
 /* Low-level pieces of reset()/do_step() for step-by-step parity tests (synchronous). */
 int evm_env_debug_reset_begin(EvmEnv *env, const uint8_t *d_mask);
 int evm_env_debug_physics_steps(EvmEnv *env, int n_steps, const uint8_t *d_mask);
+/* Host-only (no HIP call): parse a skeleton fixture and return what the loader derived.
+ * counts[10] = nb nm nhinge nfixed nmuscle state_dim action_dim root max_steps initial_remaining;
+ * h_out (may be NULL) = per body the 19 floats of evm_env_get_body_constants; capacity 64 bodies. */
+int evm_skeleton_probe(const char *skeleton_path, int *counts, float *h_out);
 /* Loader cross-check: per body 19 floats [mass, inv_mass, invI xyz, friction, break_thr, M0 rows(9), t0(3)] */
 int evm_env_get_body_constants(const EvmEnv *env, float *h_out);
 /* Per-env diagnostics of the last physics step: [max |delta impulse| of the last PGS iteration, contacts] */

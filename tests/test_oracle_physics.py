@@ -1,0 +1,114 @@
+"""Analytic invariants of the CPU oracle's rigid-body step: the checks that can be derived
+without Bullet.  They pin integration order, gravity, contact margins, constraint satisfaction and motors."""
+import numpy as np
+import pytest
+
+import blob
+import orc
+from conftest import write_skeleton
+
+DT = np.float32(1.0) / np.float32(60.0)
+
+
+def one_cube(tmp_path, scale=(0.2, 0.2, 0.2), mass=1.0):
+    return write_skeleton(tmp_path / "cube.skel", [dict(name="body", mass=mass, scale=scale)])
+
+
+def test_free_fall_semi_implicit_euler(orc_lib, tmp_path):
+    e = orc.OracleEnv(seed=1, skeleton=one_cube(tmp_path), lib=orc_lib)
+    e.reset_begin()
+    p0 = e.poses()[0, :3].copy()
+    assert np.allclose(p0, [1.0, 0.25, 2.0], atol=1e-6)  # root_pos, robot_walk.cpp:78
+    g_dt = np.float32(-9.8) * DT
+    y, v = np.float64(p0[1]), 0.0
+    for k in range(1, 16):
+        e.physics_step()
+        st = blob.body_view(e.get_state()[None], 1)
+        v += float(g_dt)          # v += g dt first ...
+        y += v * float(DT)        # ... then x += v dt with the NEW velocity
+        assert abs(st["lin"][0, 0, 1] - v) < 2e-6
+        assert abs(st["pos"][0, 0, 1] - y) < 2e-6
+        assert abs(st["lin"][0, 0, 0]) < 1e-7 and abs(st["lin"][0, 0, 2]) < 1e-7
+
+
+def test_cube_rests_on_margins(orc_lib, tmp_path):
+    h = 0.2
+    e = orc.OracleEnv(seed=2, skeleton=one_cube(tmp_path, (h, h, h)), lib=orc_lib)
+    e.reset_begin()
+    e.physics_step(600)
+    st = blob.body_view(e.get_state()[None], 1)
+    # floor top face y = -1; both hulls carry a 0.04 collision margin
+    rest = -1.0 + 0.04 + 0.04 + h
+    assert abs(st["pos"][0, 0, 1] - rest) < 6e-3
+    assert np.abs(st["lin"][0, 0]).max() < 2e-2 and np.abs(st["ang"][0, 0]).max() < 5e-2
+    assert e.counters()["contacts"] >= 1
+
+
+def test_motion_state_lags_one_step(orc_lib, tmp_path):
+    e = orc.OracleEnv(seed=3, skeleton=one_cube(tmp_path), lib=orc_lib)
+    e.reset_begin()
+    prev = None
+    for _ in range(5):
+        e.physics_step()
+        s = e.get_state()
+        f = blob.fields(1, 1, 0)
+        ms = s[f["ms"]]
+        pos = blob.body_view(s[None], 1)["pos"][0, 0]
+        if prev is not None:
+            np.testing.assert_allclose(ms, prev, atol=2e-6)
+        prev = pos.copy()
+
+
+def _anchor_errors(e):
+    """World distance between the two anchor points of every p2p joint of the spider."""
+    import re
+    skel = open(orc.SKEL).read().split("\n")
+    names = [l.split()[1] for l in skel if l.startswith("member ")]
+    mus = [l.split() for l in skel if l.startswith("muscle ")]
+    poses = e.poses()
+
+    def rot(q):
+        x, y, z, w = q
+        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                         [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                         [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+    errs = []
+    for k, m in enumerate(mus):
+        a, b = names.index(m[2]), names.index(m[3])
+        pa = np.array([float.fromhex(v) for v in m[8:11]])
+        pb = np.array([float.fromhex(v) for v in m[11:14]])
+        for member, piv, sphere in ((a, pa, 17 + 2 * k), (b, pb, 18 + 2 * k)):
+            w = poses[member, :3] + rot(poses[member, 3:]) @ piv
+            errs.append(np.linalg.norm(w - poses[sphere, :3]))
+    return np.array(errs)
+
+
+def test_joint_anchors_stay_together(orc_lib):
+    e = orc.OracleEnv(seed=1234, lib=orc_lib)
+    e.reset()
+    # Most anchors coincide; a muscle whose slider starts below its lower limit (signed position along the
+    # free-spinning attach sphere's x axis) keeps fighting its two p2p joints, so the
+    # worst anchor is only bounded loosely.
+    err = _anchor_errors(e)
+    assert np.median(err) < 2e-3 and err.max() < 0.2
+    rng = np.random.default_rng(0)
+    for _ in range(50):
+        e.do_step(rng.uniform(-1, 1, 12).astype(np.float32))
+    err = _anchor_errors(e)
+    assert np.median(err) < 5e-3 and err.max() < 0.3
+    assert np.abs(e.poses()[:, :3]).max() < 10.0
+
+
+def test_muscle_motor_direction_and_saturation(orc_lib):
+    lens = {}
+    for sign in (-1.0, 1.0):
+        e = orc.OracleEnv(seed=11, lib=orc_lib)
+        e.reset()
+        a = np.full(12, sign, np.float32)
+        for _ in range(15):
+            obs, _, _ = e.do_step(a)
+        lens[sign] = obs[323::4].copy()  # slider linear positions
+        imp = obs[324::4]
+        # applied impulse is either the saturated motor row (64 N / 60 Hz) or the ~0 angular-limit row
+        assert np.all((np.abs(np.abs(imp) - 64.0 / 60.0) < 1e-3) | (np.abs(imp) < 1.07))
+    assert (lens[1.0] > lens[-1.0]).sum() >= 10  # positive action extends the muscle (btSliderConstraint sign)
