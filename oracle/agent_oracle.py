@@ -1,0 +1,141 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.  numpy fp32 restatement of the agent half of the path:
+
+  ActorModule / CriticModule forward    evo_motion_networks/src/networks/actor.cpp:9-48, critic.cpp:8-35
+  truncated normal sample/log-pdf/entropy evo_motion_networks/src/functions.cpp:53-68,94-128
+  GAE / advantage normalisation / returns evo_motion_networks/src/agents/ppo_gae.cpp:127-151
+
+Pinned against tests/golden/agent_golden.txt, which is produced by the reference's own compiled code
+(oracle/ref_build.sh + oracle/ref_golden.cpp) — see tests/test_agent_oracle.py.
+"""
+import math
+
+import numpy as np
+from scipy import special
+
+F = np.float32
+SIGMA_MIN, SIGMA_MAX, AB_BOUND = F(1e-6), F(1e6), F(5.0)  # functions.cpp:9-11
+
+
+# ---- deterministic parameter pattern shared with oracle/ref_golden.cpp ------------------------------
+def pat(tensor, k, scale):
+    k = np.asarray(k, dtype=np.uint64)
+    h = (np.uint64(tensor) * np.uint64(2654435761) + k * np.uint64(40503) + np.uint64(12345)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(13)
+    h = (h * np.uint64(0x5BD1E995)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(15)
+    v = (h & np.uint64(0xFFFFFF)).astype(np.float32) / F(16777216.0) - F(0.5)
+    return (v * F(scale)).astype(np.float32)
+
+
+ACTOR_SHAPES = [("head.0.weight", (256, 371)), ("head.0.bias", (256,)), ("head.2.weight", (256,)), ("head.2.bias", (256,)),
+                ("head.3.weight", (256, 256)), ("head.3.bias", (256,)), ("head.5.weight", (256,)), ("head.5.bias", (256,)),
+                ("mu.0.weight", (12, 256)), ("mu.0.bias", (12,)), ("sigma.0.weight", (12, 256)), ("sigma.0.bias", (12,))]
+CRITIC_SHAPES = [("critic.0.weight", (256, 371)), ("critic.0.bias", (256,)), ("critic.2.weight", (256,)), ("critic.2.bias", (256,)),
+                 ("critic.3.weight", (256, 256)), ("critic.3.bias", (256,)), ("critic.5.weight", (256,)), ("critic.5.bias", (256,)),
+                 ("critic.6.weight", (1, 256)), ("critic.6.bias", (1,))]
+
+
+def pattern_params(shapes, base):
+    out = {}
+    for t, (name, shape) in enumerate(shapes):
+        n = int(np.prod(shape))
+        if len(shape) == 2:
+            scale, off = F(2.0) / np.sqrt(F(shape[1])), F(0)
+        elif ".2." in name or ".5." in name:
+            scale, off = F(0.2), F(1.0) if "weight" in name else F(0)
+        else:
+            scale, off = F(0.2), F(0)
+        out[name] = (off + pat(base + t, np.arange(n), scale)).astype(np.float32).reshape(shape)
+    return out
+
+
+# ---- modules ------------------------------------------------------------------------------------------
+def mish(x):
+    x = x.astype(np.float32)
+    with np.errstate(over="ignore"):
+        return (x * np.tanh(np.log1p(np.exp(x)))).astype(np.float32)
+
+
+def softplus(x):  # torch::nn::Softplus(beta=1, threshold=20)
+    x = x.astype(np.float32)
+    with np.errstate(over="ignore"):
+        return np.where(x > F(20), x, np.log1p(np.exp(x))).astype(np.float32)
+
+
+def layer_norm(x, w, b, eps=F(1e-5)):
+    m = x.mean(-1, keepdims=True, dtype=np.float32)
+    v = ((x - m) ** 2).mean(-1, keepdims=True, dtype=np.float32)
+    return ((x - m) / np.sqrt(v + eps) * w + b).astype(np.float32)
+
+
+def trunk(x, p, pre):
+    h = x.astype(np.float32) @ p[pre + ".0.weight"].T + p[pre + ".0.bias"]
+    h = layer_norm(mish(h), p[pre + ".2.weight"], p[pre + ".2.bias"])
+    h = h @ p[pre + ".3.weight"].T + p[pre + ".3.bias"]
+    return layer_norm(mish(h), p[pre + ".5.weight"], p[pre + ".5.bias"])
+
+
+def actor_forward(x, p):
+    h = trunk(x, p, "head")
+    mu = np.tanh(h @ p["mu.0.weight"].T + p["mu.0.bias"]).astype(np.float32)
+    sigma = softplus(h @ p["sigma.0.weight"].T + p["sigma.0.bias"])
+    return mu, sigma
+
+
+def critic_forward(x, p):
+    h = trunk(x, p, "critic")
+    return (h @ p["critic.6.weight"].T + p["critic.6.bias"]).astype(np.float32)
+
+
+# ---- truncated normal ---------------------------------------------------------------------------------
+def _theta(x):
+    return (F(0.5) * (F(1.0) + special.erf((x / F(math.sqrt(2.0))).astype(np.float32)))).astype(np.float32)
+
+
+def _phi(z):
+    return (np.exp(F(-0.5) * z * z) / F(math.sqrt(2.0 * math.pi))).astype(np.float32)
+
+
+def _ab(mu, sigma, lo, hi):
+    s = np.clip(sigma.astype(np.float32), SIGMA_MIN, SIGMA_MAX)
+    a = np.clip((F(lo) - mu) / s, -AB_BOUND, AB_BOUND).astype(np.float32)
+    b = np.clip((F(hi) - mu) / s, -AB_BOUND, AB_BOUND).astype(np.float32)
+    return s, a, b
+
+
+def tn_log_pdf(x, mu, sigma, lo=-1.0, hi=1.0):
+    s, a, b = _ab(mu, sigma, lo, hi)
+    z = _theta(b) - _theta(a)
+    with np.errstate(divide="ignore"):
+        return (F(-0.5 * math.log(2.0 * math.pi)) - np.log(s) - F(0.5) * ((x - mu) / s) ** 2 - np.log(z)).astype(np.float32)
+
+
+def tn_entropy(mu, sigma, lo=-1.0, hi=1.0):
+    s, a, b = _ab(mu, sigma, lo, hi)
+    z = _theta(b) - _theta(a)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return (np.log(F(math.sqrt(2.0 * math.pi * math.e)) * s * z) + F(0.5) * (a * _phi(a) - b * _phi(b)) / z).astype(np.float32)
+
+
+def tn_sample(mu, sigma, u, lo=-1.0, hi=1.0):
+    s, a, b = _ab(mu, sigma, lo, hi)
+    cdf = np.clip(_theta(a) + u.astype(np.float32) * (_theta(b) - _theta(a)), F(0), F(1)).astype(np.float32)
+    inv = (F(math.sqrt(2.0)) * special.erfinv((F(2.0) * cdf - F(1.0)).astype(np.float32))).astype(np.float32)
+    return np.clip(inv * s + mu, F(lo), F(hi)).astype(np.float32)
+
+
+# ---- GAE (ppo_gae.cpp:127-151) ------------------------------------------------------------------------
+def gae(rewards, done, curr_values, next_values, gamma, lam):
+    """[B,T,1] padded tensors (done padded with 1) -> mask, normalised advantages, returns."""
+    r, d, cv, nv = [np.asarray(t, np.float32) for t in (rewards, done, curr_values, next_values)]
+    B, T = r.shape[:2]
+    mask = np.concatenate([np.ones((B, 1, 1), np.float32), (F(1) - d)[:, : T - 1]], 1) == 1.0
+    deltas = r + (F(1) - d) * F(gamma) * nv - cv
+    adv = np.zeros_like(r)
+    g = np.zeros((B, 1), np.float32)
+    for t in range(T - 1, -1, -1):
+        g = deltas[:, t] * mask[:, t] + F(gamma) * F(lam) * (F(1) - d[:, t]) * g
+        adv[:, t] = g
+    sel = adv[mask]
+    adv = ((adv - sel.mean(dtype=np.float32)) / (sel.std(ddof=1, dtype=np.float32) + F(1e-8))).astype(np.float32)
+    return mask, adv, (adv + cv).astype(np.float32)
