@@ -5,3 +5,5 @@ Environment / Agent interfaces in env.py / agent.py.  The CPU oracle under /orac
 and is never imported from here."""
 from ._lib import DEFAULT_SKELETON, EvmError, LIB_PATH  # noqa: F401
 from .env import RolloutStep, Step, VecRobotWalk  # noqa: F401
+from .agent import (ActorModule, CriticModule, FusedActorCritic, RandomAgent, VecPpoGaeAgent,  # noqa: F401,E402
+                    ppo_train, gae_advantages, truncated_normal_log_pdf, truncated_normal_entropy, truncated_normal_sample)

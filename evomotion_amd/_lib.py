@@ -56,6 +56,12 @@ def _load():
     lib.evm_skeleton_probe.argtypes = [cp, ip, fp]
     lib.evm_env_get_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_longlong)]
     lib.evm_env_clear_stats.argtypes = [vp]
+    lib.evm_policy_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(vp)]
+    lib.evm_policy_destroy.argtypes = [vp]
+    lib.evm_policy_destroy.restype = None
+    lib.evm_policy_param_counts.argtypes = [vp, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]
+    lib.evm_policy_set_weights.argtypes = [vp, fp, ctypes.c_size_t, fp, ctypes.c_size_t]
+    lib.evm_policy_forward.argtypes = [vp, ctypes.c_int, vp, vp, ctypes.c_uint64, vp, vp, vp, vp, vp, vp]
     lib.evm_env_timing_begin.argtypes = [vp, vp]
     lib.evm_env_timing_end.argtypes = [vp, vp, fp, ip]
     return lib

@@ -1,0 +1,333 @@
+"""Agent side of the rollout path — mirrors of the reference's evo_motion_networks pieces that the PPO loop touches.
+
+  ActorModule / CriticModule / init_weights   evo_motion_networks/src/networks/actor.cpp:9-48, critic.cpp:8-35, init.cpp:7-21
+  truncated normal log-pdf / entropy          evo_motion_networks/src/functions.cpp:53-68,113-128
+  PpoGaeAgent::train                          evo_motion_networks/src/agents/ppo_gae.cpp:117-190
+  PpoGaeAgent::act (batched, fused HIP)       evo_motion_networks/src/agents/ppo_gae.cpp:29-45  -> evm_policy_forward
+  RandomAgent::act                            evo_motion_networks/src/agents/debug_agents.cpp:28-30
+
+The rollout forward is the fused MFMA kernel behind the C ABI (`FusedActorCritic`); the PPO update runs on
+PyTorch-ROCm autograd over the same parameters, with an RCCL exchange only here.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+from torch import nn
+
+from ._lib import check, lib
+
+SIGMA_MIN, SIGMA_MAX, ALPHA_BETA_BOUND = 1e-6, 1e6, 5.0  # functions.cpp:9-11
+
+
+def init_weights(m):
+    """init.cpp:7-21: xavier_normal(gain 0.1), bias N(0, 0.1), LayerNorm ones/zeros."""
+    if isinstance(m, nn.Linear):
+        nn.init.xavier_normal_(m.weight, 1e-1)
+        if m.bias is not None:
+            nn.init.normal_(m.bias, 0.0, 1e-1)
+    elif isinstance(m, nn.LayerNorm) and m.elementwise_affine:
+        nn.init.ones_(m.weight)
+        nn.init.zeros_(m.bias)
+
+
+def _trunk(s, h):
+    return nn.Sequential(nn.Linear(s, h), nn.Mish(), nn.LayerNorm(h, eps=1e-5), nn.Linear(h, h), nn.Mish(), nn.LayerNorm(h, eps=1e-5))
+
+
+class ActorModule(nn.Module):
+    """Same parameter names as the reference's ActorModule (head.0.weight ... mu.0.weight, sigma.0.weight)."""
+
+    def __init__(self, state_space, action_space, hidden_size):
+        super().__init__()
+        self.head = _trunk(state_space[0], hidden_size)
+        self.mu = nn.Sequential(nn.Linear(hidden_size, action_space[0]), nn.Tanh())
+        self.sigma = nn.Sequential(nn.Linear(hidden_size, action_space[0]), nn.Softplus())
+        self.apply(init_weights)
+
+    def forward(self, state):
+        h = self.head(state)
+        return self.mu(h), self.sigma(h)
+
+
+class CriticModule(nn.Module):
+    def __init__(self, state_space, hidden_size):
+        super().__init__()
+        t = _trunk(state_space[0], hidden_size)
+        self.critic = nn.Sequential(*list(t.children()), nn.Linear(hidden_size, 1))
+        self.apply(init_weights)
+
+    def forward(self, state):
+        return self.critic(state)
+
+
+def count_parameters(*modules):
+    return sum(p.numel() for m in modules for p in m.parameters())
+
+
+def flat_parameters(module):
+    """Flat fp32 vector in named_parameters() order — the layout evm_policy_set_weights expects."""
+    return torch.cat([p.detach().reshape(-1).float().cpu() for _, p in module.named_parameters()]).contiguous()
+
+
+# ---- truncated normal (functions.cpp) --------------------------------------------------------------------
+def _phi(z):
+    return torch.exp(-0.5 * torch.pow(z, 2.0)) / math.sqrt(2.0 * math.pi)
+
+
+def _theta(x):
+    return 0.5 * (1.0 + torch.erf(x / math.sqrt(2.0)))
+
+
+def _alpha_beta(mu, sigma, lo, hi):
+    s = torch.clamp(sigma, SIGMA_MIN, SIGMA_MAX)
+    a = torch.clamp((lo - mu) / s, -ALPHA_BETA_BOUND, ALPHA_BETA_BOUND)
+    b = torch.clamp((hi - mu) / s, -ALPHA_BETA_BOUND, ALPHA_BETA_BOUND)
+    return s, a, b
+
+
+def truncated_normal_log_pdf(x, mu, sigma, lo=-1.0, hi=1.0):
+    s, a, b = _alpha_beta(mu, sigma, lo, hi)
+    z = _theta(b) - _theta(a)
+    return -0.5 * math.log(2.0 * math.pi) - torch.log(s) - 0.5 * torch.pow((x - mu) / s, 2.0) - torch.log(z)
+
+
+def truncated_normal_entropy(mu, sigma, lo=-1.0, hi=1.0):
+    s, a, b = _alpha_beta(mu, sigma, lo, hi)
+    z = _theta(b) - _theta(a)
+    return torch.log(math.sqrt(2.0 * math.pi * math.e) * s * z) + 0.5 * (a * _phi(a) - b * _phi(b)) / z
+
+
+def truncated_normal_sample(mu, sigma, lo=-1.0, hi=1.0, u=None):
+    s, a, b = _alpha_beta(mu, sigma, lo, hi)
+    if u is None:
+        u = torch.rand(mu.shape, device=mu.device)
+    cdf = torch.clamp(_theta(a) + u * (_theta(b) - _theta(a)), 0.0, 1.0)
+    return torch.clamp(math.sqrt(2.0) * torch.erfinv(2.0 * cdf - 1.0) * s + mu, lo, hi)
+
+
+# ---- PPO / GAE update (ppo_gae.cpp:117-190) -----------------------------------------------------------------
+def _dist_ready():
+    return torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+
+
+def masked_mean_std(x, mask):
+    """mean and unbiased std of x[mask] over ALL ranks (one all_gather of three numbers per rank; Chan's merge)."""
+    sel = torch.masked_select(x, mask)
+    if not _dist_ready():  # single process: literally the reference's two calls (ppo_gae.cpp:148-149)
+        return sel.mean(), sel.std(), torch.tensor(float(sel.numel()), device=x.device, dtype=torch.float64)
+    n = torch.tensor(float(sel.numel()), device=x.device, dtype=torch.float64)
+    mean = sel.double().mean() if sel.numel() else torch.zeros((), device=x.device, dtype=torch.float64)
+    m2 = ((sel.double() - mean) ** 2).sum() if sel.numel() else torch.zeros((), device=x.device, dtype=torch.float64)
+    if _dist_ready():
+        trip = torch.stack([n, mean, m2])
+        allt = [torch.zeros_like(trip) for _ in range(torch.distributed.get_world_size())]
+        torch.distributed.all_gather(allt, trip)
+        n, mean, m2 = allt[0]
+        for t in allt[1:]:
+            nb, mb, m2b = t
+            tot = n + nb
+            if float(tot) == 0:
+                continue
+            d = mb - mean
+            mean = mean + d * nb / tot
+            m2 = m2 + m2b + d * d * n * nb / tot
+            n = tot
+    std = torch.sqrt(m2 / torch.clamp(n - 1, min=1.0))
+    return mean.to(x.dtype), std.to(x.dtype), n
+
+
+def gae_advantages(rewards, done, curr_values, next_values, gamma, lam, mask=None):
+    """[B,T,1] tensors -> (mask, normalised advantages, returns).
+
+    mask=None reproduces the reference exactly: trajectories are padded with done = 1 and the mask is the
+    shifted done flag (ppo_gae.cpp:127-132).  The vectorised rollout passes an explicit transition mask instead
+    (rows contain settle steps in the middle, not only trailing padding); a masked step contributes nothing and
+    stops the backward recursion, which is what the shifted mask does for trailing padding."""
+    B, T = rewards.shape[:2]
+    explicit = mask is not None
+    if not explicit:
+        mask = torch.eq(torch.cat([torch.ones(B, 1, 1, device=rewards.device), (1.0 - done)[:, : T - 1]], 1), 1.0)
+    deltas = rewards + (1.0 - done) * gamma * next_values - curr_values
+    g = torch.zeros(B, 1, device=rewards.device)
+    adv = []
+    for t in range(T - 1, -1, -1):
+        g = deltas[:, t] * mask[:, t] + gamma * lam * (1.0 - done[:, t]) * g
+        if explicit:
+            g = g * mask[:, t]
+        adv.append(g)
+    adv = torch.stack(adv, 1).flip([1])
+    mean, std, _ = masked_mean_std(adv, mask)
+    adv = (adv - mean) / (std + 1e-8)
+    return mask, adv, adv + curr_values  # returns = NORMALISED advantages + V
+
+
+def _all_reduce_grads(params):
+    if not _dist_ready():
+        return
+    flat = torch.cat([p.grad.reshape(-1) for p in params])
+    torch.distributed.all_reduce(flat)  # losses are normalised by the global count, so SUM is the global gradient
+    o = 0
+    for p in params:
+        n = p.numel()
+        p.grad.copy_(flat[o:o + n].view_as(p))
+        o += n
+
+
+def ppo_train(actor, critic, actor_opt, critic_opt, states, actions, rewards, done, log_prob, curr_values, next_values,
+              gamma, lam, epsilon, entropy_factor, critic_loss_factor, epoch, clip_grad_norm, mask=None):
+    """One PpoGaeAgent::train() call on padded [B,T,*] tensors; returns the last (actor_loss, critic_loss)."""
+    actor.train()
+    critic.train()
+    mask, adv, returns = gae_advantages(rewards, done, curr_values, next_values, gamma, lam, mask)
+    adv, returns = adv.detach(), returns.detach()
+    n_local = mask.sum()
+    n_glob = n_local.double().clone()
+    if _dist_ready():
+        torch.distributed.all_reduce(n_glob)
+    scale = (n_local.double() / n_glob).float() if _dist_ready() else None
+    a_loss = c_loss = None
+    for _ in range(epoch):
+        mu, sigma = actor(states)
+        lp = truncated_normal_log_pdf(actions, mu, sigma)
+        ent = truncated_normal_entropy(mu, sigma)
+        value = critic(states)
+        ratios = torch.exp(lp - log_prob)
+        s1 = ratios * adv
+        s2 = torch.clamp(ratios, 1.0 - epsilon, 1.0 + epsilon) * adv
+        a_loss = -torch.mean(torch.masked_select(torch.min(s1, s2) + entropy_factor * ent, mask.expand_as(ent)))
+        actor_opt.zero_grad()
+        (a_loss * scale if scale is not None else a_loss).backward()
+        _all_reduce_grads(list(actor.parameters()))
+        nn.utils.clip_grad_norm_(actor.parameters(), clip_grad_norm)
+        actor_opt.step()
+        c_loss = critic_loss_factor * torch.mean(torch.masked_select(torch.pow(value - returns, 2.0), mask))
+        critic_opt.zero_grad()
+        (c_loss * scale if scale is not None else c_loss).backward()
+        _all_reduce_grads(list(critic.parameters()))
+        nn.utils.clip_grad_norm_(critic.parameters(), clip_grad_norm)
+        critic_opt.step()
+    return float(a_loss.detach()), float(c_loss.detach())
+
+
+# ---- fused rollout forward (HIP) ----------------------------------------------------------------------------
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class FusedActorCritic:
+    """Batched PpoGaeAgent::act on the GPU: actor + critic forward, truncated-normal sample and log-pdf."""
+
+    def __init__(self, state_dim, action_dim, hidden_size=256, device=0):
+        self.device = torch.device("cuda", device)
+        self.S, self.A = state_dim, action_dim
+        self._h = ctypes.c_void_p()
+        torch.cuda.set_device(self.device)
+        check(lib.evm_policy_create(state_dim, action_dim, hidden_size, device, ctypes.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib.evm_policy_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_weights(self, actor_flat, critic_flat):
+        a = np.ascontiguousarray(actor_flat, np.float32)
+        c = np.ascontiguousarray(critic_flat, np.float32)
+        fp = ctypes.POINTER(ctypes.c_float)
+        check(lib.evm_policy_set_weights(self._h, a.ctypes.data_as(fp), a.size, c.ctypes.data_as(fp), c.size))
+
+    def load_modules(self, actor, critic):
+        self.set_weights(flat_parameters(actor).numpy(), flat_parameters(critic).numpy())
+
+    def forward(self, obs, uniform=None, seed=0, want_dist=False):
+        n = obs.shape[0]
+        assert obs.is_cuda and obs.dtype == torch.float32 and obs.is_contiguous() and obs.shape[1] == self.S
+        action = torch.empty(n, self.A, device=self.device)
+        logp = torch.empty(n, self.A, device=self.device)
+        value = torch.empty(n, device=self.device)
+        mu = torch.empty(n, self.A, device=self.device) if want_dist else None
+        sigma = torch.empty(n, self.A, device=self.device) if want_dist else None
+        stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        check(lib.evm_policy_forward(self._h, n, _ptr(obs), _ptr(uniform), seed, _ptr(action), _ptr(logp), _ptr(value),
+                                     _ptr(mu), _ptr(sigma), stream))
+        return (action, logp, value, mu, sigma) if want_dist else (action, logp, value)
+
+
+class RandomAgent:
+    """debug_agents.cpp:28-30: 2 * U[0,1)^A - 1, batched."""
+
+    def __init__(self, action_space, device):
+        self.A, self.device = action_space[0], device
+
+    def act(self, state, reward=None):
+        return 2.0 * torch.rand(state.shape[0], self.A, device=self.device) - 1.0
+
+
+class VecPpoGaeAgent:
+    """Vectorised PpoGaeAgent: fixed-horizon rollouts of N envs instead of a replay buffer of whole episodes.
+
+    Hyper-parameter names follow agent_factory.cpp:137-146.  Transitions emitted while an env is inside reset()
+    (valid == 0) are masked out exactly like the reference's padding (done = 1, shifted mask)."""
+
+    def __init__(self, seed, state_space, action_space, hidden_size=256, gamma=0.99, lam=0.95, epsilon=0.2,
+                 entropy_factor=0.01, critic_loss_factor=0.5, epoch=8, learning_rate=1e-3, clip_grad_norm=0.5,
+                 device=0, horizon=32):
+        torch.manual_seed(seed)
+        self.device = torch.device("cuda", device)
+        self.actor = ActorModule(state_space, action_space, hidden_size).to(self.device)
+        self.critic = CriticModule(state_space, hidden_size).to(self.device)
+        self.actor_opt = torch.optim.Adam(self.actor.parameters(), lr=learning_rate)
+        self.critic_opt = torch.optim.Adam(self.critic.parameters(), lr=learning_rate)
+        self.hp = dict(gamma=gamma, lam=lam, epsilon=epsilon, entropy_factor=entropy_factor,
+                       critic_loss_factor=critic_loss_factor, epoch=epoch, clip_grad_norm=clip_grad_norm)
+        self.fused = FusedActorCritic(state_space[0], action_space[0], hidden_size, device)
+        self.fused.load_modules(self.actor, self.critic)
+        self.horizon = horizon
+        self.seed = seed
+        self._buf = None
+
+    def count_parameters(self):
+        return count_parameters(self.actor, self.critic)
+
+    def rollout(self, env, last=None):
+        """`horizon` calls of policy forward + evm_env_step_autoreset; everything stays on the device."""
+        T, N, S, A = self.horizon, env.n_envs, env.state_dim, env.action_dim
+        if self._buf is None:
+            z = lambda *s, **k: torch.zeros(*s, device=self.device, **k)
+            self._buf = dict(states=z(T, N, S), actions=z(T, N, A), logp=z(T, N, A), values=z(T, N), rewards=z(T, N),
+                             done=z(T, N), valid=z(T, N), next_values=z(T, N))
+        b = self._buf
+        obs = env.obs
+        for t in range(T):
+            b["states"][t].copy_(obs)
+            action, logp, value = self.fused.forward(obs, seed=self.seed)
+            b["actions"][t], b["logp"][t], b["values"][t] = action, logp, value
+            st = env.step_autoreset(action)
+            b["rewards"][t].copy_(st.reward)
+            b["done"][t].copy_(st.done.float())
+            b["valid"][t].copy_(st.valid.float())
+            obs = st.state
+        _, _, last_v = self.fused.forward(obs, seed=self.seed)
+        b["next_values"][:-1] = b["values"][1:]
+        b["next_values"][-1] = last_v
+        return b
+
+    def update(self):
+        b = self._buf
+        # [T,N] -> the reference's [B,T,1] layout; only do_step transitions (valid == 1) are trained on: settle
+        # calls (0) and reset()'s own emission (2) are not transitions
+        tr = lambda x: x.transpose(0, 1).contiguous()
+        mask = tr(b["valid"]).unsqueeze(-1) == 1.0
+        done = torch.where(mask, tr(b["done"]).unsqueeze(-1), torch.ones((), device=self.device))
+        out = ppo_train(self.actor, self.critic, self.actor_opt, self.critic_opt, tr(b["states"]), tr(b["actions"]),
+                        tr(b["rewards"]).unsqueeze(-1), done, tr(b["logp"]), tr(b["values"]).unsqueeze(-1),
+                        tr(b["next_values"]).unsqueeze(-1), mask=mask, **self.hp)
+        self.fused.load_modules(self.actor, self.critic)
+        return out

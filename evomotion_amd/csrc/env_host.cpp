@@ -17,6 +17,11 @@ int fail(int code, const std::string &msg) {
     g_err = msg;
     return code;
 }
+}  // namespace
+namespace evm {
+void set_last_error(const std::string &m) { g_err = m; }
+}
+namespace {
 #define HIP_TRY(expr)                                                                              \
     do {                                                                                           \
         hipError_t e_ = (expr);                                                                    \

@@ -1117,7 +1117,7 @@ __global__ __launch_bounds__(64) void k_env_step(EnvDev d, const float *__restri
             d.settle_left[c.env] = left;
             do_observe = left == 0;
         }
-        valid[c.env] = do_observe ? 1 : 0;
+        valid[c.env] = do_observe ? (settling ? 2 : 1) : 0;  // 1 = do_step transition, 2 = reset()'s own step
     }
     if (do_observe) {
         observe(c, obs, reward, done);

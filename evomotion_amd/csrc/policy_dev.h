@@ -1,0 +1,26 @@
+// Device-side view of the actor / critic weights used by policy_kernels.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace evm {
+
+struct NetDev {
+    const float *w1t;  // [K1pad][256]  Linear(S, 256) weight, transposed, zero padded to a multiple of 32 rows
+    const float *b1, *g1, *be1;  // bias, LayerNorm weight / bias
+    const float *w2t;  // [256][256]
+    const float *b2, *g2, *be2;
+    const float *wh;   // heads, row major [out][256]: actor = mu rows then sigma rows (2A), critic = 1 row
+    const float *bh;
+};
+struct PolicyDev {
+    int S, A, K1pad;
+    NetDev actor, critic;
+};
+
+size_t policy_lds_bytes();
+hipError_t launch_policy_forward(const PolicyDev &p, int n, const float *obs, const float *uniform, uint64_t seed,
+                                 uint64_t counter, float *action, float *logp, float *value, float *mu, float *sigma,
+                                 hipStream_t s);
+
+}  // namespace evm

@@ -1,0 +1,126 @@
+// C ABI for the fused actor-critic forward (include/evomotion.h, evm_policy_*).
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/evomotion.h"
+#include "policy_dev.h"
+
+namespace {
+thread_local std::string g_perr;
+}
+extern "C" const char *evm_last_error(void);
+namespace evm { void set_last_error(const std::string &m); }
+
+struct EvmPolicy {
+    int S, A, H, K1pad, device;
+    float *arena;
+    size_t arena_floats;
+    evm::PolicyDev dev;
+    uint64_t counter;
+};
+
+static int pfail(int code, const std::string &m) { evm::set_last_error(m); return code; }
+
+extern "C" {
+
+int evm_policy_create(int state_dim, int action_dim, int hidden_size, int device, EvmPolicy **out) {
+    if (!out) return pfail(EVM_E_INVALID, "out is null");
+    *out = nullptr;
+    if (hidden_size != 256) return pfail(EVM_E_UNSUPPORTED, "the fused forward is built for hidden_size = 256");
+    if (state_dim < 1 || action_dim < 1 || 2 * action_dim > 32) return pfail(EVM_E_INVALID, "unsupported state/action size");
+    if (hipSetDevice(device) != hipSuccess) return pfail(EVM_E_HIP, "hipSetDevice failed");
+    EvmPolicy *p = new EvmPolicy();
+    p->S = state_dim; p->A = action_dim; p->H = hidden_size; p->device = device; p->counter = 0;
+    p->K1pad = (state_dim + 31) / 32 * 32;
+    const size_t per_net = (size_t) p->K1pad * 256 + 3 * 256 + 256 * 256 + 3 * 256;
+    p->arena_floats = 2 * per_net + ((size_t) 2 * action_dim * 256 + 2 * action_dim) + (256 + 1);
+    if (hipMalloc((void **) &p->arena, p->arena_floats * 4) != hipSuccess) { delete p; return pfail(EVM_E_HIP, "hipMalloc failed"); }
+    hipMemset(p->arena, 0, p->arena_floats * 4);
+    float *b = p->arena;
+    auto carve = [&](evm::NetDev &n, size_t head_w, size_t head_b) {
+        n.w1t = b; b += (size_t) p->K1pad * 256;
+        n.b1 = b; b += 256; n.g1 = b; b += 256; n.be1 = b; b += 256;
+        n.w2t = b; b += 256 * 256;
+        n.b2 = b; b += 256; n.g2 = b; b += 256; n.be2 = b; b += 256;
+        n.wh = b; b += head_w; n.bh = b; b += head_b;
+    };
+    carve(p->dev.actor, (size_t) 2 * action_dim * 256, 2 * action_dim);
+    carve(p->dev.critic, 256, 1);
+    p->dev.S = state_dim; p->dev.A = action_dim; p->dev.K1pad = p->K1pad;
+    *out = p;
+    return EVM_OK;
+}
+
+void evm_policy_destroy(EvmPolicy *p) {
+    if (!p) return;
+    if (p->arena) (void) hipFree(p->arena);
+    delete p;
+}
+
+int evm_policy_param_counts(const EvmPolicy *p, size_t *n_actor, size_t *n_critic) {
+    if (!p) return pfail(EVM_E_INVALID, "policy is null");
+    const size_t trunk = (size_t) 256 * p->S + 256 + 256 + 256 + 256 * 256 + 256 + 256 + 256;
+    if (n_actor) *n_actor = trunk + 2 * ((size_t) p->A * 256 + p->A);
+    if (n_critic) *n_critic = trunk + 256 + 1;
+    return EVM_OK;
+}
+
+// h_actor / h_critic: flat fp32 parameters in the reference's named_parameters() order
+//   actor : head.0.{weight[256,S],bias} head.2.{weight,bias} head.3.{weight[256,256],bias} head.5.{weight,bias}
+//           mu.0.{weight[A,256],bias} sigma.0.{weight[A,256],bias}      (actor.cpp:9-28)
+//   critic: critic.0 .2 .3 .5 as above, critic.6.{weight[1,256],bias}   (critic.cpp:8-21)
+int evm_policy_set_weights(EvmPolicy *p, const float *h_actor, size_t n_actor, const float *h_critic, size_t n_critic) {
+    if (!p || !h_actor || !h_critic) return pfail(EVM_E_INVALID, "null argument");
+    size_t ea, ec;
+    evm_policy_param_counts(p, &ea, &ec);
+    if (n_actor != ea || n_critic != ec) return pfail(EVM_E_INVALID, "parameter count mismatch");
+    std::vector<float> host(p->arena_floats, 0.f);
+    auto pack = [&](const evm::NetDev &n, const float *src, int heads, bool actor) {
+        const int S = p->S, A = p->A;
+        float *w1t = host.data() + (n.w1t - p->arena);
+        for (int o = 0; o < 256; o++)
+            for (int k = 0; k < S; k++) w1t[(size_t) k * 256 + o] = src[(size_t) o * S + k];
+        src += (size_t) 256 * S;
+        memcpy(host.data() + (n.b1 - p->arena), src, 256 * 4); src += 256;
+        memcpy(host.data() + (n.g1 - p->arena), src, 256 * 4); src += 256;
+        memcpy(host.data() + (n.be1 - p->arena), src, 256 * 4); src += 256;
+        float *w2t = host.data() + (n.w2t - p->arena);
+        for (int o = 0; o < 256; o++)
+            for (int k = 0; k < 256; k++) w2t[(size_t) k * 256 + o] = src[(size_t) o * 256 + k];
+        src += 256 * 256;
+        memcpy(host.data() + (n.b2 - p->arena), src, 256 * 4); src += 256;
+        memcpy(host.data() + (n.g2 - p->arena), src, 256 * 4); src += 256;
+        memcpy(host.data() + (n.be2 - p->arena), src, 256 * 4); src += 256;
+        float *wh = host.data() + (n.wh - p->arena), *bh = host.data() + (n.bh - p->arena);
+        if (actor) {
+            memcpy(wh, src, (size_t) A * 256 * 4); src += (size_t) A * 256;                 // mu.0.weight
+            memcpy(bh, src, A * 4); src += A;                                                // mu.0.bias
+            memcpy(wh + (size_t) A * 256, src, (size_t) A * 256 * 4); src += (size_t) A * 256;  // sigma.0.weight
+            memcpy(bh + A, src, A * 4); src += A;
+        } else {
+            memcpy(wh, src, 256 * 4); src += 256;
+            bh[0] = src[0];
+        }
+        (void) heads;
+    };
+    pack(p->dev.actor, h_actor, 2 * p->A, true);
+    pack(p->dev.critic, h_critic, 1, false);
+    if (hipMemcpy(p->arena, host.data(), p->arena_floats * 4, hipMemcpyHostToDevice) != hipSuccess)
+        return pfail(EVM_E_HIP, "weight upload failed");
+    return EVM_OK;
+}
+
+int evm_policy_forward(EvmPolicy *p, int n, const float *d_obs, const float *d_uniform, uint64_t seed, float *d_action,
+                       float *d_logp, float *d_value, float *d_mu, float *d_sigma, void *stream) {
+    if (!p || !d_obs || !d_action || !d_logp || !d_value) return pfail(EVM_E_INVALID, "null argument");
+    if (n < 1) return pfail(EVM_E_INVALID, "n must be >= 1");
+    hipError_t e = evm::launch_policy_forward(p->dev, n, d_obs, d_uniform, seed, p->counter++, d_action, d_logp, d_value,
+                                              d_mu, d_sigma, (hipStream_t) stream);
+    if (e != hipSuccess) return pfail(EVM_E_HIP, std::string("policy forward: ") + hipGetErrorString(e));
+    return EVM_OK;
+}
+
+}  // extern "C"

@@ -78,8 +78,9 @@ int evm_env_step(EvmEnv *env, const float *d_action, float *d_obs, float *d_rewa
  * Rollout form of the reference's train loop body (src/train.cpp:61-66): do_step for running envs; an env
  * whose previous transition was `done` starts reset() instead and spends the next 2*reset_frames calls in
  * its settle steps, one physics step per call (d_valid = 0, outputs untouched), then emits reset()'s own
- * step (d_valid = 1).  Every lane does exactly one physics step per call, so the wavefront never diverges
- * on episode boundaries.  The per-env transition sequence is the reference's.
+ * step (d_valid = 2: the first state of the next episode, not a transition).  d_valid = 1 marks a do_step
+ * transition.  Every lane does exactly one physics step per call, so the wavefront never diverges on episode
+ * boundaries.  The per-env transition sequence is the reference's.
  */
 int evm_env_step_autoreset(EvmEnv *env, const float *d_action, float *d_obs, float *d_reward, uint8_t *d_done,
                            uint8_t *d_valid, void *stream);
@@ -121,6 +122,23 @@ int evm_env_clear_stats(EvmEnv *env);
  * on the env's stream since evm_env_timing_begin(); used by bench.py for the roofline line. */
 int evm_env_timing_begin(EvmEnv *env, void *stream);
 int evm_env_timing_end(EvmEnv *env, void *stream, float *ms_total, int *n_launches);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Agent side of the rollout: PpoGaeAgent::act for a whole batch
+ * (evo_motion_networks/src/agents/ppo_gae.cpp:29-45; ActorModule / CriticModule networks/actor.cpp:9-48,
+ *  networks/critic.cpp:8-35; truncated normal functions.cpp:53-68,94-111), hidden_size = 256.
+ * ------------------------------------------------------------------------------------------------------- */
+int evm_policy_create(int state_dim, int action_dim, int hidden_size, int device, EvmPolicy **out);
+void evm_policy_destroy(EvmPolicy *p);
+int evm_policy_param_counts(const EvmPolicy *p, size_t *n_actor, size_t *n_critic); /* 168216 / 162305 */
+/* Flat fp32 parameters in the reference's named_parameters() order (weights [out,in] row major). */
+int evm_policy_set_weights(EvmPolicy *p, const float *h_actor, size_t n_actor, const float *h_critic, size_t n_critic);
+/* (mu, sigma) = actor(obs); action = truncated_normal_sample(mu, sigma, -1, 1); logp = truncated_normal_log_pdf;
+ * value = critic(obs).  d_uniform [n, A] supplies the U[0,1) draws the reference takes from at::rand (pass NULL to
+ * use the built-in counter-based generator keyed by seed and an internal call counter).
+ * d_action, d_logp [n, A]; d_value [n]; d_mu, d_sigma [n, A] optional (may be NULL). */
+int evm_policy_forward(EvmPolicy *p, int n, const float *d_obs, const float *d_uniform, uint64_t seed, float *d_action,
+                       float *d_logp, float *d_value, float *d_mu, float *d_sigma, void *stream);
 
 #ifdef __cplusplus
 }

@@ -168,15 +168,16 @@ def test_autoreset_rollout_semantics(torch_mod, orc_lib):
     for k in range(calls):
         a = torch.from_numpy(rng.uniform(-1, 1, (n, 12)).astype(np.float32))
         st = env.step_autoreset(a)
-        valid, done = st.valid.cpu().numpy().astype(bool), st.done.cpu().numpy().astype(bool)
+        vcode = st.valid.cpu().numpy()
+        valid, done = vcode.astype(bool), st.done.cpu().numpy().astype(bool)
         for i in range(n):
             if settle[i] == 0 and prev_done[i]:
                 settle[i] = 60
             if settle[i] > 0:
                 settle[i] -= 1
-                assert valid[i] == (settle[i] == 0), (k, i)
+                assert vcode[i] == (2 if settle[i] == 0 else 0), (k, i)
             else:
-                assert valid[i]
+                assert vcode[i] == 1
                 n_steps += 1
         prev_done = np.where(valid, done, False)
     s = env.stats()

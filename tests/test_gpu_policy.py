@@ -1,0 +1,110 @@
+"""Fused MFMA actor-critic forward (evm_policy_forward) against the reference's golden vectors and the oracle."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import agent_oracle as ao  # noqa: E402
+import golden_io  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return golden_io.load()
+
+
+@pytest.fixture(scope="module")
+def fused():
+    import torch
+    from evomotion_amd import FusedActorCritic
+    assert torch.cuda.is_available()
+    f = FusedActorCritic(371, 12, 256, 0)
+    pa, pc = ao.pattern_params(ao.ACTOR_SHAPES, 100), ao.pattern_params(ao.CRITIC_SHAPES, 200)
+    f.set_weights(np.concatenate([pa[n].ravel() for n, _ in ao.ACTOR_SHAPES]),
+                  np.concatenate([pc[n].ravel() for n, _ in ao.CRITIC_SHAPES]))
+    return f, pa, pc
+
+
+def test_forward_matches_reference_golden(gold, fused):
+    import torch
+    f, pa, pc = fused
+    x = torch.from_numpy(gold["X"]).cuda()
+    u = torch.full((8, 12), 0.5, device="cuda")
+    action, logp, value, mu, sigma = f.forward(x, uniform=u, want_dist=True)
+    # fp32 MFMA is a k-ordered fma chain; the reference's CPU GEMM sums in another order: 2e-5 absolute
+    np.testing.assert_allclose(mu.cpu().numpy(), gold["mu"], atol=2e-5)
+    np.testing.assert_allclose(sigma.cpu().numpy(), gold["sigma"], atol=2e-5, rtol=2e-5)
+    np.testing.assert_allclose(value.cpu().numpy()[:, None], gold["value"], atol=5e-5)
+    # single state (Agent::act path)
+    a1, l1, v1, m1, s1 = f.forward(x[:1].contiguous(), uniform=u[:1].contiguous(), want_dist=True)
+    np.testing.assert_allclose(m1.cpu().numpy()[0], gold["mu_1d"], atol=2e-5)
+
+
+def test_sampling_and_logp_against_oracle(gold, fused):
+    import torch
+    f, pa, pc = fused
+    rng = np.random.default_rng(0)
+    n = 333  # ragged: not a multiple of the 64-row tile
+    x = rng.uniform(-1, 1, (n, 371)).astype(np.float32)
+    u = rng.uniform(0, 1, (n, 12)).astype(np.float32)
+    action, logp, value, mu, sigma = f.forward(torch.from_numpy(x).cuda(), uniform=torch.from_numpy(u).cuda(), want_dist=True)
+    mu_o, sg_o = ao.actor_forward(x, pa)
+    v_o = ao.critic_forward(x, pc)
+    np.testing.assert_allclose(mu.cpu().numpy(), mu_o, atol=3e-5)
+    np.testing.assert_allclose(sigma.cpu().numpy(), sg_o, atol=3e-5, rtol=3e-5)
+    np.testing.assert_allclose(value.cpu().numpy(), v_o[:, 0], atol=1e-4)
+    # sample / log-pdf evaluated at the kernel's own (mu, sigma): isolates the epilogue from the GEMM rounding
+    m, s = mu.cpu().numpy(), sigma.cpu().numpy()
+    a_o = ao.tn_sample(m, s, u)
+    a = action.cpu().numpy()
+    assert (np.abs(a) <= 1).all() and np.isfinite(a).all()
+    np.testing.assert_allclose(a, a_o, atol=5e-4)
+    lp_o = ao.tn_log_pdf(a, m, s)
+    np.testing.assert_allclose(logp.cpu().numpy(), lp_o, atol=2e-4, rtol=2e-4)
+
+
+def test_matches_torch_modules_at_full_batch(fused):
+    import torch
+    from evomotion_amd import ActorModule, CriticModule, FusedActorCritic
+    torch.manual_seed(1234)
+    actor, critic = ActorModule([371], [12], 256).cuda().eval(), CriticModule([371], 256).cuda().eval()
+    f = FusedActorCritic(371, 12, 256, 0)
+    f.load_modules(actor, critic)
+    x = torch.randn(4096, 371, device="cuda")
+    action, logp, value, mu, sigma = f.forward(x, want_dist=True)
+    with torch.no_grad():
+        m_t, s_t = actor(x)
+        v_t = critic(x)
+    assert (mu - m_t).abs().max() < 5e-5 and (sigma - s_t).abs().max() < 5e-5
+    assert (value - v_t[:, 0]).abs().max() < 1e-4
+    assert action.abs().max() <= 1 and torch.isfinite(logp).all()
+    # built-in counter-based generator: a new draw every call, same call sequence -> same stream
+    a2, _, _ = f.forward(x)
+    assert not torch.equal(a2, action)
+    g = FusedActorCritic(371, 12, 256, 0)
+    g.load_modules(actor, critic)
+    b1, _, _ = g.forward(x)
+    assert torch.equal(b1, action)
+    # empirical mean of samples tracks mu for small sigma dims
+    assert (action - mu).abs().mean() < (sigma.mean() * 2)
+
+
+def test_rollout_and_update_smoke():
+    import torch
+    from evomotion_amd import VecPpoGaeAgent, VecRobotWalk
+    env = VecRobotWalk(256, seed=1)
+    env.reset()
+    agent = VecPpoGaeAgent(1234, [371], [12], horizon=8, epoch=2)
+    assert agent.count_parameters() == 330521
+    w0 = agent.actor.head[0].weight.detach().clone()
+    for _ in range(2):
+        buf = agent.rollout(env)
+        assert torch.isfinite(buf["states"]).all() and set(buf["valid"].unique().tolist()) <= {0.0, 1.0, 2.0}
+        al, cl = agent.update()
+        assert np.isfinite(al) and np.isfinite(cl)
+    assert not torch.equal(w0, agent.actor.head[0].weight)
