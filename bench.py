@@ -45,6 +45,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=256)
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=["dynamics", "ppo"], default="dynamics",
+                    help="dynamics = BASELINE configs[1] (random actions, headline); ppo = configs[2]/[3]: fused MFMA "
+                         "actor-critic forward inside the rollout, PPO update every --horizon steps")
+    ap.add_argument("--horizon", type=int, default=32)
+    ap.add_argument("--no-update", action="store_true", help="ppo mode: rollout only")
     args = ap.parse_args()
 
     import torch
@@ -74,17 +79,38 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        env.step_autoreset(actions[i % bank])
+    agent = None
+    if args.mode == "ppo":
+        from evomotion_amd import VecPpoGaeAgent
+        agent = VecPpoGaeAgent(1234, [env.state_dim], [env.action_dim], hidden_size=256, device=local_rank,
+                               horizon=args.horizon, epoch=8, learning_rate=1e-3)
+
+    def run(k_steps, offset=0):
+        if agent is None:
+            for i in range(k_steps):
+                env.step_autoreset(actions[(offset + i) % bank])
+            return
+        done_steps = 0
+        while done_steps < k_steps:  # whole horizons only: K is rounded up to a multiple of --horizon
+            agent.rollout(env)
+            if not args.no_update:
+                agent.update()
+            done_steps += args.horizon
+
+    run(args.warmup)
     barrier()
     env.clear_stats()
     env.timing_begin()
+    if agent is not None:
+        agent.fused.timing_begin()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        env.step_autoreset(actions[i % bank])
+    run(args.steps, args.warmup)
     ms_kernel, n_launch = env.timing_end()
+    ms_policy, n_policy = agent.fused.timing_end() if agent is not None else (0.0, 0)
     barrier()
     t1 = time.perf_counter()
+    if agent is not None:
+        args.steps = n_launch
     elapsed = t1 - t0
     st = env.stats()
     tt = torch.tensor([elapsed, float(st["env_steps"]), float(st["resets"])], dtype=torch.float64, device=dev)
@@ -112,8 +138,11 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "robot_walk, %d envs/GPU on %d MI355X, HIP dynamics only, uniform random actions, "
-                            "rollout form with in-band reset (configs[1])" % (n, world),
+                "workload": ("robot_walk, %d envs/GPU on %d MI355X, HIP dynamics only, uniform random actions, "
+                             "rollout form with in-band reset (configs[1])" % (n, world)) if agent is None else
+                            ("robot_walk, %d envs/GPU on %d MI355X, PPO hidden_size=256, fused MFMA actor-critic forward "
+                             "in the rollout, horizon %d, %s (configs[2])" % (n, world, args.horizon,
+                              "rollout only" if args.no_update else "PyTorch-ROCm PPO update (epoch 8) every horizon")),
                 "envs_per_gpu": n,
                 "physics_steps_per_s": world * n * args.steps / elapsed,
                 "do_step_fraction": env_steps / (world * n * args.steps),
@@ -127,6 +156,12 @@ def main():
                         "bound (about 50 FLOP per algorithmic byte), see DESIGN.md" % n,
             },
         }
+        if agent is not None and n_policy:
+            pol_ms = ms_policy / n_policy
+            tf = 654848.0 * n / (pol_ms * 1e-3) / 1e12  # 654 848 GEMM FLOP per act
+            out["roofline_policy"] = {"bound": "mfma", "achieved": tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                      "frac": tf / VALU_PEAK_TFLOPS, "traffic": None, "kernel": "k_policy_forward",
+                                      "launch_ms": pol_ms, "note": "fp32-input MFMA (v_mfma_f32_32x32x2_f32), dense fp32 matrix peak"}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

@@ -62,6 +62,8 @@ def _load():
     lib.evm_policy_param_counts.argtypes = [vp, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]
     lib.evm_policy_set_weights.argtypes = [vp, fp, ctypes.c_size_t, fp, ctypes.c_size_t]
     lib.evm_policy_forward.argtypes = [vp, ctypes.c_int, vp, vp, ctypes.c_uint64, vp, vp, vp, vp, vp, vp]
+    lib.evm_policy_timing_begin.argtypes = [vp]
+    lib.evm_policy_timing_end.argtypes = [vp, vp, fp, ip]
     lib.evm_env_timing_begin.argtypes = [vp, vp]
     lib.evm_env_timing_end.argtypes = [vp, vp, fp, ip]
     return lib

@@ -237,6 +237,15 @@ class FusedActorCritic:
         except Exception:
             pass
 
+    def timing_begin(self):
+        check(lib.evm_policy_timing_begin(self._h))
+
+    def timing_end(self):
+        ms, n = ctypes.c_float(), ctypes.c_int()
+        stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        check(lib.evm_policy_timing_end(self._h, stream, ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
+
     def set_weights(self, actor_flat, critic_flat):
         a = np.ascontiguousarray(actor_flat, np.float32)
         c = np.ascontiguousarray(critic_flat, np.float32)

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/evomotion.h"
@@ -39,6 +40,8 @@ struct EvmEnv {
     hipEvent_t ev0, ev1;
     int timed_launches;
     bool timing;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pairs;  // one pair per timed launch
+    size_t ev_used;
 };
 
 static const EvmEnv *g_skel_owner = nullptr;
@@ -78,6 +81,7 @@ int evm_env_create(const char *skeleton_path, int n_envs, int device, uint64_t s
     env->arena = nullptr;
     env->timing = false;
     env->timed_launches = 0;
+    env->ev_used = 0;
     std::string err;
     int rc = evm::load_skeleton_constants(skeleton_path, prm, env->skel, err);
     if (rc != EVM_OK) { delete env; return fail(rc, err); }
@@ -122,8 +126,9 @@ void evm_env_destroy(EvmEnv *env) {
     if (!env) return;
     if (g_skel_owner == env) g_skel_owner = nullptr;
     if (env->arena) hipFree(env->arena);
-    hipEventDestroy(env->ev0);
-    hipEventDestroy(env->ev1);
+    (void) hipEventDestroy(env->ev0);
+    (void) hipEventDestroy(env->ev1);
+    for (auto &pr : env->ev_pairs) { (void) hipEventDestroy(pr.first); (void) hipEventDestroy(pr.second); }
     delete env;
 }
 
@@ -146,8 +151,21 @@ static int step_launch(EvmEnv *env, int mode, const float *a, float *obs, float 
                        const uint8_t *mask, hipStream_t s) {
     int rc = ensure_skeleton(env, s);
     if (rc != EVM_OK) return rc;
+    if (env->timing) {
+        if (env->ev_used == env->ev_pairs.size()) {
+            hipEvent_t a0, a1;
+            HIP_TRY(hipEventCreate(&a0));
+            HIP_TRY(hipEventCreate(&a1));
+            env->ev_pairs.push_back({a0, a1});
+        }
+        HIP_TRY(hipEventRecord(env->ev_pairs[env->ev_used].first, s));
+    }
     HIP_TRY(evm::launch_step(env->d, env->skel.nb, mode, a, obs, rew, done, valid, mask, s));
-    if (env->timing) env->timed_launches++;
+    if (env->timing) {
+        HIP_TRY(hipEventRecord(env->ev_pairs[env->ev_used].second, s));
+        env->ev_used++;
+        env->timed_launches++;
+    }
     return EVM_OK;
 }
 
@@ -392,17 +410,21 @@ int evm_env_clear_stats(EvmEnv *env) {
 // ---- timing ------------------------------------------------------------------------------------
 int evm_env_timing_begin(EvmEnv *env, void *stream) {
     if (!env) return fail(EVM_E_INVALID, "env is null");
+    (void) stream;
     env->timing = true;
     env->timed_launches = 0;
-    HIP_TRY(hipEventRecord(env->ev0, (hipStream_t) stream));
+    env->ev_used = 0;
     return EVM_OK;
 }
 int evm_env_timing_end(EvmEnv *env, void *stream, float *ms_total, int *n_launches) {
     if (!env) return fail(EVM_E_INVALID, "env is null");
-    HIP_TRY(hipEventRecord(env->ev1, (hipStream_t) stream));
-    HIP_TRY(hipEventSynchronize(env->ev1));
+    HIP_TRY(hipStreamSynchronize((hipStream_t) stream));
     float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, env->ev0, env->ev1));
+    for (size_t i = 0; i < env->ev_used; i++) {
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, env->ev_pairs[i].first, env->ev_pairs[i].second));
+        ms += t;
+    }
     env->timing = false;
     if (ms_total) *ms_total = ms;
     if (n_launches) *n_launches = env->timed_launches;

@@ -3,6 +3,7 @@
 
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/evomotion.h"
@@ -20,6 +21,9 @@ struct EvmPolicy {
     size_t arena_floats;
     evm::PolicyDev dev;
     uint64_t counter;
+    bool timing;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pairs;
+    size_t ev_used;
 };
 
 static int pfail(int code, const std::string &m) { evm::set_last_error(m); return code; }
@@ -33,7 +37,7 @@ int evm_policy_create(int state_dim, int action_dim, int hidden_size, int device
     if (state_dim < 1 || action_dim < 1 || 2 * action_dim > 32) return pfail(EVM_E_INVALID, "unsupported state/action size");
     if (hipSetDevice(device) != hipSuccess) return pfail(EVM_E_HIP, "hipSetDevice failed");
     EvmPolicy *p = new EvmPolicy();
-    p->S = state_dim; p->A = action_dim; p->H = hidden_size; p->device = device; p->counter = 0;
+    p->S = state_dim; p->A = action_dim; p->H = hidden_size; p->device = device; p->counter = 0; p->timing = false; p->ev_used = 0;
     p->K1pad = (state_dim + 31) / 32 * 32;
     const size_t per_net = (size_t) p->K1pad * 256 + 3 * 256 + 256 * 256 + 3 * 256;
     p->arena_floats = 2 * per_net + ((size_t) 2 * action_dim * 256 + 2 * action_dim) + (256 + 1);
@@ -57,6 +61,7 @@ int evm_policy_create(int state_dim, int action_dim, int hidden_size, int device
 void evm_policy_destroy(EvmPolicy *p) {
     if (!p) return;
     if (p->arena) (void) hipFree(p->arena);
+    for (auto &pr : p->ev_pairs) { (void) hipEventDestroy(pr.first); (void) hipEventDestroy(pr.second); }
     delete p;
 }
 
@@ -117,9 +122,40 @@ int evm_policy_forward(EvmPolicy *p, int n, const float *d_obs, const float *d_u
                        float *d_logp, float *d_value, float *d_mu, float *d_sigma, void *stream) {
     if (!p || !d_obs || !d_action || !d_logp || !d_value) return pfail(EVM_E_INVALID, "null argument");
     if (n < 1) return pfail(EVM_E_INVALID, "n must be >= 1");
+    hipStream_t s = (hipStream_t) stream;
+    if (p->timing) {
+        if (p->ev_used == p->ev_pairs.size()) {
+            hipEvent_t a0, a1;
+            if (hipEventCreate(&a0) != hipSuccess || hipEventCreate(&a1) != hipSuccess) return pfail(EVM_E_HIP, "hipEventCreate failed");
+            p->ev_pairs.push_back({a0, a1});
+        }
+        (void) hipEventRecord(p->ev_pairs[p->ev_used].first, s);
+    }
     hipError_t e = evm::launch_policy_forward(p->dev, n, d_obs, d_uniform, seed, p->counter++, d_action, d_logp, d_value,
-                                              d_mu, d_sigma, (hipStream_t) stream);
+                                              d_mu, d_sigma, s);
     if (e != hipSuccess) return pfail(EVM_E_HIP, std::string("policy forward: ") + hipGetErrorString(e));
+    if (p->timing) { (void) hipEventRecord(p->ev_pairs[p->ev_used].second, s); p->ev_used++; }
+    return EVM_OK;
+}
+
+int evm_policy_timing_begin(EvmPolicy *p) {
+    if (!p) return pfail(EVM_E_INVALID, "policy is null");
+    p->timing = true;
+    p->ev_used = 0;
+    return EVM_OK;
+}
+int evm_policy_timing_end(EvmPolicy *p, void *stream, float *ms_total, int *n_launches) {
+    if (!p) return pfail(EVM_E_INVALID, "policy is null");
+    if (hipStreamSynchronize((hipStream_t) stream) != hipSuccess) return pfail(EVM_E_HIP, "stream sync failed");
+    float ms = 0.f;
+    for (size_t i = 0; i < p->ev_used; i++) {
+        float t = 0.f;
+        (void) hipEventElapsedTime(&t, p->ev_pairs[i].first, p->ev_pairs[i].second);
+        ms += t;
+    }
+    p->timing = false;
+    if (ms_total) *ms_total = ms;
+    if (n_launches) *n_launches = (int) p->ev_used;
     return EVM_OK;
 }
 

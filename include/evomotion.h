@@ -118,8 +118,9 @@ int evm_env_get_diagnostics(const EvmEnv *env, float *d_out /* [n_envs, 2] */, v
 int evm_env_get_stats(EvmEnv *env, long long *h_out /* [2] */);
 int evm_env_clear_stats(EvmEnv *env);
 
-/* Last launch statistics: average duration in ms of the dynamics kernel launches bracketed by HIP events
- * on the env's stream since evm_env_timing_begin(); used by bench.py for the roofline line. */
+/* Kernel timing for bench.py's roofline line: between _begin and _end every dynamics-kernel launch is bracketed
+ * by its own pair of HIP events on the launch stream; _end synchronises the stream and returns the summed
+ * duration (ms) and the number of launches. */
 int evm_env_timing_begin(EvmEnv *env, void *stream);
 int evm_env_timing_end(EvmEnv *env, void *stream, float *ms_total, int *n_launches);
 
@@ -139,6 +140,9 @@ int evm_policy_set_weights(EvmPolicy *p, const float *h_actor, size_t n_actor, c
  * d_action, d_logp [n, A]; d_value [n]; d_mu, d_sigma [n, A] optional (may be NULL). */
 int evm_policy_forward(EvmPolicy *p, int n, const float *d_obs, const float *d_uniform, uint64_t seed, float *d_action,
                        float *d_logp, float *d_value, float *d_mu, float *d_sigma, void *stream);
+
+int evm_policy_timing_begin(EvmPolicy *p);
+int evm_policy_timing_end(EvmPolicy *p, void *stream, float *ms_total, int *n_launches);
 
 #ifdef __cplusplus
 }
