@@ -1,4 +1,5 @@
-// Device-side view of the vectorised environment state (struct-of-arrays, [field][env], env padded to 64).
+// Device-side view of the vectorised environment state.  Every array is [tile][slot][64 lanes] (tile = 64
+// consecutive envs = one wavefront): a slot of a tile is one coalesced 256-byte line.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -14,7 +15,7 @@ namespace evm {
 struct EnvDev {
     int n;       // padded env count (multiple of 64)
     int n_real;  // env count
-    float *pos, *quat, *lin, *ang;  // [nb*3|4][n]
+    float *pos, *quat, *lin, *ang;  // [n/64][nb*3|4][64]
     float *hist;                    // [nm*6][n]  last_lin, last_ang (proprioception_state.cpp:33-34)
     int *mfn;                       // [nm][n]    persistent manifold point counts
     float *mfp;                     // [nm*4*9][n] localA3 localB3 dist applied applied_lateral

@@ -30,6 +30,9 @@ namespace {
     } while (0)
 }  // namespace
 
+// element (slot k, env e) of an array with `cnt` slots per env; device layout is [tile][slot][64 lanes]
+static inline size_t tix(size_t cnt, size_t k, size_t e) { return ((e >> 6) * cnt + k) * 64 + (e & 63); }
+
 struct EvmEnv {
     EvmSkelC skel;
     evm::EnvDev d;
@@ -266,7 +269,7 @@ int evm_env_get_diagnostics(const EvmEnv *env, float *d_out, void *stream) {
     std::vector<float> h(2 * (size_t) env->d.n), o(2 * (size_t) env->d.n_real);
     HIP_TRY(hipStreamSynchronize((hipStream_t) stream));
     HIP_TRY(hipMemcpy(h.data(), env->d.diag, h.size() * 4, hipMemcpyDeviceToHost));
-    for (int e = 0; e < env->d.n_real; e++) { o[2 * e] = h[e]; o[2 * e + 1] = h[(size_t) env->d.n + e]; }
+    for (int e = 0; e < env->d.n_real; e++) { o[2 * e] = h[tix(2, 0, e)]; o[2 * e + 1] = h[tix(2, 1, e)]; }
     HIP_TRY(hipMemcpy(d_out, o.data(), o.size() * 4, hipMemcpyHostToDevice));
     return EVM_OK;
 }
@@ -304,7 +307,9 @@ int evm_env_get_state(EvmEnv *env, float *h_state) {
     HIP_TRY(dl(env->d.hist, 6 * S.nm, m.hist)); HIP_TRY(dl(env->d.mfp, 36 * S.nm, m.mfp));
     HIP_TRY(dl(env->d.target, S.nmus > 0 ? S.nmus : 1, m.target)); HIP_TRY(dl(env->d.E, 9, m.E));
     HIP_TRY(dl(env->d.iinv_stale, 6 * S.nb, m.iinv));
-    HIP_TRY(dl(env->d.scratch + (size_t) S.sc_ms * n, 3 * S.nm, m.scratch_ms));
+    m.scratch_ms.resize((size_t) 3 * S.nm * n);
+    HIP_TRY(hipMemcpy2D(m.scratch_ms.data(), (size_t) 3 * S.nm * 256, env->d.scratch + (size_t) S.sc_ms * 64,
+                        (size_t) S.sc_total * 256, (size_t) 3 * S.nm * 256, n / 64, hipMemcpyDeviceToHost));
     HIP_TRY(dli(env->d.mfn, S.nm, m.mfn)); HIP_TRY(dli(env->d.flags, 1, m.flags));
     HIP_TRY(dli(env->d.curr_step, 1, m.curr)); HIP_TRY(dli(env->d.remaining, 1, m.rem));
     const int ss = evm_env_state_size(env);
@@ -313,24 +318,24 @@ int evm_env_get_state(EvmEnv *env, float *h_state) {
         int k = 0;
         const bool pending = (m.flags[e] & EVM_FLAG_PENDING) != 0;
         for (int b = 0; b < S.nb; b++) {
-            for (int a = 0; a < 3; a++) o[k++] = m.pos[(size_t) (3 * b + a) * n + e];
+            for (int a = 0; a < 3; a++) o[k++] = m.pos[tix(3 * S.nb, 3 * b + a, e)];
             if (pending) { o[k++] = 0.f; o[k++] = 0.f; o[k++] = 0.f; o[k++] = 1.f; }
-            else for (int a = 0; a < 4; a++) o[k++] = m.quat[(size_t) (4 * b + a) * n + e];
-            for (int a = 0; a < 3; a++) o[k++] = m.lin[(size_t) (3 * b + a) * n + e];
-            for (int a = 0; a < 3; a++) o[k++] = m.ang[(size_t) (3 * b + a) * n + e];
+            else for (int a = 0; a < 4; a++) o[k++] = m.quat[tix(4 * S.nb, 4 * b + a, e)];
+            for (int a = 0; a < 3; a++) o[k++] = m.lin[tix(3 * S.nb, 3 * b + a, e)];
+            for (int a = 0; a < 3; a++) o[k++] = m.ang[tix(3 * S.nb, 3 * b + a, e)];
         }
         o[k++] = pending ? 1.f : 0.f;
-        for (int a = 0; a < 9; a++) o[k++] = m.E[(size_t) a * n + e];
-        for (int a = 0; a < 6 * S.nb; a++) o[k++] = m.iinv[(size_t) a * n + e];
-        for (int a = 0; a < 3 * S.nm; a++) o[k++] = m.scratch_ms[(size_t) a * n + e];
-        for (int a = 0; a < 6 * S.nm; a++) o[k++] = m.hist[(size_t) a * n + e];
+        for (int a = 0; a < 9; a++) o[k++] = m.E[tix(9, a, e)];
+        for (int a = 0; a < 6 * S.nb; a++) o[k++] = m.iinv[tix(6 * S.nb, a, e)];
+        for (int a = 0; a < 3 * S.nm; a++) o[k++] = m.scratch_ms[tix(3 * S.nm, a, e)];
+        for (int a = 0; a < 6 * S.nm; a++) o[k++] = m.hist[tix(6 * S.nm, a, e)];
         for (int mm = 0; mm < S.nm; mm++) {
-            const int cnt = m.mfn[(size_t) mm * n + e];
+            const int cnt = m.mfn[tix(S.nm, mm, e)];
             o[k++] = (float) cnt;
             for (int j = 0; j < 4; j++)
-                for (int f = 0; f < 9; f++) o[k++] = j < cnt ? m.mfp[(size_t) ((mm * 4 + j) * 9 + f) * n + e] : 0.f;
+                for (int f = 0; f < 9; f++) o[k++] = j < cnt ? m.mfp[tix(36 * S.nm, (mm * 4 + j) * 9 + f, e)] : 0.f;
         }
-        for (int a = 0; a < S.nmus; a++) o[k++] = m.target[(size_t) a * n + e];
+        for (int a = 0; a < S.nmus; a++) o[k++] = m.target[tix((S.nmus > 0 ? S.nmus : 1), a, e)];
         o[k++] = (m.flags[e] & EVM_FLAG_POWERED) ? 1.f : 0.f;
         o[k++] = (float) m.curr[e];
         o[k++] = (float) m.rem[e];
@@ -356,22 +361,22 @@ int evm_env_set_state(EvmEnv *env, const float *h_state) {
         const float *in = h_state + (size_t) e * ss;
         int k = 0;
         for (int b = 0; b < S.nb; b++) {
-            for (int a = 0; a < 3; a++) m.pos[(size_t) (3 * b + a) * n + e] = in[k++];
-            for (int a = 0; a < 4; a++) m.quat[(size_t) (4 * b + a) * n + e] = in[k++];
-            for (int a = 0; a < 3; a++) m.lin[(size_t) (3 * b + a) * n + e] = in[k++];
-            for (int a = 0; a < 3; a++) m.ang[(size_t) (3 * b + a) * n + e] = in[k++];
+            for (int a = 0; a < 3; a++) m.pos[tix(3 * S.nb, 3 * b + a, e)] = in[k++];
+            for (int a = 0; a < 4; a++) m.quat[tix(4 * S.nb, 4 * b + a, e)] = in[k++];
+            for (int a = 0; a < 3; a++) m.lin[tix(3 * S.nb, 3 * b + a, e)] = in[k++];
+            for (int a = 0; a < 3; a++) m.ang[tix(3 * S.nb, 3 * b + a, e)] = in[k++];
         }
         const bool pending = in[k++] != 0.f;
-        for (int a = 0; a < 9; a++) m.E[(size_t) a * n + e] = in[k++];
-        for (int a = 0; a < 6 * S.nb; a++) m.iinv[(size_t) a * n + e] = in[k++];
-        for (int a = 0; a < 3 * S.nm; a++) m.scratch_ms[(size_t) a * n + e] = in[k++];
-        for (int a = 0; a < 6 * S.nm; a++) m.hist[(size_t) a * n + e] = in[k++];
+        for (int a = 0; a < 9; a++) m.E[tix(9, a, e)] = in[k++];
+        for (int a = 0; a < 6 * S.nb; a++) m.iinv[tix(6 * S.nb, a, e)] = in[k++];
+        for (int a = 0; a < 3 * S.nm; a++) m.scratch_ms[tix(3 * S.nm, a, e)] = in[k++];
+        for (int a = 0; a < 6 * S.nm; a++) m.hist[tix(6 * S.nm, a, e)] = in[k++];
         for (int mm = 0; mm < S.nm; mm++) {
-            m.mfn[(size_t) mm * n + e] = (int) in[k++];
+            m.mfn[tix(S.nm, mm, e)] = (int) in[k++];
             for (int j = 0; j < 4; j++)
-                for (int f = 0; f < 9; f++) m.mfp[(size_t) ((mm * 4 + j) * 9 + f) * n + e] = in[k++];
+                for (int f = 0; f < 9; f++) m.mfp[tix(36 * S.nm, (mm * 4 + j) * 9 + f, e)] = in[k++];
         }
-        for (int a = 0; a < S.nmus; a++) m.target[(size_t) a * n + e] = in[k++];
+        for (int a = 0; a < S.nmus; a++) m.target[tix((S.nmus > 0 ? S.nmus : 1), a, e)] = in[k++];
         const bool powered = in[k++] != 0.f;
         m.curr[e] = (int) in[k++];
         m.rem[e] = (int) in[k++];
@@ -385,7 +390,8 @@ int evm_env_set_state(EvmEnv *env, const float *h_state) {
     HIP_TRY(ul(env->d.pos, m.pos)); HIP_TRY(ul(env->d.quat, m.quat)); HIP_TRY(ul(env->d.lin, m.lin));
     HIP_TRY(ul(env->d.ang, m.ang)); HIP_TRY(ul(env->d.hist, m.hist)); HIP_TRY(ul(env->d.mfp, m.mfp));
     HIP_TRY(ul(env->d.target, m.target)); HIP_TRY(ul(env->d.E, m.E)); HIP_TRY(ul(env->d.iinv_stale, m.iinv));
-    HIP_TRY(ul(env->d.scratch + (size_t) S.sc_ms * n, m.scratch_ms));
+    HIP_TRY(hipMemcpy2D(env->d.scratch + (size_t) S.sc_ms * 64, (size_t) S.sc_total * 256, m.scratch_ms.data(),
+                        (size_t) 3 * S.nm * 256, (size_t) 3 * S.nm * 256, n / 64, hipMemcpyHostToDevice));
     HIP_TRY(uli(env->d.mfn, m.mfn)); HIP_TRY(uli(env->d.flags, m.flags));
     HIP_TRY(uli(env->d.curr_step, m.curr)); HIP_TRY(uli(env->d.remaining, m.rem));
     return EVM_OK;
@@ -397,7 +403,7 @@ int evm_env_get_stats(EvmEnv *env, long long *h_out) {
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(h.data(), env->d.stat, h.size() * 4, hipMemcpyDeviceToHost));
     h_out[0] = h_out[1] = 0;
-    for (int e = 0; e < env->d.n_real; e++) { h_out[0] += h[e]; h_out[1] += h[(size_t) env->d.n + e]; }
+    for (int e = 0; e < env->d.n_real; e++) { h_out[0] += h[tix(2, 0, e)]; h_out[1] += h[tix(2, 1, e)]; }
     return EVM_OK;
 }
 int evm_env_clear_stats(EvmEnv *env) {

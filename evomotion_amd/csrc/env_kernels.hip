@@ -37,26 +37,50 @@ __constant__ EvmSkelC c_skel;
 #define NUM_ITER 10
 
 struct Ctx {
-    EnvDev d;
+    EnvDev d;  // array bases
+    EnvDev t;  // the same arrays advanced to this wave's 64-env tile: element (slot k, lane) = t.arr[k * 64 + lane]
     int env, lane;
     float *lds;
 };
 
-#define GS(arr, k) (c.d.arr[(size_t) (k) * (size_t) c.d.n + (size_t) c.env])
-#define SC(k) (c.d.scratch[(size_t) (k) * (size_t) c.d.n + (size_t) c.env])
+// HBM layout: every array is [tile][slot][64 lanes].  Inside a kernel the tile base is wave-uniform (SGPR pair),
+// the lane offset is one VGPR shared by every access, and the slot offset is an immediate or one scalar add:
+// no per-access 64-bit address arithmetic.
+DEV Ctx make_ctx(const EnvDev &d, float *lds) {
+    Ctx c;
+    c.d = d;
+    c.t = d;
+    c.lane = threadIdx.x;
+    c.env = blockIdx.x * 64 + threadIdx.x;
+    c.lds = lds;
+    const size_t tile = (size_t) blockIdx.x * 64;
+    const int nb = c_skel.nb, nm = c_skel.nm, nmus = c_skel.nmus > 0 ? c_skel.nmus : 1;
+    c.t.pos = d.pos + tile * (3 * nb); c.t.quat = d.quat + tile * (4 * nb);
+    c.t.lin = d.lin + tile * (3 * nb); c.t.ang = d.ang + tile * (3 * nb);
+    c.t.hist = d.hist + tile * (6 * nm); c.t.mfn = d.mfn + tile * nm; c.t.mfp = d.mfp + tile * (36 * nm);
+    c.t.target = d.target + tile * nmus; c.t.E = d.E + tile * 9; c.t.iinv_stale = d.iinv_stale + tile * (6 * nb);
+    c.t.mt = d.mt + tile * 624; c.t.scratch = d.scratch + tile * c_skel.sc_total;
+    c.t.diag = d.diag + tile * 2; c.t.stat = d.stat + tile * 2;
+    return c;
+}
+
+#define GS(arr, k) (c.t.arr[((k) << 6) + c.lane])
+#define SC(k) (c.t.scratch[((k) << 6) + c.lane])
 #define LDV(b, k) (c.lds[(((b) * 6 + (k)) << 6) + c.lane])
 #define LII(b, k) (c.lds[(((c_skel.nb + (b)) * 6 + (k)) << 6) + c.lane])
 
-DEV F3 gs3(const float *base, size_t n, size_t env, int k) {
-    return f3(base[(size_t) k * n + env], base[(size_t) (k + 1) * n + env], base[(size_t) (k + 2) * n + env]);
+DEV F3 gs3(const float *tile, int lane, int k) {
+    const float *p = tile + (k << 6) + lane;
+    return f3(p[0], p[64], p[128]);
 }
-DEV void ss3(float *base, size_t n, size_t env, int k, F3 v) {
-    base[(size_t) k * n + env] = v.x; base[(size_t) (k + 1) * n + env] = v.y; base[(size_t) (k + 2) * n + env] = v.z;
+DEV void ss3(float *tile, int lane, int k, F3 v) {
+    float *p = tile + (k << 6) + lane;
+    p[0] = v.x; p[64] = v.y; p[128] = v.z;
 }
-#define G3(arr, k) gs3(c.d.arr, c.d.n, c.env, (k))
-#define S3(arr, k, v) ss3(c.d.arr, c.d.n, c.env, (k), (v))
-#define SC3(k) gs3(c.d.scratch, c.d.n, c.env, (k))
-#define SSC3(k, v) ss3(c.d.scratch, c.d.n, c.env, (k), (v))
+#define G3(arr, k) gs3(c.t.arr, c.lane, (k))
+#define S3(arr, k, v) ss3(c.t.arr, c.lane, (k), (v))
+#define SC3(k) gs3(c.t.scratch, c.lane, (k))
+#define SSC3(k, v) ss3(c.t.scratch, c.lane, (k), (v))
 
 // ---------------------------------------------------------------------------------------------
 // body views
@@ -808,17 +832,16 @@ DEV float contact_iter(const Ctx &c, int m, int n) {
 // ---------------------------------------------------------------------------------------------
 DEV float mt_uniform01(const Ctx &c) {
     int idx = c.d.mt_idx[c.env];
-    const size_t n = c.d.n, e = c.env;
-    uint32_t *mt = c.d.mt;
+    uint32_t *mt = c.t.mt + c.lane;
     if (idx >= 624) {
         for (int i = 0; i < 624; i++) {
-            const uint32_t a = mt[(size_t) i * n + e], b = mt[(size_t) ((i + 1) % 624) * n + e];
+            const uint32_t a = mt[i << 6], b = mt[((i + 1) % 624) << 6];
             const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
-            mt[(size_t) i * n + e] = mt[(size_t) ((i + 397) % 624) * n + e] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            mt[i << 6] = mt[((i + 397) % 624) << 6] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
         }
         idx = 0;
     }
-    uint32_t y = mt[(size_t) idx * n + e];
+    uint32_t y = mt[idx << 6];
     c.d.mt_idx[c.env] = idx + 1;
     y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
     float r = xm((float) y, 2.3283064365386963e-10f);
@@ -1083,11 +1106,7 @@ template <int MODE>
 __global__ __launch_bounds__(64) void k_env_step(EnvDev d, const float *__restrict__ action, float *obs, float *reward,
                                                  uint8_t *done, uint8_t *valid, const uint8_t *__restrict__ mask) {
     extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
-    Ctx c;
-    c.d = d;
-    c.lane = threadIdx.x;
-    c.env = blockIdx.x * 64 + threadIdx.x;
-    c.lds = lds_dyn;
+    Ctx c = make_ctx(d, lds_dyn);
     if (c.env >= d.n_real) return;
     if (mask && !mask[c.env]) return;
     int flags = d.flags[c.env];
@@ -1098,11 +1117,11 @@ __global__ __launch_bounds__(64) void k_env_step(EnvDev d, const float *__restri
             flags = d.flags[c.env] & ~EVM_FLAG_DONE;
             d.flags[c.env] = flags;
             d.settle_left[c.env] = 2 * c_skel.reset_frames;
-            d.stat[(size_t) d.n + c.env] += 1;
+            GS(stat, 1) += 1;
         }
         settling = d.settle_left[c.env] > 0;
     }
-    if ((MODE & 4) && !settling) d.stat[c.env] += 1;
+    if ((MODE & 4) && !settling) GS(stat, 0) += 1;
     if ((MODE & 1) && !settling) {  // MuscleController::on_input -> Muscle::contract
         for (int mi = 0; mi < c_skel.nmus; mi++)
             GS(target, mi) = action[(size_t) c.env * c_skel.nmus + mi] * c_skel.muscle[mi].speed;
@@ -1127,11 +1146,7 @@ __global__ __launch_bounds__(64) void k_env_step(EnvDev d, const float *__restri
 }
 
 __global__ __launch_bounds__(64) void k_env_repose(EnvDev d, const uint8_t *__restrict__ mask) {
-    Ctx c;
-    c.d = d;
-    c.lane = threadIdx.x;
-    c.env = blockIdx.x * 64 + threadIdx.x;
-    c.lds = nullptr;
+    Ctx c = make_ctx(d, nullptr);
     if (c.env >= d.n_real) return;
     if (mask && !mask[c.env]) return;
     repose(c);
@@ -1141,18 +1156,14 @@ __global__ __launch_bounds__(64) void k_env_repose(EnvDev d, const uint8_t *__re
 
 // creation state: world transform = first_model_matrix (E = identity, reset-pending), MT19937 seeded
 __global__ __launch_bounds__(64) void k_env_init(EnvDev d, uint64_t seed) {
-    Ctx c;
-    c.d = d;
-    c.lane = threadIdx.x;
-    c.env = blockIdx.x * 64 + threadIdx.x;
-    c.lds = nullptr;
+    Ctx c = make_ctx(d, nullptr);
     if (c.env >= d.n) return;
-    const size_t n = d.n, e = c.env;
+    const size_t e = c.env;
     uint32_t x = (uint32_t) (seed + (uint64_t) c.env);
-    d.mt[e] = x;
+    GS(mt, 0) = x;
     for (int i = 1; i < 624; i++) {
         x = 1812433253u * (x ^ (x >> 30)) + (uint32_t) i;
-        d.mt[(size_t) i * n + e] = x;
+        GS(mt, i) = x;
     }
     d.mt_idx[e] = 624;
     for (int b = 0; b < c_skel.nb; b++) {
@@ -1186,10 +1197,7 @@ __global__ __launch_bounds__(64) void k_env_init(EnvDev d, uint64_t seed) {
 }
 
 __global__ __launch_bounds__(64) void k_env_poses(EnvDev d, float *out) {
-    Ctx c;
-    c.d = d;
-    c.lane = threadIdx.x;
-    c.env = blockIdx.x * 64 + threadIdx.x;
+    Ctx c = make_ctx(d, nullptr);
     if (c.env >= d.n_real) return;
     const bool pending = (d.flags[c.env] & EVM_FLAG_PENDING) != 0;
     M33 E = m33(f3(GS(E, 0), GS(E, 1), GS(E, 2)), f3(GS(E, 3), GS(E, 4), GS(E, 5)), f3(GS(E, 6), GS(E, 7), GS(E, 8)));
