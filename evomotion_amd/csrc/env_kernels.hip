@@ -156,7 +156,7 @@ DEV void row_setup(F3 ax, F3 relA, F3 relB, const BodyK &A, const BodyK &B, floa
     rhs = err * jd + (0.f - rel_vel) * jd;
 }
 
-template <bool LIN>
+template <bool LIN, bool BOUNDED>
 DEV float row_iter(F3 ax, F3 relA, F3 relB, BodyD &A, BodyD &B, float jd, float rhs, float lo, float hi,
                    float &applied) {
     F3 c1, c2;
@@ -177,17 +177,30 @@ DEV float row_iter(F3 ax, F3 relA, F3 relB, BodyD &A, BodyD &B, float jd, float 
     dI -= d1 * jd;
     dI -= d2 * jd;
     const float sum = applied + dI;
-    if (sum < lo) { dI = lo - applied; applied = lo; }
-    else if (sum > hi) { dI = hi - applied; applied = hi; }
-    else applied = sum;
+    if (BOUNDED) {
+        if (sum < lo) { dI = lo - applied; applied = lo; }
+        else if (sum > hi) { dI = hi - applied; applied = hi; }
+        else applied = sum;
+    } else applied = sum;
     if (LIN) {
-        A.dl = A.dl + (ax * A.im) * dI;
-        B.dl = B.dl + ((-ax) * B.im) * dI;
+        A.dl = A.dl + ax * (A.im * dI);
+        B.dl = B.dl - ax * (B.im * dI);
     }
     A.da = A.da + angA * dI;
     B.da = B.da + angB * dI;
     return dI;
 }
+
+// register block holding one constraint's scratch record (loaded one constraint ahead of its use)
+struct Blk42 {
+    float v[42];
+};
+DEV void blk_load42(const Ctx &c, int slot, Blk42 &b) {
+    const float *p = c.t.scratch + (slot << 6) + c.lane;
+#pragma unroll
+    for (int i = 0; i < 42; i++) b.v[i] = p[i << 6];
+}
+DEV F3 v3(const float *v, int i) { return f3(v[i], v[i + 1], v[i + 2]); }
 
 // ---------------------------------------------------------------------------------------------
 // hinge  (btHingeConstraint::getInfo2InternalUsingFrameOffset)
@@ -260,22 +273,22 @@ DEV void hinge_setup(const Ctx &c, int hi) {
     for (int r = 0; r < 6; r++) { SC(s + 15 + r) = jd[r]; SC(s + 21 + r) = rhs[r]; SC(s + 29 + r) = 0.f; }
     SC(s + 27) = lo; SC(s + 28) = hi_;
 }
-DEV float hinge_iter(const Ctx &c, int hi) {
+DEV float hinge_solve(const Ctx &c, int hi, const Blk42 &k) {
     const EvmHingeC &H = c_skel.hinge[hi];
     const int s = c_skel.sc_h + EVM_H_STRIDE * hi;
-    const F3 relA = SC3(s + 0), relB = SC3(s + 3), p = SC3(s + 6), q = SC3(s + 9), ax1 = SC3(s + 12);
-    float jd[6], rhs[6], ap[6];
+    const F3 relA = v3(k.v, 0), relB = v3(k.v, 3), p = v3(k.v, 6), q = v3(k.v, 9), ax1 = v3(k.v, 12);
+    float ap[6];
 #pragma unroll
-    for (int r = 0; r < 6; r++) { jd[r] = SC(s + 15 + r); rhs[r] = SC(s + 21 + r); ap[r] = SC(s + 29 + r); }
-    const float lo = SC(s + 27), hi_ = SC(s + 28);
+    for (int r = 0; r < 6; r++) ap[r] = k.v[29 + r];
+    const float lo = k.v[27], hi_ = k.v[28];
     BodyD A = load_bodyd(c, H.a), B = load_bodyd(c, H.b);
     float res = 0.f;
-    res = fmaxf(res, fabsf(row_iter<true>(p, relA, relB, A, B, jd[0], rhs[0], -EVM_INF, EVM_INF, ap[0])));
-    res = fmaxf(res, fabsf(row_iter<true>(q, relA, relB, A, B, jd[1], rhs[1], -EVM_INF, EVM_INF, ap[1])));
-    res = fmaxf(res, fabsf(row_iter<true>(ax1, relA, relB, A, B, jd[2], rhs[2], -EVM_INF, EVM_INF, ap[2])));
-    res = fmaxf(res, fabsf(row_iter<false>(p, relA, relB, A, B, jd[3], rhs[3], -EVM_INF, EVM_INF, ap[3])));
-    res = fmaxf(res, fabsf(row_iter<false>(q, relA, relB, A, B, jd[4], rhs[4], -EVM_INF, EVM_INF, ap[4])));
-    if (jd[5] != 0.f) res = fmaxf(res, fabsf(row_iter<false>(ax1, relA, relB, A, B, jd[5], rhs[5], lo, hi_, ap[5])));
+    res = fmaxf(res, fabsf(row_iter<true, false>(p, relA, relB, A, B, k.v[15], k.v[21], 0.f, 0.f, ap[0])));
+    res = fmaxf(res, fabsf(row_iter<true, false>(q, relA, relB, A, B, k.v[16], k.v[22], 0.f, 0.f, ap[1])));
+    res = fmaxf(res, fabsf(row_iter<true, false>(ax1, relA, relB, A, B, k.v[17], k.v[23], 0.f, 0.f, ap[2])));
+    res = fmaxf(res, fabsf(row_iter<false, false>(p, relA, relB, A, B, k.v[18], k.v[24], 0.f, 0.f, ap[3])));
+    res = fmaxf(res, fabsf(row_iter<false, false>(q, relA, relB, A, B, k.v[19], k.v[25], 0.f, 0.f, ap[4])));
+    if (k.v[20] != 0.f) res = fmaxf(res, fabsf(row_iter<false, true>(ax1, relA, relB, A, B, k.v[20], k.v[26], lo, hi_, ap[5])));
     store_bodyd(c, H.a, A); store_bodyd(c, H.b, B);
 #pragma unroll
     for (int r = 0; r < 6; r++) SC(s + 29 + r) = ap[r];
@@ -340,21 +353,21 @@ DEV void fixed_setup(const Ctx &c, int fi) {
 #pragma unroll
     for (int r = 0; r < 6; r++) { SC(s + 24 + r) = jd[r]; SC(s + 30 + r) = rhs[r]; SC(s + 36 + r) = 0.f; }
 }
-DEV float fixed_iter(const Ctx &c, int fi) {
+DEV float fixed_solve(const Ctx &c, int fi, const Blk42 &k) {
     const EvmFixedC &X = c_skel.fixed[fi];
     const int s = c_skel.sc_f + EVM_F_STRIDE * fi;
-    const F3 relA = SC3(s + 0), relB = SC3(s + 3);
-    float jd[6], rhs[6], ap[6];
+    const F3 relA = v3(k.v, 0), relB = v3(k.v, 3);
+    float ap[6];
 #pragma unroll
-    for (int r = 0; r < 6; r++) { jd[r] = SC(s + 24 + r); rhs[r] = SC(s + 30 + r); ap[r] = SC(s + 36 + r); }
+    for (int r = 0; r < 6; r++) ap[r] = k.v[36 + r];
     BodyD A = load_bodyd(c, X.a), B = load_bodyd(c, X.b);
     float res = 0.f;
 #pragma unroll
     for (int r = 0; r < 3; r++)
-        res = fmaxf(res, fabsf(row_iter<false>(SC3(s + 6 + 3 * r), relA, relB, A, B, jd[r], rhs[r], -EVM_INF, EVM_INF, ap[r])));
+        res = fmaxf(res, fabsf(row_iter<false, false>(v3(k.v, 6 + 3 * r), relA, relB, A, B, k.v[24 + r], k.v[30 + r], 0.f, 0.f, ap[r])));
 #pragma unroll
     for (int r = 0; r < 3; r++)
-        res = fmaxf(res, fabsf(row_iter<true>(SC3(s + 15 + 3 * r), relA, relB, A, B, jd[3 + r], rhs[3 + r], -EVM_INF, EVM_INF, ap[3 + r])));
+        res = fmaxf(res, fabsf(row_iter<true, false>(v3(k.v, 15 + 3 * r), relA, relB, A, B, k.v[27 + r], k.v[33 + r], 0.f, 0.f, ap[3 + r])));
     store_bodyd(c, X.a, A); store_bodyd(c, X.b, B);
 #pragma unroll
     for (int r = 0; r < 6; r++) SC(s + 36 + r) = ap[r];
@@ -480,23 +493,36 @@ DEV void slider_setup(const Ctx &c, int mi, bool powered_in, float target_vel) {
     SC(s + 33) = lo; SC(s + 34) = hi_;
     SC(c_skel.sc_mobs + 4 * mi) = lin_pos;  // btSliderConstraint::getLinearPos(), MuscleState
 }
-DEV float slider_iter(const Ctx &c, int mi) {
+// one muscle = slider + p2p_a + p2p_b: 41 + 15 + 15 scratch floats, loaded one muscle ahead
+struct MusBlk {
+    float s[41];
+    float p0[15], p1[15];
+};
+DEV void mus_load(const Ctx &c, int mi, MusBlk &b) {
+    const float *ps = c.t.scratch + ((c_skel.sc_s + EVM_S_STRIDE * mi) << 6) + c.lane;
+#pragma unroll
+    for (int i = 0; i < 41; i++) b.s[i] = ps[i << 6];
+    const float *pp = c.t.scratch + ((c_skel.sc_p + EVM_P_STRIDE * 2 * mi) << 6) + c.lane;
+#pragma unroll
+    for (int i = 0; i < 15; i++) { b.p0[i] = pp[i << 6]; b.p1[i] = pp[(15 + i) << 6]; }
+}
+DEV float slider_solve(const Ctx &c, int mi, const MusBlk &k) {
     const EvmMuscleC &M = c_skel.muscle[mi];
     const int s = c_skel.sc_s + EVM_S_STRIDE * mi;
-    const F3 p = SC3(s + 0), q = SC3(s + 3), ax1 = SC3(s + 6), p2 = SC3(s + 9), q2 = SC3(s + 12);
-    const F3 relA = SC3(s + 15), relB = SC3(s + 18);
-    float jd[6], rhs[6], ap[6];
+    const F3 p = v3(k.s, 0), q = v3(k.s, 3), ax1 = v3(k.s, 6), p2 = v3(k.s, 9), q2 = v3(k.s, 12);
+    const F3 relA = v3(k.s, 15), relB = v3(k.s, 18);
+    float ap[6];
 #pragma unroll
-    for (int r = 0; r < 6; r++) { jd[r] = SC(s + 21 + r); rhs[r] = SC(s + 27 + r); ap[r] = SC(s + 35 + r); }
-    const float lo = SC(s + 33), hi_ = SC(s + 34);
+    for (int r = 0; r < 6; r++) ap[r] = k.s[35 + r];
+    const float lo = k.s[33], hi_ = k.s[34];
     BodyD A = load_bodyd(c, M.sa), B = load_bodyd(c, M.sb);
     float res = 0.f;
-    res = fmaxf(res, fabsf(row_iter<false>(p, relA, relB, A, B, jd[0], rhs[0], -EVM_INF, EVM_INF, ap[0])));
-    res = fmaxf(res, fabsf(row_iter<false>(q, relA, relB, A, B, jd[1], rhs[1], -EVM_INF, EVM_INF, ap[1])));
-    res = fmaxf(res, fabsf(row_iter<true>(p2, relA, relB, A, B, jd[2], rhs[2], -EVM_INF, EVM_INF, ap[2])));
-    res = fmaxf(res, fabsf(row_iter<true>(q2, relA, relB, A, B, jd[3], rhs[3], -EVM_INF, EVM_INF, ap[3])));
-    if (jd[4] != 0.f) res = fmaxf(res, fabsf(row_iter<true>(ax1, relA, relB, A, B, jd[4], rhs[4], lo, hi_, ap[4])));
-    if (jd[5] != 0.f) res = fmaxf(res, fabsf(row_iter<false>(ax1, relA, relB, A, B, jd[5], rhs[5], -EVM_INF, EVM_INF, ap[5])));
+    res = fmaxf(res, fabsf(row_iter<false, false>(p, relA, relB, A, B, k.s[21], k.s[27], 0.f, 0.f, ap[0])));
+    res = fmaxf(res, fabsf(row_iter<false, false>(q, relA, relB, A, B, k.s[22], k.s[28], 0.f, 0.f, ap[1])));
+    res = fmaxf(res, fabsf(row_iter<true, false>(p2, relA, relB, A, B, k.s[23], k.s[29], 0.f, 0.f, ap[2])));
+    res = fmaxf(res, fabsf(row_iter<true, false>(q2, relA, relB, A, B, k.s[24], k.s[30], 0.f, 0.f, ap[3])));
+    if (k.s[25] != 0.f) res = fmaxf(res, fabsf(row_iter<true, true>(ax1, relA, relB, A, B, k.s[25], k.s[31], lo, hi_, ap[4])));
+    if (k.s[26] != 0.f) res = fmaxf(res, fabsf(row_iter<false, false>(ax1, relA, relB, A, B, k.s[26], k.s[32], 0.f, 0.f, ap[5])));
     store_bodyd(c, M.sa, A); store_bodyd(c, M.sb, B);
 #pragma unroll
     for (int r = 0; r < 6; r++) SC(s + 35 + r) = ap[r];
@@ -525,22 +551,51 @@ DEV void p2p_setup(const Ctx &c, int mi, int which) {
     SSC3(s + 0, a1); SSC3(s + 3, a2);
     SC(s + 12) = 0.f; SC(s + 13) = 0.f; SC(s + 14) = 0.f;
 }
-DEV float p2p_iter(const Ctx &c, int mi, int which) {
+// p2p rows along the world axes.  The pivot in the attach sphere is the origin (muscle.cpp:52,55), so the
+// sphere-side lever arm a2 is exactly zero: body B only takes the linear part.
+DEV float p2p_solve(const Ctx &c, int mi, int which, const float *k) {
     const EvmMuscleC &M = c_skel.muscle[mi];
     const int ba = which ? M.mb : M.ma, bb = which ? M.sb : M.sa;
     const int s = c_skel.sc_p + EVM_P_STRIDE * (2 * mi + which);
-    const F3 a1 = SC3(s + 0), a2 = SC3(s + 3);
-    float jd[3], rhs[3], ap[3];
-#pragma unroll
-    for (int r = 0; r < 3; r++) { jd[r] = SC(s + 6 + r); rhs[r] = SC(s + 9 + r); ap[r] = SC(s + 12 + r); }
-    BodyD A = load_bodyd(c, ba), B = load_bodyd(c, bb);
+    const F3 a1 = v3(k, 0);
+    BodyD A = load_bodyd(c, ba);
+    F3 dlB = f3(LDV(bb, 0), LDV(bb, 1), LDV(bb, 2));
+    const float imB = c_skel.body[bb].inv_mass;
+    float ap0 = k[12], ap1 = k[13], ap2 = k[14];
     float res = 0.f;
-    res = fmaxf(res, fabsf(row_iter<true>(f3(1.f, 0.f, 0.f), a1, a2, A, B, jd[0], rhs[0], -EVM_INF, EVM_INF, ap[0])));
-    res = fmaxf(res, fabsf(row_iter<true>(f3(0.f, 1.f, 0.f), a1, a2, A, B, jd[1], rhs[1], -EVM_INF, EVM_INF, ap[1])));
-    res = fmaxf(res, fabsf(row_iter<true>(f3(0.f, 0.f, 1.f), a1, a2, A, B, jd[2], rhs[2], -EVM_INF, EVM_INF, ap[2])));
-    store_bodyd(c, ba, A); store_bodyd(c, bb, B);
-#pragma unroll
-    for (int r = 0; r < 3; r++) SC(s + 12 + r) = ap[r];
+    {   // x: c1 = a1 x e_x = (0, a1.z, -a1.y)
+        const F3 angA = f3(A.I.xy * a1.z - A.I.xz * a1.y, A.I.yy * a1.z - A.I.yz * a1.y, A.I.yz * a1.z - A.I.zz * a1.y);
+        const float d1 = A.dl.x + (a1.z * A.da.y - a1.y * A.da.z);
+        float dI = k[9];
+        dI -= d1 * k[6];
+        dI -= (-dlB.x) * k[6];
+        ap0 += dI;
+        A.dl.x += A.im * dI; A.da = A.da + angA * dI; dlB.x -= imB * dI;
+        res = fmaxf(res, fabsf(dI));
+    }
+    {   // y: c1 = a1 x e_y = (-a1.z, 0, a1.x)
+        const F3 angA = f3(A.I.xz * a1.x - A.I.xx * a1.z, A.I.yz * a1.x - A.I.xy * a1.z, A.I.zz * a1.x - A.I.xz * a1.z);
+        const float d1 = A.dl.y + (a1.x * A.da.z - a1.z * A.da.x);
+        float dI = k[10];
+        dI -= d1 * k[7];
+        dI -= (-dlB.y) * k[7];
+        ap1 += dI;
+        A.dl.y += A.im * dI; A.da = A.da + angA * dI; dlB.y -= imB * dI;
+        res = fmaxf(res, fabsf(dI));
+    }
+    {   // z: c1 = a1 x e_z = (a1.y, -a1.x, 0)
+        const F3 angA = f3(A.I.xx * a1.y - A.I.xy * a1.x, A.I.xy * a1.y - A.I.yy * a1.x, A.I.xz * a1.y - A.I.yz * a1.x);
+        const float d1 = A.dl.z + (a1.y * A.da.x - a1.x * A.da.y);
+        float dI = k[11];
+        dI -= d1 * k[8];
+        dI -= (-dlB.z) * k[8];
+        ap2 += dI;
+        A.dl.z += A.im * dI; A.da = A.da + angA * dI; dlB.z -= imB * dI;
+        res = fmaxf(res, fabsf(dI));
+    }
+    store_bodyd(c, ba, A);
+    LDV(bb, 0) = dlB.x; LDV(bb, 1) = dlB.y; LDV(bb, 2) = dlB.z;
+    SC(s + 12) = ap0; SC(s + 13) = ap1; SC(s + 14) = ap2;
     return res;
 }
 
@@ -1042,17 +1097,42 @@ DEV void physics_step(const Ctx &c, int flags) {
     }
 
     // ---- projected Gauss-Seidel sweeps ----
+    // Each visit needs ~40-70 scratch floats; a wave alone on its CU has nothing to overlap a load round trip
+    // with, so the record of constraint i+1 is requested before constraint i is solved (two register blocks,
+    // ping-pong, loop unrolled by two so no block is ever copied).
+    auto con_slot = [&](int ci) { return c_skel.con_type[ci] == 0 ? c_skel.sc_h + EVM_H_STRIDE * c_skel.con_idx[ci]
+                                                                 : c_skel.sc_f + EVM_F_STRIDE * c_skel.con_idx[ci]; };
+    auto con_solve = [&](int ci, const Blk42 &k) {
+        return c_skel.con_type[ci] == 0 ? hinge_solve(c, c_skel.con_idx[ci], k) : fixed_solve(c, c_skel.con_idx[ci], k);
+    };
+    auto mus_solve = [&](int mi, const MusBlk &k) {
+        float r = slider_solve(c, mi, k);
+        r = fmaxf(r, p2p_solve(c, mi, 0, k.p0));
+        return fmaxf(r, p2p_solve(c, mi, 1, k.p1));
+    };
+    const int ncon = c_skel.ncon, nmus = c_skel.nmus;
     float res = 0.f;
     for (int it = 0; it < NUM_ITER; it++) {
         res = 0.f;
-        for (int ci = 0; ci < c_skel.ncon; ci++) {
-            if (c_skel.con_type[ci] == 0) res = fmaxf(res, hinge_iter(c, c_skel.con_idx[ci]));
-            else res = fmaxf(res, fixed_iter(c, c_skel.con_idx[ci]));
+        if (ncon > 0) {
+            Blk42 ka, kb;
+            blk_load42(c, con_slot(0), ka);
+            for (int ci = 0; ci < ncon; ci += 2) {
+                if (ci + 1 < ncon) blk_load42(c, con_slot(ci + 1), kb);
+                res = fmaxf(res, con_solve(ci, ka));
+                if (ci + 2 < ncon) blk_load42(c, con_slot(ci + 2), ka);
+                if (ci + 1 < ncon) res = fmaxf(res, con_solve(ci + 1, kb));
+            }
         }
-        for (int mi = 0; mi < c_skel.nmus; mi++) {
-            res = fmaxf(res, slider_iter(c, mi));
-            res = fmaxf(res, p2p_iter(c, mi, 0));
-            res = fmaxf(res, p2p_iter(c, mi, 1));
+        if (nmus > 0) {
+            MusBlk ma, mb;
+            mus_load(c, 0, ma);
+            for (int mi = 0; mi < nmus; mi += 2) {
+                if (mi + 1 < nmus) mus_load(c, mi + 1, mb);
+                res = fmaxf(res, mus_solve(mi, ma));
+                if (mi + 2 < nmus) mus_load(c, mi + 2, ma);
+                if (mi + 1 < nmus) res = fmaxf(res, mus_solve(mi + 1, mb));
+            }
         }
         for (int m = 0; m < c_skel.nm; m++)
             if (cmask & (1u << m)) res = fmaxf(res, contact_iter(c, m, GS(mfn, m)));
