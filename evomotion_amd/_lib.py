@@ -56,6 +56,7 @@ def _load():
     lib.evm_skeleton_probe.argtypes = [cp, ip, fp]
     lib.evm_env_get_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_longlong)]
     lib.evm_env_clear_stats.argtypes = [vp]
+    lib.evm_env_get_stamps.argtypes = [vp, ctypes.POINTER(ctypes.c_ulonglong)]
     lib.evm_policy_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(vp)]
     lib.evm_policy_destroy.argtypes = [vp]
     lib.evm_policy_destroy.restype = None

@@ -27,6 +27,7 @@ struct EnvDev {
     int *mt_idx;                    // [n]
     float *scratch;                 // [sc_total][n] per-step constraint data
     float *diag;                    // [2][n]
+    unsigned long long *stamps;     // [n/64][16] phase clock stamps (diagnostic builds with -DEVM_STAMPS only)
     int *stat;                      // [2][n]     do_step transitions emitted, resets started (rollout form)
 };
 

@@ -104,7 +104,7 @@ int evm_env_create(const char *skeleton_path, int n_envs, int device, uint64_t s
         {(void **) &env->d.flags, 1}, {(void **) &env->d.curr_step, 1}, {(void **) &env->d.remaining, 1},
         {(void **) &env->d.settle_left, 1}, {(void **) &env->d.E, 9}, {(void **) &env->d.iinv_stale, 6u * S.nb},
         {(void **) &env->d.mt, 624}, {(void **) &env->d.mt_idx, 1}, {(void **) &env->d.scratch, (size_t) S.sc_total},
-        {(void **) &env->d.diag, 2}, {(void **) &env->d.stat, 2}};
+        {(void **) &env->d.diag, 2}, {(void **) &env->d.stat, 2}, {(void **) &env->d.stamps, 1}};  // stamps: 16 u64 per tile = 128 B <= 256 B
     size_t total = 0;
     for (auto &s : segs) total += s.count * n * 4;
     he = hipMalloc(&env->arena, total);
@@ -404,6 +404,12 @@ int evm_env_get_stats(EvmEnv *env, long long *h_out) {
     HIP_TRY(hipMemcpy(h.data(), env->d.stat, h.size() * 4, hipMemcpyDeviceToHost));
     h_out[0] = h_out[1] = 0;
     for (int e = 0; e < env->d.n_real; e++) { h_out[0] += h[tix(2, 0, e)]; h_out[1] += h[tix(2, 1, e)]; }
+    return EVM_OK;
+}
+int evm_env_get_stamps(EvmEnv *env, unsigned long long *h_out /* [n_tiles, 16] */) {
+    if (!env || !h_out) return fail(EVM_E_INVALID, "null argument");
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(h_out, env->d.stamps, (size_t) (env->d.n / 64) * 16 * 8, hipMemcpyDeviceToHost));
     return EVM_OK;
 }
 int evm_env_clear_stats(EvmEnv *env) {

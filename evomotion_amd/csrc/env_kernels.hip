@@ -34,12 +34,15 @@ __constant__ EvmSkelC c_skel;
 #define WARM_F 0.85f
 #define SPLIT_THR_F (-0.04f)
 #define SPLIT_TURN_ERP_F 0.1f
+#ifndef NUM_ITER
 #define NUM_ITER 10
+#endif
 
 struct Ctx {
     EnvDev d;  // array bases
     EnvDev t;  // the same arrays advanced to this wave's 64-env tile: element (slot k, lane) = t.arr[k * 64 + lane]
     int env, lane;
+    int wave;  // 0..EVM_NW-1 inside the step kernel (wave-uniform), 0 elsewhere
     float *lds;
 };
 
@@ -50,8 +53,9 @@ DEV Ctx make_ctx(const EnvDev &d, float *lds) {
     Ctx c;
     c.d = d;
     c.t = d;
-    c.lane = threadIdx.x;
-    c.env = blockIdx.x * 64 + threadIdx.x;
+    c.lane = threadIdx.x & 63;
+    c.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    c.env = blockIdx.x * 64 + c.lane;
     c.lds = lds;
     const size_t tile = (size_t) blockIdx.x * 64;
     const int nb = c_skel.nb, nm = c_skel.nm, nmus = c_skel.nmus > 0 ? c_skel.nmus : 1;
@@ -117,14 +121,15 @@ DEV BodyK load_bodyk(const Ctx &c, int b) {
     k.im = c_skel.body[b].inv_mass;
     return k;
 }
-DEV BodyD load_bodyd(const Ctx &c, int b) {
+DEV BodyD load_bodyd(const Ctx &c, int b, float im) {
     BodyD k;
     k.dl = f3(LDV(b, 0), LDV(b, 1), LDV(b, 2));
     k.da = f3(LDV(b, 3), LDV(b, 4), LDV(b, 5));
     k.I = lds_inertia(c, b);
-    k.im = c_skel.body[b].inv_mass;
+    k.im = im;
     return k;
 }
+DEV BodyD load_bodyd(const Ctx &c, int b) { return load_bodyd(c, b, c_skel.body[b].inv_mass); }
 DEV void store_bodyd(const Ctx &c, int b, const BodyD &k) {
     LDV(b, 0) = k.dl.x; LDV(b, 1) = k.dl.y; LDV(b, 2) = k.dl.z;
     LDV(b, 3) = k.da.x; LDV(b, 4) = k.da.y; LDV(b, 5) = k.da.z;
@@ -195,10 +200,14 @@ DEV float row_iter(F3 ax, F3 relA, F3 relB, BodyD &A, BodyD &B, float jd, float 
 struct Blk42 {
     float v[42];
 };
-DEV void blk_load42(const Ctx &c, int slot, Blk42 &b) {
-    const float *p = c.t.scratch + (slot << 6) + c.lane;
+DEV void blk_load(const Ctx &c, const EvmVisitC &v, Blk42 &b) {
+    const float *p = c.t.scratch + (v.slot << 6) + c.lane;
 #pragma unroll
-    for (int i = 0; i < 42; i++) b.v[i] = p[i << 6];
+    for (int i = 0; i < 15; i++) b.v[i] = p[i << 6];
+    if (v.nslots > 15) {  // wave-uniform: p2p records are 15 floats, the others 35..42
+#pragma unroll
+        for (int i = 15; i < 42; i++) b.v[i] = p[i << 6];
+    }
 }
 DEV F3 v3(const float *v, int i) { return f3(v[i], v[i + 1], v[i + 2]); }
 
@@ -273,15 +282,14 @@ DEV void hinge_setup(const Ctx &c, int hi) {
     for (int r = 0; r < 6; r++) { SC(s + 15 + r) = jd[r]; SC(s + 21 + r) = rhs[r]; SC(s + 29 + r) = 0.f; }
     SC(s + 27) = lo; SC(s + 28) = hi_;
 }
-DEV float hinge_solve(const Ctx &c, int hi, const Blk42 &k) {
-    const EvmHingeC &H = c_skel.hinge[hi];
-    const int s = c_skel.sc_h + EVM_H_STRIDE * hi;
+DEV float hinge_solve(const Ctx &c, const EvmVisitC &V, const Blk42 &k) {
+    const int s = V.slot;
     const F3 relA = v3(k.v, 0), relB = v3(k.v, 3), p = v3(k.v, 6), q = v3(k.v, 9), ax1 = v3(k.v, 12);
     float ap[6];
 #pragma unroll
     for (int r = 0; r < 6; r++) ap[r] = k.v[29 + r];
     const float lo = k.v[27], hi_ = k.v[28];
-    BodyD A = load_bodyd(c, H.a), B = load_bodyd(c, H.b);
+    BodyD A = load_bodyd(c, V.a, V.imA), B = load_bodyd(c, V.b, V.imB);
     float res = 0.f;
     res = fmaxf(res, fabsf(row_iter<true, false>(p, relA, relB, A, B, k.v[15], k.v[21], 0.f, 0.f, ap[0])));
     res = fmaxf(res, fabsf(row_iter<true, false>(q, relA, relB, A, B, k.v[16], k.v[22], 0.f, 0.f, ap[1])));
@@ -289,7 +297,7 @@ DEV float hinge_solve(const Ctx &c, int hi, const Blk42 &k) {
     res = fmaxf(res, fabsf(row_iter<false, false>(p, relA, relB, A, B, k.v[18], k.v[24], 0.f, 0.f, ap[3])));
     res = fmaxf(res, fabsf(row_iter<false, false>(q, relA, relB, A, B, k.v[19], k.v[25], 0.f, 0.f, ap[4])));
     if (k.v[20] != 0.f) res = fmaxf(res, fabsf(row_iter<false, true>(ax1, relA, relB, A, B, k.v[20], k.v[26], lo, hi_, ap[5])));
-    store_bodyd(c, H.a, A); store_bodyd(c, H.b, B);
+    store_bodyd(c, V.a, A); store_bodyd(c, V.b, B);
 #pragma unroll
     for (int r = 0; r < 6; r++) SC(s + 29 + r) = ap[r];
     return res;
@@ -353,14 +361,13 @@ DEV void fixed_setup(const Ctx &c, int fi) {
 #pragma unroll
     for (int r = 0; r < 6; r++) { SC(s + 24 + r) = jd[r]; SC(s + 30 + r) = rhs[r]; SC(s + 36 + r) = 0.f; }
 }
-DEV float fixed_solve(const Ctx &c, int fi, const Blk42 &k) {
-    const EvmFixedC &X = c_skel.fixed[fi];
-    const int s = c_skel.sc_f + EVM_F_STRIDE * fi;
+DEV float fixed_solve(const Ctx &c, const EvmVisitC &V, const Blk42 &k) {
+    const int s = V.slot;
     const F3 relA = v3(k.v, 0), relB = v3(k.v, 3);
     float ap[6];
 #pragma unroll
     for (int r = 0; r < 6; r++) ap[r] = k.v[36 + r];
-    BodyD A = load_bodyd(c, X.a), B = load_bodyd(c, X.b);
+    BodyD A = load_bodyd(c, V.a, V.imA), B = load_bodyd(c, V.b, V.imB);
     float res = 0.f;
 #pragma unroll
     for (int r = 0; r < 3; r++)
@@ -368,7 +375,7 @@ DEV float fixed_solve(const Ctx &c, int fi, const Blk42 &k) {
 #pragma unroll
     for (int r = 0; r < 3; r++)
         res = fmaxf(res, fabsf(row_iter<true, false>(v3(k.v, 15 + 3 * r), relA, relB, A, B, k.v[27 + r], k.v[33 + r], 0.f, 0.f, ap[3 + r])));
-    store_bodyd(c, X.a, A); store_bodyd(c, X.b, B);
+    store_bodyd(c, V.a, A); store_bodyd(c, V.b, B);
 #pragma unroll
     for (int r = 0; r < 6; r++) SC(s + 36 + r) = ap[r];
     return res;
@@ -493,37 +500,24 @@ DEV void slider_setup(const Ctx &c, int mi, bool powered_in, float target_vel) {
     SC(s + 33) = lo; SC(s + 34) = hi_;
     SC(c_skel.sc_mobs + 4 * mi) = lin_pos;  // btSliderConstraint::getLinearPos(), MuscleState
 }
-// one muscle = slider + p2p_a + p2p_b: 41 + 15 + 15 scratch floats, loaded one muscle ahead
-struct MusBlk {
-    float s[41];
-    float p0[15], p1[15];
-};
-DEV void mus_load(const Ctx &c, int mi, MusBlk &b) {
-    const float *ps = c.t.scratch + ((c_skel.sc_s + EVM_S_STRIDE * mi) << 6) + c.lane;
-#pragma unroll
-    for (int i = 0; i < 41; i++) b.s[i] = ps[i << 6];
-    const float *pp = c.t.scratch + ((c_skel.sc_p + EVM_P_STRIDE * 2 * mi) << 6) + c.lane;
-#pragma unroll
-    for (int i = 0; i < 15; i++) { b.p0[i] = pp[i << 6]; b.p1[i] = pp[(15 + i) << 6]; }
-}
-DEV float slider_solve(const Ctx &c, int mi, const MusBlk &k) {
-    const EvmMuscleC &M = c_skel.muscle[mi];
-    const int s = c_skel.sc_s + EVM_S_STRIDE * mi;
-    const F3 p = v3(k.s, 0), q = v3(k.s, 3), ax1 = v3(k.s, 6), p2 = v3(k.s, 9), q2 = v3(k.s, 12);
-    const F3 relA = v3(k.s, 15), relB = v3(k.s, 18);
+DEV float slider_solve(const Ctx &c, const EvmVisitC &V, const Blk42 &kk) {
+    const float *ks = kk.v;
+    const int s = V.slot;
+    const F3 p = v3(ks, 0), q = v3(ks, 3), ax1 = v3(ks, 6), p2 = v3(ks, 9), q2 = v3(ks, 12);
+    const F3 relA = v3(ks, 15), relB = v3(ks, 18);
     float ap[6];
 #pragma unroll
-    for (int r = 0; r < 6; r++) ap[r] = k.s[35 + r];
-    const float lo = k.s[33], hi_ = k.s[34];
-    BodyD A = load_bodyd(c, M.sa), B = load_bodyd(c, M.sb);
+    for (int r = 0; r < 6; r++) ap[r] = ks[35 + r];
+    const float lo = ks[33], hi_ = ks[34];
+    BodyD A = load_bodyd(c, V.a, V.imA), B = load_bodyd(c, V.b, V.imB);
     float res = 0.f;
-    res = fmaxf(res, fabsf(row_iter<false, false>(p, relA, relB, A, B, k.s[21], k.s[27], 0.f, 0.f, ap[0])));
-    res = fmaxf(res, fabsf(row_iter<false, false>(q, relA, relB, A, B, k.s[22], k.s[28], 0.f, 0.f, ap[1])));
-    res = fmaxf(res, fabsf(row_iter<true, false>(p2, relA, relB, A, B, k.s[23], k.s[29], 0.f, 0.f, ap[2])));
-    res = fmaxf(res, fabsf(row_iter<true, false>(q2, relA, relB, A, B, k.s[24], k.s[30], 0.f, 0.f, ap[3])));
-    if (k.s[25] != 0.f) res = fmaxf(res, fabsf(row_iter<true, true>(ax1, relA, relB, A, B, k.s[25], k.s[31], lo, hi_, ap[4])));
-    if (k.s[26] != 0.f) res = fmaxf(res, fabsf(row_iter<false, false>(ax1, relA, relB, A, B, k.s[26], k.s[32], 0.f, 0.f, ap[5])));
-    store_bodyd(c, M.sa, A); store_bodyd(c, M.sb, B);
+    res = fmaxf(res, fabsf(row_iter<false, false>(p, relA, relB, A, B, ks[21], ks[27], 0.f, 0.f, ap[0])));
+    res = fmaxf(res, fabsf(row_iter<false, false>(q, relA, relB, A, B, ks[22], ks[28], 0.f, 0.f, ap[1])));
+    res = fmaxf(res, fabsf(row_iter<true, false>(p2, relA, relB, A, B, ks[23], ks[29], 0.f, 0.f, ap[2])));
+    res = fmaxf(res, fabsf(row_iter<true, false>(q2, relA, relB, A, B, ks[24], ks[30], 0.f, 0.f, ap[3])));
+    if (ks[25] != 0.f) res = fmaxf(res, fabsf(row_iter<true, true>(ax1, relA, relB, A, B, ks[25], ks[31], lo, hi_, ap[4])));
+    if (ks[26] != 0.f) res = fmaxf(res, fabsf(row_iter<false, false>(ax1, relA, relB, A, B, ks[26], ks[32], 0.f, 0.f, ap[5])));
+    store_bodyd(c, V.a, A); store_bodyd(c, V.b, B);
 #pragma unroll
     for (int r = 0; r < 6; r++) SC(s + 35 + r) = ap[r];
     return res;
@@ -553,14 +547,14 @@ DEV void p2p_setup(const Ctx &c, int mi, int which) {
 }
 // p2p rows along the world axes.  The pivot in the attach sphere is the origin (muscle.cpp:52,55), so the
 // sphere-side lever arm a2 is exactly zero: body B only takes the linear part.
-DEV float p2p_solve(const Ctx &c, int mi, int which, const float *k) {
-    const EvmMuscleC &M = c_skel.muscle[mi];
-    const int ba = which ? M.mb : M.ma, bb = which ? M.sb : M.sa;
-    const int s = c_skel.sc_p + EVM_P_STRIDE * (2 * mi + which);
+DEV float p2p_solve(const Ctx &c, const EvmVisitC &V, const Blk42 &kk) {
+    const float *k = kk.v;
+    const int ba = V.a, bb = V.b;
+    const int s = V.slot;
     const F3 a1 = v3(k, 0);
-    BodyD A = load_bodyd(c, ba);
+    BodyD A = load_bodyd(c, ba, V.imA);
     F3 dlB = f3(LDV(bb, 0), LDV(bb, 1), LDV(bb, 2));
-    const float imB = c_skel.body[bb].inv_mass;
+    const float imB = V.imB;
     float ap0 = k[12], ap1 = k[13], ap2 = k[14];
     float res = 0.f;
     {   // x: c1 = a1 x e_x = (0, a1.z, -a1.y)
@@ -968,9 +962,9 @@ DEV void observe(const Ctx &c, float *obs, float *reward, uint8_t *done) {
     const float PI_F = (float) 3.14159265358979323846;
     const int root = c_skel.root;
     const F3 root_ms = SC3(c_skel.sc_ms + 3 * root);
-    int k = 0;
-    for (int si = 0; si < c_skel.nm; si++) {
+    for (int si = c.wave; si < c_skel.nm; si += EVM_NW) {  // state blocks are independent: dealt to the waves
         const int m = c_skel.state_member[si];
+        const int k = 19 * si;
         const Q4 qs = q4(GS(quat, 4 * m), GS(quat, 4 * m + 1), GS(quat, 4 * m + 2), GS(quat, 4 * m + 3));
         const Q4 q = quat_from_mat(mat_from_quat(qs));  // getWorldTransform().getRotation()
         float yaw, pitch, roll;
@@ -994,15 +988,15 @@ DEV void observe(const Ctx &c, float *obs, float *reward, uint8_t *done) {
             const F3 d = SC3(c_skel.sc_ms + 3 * m) - root_ms;
             o[k + 16] = d.x; o[k + 17] = d.y; o[k + 18] = d.z;
         }
-        k += 19;
     }
-    for (int mi = 0; mi < c_skel.nmus; mi++) {
+    for (int mi = c.wave; mi < c_skel.nmus; mi += EVM_NW) {
+        const int k = 19 * c_skel.nm + 4 * mi;
         o[k + 0] = SC(c_skel.sc_mobs + 4 * mi + 0);
         o[k + 1] = SC(c_skel.sc_mobs + 4 * mi + 1);
         o[k + 2] = SC(c_skel.sc_mobs + 4 * mi + 2);
         o[k + 3] = SC(c_skel.sc_mobs + 4 * mi + 3);
-        k += 4;
     }
+    if (c.wave != 0) return;
     const float vz = GS(lin, 3 * root + 2);
     int remaining = c.d.remaining[c.env], cs = c.d.curr_step[c.env];
     if (vz < c_skel.min_vel) remaining -= 1;
@@ -1018,7 +1012,18 @@ DEV void observe(const Ctx &c, float *obs, float *reward, uint8_t *done) {
 // ---------------------------------------------------------------------------------------------
 // one stepSimulation(1/60) for this lane's env
 // ---------------------------------------------------------------------------------------------
+#ifdef EVM_STAMPS
+#define STAMP(i) do { if (c.lane == 0 && c.wave == 0) c.d.stamps[(size_t) blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
 DEV void physics_step(const Ctx &c, int flags) {
+    // Four waves (one per SIMD of the CU) work on the SAME 64 environments and share the LDS tile.  Work items
+    // of a phase that touch disjoint bodies are dealt to the waves; __syncthreads() closes every phase.  The
+    // Gauss-Seidel sweep keeps Bullet's order up to exact commutation (level schedule in EvmSkelC::sched).
+    const int W = c.wave;
+    STAMP(0);
     const bool pending = (flags & EVM_FLAG_PENDING) != 0;
     const bool powered = (flags & EVM_FLAG_POWERED) != 0;
     const bool any_pending = __any(pending);
@@ -1027,7 +1032,7 @@ DEV void physics_step(const Ctx &c, int flags) {
         E = m33(f3(GS(E, 0), GS(E, 1), GS(E, 2)), f3(GS(E, 3), GS(E, 4), GS(E, 5)), f3(GS(E, 6), GS(E, 7), GS(E, 8)));
 
     // ---- bodies: world basis, inverse inertia tile -> LDS, implicit gyroscopic impulse, zero deltas ----
-    for (int b = 0; b < c_skel.nb; b++) {
+    for (int b = W; b < c_skel.nb; b += EVM_NW) {
         const EvmBodyC &BC = c_skel.body[b];
         const Q4 q0 = q4(GS(quat, 4 * b), GS(quat, 4 * b + 1), GS(quat, 4 * b + 2), GS(quat, 4 * b + 3));
         M33 R = mat_from_quat(q0);
@@ -1069,79 +1074,79 @@ DEV void physics_step(const Ctx &c, int flags) {
         const F3 omega2 = quat_rotate(q, ob);
         SSC3(c_skel.sc_ext + 3 * b, omega2 - omega1);
     }
+    __syncthreads();
+    STAMP(1);
 
-    // ---- collision: hull vs floor plane, persistent manifolds ----
+    // ---- collision: hull vs floor plane, persistent manifolds (members dealt to waves by hull size) ----
+    for (int m = 0; m < c_skel.nm; m++)
+        if (c_skel.member_wave[m] == W && c_skel.member[m].contact_response) contact_update(c, m);
+    __syncthreads();
     int ncontact = 0;
     unsigned cmask = 0;  // wave-uniform: members with a cached point in any lane
     for (int m = 0; m < c_skel.nm; m++) {
-        int n = 0;
-        if (c_skel.member[m].contact_response) n = contact_update(c, m);
+        const int n = GS(mfn, m);
         ncontact += n;
         if (__any(n > 0)) cmask |= 1u << m;
     }
+    STAMP(2);
 
-    // ---- joint rows (Bullet order: skeleton constraints in file order, then slider, p2p_a, p2p_b per muscle) ----
-    for (int ci = 0; ci < c_skel.ncon; ci++) {
-        if (c_skel.con_type[ci] == 0) hinge_setup(c, c_skel.con_idx[ci]);
-        else fixed_setup(c, c_skel.con_idx[ci]);
+    // ---- joint rows: every constraint's record is independent of the others ----
+    for (int v = W; v < c_skel.nvisit; v += EVM_NW) {
+        const EvmVisitC &V = c_skel.visit[v];
+        switch (V.type) {
+            case 0: hinge_setup(c, (V.slot - c_skel.sc_h) / EVM_H_STRIDE); break;
+            case 1: fixed_setup(c, (V.slot - c_skel.sc_f) / EVM_F_STRIDE); break;
+            case 2: { const int mi = (V.slot - c_skel.sc_s) / EVM_S_STRIDE; slider_setup(c, mi, powered, GS(target, mi)); break; }
+            default: { const int k = (V.slot - c_skel.sc_p) / EVM_P_STRIDE; p2p_setup(c, k >> 1, k & 1); break; }
+        }
     }
-    for (int mi = 0; mi < c_skel.nmus; mi++) {
-        slider_setup(c, mi, powered, GS(target, mi));
-        p2p_setup(c, mi, 0);
-        p2p_setup(c, mi, 1);
-    }
-    // ---- contact rows: setup + warm start + split impulse ----
+    STAMP(3);
+    // ---- contact rows: setup + warm start + split impulse (touches the member's own deltas only) ----
     for (int m = 0; m < c_skel.nm; m++) {
+        if (c_skel.member_wave[m] != W) continue;
         if (cmask & (1u << m)) contact_setup(c, m, GS(mfn, m));
         else { SSC3(c_skel.sc_pt + 6 * m, f3(0.f, 0.f, 0.f)); SSC3(c_skel.sc_pt + 6 * m + 3, f3(0.f, 0.f, 0.f)); }
     }
+    __syncthreads();
+    STAMP(4);
 
     // ---- projected Gauss-Seidel sweeps ----
-    // Each visit needs ~40-70 scratch floats; a wave alone on its CU has nothing to overlap a load round trip
-    // with, so the record of constraint i+1 is requested before constraint i is solved (two register blocks,
-    // ping-pong, loop unrolled by two so no block is ever copied).
-    auto con_slot = [&](int ci) { return c_skel.con_type[ci] == 0 ? c_skel.sc_h + EVM_H_STRIDE * c_skel.con_idx[ci]
-                                                                 : c_skel.sc_f + EVM_F_STRIDE * c_skel.con_idx[ci]; };
-    auto con_solve = [&](int ci, const Blk42 &k) {
-        return c_skel.con_type[ci] == 0 ? hinge_solve(c, c_skel.con_idx[ci], k) : fixed_solve(c, c_skel.con_idx[ci], k);
+    // A wave walks its slice of the level schedule (EvmSkelC::sched); a workgroup barrier closes each level.
+    auto solve = [&](const EvmVisitC &V, const Blk42 &k) -> float {
+        switch (V.type) {
+            case 0: return hinge_solve(c, V, k);
+            case 1: return fixed_solve(c, V, k);
+            case 2: return slider_solve(c, V, k);
+            default: return p2p_solve(c, V, k);
+        }
     };
-    auto mus_solve = [&](int mi, const MusBlk &k) {
-        float r = slider_solve(c, mi, k);
-        r = fmaxf(r, p2p_solve(c, mi, 0, k.p0));
-        return fmaxf(r, p2p_solve(c, mi, 1, k.p1));
-    };
-    const int ncon = c_skel.ncon, nmus = c_skel.nmus;
+    const int ns = c_skel.nsched[W];
+    const unsigned short *sched = c_skel.sched[W];
     float res = 0.f;
     for (int it = 0; it < NUM_ITER; it++) {
         res = 0.f;
-        if (ncon > 0) {
-            Blk42 ka, kb;
-            blk_load42(c, con_slot(0), ka);
-            for (int ci = 0; ci < ncon; ci += 2) {
-                if (ci + 1 < ncon) blk_load42(c, con_slot(ci + 1), kb);
-                res = fmaxf(res, con_solve(ci, ka));
-                if (ci + 2 < ncon) blk_load42(c, con_slot(ci + 2), ka);
-                if (ci + 1 < ncon) res = fmaxf(res, con_solve(ci + 1, kb));
+        for (int i = 0; i < ns; i++) {
+            const int e = sched[i];
+            if ((e & 0x7fff) != EVM_SCHED_NONE) {
+                const EvmVisitC va = c_skel.visit[e & 0x7fff];
+                Blk42 ka;
+                blk_load(c, va, ka);
+                res = fmaxf(res, solve(va, ka));
             }
-        }
-        if (nmus > 0) {
-            MusBlk ma, mb;
-            mus_load(c, 0, ma);
-            for (int mi = 0; mi < nmus; mi += 2) {
-                if (mi + 1 < nmus) mus_load(c, mi + 1, mb);
-                res = fmaxf(res, mus_solve(mi, ma));
-                if (mi + 2 < nmus) mus_load(c, mi + 2, ma);
-                if (mi + 1 < nmus) res = fmaxf(res, mus_solve(mi + 1, mb));
-            }
+            if (e & EVM_SCHED_BARRIER) __syncthreads();  // closes a dependency level
         }
         for (int m = 0; m < c_skel.nm; m++)
-            if (cmask & (1u << m)) res = fmaxf(res, contact_iter(c, m, GS(mfn, m)));
+            if (c_skel.member_wave[m] == W && (cmask & (1u << m))) res = fmaxf(res, contact_iter(c, m, GS(mfn, m)));
+        __syncthreads();
     }
-    GS(diag, 0) = res;
-    GS(diag, 1) = (float) ncontact;
+    STAMP(5);
+    if (W == 0) {
+        GS(diag, 0) = res;
+        GS(diag, 1) = (float) ncontact;
+    }
 
     // ---- muscle readbacks: getAppliedImpulse() = impulse of the last row written back ----
-    for (int mi = 0; mi < c_skel.nmus; mi++) {
+    for (int mi = W; mi < c_skel.nmus; mi += EVM_NW) {
         const int s = c_skel.sc_s + EVM_S_STRIDE * mi;
         const float jd4 = SC(s + 25), jd5 = SC(s + 26);
         const float a3 = SC(s + 38), a4 = SC(s + 39), a5 = SC(s + 40);
@@ -1149,9 +1154,10 @@ DEV void physics_step(const Ctx &c, int flags) {
         SC(c_skel.sc_mobs + 4 * mi + 2) = SC(c_skel.sc_p + EVM_P_STRIDE * (2 * mi) + 14);
         SC(c_skel.sc_mobs + 4 * mi + 3) = SC(c_skel.sc_p + EVM_P_STRIDE * (2 * mi + 1) + 14);
     }
+    STAMP(6);
 
     // ---- write back velocities, split-impulse pose correction, integrate transforms ----
-    for (int b = 0; b < c_skel.nb; b++) {
+    for (int b = W; b < c_skel.nb; b += EVM_NW) {
         F3 o = G3(pos, 3 * b);
         M33 R = m33(SC3(c_skel.sc_r + 9 * b), SC3(c_skel.sc_r + 9 * b + 3), SC3(c_skel.sc_r + 9 * b + 6));
         const F3 dl = f3(LDV(b, 0), LDV(b, 1), LDV(b, 2)), da = f3(LDV(b, 3), LDV(b, 4), LDV(b, 5));
@@ -1176,6 +1182,8 @@ DEV void physics_step(const Ctx &c, int flags) {
         S3(ang, 3 * b, ang);
         if (b < c_skel.nm) SSC3(c_skel.sc_ms + 3 * b, o2 + lin * (0.f - DT_F));  // btDefaultMotionState, one step behind
     }
+    __syncthreads();
+    STAMP(7);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1183,46 +1191,53 @@ DEV void physics_step(const Ctx &c, int flags) {
 // ---------------------------------------------------------------------------------------------
 // MODE bits: 1 apply action, 2 observe, 4 auto-reset rollout form
 template <int MODE>
-__global__ __launch_bounds__(64) void k_env_step(EnvDev d, const float *__restrict__ action, float *obs, float *reward,
-                                                 uint8_t *done, uint8_t *valid, const uint8_t *__restrict__ mask) {
+__global__ __launch_bounds__(64 * EVM_NW) void k_env_step(EnvDev d, const float *__restrict__ action, float *obs,
+                                                          float *reward, uint8_t *done, uint8_t *valid,
+                                                          const uint8_t *__restrict__ mask) {
     extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
     Ctx c = make_ctx(d, lds_dyn);
+    // lanes outside the batch / the mask drop out; every wave of the workgroup owns the same lanes, so either
+    // all four waves keep running (and meet at every barrier) or all four leave here
     if (c.env >= d.n_real) return;
     if (mask && !mask[c.env]) return;
-    int flags = d.flags[c.env];
-    bool settling = false;
+    const bool lead = c.wave == 0;  // per-env bookkeeping is written by wave 0 only
     if (MODE & 4) {
-        if (flags & EVM_FLAG_DONE) {
+        if (lead && (d.flags[c.env] & EVM_FLAG_DONE)) {
             repose(c);
-            flags = d.flags[c.env] & ~EVM_FLAG_DONE;
-            d.flags[c.env] = flags;
+            d.flags[c.env] &= ~EVM_FLAG_DONE;
             d.settle_left[c.env] = 2 * c_skel.reset_frames;
             GS(stat, 1) += 1;
         }
-        settling = d.settle_left[c.env] > 0;
+        __syncthreads();
     }
-    if ((MODE & 4) && !settling) GS(stat, 0) += 1;
-    if ((MODE & 1) && !settling) {  // MuscleController::on_input -> Muscle::contract
-        for (int mi = 0; mi < c_skel.nmus; mi++)
-            GS(target, mi) = action[(size_t) c.env * c_skel.nmus + mi] * c_skel.muscle[mi].speed;
-        flags |= EVM_FLAG_POWERED;
+    int flags = d.flags[c.env];
+    const int settle0 = (MODE & 4) ? d.settle_left[c.env] : 0;
+    const bool settling = settle0 > 0;
+    if (MODE & 1) {
+        if (lead && !settling) {  // MuscleController::on_input -> Muscle::contract
+            for (int mi = 0; mi < c_skel.nmus; mi++)
+                GS(target, mi) = action[(size_t) c.env * c_skel.nmus + mi] * c_skel.muscle[mi].speed;
+            if (MODE & 4) GS(stat, 0) += 1;
+        }
+        if (!settling) flags |= EVM_FLAG_POWERED;
+        __syncthreads();  // targets are read by whichever wave sets up the slider
     }
     physics_step(c, flags);
     flags &= ~EVM_FLAG_PENDING;
     bool do_observe = (MODE & 2) != 0;
     if (MODE & 4) {
-        if (settling) {
-            const int left = d.settle_left[c.env] - 1;
-            d.settle_left[c.env] = left;
-            do_observe = left == 0;
+        if (settling) do_observe = settle0 == 1;
+        if (lead) {
+            if (settling) d.settle_left[c.env] = settle0 - 1;
+            valid[c.env] = do_observe ? (settling ? 2 : 1) : 0;  // 1 = do_step transition, 2 = reset()'s own step
         }
-        valid[c.env] = do_observe ? (settling ? 2 : 1) : 0;  // 1 = do_step transition, 2 = reset()'s own step
     }
     if (do_observe) {
         observe(c, obs, reward, done);
-        if ((MODE & 4) && done[c.env]) flags |= EVM_FLAG_DONE;
+        STAMP(8);
+        if (lead && (MODE & 4) && done[c.env]) flags |= EVM_FLAG_DONE;
     }
-    d.flags[c.env] = flags;
+    if (lead) d.flags[c.env] = flags;
 }
 
 __global__ __launch_bounds__(64) void k_env_repose(EnvDev d, const uint8_t *__restrict__ mask) {
@@ -1311,7 +1326,7 @@ static hipError_t launch_mode(const EnvDev &d, int nb, const float *action, floa
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_env_step<MODE>), dim3(d.n / 64), dim3(64), lds, s, d, action, obs, reward, done, valid, mask);
+    hipLaunchKernelGGL((k_env_step<MODE>), dim3(d.n / 64), dim3(64 * EVM_NW), lds, s, d, action, obs, reward, done, valid, mask);
     return hipGetLastError();
 }
 hipError_t launch_step(const EnvDev &d, int nb, int mode, const float *action, float *obs, float *reward, uint8_t *done,

@@ -50,6 +50,25 @@ struct EvmMuscleC {
     float max_force;
     float factA, factB;
 };
+// One Gauss-Seidel visit (a constraint) in Bullet's solve order, everything the sweep needs in one 32-byte
+// scalar load so that it can be fetched a visit ahead.
+struct EvmVisitC {
+    int type;    // 0 hinge, 1 fixed, 2 slider, 3 p2p
+    int slot;    // first scratch slot of the constraint's record
+    int a, b;    // body indices
+    float imA, imB;
+    int nslots;  // record length
+    int pad;
+};
+#define EVM_MAX_VISITS (EVM_MAX_HINGES + EVM_MAX_FIXED + 3 * EVM_MAX_MUSCLES)
+#ifndef EVM_NW
+#define EVM_NW 4
+#endif
+//                 // waves per workgroup = SIMDs per CU; all of them work on the same 64 envs
+#define EVM_MAX_SCHED (EVM_MAX_VISITS + 64)
+#define EVM_SCHED_NONE 0x7fff
+#define EVM_SCHED_BARRIER 0x8000
+
 struct EvmSkelC {
     int nb, nm, nh, nf, nmus, root;
     int obs_dim, act_dim;
@@ -63,6 +82,16 @@ struct EvmSkelC {
     int max_steps, init_remaining, reset_frames;
     // scratch layout (offsets in floats-per-env)
     int sc_r, sc_ext, sc_ms, sc_pt, sc_mobs, sc_h, sc_f, sc_s, sc_p, sc_c, sc_total;
+    int nvisit;
+    EvmVisitC visit[EVM_MAX_VISITS];
+    // Level schedule of the sweep: visits that share no body commute exactly, so the Bullet-ordered visit list
+    // is cut into dependency levels (ASAP); the visits of a level are spread over the EVM_NW waves and a
+    // workgroup barrier closes the level.  Entry = visit index | EVM_SCHED_BARRIER on the last entry of a level
+    // (EVM_SCHED_NONE = no visit for this wave in this level, barrier only).
+    int nlevels;
+    int nsched[EVM_NW];
+    unsigned short sched[EVM_NW][EVM_MAX_SCHED];
+    int member_wave[EVM_MAX_MEMBERS];  // which wave scans / solves the contacts of member m (balanced by hull size)
     EvmBodyC body[EVM_MAX_BODIES];
     EvmMemberC member[EVM_MAX_MEMBERS];
     EvmHingeC hinge[EVM_MAX_HINGES];

@@ -1,5 +1,6 @@
 #include "skeleton_host.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -384,6 +385,104 @@ int load_skeleton_constants(const char *path, const EvmEnvParams &prm, EvmSkelC 
     S.sc_p = o; o += EVM_P_STRIDE * 2 * nmus;
     S.sc_c = o; o += EVM_C_STRIDE * 4 * nm;
     S.sc_total = o;
+
+    // ---- sweep visit list (Bullet order: skeleton constraints, then slider / p2p_a / p2p_b per muscle) ----
+    int nv = 0;
+    for (int ci = 0; ci < S.ncon; ci++) {
+        EvmVisitC &v = S.visit[nv++];
+        if (S.con_type[ci] == 0) {
+            const EvmHingeC &h = S.hinge[S.con_idx[ci]];
+            v.type = 0; v.slot = S.sc_h + EVM_H_STRIDE * S.con_idx[ci]; v.a = h.a; v.b = h.b; v.nslots = EVM_H_STRIDE;
+        } else {
+            const EvmFixedC &x = S.fixed[S.con_idx[ci]];
+            v.type = 1; v.slot = S.sc_f + EVM_F_STRIDE * S.con_idx[ci]; v.a = x.a; v.b = x.b; v.nslots = EVM_F_STRIDE;
+        }
+    }
+    for (int k = 0; k < nmus; k++) {
+        const EvmMuscleC &m = S.muscle[k];
+        EvmVisitC &v = S.visit[nv++];
+        v.type = 2; v.slot = S.sc_s + EVM_S_STRIDE * k; v.a = m.sa; v.b = m.sb; v.nslots = EVM_S_STRIDE;
+        EvmVisitC &pa = S.visit[nv++];
+        pa.type = 3; pa.slot = S.sc_p + EVM_P_STRIDE * (2 * k); pa.a = m.ma; pa.b = m.sa; pa.nslots = EVM_P_STRIDE;
+        EvmVisitC &pb = S.visit[nv++];
+        pb.type = 3; pb.slot = S.sc_p + EVM_P_STRIDE * (2 * k + 1); pb.a = m.mb; pb.b = m.sb; pb.nslots = EVM_P_STRIDE;
+    }
+    for (int i = 0; i < nv; i++) {
+        S.visit[i].imA = S.body[S.visit[i].a].inv_mass;
+        S.visit[i].imB = S.body[S.visit[i].b].inv_mass;
+        S.visit[i].pad = 0;
+    }
+    S.nvisit = nv;
+
+    // ---- level schedule ----
+    {
+        std::vector<int> last(nb, 0), level(nv, 0);
+        int nlev = 0;
+        for (int i = 0; i < nv; i++) {
+            int l = 1 + std::max(last[S.visit[i].a], last[S.visit[i].b]);
+            level[i] = l;
+            last[S.visit[i].a] = last[S.visit[i].b] = l;
+            nlev = std::max(nlev, l);
+        }
+        S.nlevels = nlev;
+        // latest level each visit may take: just before the next visit (in Bullet order) that shares a body
+        std::vector<int> alap(nv, nlev);
+        for (int i = 0; i < nv; i++)
+            for (int j = i + 1; j < nv; j++) {
+                const bool share = S.visit[j].a == S.visit[i].a || S.visit[j].a == S.visit[i].b ||
+                                   S.visit[j].b == S.visit[i].a || S.visit[j].b == S.visit[i].b;
+                if (share) { alap[i] = std::min(alap[i], level[j] - 1); }
+            }
+        const float cost[4] = {6.f, 6.f, 6.f, 1.5f};
+        std::vector<std::vector<float>> load(nlev + 1, std::vector<float>(EVM_NW, 0.f));
+        std::vector<std::vector<std::vector<int>>> per(nlev + 1, std::vector<std::vector<int>>(EVM_NW));
+        auto place = [&](int v, int l) {
+            int best = 0;
+            for (int w = 1; w < EVM_NW; w++) if (load[l][w] < load[l][best]) best = w;
+            per[l][best].push_back(v);
+            load[l][best] += cost[S.visit[v].type];
+        };
+        auto makespan_after = [&](int v, int l) {
+            float mn = load[l][0], mx = load[l][0];
+            for (int w = 1; w < EVM_NW; w++) { mn = std::min(mn, load[l][w]); mx = std::max(mx, load[l][w]); }
+            return std::max(mx, mn + cost[S.visit[v].type]) - mx;  // growth of the level's critical path
+        };
+        std::vector<int> order(nv);
+        for (int i = 0; i < nv; i++) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return cost[S.visit[x].type] > cost[S.visit[y].type]; });
+        for (int v : order) if (alap[v] <= level[v]) place(v, level[v]);           // no freedom
+        for (int v : order) if (alap[v] > level[v]) {                              // floating (the muscle sliders)
+            int bl = level[v];
+            float bg = makespan_after(v, bl);
+            for (int l = level[v] + 1; l <= alap[v]; l++) { float g = makespan_after(v, l); if (g < bg) { bg = g; bl = l; } }
+            level[v] = bl;
+            place(v, bl);
+        }
+        for (int w = 0; w < EVM_NW; w++) S.nsched[w] = 0;
+        for (int l = 1; l <= nlev; l++)
+            for (int w = 0; w < EVM_NW; w++) {
+                std::vector<int> &q = per[l][w];
+                std::sort(q.begin(), q.end());  // keep Bullet order inside a wave's slice of the level
+                if (q.empty()) q.push_back(EVM_SCHED_NONE);
+                for (size_t k = 0; k < q.size(); k++) {
+                    if (S.nsched[w] >= EVM_MAX_SCHED) { err = "sweep schedule overflow"; return EVM_E_UNSUPPORTED; }
+                    unsigned short e = (unsigned short) q[k];
+                    if (k + 1 == q.size()) e |= EVM_SCHED_BARRIER;
+                    S.sched[w][S.nsched[w]++] = e;
+                }
+            }
+        // members -> waves, heaviest hull first
+        std::vector<int> ms(nm);
+        for (int i = 0; i < nm; i++) ms[i] = i;
+        std::stable_sort(ms.begin(), ms.end(), [&](int x, int y) { return S.member[x].hull_n > S.member[y].hull_n; });
+        int loadm[EVM_NW] = {0};
+        for (int m : ms) {
+            int best = 0;
+            for (int w = 1; w < EVM_NW; w++) if (loadm[w] < loadm[best]) best = w;
+            S.member_wave[m] = best;
+            loadm[best] += S.member[m].hull_n + 16;
+        }
+    }
     return EVM_OK;
 }
 

@@ -117,6 +117,8 @@ int evm_env_get_diagnostics(const EvmEnv *env, float *d_out /* [n_envs, 2] */, v
  * evm_env_step_autoreset (the reset()'s own step and settle calls are not counted), h_out[1] = resets started. */
 int evm_env_get_stats(EvmEnv *env, long long *h_out /* [2] */);
 int evm_env_clear_stats(EvmEnv *env);
+/* Diagnostic builds (-DEVM_STAMPS) only: s_memtime stamps at the phase boundaries of the last step, [n_tiles, 16]. */
+int evm_env_get_stamps(EvmEnv *env, unsigned long long *h_out);
 
 /* Kernel timing for bench.py's roofline line: between _begin and _end every dynamics-kernel launch is bracketed
  * by its own pair of HIP events on the launch stream; _end synchronises the stream and returns the summed
