@@ -72,6 +72,22 @@ DEV Ctx make_ctx(const EnvDev &d, float *lds) {
 #define SC(k) (c.t.scratch[((k) << 6) + c.lane])
 #define LDV(b, k) (c.lds[(((b) * 6 + (k)) << 6) + c.lane])
 #define LII(b, k) (c.lds[(((c_skel.nb + (b)) * 6 + (k)) << 6) + c.lane])
+// per-body version counters (one int per body) behind the float tiles: dataflow synchronisation of the sweep
+#define LVER(c_) (reinterpret_cast<int *>((c_).lds + (size_t) c_skel.nb * 12 * 64))
+
+// Wait until body b has been written `expect` times (monotonic counter, workgroup-scope acquire).  Bounded:
+// a schedule bug must not hang the GPU; on timeout the diagnostic slot is poisoned and the wave goes on.
+DEV void wait_version(const Ctx &c, int b, int expect) {
+    int *ver = LVER(c);
+    int spins = 0;
+    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&ver[b], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < expect) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1 << 22)) { c.t.diag[c.lane] = -1.f; break; }
+    }
+}
+DEV void publish_version(const Ctx &c, int b, int value) {
+    __hip_atomic_store(&LVER(c)[b], value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 
 DEV F3 gs3(const float *tile, int lane, int k) {
     const float *p = tile + (k << 6) + lane;
@@ -633,7 +649,20 @@ DEV int contact_update(const Ctx &c, int m) {
     float best = EVM_INF;
     int bi = 0;
     const float *hp = c_skel.hull + 3 * MB.hull_off;
-    for (int i = 0; i < MB.hull_n; i++) {
+    // 8 vertices per trip: the 24 coordinates are wave-uniform, so they arrive as a few wide scalar loads with
+    // one wait instead of one scalar round trip per vertex
+    const int n8 = MB.hull_n & ~7;
+    for (int i0 = 0; i0 < n8; i0 += 8) {
+        float pc[24];
+#pragma unroll
+        for (int k = 0; k < 24; k++) pc[k] = hp[3 * i0 + k];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const float wy = xa(xa(xa(xm(R.r1.x, pc[3 * k]), xm(R.r1.y, pc[3 * k + 1])), xm(R.r1.z, pc[3 * k + 2])), o.y);
+            if (wy < best) { best = wy; bi = i0 + k; }
+        }
+    }
+    for (int i = n8; i < MB.hull_n; i++) {
         const float px = hp[3 * i], py = hp[3 * i + 1], pz = hp[3 * i + 2];
         const float wy = xa(xa(xa(xm(R.r1.x, px), xm(R.r1.y, py)), xm(R.r1.z, pz)), o.y);
         if (wy < best) { best = wy; bi = i; }
@@ -1013,6 +1042,7 @@ DEV void observe(const Ctx &c, float *obs, float *reward, uint8_t *done) {
 // one stepSimulation(1/60) for this lane's env
 // ---------------------------------------------------------------------------------------------
 #ifdef EVM_STAMPS
+#define STAMPX(i) do { if (c.lane == 0) c.d.stamps[(size_t) blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #define STAMP(i) do { if (c.lane == 0 && c.wave == 0) c.d.stamps[(size_t) blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define STAMP(i) do { } while (0)
@@ -1051,6 +1081,7 @@ DEV void physics_step(const Ctx &c, int flags) {
         LII(b, 0) = I.xx; LII(b, 1) = I.xy; LII(b, 2) = I.xz; LII(b, 3) = I.yy; LII(b, 4) = I.yz; LII(b, 5) = I.zz;
 #pragma unroll
         for (int k = 0; k < 6; k++) LDV(b, k) = 0.f;
+        LVER(c)[b] = 0;
         // btRigidBody::computeGyroscopicImpulseImplicit_Body
         const F3 omega1 = G3(ang, 3 * b);
         const F3 idl = f3(1.f / invI.x, 1.f / invI.y, 1.f / invI.z);
@@ -1121,24 +1152,65 @@ DEV void physics_step(const Ctx &c, int flags) {
         }
     };
     const int ns = c_skel.nsched[W];
-    const unsigned short *sched = c_skel.sched[W];
+    const int *sched = c_skel.sched[W];
     float res = 0.f;
+    // Dataflow sweep.  Visits that share no body commute exactly, so the only ordering that matters is, per body,
+    // the order of the visits that touch it.  Every body carries a version counter in LDS (= how many visits
+    // have written it); a visit waits until its two bodies have reached the versions it expects (the number of
+    // earlier visits in Bullet order that touch them, plus a per-sweep stride), solves, and publishes the new
+    // versions with release semantics.  No workgroup barrier inside a sweep: the four leg chains drift freely
+    // and only the real dependency chain (the visits on the root body) is serial.  Each wave walks its slice of
+    // the level-sorted schedule, so the globally lowest unfinished visit is always at the head of some wave's
+    // list and cannot be blocked: no deadlock.  The record of the wave's next visit is requested before the
+    // current one is solved (two register blocks, ping-pong, unrolled by two so no block is ever copied).
+    auto vis_of = [&](int e) { return (e & 0x7fff) == EVM_SCHED_NONE ? 0 : (e & 0x7fff); };
+    auto run_visit = [&](const EvmVisitC &V, const Blk42 &k, int it) -> float {
+        const int expA = it * c_skel.body[V.a].per_sweep + (V.need & 0xffff);
+        const int expB = it * c_skel.body[V.b].per_sweep + (V.need >> 16);
+#ifdef EVM_STAMPS
+        const bool st = it == 3 && V.a == 0 && V.type == 0 && V.b == 2;  // the c1 hinge (body, legB) in sweep 3
+        if (st) STAMPX(9);
+#endif
+        wait_version(c, V.a, expA);
+        wait_version(c, V.b, expB);
+#ifdef EVM_STAMPS
+        if (st) STAMPX(10);
+#endif
+        const float r = solve(V, k);
+#ifdef EVM_STAMPS
+        if (st) STAMPX(11);
+#endif
+        publish_version(c, V.a, expA + 1);
+        publish_version(c, V.b, expB + 1);
+#ifdef EVM_STAMPS
+        if (st) STAMPX(12);
+#endif
+        return r;
+    };
     for (int it = 0; it < NUM_ITER; it++) {
         res = 0.f;
-        for (int i = 0; i < ns; i++) {
-            const int e = sched[i];
-            if ((e & 0x7fff) != EVM_SCHED_NONE) {
-                const EvmVisitC va = c_skel.visit[e & 0x7fff];
-                Blk42 ka;
-                blk_load(c, va, ka);
-                res = fmaxf(res, solve(va, ka));
+        if (ns > 0) {
+            Blk42 ka, kb;
+            int ea = sched[0], eb = ea;
+            EvmVisitC va = c_skel.visit[vis_of(ea)], vb = va;
+            blk_load(c, va, ka);
+            for (int i = 0; i < ns; i += 2) {
+                if (i + 1 < ns) { eb = sched[i + 1]; vb = c_skel.visit[vis_of(eb)]; blk_load(c, vb, kb); }
+                if ((ea & 0x7fff) != EVM_SCHED_NONE) res = fmaxf(res, run_visit(va, ka, it));
+                if (i + 2 < ns) { ea = sched[i + 2]; va = c_skel.visit[vis_of(ea)]; blk_load(c, va, ka); }
+                if (i + 1 < ns && (eb & 0x7fff) != EVM_SCHED_NONE) res = fmaxf(res, run_visit(vb, kb, it));
             }
-            if (e & EVM_SCHED_BARRIER) __syncthreads();  // closes a dependency level
         }
-        for (int m = 0; m < c_skel.nm; m++)
-            if (c_skel.member_wave[m] == W && (cmask & (1u << m))) res = fmaxf(res, contact_iter(c, m, GS(mfn, m)));
-        __syncthreads();
+        // contact rows of a member come after all of its joint visits of this sweep and before the next sweep's
+        for (int m = 0; m < c_skel.nm; m++) {
+            if (c_skel.member_wave[m] != W) continue;
+            const int ps = c_skel.body[m].per_sweep;
+            wait_version(c, m, it * ps + ps - 1);
+            if (cmask & (1u << m)) res = fmaxf(res, contact_iter(c, m, GS(mfn, m)));
+            publish_version(c, m, (it + 1) * ps);
+        }
     }
+    __syncthreads();
     STAMP(5);
     if (W == 0) {
         GS(diag, 0) = res;
@@ -1313,7 +1385,7 @@ __global__ __launch_bounds__(64) void k_env_poses(EnvDev d, float *out) {
 hipError_t upload_skeleton(const EvmSkelC *h, hipStream_t s) {
     return hipMemcpyToSymbolAsync(HIP_SYMBOL(c_skel), h, sizeof(EvmSkelC), 0, hipMemcpyHostToDevice, s);
 }
-size_t step_lds_bytes(int nb) { return (size_t) nb * 12 * 64 * sizeof(float); }
+size_t step_lds_bytes(int nb) { return (size_t) nb * 12 * 64 * sizeof(float) + (size_t) ((nb + 63) / 64) * 256; }  // tiles + version counters
 
 template <int MODE>
 static hipError_t launch_mode(const EnvDev &d, int nb, const float *action, float *obs, float *reward, uint8_t *done,

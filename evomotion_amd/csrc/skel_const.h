@@ -23,6 +23,7 @@ struct EvmBodyC {
     float inv_inertia[3];
     float ext_force_y;  // (gravity_force * inv_mass) * dt, y component (x = z = 0)
     float mass, friction;
+    int per_sweep;  // visits touching this body in one sweep (joint visits + 1 contact visit for members)
     float m0[9];  // first_model_matrix basis, btMatrix3x3 rows (may be non-orthonormal: SURVEY App. A)
     float t0[3];  // first_model_matrix origin
 };
@@ -58,13 +59,13 @@ struct EvmVisitC {
     int a, b;    // body indices
     float imA, imB;
     int nslots;  // record length
-    int pad;
+    int need;    // bodies' version counters this visit waits for: needA | needB << 16 (visits earlier in the sweep that touch the body)
 };
 #define EVM_MAX_VISITS (EVM_MAX_HINGES + EVM_MAX_FIXED + 3 * EVM_MAX_MUSCLES)
 #ifndef EVM_NW
-#define EVM_NW 4
+#define EVM_NW 8
 #endif
-//                 // waves per workgroup = SIMDs per CU; all of them work on the same 64 envs
+
 #define EVM_MAX_SCHED (EVM_MAX_VISITS + 64)
 #define EVM_SCHED_NONE 0x7fff
 #define EVM_SCHED_BARRIER 0x8000
@@ -90,7 +91,7 @@ struct EvmSkelC {
     // (EVM_SCHED_NONE = no visit for this wave in this level, barrier only).
     int nlevels;
     int nsched[EVM_NW];
-    unsigned short sched[EVM_NW][EVM_MAX_SCHED];
+    int sched[EVM_NW][EVM_MAX_SCHED];
     int member_wave[EVM_MAX_MEMBERS];  // which wave scans / solves the contacts of member m (balanced by hull size)
     EvmBodyC body[EVM_MAX_BODIES];
     EvmMemberC member[EVM_MAX_MEMBERS];

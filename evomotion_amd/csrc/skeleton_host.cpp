@@ -410,7 +410,15 @@ int load_skeleton_constants(const char *path, const EvmEnvParams &prm, EvmSkelC 
     for (int i = 0; i < nv; i++) {
         S.visit[i].imA = S.body[S.visit[i].a].inv_mass;
         S.visit[i].imB = S.body[S.visit[i].b].inv_mass;
-        S.visit[i].pad = 0;
+    }
+    {   // dataflow bookkeeping: per-body version each visit must observe before it may run
+        std::vector<int> cnt(nb, 0);
+        for (int i = 0; i < nv; i++) {
+            S.visit[i].need = cnt[S.visit[i].a] | (cnt[S.visit[i].b] << 16);
+            cnt[S.visit[i].a]++;
+            cnt[S.visit[i].b]++;
+        }
+        for (int b = 0; b < nb; b++) S.body[b].per_sweep = cnt[b] + (b < nm ? 1 : 0);
     }
     S.nvisit = nv;
 
@@ -466,7 +474,7 @@ int load_skeleton_constants(const char *path, const EvmEnvParams &prm, EvmSkelC 
                 if (q.empty()) q.push_back(EVM_SCHED_NONE);
                 for (size_t k = 0; k < q.size(); k++) {
                     if (S.nsched[w] >= EVM_MAX_SCHED) { err = "sweep schedule overflow"; return EVM_E_UNSUPPORTED; }
-                    unsigned short e = (unsigned short) q[k];
+                    int e = q[k];
                     if (k + 1 == q.size()) e |= EVM_SCHED_BARRIER;
                     S.sched[w][S.nsched[w]++] = e;
                 }

@@ -27,3 +27,9 @@ tot = acc[:8].sum()
 for nm, v in zip(names, acc[:8]):
     print("%-14s %9.0f ticks  %5.1f %%" % (nm, v / K, 100 * v / tot))
 print("total ticks/step", tot / K, "(s_memtime ticks at 100 MHz: x10 ns)")
+# optional fine stamps 9..12 around one hinge visit (wait / solve / publish)
+st = (ctypes.c_ulonglong * (n // 64 * 16))()
+check(lib.evm_env_get_stamps(env._h, st))
+s = np.array(st, dtype=np.uint64).reshape(-1, 16).astype(np.float64)
+d = np.diff(s[:, 9:13], axis=1)
+print("one hinge visit (median over tiles): wait %.0f  solve %.0f  publish %.0f ticks" % tuple(np.median(d, axis=0)))
