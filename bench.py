@@ -49,6 +49,8 @@ def main():
                     help="dynamics = BASELINE configs[1] (random actions, headline); ppo = configs[2]/[3]: fused MFMA "
                          "actor-critic forward inside the rollout, PPO update every --horizon steps")
     ap.add_argument("--horizon", type=int, default=32)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
+                    "the N>1 path with several ranks on ONE GPU)")
     ap.add_argument("--no-update", action="store_true", help="ppo mode: rollout only")
     args = ap.parse_args()
 
@@ -58,10 +60,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = max(torch.cuda.device_count(), 1)
+    dev_index = local_rank % ndev
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(args.backend)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    local_rank = dev_index
 
     from evomotion_amd import VecRobotWalk
 
@@ -75,6 +83,7 @@ def main():
     actions = torch.rand(bank, n, env.action_dim, device=dev, generator=g) * 2.0 - 1.0
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -113,7 +122,8 @@ def main():
         args.steps = n_launch
     elapsed = t1 - t0
     st = env.stats()
-    tt = torch.tensor([elapsed, float(st["env_steps"]), float(st["resets"])], dtype=torch.float64, device=dev)
+    tt = torch.tensor([elapsed, float(st["env_steps"]), float(st["resets"])], dtype=torch.float64,
+                      device=dev if args.backend == "nccl" else "cpu")
     if world > 1:
         tmax = tt.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

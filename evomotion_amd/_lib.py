@@ -54,6 +54,7 @@ def _load():
     lib.evm_env_get_body_constants.argtypes = [vp, fp]
     lib.evm_env_get_diagnostics.argtypes = [vp, vp, vp]
     lib.evm_skeleton_probe.argtypes = [cp, ip, fp]
+    lib.evm_skeleton_schedule.argtypes = [cp, ip, ip, ip, ctypes.c_int]
     lib.evm_env_get_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_longlong)]
     lib.evm_env_clear_stats.argtypes = [vp]
     lib.evm_env_get_stamps.argtypes = [vp, ctypes.POINTER(ctypes.c_ulonglong)]

@@ -189,13 +189,13 @@ int evm_env_reset(EvmEnv *env, const uint8_t *d_mask, float *d_obs, float *d_rew
 }
 
 int evm_env_step(EvmEnv *env, const float *d_action, float *d_obs, float *d_reward, uint8_t *d_done, void *stream) {
-    if (!env || !d_action || !d_obs || !d_reward || !d_done) return fail(EVM_E_INVALID, "null argument");
+    if (!env || (!d_action && env->skel.act_dim > 0) || !d_obs || !d_reward || !d_done) return fail(EVM_E_INVALID, "null argument");
     return step_launch(env, 3, d_action, d_obs, d_reward, d_done, nullptr, nullptr, (hipStream_t) stream);
 }
 
 int evm_env_step_autoreset(EvmEnv *env, const float *d_action, float *d_obs, float *d_reward, uint8_t *d_done,
                            uint8_t *d_valid, void *stream) {
-    if (!env || !d_action || !d_obs || !d_reward || !d_done || !d_valid) return fail(EVM_E_INVALID, "null argument");
+    if (!env || (!d_action && env->skel.act_dim > 0) || !d_obs || !d_reward || !d_done || !d_valid) return fail(EVM_E_INVALID, "null argument");
     return step_launch(env, 7, d_action, d_obs, d_reward, d_done, d_valid, nullptr, (hipStream_t) stream);
 }
 
@@ -241,6 +241,28 @@ int evm_skeleton_probe(const char *skeleton_path, int *counts /* nb nm nh nf nmu
         counts[9] = S->init_remaining;
     }
     if (out) body_constants(*S, out);
+    delete S;
+    return EVM_OK;
+}
+
+// Host-only: the sweep schedule the loader derived.  visits [nvisit,4] = (type, a, b, level);
+// sched [EVM_NW, cap] entries (visit | 0x8000 on the last entry of a level, 0x7fff = none); returns sizes in dims[4] =
+// (nvisit, nlevels, n_waves, cap).
+int evm_skeleton_schedule(const char *skeleton_path, int *dims, int *visits, int *sched, int cap) {
+    EvmEnvParams prm;
+    evm_env_default_params(&prm);
+    EvmSkelC *S = new EvmSkelC();
+    std::string err;
+    int rc = evm::load_skeleton_constants(skeleton_path, prm, *S, err);
+    if (rc != EVM_OK) { delete S; return fail(rc, err); }
+    if (dims) { dims[0] = S->nvisit; dims[1] = S->nlevels; dims[2] = EVM_NW; dims[3] = cap; }
+    for (int w = 0; w < EVM_NW && sched; w++) {
+        for (int i = 0; i < cap; i++) sched[w * cap + i] = i < S->nsched[w] ? S->sched[w][i] : -1;
+    }
+    for (int i = 0; i < S->nvisit && visits; i++) {
+        visits[4 * i] = S->visit[i].type; visits[4 * i + 1] = S->visit[i].a; visits[4 * i + 2] = S->visit[i].b;
+        visits[4 * i + 3] = S->visit[i].need;
+    }
     delete S;
     return EVM_OK;
 }

@@ -44,7 +44,8 @@ def compare(a, b, nb, nm, nmus):
         res["iinv(pending)"] = float(np.abs(a[pend][:, f["iinv"]] - b[pend][:, f["iinv"]]).max())
         res["E(pending)"] = float(np.abs(a[pend][:, f["E"]] - b[pend][:, f["E"]]).max())
     for k in ("pending", "ms", "hist", "target", "powered", "counters"):
-        res[k] = float(np.abs(a[..., f[k]] - b[..., f[k]]).max())
+        d = np.abs(a[..., f[k]] - b[..., f[k]])
+        res[k] = float(d.max()) if d.size else 0.0
     ma = a[..., f["manifold"]].reshape(a.shape[:-1] + (nm, 37))
     mb = b[..., f["manifold"]].reshape(b.shape[:-1] + (nm, 37))
     res["mf_count"] = float(np.abs(ma[..., 0] - mb[..., 0]).max())

@@ -212,3 +212,127 @@ def test_full_batch_invariants(torch_mod):
         a = torch.rand(n, 12, device="cuda", generator=g) * 2 - 1
         st2 = env2.do_step(a)
     assert torch.equal(st2.state, st.state)
+
+
+def _tf_compare(env, orcs, nb, nm, nmus, steps, rng, act_dim):
+    import torch
+    worst = dict(pos=0.0, lin=0.0, ang=0.0, obs=0.0)
+    for k in range(steps):
+        so = np.stack([o.get_state() for o in orcs])
+        env.set_state(so)
+        a = rng.uniform(-1, 1, (len(orcs), max(act_dim, 1))).astype(np.float32)[:, :act_dim]
+        st = env.do_step(torch.from_numpy(np.ascontiguousarray(a)))
+        og = st.state.cpu().numpy()
+        outs = [o.do_step(a[i]) for i, o in enumerate(orcs)]
+        d = blob.compare(np.stack([o.get_state() for o in orcs]), env.get_state(), nb, nm, nmus)
+        for key in ("pos", "lin", "ang"):
+            worst[key] = max(worst[key], d[key])
+        e = np.abs(og - np.stack([x[0] for x in outs]))
+        if nmus:
+            cols = 19 * nm + 1 + 4 * np.arange(nmus)
+            e[:, cols] = np.where(e[:, cols] > 1e-3, 0, e[:, cols])
+        worst["obs"] = max(worst["obs"], float(e.max()))
+    return worst
+
+
+def test_generic_skeletons(torch_mod, orc_lib, tmp_path):
+    """The loader and the kernel are topology-generic: a single box, and a hinge/fixed chain with two muscles."""
+    from conftest import write_skeleton
+    rng = np.random.default_rng(5)
+    # (1) one cube: free fall, landing, resting contact
+    cube = write_skeleton(tmp_path / "cube.skel", [dict(name="body", mass=1.0, scale=(0.2, 0.2, 0.2))])
+    n = 8
+    env = make(n, parameters=dict(skeleton_json_path=cube))
+    orcs = [orc.OracleEnv(seed=1234 + i, skeleton=cube, lib=orc_lib) for i in range(n)]
+    assert env.state_dim == 19 and env.action_dim == 0 and env.n_bodies == 1
+    env.debug_reset_begin()
+    for o in orcs:
+        o.reset_begin()
+    for k in range(120):  # free-running: free fall is exactly reproducible, the landing is contact-rich
+        env.debug_physics_steps(1)
+        for o in orcs:
+            o.physics_step()
+        if k == 20:
+            d = blob.compare(np.stack([o.get_state() for o in orcs]), env.get_state(), 1, 1, 0)
+            assert d["pos"] < 1e-6 and d["lin"] < 1e-6, d
+    d = blob.compare(np.stack([o.get_state() for o in orcs]), env.get_state(), 1, 1, 0)
+    assert d["pos"] < 5e-2, d
+    w = _tf_compare(env, orcs, 1, 1, 0, 30, rng, 0)  # teacher-forced through resting contact
+    assert w["pos"] < 5e-6 and w["lin"] < 5e-4 and w["ang"] < 5e-3 and w["obs"] < 5e-3, w
+    # (2) chain with interleaved hinge / fixed constraints and two muscles
+    members = [dict(name="body", mass=2.0, scale=(0.4, 0.2, 0.5))]
+    cons, mus = [], []
+    for k in range(5):
+        members.append(dict(name=f"seg{k}", mass=0.25, t=(0.65 + 0.5 * k, 0, 0), scale=(0.2, 0.1, 0.1)))
+        parent = "body" if k == 0 else f"seg{k-1}"
+        pp = (0.4, 0, 0) if k == 0 else (0.25, 0, 0)
+        if k % 2 == 0:
+            cons.append(dict(type="hinge", name=f"c{k}", parent=parent, child=f"seg{k}", pivot_p=pp, pivot_c=(-0.25, 0, 0),
+                             axis_p=(0, 0, 1), axis_c=(0, 0, 1), lo=-1.0, hi=1.0))
+        else:
+            cons.append(dict(type="fixed", name=f"c{k}", parent=parent, child=f"seg{k}", tp=pp, tc=(-0.25, 0, 0)))
+    mus.append(dict(name="m0", a="body", b="seg0", pos_a=(0.2, 0.15, 0), pos_b=(0, 0.1, 0)))
+    mus.append(dict(name="m1", a="seg1", b="seg3", pos_a=(0, 0.1, 0), pos_b=(0, 0.1, 0)))
+    chain = write_skeleton(tmp_path / "chain.skel", members, cons, mus)
+    env = make(n, parameters=dict(skeleton_json_path=chain))
+    orcs = [orc.OracleEnv(seed=77 + i, skeleton=chain, lib=orc_lib) for i in range(n)]
+    assert env.state_dim == 19 * 6 + 8 and env.action_dim == 2 and env.n_bodies == 10
+    assert np.array_equal(env.body_constants()[:6].view(np.uint32), orcs[0].body_constants()[:6].view(np.uint32))
+    for o in orcs:
+        o.reset()
+    w = _tf_compare(env, orcs, 10, 6, 2, 40, rng, 2)
+    assert w["pos"] < 5e-6 and w["lin"] < 1e-3 and w["ang"] < 5e-3 and w["obs"] < 5e-3, w
+
+
+def test_autoreset_episode_matches_oracle(torch_mod, orc_lib):
+    """Rollout form vs the reference loop `while(!done) do_step; reset()`, call by call.  The oracle mirrors the
+    in-band reset (reset_begin, then one settle step per call, compute_step after the 60th) and the GPU state is
+    re-synchronised from the oracle before every call, so every comparison is a single-step one."""
+    torch = torch_mod
+    n, calls = 8, 220
+    env = make(n, parameters=dict(initial_remaining_seconds=0.1))
+    orcs = [orc.OracleEnv(seed=1234 + i, initial_remaining_seconds=0.1, lib=orc_lib) for i in range(n)]
+    init_remaining = orcs[0].counters()["remaining_steps"]
+    env.reset()
+    outs = [o.reset() for o in orcs]
+    done_o = [r[2] for r in outs]
+    settle = [0] * n
+    env.set_state(np.stack([o.get_state() for o in orcs]))
+    # the rollout flag "previous transition was terminal" is the GPU's own bookkeeping: start from a state where
+    # no env is flagged (reset() clears it) and let both sides evolve
+    assert not any(done_o)
+    rng = np.random.default_rng(2)
+    n_trans = n_emit = 0
+    worst = 0.0
+    for k in range(calls):
+        env.set_state(np.stack([o.get_state() for o in orcs]))
+        a = rng.uniform(-1, 1, (n, 12)).astype(np.float32)
+        rs = env.step_autoreset(torch.from_numpy(a))
+        v, og, dg = rs.valid.cpu().numpy(), rs.state.cpu().numpy(), rs.done.cpu().numpy().astype(bool)
+        for i, o in enumerate(orcs):
+            if settle[i] == 0 and done_o[i]:  # the reference loop calls reset() now
+                o.reset_begin()
+                o.L.orc_env_set_counters(o.h, 0, init_remaining)  # robot_walk.cpp:100-101, nothing reads them earlier
+                settle[i] = 60
+                done_o[i] = False
+            if settle[i] > 0:
+                o.physics_step()
+                settle[i] -= 1
+                if settle[i] > 0:
+                    assert v[i] == 0, (k, i)
+                    continue
+                obs_o, r_o, d_o = o.compute_step()
+                assert v[i] == 2, (k, i)
+                n_emit += 1
+            else:
+                obs_o, r_o, d_o = o.do_step(a[i])
+                assert v[i] == 1, (k, i)
+                n_trans += 1
+            done_o[i] = d_o
+            assert dg[i] == d_o, (k, i, v[i])
+            e = np.abs(og[i] - obs_o)
+            e[SLIDER_IMPULSE_COLS] = np.where(e[SLIDER_IMPULSE_COLS] > 1e-3, 0, e[SLIDER_IMPULSE_COLS])
+            worst = max(worst, float(e.max()))
+    print("autoreset vs oracle loop: %d transitions, %d reset emissions, worst obs diff %.3g" % (n_trans, n_emit, worst))
+    assert n_emit >= n and n_trans > 100
+    assert worst < 2e-3
