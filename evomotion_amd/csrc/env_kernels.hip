@@ -1163,29 +1163,49 @@ DEV void physics_step(const Ctx &c, int flags) {
     // the level-sorted schedule, so the globally lowest unfinished visit is always at the head of some wave's
     // list and cannot be blocked: no deadlock.  The record of the wave's next visit is requested before the
     // current one is solved (two register blocks, ping-pong, unrolled by two so no block is ever copied).
-    auto vis_of = [&](int e) { return (e & 0x7fff) == EVM_SCHED_NONE ? 0 : (e & 0x7fff); };
+    auto vis_of = [&](int e) { return (e & EVM_SCHED_CONTACT) ? 0 : e; };  // contact entries prefetch visit 0: harmless
+#ifdef EVM_STAMPS2
+    unsigned long long t_wait = 0, t_solve = 0;
+#endif
     auto run_visit = [&](const EvmVisitC &V, const Blk42 &k, int it) -> float {
         const int expA = it * c_skel.body[V.a].per_sweep + (V.need & 0xffff);
         const int expB = it * c_skel.body[V.b].per_sweep + (V.need >> 16);
-#ifdef EVM_STAMPS
-        const bool st = it == 3 && V.a == 0 && V.type == 0 && V.b == 2;  // the c1 hinge (body, legB) in sweep 3
-        if (st) STAMPX(9);
+#ifdef EVM_STAMPS2
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
 #endif
         wait_version(c, V.a, expA);
         wait_version(c, V.b, expB);
-#ifdef EVM_STAMPS
-        if (st) STAMPX(10);
+#ifdef EVM_STAMPS2
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();
 #endif
         const float r = solve(V, k);
-#ifdef EVM_STAMPS
-        if (st) STAMPX(11);
-#endif
         publish_version(c, V.a, expA + 1);
         publish_version(c, V.b, expB + 1);
-#ifdef EVM_STAMPS
-        if (st) STAMPX(12);
+#ifdef EVM_STAMPS2
+        t_wait += t1 - t0; t_solve += __builtin_amdgcn_s_memtime() - t1;
 #endif
         return r;
+    };
+    // contact rows of a member: after all of its joint visits of this sweep, before the next sweep's
+    auto run_contact = [&](int m, int it) -> float {
+        const int ps = c_skel.body[m].per_sweep;
+#ifdef EVM_STAMPS2
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#endif
+        wait_version(c, m, it * ps + ps - 1);
+#ifdef EVM_STAMPS2
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+#endif
+        float r = 0.f;
+        if (cmask & (1u << m)) r = contact_iter(c, m, GS(mfn, m));
+        publish_version(c, m, (it + 1) * ps);
+#ifdef EVM_STAMPS2
+        t_wait += t1 - t0; t_solve += __builtin_amdgcn_s_memtime() - t1;
+#endif
+        return r;
+    };
+    auto run_entry = [&](int e, const EvmVisitC &V, const Blk42 &k, int it) -> float {
+        return (e & EVM_SCHED_CONTACT) ? run_contact(e & (EVM_SCHED_CONTACT - 1), it) : run_visit(V, k, it);
     };
     for (int it = 0; it < NUM_ITER; it++) {
         res = 0.f;
@@ -1196,20 +1216,15 @@ DEV void physics_step(const Ctx &c, int flags) {
             blk_load(c, va, ka);
             for (int i = 0; i < ns; i += 2) {
                 if (i + 1 < ns) { eb = sched[i + 1]; vb = c_skel.visit[vis_of(eb)]; blk_load(c, vb, kb); }
-                if ((ea & 0x7fff) != EVM_SCHED_NONE) res = fmaxf(res, run_visit(va, ka, it));
+                res = fmaxf(res, run_entry(ea, va, ka, it));
                 if (i + 2 < ns) { ea = sched[i + 2]; va = c_skel.visit[vis_of(ea)]; blk_load(c, va, ka); }
-                if (i + 1 < ns && (eb & 0x7fff) != EVM_SCHED_NONE) res = fmaxf(res, run_visit(vb, kb, it));
+                if (i + 1 < ns) res = fmaxf(res, run_entry(eb, vb, kb, it));
             }
         }
-        // contact rows of a member come after all of its joint visits of this sweep and before the next sweep's
-        for (int m = 0; m < c_skel.nm; m++) {
-            if (c_skel.member_wave[m] != W) continue;
-            const int ps = c_skel.body[m].per_sweep;
-            wait_version(c, m, it * ps + ps - 1);
-            if (cmask & (1u << m)) res = fmaxf(res, contact_iter(c, m, GS(mfn, m)));
-            publish_version(c, m, (it + 1) * ps);
-        }
     }
+#ifdef EVM_STAMPS2
+    if (c.lane == 0) { c.d.stamps[(size_t) blockIdx.x * 16 + 2 * W] = t_wait; c.d.stamps[(size_t) blockIdx.x * 16 + 2 * W + 1] = t_solve; }
+#endif
     __syncthreads();
     STAMP(5);
     if (W == 0) {

@@ -69,6 +69,7 @@ struct EvmVisitC {
 #define EVM_MAX_SCHED (EVM_MAX_VISITS + 64)
 #define EVM_SCHED_NONE 0x7fff
 #define EVM_SCHED_BARRIER 0x8000
+#define EVM_SCHED_CONTACT 0x4000   // entry = EVM_SCHED_CONTACT | member: the member's contact rows of this sweep
 
 struct EvmSkelC {
     int nb, nm, nh, nf, nmus, root;
@@ -85,10 +86,11 @@ struct EvmSkelC {
     int sc_r, sc_ext, sc_ms, sc_pt, sc_mobs, sc_h, sc_f, sc_s, sc_p, sc_c, sc_total;
     int nvisit;
     EvmVisitC visit[EVM_MAX_VISITS];
-    // Level schedule of the sweep: visits that share no body commute exactly, so the Bullet-ordered visit list
-    // is cut into dependency levels (ASAP); the visits of a level are spread over the EVM_NW waves and a
-    // workgroup barrier closes the level.  Entry = visit index | EVM_SCHED_BARRIER on the last entry of a level
-    // (EVM_SCHED_NONE = no visit for this wave in this level, barrier only).
+    // Sweep schedule: visits that share no body commute exactly, so only the per-body order of visits matters.
+    // The host list-schedules one sweep (joint visits + one contact visit per member) onto the EVM_NW waves with
+    // a cost model, bottom-level priorities and a hop latency between waves; each wave's list is ordered by
+    // simulated start time (a linear extension of the dependency order => no deadlock with the version counters).
+    // Entry = joint visit index, or EVM_SCHED_CONTACT | member.
     int nlevels;
     int nsched[EVM_NW];
     int sched[EVM_NW][EVM_MAX_SCHED];

@@ -422,63 +422,76 @@ int load_skeleton_constants(const char *path, const EvmEnvParams &prm, EvmSkelC 
     }
     S.nvisit = nv;
 
-    // ---- level schedule ----
+    // ---- sweep schedule (list scheduling of one Gauss-Seidel sweep onto EVM_NW waves) ----
     {
-        std::vector<int> last(nb, 0), level(nv, 0);
+        // dependency depth, reported for information (the chain of visits on the root body)
+        std::vector<int> lastl(nb, 0);
         int nlev = 0;
         for (int i = 0; i < nv; i++) {
-            int l = 1 + std::max(last[S.visit[i].a], last[S.visit[i].b]);
-            level[i] = l;
-            last[S.visit[i].a] = last[S.visit[i].b] = l;
+            int l = 1 + std::max(lastl[S.visit[i].a], lastl[S.visit[i].b]);
+            lastl[S.visit[i].a] = lastl[S.visit[i].b] = l;
             nlev = std::max(nlev, l);
         }
         S.nlevels = nlev;
-        // latest level each visit may take: just before the next visit (in Bullet order) that shares a body
-        std::vector<int> alap(nv, nlev);
-        for (int i = 0; i < nv; i++)
-            for (int j = i + 1; j < nv; j++) {
-                const bool share = S.visit[j].a == S.visit[i].a || S.visit[j].a == S.visit[i].b ||
-                                   S.visit[j].b == S.visit[i].a || S.visit[j].b == S.visit[i].b;
-                if (share) { alap[i] = std::min(alap[i], level[j] - 1); }
-            }
-        const float cost[4] = {6.f, 6.f, 6.f, 1.5f};
-        std::vector<std::vector<float>> load(nlev + 1, std::vector<float>(EVM_NW, 0.f));
-        std::vector<std::vector<std::vector<int>>> per(nlev + 1, std::vector<std::vector<int>>(EVM_NW));
-        auto place = [&](int v, int l) {
-            int best = 0;
-            for (int w = 1; w < EVM_NW; w++) if (load[l][w] < load[l][best]) best = w;
-            per[l][best].push_back(v);
-            load[l][best] += cost[S.visit[v].type];
-        };
-        auto makespan_after = [&](int v, int l) {
-            float mn = load[l][0], mx = load[l][0];
-            for (int w = 1; w < EVM_NW; w++) { mn = std::min(mn, load[l][w]); mx = std::max(mx, load[l][w]); }
-            return std::max(mx, mn + cost[S.visit[v].type]) - mx;  // growth of the level's critical path
-        };
-        std::vector<int> order(nv);
-        for (int i = 0; i < nv; i++) order[i] = i;
-        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return cost[S.visit[x].type] > cost[S.visit[y].type]; });
-        for (int v : order) if (alap[v] <= level[v]) place(v, level[v]);           // no freedom
-        for (int v : order) if (alap[v] > level[v]) {                              // floating (the muscle sliders)
-            int bl = level[v];
-            float bg = makespan_after(v, bl);
-            for (int l = level[v] + 1; l <= alap[v]; l++) { float g = makespan_after(v, l); if (g < bg) { bg = g; bl = l; } }
-            level[v] = bl;
-            place(v, bl);
-        }
-        for (int w = 0; w < EVM_NW; w++) S.nsched[w] = 0;
-        for (int l = 1; l <= nlev; l++)
-            for (int w = 0; w < EVM_NW; w++) {
-                std::vector<int> &q = per[l][w];
-                std::sort(q.begin(), q.end());  // keep Bullet order inside a wave's slice of the level
-                if (q.empty()) q.push_back(EVM_SCHED_NONE);
-                for (size_t k = 0; k < q.size(); k++) {
-                    if (S.nsched[w] >= EVM_MAX_SCHED) { err = "sweep schedule overflow"; return EVM_E_UNSUPPORTED; }
-                    int e = q[k];
-                    if (k + 1 == q.size()) e |= EVM_SCHED_BARRIER;
-                    S.sched[w][S.nsched[w]++] = e;
+        // items: joint visits in Bullet order, then one contact item per member (after all its joint visits)
+        struct Item { int a, b; float cost; int entry; };
+        std::vector<Item> items;
+        // measured on MI355X (tools/stamps*.py): a 6-row visit ~2400 cycles, a p2p visit ~900, wave-to-wave hop ~500
+        const float cost_of[4] = {2400.f, 2400.f, 2400.f, 900.f};
+        for (int i = 0; i < nv; i++) items.push_back({S.visit[i].a, S.visit[i].b, cost_of[S.visit[i].type], i});
+        for (int m = 0; m < nm; m++)
+            items.push_back({m, m, S.member[m].hull_n > 64 ? 2500.f : 400.f, EVM_SCHED_CONTACT | m});
+        const int ni = (int) items.size();
+        const float hop = 500.f;
+        std::vector<std::vector<int>> preds(ni), succs(ni);
+        {
+            std::vector<int> last(nb, -1);
+            for (int i = 0; i < ni; i++) {
+                for (int body : {items[i].a, items[i].b}) {
+                    if (last[body] >= 0 && (preds[i].empty() || preds[i].back() != last[body])) {
+                        preds[i].push_back(last[body]);
+                        succs[last[body]].push_back(i);
+                    }
                 }
+                last[items[i].a] = last[items[i].b] = i;
             }
+        }
+        std::vector<float> bl(ni, 0.f);  // bottom level = longest path to the end of the sweep
+        for (int i = ni - 1; i >= 0; i--) {
+            float m = 0.f;
+            for (int sidx : succs[i]) m = std::max(m, bl[sidx]);
+            bl[i] = items[i].cost + m;
+        }
+        std::vector<int> npred(ni), wave_of(ni, -1);
+        std::vector<float> finish(ni, 0.f), avail(EVM_NW, 0.f);
+        std::vector<std::vector<int>> lists(EVM_NW);
+        for (int i = 0; i < ni; i++) npred[i] = (int) preds[i].size();
+        std::vector<char> done(ni, 0);
+        for (int step = 0; step < ni; step++) {
+            int pick = -1;
+            for (int i = 0; i < ni; i++)
+                if (!done[i] && npred[i] == 0 && (pick < 0 || bl[i] > bl[pick])) pick = i;
+            int bw = 0;
+            float bstart = 1e30f;
+            for (int w = 0; w < EVM_NW; w++) {
+                float st = avail[w];
+                for (int pidx : preds[pick]) st = std::max(st, finish[pidx] + (wave_of[pidx] != w ? hop : 0.f));
+                if (st < bstart - 1e-3f) { bstart = st; bw = w; }
+            }
+            wave_of[pick] = bw;
+            finish[pick] = bstart + items[pick].cost;
+            avail[bw] = finish[pick];
+            lists[bw].push_back(pick);
+            done[pick] = 1;
+            for (int sidx : succs[pick]) npred[sidx]--;
+        }
+        for (int w = 0; w < EVM_NW; w++) {
+            S.nsched[w] = 0;
+            for (int it : lists[w]) {
+                if (S.nsched[w] >= EVM_MAX_SCHED) { err = "sweep schedule overflow"; return EVM_E_UNSUPPORTED; }
+                S.sched[w][S.nsched[w]++] = items[it].entry;
+            }
+        }
         // members -> waves, heaviest hull first
         std::vector<int> ms(nm);
         for (int i = 0; i < nm; i++) ms[i] = i;

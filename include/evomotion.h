@@ -110,7 +110,7 @@ int evm_env_debug_physics_steps(EvmEnv *env, int n_steps, const uint8_t *d_mask)
 int evm_skeleton_probe(const char *skeleton_path, int *counts, float *h_out);
 /* Host-only: the Gauss-Seidel visit list (Bullet order) and the per-wave dataflow schedule derived from it.
  * dims[4] = nvisit, nlevels, n_waves, cap; visits [nvisit,4] = type, body a, body b, need (needA | needB << 16);
- * sched [n_waves, cap] = visit index | 0x8000 on a level's last entry, 0x7fff = idle in that level, -1 = past the end. */
+ * sched [n_waves, cap] = joint visit index, or 0x4000 | member for that member's contact rows, -1 = past the end. */
 int evm_skeleton_schedule(const char *skeleton_path, int *dims, int *visits, int *sched, int cap);
 /* Loader cross-check: per body 19 floats [mass, inv_mass, invI xyz, friction, break_thr, M0 rows(9), t0(3)] */
 int evm_env_get_body_constants(const EvmEnv *env, float *h_out);

@@ -18,45 +18,60 @@ def schedule(hip_lib, path):
     return visits[:nv], sched.reshape(-1)[: nw * cap].reshape(nw, cap), nlev, nw
 
 
-def check(visits, sched, nlev, nw):
+CONTACT = 0x4000
+
+
+def check(visits, sched, nlev, nw, nm):
+    """Every joint visit and every member's contact visit appears exactly once; the per-body `need` counters are
+    Bullet-order prefix counts; and (dependency edges) U (each wave's list order) is acyclic, i.e. there is a global
+    linear extension, so the version-counter waits cannot deadlock."""
     nv = len(visits)
-    level = -np.ones(nv, int)
-    pos = {}
-    for w in range(nw):
-        l = 0
-        for i, e in enumerate(sched[w]):
-            if e < 0:
-                break
-            v = e & 0x7FFF
-            if v != 0x7FFF:
-                assert level[v] == -1, "visit scheduled twice"
-                level[v] = l
-                pos[v] = (w, i)
-            if e & 0x8000:
-                l += 1
-        assert l == nlev, "every wave closes every level exactly once"
-    assert (level >= 0).all(), "every visit is scheduled"
+    lists = [[int(e) for e in sched[w] if e >= 0] for w in range(nw)]
+    flat = [e for l in lists for e in l]
+    assert sorted(e for e in flat if not e & CONTACT) == list(range(nv))
+    assert sorted(e & (CONTACT - 1) for e in flat if e & CONTACT) == list(range(nm))
     cnt = {}
     for i in range(nv):
         t, a, b, need = visits[i]
-        # the version each body must have reached = number of earlier visits (Bullet order) touching it
         assert need & 0xFFFF == cnt.get(a, 0) and need >> 16 == cnt.get(b, 0)
         cnt[a] = cnt.get(a, 0) + 1
         cnt[b] = cnt.get(b, 0) + 1
-        for j in range(i + 1, nv):
-            if {a, b} & {visits[j][1], visits[j][2]}:
-                assert level[i] < level[j], (i, j)  # dependent visits keep Bullet's order
-    # deadlock freedom: each wave's list is sorted by level
-    for w in range(nw):
-        ls = [level[e & 0x7FFF] for e in sched[w] if e >= 0 and (e & 0x7FFF) != 0x7FFF]
-        assert ls == sorted(ls)
+    # items in dependency order: joints (Bullet order) then contacts; edge = previous item touching the same body
+    bodies = {i: {int(visits[i][1]), int(visits[i][2])} for i in range(nv)}
+    items = list(range(nv)) + [CONTACT | m for m in range(nm)]
+    for m in range(nm):
+        bodies[CONTACT | m] = {m}
+    edges = {e: set() for e in items}
+    last = {}
+    for e in items:
+        for bd in bodies[e]:
+            if bd in last:
+                edges[last[bd]].add(e)
+            last[bd] = e
+    for l in lists:
+        for x, y in zip(l, l[1:]):
+            edges[x].add(y)
+    indeg = {e: 0 for e in items}
+    for e in items:
+        for y in edges[e]:
+            indeg[y] += 1
+    ready = [e for e in items if indeg[e] == 0]
+    seen = 0
+    while ready:
+        e = ready.pop()
+        seen += 1
+        for y in edges[e]:
+            indeg[y] -= 1
+            if indeg[y] == 0:
+                ready.append(y)
+    assert seen == len(items), "cycle: the schedule could deadlock"
 
 
 def test_spider_schedule(hip_lib):
     visits, sched, nlev, nw = schedule(hip_lib, hip_lib.DEFAULT_SKELETON)
     assert len(visits) == 52 and nlev == 8  # 12 hinges + 4 fixed + 12 x (slider, p2p, p2p); depth = the root-body chain
     assert (visits[:16, 0] <= 1).all() and list(visits[16:19, 0]) == [2, 3, 3]  # Bullet order (skeleton.cpp:77-90)
-    check(visits, sched, nlev, nw)
+    check(visits, sched, nlev, nw, 17)
 
 
 def test_generic_skeleton_schedules(hip_lib, tmp_path):
@@ -75,8 +90,9 @@ def test_generic_skeleton_schedules(hip_lib, tmp_path):
     path = write_skeleton(tmp_path / "chain.skel", members, cons, mus)
     visits, sched, nlev, nw = schedule(hip_lib, path)
     assert len(visits) == 5 + 6
-    check(visits, sched, nlev, nw)
+    check(visits, sched, nlev, nw, 6)
     # single body, no constraints: empty schedule
     path = write_skeleton(tmp_path / "cube.skel", [dict(name="body", mass=1.0, scale=(0.2, 0.2, 0.2))])
     visits, sched, nlev, nw = schedule(hip_lib, path)
     assert len(visits) == 0 and nlev == 0
+    check(visits, sched, nlev, nw, 1)
