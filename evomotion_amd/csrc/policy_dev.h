@@ -6,9 +6,9 @@
 namespace evm {
 
 struct NetDev {
-    const float *w1t;  // [K1pad][256]  Linear(S, 256) weight, transposed, zero padded to a multiple of 32 rows
+    const float *w1t;  // Linear(S, 256) weight packed [K1/8][256][2][4] (zero padded to K1 = 384), see policy_kernels.hip
     const float *b1, *g1, *be1;  // bias, LayerNorm weight / bias
-    const float *w2t;  // [256][256]
+    const float *w2t;  // Linear(256, 256) weight packed [32][256][2][4]
     const float *b2, *g2, *be2;
     const float *wh;   // heads, row major [out][256]: actor = mu rows then sigma rows (2A), critic = 1 row
     const float *bh;

@@ -34,11 +34,11 @@ int evm_policy_create(int state_dim, int action_dim, int hidden_size, int device
     if (!out) return pfail(EVM_E_INVALID, "out is null");
     *out = nullptr;
     if (hidden_size != 256) return pfail(EVM_E_UNSUPPORTED, "the fused forward is built for hidden_size = 256");
-    if (state_dim < 1 || action_dim < 1 || 2 * action_dim > 32) return pfail(EVM_E_INVALID, "unsupported state/action size");
+    if (state_dim < 1 || state_dim > 384 || action_dim < 1 || 2 * action_dim > 32) return pfail(EVM_E_INVALID, "unsupported state/action size");
     if (hipSetDevice(device) != hipSuccess) return pfail(EVM_E_HIP, "hipSetDevice failed");
     EvmPolicy *p = new EvmPolicy();
     p->S = state_dim; p->A = action_dim; p->H = hidden_size; p->device = device; p->counter = 0; p->timing = false; p->ev_used = 0;
-    p->K1pad = (state_dim + 31) / 32 * 32;
+    p->K1pad = 384;  // K1 of policy_kernels.hip
     const size_t per_net = (size_t) p->K1pad * 256 + 3 * 256 + 256 * 256 + 3 * 256;
     p->arena_floats = 2 * per_net + ((size_t) 2 * action_dim * 256 + 2 * action_dim) + (256 + 1);
     if (hipMalloc((void **) &p->arena, p->arena_floats * 4) != hipSuccess) { delete p; return pfail(EVM_E_HIP, "hipMalloc failed"); }
@@ -85,16 +85,23 @@ int evm_policy_set_weights(EvmPolicy *p, const float *h_actor, size_t n_actor, c
     std::vector<float> host(p->arena_floats, 0.f);
     auto pack = [&](const evm::NetDev &n, const float *src, int heads, bool actor) {
         const int S = p->S, A = p->A;
+        // packed for the MFMA B operand: Wp[s4][col][h][t] = W[col][k = 2 (4 s4 + t) + h]   (policy_kernels.hip)
         float *w1t = host.data() + (n.w1t - p->arena);
         for (int o = 0; o < 256; o++)
-            for (int k = 0; k < S; k++) w1t[(size_t) k * 256 + o] = src[(size_t) o * S + k];
+            for (int k = 0; k < S; k++) {
+                const int st = k >> 1, h = k & 1, s4 = st >> 2, t = st & 3;
+                w1t[(((size_t) s4 * 256 + o) * 2 + h) * 4 + t] = src[(size_t) o * S + k];
+            }
         src += (size_t) 256 * S;
         memcpy(host.data() + (n.b1 - p->arena), src, 256 * 4); src += 256;
         memcpy(host.data() + (n.g1 - p->arena), src, 256 * 4); src += 256;
         memcpy(host.data() + (n.be1 - p->arena), src, 256 * 4); src += 256;
         float *w2t = host.data() + (n.w2t - p->arena);
         for (int o = 0; o < 256; o++)
-            for (int k = 0; k < 256; k++) w2t[(size_t) k * 256 + o] = src[(size_t) o * 256 + k];
+            for (int k = 0; k < 256; k++) {
+                const int st = k >> 1, h = k & 1, s4 = st >> 2, t = st & 3;
+                w2t[(((size_t) s4 * 256 + o) * 2 + h) * 4 + t] = src[(size_t) o * 256 + k];
+            }
         src += 256 * 256;
         memcpy(host.data() + (n.b2 - p->arena), src, 256 * 4); src += 256;
         memcpy(host.data() + (n.g2 - p->arena), src, 256 * 4); src += 256;

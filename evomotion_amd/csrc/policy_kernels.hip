@@ -5,11 +5,12 @@
 //   ActorModule / CriticModule forward   evo_motion_networks/src/networks/actor.cpp:30-48, critic.cpp:23-35
 //   truncated_normal_sample / _log_pdf   evo_motion_networks/src/functions.cpp:53-68,94-111
 //
-// One workgroup (4 waves) owns a 64-row tile of the batch and ONE of the two networks (blockIdx.y: 0 actor,
+// One workgroup (4 waves) owns a TM-row tile of the batch and ONE of the two networks (blockIdx.y: 0 actor,
 // 1 critic).  Both hidden layers run on v_mfma_f32_32x32x2_f32 (exact fp32, k-ordered fma chain): each wave
-// owns 64 rows x 64 output columns as 2x2 accumulator tiles.  A operands come from LDS (observations staged
-// in 32-wide K chunks, activations kept in a [64][257] tile), B operands are read straight from the
-// pre-transposed [K][256] weights (two 128-byte segments per wave-instruction, L2 resident).  Bias, Mish,
+// owns TM rows x 64 output columns as RT x 2 accumulator tiles.  A operands come from LDS (observations staged
+// once, activations in a second tile, both "k-split" so a lane reads four k-steps with one ds_read_b128), B
+// operands are read straight from host-packed weights (one global_load_dwordx4 per lane per four k-steps,
+// 1 KiB contiguous per wave instruction, L2 resident).  Bias, Mish,
 // LayerNorm, the tanh/softplus heads, inverse-CDF sampling and the log-pdf are fused behind the GEMMs.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -20,75 +21,95 @@ namespace evm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#define PT 256       // threads per workgroup
-#define TM 64        // rows per workgroup
-#define HLD 257      // activation tile leading dimension (bank = (row + k) mod 32)
-#define XLD 33       // observation chunk leading dimension
+#define PT 256        // threads per workgroup (4 waves)
+#define RT 1          // 32-row MFMA tiles per wave: a workgroup owns TM = 32 RT rows.  RT = 1 puts the 4096-env batch
+                      // of BASELINE configs[2] on 2 x 128 = 256 workgroups, one per CU (RT = 2 left half the chip idle)
+#define TM (32 * RT)
+#define PARTS (PT / TM)   // threads sharing a row in the row-wise epilogues
+#define RUN (256 / PARTS) // stored activations per thread (a contiguous run of the k-split row)
+#define K1 384        // padded input width of layer 1 (371 -> 384), fixed by the host packer
+#define ALD1 (K1 + 4) // k-split observation tile row stride
+#define ALD2 (256 + 4) // k-split activation tile row stride
+#define HIDX(row, c) ((row) * ALD2 + ((c) & 1) * 128 + ((c) >> 1))
 
-__device__ __forceinline__ float mish_f(float x) { return x * tanhf(log1pf(expf(x))); }
+// Mish(x) = x tanh(softplus(x)).  With n = e^x: tanh(log(1 + n)) = n (n + 2) / (n (n + 2) + 2), all terms positive
+// (no cancellation), one exp and one division instead of exp + log1p + tanh (which cost ~300 VALU instructions per
+// value and were 40 % of the kernel).  x > 20: the ratio is 1 to fp32 precision and e^x would overflow at 88.
+__device__ __forceinline__ float mish_f(float x) {
+    const float n = __expf(fminf(x, 20.f));
+    const float m = n * (n + 2.f);
+    return x * __fdividef(m, m + 2.f);
+}
 __device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 __device__ __forceinline__ float theta_f(float x) { return 0.5f * (1.0f + erff(x / 1.41421356237309504880f)); }
 
-// one dense layer: acc[2][2] += A(64 x K, from LDS or staged from global) * Wt(K x 256)
-template <bool FROM_GLOBAL>
-__device__ __forceinline__ void dense_layer(const float *__restrict__ X, int n_rows, int row0, int S, int Kpad,
-                                            const float *__restrict__ Wt, float *xs, const float *hb, int wave, int lane,
-                                            f32x16 (&acc)[2][2]) {
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Operand packing for v_mfma_f32_32x32x2_f32: lane l = (j = l & 31, h = l >> 5) needs A[row j][k = 2s + h] and
+// B[k = 2s + h][col j] for k-step s.  Both operands are stored "k-split" so that FOUR consecutive k-steps of a
+// lane are 16 contiguous bytes:
+//   weights (global, packed on the host):  Wp[s4][col 0..255][h 0..1][t 0..3] = W[col][k = 2 (4 s4 + t) + h]
+//       -> one global_load_dwordx4 per lane per 4 k-steps, 1 KiB contiguous per wave instruction
+//   activations / observations (LDS):      As[row][h][kk] with k = 2 kk + h, row stride ALD floats
+//       -> one ds_read_b128 per lane per 4 k-steps
+// ALD = 2 * KH + 4 with KH = K/2 (a multiple of 4): the +4 skews rows by one 16-byte slot so that the 16-lane groups
+// of ds_read_b128 hit distinct slots.
+template <int K>
+__device__ __forceinline__ void dense_layer(const float *as, int ald, const float *__restrict__ Wp, int wave, int lane,
+                                            f32x16 (&acc)[RT][2]) {
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < RT; i++)
 #pragma unroll
         for (int j = 0; j < 2; j++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-    const int ai = lane & 31, ak = lane >> 5;
-    const int col = wave * 64 + (lane & 31);
-    if (FROM_GLOBAL) {
-        const int t = threadIdx.x;
-        const int srow = t >> 2, sk = (t & 3) * 8;
-        for (int kc = 0; kc < Kpad; kc += 32) {
-            // stage X[row0 .. row0+64)[kc .. kc+32) -> xs[64][XLD]
-            const int gr = row0 + srow;
+    const int aj = lane & 31, ah = lane >> 5;
+    const int col = wave * 64 + aj;
+    constexpr int KH = K / 2;
+    const float *ap = as + aj * ald + ah * KH;
+    const float *b0p = Wp + ((size_t) col * 2 + ah) * 4;
+    const float *b1p = Wp + ((size_t) (col + 32) * 2 + ah) * 4;
+    // Software pipeline, 4-deep register ring: the operands of block s4 + 3 are requested before the 8 RT MFMAs of
+    // block s4 issue, i.e. ~1500 cycles ahead — more than an L2 hit.  (Left to itself the compiler issued each
+    // block's loads right before its own MFMAs and waited on them: the kernel ran at half speed.)
+    constexpr int NB = K / 8;
+    static_assert(NB % 4 == 0, "K must be a multiple of 32");
+    f32x4 a[4][RT], b0[4], b1[4];
+#define EVM_LOADQ(q, s)                                                                                   \
+    {                                                                                                     \
+        _Pragma("unroll") for (int i = 0; i < RT; i++) a[q][i] =                                        \
+            *reinterpret_cast<const f32x4 *>(ap + i * 32 * ald + 4 * (s));                                \
+        b0[q] = *reinterpret_cast<const f32x4 *>(b0p + (size_t) (s) * 2048);                              \
+        b1[q] = *reinterpret_cast<const f32x4 *>(b1p + (size_t) (s) * 2048);                              \
+    }
+    EVM_LOADQ(0, 0) EVM_LOADQ(1, 1) EVM_LOADQ(2, 2)
+    __builtin_amdgcn_sched_barrier(0);
+    for (int s4 = 0; s4 < NB; s4 += 4) {
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int k = kc + sk + u;
-                float v = 0.f;
-                if (gr < n_rows && k < S) v = X[(size_t) gr * S + k];
-                xs[srow * XLD + sk + u] = v;
-            }
-            __syncthreads();
-#pragma unroll 4
-            for (int kk = 0; kk < 32; kk += 2) {
-                const float a0 = xs[ai * XLD + kk + ak], a1 = xs[(32 + ai) * XLD + kk + ak];
-                const float *wr = Wt + (size_t) (kc + kk + ak) * 256 + col;
-                const float b0 = wr[0], b1 = wr[32];
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-            }
-            __syncthreads();
-        }
-    } else {
-#pragma unroll 4
-        for (int k = 0; k < Kpad; k += 2) {
-            const float a0 = hb[ai * HLD + k + ak], a1 = hb[(32 + ai) * HLD + k + ak];
-            const float *wr = Wt + (size_t) (k + ak) * 256 + col;
-            const float b0 = wr[0], b1 = wr[32];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        for (int q = 0; q < 4; q++) {
+            const int sn = min(s4 + q + 3, NB - 1);  // the last three requests re-read the final block (harmless)
+            EVM_LOADQ((q + 3) & 3, sn)
+            __builtin_amdgcn_sched_barrier(0);  // keep the requests ahead of this block's MFMAs
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+                for (int i = 0; i < RT; i++) {
+                    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][i][t], b0[q][t], acc[i][0], 0, 0, 0);
+                    acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][i][t], b1[q][t], acc[i][1], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
+#undef EVM_LOADQ
 }
 
 // bias + Mish into the activation tile, then LayerNorm(256) per row
-__device__ __forceinline__ void epilogue_mish_ln(f32x16 (&acc)[2][2], const float *__restrict__ bias,
+__device__ __forceinline__ void epilogue_mish_ln(f32x16 (&acc)[RT][2], const float *__restrict__ bias,
                                                  const float *__restrict__ gamma, const float *__restrict__ beta,
                                                  float *hb, int wave, int lane) {
     // C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < RT; i++)
 #pragma unroll
         for (int j = 0; j < 2; j++) {
             const int c = wave * 64 + j * 32 + (lane & 31);
@@ -96,21 +117,40 @@ __device__ __forceinline__ void epilogue_mish_ln(f32x16 (&acc)[2][2], const floa
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                hb[row * HLD + c] = mish_f(acc[i][j][r] + b);
+                hb[HIDX(row, c)] = mish_f(acc[i][j][r] + b);
             }
         }
     __syncthreads();
-    const int t = threadIdx.x, row = t >> 2, part = t & 3;
+    // LayerNorm: PARTS threads per row, each owning a contiguous RUN of the k-split row (which columns a thread
+    // holds does not matter for the statistics); element q of the stored row is column 2 (q & 127) + (q >> 7)
+    const int t = threadIdx.x, row = t / PARTS, part = t % PARTS;
+    f32x4 *hr = reinterpret_cast<f32x4 *>(hb + row * ALD2 + part * RUN);
+    f32x4 x[RUN / 4];
     float s = 0.f;
-    for (int c = part * 64; c < part * 64 + 64; c++) s += hb[row * HLD + c];
-    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2);
+#pragma unroll
+    for (int i = 0; i < RUN / 4; i++) { x[i] = hr[i]; s += (x[i][0] + x[i][1]) + (x[i][2] + x[i][3]); }
+#pragma unroll
+    for (int m = 1; m < PARTS; m <<= 1) s += __shfl_xor(s, m);
     const float mean = s / 256.f;
     float v = 0.f;
-    for (int c = part * 64; c < part * 64 + 64; c++) { const float d = hb[row * HLD + c] - mean; v += d * d; }
-    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2);
+#pragma unroll
+    for (int i = 0; i < RUN / 4; i++)
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const float d = x[i][u] - mean; v += d * d; }
+#pragma unroll
+    for (int m = 1; m < PARTS; m <<= 1) v += __shfl_xor(v, m);
     const float rstd = 1.0f / sqrtf(v / 256.f + 1e-5f);
-    for (int c = part * 64; c < part * 64 + 64; c++)
-        hb[row * HLD + c] = (hb[row * HLD + c] - mean) * rstd * gamma[c] + beta[c];
+#pragma unroll
+    for (int i = 0; i < RUN / 4; i++) {
+        f32x4 y;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int q = part * RUN + 4 * i + u;
+            const int c = 2 * (q & 127) + (q >> 7);
+            y[u] = (x[i][u] - mean) * rstd * gamma[c] + beta[c];
+        }
+        hr[i] = y;
+    }
     __syncthreads();
 }
 
@@ -128,42 +168,106 @@ __global__ __launch_bounds__(PT) void k_policy_forward(PolicyDev p, int n, const
                                                        float *action, float *logp, float *value, float *mu_out,
                                                        float *sigma_out) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float *hb = sm;               // [64][HLD]
-    float *xs = sm + TM * HLD;    // [64][XLD]
-    const int net = blockIdx.y;   // 0 actor, 1 critic
+    // one buffer, two lives: the observation tile [TM][ALD1] during layer 1, then the activation tile [TM][ALD2]
+    // followed by the staged head weights [32][256] and the head pre-activations [TM][32]
+    float *xs = sm;
+    float *hb = sm;
+    const int net = blockIdx.y;    // 0 actor, 1 critic
     const int row0 = blockIdx.x * TM;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const NetDev &N = net == 0 ? p.actor : p.critic;
-    f32x16 acc[2][2];
-    dense_layer<true>(obs, n, row0, p.S, p.K1pad, N.w1t, xs, hb, wave, lane, acc);
+    {   // stage the TM x S observation tile once, zero padded to K1 columns, k-split in LDS
+        const int S = p.S;
+        const size_t base = (size_t) row0 * S;
+        const int tile = TM * S;  // floats; rows of the tile are contiguous in memory
+        if (row0 + TM <= n && (tile & 3) == 0 && ((reinterpret_cast<uintptr_t>(obs + base)) & 15) == 0) {
+            // full, 16-byte aligned tile: flat float4 loads, all in flight together
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(obs + base);
+            const int nq = tile >> 2;
+            constexpr int NIT = (TM * K1 / 4 + PT - 1) / PT;  // upper bound (S <= K1)
+            f32x4 v[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; it++) {
+                const int q = it * PT + (int) threadIdx.x;
+                v[it] = src[min(q, nq - 1)];
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; it++) {
+                const int q = it * PT + (int) threadIdx.x;
+                if (q < nq) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int e = 4 * q + u, r = e / S, k = e - r * S;
+                        xs[r * ALD1 + (k & 1) * (K1 / 2) + (k >> 1)] = v[it][u];
+                    }
+                }
+            }
+            for (int e = threadIdx.x; e < TM * (K1 - S); e += PT) {
+                const int r = e / (K1 - S), k = S + e % (K1 - S);
+                xs[r * ALD1 + (k & 1) * (K1 / 2) + (k >> 1)] = 0.f;
+            }
+        } else {
+            // ragged last tile or unaligned caller buffer: scalar loads, clamped address + select (no branches)
+            const size_t last = (size_t) n * S - 1;
+            for (int e = threadIdx.x; e < TM * K1; e += PT) {
+                const int r = e / K1, k = e % K1;
+                const bool ok = row0 + r < n && k < S;
+                const size_t g = base + (size_t) r * S + k;
+                const float v = obs[g < last ? g : last];
+                xs[r * ALD1 + (k & 1) * (K1 / 2) + (k >> 1)] = ok ? v : 0.f;
+            }
+        }
+    }
+    __syncthreads();
+    f32x16 acc[RT][2];
+    dense_layer<K1>(xs, ALD1, N.w1t, wave, lane, acc);
+    __syncthreads();  // every wave has finished reading the observation tile
     epilogue_mish_ln(acc, N.b1, N.g1, N.be1, hb, wave, lane);
-    dense_layer<false>(nullptr, n, row0, p.S, 256, N.w2t, xs, hb, wave, lane, acc);
+    dense_layer<256>(hb, ALD2, N.w2t, wave, lane, acc);
     __syncthreads();  // every wave has finished reading the layer-1 activations
     epilogue_mish_ln(acc, N.b2, N.g2, N.be2, hb, wave, lane);
 
-    const int t = threadIdx.x, row = t >> 2, part = t & 3;
+    // heads: Linear(256, 1) for the critic, Linear(256, A) x 2 (mu, sigma) for the actor.  The head weights are
+    // staged into the (dead) observation tile in the activations' k-split order; thread (row, part) takes its RUN
+    // stored activations against every output and the 4 parts are summed with two shuffles.
+    const int t = threadIdx.x, row = t / PARTS, part = t % PARTS;
     const int gr = row0 + row;
-    if (net == 1) {  // critic head: Linear(256, 1)
-        float s = 0.f;
-        for (int c = part * 64; c < part * 64 + 64; c++) s += hb[row * HLD + c] * N.wh[c];
-        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2);
-        if (part == 0 && gr < n) value[gr] = s + N.bh[0];
-        return;
-    }
-    // actor heads: mu = tanh(Linear(256, A)), sigma = softplus(Linear(256, A)); 2A outputs split over 4 threads
     const int A = p.A;
-    for (int o = part; o < 2 * A; o += 4) {
-        const float *w = N.wh + (size_t) o * 256;
-        float s = 0.f;
-        for (int c = 0; c < 256; c++) s += hb[row * HLD + c] * w[c];
-        s += N.bh[o];
-        xs[row * XLD + o] = s;  // pre-activation heads parked in the idle staging tile; 2A <= 32 is checked on the host
+    const int nout = net == 1 ? 1 : 2 * A;
+    float *wl = sm + TM * ALD2;  // [nout][256] k-split
+    float *hs = wl + 32 * 256;   // [TM][32] pre-activations
+    for (int e = threadIdx.x; e < nout * 256; e += PT) {
+        const int c = e & 255;
+        wl[(e & ~255) + (c & 1) * 128 + (c >> 1)] = N.wh[e];
     }
     __syncthreads();
-    for (int a = part; a < A; a += 4) {
+    {
+        const f32x4 *hr = reinterpret_cast<const f32x4 *>(hb + row * ALD2 + part * RUN);
+        f32x4 x[RUN / 4];
+#pragma unroll
+        for (int i = 0; i < RUN / 4; i++) x[i] = hr[i];
+        for (int o = 0; o < nout; o++) {
+            const f32x4 *wr = reinterpret_cast<const f32x4 *>(wl + o * 256 + part * RUN);
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < RUN / 4; i++) {
+                const f32x4 w = wr[i];
+                sum += (x[i][0] * w[0] + x[i][1] * w[1]) + (x[i][2] * w[2] + x[i][3] * w[3]);
+            }
+#pragma unroll
+            for (int m = 1; m < PARTS; m <<= 1) sum += __shfl_xor(sum, m);
+            if (part == 0) hs[row * 32 + o] = sum + N.bh[o];
+        }
+    }
+    if (net == 1) {
+        if (part == 0 && gr < n) value[gr] = hs[row * 32];
+        return;
+    }
+    __syncthreads();
+    for (int a = part; a < A; a += PARTS) {
         if (gr >= n) continue;
-        const float mu = tanhf(xs[row * XLD + a]);
-        const float sigma = softplus_f(xs[row * XLD + A + a]);
+        const float mu = tanhf(hs[row * 32 + a]);
+        const float sigma = softplus_f(hs[row * 32 + A + a]);
         // truncated_normal_sample(mu, sigma, -1, 1)
         const float ss = fminf(fmaxf(sigma, 1e-6f), 1e6f);
         const float al = fminf(fmaxf((-1.f - mu) / ss, -5.f), 5.f);
@@ -185,7 +289,10 @@ __global__ __launch_bounds__(PT) void k_policy_forward(PolicyDev p, int n, const
     }
 }
 
-size_t policy_lds_bytes() { return (size_t) (TM * HLD + TM * XLD) * sizeof(float); }
+size_t policy_lds_bytes() {
+    const size_t a = (size_t) TM * ALD1, b = (size_t) TM * ALD2 + 32 * 256 + TM * 32;
+    return (a > b ? a : b) * sizeof(float);
+}
 
 hipError_t launch_policy_forward(const PolicyDev &p, int n, const float *obs, const float *uniform, uint64_t seed,
                                  uint64_t counter, float *action, float *logp, float *value, float *mu, float *sigma,

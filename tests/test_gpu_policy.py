@@ -49,7 +49,7 @@ def test_sampling_and_logp_against_oracle(gold, fused):
     import torch
     f, pa, pc = fused
     rng = np.random.default_rng(0)
-    n = 333  # ragged: not a multiple of the 64-row tile
+    n = 333  # ragged: not a multiple of the 32-row tile
     x = rng.uniform(-1, 1, (n, 371)).astype(np.float32)
     u = rng.uniform(0, 1, (n, 12)).astype(np.float32)
     action, logp, value, mu, sigma = f.forward(torch.from_numpy(x).cuda(), uniform=torch.from_numpy(u).cuda(), want_dist=True)
@@ -66,6 +66,26 @@ def test_sampling_and_logp_against_oracle(gold, fused):
     np.testing.assert_allclose(a, a_o, atol=5e-4)
     lp_o = ao.tn_log_pdf(a, m, s)
     np.testing.assert_allclose(logp.cpu().numpy(), lp_o, atol=2e-4, rtol=2e-4)
+
+
+def test_unaligned_observation_buffer_takes_the_scalar_staging_path(fused):
+    """A caller buffer that is only 4-byte aligned (the C ABI promises nothing more) must give the same outputs as the
+    16-byte aligned float4 staging path."""
+    import torch
+    f, pa, pc = fused
+    g = torch.Generator(device="cpu").manual_seed(5)
+    n = 96
+    x = (torch.rand(n, 371, generator=g) * 2 - 1)
+    u = torch.rand(n, 12, generator=g).cuda()
+    aligned = x.cuda()
+    buf = torch.zeros(n * 371 + 1, device="cuda")
+    buf[1:] = aligned.reshape(-1)
+    shifted = buf[1:].view(n, 371)
+    assert shifted.data_ptr() % 16 == 4 and shifted.is_contiguous()
+    ref = f.forward(aligned, uniform=u, want_dist=True)
+    got = f.forward(shifted, uniform=u, want_dist=True)
+    for r, o in zip(ref, got):
+        assert torch.equal(r, o)
 
 
 def test_matches_torch_modules_at_full_batch(fused):
