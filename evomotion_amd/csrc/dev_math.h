@@ -80,6 +80,33 @@ DEV F3 quat_rotate(Q4 r, F3 v) {
     Q4 t = qmul(qmulv(r, v), qinv(r));
     return f3(t.x, t.y, t.z);
 }
+// ---- packed pairs -------------------------------------------------------------------------------------------
+// gfx950 issues v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 (two fp32 per lane per instruction) at the same rate as
+// their scalar forms: the chip's fp32 vector peak is quoted with them.  The two sides of a constraint row (body A
+// and body B) run the same arithmetic on different operands, so a row is written once on (A, B) pairs.
+typedef float P2 __attribute__((ext_vector_type(2)));
+DEV P2 p2(float a, float b) { P2 r; r.x = a; r.y = b; return r; }
+struct F3P {
+    P2 x, y, z;
+};
+DEV F3P f3p(P2 x, P2 y, P2 z) { F3P r; r.x = x; r.y = y; r.z = z; return r; }
+DEV F3P pair(F3 a, F3 b) { return f3p(p2(a.x, b.x), p2(a.y, b.y), p2(a.z, b.z)); }
+DEV F3 lo(const F3P &a) { return f3(a.x.x, a.y.x, a.z.x); }
+DEV F3 hi(const F3P &a) { return f3(a.x.y, a.y.y, a.z.y); }
+DEV F3P operator+(F3P a, F3P b) { return f3p(a.x + b.x, a.y + b.y, a.z + b.z); }
+DEV F3P operator-(F3P a, F3P b) { return f3p(a.x - b.x, a.y - b.y, a.z - b.z); }
+DEV F3P operator*(F3P a, P2 s) { return f3p(a.x * s, a.y * s, a.z * s); }
+DEV F3P operator*(F3P a, float s) { return f3p(a.x * s, a.y * s, a.z * s); }
+DEV P2 dot(F3P a, F3P b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+DEV F3P cross(F3P a, F3P b) { return f3p(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+struct S33P {
+    P2 xx, xy, xz, yy, yz, zz;
+};
+DEV F3P mul(const S33P &s, F3P v) {
+    return f3p(s.xx * v.x + s.xy * v.y + s.xz * v.z, s.xy * v.x + s.yy * v.y + s.yz * v.z,
+               s.xz * v.x + s.yz * v.y + s.zz * v.z);
+}
+
 // Individually rounded multiply / add (no fma contraction).  Used only where a DISCRETE decision of the
 // reference algorithm hangs on rounding noise (zero-width slider limit, deepest-vertex choice), so that the
 // decision is reproducible from identical inputs.

@@ -212,17 +212,64 @@ DEV float row_iter(F3 ax, F3 relA, F3 relB, BodyD &A, BodyD &B, float jd, float 
     return dI;
 }
 
+// Both bodies of a joint visit as (A, B) pairs: one packed instruction serves both sides of a row.
+struct BodyPD {
+    F3P dl, da;
+    S33P I;
+    P2 im;
+};
+DEV BodyPD load_bodypd(const Ctx &c, int a, int b, float imA, float imB) {
+    BodyPD k;
+    k.dl = f3p(p2(LDV(a, 0), LDV(b, 0)), p2(LDV(a, 1), LDV(b, 1)), p2(LDV(a, 2), LDV(b, 2)));
+    k.da = f3p(p2(LDV(a, 3), LDV(b, 3)), p2(LDV(a, 4), LDV(b, 4)), p2(LDV(a, 5), LDV(b, 5)));
+    k.I.xx = p2(LII(a, 0), LII(b, 0)); k.I.xy = p2(LII(a, 1), LII(b, 1)); k.I.xz = p2(LII(a, 2), LII(b, 2));
+    k.I.yy = p2(LII(a, 3), LII(b, 3)); k.I.yz = p2(LII(a, 4), LII(b, 4)); k.I.zz = p2(LII(a, 5), LII(b, 5));
+    k.im = p2(imA, imB);
+    return k;
+}
+DEV void store_bodypd(const Ctx &c, int a, int b, const BodyPD &k) {
+    LDV(a, 0) = k.dl.x.x; LDV(a, 1) = k.dl.y.x; LDV(a, 2) = k.dl.z.x;
+    LDV(a, 3) = k.da.x.x; LDV(a, 4) = k.da.y.x; LDV(a, 5) = k.da.z.x;
+    LDV(b, 0) = k.dl.x.y; LDV(b, 1) = k.dl.y.y; LDV(b, 2) = k.dl.z.y;
+    LDV(b, 3) = k.da.x.y; LDV(b, 4) = k.da.y.y; LDV(b, 5) = k.da.z.y;
+}
+// One Gauss-Seidel row on the pair.  With axp = (ax, -ax): c = rel x axp gives (relA x ax, -(relB x ax)), and
+// d = axp . dl + c . da gives (J_A . delta_A, J_B . delta_B) exactly as the two scalar sides did.
+template <bool LIN, bool BOUNDED>
+DEV float row_iter(F3 ax, const F3P &rel, BodyPD &Q, float jd, float rhs, float lo, float hi, float &applied) {
+    const F3P axp = f3p(p2(ax.x, -ax.x), p2(ax.y, -ax.y), p2(ax.z, -ax.z));
+    const F3P cc = LIN ? cross(rel, axp) : axp;
+    const P2 d = LIN ? dot(axp, Q.dl) + dot(cc, Q.da) : dot(cc, Q.da);
+    const F3P ang = mul(Q.I, cc);
+    float dI = rhs;
+    dI -= d.x * jd;
+    dI -= d.y * jd;
+    const float sum = applied + dI;
+    if (BOUNDED) {
+        if (sum < lo) { dI = lo - applied; applied = lo; }
+        else if (sum > hi) { dI = hi - applied; applied = hi; }
+        else applied = sum;
+    } else applied = sum;
+    if (LIN) Q.dl = Q.dl + axp * (Q.im * dI);
+    Q.da = Q.da + ang * dI;
+    return dI;
+}
+
 // register block holding one constraint's scratch record (loaded one constraint ahead of its use)
 struct Blk42 {
-    float v[42];
+    float v[EVM_CM_STRIDE];  // the largest record (a member's contact rows)
 };
 DEV void blk_load(const Ctx &c, const EvmVisitC &v, Blk42 &b) {
     const float *p = c.t.scratch + (v.slot << 6) + c.lane;
 #pragma unroll
     for (int i = 0; i < 15; i++) b.v[i] = p[i << 6];
-    if (v.nslots > 15) {  // wave-uniform: p2p records are 15 floats, the others 35..42
+    if (v.nslots > 15) {  // wave-uniform: p2p records are 15 floats, joints 35..42, contacts 48
 #pragma unroll
         for (int i = 15; i < 42; i++) b.v[i] = p[i << 6];
+        if (v.nslots > 42) {
+#pragma unroll
+            for (int i = 42; i < EVM_CM_STRIDE; i++) b.v[i] = p[i << 6];
+        }
     }
 }
 DEV F3 v3(const float *v, int i) { return f3(v[i], v[i + 1], v[i + 2]); }
@@ -305,15 +352,16 @@ DEV float hinge_solve(const Ctx &c, const EvmVisitC &V, const Blk42 &k) {
 #pragma unroll
     for (int r = 0; r < 6; r++) ap[r] = k.v[29 + r];
     const float lo = k.v[27], hi_ = k.v[28];
-    BodyD A = load_bodyd(c, V.a, V.imA), B = load_bodyd(c, V.b, V.imB);
+    BodyPD Q = load_bodypd(c, V.a, V.b, V.imA, V.imB);
+    const F3P rel = pair(relA, relB);
     float res = 0.f;
-    res = fmaxf(res, fabsf(row_iter<true, false>(p, relA, relB, A, B, k.v[15], k.v[21], 0.f, 0.f, ap[0])));
-    res = fmaxf(res, fabsf(row_iter<true, false>(q, relA, relB, A, B, k.v[16], k.v[22], 0.f, 0.f, ap[1])));
-    res = fmaxf(res, fabsf(row_iter<true, false>(ax1, relA, relB, A, B, k.v[17], k.v[23], 0.f, 0.f, ap[2])));
-    res = fmaxf(res, fabsf(row_iter<false, false>(p, relA, relB, A, B, k.v[18], k.v[24], 0.f, 0.f, ap[3])));
-    res = fmaxf(res, fabsf(row_iter<false, false>(q, relA, relB, A, B, k.v[19], k.v[25], 0.f, 0.f, ap[4])));
-    if (k.v[20] != 0.f) res = fmaxf(res, fabsf(row_iter<false, true>(ax1, relA, relB, A, B, k.v[20], k.v[26], lo, hi_, ap[5])));
-    store_bodyd(c, V.a, A); store_bodyd(c, V.b, B);
+    res = fmaxf(res, fabsf(row_iter<true, false>(p, rel, Q, k.v[15], k.v[21], 0.f, 0.f, ap[0])));
+    res = fmaxf(res, fabsf(row_iter<true, false>(q, rel, Q, k.v[16], k.v[22], 0.f, 0.f, ap[1])));
+    res = fmaxf(res, fabsf(row_iter<true, false>(ax1, rel, Q, k.v[17], k.v[23], 0.f, 0.f, ap[2])));
+    res = fmaxf(res, fabsf(row_iter<false, false>(p, rel, Q, k.v[18], k.v[24], 0.f, 0.f, ap[3])));
+    res = fmaxf(res, fabsf(row_iter<false, false>(q, rel, Q, k.v[19], k.v[25], 0.f, 0.f, ap[4])));
+    if (k.v[20] != 0.f) res = fmaxf(res, fabsf(row_iter<false, true>(ax1, rel, Q, k.v[20], k.v[26], lo, hi_, ap[5])));
+    store_bodypd(c, V.a, V.b, Q);
 #pragma unroll
     for (int r = 0; r < 6; r++) SC(s + 29 + r) = ap[r];
     return res;
@@ -383,15 +431,16 @@ DEV float fixed_solve(const Ctx &c, const EvmVisitC &V, const Blk42 &k) {
     float ap[6];
 #pragma unroll
     for (int r = 0; r < 6; r++) ap[r] = k.v[36 + r];
-    BodyD A = load_bodyd(c, V.a, V.imA), B = load_bodyd(c, V.b, V.imB);
+    BodyPD Q = load_bodypd(c, V.a, V.b, V.imA, V.imB);
+    const F3P rel = pair(relA, relB);
     float res = 0.f;
 #pragma unroll
     for (int r = 0; r < 3; r++)
-        res = fmaxf(res, fabsf(row_iter<false, false>(v3(k.v, 6 + 3 * r), relA, relB, A, B, k.v[24 + r], k.v[30 + r], 0.f, 0.f, ap[r])));
+        res = fmaxf(res, fabsf(row_iter<false, false>(v3(k.v, 6 + 3 * r), rel, Q, k.v[24 + r], k.v[30 + r], 0.f, 0.f, ap[r])));
 #pragma unroll
     for (int r = 0; r < 3; r++)
-        res = fmaxf(res, fabsf(row_iter<true, false>(v3(k.v, 15 + 3 * r), relA, relB, A, B, k.v[27 + r], k.v[33 + r], 0.f, 0.f, ap[3 + r])));
-    store_bodyd(c, V.a, A); store_bodyd(c, V.b, B);
+        res = fmaxf(res, fabsf(row_iter<true, false>(v3(k.v, 15 + 3 * r), rel, Q, k.v[27 + r], k.v[33 + r], 0.f, 0.f, ap[3 + r])));
+    store_bodypd(c, V.a, V.b, Q);
 #pragma unroll
     for (int r = 0; r < 6; r++) SC(s + 36 + r) = ap[r];
     return res;
@@ -519,21 +568,22 @@ DEV void slider_setup(const Ctx &c, int mi, bool powered_in, float target_vel) {
 DEV float slider_solve(const Ctx &c, const EvmVisitC &V, const Blk42 &kk) {
     const float *ks = kk.v;
     const int s = V.slot;
-    const F3 p = v3(ks, 0), q = v3(ks, 3), ax1 = v3(ks, 6), p2 = v3(ks, 9), q2 = v3(ks, 12);
+    const F3 p = v3(ks, 0), q = v3(ks, 3), ax1 = v3(ks, 6), p2_ = v3(ks, 9), q2 = v3(ks, 12);
     const F3 relA = v3(ks, 15), relB = v3(ks, 18);
     float ap[6];
 #pragma unroll
     for (int r = 0; r < 6; r++) ap[r] = ks[35 + r];
     const float lo = ks[33], hi_ = ks[34];
-    BodyD A = load_bodyd(c, V.a, V.imA), B = load_bodyd(c, V.b, V.imB);
+    BodyPD Q = load_bodypd(c, V.a, V.b, V.imA, V.imB);
+    const F3P rel = pair(relA, relB);
     float res = 0.f;
-    res = fmaxf(res, fabsf(row_iter<false, false>(p, relA, relB, A, B, ks[21], ks[27], 0.f, 0.f, ap[0])));
-    res = fmaxf(res, fabsf(row_iter<false, false>(q, relA, relB, A, B, ks[22], ks[28], 0.f, 0.f, ap[1])));
-    res = fmaxf(res, fabsf(row_iter<true, false>(p2, relA, relB, A, B, ks[23], ks[29], 0.f, 0.f, ap[2])));
-    res = fmaxf(res, fabsf(row_iter<true, false>(q2, relA, relB, A, B, ks[24], ks[30], 0.f, 0.f, ap[3])));
-    if (ks[25] != 0.f) res = fmaxf(res, fabsf(row_iter<true, true>(ax1, relA, relB, A, B, ks[25], ks[31], lo, hi_, ap[4])));
-    if (ks[26] != 0.f) res = fmaxf(res, fabsf(row_iter<false, false>(ax1, relA, relB, A, B, ks[26], ks[32], 0.f, 0.f, ap[5])));
-    store_bodyd(c, V.a, A); store_bodyd(c, V.b, B);
+    res = fmaxf(res, fabsf(row_iter<false, false>(p, rel, Q, ks[21], ks[27], 0.f, 0.f, ap[0])));
+    res = fmaxf(res, fabsf(row_iter<false, false>(q, rel, Q, ks[22], ks[28], 0.f, 0.f, ap[1])));
+    res = fmaxf(res, fabsf(row_iter<true, false>(p2_, rel, Q, ks[23], ks[29], 0.f, 0.f, ap[2])));
+    res = fmaxf(res, fabsf(row_iter<true, false>(q2, rel, Q, ks[24], ks[30], 0.f, 0.f, ap[3])));
+    if (ks[25] != 0.f) res = fmaxf(res, fabsf(row_iter<true, true>(ax1, rel, Q, ks[25], ks[31], lo, hi_, ap[4])));
+    if (ks[26] != 0.f) res = fmaxf(res, fabsf(row_iter<false, false>(ax1, rel, Q, ks[26], ks[32], 0.f, 0.f, ap[5])));
+    store_bodypd(c, V.a, V.b, Q);
 #pragma unroll
     for (int r = 0; r < 6; r++) SC(s + 35 + r) = ap[r];
     return res;
@@ -775,6 +825,7 @@ DEV void contact_setup(const Ctx &c, int m, int n) {
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         pjd[j] = 0.f; prhs[j] = 0.f; ppush[j] = 0.f; pc2[j] = f3(0, 0, 0); pang[j] = f3(0, 0, 0);
+        if (j >= n) SC(c_skel.sc_c + EVM_CM_STRIDE * m + EVM_C_STRIDE * j + 6) = 0.f;  // jd_n == 0 marks "no point" for the sweeps
         if (j < n) {
             const F3 lb = f3(MFP(m, j, 3), MFP(m, j, 4), MFP(m, j, 5));
             const float dist = MFP(m, j, 6);
@@ -822,10 +873,12 @@ DEV void contact_setup(const Ctx &c, int m, int n) {
             const float fapplied = MFP(m, j, 8) * WARM_F;
             D.dl = D.dl + ((-fn2) * B.im) * (-fapplied);
             D.da = D.da + (-fangB) * (-fapplied);
-            const int s = c_skel.sc_c + EVM_C_STRIDE * (4 * m + j);
+            const int s = c_skel.sc_c + EVM_CM_STRIDE * m + EVM_C_STRIDE * j;
             SSC3(s + 0, rel); SSC3(s + 3, lat);
             SC(s + 6) = jd; SC(s + 7) = rhs; SC(s + 8) = fjd; SC(s + 9) = frhs;
-            MFP(m, j, 7) = applied; MFP(m, j, 8) = fapplied;
+            // the accumulated impulses live in the record during the sweeps (contact_writeback returns them)
+            SC(c_skel.sc_c + EVM_CM_STRIDE * m + 40 + 2 * j) = applied;
+            SC(c_skel.sc_c + EVM_CM_STRIDE * m + 41 + 2 * j) = fapplied;
             pjd[j] = jd; prhs[j] = rhs_pen; pc2[j] = c2; pang[j] = angB;
             any_pen = any_pen || (rhs_pen != 0.f);
         }
@@ -850,21 +903,24 @@ DEV void contact_setup(const Ctx &c, int m, int n) {
     SSC3(c_skel.sc_pt + 6 * m, push); SSC3(c_skel.sc_pt + 6 * m + 3, turn);
 }
 
-DEV float contact_iter(const Ctx &c, int m, int n) {
+// Gauss-Seidel rows of member m's contact points; k = the member's record, requested one schedule entry ahead
+DEV float contact_iter(const Ctx &c, int m, const Blk42 &k) {
     const EvmMemberC &MB = c_skel.member[m];
+    const int rec = c_skel.sc_c + EVM_CM_STRIDE * m;
     BodyD D = load_bodyd(c, m);
     float res = 0.f;
     float apn[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         apn[j] = 0.f;
-        if (j < n) {  // resolveSingleConstraintRowLowerLimit
-            const int s = c_skel.sc_c + EVM_C_STRIDE * (4 * m + j);
-            const F3 rel = SC3(s + 0);
-            const float jd = SC(s + 6), rhs = SC(s + 7);
+        const bool has = k.v[10 * j + 6] != 0.f;  // jd_n = 1 / denominator > 0 for a live point
+        if (!__any(has)) continue;
+        if (has) {  // resolveSingleConstraintRowLowerLimit
+            const F3 rel = v3(k.v, 10 * j);
+            const float jd = k.v[10 * j + 6], rhs = k.v[10 * j + 7];
             const F3 c2 = -cross(rel, f3(0.f, -1.f, 0.f));
             const F3 angB = mul(D.I, c2);
-            float ap = MFP(m, j, 7);
+            float ap = k.v[40 + 2 * j];
             float dI = rhs;
             const float d2 = D.dl.y + dot(c2, D.da);
             dI -= d2 * jd;
@@ -872,22 +928,22 @@ DEV float contact_iter(const Ctx &c, int m, int n) {
             if (sum < 0.f) { dI = 0.f - ap; ap = 0.f; } else ap = sum;
             D.dl = D.dl + (f3(0.f, 1.f, 0.f) * D.im) * dI;
             D.da = D.da + angB * dI;
-            MFP(m, j, 7) = ap;
+            SC(rec + 40 + 2 * j) = ap;
             apn[j] = ap;
             res = fmaxf(res, fabsf(dI));
         }
     }
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        if (j < n && apn[j] > 0.f) {  // friction row with limits +-mu * normal impulse
-            const int s = c_skel.sc_c + EVM_C_STRIDE * (4 * m + j);
-            const F3 rel = SC3(s + 0), lat = SC3(s + 3);
-            const float jd = SC(s + 8), rhs = SC(s + 9);
+        if (!__any(apn[j] > 0.f)) continue;
+        if (apn[j] > 0.f) {  // friction row with limits +-mu * normal impulse
+            const F3 rel = v3(k.v, 10 * j), lat = v3(k.v, 10 * j + 3);
+            const float jd = k.v[10 * j + 8], rhs = k.v[10 * j + 9];
             const F3 n2 = -lat;
             const F3 c2 = cross(rel, n2);
             const F3 angB = mul(D.I, c2);
             const float lim = MB.mu * apn[j];
-            float ap = MFP(m, j, 8);
+            float ap = k.v[41 + 2 * j];
             float dI = rhs;
             const float d2 = dot(n2, D.dl) + dot(c2, D.da);
             dI -= d2 * jd;
@@ -897,12 +953,19 @@ DEV float contact_iter(const Ctx &c, int m, int n) {
             else ap = sum;
             D.dl = D.dl + (n2 * D.im) * dI;
             D.da = D.da + angB * dI;
-            MFP(m, j, 8) = ap;
+            SC(rec + 41 + 2 * j) = ap;
             res = fmaxf(res, fabsf(dI));
         }
     }
     store_bodyd(c, m, D);
     return res;
+}
+// after the sweeps: the accumulated impulses go back into the persistent manifold (warm start of the next step)
+DEV void contact_writeback(const Ctx &c, int m, int n) {
+    const int rec = c_skel.sc_c + EVM_CM_STRIDE * m;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        if (j < n) { MFP(m, j, 7) = SC(rec + 40 + 2 * j); MFP(m, j, 8) = SC(rec + 41 + 2 * j); }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1054,6 +1117,11 @@ DEV void physics_step(const Ctx &c, int flags) {
     // Gauss-Seidel sweep keeps Bullet's order up to exact commutation (level schedule in EvmSkelC::sched).
     const int W = c.wave;
     STAMP(0);
+#ifdef EVM_STAMPS3
+    if (W == 0 && c.lane < 16) c.d.stamps[(size_t) blockIdx.x * 16 + c.lane] = 0;
+    unsigned long long t_type[6] = {0, 0, 0, 0, 0, 0};
+    unsigned n_type[6] = {0, 0, 0, 0, 0, 0};
+#endif
     const bool pending = (flags & EVM_FLAG_PENDING) != 0;
     const bool powered = (flags & EVM_FLAG_POWERED) != 0;
     const bool any_pending = __any(pending);
@@ -1163,7 +1231,15 @@ DEV void physics_step(const Ctx &c, int flags) {
     // the level-sorted schedule, so the globally lowest unfinished visit is always at the head of some wave's
     // list and cannot be blocked: no deadlock.  The record of the wave's next visit is requested before the
     // current one is solved (two register blocks, ping-pong, unrolled by two so no block is ever copied).
-    auto vis_of = [&](int e) { return (e & EVM_SCHED_CONTACT) ? 0 : e; };  // contact entries prefetch visit 0: harmless
+    // schedule entry -> visit descriptor; a member's contact rows are a pseudo visit (type 4) on its 48-float record
+    auto entry_visit = [&](int e) -> EvmVisitC {
+        if (!(e & EVM_SCHED_CONTACT)) return c_skel.visit[e];
+        EvmVisitC v;
+        const int m = e & (EVM_SCHED_CONTACT - 1);
+        v.type = 4; v.slot = c_skel.sc_c + EVM_CM_STRIDE * m; v.a = m; v.b = m; v.imA = 0.f; v.imB = 0.f;
+        v.nslots = (cmask & (1u << m)) ? EVM_CM_STRIDE : 0; v.need = 0;
+        return v;
+    };
 #ifdef EVM_STAMPS2
     unsigned long long t_wait = 0, t_solve = 0;
 #endif
@@ -1178,16 +1254,26 @@ DEV void physics_step(const Ctx &c, int flags) {
 #ifdef EVM_STAMPS2
         const unsigned long long t1 = __builtin_amdgcn_s_memtime();
 #endif
+#ifdef EVM_STAMPS3
+        const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+#endif
         const float r = solve(V, k);
         publish_version(c, V.a, expA + 1);
         publish_version(c, V.b, expB + 1);
+#ifdef EVM_STAMPS3
+        {
+            const unsigned long long dt = __builtin_amdgcn_s_memtime() - ts0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) if (V.type == q) { t_type[q] += dt; n_type[q]++; }
+        }
+#endif
 #ifdef EVM_STAMPS2
         t_wait += t1 - t0; t_solve += __builtin_amdgcn_s_memtime() - t1;
 #endif
         return r;
     };
     // contact rows of a member: after all of its joint visits of this sweep, before the next sweep's
-    auto run_contact = [&](int m, int it) -> float {
+    auto run_contact = [&](int m, int it, const Blk42 &k) -> float {
         const int ps = c_skel.body[m].per_sweep;
 #ifdef EVM_STAMPS2
         const unsigned long long t0 = __builtin_amdgcn_s_memtime();
@@ -1197,33 +1283,83 @@ DEV void physics_step(const Ctx &c, int flags) {
         const unsigned long long t1 = __builtin_amdgcn_s_memtime();
 #endif
         float r = 0.f;
-        if (cmask & (1u << m)) r = contact_iter(c, m, GS(mfn, m));
+#ifdef EVM_STAMPS3
+        const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+#endif
+        if (cmask & (1u << m)) r = contact_iter(c, m, k);
         publish_version(c, m, (it + 1) * ps);
+#ifdef EVM_STAMPS3
+        {
+            const unsigned long long dt = __builtin_amdgcn_s_memtime() - ts0;
+            if (cmask & (1u << m)) { t_type[4] += dt; n_type[4]++; } else { t_type[5] += dt; n_type[5]++; }
+        }
+#endif
 #ifdef EVM_STAMPS2
         t_wait += t1 - t0; t_solve += __builtin_amdgcn_s_memtime() - t1;
 #endif
         return r;
     };
     auto run_entry = [&](int e, const EvmVisitC &V, const Blk42 &k, int it) -> float {
-        return (e & EVM_SCHED_CONTACT) ? run_contact(e & (EVM_SCHED_CONTACT - 1), it) : run_visit(V, k, it);
+        return (e & EVM_SCHED_CONTACT) ? run_contact(e & (EVM_SCHED_CONTACT - 1), it, k) : run_visit(V, k, it);
     };
-    for (int it = 0; it < NUM_ITER; it++) {
-        res = 0.f;
-        if (ns > 0) {
-            Blk42 ka, kb;
-            int ea = sched[0], eb = ea;
-            EvmVisitC va = c_skel.visit[vis_of(ea)], vb = va;
-            blk_load(c, va, ka);
-            for (int i = 0; i < ns; i += 2) {
-                if (i + 1 < ns) { eb = sched[i + 1]; vb = c_skel.visit[vis_of(eb)]; blk_load(c, vb, kb); }
-                res = fmaxf(res, run_entry(ea, va, ka, it));
-                if (i + 2 < ns) { ea = sched[i + 2]; va = c_skel.visit[vis_of(ea)]; blk_load(c, va, ka); }
-                if (i + 1 < ns) res = fmaxf(res, run_entry(eb, vb, kb, it));
+    // The wave's entries of all NUM_ITER sweeps form one stream (no barrier between sweeps: the version counters
+    // carry the sweep number).  Three-stage software pipeline over the stream: the descriptor (scalar loads) of
+    // entry j + 2 and the record (vector loads, two register blocks in ping-pong) of entry j + 1 are requested
+    // before entry j runs, so neither latency sits between a wave's consecutive visits.
+    if (ns == 1) {
+        // a record may only be requested after the wave's previous run of the same entry has stored it; with a
+        // single entry that is the immediately preceding one, so there is nothing to overlap
+        const int e = sched[0];
+        const EvmVisitC v = entry_visit(e);
+        for (int it = 0; it < NUM_ITER; it++) {
+            Blk42 k;
+            blk_load(c, v, k);
+            res = run_entry(e, v, k, it);
+        }
+    } else if (ns > 1) {
+        const int T = NUM_ITER * ns;
+        int f_i = 0, f_it = 0;  // stream position of the next descriptor to fetch
+        auto fetch = [&](int &e, EvmVisitC &v, int &it_) {
+            e = sched[f_i];
+            v = entry_visit(e);
+            it_ = f_it;
+            if (++f_i == ns) { f_i = 0; f_it++; }  // runs past the end by up to three entries: fetched, never run
+        };
+        Blk42 ka, kb;
+        int e0, e1, e2, e3, it0, it1, it2, it3;
+        EvmVisitC v0, v1, v2, v3;
+        fetch(e0, v0, it0);
+        fetch(e1, v1, it1);
+        blk_load(c, v0, ka);
+        for (int j = 0; j < T; j += 2) {
+            blk_load(c, v1, kb);
+            fetch(e2, v2, it2);
+            {
+                const float r = run_entry(e0, v0, ka, it0);
+                if (it0 == NUM_ITER - 1) res = fmaxf(res, r);
             }
+            blk_load(c, v2, ka);
+            fetch(e3, v3, it3);
+            if (j + 1 < T) {
+                const float r = run_entry(e1, v1, kb, it1);
+                if (it1 == NUM_ITER - 1) res = fmaxf(res, r);
+            }
+            e0 = e2; v0 = v2; it0 = it2;
+            e1 = e3; v1 = v3; it1 = it3;
         }
     }
 #ifdef EVM_STAMPS2
     if (c.lane == 0) { c.d.stamps[(size_t) blockIdx.x * 16 + 2 * W] = t_wait; c.d.stamps[(size_t) blockIdx.x * 16 + 2 * W + 1] = t_solve; }
+#endif
+#ifdef EVM_STAMPS3
+    __syncthreads();
+    if (c.lane == 0) {
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            atomicAdd(&c.d.stamps[(size_t) blockIdx.x * 16 + 2 * q], t_type[q]);
+            atomicAdd(&c.d.stamps[(size_t) blockIdx.x * 16 + 2 * q + 1], (unsigned long long) n_type[q]);
+        }
+    }
 #endif
     __syncthreads();
     STAMP(5);
@@ -1232,6 +1368,12 @@ DEV void physics_step(const Ctx &c, int flags) {
         GS(diag, 1) = (float) ncontact;
     }
 
+    // ---- contact impulses back into the manifolds (by the wave that ran the member's contact rows) ----
+    for (int i = 0; i < ns; i++) {
+        const int e = sched[i];
+        if ((e & EVM_SCHED_CONTACT) && (cmask & (1u << (e & (EVM_SCHED_CONTACT - 1)))))
+            contact_writeback(c, e & (EVM_SCHED_CONTACT - 1), GS(mfn, e & (EVM_SCHED_CONTACT - 1)));
+    }
     // ---- muscle readbacks: getAppliedImpulse() = impulse of the last row written back ----
     for (int mi = W; mi < c_skel.nmus; mi += EVM_NW) {
         const int s = c_skel.sc_s + EVM_S_STRIDE * mi;

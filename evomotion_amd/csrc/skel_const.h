@@ -16,7 +16,8 @@
 #define EVM_F_STRIDE 42   // fixed : relA3 relB3 angax9 linax9 | jd6 | rhs6 | applied6
 #define EVM_S_STRIDE 41   // slider: p3 q3 ax3 p2_3 q2_3 relA3 relB3 | jd6 | rhs6 | lo hi | applied6
 #define EVM_P_STRIDE 15   // p2p   : a1_3 a2_3 | jd3 | rhs3 | applied3
-#define EVM_C_STRIDE 10   // contact point: rel3 lat3 | jd_n rhs_n jd_f rhs_f   (applied values live in the manifold)
+#define EVM_C_STRIDE 10   // contact point: rel3 lat3 | jd_n rhs_n jd_f rhs_f
+#define EVM_CM_STRIDE 48  // contact record of a member: 4 points x EVM_C_STRIDE, then 4 x (applied normal, applied lateral)
 
 struct EvmBodyC {
     float inv_mass;
@@ -84,6 +85,7 @@ struct EvmSkelC {
     int max_steps, init_remaining, reset_frames;
     // scratch layout (offsets in floats-per-env)
     int sc_r, sc_ext, sc_ms, sc_pt, sc_mobs, sc_h, sc_f, sc_s, sc_p, sc_c, sc_total;
+    float sched_cycles;  // host estimate of the 10 sweeps under the schedule's cost model (information only)
     int nvisit;
     EvmVisitC visit[EVM_MAX_VISITS];
     // Sweep schedule: visits that share no body commute exactly, so only the per-body order of visits matters.

@@ -383,7 +383,7 @@ int load_skeleton_constants(const char *path, const EvmEnvParams &prm, EvmSkelC 
     S.sc_f = o; o += EVM_F_STRIDE * nf;
     S.sc_s = o; o += EVM_S_STRIDE * nmus;
     S.sc_p = o; o += EVM_P_STRIDE * 2 * nmus;
-    S.sc_c = o; o += EVM_C_STRIDE * 4 * nm;
+    S.sc_c = o; o += EVM_CM_STRIDE * nm;
     S.sc_total = o;
 
     // ---- sweep visit list (Bullet order: skeleton constraints, then slider / p2p_a / p2p_b per muscle) ----
@@ -436,13 +436,16 @@ int load_skeleton_constants(const char *path, const EvmEnvParams &prm, EvmSkelC 
         // items: joint visits in Bullet order, then one contact item per member (after all its joint visits)
         struct Item { int a, b; float cost; int entry; };
         std::vector<Item> items;
-        // measured on MI355X (tools/stamps*.py): a 6-row visit ~2400 cycles, a p2p visit ~900, wave-to-wave hop ~500
-        const float cost_of[4] = {2400.f, 2400.f, 2400.f, 900.f};
+        // measured on MI355X (tools/stamps3.py, cycles with two waves per SIMD): hinge 1750, fixed 1650, slider 2150,
+        // p2p 900, a member's contact rows 1800 (with random actions some env of a 64-env tile touches the ground
+        // with nearly every member, so every member is costed as active); ~600 cycles of per-entry overhead
+        // (descriptor + record prefetch issue), ~300 for a dependency that crosses waves
+        const float ovh = 600.f;
+        const float cost_of[4] = {1750.f + ovh, 1650.f + ovh, 2150.f + ovh, 900.f + ovh};
         for (int i = 0; i < nv; i++) items.push_back({S.visit[i].a, S.visit[i].b, cost_of[S.visit[i].type], i});
-        for (int m = 0; m < nm; m++)
-            items.push_back({m, m, S.member[m].hull_n > 64 ? 2500.f : 400.f, EVM_SCHED_CONTACT | m});
+        for (int m = 0; m < nm; m++) items.push_back({m, m, 1800.f + ovh, EVM_SCHED_CONTACT | m});
         const int ni = (int) items.size();
-        const float hop = 500.f;
+        const float hop = 300.f;
         std::vector<std::vector<int>> preds(ni), succs(ni);
         {
             std::vector<int> last(nb, -1);
@@ -462,9 +465,10 @@ int load_skeleton_constants(const char *path, const EvmEnvParams &prm, EvmSkelC 
             for (int sidx : succs[i]) m = std::max(m, bl[sidx]);
             bl[i] = items[i].cost + m;
         }
-        std::vector<int> npred(ni), wave_of(ni, -1);
+        // 1. list scheduling of one sweep (bottom-level priority): gives the global order `topo` — a topological
+        //    order of the sweep's dependency graph — and a first assignment
+        std::vector<int> npred(ni), wave_of(ni, -1), topo;
         std::vector<float> finish(ni, 0.f), avail(EVM_NW, 0.f);
-        std::vector<std::vector<int>> lists(EVM_NW);
         for (int i = 0; i < ni; i++) npred[i] = (int) preds[i].size();
         std::vector<char> done(ni, 0);
         for (int step = 0; step < ni; step++) {
@@ -481,16 +485,73 @@ int load_skeleton_constants(const char *path, const EvmEnvParams &prm, EvmSkelC 
             wave_of[pick] = bw;
             finish[pick] = bstart + items[pick].cost;
             avail[bw] = finish[pick];
-            lists[bw].push_back(pick);
+            topo.push_back(pick);
             done[pick] = 1;
             for (int sidx : succs[pick]) npred[sidx]--;
         }
-        for (int w = 0; w < EVM_NW; w++) {
-            S.nsched[w] = 0;
-            for (int it : lists[w]) {
-                if (S.nsched[w] >= EVM_MAX_SCHED) { err = "sweep schedule overflow"; return EVM_E_UNSUPPORTED; }
-                S.sched[w][S.nsched[w]++] = items[it].entry;
+        // 2. the kernel runs the sweeps back to back without a barrier, so what matters is the steady state of the
+        //    cyclic schedule, not one sweep's makespan: simulate NUM_ITER sweeps (each wave runs its entries in
+        //    `topo` order; an entry starts when its wave is free and the last writers of its bodies are done) and
+        //    improve the assignment by local search (move one entry to another wave while the total shrinks).
+        //    Every wave's list stays sorted by the one global topological order, which is what rules out deadlock.
+        auto simulate = [&](const std::vector<int> &asg) -> float {
+            float wave_t[EVM_NW] = {0.f};
+            std::vector<float> ready(nb, 0.f);
+            std::vector<int> lastw(nb, -1);
+            for (int sweep = 0; sweep < 10; sweep++)
+                for (int i : topo) {
+                    const int w = asg[i];
+                    float st = wave_t[w];
+                    for (int body : {items[i].a, items[i].b}) {
+                        const float r = ready[body] + ((lastw[body] >= 0 && lastw[body] != w) ? hop : 0.f);
+                        if (r > st) st = r;
+                    }
+                    const float fn = st + items[i].cost;
+                    wave_t[w] = fn;
+                    ready[items[i].a] = ready[items[i].b] = fn;
+                    lastw[items[i].a] = lastw[items[i].b] = w;
+                }
+            float m = 0.f;
+            for (int w = 0; w < EVM_NW; w++) m = std::max(m, wave_t[w]);
+            return m;
+        };
+        auto improve = [&](std::vector<int> &asg) -> float {
+            float best = simulate(asg);
+            for (int pass = 0; pass < 40; pass++) {
+                bool moved = false;
+                for (int i : topo) {
+                    const int w0 = asg[i];
+                    int bw = w0;
+                    float bv = best;
+                    for (int w = 0; w < EVM_NW; w++) {
+                        if (w == w0) continue;
+                        asg[i] = w;
+                        const float v = simulate(asg);
+                        if (v < bv - 0.5f) { bv = v; bw = w; }
+                    }
+                    asg[i] = bw;
+                    if (bw != w0) { best = bv; moved = true; }
+                }
+                if (!moved) break;
             }
+            return best;
+        };
+        float best_total = improve(wave_of);
+        {   // a few deterministic restarts from pseudo-random assignments (LCG), keep the best
+            uint32_t lcg = 12345u;
+            for (int trial = 0; trial < 6 && EVM_NW > 1; trial++) {
+                std::vector<int> asg(ni);
+                for (int i = 0; i < ni; i++) { lcg = lcg * 1664525u + 1013904223u; asg[i] = (int) ((lcg >> 16) % EVM_NW); }
+                const float v = improve(asg);
+                if (v < best_total - 0.5f) { best_total = v; wave_of = asg; }
+            }
+        }
+        S.sched_cycles = best_total;
+        for (int w = 0; w < EVM_NW; w++) S.nsched[w] = 0;
+        for (int i : topo) {
+            const int w = wave_of[i];
+            if (S.nsched[w] >= EVM_MAX_SCHED) { err = "sweep schedule overflow"; return EVM_E_UNSUPPORTED; }
+            S.sched[w][S.nsched[w]++] = items[i].entry;
         }
         // members -> waves, heaviest hull first
         std::vector<int> ms(nm);

@@ -25,8 +25,8 @@ for k in range(K + 70):
         acc[:8] += np.median(d, axis=0)
 tot = acc[:8].sum()
 for nm, v in zip(names, acc[:8]):
-    print("%-14s %9.0f ticks  %5.1f %%" % (nm, v / K, 100 * v / tot))
-print("total ticks/step", tot / K, "(s_memtime ticks at 100 MHz: x10 ns)")
+    print("%-14s %9.0f cycles %5.1f %%" % (nm, v / K, 100 * v / tot))
+print("total cycles/step", tot / K, "(s_memtime counts shader-clock cycles, ~2.0 GHz under this load)")
 # optional fine stamps 9..12 around one hinge visit (wait / solve / publish)
 st = (ctypes.c_ulonglong * (n // 64 * 16))()
 check(lib.evm_env_get_stamps(env._h, st))
