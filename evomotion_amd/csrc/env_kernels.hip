@@ -70,6 +70,8 @@ DEV Ctx make_ctx(const EnvDev &d, float *lds) {
 
 #define GS(arr, k) (c.t.arr[((k) << 6) + c.lane])
 #define SC(k) (c.t.scratch[((k) << 6) + c.lane])
+// field f of the quad-packed record that starts at slot `base` (a multiple of 4), see skel_const.h
+#define RC(base, f) (c.t.scratch[(((base) + ((f) & ~3)) << 6) + (c.lane << 2) + ((f) & 3)])
 #define LDV(b, k) (c.lds[(((b) * 6 + (k)) << 6) + c.lane])
 #define LII(b, k) (c.lds[(((c_skel.nb + (b)) * 6 + (k)) << 6) + c.lane])
 // per-body version counters (one int per body) behind the float tiles: dataflow synchronisation of the sweep
@@ -256,22 +258,44 @@ DEV float row_iter(F3 ax, const F3P &rel, BodyPD &Q, float jd, float rhs, float 
 }
 
 // register block holding one constraint's scratch record (loaded one constraint ahead of its use)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct Blk42 {
-    float v[EVM_CM_STRIDE];  // the largest record (a member's contact rows)
+    f32x4 q[EVM_CM_STRIDE / 4];  // the largest record (a member's contact rows); kept as quads so that the
+                                 // conditional tail loads merge as whole register tuples (no copies, no early wait)
 };
+#define KV(k, f) ((k).q[(f) >> 2][(f) & 3])
+#define KV3(k, f) f3(KV(k, f), KV(k, (f) + 1), KV(k, (f) + 2))
+DEV const f32x4 *rec_quads(const Ctx &c, int slot) {
+    return reinterpret_cast<const f32x4 *>(c.t.scratch + ((size_t) slot << 6)) + c.lane;
+}
+template <int Q0, int Q1>
+DEV void blk_load_quads(const f32x4 *p, Blk42 &b) {
+#pragma unroll
+    for (int q = Q0; q < Q1; q++) b.q[q] = p[q << 6];
+}
 DEV void blk_load(const Ctx &c, const EvmVisitC &v, Blk42 &b) {
-    const float *p = c.t.scratch + (v.slot << 6) + c.lane;
-#pragma unroll
-    for (int i = 0; i < 15; i++) b.v[i] = p[i << 6];
-    if (v.nslots > 15) {  // wave-uniform: p2p records are 15 floats, joints 35..42, contacts 48
-#pragma unroll
-        for (int i = 15; i < 42; i++) b.v[i] = p[i << 6];
-        if (v.nslots > 42) {
-#pragma unroll
-            for (int i = 42; i < EVM_CM_STRIDE; i++) b.v[i] = p[i << 6];
+    const f32x4 *p = rec_quads(c, v.slot);
+    blk_load_quads<0, 4>(p, b);
+    if (v.nslots > 16) {  // wave-uniform: p2p records are 4 quads, hinges 9, fixed / slider 11, contacts 12
+        blk_load_quads<4, 9>(p, b);
+        if (v.nslots > 36) {
+            blk_load_quads<9, 11>(p, b);
+            if (v.nslots > 44) blk_load_quads<11, 12>(p, b);
         }
     }
 }
+// store quads [Q0, Q1) of a record from a register image
+template <int Q0, int Q1>
+DEV void rec_store(const Ctx &c, int slot, const float *r) {
+    f32x4 *p = reinterpret_cast<f32x4 *>(c.t.scratch + ((size_t) slot << 6)) + c.lane;
+#pragma unroll
+    for (int q = Q0; q < Q1; q++) {
+        f32x4 x;
+        x[0] = r[4 * q]; x[1] = r[4 * q + 1]; x[2] = r[4 * q + 2]; x[3] = r[4 * q + 3];
+        p[q << 6] = x;
+    }
+}
+DEV void put3(float *r, int i, F3 v) { r[i] = v.x; r[i + 1] = v.y; r[i + 2] = v.z; }
 DEV F3 v3(const float *v, int i) { return f3(v[i], v[i + 1], v[i + 2]); }
 
 // ---------------------------------------------------------------------------------------------
@@ -339,31 +363,37 @@ DEV void hinge_setup(const Ctx &c, int hi) {
         err *= H.bias;
         row_setup<false>(ax1, relA, relB, A, B, err, jd[5], rhs[5]);
     }
-    const int s = c_skel.sc_h + EVM_H_STRIDE * hi;
-    SSC3(s + 0, relA); SSC3(s + 3, relB); SSC3(s + 6, p); SSC3(s + 9, q); SSC3(s + 12, ax1);
+    float rec[EVM_H_STRIDE];
+    put3(rec, 0, relA); put3(rec, 3, relB); put3(rec, 6, p); put3(rec, 9, q); put3(rec, 12, ax1);
 #pragma unroll
-    for (int r = 0; r < 6; r++) { SC(s + 15 + r) = jd[r]; SC(s + 21 + r) = rhs[r]; SC(s + 29 + r) = 0.f; }
-    SC(s + 27) = lo; SC(s + 28) = hi_;
+    for (int r = 0; r < 6; r++) { rec[15 + r] = jd[r]; rec[21 + r] = rhs[r]; rec[28 + r] = 0.f; }
+    rec[27] = 0.f; rec[34] = lo; rec[35] = hi_;
+    rec_store<0, EVM_H_STRIDE / 4>(c, c_skel.sc_h + EVM_H_STRIDE * hi, rec);
 }
 DEV float hinge_solve(const Ctx &c, const EvmVisitC &V, const Blk42 &k) {
     const int s = V.slot;
-    const F3 relA = v3(k.v, 0), relB = v3(k.v, 3), p = v3(k.v, 6), q = v3(k.v, 9), ax1 = v3(k.v, 12);
+    const F3 relA = KV3(k, 0), relB = KV3(k, 3), p = KV3(k, 6), q = KV3(k, 9), ax1 = KV3(k, 12);
     float ap[6];
 #pragma unroll
-    for (int r = 0; r < 6; r++) ap[r] = k.v[29 + r];
-    const float lo = k.v[27], hi_ = k.v[28];
+    for (int r = 0; r < 6; r++) ap[r] = KV(k, 28 + r);
+    const float lo = KV(k, 34), hi_ = KV(k, 35);
     BodyPD Q = load_bodypd(c, V.a, V.b, V.imA, V.imB);
     const F3P rel = pair(relA, relB);
     float res = 0.f;
-    res = fmaxf(res, fabsf(row_iter<true, false>(p, rel, Q, k.v[15], k.v[21], 0.f, 0.f, ap[0])));
-    res = fmaxf(res, fabsf(row_iter<true, false>(q, rel, Q, k.v[16], k.v[22], 0.f, 0.f, ap[1])));
-    res = fmaxf(res, fabsf(row_iter<true, false>(ax1, rel, Q, k.v[17], k.v[23], 0.f, 0.f, ap[2])));
-    res = fmaxf(res, fabsf(row_iter<false, false>(p, rel, Q, k.v[18], k.v[24], 0.f, 0.f, ap[3])));
-    res = fmaxf(res, fabsf(row_iter<false, false>(q, rel, Q, k.v[19], k.v[25], 0.f, 0.f, ap[4])));
-    if (k.v[20] != 0.f) res = fmaxf(res, fabsf(row_iter<false, true>(ax1, rel, Q, k.v[20], k.v[26], lo, hi_, ap[5])));
+    res = fmaxf(res, fabsf(row_iter<true, false>(p, rel, Q, KV(k, 15), KV(k, 21), 0.f, 0.f, ap[0])));
+    res = fmaxf(res, fabsf(row_iter<true, false>(q, rel, Q, KV(k, 16), KV(k, 22), 0.f, 0.f, ap[1])));
+    res = fmaxf(res, fabsf(row_iter<true, false>(ax1, rel, Q, KV(k, 17), KV(k, 23), 0.f, 0.f, ap[2])));
+    res = fmaxf(res, fabsf(row_iter<false, false>(p, rel, Q, KV(k, 18), KV(k, 24), 0.f, 0.f, ap[3])));
+    res = fmaxf(res, fabsf(row_iter<false, false>(q, rel, Q, KV(k, 19), KV(k, 25), 0.f, 0.f, ap[4])));
+    if (KV(k, 20) != 0.f) res = fmaxf(res, fabsf(row_iter<false, true>(ax1, rel, Q, KV(k, 20), KV(k, 26), lo, hi_, ap[5])));
     store_bodypd(c, V.a, V.b, Q);
+    {
+        float w[EVM_H_STRIDE];
 #pragma unroll
-    for (int r = 0; r < 6; r++) SC(s + 29 + r) = ap[r];
+        for (int r = 0; r < 6; r++) w[28 + r] = ap[r];
+        w[34] = lo; w[35] = hi_;
+        rec_store<7, 9>(c, s, w);
+    }
     return res;
 }
 
@@ -418,31 +448,38 @@ DEV void fixed_setup(const Ctx &c, int fi) {
     row_setup<true>(l0, relA, relB, A, B, k * linDiff.x * 1.f, jd[3], rhs[3]);
     row_setup<true>(l1, relA, relB, A, B, k * linDiff.y * 1.f, jd[4], rhs[4]);
     row_setup<true>(l2, relA, relB, A, B, k * linDiff.z * 1.f, jd[5], rhs[5]);
-    const int s = c_skel.sc_f + EVM_F_STRIDE * fi;
-    SSC3(s + 0, relA); SSC3(s + 3, relB);
-    SSC3(s + 6, a0); SSC3(s + 9, a1); SSC3(s + 12, a2);
-    SSC3(s + 15, l0); SSC3(s + 18, l1); SSC3(s + 21, l2);
+    float rec[EVM_F_STRIDE];
+    put3(rec, 0, relA); put3(rec, 3, relB);
+    put3(rec, 6, a0); put3(rec, 9, a1); put3(rec, 12, a2);
+    put3(rec, 15, l0); put3(rec, 18, l1); put3(rec, 21, l2);
 #pragma unroll
-    for (int r = 0; r < 6; r++) { SC(s + 24 + r) = jd[r]; SC(s + 30 + r) = rhs[r]; SC(s + 36 + r) = 0.f; }
+    for (int r = 0; r < 6; r++) { rec[24 + r] = jd[r]; rec[30 + r] = rhs[r]; rec[36 + r] = 0.f; }
+    rec[42] = 0.f; rec[43] = 0.f;
+    rec_store<0, EVM_F_STRIDE / 4>(c, c_skel.sc_f + EVM_F_STRIDE * fi, rec);
 }
 DEV float fixed_solve(const Ctx &c, const EvmVisitC &V, const Blk42 &k) {
     const int s = V.slot;
-    const F3 relA = v3(k.v, 0), relB = v3(k.v, 3);
+    const F3 relA = KV3(k, 0), relB = KV3(k, 3);
     float ap[6];
 #pragma unroll
-    for (int r = 0; r < 6; r++) ap[r] = k.v[36 + r];
+    for (int r = 0; r < 6; r++) ap[r] = KV(k, 36 + r);
     BodyPD Q = load_bodypd(c, V.a, V.b, V.imA, V.imB);
     const F3P rel = pair(relA, relB);
     float res = 0.f;
 #pragma unroll
     for (int r = 0; r < 3; r++)
-        res = fmaxf(res, fabsf(row_iter<false, false>(v3(k.v, 6 + 3 * r), rel, Q, k.v[24 + r], k.v[30 + r], 0.f, 0.f, ap[r])));
+        res = fmaxf(res, fabsf(row_iter<false, false>(KV3(k, 6 + 3 * r), rel, Q, KV(k, 24 + r), KV(k, 30 + r), 0.f, 0.f, ap[r])));
 #pragma unroll
     for (int r = 0; r < 3; r++)
-        res = fmaxf(res, fabsf(row_iter<true, false>(v3(k.v, 15 + 3 * r), rel, Q, k.v[27 + r], k.v[33 + r], 0.f, 0.f, ap[3 + r])));
+        res = fmaxf(res, fabsf(row_iter<true, false>(KV3(k, 15 + 3 * r), rel, Q, KV(k, 27 + r), KV(k, 33 + r), 0.f, 0.f, ap[3 + r])));
     store_bodypd(c, V.a, V.b, Q);
+    {
+        float w[EVM_F_STRIDE];
 #pragma unroll
-    for (int r = 0; r < 6; r++) SC(s + 36 + r) = ap[r];
+        for (int r = 0; r < 6; r++) w[36 + r] = ap[r];
+        w[42] = 0.f; w[43] = 0.f;
+        rec_store<9, 11>(c, s, w);
+    }
     return res;
 }
 
@@ -557,35 +594,40 @@ DEV void slider_setup(const Ctx &c, int mi, bool powered_in, float target_vel) {
         err *= 1.0f;
         row_setup<false>(ax1, relA, relB, A, B, err, jd[5], rhs[5]);
     }
-    const int s = c_skel.sc_s + EVM_S_STRIDE * mi;
-    SSC3(s + 0, p); SSC3(s + 3, q); SSC3(s + 6, ax1); SSC3(s + 9, p2); SSC3(s + 12, q2);
-    SSC3(s + 15, relA); SSC3(s + 18, relB);
+    float rec[EVM_S_STRIDE];
+    put3(rec, 0, p); put3(rec, 3, q); put3(rec, 6, ax1); put3(rec, 9, p2); put3(rec, 12, q2);
+    put3(rec, 15, relA); put3(rec, 18, relB);
 #pragma unroll
-    for (int r = 0; r < 6; r++) { SC(s + 21 + r) = jd[r]; SC(s + 27 + r) = rhs[r]; SC(s + 35 + r) = 0.f; }
-    SC(s + 33) = lo; SC(s + 34) = hi_;
+    for (int r = 0; r < 6; r++) { rec[21 + r] = jd[r]; rec[27 + r] = rhs[r]; rec[36 + r] = 0.f; }
+    rec[33] = lo; rec[34] = hi_; rec[35] = 0.f; rec[42] = 0.f; rec[43] = 0.f;
+    rec_store<0, EVM_S_STRIDE / 4>(c, c_skel.sc_s + EVM_S_STRIDE * mi, rec);
     SC(c_skel.sc_mobs + 4 * mi) = lin_pos;  // btSliderConstraint::getLinearPos(), MuscleState
 }
 DEV float slider_solve(const Ctx &c, const EvmVisitC &V, const Blk42 &kk) {
-    const float *ks = kk.v;
     const int s = V.slot;
-    const F3 p = v3(ks, 0), q = v3(ks, 3), ax1 = v3(ks, 6), p2_ = v3(ks, 9), q2 = v3(ks, 12);
-    const F3 relA = v3(ks, 15), relB = v3(ks, 18);
+    const F3 p = KV3(kk, 0), q = KV3(kk, 3), ax1 = KV3(kk, 6), p2_ = KV3(kk, 9), q2 = KV3(kk, 12);
+    const F3 relA = KV3(kk, 15), relB = KV3(kk, 18);
     float ap[6];
 #pragma unroll
-    for (int r = 0; r < 6; r++) ap[r] = ks[35 + r];
-    const float lo = ks[33], hi_ = ks[34];
+    for (int r = 0; r < 6; r++) ap[r] = KV(kk, 36 + r);
+    const float lo = KV(kk, 33), hi_ = KV(kk, 34);
     BodyPD Q = load_bodypd(c, V.a, V.b, V.imA, V.imB);
     const F3P rel = pair(relA, relB);
     float res = 0.f;
-    res = fmaxf(res, fabsf(row_iter<false, false>(p, rel, Q, ks[21], ks[27], 0.f, 0.f, ap[0])));
-    res = fmaxf(res, fabsf(row_iter<false, false>(q, rel, Q, ks[22], ks[28], 0.f, 0.f, ap[1])));
-    res = fmaxf(res, fabsf(row_iter<true, false>(p2_, rel, Q, ks[23], ks[29], 0.f, 0.f, ap[2])));
-    res = fmaxf(res, fabsf(row_iter<true, false>(q2, rel, Q, ks[24], ks[30], 0.f, 0.f, ap[3])));
-    if (ks[25] != 0.f) res = fmaxf(res, fabsf(row_iter<true, true>(ax1, rel, Q, ks[25], ks[31], lo, hi_, ap[4])));
-    if (ks[26] != 0.f) res = fmaxf(res, fabsf(row_iter<false, false>(ax1, rel, Q, ks[26], ks[32], 0.f, 0.f, ap[5])));
+    res = fmaxf(res, fabsf(row_iter<false, false>(p, rel, Q, KV(kk, 21), KV(kk, 27), 0.f, 0.f, ap[0])));
+    res = fmaxf(res, fabsf(row_iter<false, false>(q, rel, Q, KV(kk, 22), KV(kk, 28), 0.f, 0.f, ap[1])));
+    res = fmaxf(res, fabsf(row_iter<true, false>(p2_, rel, Q, KV(kk, 23), KV(kk, 29), 0.f, 0.f, ap[2])));
+    res = fmaxf(res, fabsf(row_iter<true, false>(q2, rel, Q, KV(kk, 24), KV(kk, 30), 0.f, 0.f, ap[3])));
+    if (KV(kk, 25) != 0.f) res = fmaxf(res, fabsf(row_iter<true, true>(ax1, rel, Q, KV(kk, 25), KV(kk, 31), lo, hi_, ap[4])));
+    if (KV(kk, 26) != 0.f) res = fmaxf(res, fabsf(row_iter<false, false>(ax1, rel, Q, KV(kk, 26), KV(kk, 32), 0.f, 0.f, ap[5])));
     store_bodypd(c, V.a, V.b, Q);
+    {
+        float w[EVM_S_STRIDE];
 #pragma unroll
-    for (int r = 0; r < 6; r++) SC(s + 35 + r) = ap[r];
+        for (int r = 0; r < 6; r++) w[36 + r] = ap[r];
+        w[42] = 0.f; w[43] = 0.f;
+        rec_store<9, 11>(c, s, w);
+    }
     return res;
 }
 
@@ -601,34 +643,31 @@ DEV void p2p_setup(const Ctx &c, int mi, int which) {
     const F3 a2 = mul(B.R, f3(0.f, 0.f, 0.f));
     const float k = FPS_F * ERP_F;
     const int s = c_skel.sc_p + EVM_P_STRIDE * (2 * mi + which);
-    float jd, rhs;
-    row_setup<true>(f3(1.f, 0.f, 0.f), a1, a2, A, B, k * (a2.x + B.o.x - a1.x - A.o.x), jd, rhs);
-    SC(s + 6) = jd; SC(s + 9) = rhs;
-    row_setup<true>(f3(0.f, 1.f, 0.f), a1, a2, A, B, k * (a2.y + B.o.y - a1.y - A.o.y), jd, rhs);
-    SC(s + 7) = jd; SC(s + 10) = rhs;
-    row_setup<true>(f3(0.f, 0.f, 1.f), a1, a2, A, B, k * (a2.z + B.o.z - a1.z - A.o.z), jd, rhs);
-    SC(s + 8) = jd; SC(s + 11) = rhs;
-    SSC3(s + 0, a1); SSC3(s + 3, a2);
-    SC(s + 12) = 0.f; SC(s + 13) = 0.f; SC(s + 14) = 0.f;
+    float rec[EVM_P_STRIDE];
+    row_setup<true>(f3(1.f, 0.f, 0.f), a1, a2, A, B, k * (a2.x + B.o.x - a1.x - A.o.x), rec[6], rec[9]);
+    row_setup<true>(f3(0.f, 1.f, 0.f), a1, a2, A, B, k * (a2.y + B.o.y - a1.y - A.o.y), rec[7], rec[10]);
+    row_setup<true>(f3(0.f, 0.f, 1.f), a1, a2, A, B, k * (a2.z + B.o.z - a1.z - A.o.z), rec[8], rec[11]);
+    put3(rec, 0, a1); put3(rec, 3, a2);
+    rec[12] = 0.f; rec[13] = 0.f; rec[14] = 0.f; rec[15] = 0.f;
+    rec_store<0, EVM_P_STRIDE / 4>(c, s, rec);
 }
 // p2p rows along the world axes.  The pivot in the attach sphere is the origin (muscle.cpp:52,55), so the
 // sphere-side lever arm a2 is exactly zero: body B only takes the linear part.
 DEV float p2p_solve(const Ctx &c, const EvmVisitC &V, const Blk42 &kk) {
-    const float *k = kk.v;
     const int ba = V.a, bb = V.b;
     const int s = V.slot;
-    const F3 a1 = v3(k, 0);
+    const F3 a1 = KV3(kk, 0);
     BodyD A = load_bodyd(c, ba, V.imA);
     F3 dlB = f3(LDV(bb, 0), LDV(bb, 1), LDV(bb, 2));
     const float imB = V.imB;
-    float ap0 = k[12], ap1 = k[13], ap2 = k[14];
+    float ap0 = KV(kk, 12), ap1 = KV(kk, 13), ap2 = KV(kk, 14);
     float res = 0.f;
     {   // x: c1 = a1 x e_x = (0, a1.z, -a1.y)
         const F3 angA = f3(A.I.xy * a1.z - A.I.xz * a1.y, A.I.yy * a1.z - A.I.yz * a1.y, A.I.yz * a1.z - A.I.zz * a1.y);
         const float d1 = A.dl.x + (a1.z * A.da.y - a1.y * A.da.z);
-        float dI = k[9];
-        dI -= d1 * k[6];
-        dI -= (-dlB.x) * k[6];
+        float dI = KV(kk, 9);
+        dI -= d1 * KV(kk, 6);
+        dI -= (-dlB.x) * KV(kk, 6);
         ap0 += dI;
         A.dl.x += A.im * dI; A.da = A.da + angA * dI; dlB.x -= imB * dI;
         res = fmaxf(res, fabsf(dI));
@@ -636,9 +675,9 @@ DEV float p2p_solve(const Ctx &c, const EvmVisitC &V, const Blk42 &kk) {
     {   // y: c1 = a1 x e_y = (-a1.z, 0, a1.x)
         const F3 angA = f3(A.I.xz * a1.x - A.I.xx * a1.z, A.I.yz * a1.x - A.I.xy * a1.z, A.I.zz * a1.x - A.I.xz * a1.z);
         const float d1 = A.dl.y + (a1.x * A.da.z - a1.z * A.da.x);
-        float dI = k[10];
-        dI -= d1 * k[7];
-        dI -= (-dlB.y) * k[7];
+        float dI = KV(kk, 10);
+        dI -= d1 * KV(kk, 7);
+        dI -= (-dlB.y) * KV(kk, 7);
         ap1 += dI;
         A.dl.y += A.im * dI; A.da = A.da + angA * dI; dlB.y -= imB * dI;
         res = fmaxf(res, fabsf(dI));
@@ -646,16 +685,20 @@ DEV float p2p_solve(const Ctx &c, const EvmVisitC &V, const Blk42 &kk) {
     {   // z: c1 = a1 x e_z = (a1.y, -a1.x, 0)
         const F3 angA = f3(A.I.xx * a1.y - A.I.xy * a1.x, A.I.xy * a1.y - A.I.yy * a1.x, A.I.xz * a1.y - A.I.yz * a1.x);
         const float d1 = A.dl.z + (a1.y * A.da.x - a1.x * A.da.y);
-        float dI = k[11];
-        dI -= d1 * k[8];
-        dI -= (-dlB.z) * k[8];
+        float dI = KV(kk, 11);
+        dI -= d1 * KV(kk, 8);
+        dI -= (-dlB.z) * KV(kk, 8);
         ap2 += dI;
         A.dl.z += A.im * dI; A.da = A.da + angA * dI; dlB.z -= imB * dI;
         res = fmaxf(res, fabsf(dI));
     }
     store_bodyd(c, ba, A);
     LDV(bb, 0) = dlB.x; LDV(bb, 1) = dlB.y; LDV(bb, 2) = dlB.z;
-    SC(s + 12) = ap0; SC(s + 13) = ap1; SC(s + 14) = ap2;
+    {
+        float w[EVM_P_STRIDE];
+        w[12] = ap0; w[13] = ap1; w[14] = ap2; w[15] = 0.f;
+        rec_store<3, 4>(c, s, w);
+    }
     return res;
 }
 
@@ -822,10 +865,12 @@ DEV void contact_setup(const Ctx &c, int m, int n) {
     F3 pc2[4], pang[4];
     float pjd[4], prhs[4], ppush[4];
     bool any_pen = false;
+    float rec[EVM_CM_STRIDE];  // record image; jd_n == 0 marks "no point" for the sweeps
+#pragma unroll
+    for (int i = 0; i < EVM_CM_STRIDE; i++) rec[i] = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         pjd[j] = 0.f; prhs[j] = 0.f; ppush[j] = 0.f; pc2[j] = f3(0, 0, 0); pang[j] = f3(0, 0, 0);
-        if (j >= n) SC(c_skel.sc_c + EVM_CM_STRIDE * m + EVM_C_STRIDE * j + 6) = 0.f;  // jd_n == 0 marks "no point" for the sweeps
         if (j < n) {
             const F3 lb = f3(MFP(m, j, 3), MFP(m, j, 4), MFP(m, j, 5));
             const float dist = MFP(m, j, 6);
@@ -873,17 +918,17 @@ DEV void contact_setup(const Ctx &c, int m, int n) {
             const float fapplied = MFP(m, j, 8) * WARM_F;
             D.dl = D.dl + ((-fn2) * B.im) * (-fapplied);
             D.da = D.da + (-fangB) * (-fapplied);
-            const int s = c_skel.sc_c + EVM_CM_STRIDE * m + EVM_C_STRIDE * j;
-            SSC3(s + 0, rel); SSC3(s + 3, lat);
-            SC(s + 6) = jd; SC(s + 7) = rhs; SC(s + 8) = fjd; SC(s + 9) = frhs;
+            put3(rec, EVM_C_STRIDE * j, rel); put3(rec, EVM_C_STRIDE * j + 3, lat);
+            rec[EVM_C_STRIDE * j + 6] = jd; rec[EVM_C_STRIDE * j + 7] = rhs;
+            rec[EVM_C_STRIDE * j + 8] = fjd; rec[EVM_C_STRIDE * j + 9] = frhs;
             // the accumulated impulses live in the record during the sweeps (contact_writeback returns them)
-            SC(c_skel.sc_c + EVM_CM_STRIDE * m + 40 + 2 * j) = applied;
-            SC(c_skel.sc_c + EVM_CM_STRIDE * m + 41 + 2 * j) = fapplied;
+            rec[40 + 2 * j] = applied; rec[41 + 2 * j] = fapplied;
             pjd[j] = jd; prhs[j] = rhs_pen; pc2[j] = c2; pang[j] = angB;
             any_pen = any_pen || (rhs_pen != 0.f);
         }
     }
     store_bodyd(c, m, D);
+    rec_store<0, EVM_CM_STRIDE / 4>(c, c_skel.sc_c + EVM_CM_STRIDE * m, rec);
     if (__any(any_pen)) {
         for (int it = 0; it < NUM_ITER; it++) {
 #pragma unroll
@@ -910,17 +955,20 @@ DEV float contact_iter(const Ctx &c, int m, const Blk42 &k) {
     BodyD D = load_bodyd(c, m);
     float res = 0.f;
     float apn[4];
+    float w[EVM_CM_STRIDE];
+#pragma unroll
+    for (int i = 40; i < EVM_CM_STRIDE; i++) w[i] = KV(k, i);
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         apn[j] = 0.f;
-        const bool has = k.v[10 * j + 6] != 0.f;  // jd_n = 1 / denominator > 0 for a live point
+        const bool has = KV(k, 10 * j + 6) != 0.f;  // jd_n = 1 / denominator > 0 for a live point
         if (!__any(has)) continue;
         if (has) {  // resolveSingleConstraintRowLowerLimit
-            const F3 rel = v3(k.v, 10 * j);
-            const float jd = k.v[10 * j + 6], rhs = k.v[10 * j + 7];
+            const F3 rel = KV3(k, 10 * j);
+            const float jd = KV(k, 10 * j + 6), rhs = KV(k, 10 * j + 7);
             const F3 c2 = -cross(rel, f3(0.f, -1.f, 0.f));
             const F3 angB = mul(D.I, c2);
-            float ap = k.v[40 + 2 * j];
+            float ap = KV(k, 40 + 2 * j);
             float dI = rhs;
             const float d2 = D.dl.y + dot(c2, D.da);
             dI -= d2 * jd;
@@ -928,7 +976,7 @@ DEV float contact_iter(const Ctx &c, int m, const Blk42 &k) {
             if (sum < 0.f) { dI = 0.f - ap; ap = 0.f; } else ap = sum;
             D.dl = D.dl + (f3(0.f, 1.f, 0.f) * D.im) * dI;
             D.da = D.da + angB * dI;
-            SC(rec + 40 + 2 * j) = ap;
+            w[40 + 2 * j] = ap;
             apn[j] = ap;
             res = fmaxf(res, fabsf(dI));
         }
@@ -937,13 +985,13 @@ DEV float contact_iter(const Ctx &c, int m, const Blk42 &k) {
     for (int j = 0; j < 4; j++) {
         if (!__any(apn[j] > 0.f)) continue;
         if (apn[j] > 0.f) {  // friction row with limits +-mu * normal impulse
-            const F3 rel = v3(k.v, 10 * j), lat = v3(k.v, 10 * j + 3);
-            const float jd = k.v[10 * j + 8], rhs = k.v[10 * j + 9];
+            const F3 rel = KV3(k, 10 * j), lat = KV3(k, 10 * j + 3);
+            const float jd = KV(k, 10 * j + 8), rhs = KV(k, 10 * j + 9);
             const F3 n2 = -lat;
             const F3 c2 = cross(rel, n2);
             const F3 angB = mul(D.I, c2);
             const float lim = MB.mu * apn[j];
-            float ap = k.v[41 + 2 * j];
+            float ap = KV(k, 41 + 2 * j);
             float dI = rhs;
             const float d2 = dot(n2, D.dl) + dot(c2, D.da);
             dI -= d2 * jd;
@@ -953,11 +1001,12 @@ DEV float contact_iter(const Ctx &c, int m, const Blk42 &k) {
             else ap = sum;
             D.dl = D.dl + (n2 * D.im) * dI;
             D.da = D.da + angB * dI;
-            SC(rec + 41 + 2 * j) = ap;
+            w[41 + 2 * j] = ap;
             res = fmaxf(res, fabsf(dI));
         }
     }
     store_bodyd(c, m, D);
+    rec_store<10, 12>(c, rec, w);
     return res;
 }
 // after the sweeps: the accumulated impulses go back into the persistent manifold (warm start of the next step)
@@ -965,7 +1014,7 @@ DEV void contact_writeback(const Ctx &c, int m, int n) {
     const int rec = c_skel.sc_c + EVM_CM_STRIDE * m;
 #pragma unroll
     for (int j = 0; j < 4; j++)
-        if (j < n) { MFP(m, j, 7) = SC(rec + 40 + 2 * j); MFP(m, j, 8) = SC(rec + 41 + 2 * j); }
+        if (j < n) { MFP(m, j, 7) = RC(rec, 40 + 2 * j); MFP(m, j, 8) = RC(rec, 41 + 2 * j); }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1377,11 +1426,11 @@ DEV void physics_step(const Ctx &c, int flags) {
     // ---- muscle readbacks: getAppliedImpulse() = impulse of the last row written back ----
     for (int mi = W; mi < c_skel.nmus; mi += EVM_NW) {
         const int s = c_skel.sc_s + EVM_S_STRIDE * mi;
-        const float jd4 = SC(s + 25), jd5 = SC(s + 26);
-        const float a3 = SC(s + 38), a4 = SC(s + 39), a5 = SC(s + 40);
+        const float jd4 = RC(s, 25), jd5 = RC(s, 26);
+        const float a3 = RC(s, 39), a4 = RC(s, 40), a5 = RC(s, 41);
         SC(c_skel.sc_mobs + 4 * mi + 1) = jd5 != 0.f ? a5 : (jd4 != 0.f ? a4 : a3);
-        SC(c_skel.sc_mobs + 4 * mi + 2) = SC(c_skel.sc_p + EVM_P_STRIDE * (2 * mi) + 14);
-        SC(c_skel.sc_mobs + 4 * mi + 3) = SC(c_skel.sc_p + EVM_P_STRIDE * (2 * mi + 1) + 14);
+        SC(c_skel.sc_mobs + 4 * mi + 2) = RC(c_skel.sc_p + EVM_P_STRIDE * (2 * mi), 14);
+        SC(c_skel.sc_mobs + 4 * mi + 3) = RC(c_skel.sc_p + EVM_P_STRIDE * (2 * mi + 1), 14);
     }
     STAMP(6);
 

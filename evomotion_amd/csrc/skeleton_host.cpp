@@ -379,6 +379,7 @@ int load_skeleton_constants(const char *path, const EvmEnvParams &prm, EvmSkelC 
     S.sc_ms = o; o += 3 * nm;
     S.sc_pt = o; o += 6 * nm;
     S.sc_mobs = o; o += 4 * nmus;
+    o = (o + 3) & ~3;  // records are quad-packed: bases on multiples of 4 slots (skel_const.h)
     S.sc_h = o; o += EVM_H_STRIDE * nh;
     S.sc_f = o; o += EVM_F_STRIDE * nf;
     S.sc_s = o; o += EVM_S_STRIDE * nmus;
