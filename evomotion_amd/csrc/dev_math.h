@@ -123,6 +123,14 @@ DEV float xs_(float a, float b) {
 #pragma clang fp contract(off)
     return a - b;
 }
+DEV P2 xm2(P2 a, P2 b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+DEV P2 xa2(P2 a, P2 b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
 DEV float xdot(F3 a, F3 b) { return xa(xa(xm(a.x, b.x), xm(a.y, b.y)), xm(a.z, b.z)); }
 // btMatrix3x3::setRotation, every operation individually rounded
 DEV M33 mat_from_quat(Q4 q) {

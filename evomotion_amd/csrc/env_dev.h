@@ -32,8 +32,8 @@ struct EnvDev {
 };
 
 hipError_t upload_skeleton(const EvmSkelC *h, hipStream_t s);
-size_t step_lds_bytes(int nb);
-hipError_t launch_step(const EnvDev &d, int nb, int mode, const float *action, float *obs, float *reward,
+size_t step_lds_bytes(int nb, int nscan);
+hipError_t launch_step(const EnvDev &d, size_t lds_bytes, int mode, const float *action, float *obs, float *reward,
                        uint8_t *done, uint8_t *valid, const uint8_t *mask, hipStream_t s);
 hipError_t launch_repose(const EnvDev &d, const uint8_t *mask, hipStream_t s);
 hipError_t launch_init(const EnvDev &d, uint64_t seed, hipStream_t s);

@@ -89,7 +89,7 @@ int evm_env_create(const char *skeleton_path, int n_envs, int device, uint64_t s
     int rc = evm::load_skeleton_constants(skeleton_path, prm, env->skel, err);
     if (rc != EVM_OK) { delete env; return fail(rc, err); }
     const EvmSkelC &S = env->skel;
-    if (evm::step_lds_bytes(S.nb) > 160 * 1024) { delete env; return fail(EVM_E_UNSUPPORTED, "skeleton has too many bodies for the LDS tile"); }
+    if (evm::step_lds_bytes(S.nb, S.nscan) > 160 * 1024) { delete env; return fail(EVM_E_UNSUPPORTED, "skeleton has too many bodies for the LDS tile"); }
     hipError_t he = hipSetDevice(device);
     if (he != hipSuccess) { delete env; return fail(EVM_E_HIP, std::string("hipSetDevice: ") + hipGetErrorString(he)); }
 
@@ -163,7 +163,7 @@ static int step_launch(EvmEnv *env, int mode, const float *a, float *obs, float 
         }
         HIP_TRY(hipEventRecord(env->ev_pairs[env->ev_used].first, s));
     }
-    HIP_TRY(evm::launch_step(env->d, env->skel.nb, mode, a, obs, rew, done, valid, mask, s));
+    HIP_TRY(evm::launch_step(env->d, evm::step_lds_bytes(env->skel.nb, env->skel.nscan), mode, a, obs, rew, done, valid, mask, s));
     if (env->timing) {
         HIP_TRY(hipEventRecord(env->ev_pairs[env->ev_used].second, s));
         env->ev_used++;

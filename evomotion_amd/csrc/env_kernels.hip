@@ -76,6 +76,8 @@ DEV Ctx make_ctx(const EnvDev &d, float *lds) {
 #define LII(b, k) (c.lds[(((c_skel.nb + (b)) * 6 + (k)) << 6) + c.lane])
 // per-body version counters (one int per body) behind the float tiles: dataflow synchronisation of the sweep
 #define LVER(c_) (reinterpret_cast<int *>((c_).lds + (size_t) c_skel.nb * 12 * 64))
+// partial results of the hull scans: slice i -> (minimum world y, vertex index as int bits)
+#define LPART(i, k) (c.lds[(size_t) c_skel.nb * 12 * 64 + (size_t) ((c_skel.nb + 63) / 64) * 64 + ((((i) << 1) + (k)) << 6) + c.lane])
 
 // Wait until body b has been written `expect` times (monotonic counter, workgroup-scope acquire).  Bounded:
 // a schedule bug must not hang the GPU; on timeout the diagnostic slot is poisoned and the wave goes on.
@@ -732,34 +734,67 @@ DEV void store_mp(const Ctx &c, int m, int slot, const MPoint &p) {
     MFP(m, slot, 6) = p.dist; MFP(m, slot, 7) = p.ap; MFP(m, slot, 8) = p.apl;
 }
 
-// collision + manifold maintenance for member m; returns the number of cached points afterwards
+// Deepest-vertex scan of one hull slice: the first strict minimum of world y over the slice, every product and
+// sum individually rounded (no fma contraction) so that the discrete choice follows the same rounding as a plain
+// multiply/add sequence.  Two vertices per packed instruction (pair layout of EvmSkelC::hull); the coordinates
+// are wave-uniform and arrive as wide scalar loads, four pairs per trip.  Even and odd vertices keep separate
+// running minima, merged at the end (lower value first, then lower index).
+DEV void hull_scan(const Ctx &c, int si) {
+    const EvmScanC &S = c_skel.scan[si];
+    const int m = S.member;
+    const EvmMemberC &MB = c_skel.member[m];
+    const F3 r1 = SC3(c_skel.sc_r + 9 * m + 3);
+    const float oy = GS(pos, 3 * m + 1);
+    const P2 rx = p2(r1.x, r1.x), ry = p2(r1.y, r1.y), rz = p2(r1.z, r1.z), oyp = p2(oy, oy);
+    const float *hp = c_skel.hull + 3 * (MB.hull_off + S.begin);  // 6 floats per vertex pair
+    const int np = (S.end - S.begin + 1) >> 1;
+    P2 best = p2(EVM_INF, EVM_INF);
+    int be = 0, bo = 0;  // pair index of the even / odd minimum
+#define EVM_SCAN_PAIR(H, Q, PI)                                                                       \
+    {                                                                                                 \
+        const P2 x = p2(H[6 * (Q)], H[6 * (Q) + 1]), y = p2(H[6 * (Q) + 2], H[6 * (Q) + 3]),          \
+                 z = p2(H[6 * (Q) + 4], H[6 * (Q) + 5]);                                              \
+        const P2 wy = xa2(xa2(xa2(xm2(rx, x), xm2(ry, y)), xm2(rz, z)), oyp);                         \
+        const bool ce = wy.x < best.x, co = wy.y < best.y;                                            \
+        best = p2(ce ? wy.x : best.x, co ? wy.y : best.y);                                            \
+        be = ce ? (PI) : be;                                                                          \
+        bo = co ? (PI) : bo;                                                                          \
+    }
+    int p = 0;
+    for (; p + 4 <= np; p += 4) {
+        float h[24];
+#pragma unroll
+        for (int k = 0; k < 24; k++) h[k] = hp[6 * p + k];
+#pragma unroll
+        for (int q = 0; q < 4; q++) EVM_SCAN_PAIR(h, q, p + q)
+    }
+    for (; p < np; p++) {
+        float h[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) h[k] = hp[6 * p + k];
+        EVM_SCAN_PAIR(h, 0, p)
+    }
+#undef EVM_SCAN_PAIR
+    float b = best.x;
+    int bi = 2 * be;
+    if (best.y < b || (best.y == b && 2 * bo + 1 < bi)) { b = best.y; bi = 2 * bo + 1; }
+    LPART(si, 0) = b;
+    LPART(si, 1) = __int_as_float(S.begin + bi);
+}
+
+// manifold maintenance for member m from the scanned deepest vertex; returns the number of cached points afterwards
 DEV int contact_update(const Ctx &c, int m) {
     const EvmMemberC &MB = c_skel.member[m];
     const F3 o = G3(pos, 3 * m);
     const M33 R = m33(SC3(c_skel.sc_r + 9 * m), SC3(c_skel.sc_r + 9 * m + 3), SC3(c_skel.sc_r + 9 * m + 6));
-    // deepest hull vertex: first strict minimum of world y, evaluated without fma contraction so that the
-    // discrete choice follows the same rounding as a plain multiply/add sequence
-    float best = EVM_INF;
-    int bi = 0;
-    const float *hp = c_skel.hull + 3 * MB.hull_off;
-    // 8 vertices per trip: the 24 coordinates are wave-uniform, so they arrive as a few wide scalar loads with
-    // one wait instead of one scalar round trip per vertex
-    const int n8 = MB.hull_n & ~7;
-    for (int i0 = 0; i0 < n8; i0 += 8) {
-        float pc[24];
-#pragma unroll
-        for (int k = 0; k < 24; k++) pc[k] = hp[3 * i0 + k];
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const float wy = xa(xa(xa(xm(R.r1.x, pc[3 * k]), xm(R.r1.y, pc[3 * k + 1])), xm(R.r1.z, pc[3 * k + 2])), o.y);
-            if (wy < best) { best = wy; bi = i0 + k; }
-        }
+    float best = LPART(MB.scan_first, 0);
+    int bi = __float_as_int(LPART(MB.scan_first, 1));
+    for (int k = 1; k < MB.scan_count; k++) {  // slices in vertex order: a strict compare keeps the first minimum
+        const float b2 = LPART(MB.scan_first + k, 0);
+        const int i2 = __float_as_int(LPART(MB.scan_first + k, 1));
+        if (b2 < best) { best = b2; bi = i2; }
     }
-    for (int i = n8; i < MB.hull_n; i++) {
-        const float px = hp[3 * i], py = hp[3 * i + 1], pz = hp[3 * i + 2];
-        const float wy = xa(xa(xa(xm(R.r1.x, px), xm(R.r1.y, py)), xm(R.r1.z, pz)), o.y);
-        if (wy < best) { best = wy; bi = i; }
-    }
+    const float *hp = c_skel.hull;
     int n = GS(mfn, m);
     const float thr = MB.break_thr;
     const float depth = (best - c_skel.floor_top_y) - (MARGIN_F + MARGIN_F);
@@ -769,7 +804,8 @@ DEV int contact_update(const Ctx &c, int m) {
     MPoint p0 = load_mp(c, m, 0), p1 = load_mp(c, m, 1), p2 = load_mp(c, m, 2), p3 = load_mp(c, m, 3);
     const F3 fo = load_f3(c_skel.floor_o);
     if (add) {
-        const F3 ps = f3(hp[3 * bi], hp[3 * bi + 1], hp[3 * bi + 2]);
+        const int g = MB.hull_off + bi, hb = 6 * (g >> 1) + (g & 1);
+        const F3 ps = f3(hp[hb], hp[hb + 2], hp[hb + 4]);
         const F3 w = f3(xa(xa(xa(xm(R.r0.x, ps.x), xm(R.r0.y, ps.y)), xm(R.r0.z, ps.z)), o.x),
                         best,
                         xa(xa(xa(xm(R.r2.x, ps.x), xm(R.r2.y, ps.y)), xm(R.r2.z, ps.z)), o.z));
@@ -1226,6 +1262,9 @@ DEV void physics_step(const Ctx &c, int flags) {
     STAMP(1);
 
     // ---- collision: hull vs floor plane, persistent manifolds (members dealt to waves by hull size) ----
+    for (int i = 0; i < c_skel.nscan; i++)
+        if (c_skel.scan[i].wave == W) hull_scan(c, i);
+    __syncthreads();
     for (int m = 0; m < c_skel.nm; m++)
         if (c_skel.member_wave[m] == W && c_skel.member[m].contact_response) contact_update(c, m);
     __syncthreads();
@@ -1591,12 +1630,13 @@ __global__ __launch_bounds__(64) void k_env_poses(EnvDev d, float *out) {
 hipError_t upload_skeleton(const EvmSkelC *h, hipStream_t s) {
     return hipMemcpyToSymbolAsync(HIP_SYMBOL(c_skel), h, sizeof(EvmSkelC), 0, hipMemcpyHostToDevice, s);
 }
-size_t step_lds_bytes(int nb) { return (size_t) nb * 12 * 64 * sizeof(float) + (size_t) ((nb + 63) / 64) * 256; }  // tiles + version counters
+size_t step_lds_bytes(int nb, int nscan) {  // tiles + version counters + hull-scan partials
+    return (size_t) nb * 12 * 64 * sizeof(float) + (size_t) ((nb + 63) / 64) * 256 + (size_t) nscan * 2 * 64 * sizeof(float);
+}
 
 template <int MODE>
-static hipError_t launch_mode(const EnvDev &d, int nb, const float *action, float *obs, float *reward, uint8_t *done,
+static hipError_t launch_mode(const EnvDev &d, size_t lds, const float *action, float *obs, float *reward, uint8_t *done,
                               uint8_t *valid, const uint8_t *mask, hipStream_t s) {
-    const size_t lds = step_lds_bytes(nb);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_env_step<MODE>),
@@ -1607,13 +1647,13 @@ static hipError_t launch_mode(const EnvDev &d, int nb, const float *action, floa
     hipLaunchKernelGGL((k_env_step<MODE>), dim3(d.n / 64), dim3(64 * EVM_NW), lds, s, d, action, obs, reward, done, valid, mask);
     return hipGetLastError();
 }
-hipError_t launch_step(const EnvDev &d, int nb, int mode, const float *action, float *obs, float *reward, uint8_t *done,
+hipError_t launch_step(const EnvDev &d, size_t lds_bytes, int mode, const float *action, float *obs, float *reward, uint8_t *done,
                        uint8_t *valid, const uint8_t *mask, hipStream_t s) {
     switch (mode) {
-        case 0: return launch_mode<0>(d, nb, action, obs, reward, done, valid, mask, s);
-        case 2: return launch_mode<2>(d, nb, action, obs, reward, done, valid, mask, s);
-        case 3: return launch_mode<3>(d, nb, action, obs, reward, done, valid, mask, s);
-        case 7: return launch_mode<7>(d, nb, action, obs, reward, done, valid, mask, s);
+        case 0: return launch_mode<0>(d, lds_bytes, action, obs, reward, done, valid, mask, s);
+        case 2: return launch_mode<2>(d, lds_bytes, action, obs, reward, done, valid, mask, s);
+        case 3: return launch_mode<3>(d, lds_bytes, action, obs, reward, done, valid, mask, s);
+        case 7: return launch_mode<7>(d, lds_bytes, action, obs, reward, done, valid, mask, s);
         default: return hipErrorInvalidValue;
     }
 }

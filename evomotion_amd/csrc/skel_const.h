@@ -33,7 +33,8 @@ struct EvmBodyC {
     float t0[3];  // first_model_matrix origin
 };
 struct EvmMemberC {
-    int hull_off, hull_n;  // scaled hull points in hull[]
+    int hull_off, hull_n;  // scaled hull points in hull[] (hull_off is even: hulls start on a vertex pair)
+    int scan_first, scan_count;  // this member's slices in EvmSkelC::scan (in vertex order)
     float break_thr;       // relative contact breaking threshold
     float mu;              // combined friction with the floor
     int contact_response;
@@ -73,6 +74,13 @@ struct EvmVisitC {
 
 #define EVM_MAX_SCHED (EVM_MAX_VISITS + 64)
 #define EVM_SCHED_NONE 0x7fff
+// One slice of a member's hull for the deepest-vertex scan.  Large hulls are cut in two so that the scans of the
+// four 451-vertex feet fill all eight waves; the slices' (minimum, index) pairs meet in LDS.
+struct EvmScanC {
+    int member, begin, end;  // vertices [begin, end) of the member's hull, begin even
+    int wave;
+};
+#define EVM_MAX_SCAN (2 * EVM_MAX_MEMBERS)
 #define EVM_SCHED_BARRIER 0x8000
 #define EVM_SCHED_CONTACT 0x4000   // entry = EVM_SCHED_CONTACT | member: the member's contact rows of this sweep
 
@@ -100,11 +108,15 @@ struct EvmSkelC {
     int nlevels;
     int nsched[EVM_NW];
     int sched[EVM_NW][EVM_MAX_SCHED];
-    int member_wave[EVM_MAX_MEMBERS];  // which wave scans / solves the contacts of member m (balanced by hull size)
+    int member_wave[EVM_MAX_MEMBERS];  // which wave maintains the manifold and builds the contact rows of member m
+    int nscan;
+    EvmScanC scan[EVM_MAX_SCAN];
     EvmBodyC body[EVM_MAX_BODIES];
     EvmMemberC member[EVM_MAX_MEMBERS];
     EvmHingeC hinge[EVM_MAX_HINGES];
     EvmFixedC fixed[EVM_MAX_FIXED];
     EvmMuscleC muscle[EVM_MAX_MUSCLES];
+    // hull vertices in PAIRS: vertex g = 2 P + s has x, y, z at hull[6 P + s], hull[6 P + 2 + s], hull[6 P + 4 + s]
+    // (two vertices per packed multiply/add in the scan); a hull with an odd count repeats its last vertex
     float hull[EVM_MAX_HULL_PTS * 3];
 };

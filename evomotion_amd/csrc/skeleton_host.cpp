@@ -240,12 +240,15 @@ int load_skeleton_constants(const char *path, const EvmEnvParams &prm, EvmSkelC 
         const std::vector<float> &pts = shapes[sit->second].pts;
         if (hit == hull_cache.end()) {
             int n = (int) pts.size() / 3;
-            if (hull_used + n > EVM_MAX_HULL_PTS) { err = "hull table overflow"; return EVM_E_UNSUPPORTED; }
-            for (int p = 0; p < n; p++)
-                for (int a = 0; a < 3; a++) S.hull[3 * (hull_used + p) + a] = pts[3 * p + a] * m.scale[a];
+            const int npad = (n + 1) & ~1;  // pair layout (skel_const.h): an odd hull repeats its last vertex
+            if (hull_used + npad > EVM_MAX_HULL_PTS) { err = "hull table overflow"; return EVM_E_UNSUPPORTED; }
+            for (int p = 0; p < npad; p++) {
+                const int src = p < n ? p : n - 1, g = hull_used + p;
+                for (int a = 0; a < 3; a++) S.hull[6 * (g >> 1) + 2 * a + (g & 1)] = pts[3 * src + a] * m.scale[a];
+            }
             hull_cache[hk] = hull_used;
             S.member[i].hull_off = hull_used;
-            hull_used += n;
+            hull_used += npad;
         } else {
             S.member[i].hull_off = hit->second;
         }
@@ -554,16 +557,40 @@ int load_skeleton_constants(const char *path, const EvmEnvParams &prm, EvmSkelC 
             if (S.nsched[w] >= EVM_MAX_SCHED) { err = "sweep schedule overflow"; return EVM_E_UNSUPPORTED; }
             S.sched[w][S.nsched[w]++] = items[i].entry;
         }
-        // members -> waves, heaviest hull first
-        std::vector<int> ms(nm);
-        for (int i = 0; i < nm; i++) ms[i] = i;
-        std::stable_sort(ms.begin(), ms.end(), [&](int x, int y) { return S.member[x].hull_n > S.member[y].hull_n; });
-        int loadm[EVM_NW] = {0};
-        for (int m : ms) {
-            int best = 0;
-            for (int w = 1; w < EVM_NW; w++) if (loadm[w] < loadm[best]) best = w;
-            S.member_wave[m] = best;
-            loadm[best] += S.member[m].hull_n + 16;
+        // hull scans -> waves (longest first); a hull of more than 64 vertices is cut into two slices
+        S.nscan = 0;
+        for (int m = 0; m < nm; m++) {
+            S.member[m].scan_first = S.nscan;
+            const int n = S.member[m].hull_n;
+            if (S.member[m].contact_response) {
+                if (n > 64) {
+                    const int h = ((n / 2) + 1) & ~1;
+                    S.scan[S.nscan++] = {m, 0, h, 0};
+                    S.scan[S.nscan++] = {m, h, n, 0};
+                } else {
+                    S.scan[S.nscan++] = {m, 0, n, 0};
+                }
+            }
+            S.member[m].scan_count = S.nscan - S.member[m].scan_first;
+        }
+        {
+            std::vector<int> order(S.nscan);
+            for (int i = 0; i < S.nscan; i++) order[i] = i;
+            std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
+                return S.scan[x].end - S.scan[x].begin > S.scan[y].end - S.scan[y].begin;
+            });
+            int load[EVM_NW] = {0};
+            for (int i : order) {
+                int best = 0;
+                for (int w = 1; w < EVM_NW; w++) if (load[w] < load[best]) best = w;
+                S.scan[i].wave = best;
+                load[best] += S.scan[i].end - S.scan[i].begin + 16;
+            }
+        }
+        // manifold maintenance + contact rows of a member: the same work for every member, dealt round robin
+        {
+            int k = 0;
+            for (int m = 0; m < nm; m++) S.member_wave[m] = S.member[m].contact_response ? (k++ % EVM_NW) : 0;
         }
     }
     return EVM_OK;
