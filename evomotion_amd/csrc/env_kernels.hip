@@ -89,6 +89,20 @@ DEV void wait_version(const Ctx &c, int b, int expect) {
         if (++spins > (1 << 22)) { c.t.diag[c.lane] = -1.f; break; }
     }
 }
+// both bodies of a joint visit with ONE LDS round trip: two relaxed polls in flight together, one acquire fence
+// once both versions have been reached (lane 0 is always a live env; other lanes may have exited on a ragged tile)
+DEV void wait_versions2(const Ctx &c, int a, int expA, int b, int expB) {
+    int *ver = LVER(c);
+    int spins = 0;
+    for (;;) {
+        const int va = __hip_atomic_load(&ver[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const int vb = __hip_atomic_load(&ver[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (__builtin_amdgcn_readfirstlane(va) >= expA && __builtin_amdgcn_readfirstlane(vb) >= expB) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1 << 22)) { c.t.diag[c.lane] = -1.f; break; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 DEV void publish_version(const Ctx &c, int b, int value) {
     __hip_atomic_store(&LVER(c)[b], value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -222,12 +236,18 @@ struct BodyPD {
     S33P I;
     P2 im;
 };
-DEV BodyPD load_bodypd(const Ctx &c, int a, int b, float imA, float imB) {
+// world inverse inertia of both bodies: constant during the sweeps, so a visit reads it BEFORE it waits for its turn
+DEV S33P load_inertia_pair(const Ctx &c, int a, int b) {
+    S33P I;
+    I.xx = p2(LII(a, 0), LII(b, 0)); I.xy = p2(LII(a, 1), LII(b, 1)); I.xz = p2(LII(a, 2), LII(b, 2));
+    I.yy = p2(LII(a, 3), LII(b, 3)); I.yz = p2(LII(a, 4), LII(b, 4)); I.zz = p2(LII(a, 5), LII(b, 5));
+    return I;
+}
+DEV BodyPD load_bodypd(const Ctx &c, int a, int b, float imA, float imB, const S33P &I) {
     BodyPD k;
     k.dl = f3p(p2(LDV(a, 0), LDV(b, 0)), p2(LDV(a, 1), LDV(b, 1)), p2(LDV(a, 2), LDV(b, 2)));
     k.da = f3p(p2(LDV(a, 3), LDV(b, 3)), p2(LDV(a, 4), LDV(b, 4)), p2(LDV(a, 5), LDV(b, 5)));
-    k.I.xx = p2(LII(a, 0), LII(b, 0)); k.I.xy = p2(LII(a, 1), LII(b, 1)); k.I.xz = p2(LII(a, 2), LII(b, 2));
-    k.I.yy = p2(LII(a, 3), LII(b, 3)); k.I.yz = p2(LII(a, 4), LII(b, 4)); k.I.zz = p2(LII(a, 5), LII(b, 5));
+    k.I = I;
     k.im = p2(imA, imB);
     return k;
 }
@@ -372,14 +392,14 @@ DEV void hinge_setup(const Ctx &c, int hi) {
     rec[27] = 0.f; rec[34] = lo; rec[35] = hi_;
     rec_store<0, EVM_H_STRIDE / 4>(c, c_skel.sc_h + EVM_H_STRIDE * hi, rec);
 }
-DEV float hinge_solve(const Ctx &c, const EvmVisitC &V, const Blk42 &k) {
+DEV float hinge_solve(const Ctx &c, const EvmVisitC &V, const Blk42 &k, const S33P &I) {
     const int s = V.slot;
     const F3 relA = KV3(k, 0), relB = KV3(k, 3), p = KV3(k, 6), q = KV3(k, 9), ax1 = KV3(k, 12);
     float ap[6];
 #pragma unroll
     for (int r = 0; r < 6; r++) ap[r] = KV(k, 28 + r);
     const float lo = KV(k, 34), hi_ = KV(k, 35);
-    BodyPD Q = load_bodypd(c, V.a, V.b, V.imA, V.imB);
+    BodyPD Q = load_bodypd(c, V.a, V.b, V.imA, V.imB, I);
     const F3P rel = pair(relA, relB);
     float res = 0.f;
     res = fmaxf(res, fabsf(row_iter<true, false>(p, rel, Q, KV(k, 15), KV(k, 21), 0.f, 0.f, ap[0])));
@@ -459,13 +479,13 @@ DEV void fixed_setup(const Ctx &c, int fi) {
     rec[42] = 0.f; rec[43] = 0.f;
     rec_store<0, EVM_F_STRIDE / 4>(c, c_skel.sc_f + EVM_F_STRIDE * fi, rec);
 }
-DEV float fixed_solve(const Ctx &c, const EvmVisitC &V, const Blk42 &k) {
+DEV float fixed_solve(const Ctx &c, const EvmVisitC &V, const Blk42 &k, const S33P &I) {
     const int s = V.slot;
     const F3 relA = KV3(k, 0), relB = KV3(k, 3);
     float ap[6];
 #pragma unroll
     for (int r = 0; r < 6; r++) ap[r] = KV(k, 36 + r);
-    BodyPD Q = load_bodypd(c, V.a, V.b, V.imA, V.imB);
+    BodyPD Q = load_bodypd(c, V.a, V.b, V.imA, V.imB, I);
     const F3P rel = pair(relA, relB);
     float res = 0.f;
 #pragma unroll
@@ -605,7 +625,7 @@ DEV void slider_setup(const Ctx &c, int mi, bool powered_in, float target_vel) {
     rec_store<0, EVM_S_STRIDE / 4>(c, c_skel.sc_s + EVM_S_STRIDE * mi, rec);
     SC(c_skel.sc_mobs + 4 * mi) = lin_pos;  // btSliderConstraint::getLinearPos(), MuscleState
 }
-DEV float slider_solve(const Ctx &c, const EvmVisitC &V, const Blk42 &kk) {
+DEV float slider_solve(const Ctx &c, const EvmVisitC &V, const Blk42 &kk, const S33P &I) {
     const int s = V.slot;
     const F3 p = KV3(kk, 0), q = KV3(kk, 3), ax1 = KV3(kk, 6), p2_ = KV3(kk, 9), q2 = KV3(kk, 12);
     const F3 relA = KV3(kk, 15), relB = KV3(kk, 18);
@@ -613,7 +633,7 @@ DEV float slider_solve(const Ctx &c, const EvmVisitC &V, const Blk42 &kk) {
 #pragma unroll
     for (int r = 0; r < 6; r++) ap[r] = KV(kk, 36 + r);
     const float lo = KV(kk, 33), hi_ = KV(kk, 34);
-    BodyPD Q = load_bodypd(c, V.a, V.b, V.imA, V.imB);
+    BodyPD Q = load_bodypd(c, V.a, V.b, V.imA, V.imB, I);
     const F3P rel = pair(relA, relB);
     float res = 0.f;
     res = fmaxf(res, fabsf(row_iter<false, false>(p, rel, Q, KV(kk, 21), KV(kk, 27), 0.f, 0.f, ap[0])));
@@ -655,11 +675,15 @@ DEV void p2p_setup(const Ctx &c, int mi, int which) {
 }
 // p2p rows along the world axes.  The pivot in the attach sphere is the origin (muscle.cpp:52,55), so the
 // sphere-side lever arm a2 is exactly zero: body B only takes the linear part.
-DEV float p2p_solve(const Ctx &c, const EvmVisitC &V, const Blk42 &kk) {
+DEV float p2p_solve(const Ctx &c, const EvmVisitC &V, const Blk42 &kk, const S33P &I) {
     const int ba = V.a, bb = V.b;
     const int s = V.slot;
     const F3 a1 = KV3(kk, 0);
-    BodyD A = load_bodyd(c, ba, V.imA);
+    BodyD A;
+    A.dl = f3(LDV(ba, 0), LDV(ba, 1), LDV(ba, 2));
+    A.da = f3(LDV(ba, 3), LDV(ba, 4), LDV(ba, 5));
+    A.I.xx = I.xx.x; A.I.xy = I.xy.x; A.I.xz = I.xz.x; A.I.yy = I.yy.x; A.I.yz = I.yz.x; A.I.zz = I.zz.x;
+    A.im = V.imA;
     F3 dlB = f3(LDV(bb, 0), LDV(bb, 1), LDV(bb, 2));
     const float imB = V.imB;
     float ap0 = KV(kk, 12), ap1 = KV(kk, 13), ap2 = KV(kk, 14);
@@ -985,10 +1009,14 @@ DEV void contact_setup(const Ctx &c, int m, int n) {
 }
 
 // Gauss-Seidel rows of member m's contact points; k = the member's record, requested one schedule entry ahead
-DEV float contact_iter(const Ctx &c, int m, const Blk42 &k) {
+DEV float contact_iter(const Ctx &c, int m, const Blk42 &k, const S33 &I) {
     const EvmMemberC &MB = c_skel.member[m];
     const int rec = c_skel.sc_c + EVM_CM_STRIDE * m;
-    BodyD D = load_bodyd(c, m);
+    BodyD D;
+    D.dl = f3(LDV(m, 0), LDV(m, 1), LDV(m, 2));
+    D.da = f3(LDV(m, 3), LDV(m, 4), LDV(m, 5));
+    D.I = I;
+    D.im = c_skel.body[m].inv_mass;
     float res = 0.f;
     float apn[4];
     float w[EVM_CM_STRIDE];
@@ -1264,9 +1292,12 @@ DEV void physics_step(const Ctx &c, int flags) {
     // ---- collision: hull vs floor plane, persistent manifolds (members dealt to waves by hull size) ----
     for (int i = 0; i < c_skel.nscan; i++)
         if (c_skel.scan[i].wave == W) hull_scan(c, i);
+    STAMP(9);   // wave 0: its own scans done
     __syncthreads();
+    STAMP(10);  // all scans done
     for (int m = 0; m < c_skel.nm; m++)
         if (c_skel.member_wave[m] == W && c_skel.member[m].contact_response) contact_update(c, m);
+    STAMP(11);  // wave 0: its manifolds done
     __syncthreads();
     int ncontact = 0;
     unsigned cmask = 0;  // wave-uniform: members with a cached point in any lane
@@ -1299,12 +1330,12 @@ DEV void physics_step(const Ctx &c, int flags) {
 
     // ---- projected Gauss-Seidel sweeps ----
     // A wave walks its slice of the level schedule (EvmSkelC::sched); a workgroup barrier closes each level.
-    auto solve = [&](const EvmVisitC &V, const Blk42 &k) -> float {
+    auto solve = [&](const EvmVisitC &V, const Blk42 &k, const S33P &I) -> float {
         switch (V.type) {
-            case 0: return hinge_solve(c, V, k);
-            case 1: return fixed_solve(c, V, k);
-            case 2: return slider_solve(c, V, k);
-            default: return p2p_solve(c, V, k);
+            case 0: return hinge_solve(c, V, k, I);
+            case 1: return fixed_solve(c, V, k, I);
+            case 2: return slider_solve(c, V, k, I);
+            default: return p2p_solve(c, V, k, I);
         }
     };
     const int ns = c_skel.nsched[W];
@@ -1337,15 +1368,15 @@ DEV void physics_step(const Ctx &c, int flags) {
 #ifdef EVM_STAMPS2
         const unsigned long long t0 = __builtin_amdgcn_s_memtime();
 #endif
-        wait_version(c, V.a, expA);
-        wait_version(c, V.b, expB);
+        const S33P I = load_inertia_pair(c, V.a, V.b);
+        wait_versions2(c, V.a, expA, V.b, expB);
 #ifdef EVM_STAMPS2
         const unsigned long long t1 = __builtin_amdgcn_s_memtime();
 #endif
 #ifdef EVM_STAMPS3
         const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
 #endif
-        const float r = solve(V, k);
+        const float r = solve(V, k, I);
         publish_version(c, V.a, expA + 1);
         publish_version(c, V.b, expB + 1);
 #ifdef EVM_STAMPS3
@@ -1366,6 +1397,7 @@ DEV void physics_step(const Ctx &c, int flags) {
 #ifdef EVM_STAMPS2
         const unsigned long long t0 = __builtin_amdgcn_s_memtime();
 #endif
+        const S33 I = lds_inertia(c, m);
         wait_version(c, m, it * ps + ps - 1);
 #ifdef EVM_STAMPS2
         const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -1374,7 +1406,7 @@ DEV void physics_step(const Ctx &c, int flags) {
 #ifdef EVM_STAMPS3
         const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
 #endif
-        if (cmask & (1u << m)) r = contact_iter(c, m, k);
+        if (cmask & (1u << m)) r = contact_iter(c, m, k, I);
         publish_version(c, m, (it + 1) * ps);
 #ifdef EVM_STAMPS3
         {

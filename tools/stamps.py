@@ -27,9 +27,9 @@ tot = acc[:8].sum()
 for nm, v in zip(names, acc[:8]):
     print("%-14s %9.0f cycles %5.1f %%" % (nm, v / K, 100 * v / tot))
 print("total cycles/step", tot / K, "(s_memtime counts shader-clock cycles, ~2.0 GHz under this load)")
-# optional fine stamps 9..12 around one hinge visit (wait / solve / publish)
+# fine stamps inside "collide" (wave 0 of each tile): own scans, all scans, own manifolds
 st = (ctypes.c_ulonglong * (n // 64 * 16))()
 check(lib.evm_env_get_stamps(env._h, st))
 s = np.array(st, dtype=np.uint64).reshape(-1, 16).astype(np.float64)
-d = np.diff(s[:, 9:13], axis=1)
-print("one hinge visit (median over tiles): wait %.0f  solve %.0f  publish %.0f ticks" % tuple(np.median(d, axis=0)))
+print("collide detail (median over tiles, last step): wave0 scans %.0f, wait for all scans %.0f, wave0 manifolds %.0f, wait for all %.0f cycles"
+      % (np.median(s[:, 9] - s[:, 1]), np.median(s[:, 10] - s[:, 9]), np.median(s[:, 11] - s[:, 10]), np.median(s[:, 2] - s[:, 11])))
