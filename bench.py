@@ -21,6 +21,18 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 VALU_PEAK_TFLOPS = 157.3
 
 
+def measured_traffic(n):
+    """HBM-side bytes per launch of the dynamics kernel, from the committed PMC profile of this exact workload
+    (rocprofv3 cannot run inside the timed bench); None when the batch size differs from the profiled one."""
+    path = os.path.join(ROOT, "profiles", "r1c_traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        return t["traffic_bytes_per_launch"] if t["envs_per_launch"] == n else None
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(seconds=12.0):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orc
@@ -160,10 +172,12 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n),
                 "kernel": "k_env_step<7>", "launch_ms": launch_ms,
                 "note": "algorithmic 8300 B per env physics step x %d envs per launch; the kernel is fp32-VALU/latency "
-                        "bound (about 50 FLOP per algorithmic byte), see DESIGN.md" % n,
+                        "bound (about 50 FLOP per algorithmic byte); traffic = memory-side bytes per launch from the "
+                        "committed rocprofv3 PMC passes (profiles/r1c_traffic.json; per-sweep re-reads of the constraint "
+                        "records overflow the 4 MB L2 and are served by the Infinity Cache), see DESIGN.md" % n,
             },
         }
         if agent is not None and n_policy:
