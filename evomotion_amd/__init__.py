@@ -7,3 +7,4 @@ from ._lib import DEFAULT_SKELETON, EvmError, LIB_PATH  # noqa: F401
 from .env import RolloutStep, Step, VecRobotWalk  # noqa: F401
 from .agent import (ActorModule, CriticModule, FusedActorCritic, RandomAgent, VecPpoGaeAgent,  # noqa: F401,E402
                     ppo_train, gae_advantages, truncated_normal_log_pdf, truncated_normal_entropy, truncated_normal_sample)
+from .checkpoint import load_into, load_th, save_th  # noqa: F401,E402

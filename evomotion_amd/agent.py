@@ -255,6 +255,13 @@ class FusedActorCritic:
     def load_modules(self, actor, critic):
         self.set_weights(flat_parameters(actor).numpy(), flat_parameters(critic).numpy())
 
+    def load_th(self, actor_path, critic_path):
+        """Weights from `*.th` checkpoints in the reference's format (saver.h:27-39), e.g. the reference's own files."""
+        from .checkpoint import load_th
+        a, c = load_th(actor_path), load_th(critic_path)
+        self.set_weights(torch.cat([t.reshape(-1).float() for t in a.values()]).numpy(),
+                         torch.cat([t.reshape(-1).float() for t in c.values()]).numpy())
+
     def forward(self, obs, uniform=None, seed=0, want_dist=False):
         n = obs.shape[0]
         assert obs.is_cuda and obs.dtype == torch.float32 and obs.is_contiguous() and obs.shape[1] == self.S
@@ -304,6 +311,29 @@ class VecPpoGaeAgent:
 
     def count_parameters(self):
         return count_parameters(self.actor, self.critic)
+
+    def save(self, output_folder_path):
+        """PpoGaeAgent::save (ppo_gae.cpp:192-197): actor.th / critic.th in the reference's format; the optimiser
+        states go to `*_optimizer.pt` (torch.save) — the reference's optimiser archives are keyed by parameter
+        addresses of the saving process (checkpoint.py)."""
+        from .checkpoint import save_th
+        import os
+        save_th(self.actor, os.path.join(output_folder_path, "actor.th"))
+        save_th(self.critic, os.path.join(output_folder_path, "critic.th"))
+        torch.save(self.actor_opt.state_dict(), os.path.join(output_folder_path, "actor_optimizer.pt"))
+        torch.save(self.critic_opt.state_dict(), os.path.join(output_folder_path, "critic_optimizer.pt"))
+
+    def load(self, input_folder_path):
+        """PpoGaeAgent::load (ppo_gae.cpp:199-204); optimiser states are restored when our `.pt` files are present."""
+        from .checkpoint import load_into
+        import os
+        load_into(self.actor, os.path.join(input_folder_path, "actor.th"))
+        load_into(self.critic, os.path.join(input_folder_path, "critic.th"))
+        for opt, name in ((self.actor_opt, "actor_optimizer.pt"), (self.critic_opt, "critic_optimizer.pt")):
+            f = os.path.join(input_folder_path, name)
+            if os.path.isfile(f):
+                opt.load_state_dict(torch.load(f, map_location=self.device))
+        self.fused.load_modules(self.actor, self.critic)
 
     def rollout(self, env, last=None):
         """`horizon` calls of policy forward + evm_env_step_autoreset; everything stays on the device."""

@@ -21,4 +21,8 @@ if [ -f "$HERE/ref_golden.cpp" ]; then
   g++ $FLAGS "$HERE/ref_golden.cpp" -L"$OUT" -levo_motion_networks -L"$T/lib" -ltorch_cpu -lc10 \
       -Wl,-rpath,"$OUT" -Wl,-rpath,"$T/lib" -o "$OUT/ref_golden"
 fi
+if [ -f "$HERE/ref_th.cpp" ]; then
+  g++ $FLAGS "$HERE/ref_th.cpp" -L"$OUT" -levo_motion_networks -L"$T/lib" -ltorch_cpu -lc10 \
+      -Wl,-rpath,"$OUT" -Wl,-rpath,"$T/lib" -o "$OUT/ref_th"
+fi
 echo "reference build ok: $OUT"

@@ -1,0 +1,95 @@
+"""`*.th` module checkpoints (evomotion_amd/checkpoint.py) against the reference's saver.h format."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import agent_oracle as ao  # noqa: E402
+import golden_io  # noqa: E402
+from evomotion_amd.agent import ActorModule, CriticModule  # noqa: E402
+from evomotion_amd.checkpoint import load_into, load_th, save_th  # noqa: E402
+
+REF_TH = os.path.join(ROOT, "oracle", "_ref", "ref_th")
+SHIPPED = "/root/reference/resources/robot_walk_crossq_save_34/actor.th"
+TH_GOLDEN = os.path.join(ROOT, "tests", "golden", "th_golden.txt")
+
+
+def pattern_actor():
+    a = ActorModule([371], [12], 256)
+    pa = ao.pattern_params(ao.ACTOR_SHAPES, 100)
+    with torch.no_grad():
+        for n, p in a.named_parameters():
+            p.copy_(torch.from_numpy(pa[n]))
+    return a, pa
+
+
+def test_python_round_trip_keeps_names_order_and_bits(tmp_path):
+    gold = golden_io.load()
+    a, pa = pattern_actor()
+    save_th(a, str(tmp_path / "actor.th"))
+    sd = load_th(str(tmp_path / "actor.th"))
+    ref_order = [(n, s) for who, n, s in gold["_params"] if who == "actor"]  # the reference's named_parameters()
+    assert [(n, tuple(v.shape)) for n, v in sd.items()] == ref_order
+    for n, v in sd.items():
+        assert np.array_equal(v.numpy(), pa[n])
+    c = CriticModule([371], 256)
+    save_th(c, str(tmp_path / "critic.th"))
+    c2 = load_into(CriticModule([371], 256), str(tmp_path / "critic.th"))
+    for (n1, p1), (n2, p2) in zip(c.named_parameters(), c2.named_parameters()):
+        assert n1 == n2 and torch.equal(p1, p2)
+
+
+def test_errors_mirror_saver_h(tmp_path):
+    a, _ = pattern_actor()
+    with pytest.raises(RuntimeError, match="Could not find"):  # saver.h:17-18
+        save_th(a, str(tmp_path / "missing_folder" / "actor.th"))
+    with pytest.raises(RuntimeError, match="Could not find"):  # saver.h:33-34
+        load_th(str(tmp_path / "nope.th"))
+    save_th(a, str(tmp_path / "actor.th"))
+    with pytest.raises(RuntimeError, match="does not match"):
+        load_into(CriticModule([371], 256), str(tmp_path / "actor.th"))
+    with pytest.raises(RuntimeError, match="shape"):
+        load_into(ActorModule([371], [6], 256), str(tmp_path / "actor.th"))
+
+
+def test_golden_round_trip_vector_is_the_agent_golden_vector():
+    """Data-only check, runs anywhere: the reference, after load_torch() of a file written by save_th, reproduced the
+    forward outputs it gives with the same weights set directly (agent_golden.txt)."""
+    g, t = golden_io.load(), golden_io.load(TH_GOLDEN)
+    assert np.array_equal(t["roundtrip_mu"], g["mu"]) and np.array_equal(t["roundtrip_sigma"], g["sigma"])
+
+
+@pytest.mark.skipif(not os.path.isfile(REF_TH), reason="oracle/_ref not built (authoring container only)")
+def test_reference_library_reads_our_file_and_we_read_its_file(tmp_path):
+    a, pa = pattern_actor()
+    (tmp_path / "ours").mkdir()
+    (tmp_path / "theirs").mkdir()
+    save_th(a, str(tmp_path / "ours" / "actor.th"))
+    out = subprocess.run([REF_TH, "load", str(tmp_path / "ours"), "actor.th"], capture_output=True, text=True, check=True).stdout
+    (tmp_path / "o.txt").write_text(out)
+    got, g = golden_io.load(str(tmp_path / "o.txt")), golden_io.load()
+    assert np.array_equal(got["mu"], g["mu"]) and np.array_equal(got["sigma"], g["sigma"])
+    subprocess.run([REF_TH, "save", str(tmp_path / "theirs")], check=True)
+    sd = load_th(str(tmp_path / "theirs" / "actor.th"))
+    assert all(np.array_equal(sd[n].numpy(), pa[n]) for n, _ in ao.ACTOR_SHAPES)
+    pc = ao.pattern_params(ao.CRITIC_SHAPES, 200)
+    sdc = load_th(str(tmp_path / "theirs" / "critic.th"))
+    assert all(np.array_equal(sdc[n].numpy(), pc[n]) for n, _ in ao.CRITIC_SHAPES)
+
+
+@pytest.mark.skipif(not os.path.isfile(SHIPPED), reason="the reference's shipped checkpoint is only in the authoring container")
+def test_shipped_crossq_actor_loads_and_matches_the_reference_forward():
+    t = golden_io.load(TH_GOLDEN)
+    a = load_into(ActorModule([371], [12], 256), SHIPPED)  # CUDA tensors in the file: mapped to the CPU
+    a.eval()
+    x = torch.from_numpy(golden_io.load()["X"])
+    with torch.no_grad():
+        mu, sigma = a(x)
+    np.testing.assert_allclose(mu.numpy(), t["shipped_mu"], atol=2e-5)
+    np.testing.assert_allclose(sigma.numpy(), t["shipped_sigma"], atol=2e-5, rtol=2e-5)

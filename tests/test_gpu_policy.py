@@ -114,6 +114,34 @@ def test_matches_torch_modules_at_full_batch(fused):
     assert (action - mu).abs().mean() < (sigma.mean() * 2)
 
 
+def test_weights_from_th_checkpoints(fused, tmp_path):
+    """evm_policy_forward with weights read from `.th` files equals the same weights set directly; agent save/load."""
+    import torch
+    from evomotion_amd import ActorModule, CriticModule, FusedActorCritic, VecPpoGaeAgent, save_th
+    f, pa, pc = fused
+    a, c = ActorModule([371], [12], 256), CriticModule([371], 256)
+    with torch.no_grad():
+        for n, p in a.named_parameters():
+            p.copy_(torch.from_numpy(pa[n]))
+        for n, p in c.named_parameters():
+            p.copy_(torch.from_numpy(pc[n]))
+    save_th(a, str(tmp_path / "actor.th"))
+    save_th(c, str(tmp_path / "critic.th"))
+    f2 = FusedActorCritic(371, 12, 256, 0)
+    f2.load_th(str(tmp_path / "actor.th"), str(tmp_path / "critic.th"))
+    g = torch.Generator(device="cpu").manual_seed(9)
+    x = (torch.rand(100, 371, generator=g) * 2 - 1).cuda()
+    u = torch.rand(100, 12, generator=g).cuda()
+    for r, o in zip(f.forward(x, uniform=u, want_dist=True), f2.forward(x, uniform=u, want_dist=True)):
+        assert torch.equal(r, o)
+    ag = VecPpoGaeAgent(7, [371], [12], horizon=4, epoch=1)
+    ag.save(str(tmp_path))
+    ag2 = VecPpoGaeAgent(8, [371], [12], horizon=4, epoch=1)
+    ag2.load(str(tmp_path))
+    for r, o in zip(ag.fused.forward(x, uniform=u), ag2.fused.forward(x, uniform=u)):
+        assert torch.equal(r, o)
+
+
 def test_rollout_and_update_smoke():
     import torch
     from evomotion_amd import VecPpoGaeAgent, VecRobotWalk
