@@ -35,13 +35,19 @@ CRITIC_SHAPES = [("critic.0.weight", (256, 371)), ("critic.0.bias", (256,)), ("c
                  ("critic.6.weight", (1, 256)), ("critic.6.bias", (1,))]
 
 
+Q_SHAPES = [("q_network.0.weight", (256, 383)), ("q_network.0.bias", (256,)), ("q_network.2.weight", (256,)), ("q_network.2.bias", (256,)),
+            ("q_network.3.weight", (256, 256)), ("q_network.3.bias", (256,)), ("q_network.5.weight", (256,)), ("q_network.5.bias", (256,)),
+            ("q_network.6.weight", (256, 256)), ("q_network.6.bias", (256,)), ("q_network.8.weight", (256,)), ("q_network.8.bias", (256,)),
+            ("q_network.9.weight", (1, 256)), ("q_network.9.bias", (1,))]  # q_net.cpp:8-27
+
+
 def pattern_params(shapes, base):
     out = {}
     for t, (name, shape) in enumerate(shapes):
         n = int(np.prod(shape))
         if len(shape) == 2:
             scale, off = F(2.0) / np.sqrt(F(shape[1])), F(0)
-        elif ".2." in name or ".5." in name:
+        elif ".2." in name or ".5." in name or ".8." in name:
             scale, off = F(0.2), F(1.0) if "weight" in name else F(0)
         else:
             scale, off = F(0.2), F(0)
@@ -85,6 +91,15 @@ def actor_forward(x, p):
 def critic_forward(x, p):
     h = trunk(x, p, "critic")
     return (h @ p["critic.6.weight"].T + p["critic.6.bias"]).astype(np.float32)
+
+
+def q_forward(x, a, p):
+    """QNetworkModule::forward (q_net.cpp:29-43): cat(state, action) -> 3 x (Linear, Mish, LayerNorm) -> Linear(256, 1)."""
+    h = np.concatenate([x, a], axis=-1).astype(np.float32)
+    for lin, ln in (("0", "2"), ("3", "5"), ("6", "8")):
+        h = (h @ p["q_network.%s.weight" % lin].T + p["q_network.%s.bias" % lin]).astype(np.float32)
+        h = layer_norm(mish(h), p["q_network.%s.weight" % ln], p["q_network.%s.bias" % ln])
+    return (h @ p["q_network.9.weight"].T + p["q_network.9.bias"]).astype(np.float32)
 
 
 # ---- truncated normal ---------------------------------------------------------------------------------

@@ -25,4 +25,8 @@ if [ -f "$HERE/ref_th.cpp" ]; then
   g++ $FLAGS "$HERE/ref_th.cpp" -L"$OUT" -levo_motion_networks -L"$T/lib" -ltorch_cpu -lc10 \
       -Wl,-rpath,"$OUT" -Wl,-rpath,"$T/lib" -o "$OUT/ref_th"
 fi
+if [ -f "$HERE/ref_sac.cpp" ]; then
+  g++ $FLAGS "$HERE/ref_sac.cpp" -L"$OUT" -levo_motion_networks -L"$T/lib" -ltorch_cpu -lc10 \
+      -Wl,-rpath,"$OUT" -Wl,-rpath,"$T/lib" -o "$OUT/ref_sac"
+fi
 echo "reference build ok: $OUT"
