@@ -66,6 +66,14 @@ def _load():
     lib.evm_policy_forward.argtypes = [vp, ctypes.c_int, vp, vp, ctypes.c_uint64, vp, vp, vp, vp, vp, vp]
     lib.evm_policy_timing_begin.argtypes = [vp]
     lib.evm_policy_timing_end.argtypes = [vp, vp, fp, ip]
+    lib.evm_replay_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(vp)]
+    lib.evm_replay_destroy.argtypes = [vp]
+    lib.evm_replay_destroy.restype = None
+    lib.evm_replay_push.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.evm_replay_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_longlong), vp]
+    lib.evm_replay_sample.argtypes = [vp, ctypes.c_int, ctypes.c_uint64, vp, vp, vp, vp, vp, vp, vp]
+    lib.evm_replay_timing_begin.argtypes = [vp]
+    lib.evm_replay_timing_end.argtypes = [vp, vp, fp, ip, fp, ip]
     lib.evm_env_timing_begin.argtypes = [vp, vp]
     lib.evm_env_timing_end.argtypes = [vp, vp, fp, ip]
     return lib

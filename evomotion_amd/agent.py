@@ -246,9 +246,16 @@ class FusedActorCritic:
         check(lib.evm_policy_timing_end(self._h, stream, ctypes.byref(ms), ctypes.byref(n)))
         return ms.value, n.value
 
+    def set_actor(self, actor):
+        """Actor weights only (SAC has no state-value critic); the critic slot keeps whatever it holds."""
+        n_a, n_c = ctypes.c_size_t(), ctypes.c_size_t()
+        check(lib.evm_policy_param_counts(self._h, ctypes.byref(n_a), ctypes.byref(n_c)))
+        self.set_weights(flat_parameters(actor).numpy(), getattr(self, "_critic_flat", np.zeros(n_c.value, np.float32)))
+
     def set_weights(self, actor_flat, critic_flat):
         a = np.ascontiguousarray(actor_flat, np.float32)
         c = np.ascontiguousarray(critic_flat, np.float32)
+        self._critic_flat = c
         fp = ctypes.POINTER(ctypes.c_float)
         check(lib.evm_policy_set_weights(self._h, a.ctypes.data_as(fp), a.size, c.ctypes.data_as(fp), c.size))
 
@@ -262,12 +269,13 @@ class FusedActorCritic:
         self.set_weights(torch.cat([t.reshape(-1).float() for t in a.values()]).numpy(),
                          torch.cat([t.reshape(-1).float() for t in c.values()]).numpy())
 
-    def forward(self, obs, uniform=None, seed=0, want_dist=False):
+    def forward(self, obs, uniform=None, seed=0, want_dist=False, actor_only=False):
+        """actor_only: the critic network is not run and `value` is None (SoftActorCriticAgent::act)."""
         n = obs.shape[0]
         assert obs.is_cuda and obs.dtype == torch.float32 and obs.is_contiguous() and obs.shape[1] == self.S
         action = torch.empty(n, self.A, device=self.device)
         logp = torch.empty(n, self.A, device=self.device)
-        value = torch.empty(n, device=self.device)
+        value = None if actor_only else torch.empty(n, device=self.device)
         mu = torch.empty(n, self.A, device=self.device) if want_dist else None
         sigma = torch.empty(n, self.A, device=self.device) if want_dist else None
         stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)

@@ -127,7 +127,7 @@ int evm_policy_set_weights(EvmPolicy *p, const float *h_actor, size_t n_actor, c
 
 int evm_policy_forward(EvmPolicy *p, int n, const float *d_obs, const float *d_uniform, uint64_t seed, float *d_action,
                        float *d_logp, float *d_value, float *d_mu, float *d_sigma, void *stream) {
-    if (!p || !d_obs || !d_action || !d_logp || !d_value) return pfail(EVM_E_INVALID, "null argument");
+    if (!p || !d_obs || !d_action || !d_logp) return pfail(EVM_E_INVALID, "null argument");  // d_value may be NULL: actor only
     if (n < 1) return pfail(EVM_E_INVALID, "n must be >= 1");
     hipStream_t s = (hipStream_t) stream;
     if (p->timing) {

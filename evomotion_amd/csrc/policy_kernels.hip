@@ -304,7 +304,7 @@ hipError_t launch_policy_forward(const PolicyDev &p, int n, const float *obs, co
         if (e != hipSuccess) return e;
         attr = true;
     }
-    dim3 grid((n + TM - 1) / TM, 2);
+    dim3 grid((n + TM - 1) / TM, value ? 2 : 1);  // value == NULL: the critic network is not run (SAC's act)
     hipLaunchKernelGGL(k_policy_forward, grid, dim3(PT), policy_lds_bytes(), s, p, n, obs, uniform, seed, counter, action,
                        logp, value, mu, sigma);
     return hipGetLastError();

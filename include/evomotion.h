@@ -143,12 +143,39 @@ int evm_policy_set_weights(EvmPolicy *p, const float *h_actor, size_t n_actor, c
 /* (mu, sigma) = actor(obs); action = truncated_normal_sample(mu, sigma, -1, 1); logp = truncated_normal_log_pdf;
  * value = critic(obs).  d_uniform [n, A] supplies the U[0,1) draws the reference takes from at::rand (pass NULL to
  * use the built-in counter-based generator keyed by seed and an internal call counter).
- * d_action, d_logp [n, A]; d_value [n]; d_mu, d_sigma [n, A] optional (may be NULL). */
+ * d_action, d_logp [n, A]; d_value [n]; d_mu, d_sigma [n, A] optional (may be NULL).  d_value == NULL runs the actor
+ * only (SoftActorCriticAgent::act, soft_actor_critic.cpp:47-52). */
 int evm_policy_forward(EvmPolicy *p, int n, const float *d_obs, const float *d_uniform, uint64_t seed, float *d_action,
                        float *d_logp, float *d_value, float *d_mu, float *d_sigma, void *stream);
 
 int evm_policy_timing_begin(EvmPolicy *p);
 int evm_policy_timing_end(EvmPolicy *p, void *stream, float *ms_total, int *n_launches);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Replay memory of the SAC rows: ReplayBuffer add / update_last / sample for N environments at once
+ * (evo_motion_networks/src/replay_buffer.cpp:16-52,146-153; used by soft_actor_critic.cpp:47-91).
+ * Device-resident ring of `capacity_slots` rollout steps; slot t holds, for every env, the state the agent acted
+ * on, its action and what the env returned (reward, done, valid code of evm_env_step_autoreset).  The next state of
+ * a transition is the state of the following slot (for the newest slot: the last next_state pushed), so every
+ * observation is stored once.  The oldest slot is evicted first (replay_buffer.cpp:31-35).
+ * ------------------------------------------------------------------------------------------------------- */
+typedef struct EvmReplay EvmReplay;
+int evm_replay_create(int capacity_slots, int n_envs, int state_dim, int action_dim, int device, EvmReplay **out);
+void evm_replay_destroy(EvmReplay *rb);
+/* add + update_last for all envs: rows with d_valid != 1 (settle calls, reset()'s own emission) are kept in the
+ * slot but are never sampled.  d_valid == NULL: every row is a transition. */
+int evm_replay_push(EvmReplay *rb, const float *d_state, const float *d_action, const float *d_reward,
+                    const uint8_t *d_done, const uint8_t *d_valid, const float *d_next_state, void *stream);
+/* h_out[0] = stored transitions (valid rows in live slots), h_out[1] = live slots, h_out[2] = pushes so far (sync). */
+int evm_replay_stats(EvmReplay *rb, long long *h_out /* [3] */, void *stream);
+/* `batch` distinct transitions drawn uniformly from the stored ones (std::shuffle + first batch_size,
+ * replay_buffer.cpp:18-28; the draw is a keyed permutation of the stored-transition ranks).  If fewer than `batch`
+ * are stored the ranks wrap around.  Outputs [batch, S], [batch, A], [batch], [batch], [batch, S] f32.
+ * d_index (optional) [batch, 2] i32 = (slot, env) of each draw. */
+int evm_replay_sample(EvmReplay *rb, int batch, uint64_t seed, float *d_states, float *d_actions, float *d_rewards,
+                      float *d_done, float *d_next_states, int *d_index, void *stream);
+int evm_replay_timing_begin(EvmReplay *rb);
+int evm_replay_timing_end(EvmReplay *rb, void *stream, float *ms_push, int *n_push, float *ms_sample, int *n_sample);
 
 #ifdef __cplusplus
 }

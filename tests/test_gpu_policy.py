@@ -142,6 +142,20 @@ def test_weights_from_th_checkpoints(fused, tmp_path):
         assert torch.equal(r, o)
 
 
+def test_actor_only_forward_is_the_same_actor(fused):
+    """d_value == NULL (SoftActorCriticAgent::act): the critic workgroups are not launched, the actor outputs are unchanged."""
+    import torch
+    f, pa, pc = fused
+    g = torch.Generator(device="cpu").manual_seed(21)
+    x = (torch.rand(333, 371, generator=g) * 2 - 1).cuda()
+    u = torch.rand(333, 12, generator=g).cuda()
+    a0, l0, v0, m0, s0 = f.forward(x, uniform=u, want_dist=True)
+    a1, l1, v1, m1, s1 = f.forward(x, uniform=u, want_dist=True, actor_only=True)
+    assert v1 is None
+    for r, o in ((a0, a1), (l0, l1), (m0, m1), (s0, s1)):
+        assert torch.equal(r, o)
+
+
 def test_rollout_and_update_smoke():
     import torch
     from evomotion_amd import VecPpoGaeAgent, VecRobotWalk
