@@ -89,7 +89,7 @@ def test_full_size_round_trip_properties():
 def test_errors():
     from evomotion_amd import EvmError
     from evomotion_amd.replay import ReplayRing
-    with pytest.raises(EvmError):
+    with pytest.raises(ValueError):  # EVM_E_INVALID <-> std::invalid_argument
         ReplayRing(0, 4, 3, 1)
     ring = ReplayRing(2, 4, 3, 1)
     with pytest.raises(EvmError):
