@@ -57,9 +57,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=256)
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mode", choices=["dynamics", "ppo"], default="dynamics",
+    ap.add_argument("--mode", choices=["dynamics", "ppo", "sac"], default="dynamics",
                     help="dynamics = BASELINE configs[1] (random actions, headline); ppo = configs[2]/[3]: fused MFMA "
-                         "actor-critic forward inside the rollout, PPO update every --horizon steps")
+                         "actor-critic forward inside the rollout, PPO update every --horizon steps; sac = configs[4]: fused "
+                         "actor forward + device replay ring (replay_buffer_size 1024 slots), SAC update every --train-every steps")
+    ap.add_argument("--train-every", type=int, default=4)
+    ap.add_argument("--sac-batch", type=int, default=4096)
+    ap.add_argument("--replay-slots", type=int, default=1024)
     ap.add_argument("--horizon", type=int, default=32)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                     "the N>1 path with several ranks on ONE GPU)")
@@ -106,7 +110,17 @@ def main():
         agent = VecPpoGaeAgent(1234, [env.state_dim], [env.action_dim], hidden_size=256, device=local_rank,
                                horizon=args.horizon, epoch=8, learning_rate=1e-3)
 
+    sac = None
+    if args.mode == "sac":
+        from evomotion_amd import VecSacAgent
+        sac = VecSacAgent(1234, [env.state_dim], [env.action_dim], batch_size=args.sac_batch, epoch=1, learning_rate=1e-3,
+                          replay_buffer_size=args.replay_slots, train_every=args.train_every, n_envs=n, device=local_rank)
+
     def run(k_steps, offset=0):
+        if sac is not None:
+            for i in range(k_steps):
+                sac.step(env, train=not args.no_update)
+            return
         if agent is None:
             for i in range(k_steps):
                 env.step_autoreset(actions[(offset + i) % bank])
@@ -124,10 +138,14 @@ def main():
     env.timing_begin()
     if agent is not None:
         agent.fused.timing_begin()
+    if sac is not None:
+        sac.fused.timing_begin()
+        sac.replay.timing_begin()
     t0 = time.perf_counter()
     run(args.steps, args.warmup)
     ms_kernel, n_launch = env.timing_end()
-    ms_policy, n_policy = agent.fused.timing_end() if agent is not None else (0.0, 0)
+    ms_policy, n_policy = agent.fused.timing_end() if agent is not None else (sac.fused.timing_end() if sac is not None else (0.0, 0))
+    rp = sac.replay.timing_end() if sac is not None else None
     barrier()
     t1 = time.perf_counter()
     if agent is not None:
@@ -160,7 +178,10 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": ("robot_walk, %d envs/GPU on %d MI355X, HIP dynamics only, uniform random actions, "
+                "workload": ("robot_walk, %d envs/GPU on %d MI355X, SAC: fused MFMA actor forward, device replay ring of %d "
+                             "slots, %s (configs[4])" % (n, world, args.replay_slots, "rollout + ring only" if args.no_update else
+                              "PyTorch-ROCm SAC update (batch %d) every %d steps" % (args.sac_batch, args.train_every))) if sac is not None else
+                            ("robot_walk, %d envs/GPU on %d MI355X, HIP dynamics only, uniform random actions, "
                              "rollout form with in-band reset (configs[1])" % (n, world)) if agent is None else
                             ("robot_walk, %d envs/GPU on %d MI355X, PPO hidden_size=256, fused MFMA actor-critic forward "
                              "in the rollout, horizon %d, %s (configs[2])" % (n, world, args.horizon,
@@ -180,6 +201,27 @@ def main():
                         "records overflow the 4 MB L2 and are served by the Infinity Cache), see DESIGN.md" % n,
             },
         }
+        if sac is not None and n_policy:
+            pol_ms = ms_policy / n_policy
+            tf = 333312.0 * n / (pol_ms * 1e-3) / 1e12  # actor 333 312 GEMM FLOP per act
+            out["roofline_policy"] = {"bound": "mfma", "achieved": tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                      "frac": tf / VALU_PEAK_TFLOPS, "traffic": None, "kernel": "k_policy_forward (actor only)",
+                                      "launch_ms": pol_ms, "note": "fp32-input MFMA (v_mfma_f32_32x32x2_f32), dense fp32 matrix peak"}
+            # replay ring: pure byte movement.  push = one rollout step of all envs read + written once; sample = per drawn
+            # row state + next state + action + reward + done read and written once
+            S_, A_ = env.state_dim, env.action_dim
+            push_bytes = 2.0 * n * (2 * S_ + A_ + 2) * 4 + n * 2
+            out["roofline_replay_push"] = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "traffic": None,
+                                           "launch_ms": rp["ms_push"] / max(rp["n_push"], 1),
+                                           "achieved": push_bytes / (rp["ms_push"] / max(rp["n_push"], 1) * 1e-3) / 1e9,
+                                           "kernel": "k_replay_index + k_replay_copy"}
+            out["roofline_replay_push"]["frac"] = out["roofline_replay_push"]["achieved"] / HBM_PEAK_GBS
+            if rp["n_sample"]:
+                smp_bytes = 2.0 * args.sac_batch * (2 * S_ + A_ + 2) * 4
+                ms = rp["ms_sample"] / rp["n_sample"]
+                out["roofline_replay_sample"] = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "traffic": None, "launch_ms": ms,
+                                                 "achieved": smp_bytes / (ms * 1e-3) / 1e9, "frac": smp_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                 "kernel": "k_replay_plan + k_replay_gather"}
         if agent is not None and n_policy:
             pol_ms = ms_policy / n_policy
             tf = 654848.0 * n / (pol_ms * 1e-3) / 1e12  # 654 848 GEMM FLOP per act

@@ -8,3 +8,5 @@ from .env import RolloutStep, Step, VecRobotWalk  # noqa: F401
 from .agent import (ActorModule, CriticModule, FusedActorCritic, RandomAgent, VecPpoGaeAgent,  # noqa: F401,E402
                     ppo_train, gae_advantages, truncated_normal_log_pdf, truncated_normal_entropy, truncated_normal_sample)
 from .checkpoint import load_into, load_th, save_th  # noqa: F401,E402
+from .replay import ReplayRing  # noqa: F401,E402
+from .sac import EntropyParameter, QNetworkModule, VecSacAgent, sac_train  # noqa: F401,E402

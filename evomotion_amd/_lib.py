@@ -63,6 +63,7 @@ def _load():
     lib.evm_policy_destroy.restype = None
     lib.evm_policy_param_counts.argtypes = [vp, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]
     lib.evm_policy_set_weights.argtypes = [vp, fp, ctypes.c_size_t, fp, ctypes.c_size_t]
+    lib.evm_policy_set_weights_device.argtypes = [vp, vp, vp, vp]
     lib.evm_policy_forward.argtypes = [vp, ctypes.c_int, vp, vp, ctypes.c_uint64, vp, vp, vp, vp, vp, vp]
     lib.evm_policy_timing_begin.argtypes = [vp]
     lib.evm_policy_timing_end.argtypes = [vp, vp, fp, ip]

@@ -247,10 +247,8 @@ class FusedActorCritic:
         return ms.value, n.value
 
     def set_actor(self, actor):
-        """Actor weights only (SAC has no state-value critic); the critic slot keeps whatever it holds."""
-        n_a, n_c = ctypes.c_size_t(), ctypes.c_size_t()
-        check(lib.evm_policy_param_counts(self._h, ctypes.byref(n_a), ctypes.byref(n_c)))
-        self.set_weights(flat_parameters(actor).numpy(), getattr(self, "_critic_flat", np.zeros(n_c.value, np.float32)))
+        """Actor weights only (SAC has no state-value critic); device-side repack, no host round trip."""
+        self.load_modules(actor, None)
 
     def set_weights(self, actor_flat, critic_flat):
         a = np.ascontiguousarray(actor_flat, np.float32)
@@ -260,7 +258,13 @@ class FusedActorCritic:
         check(lib.evm_policy_set_weights(self._h, a.ctypes.data_as(fp), a.size, c.ctypes.data_as(fp), c.size))
 
     def load_modules(self, actor, critic):
-        self.set_weights(flat_parameters(actor).numpy(), flat_parameters(critic).numpy())
+        """Weights from (device) modules after an optimiser step: flattened and repacked on the device, asynchronously on
+        the current stream (evm_policy_set_weights_device)."""
+        flat = lambda m: None if m is None else torch.cat([p.detach().reshape(-1).float() for p in m.parameters()]).to(self.device).contiguous()
+        a, c = flat(actor), flat(critic)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        check(lib.evm_policy_set_weights_device(self._h, _ptr(a), _ptr(c), stream))
+        self._keep = (a, c)  # the kernel reads them asynchronously
 
     def load_th(self, actor_path, critic_path):
         """Weights from `*.th` checkpoints in the reference's format (saver.h:27-39), e.g. the reference's own files."""

@@ -19,6 +19,8 @@ struct PolicyDev {
 };
 
 size_t policy_lds_bytes();
+// device-side repack of one network's flat parameters (named_parameters order) into the kernel's operand layout
+hipError_t launch_policy_pack(const NetDev &n, int S, int A, bool actor, const float *flat, hipStream_t s);
 hipError_t launch_policy_forward(const PolicyDev &p, int n, const float *obs, const float *uniform, uint64_t seed,
                                  uint64_t counter, float *action, float *logp, float *value, float *mu, float *sigma,
                                  hipStream_t s);

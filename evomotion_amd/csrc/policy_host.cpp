@@ -125,6 +125,16 @@ int evm_policy_set_weights(EvmPolicy *p, const float *h_actor, size_t n_actor, c
     return EVM_OK;
 }
 
+int evm_policy_set_weights_device(EvmPolicy *p, const float *d_actor, const float *d_critic, void *stream) {
+    if (!p || (!d_actor && !d_critic)) return pfail(EVM_E_INVALID, "null argument");
+    hipStream_t s = (hipStream_t) stream;
+    hipError_t e = hipSuccess;
+    if (d_actor) e = evm::launch_policy_pack(p->dev.actor, p->S, p->A, true, d_actor, s);
+    if (e == hipSuccess && d_critic) e = evm::launch_policy_pack(p->dev.critic, p->S, p->A, false, d_critic, s);
+    if (e != hipSuccess) return pfail(EVM_E_HIP, std::string("weight repack: ") + hipGetErrorString(e));
+    return EVM_OK;
+}
+
 int evm_policy_forward(EvmPolicy *p, int n, const float *d_obs, const float *d_uniform, uint64_t seed, float *d_action,
                        float *d_logp, float *d_value, float *d_mu, float *d_sigma, void *stream) {
     if (!p || !d_obs || !d_action || !d_logp) return pfail(EVM_E_INVALID, "null argument");  // d_value may be NULL: actor only

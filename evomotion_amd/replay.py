@@ -45,9 +45,11 @@ class ReplayRing:
         check(lib.evm_replay_stats(self._h, out, self._stream()))
         return dict(transitions=int(out[0]), live_slots=int(out[1]), pushes=int(out[2]))
 
-    def sample(self, batch, seed, want_index=False):
+    def sample(self, batch, seed, want_index=False, out=None):
+        """`out` = (states, actions, rewards, done, next_states) to fill in place (static buffers of a captured update)."""
         z = lambda *s, **k: torch.empty(*s, device=self.device, **k)
-        states, actions, rewards, done, nxt = z(batch, self.S), z(batch, self.A), z(batch), z(batch), z(batch, self.S)
+        states, actions, rewards, done, nxt = out if out is not None else (z(batch, self.S), z(batch, self.A), z(batch), z(batch), z(batch, self.S))
+        assert states.shape == (batch, self.S) and nxt.shape == (batch, self.S) and states.is_contiguous() and nxt.is_contiguous()
         index = z(batch, 2, dtype=torch.int32) if want_index else None
         check(lib.evm_replay_sample(self._h, batch, ctypes.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), _ptr(states), _ptr(actions),
                                     _ptr(rewards), _ptr(done), _ptr(nxt), _ptr(index), self._stream()))

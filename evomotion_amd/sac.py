@@ -95,3 +95,105 @@ def sac_train(actor, critic_1, critic_2, target_critic_1, target_critic_2, entro
     soft_update(target_critic_1, critic_1, tau)
     soft_update(target_critic_2, critic_2, tau)
     return dict(actor=loss_actor.detach(), critic_1=loss_c1.detach(), critic_2=loss_c2.detach(), entropy=loss_entropy.detach())
+
+
+class VecSacAgent:
+    """Vectorised SoftActorCriticAgent: one act() for all N envs (fused HIP actor forward), a device replay ring, and the
+    reference's train() on batches drawn from it.  Parameter names follow agent_factory.cpp:112-119.
+
+    `replay_buffer_size` counts rollout steps (ring slots of N envs each); `train_every` counts rollout steps, like the
+    reference's global step counter (soft_actor_critic.cpp:64-65)."""
+
+    def __init__(self, seed, state_space, action_space, actor_hidden_size=256, critic_hidden_size=256, batch_size=256,
+                 epoch=1, learning_rate=1e-3, gamma=0.99, tau=0.005, replay_buffer_size=1024, train_every=4, n_envs=4096,
+                 device=0, use_graph=True):
+        from .agent import FusedActorCritic, _all_reduce_grads
+        from .replay import ReplayRing
+        torch.manual_seed(seed)
+        self.device = torch.device("cuda", device)
+        mk_q = lambda: QNetworkModule(state_space, action_space, critic_hidden_size).to(self.device)
+        self.actor = ActorModule(state_space, action_space, actor_hidden_size).to(self.device)
+        self.critic_1, self.critic_2, self.target_critic_1, self.target_critic_2 = mk_q(), mk_q(), mk_q(), mk_q()
+        self.entropy = EntropyParameter(1.0, 1).to(self.device)
+        hard_update(self.target_critic_1, self.critic_1)
+        hard_update(self.target_critic_2, self.critic_2)
+        # the update is ~10^3 small launches; it is captured once into a HIP graph and replayed (capturable Adam keeps
+        # its step counters on the device).  Data-parallel runs keep eager mode: the gradient all-reduce sits between
+        # backward and step.
+        self.use_graph = use_graph and not (torch.distributed.is_available() and torch.distributed.is_initialized()
+                                            and torch.distributed.get_world_size() > 1)
+        adam = lambda m: torch.optim.Adam(m.parameters(), lr=learning_rate, capturable=self.use_graph)
+        self.actor_opt, self.critic_1_opt, self.critic_2_opt, self.entropy_opt = adam(self.actor), adam(self.critic_1), adam(self.critic_2), adam(self.entropy)
+        self.target_entropy = -float(action_space[0])
+        self.gamma, self.tau, self.batch_size, self.epoch, self.train_every = gamma, tau, batch_size, epoch, train_every
+        self.fused = FusedActorCritic(state_space[0], action_space[0], actor_hidden_size, device)
+        self.fused.set_actor(self.actor)
+        self.replay = ReplayRing(replay_buffer_size, n_envs, state_space[0], action_space[0], device)
+        self._prev = torch.empty(n_envs, state_space[0], device=self.device)
+        self.seed, self.global_step, self.train_steps = seed, 0, 0
+        self._grad_hook = _all_reduce_grads
+        self.last_losses = None
+        self._graph = None
+        B, S, A = batch_size, state_space[0], action_space[0]
+        z = lambda *sh: torch.zeros(*sh, device=self.device)
+        self._batch = (z(B, S), z(B, A), z(B), z(B), z(B, S))
+
+    def count_parameters(self):
+        from .agent import count_parameters
+        return count_parameters(self.actor, self.critic_1, self.critic_2, self.target_critic_1, self.target_critic_2, self.entropy)
+
+    def step(self, env, train=True):
+        """act() + do_step + replay add/update_last + check_train() for all envs (soft_actor_critic.cpp:47-91)."""
+        self._prev.copy_(env.obs)
+        action, _, _ = self.fused.forward(self._prev, seed=self.seed, actor_only=True)
+        st = env.step_autoreset(action)
+        self.replay.push(self._prev, action, st.reward, st.done, st.valid, st.state)
+        if train and self.global_step % self.train_every == self.train_every - 1:
+            self.update()
+        self.global_step += 1
+        return st
+
+    def _train_once(self):
+        s, a, r, d, n = self._batch
+        return sac_train(self.actor, self.critic_1, self.critic_2, self.target_critic_1, self.target_critic_2, self.entropy,
+                         self.actor_opt, self.critic_1_opt, self.critic_2_opt, self.entropy_opt, s, a, r.unsqueeze(-1),
+                         d.unsqueeze(-1), n, self.gamma, self.tau, self.target_entropy,
+                         grad_hook=None if self.use_graph else self._grad_hook)
+
+    def update(self):
+        for e in range(self.epoch):
+            self.replay.sample(self.batch_size, seed=(self.seed << 32) ^ (self.train_steps * 1000003 + e), out=self._batch)
+            if not self.use_graph:
+                self.last_losses = self._train_once()
+            elif self._graph is None:
+                # warm-up on a side stream (allocator, optimiser state), then capture one train() call
+                side = torch.cuda.Stream(self.device)
+                side.wait_stream(torch.cuda.current_stream(self.device))
+                with torch.cuda.stream(side):
+                    for _ in range(2):
+                        self._train_once()
+                torch.cuda.current_stream(self.device).wait_stream(side)
+                self._graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self._graph):
+                    self.last_losses = self._train_once()
+                self.train_steps += 2
+            else:
+                self._graph.replay()
+            self.train_steps += 1
+        self.fused.set_actor(self.actor)
+
+    def save(self, folder):
+        """SoftActorCriticAgent::save (soft_actor_critic.cpp:181-201): module archives in the reference's format."""
+        import os
+        from .checkpoint import save_th
+        for m, f in ((self.actor, "actor.th"), (self.critic_1, "critic_1.th"), (self.target_critic_1, "target_critic_1.th"),
+                     (self.critic_2, "critic_2.th"), (self.target_critic_2, "target_critic_2.th"), (self.entropy, "entropy.th")):
+            save_th(m, os.path.join(folder, f))
+
+    def load(self, folder):
+        import os
+        from .checkpoint import load_into
+        for m, f in ((self.actor, "actor.th"), (self.critic_1, "critic_1.th"), (self.target_critic_1, "target_critic_1.th"),
+                     (self.critic_2, "critic_2.th"), (self.target_critic_2, "target_critic_2.th"), (self.entropy, "entropy.th")):
+            load_into(m, os.path.join(folder, f))
+        self.fused.set_actor(self.actor)

@@ -140,6 +140,9 @@ void evm_policy_destroy(EvmPolicy *p);
 int evm_policy_param_counts(const EvmPolicy *p, size_t *n_actor, size_t *n_critic); /* 168216 / 162305 */
 /* Flat fp32 parameters in the reference's named_parameters() order (weights [out,in] row major). */
 int evm_policy_set_weights(EvmPolicy *p, const float *h_actor, size_t n_actor, const float *h_critic, size_t n_critic);
+/* The same from DEVICE buffers, asynchronous on `stream` (no host round trip after an optimiser step); either pointer may
+ * be NULL to leave that network unchanged. */
+int evm_policy_set_weights_device(EvmPolicy *p, const float *d_actor, const float *d_critic, void *stream);
 /* (mu, sigma) = actor(obs); action = truncated_normal_sample(mu, sigma, -1, 1); logp = truncated_normal_log_pdf;
  * value = critic(obs).  d_uniform [n, A] supplies the U[0,1) draws the reference takes from at::rand (pass NULL to
  * use the built-in counter-based generator keyed by seed and an internal call counter).
