@@ -175,6 +175,17 @@ def _all_reduce_grads(params):
         o += n
 
 
+def _all_reduce_grads_mean(params):
+    """Losses that are local means (SAC, soft_actor_critic.cpp:127-153): equal shards per rank, so the global-mean
+    gradient is the rank average."""
+    if not _dist_ready():
+        return
+    _all_reduce_grads(params)
+    w = torch.distributed.get_world_size()
+    for p in params:
+        p.grad.div_(w)
+
+
 def ppo_train(actor, critic, actor_opt, critic_opt, states, actions, rewards, done, log_prob, curr_values, next_values,
               gamma, lam, epsilon, entropy_factor, critic_loss_factor, epoch, clip_grad_norm, mask=None):
     """One PpoGaeAgent::train() call on padded [B,T,*] tensors; returns the last (actor_loss, critic_loss)."""

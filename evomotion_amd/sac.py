@@ -107,7 +107,7 @@ class VecSacAgent:
     def __init__(self, seed, state_space, action_space, actor_hidden_size=256, critic_hidden_size=256, batch_size=256,
                  epoch=1, learning_rate=1e-3, gamma=0.99, tau=0.005, replay_buffer_size=1024, train_every=4, n_envs=4096,
                  device=0, use_graph=True):
-        from .agent import FusedActorCritic, _all_reduce_grads
+        from .agent import FusedActorCritic, _all_reduce_grads_mean
         from .replay import ReplayRing
         torch.manual_seed(seed)
         self.device = torch.device("cuda", device)
@@ -131,7 +131,7 @@ class VecSacAgent:
         self.replay = ReplayRing(replay_buffer_size, n_envs, state_space[0], action_space[0], device)
         self._prev = torch.empty(n_envs, state_space[0], device=self.device)
         self.seed, self.global_step, self.train_steps = seed, 0, 0
-        self._grad_hook = _all_reduce_grads
+        self._grad_hook = _all_reduce_grads_mean
         self.last_losses = None
         self._graph = None
         B, S, A = batch_size, state_space[0], action_space[0]
