@@ -284,13 +284,21 @@ class FusedActorCritic:
         self.set_weights(torch.cat([t.reshape(-1).float() for t in a.values()]).numpy(),
                          torch.cat([t.reshape(-1).float() for t in c.values()]).numpy())
 
-    def forward(self, obs, uniform=None, seed=0, want_dist=False, actor_only=False):
-        """actor_only: the critic network is not run and `value` is None (SoftActorCriticAgent::act)."""
+    def forward(self, obs, uniform=None, seed=0, want_dist=False, actor_only=False, out=None):
+        """actor_only: the critic network is not run and `value` is None (SoftActorCriticAgent::act).
+        out = (action [n, A], logp [n, A], value [n] or None): contiguous tensors the kernel writes directly."""
         n = obs.shape[0]
         assert obs.is_cuda and obs.dtype == torch.float32 and obs.is_contiguous() and obs.shape[1] == self.S
-        action = torch.empty(n, self.A, device=self.device)
-        logp = torch.empty(n, self.A, device=self.device)
-        value = None if actor_only else torch.empty(n, device=self.device)
+        if out is not None:
+            action, logp, value = out
+            assert action.is_contiguous() and logp.is_contiguous() and tuple(action.shape) == tuple(logp.shape) == (n, self.A)
+            assert value is None or (value.is_contiguous() and value.numel() == n)
+            if actor_only:
+                value = None
+        else:
+            action = torch.empty(n, self.A, device=self.device)
+            logp = torch.empty(n, self.A, device=self.device)
+            value = None if actor_only else torch.empty(n, device=self.device)
         mu = torch.empty(n, self.A, device=self.device) if want_dist else None
         sigma = torch.empty(n, self.A, device=self.device) if want_dist else None
         stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -364,19 +372,18 @@ class VecPpoGaeAgent:
         if self._buf is None:
             z = lambda *s, **k: torch.zeros(*s, device=self.device, **k)
             self._buf = dict(states=z(T, N, S), actions=z(T, N, A), logp=z(T, N, A), values=z(T, N), rewards=z(T, N),
-                             done=z(T, N), valid=z(T, N), next_values=z(T, N))
+                             done=z(T, N), valid=z(T, N), next_values=z(T, N), done_u8=z(T, N, dtype=torch.uint8),
+                             valid_u8=z(T, N, dtype=torch.uint8), scratch=(z(N, A), z(N, A), z(N)))
         b = self._buf
         obs = env.obs
         for t in range(T):
+            # two launches and one copy per step: the kernels write straight into the rows of the rollout buffer
             b["states"][t].copy_(obs)
-            action, logp, value = self.fused.forward(obs, seed=self.seed)
-            b["actions"][t], b["logp"][t], b["values"][t] = action, logp, value
-            st = env.step_autoreset(action)
-            b["rewards"][t].copy_(st.reward)
-            b["done"][t].copy_(st.done.float())
-            b["valid"][t].copy_(st.valid.float())
-            obs = st.state
-        _, _, last_v = self.fused.forward(obs, seed=self.seed)
+            self.fused.forward(obs, seed=self.seed, out=(b["actions"][t], b["logp"][t], b["values"][t]))
+            env.step_autoreset(b["actions"][t], reward_out=b["rewards"][t], done_out=b["done_u8"][t], valid_out=b["valid_u8"][t])
+        b["done"].copy_(b["done_u8"])
+        b["valid"].copy_(b["valid_u8"])
+        _, _, last_v = self.fused.forward(obs, seed=self.seed, out=b["scratch"])
         b["next_values"][:-1] = b["values"][1:]
         b["next_values"][-1] = last_v
         return b

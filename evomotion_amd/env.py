@@ -99,11 +99,17 @@ class VecRobotWalk:
         check(lib.evm_env_step(self._h, _ptr(action), _ptr(self.obs), _ptr(self.reward), _ptr(self.done), self._stream()))
         return Step(self.obs, self.reward, self.done)
 
-    def step_autoreset(self, action):
+    def step_autoreset(self, action, reward_out=None, done_out=None, valid_out=None):
+        """`*_out`: contiguous [n_envs] device tensors (f32 / u8 / u8), e.g. rows of a rollout buffer, written directly by
+        the kernel instead of the env's own buffers (no copies in the rollout loop)."""
         action = self._action(action)
-        check(lib.evm_env_step_autoreset(self._h, _ptr(action), _ptr(self.obs), _ptr(self.reward), _ptr(self.done),
-                                         _ptr(self.valid), self._stream()))
-        return RolloutStep(self.obs, self.reward, self.done, self.valid)
+        r = self.reward if reward_out is None else reward_out
+        d = self.done if done_out is None else done_out
+        v = self.valid if valid_out is None else valid_out
+        assert r.dtype == torch.float32 and d.dtype == torch.uint8 and v.dtype == torch.uint8
+        assert r.is_contiguous() and d.is_contiguous() and v.is_contiguous() and r.numel() == d.numel() == v.numel() == self.n_envs
+        check(lib.evm_env_step_autoreset(self._h, _ptr(action), _ptr(self.obs), _ptr(r), _ptr(d), _ptr(v), self._stream()))
+        return RolloutStep(self.obs, r, d, v)
 
     # -- parity / checkpoint hooks ---------------------------------------------------------------
     def body_poses(self):

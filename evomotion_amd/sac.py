@@ -130,6 +130,7 @@ class VecSacAgent:
         self.fused.set_actor(self.actor)
         self.replay = ReplayRing(replay_buffer_size, n_envs, state_space[0], action_space[0], device)
         self._prev = torch.empty(n_envs, state_space[0], device=self.device)
+        self._act = (torch.empty(n_envs, action_space[0], device=self.device), torch.empty(n_envs, action_space[0], device=self.device), None)
         self.seed, self.global_step, self.train_steps = seed, 0, 0
         self._grad_hook = _all_reduce_grads_mean
         self.last_losses = None
@@ -145,7 +146,7 @@ class VecSacAgent:
     def step(self, env, train=True):
         """act() + do_step + replay add/update_last + check_train() for all envs (soft_actor_critic.cpp:47-91)."""
         self._prev.copy_(env.obs)
-        action, _, _ = self.fused.forward(self._prev, seed=self.seed, actor_only=True)
+        action, _, _ = self.fused.forward(self._prev, seed=self.seed, actor_only=True, out=self._act)
         st = env.step_autoreset(action)
         self.replay.push(self._prev, action, st.reward, st.done, st.valid, st.state)
         if train and self.global_step % self.train_every == self.train_every - 1:
