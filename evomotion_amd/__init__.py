@@ -4,7 +4,7 @@ Product code: HIP kernels and the C ABI in csrc/ (libevomotion_hip.so), host mir
 Environment / Agent interfaces in env.py / agent.py.  The CPU oracle under /oracle is test infrastructure
 and is never imported from here."""
 from ._lib import DEFAULT_SKELETON, EvmError, LIB_PATH  # noqa: F401
-from .env import RolloutStep, Step, VecRobotWalk  # noqa: F401
+from .env import RolloutStep, Step, VecRobotJump, VecRobotWalk, get_environment  # noqa: F401
 from .agent import (ActorModule, CriticModule, FusedActorCritic, RandomAgent, VecPpoGaeAgent,  # noqa: F401,E402
                     ppo_train, gae_advantages, truncated_normal_log_pdf, truncated_normal_entropy, truncated_normal_sample)
 from .checkpoint import load_into, load_th, save_th  # noqa: F401,E402

@@ -19,6 +19,7 @@ class EvmEnvParams(ctypes.Structure):
         ("target_velocity", ctypes.c_float),
         ("minimal_velocity", ctypes.c_float),
         ("reset_frames", ctypes.c_int),
+        ("env_kind", ctypes.c_int),
     ]
 
 
@@ -37,6 +38,7 @@ def _load():
     ip = ctypes.POINTER(ctypes.c_int)
     lib.evm_last_error.restype = cp
     lib.evm_env_default_params.argtypes = [ctypes.POINTER(EvmEnvParams)]
+    lib.evm_env_default_params_for.argtypes = [cp, ctypes.POINTER(EvmEnvParams)]
     lib.evm_env_create.argtypes = [cp, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, ctypes.POINTER(EvmEnvParams), ctypes.POINTER(vp)]
     lib.evm_env_destroy.argtypes = [vp]
     lib.evm_env_destroy.restype = None
@@ -54,6 +56,7 @@ def _load():
     lib.evm_env_get_body_constants.argtypes = [vp, fp]
     lib.evm_env_get_diagnostics.argtypes = [vp, vp, vp]
     lib.evm_skeleton_probe.argtypes = [cp, ip, fp]
+    lib.evm_skeleton_digest.argtypes = [cp, ctypes.POINTER(ctypes.c_ulonglong)]
     lib.evm_skeleton_schedule.argtypes = [cp, ip, ip, ip, ctypes.c_int]
     lib.evm_env_get_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_longlong)]
     lib.evm_env_clear_stats.argtypes = [vp]

@@ -67,6 +67,20 @@ void evm_env_default_params(EvmEnvParams *p) {
     p->target_velocity = 0.5f;
     p->minimal_velocity = 0.1f;
     p->reset_frames = 30;
+    p->env_kind = 0;
+}
+
+int evm_env_default_params_for(const char *env_name, EvmEnvParams *p) {
+    if (!env_name || !p) return fail(EVM_E_INVALID, "null argument");
+    evm_env_default_params(p);
+    const std::string n = env_name;
+    if (n == "robot_walk") return EVM_OK;
+    if (n == "robot_jump") {  // RobotJumpFactory defaults, env_factory.cpp:91-100
+        p->env_kind = 1;
+        p->reset_frames = (int) ((1.f / 6.f) / (1.f / 60.f));  // static_cast<int>(reset_seconds / DELTA_T_MODEL) = 10
+        return EVM_OK;
+    }
+    return fail(EVM_E_INVALID, n);  // std::invalid_argument(env_name), env_factory.cpp:118
 }
 
 int evm_env_create(const char *skeleton_path, int n_envs, int device, uint64_t seed, const EvmEnvParams *params,
@@ -178,7 +192,7 @@ int evm_env_reset(EvmEnv *env, const uint8_t *d_mask, float *d_obs, float *d_rew
     int rc = ensure_skeleton(env, s);
     if (rc != EVM_OK) return rc;
     HIP_TRY(evm::launch_repose(env->d, d_mask, s));
-    const int settle = 2 * env->prm.reset_frames;
+    const int settle = env->skel.settle_steps;
     for (int i = 0; i < settle; i++) {
         const bool last = i == settle - 1;
         rc = step_launch(env, last ? 2 : 0, nullptr, d_obs, d_reward, d_done, nullptr, d_mask, s);
@@ -242,6 +256,24 @@ int evm_skeleton_probe(const char *skeleton_path, int *counts /* nb nm nh nf nmu
     }
     if (out) body_constants(*S, out);
     delete S;
+    return EVM_OK;
+}
+
+// Host-only: FNV-1a digest of everything the loader derived (the whole constant block the kernels read) — two input
+// formats describing the same skeleton must give the same digest.
+int evm_skeleton_digest(const char *skeleton_path, unsigned long long *h_out) {
+    if (!h_out) return fail(EVM_E_INVALID, "h_out is null");
+    EvmEnvParams prm;
+    evm_env_default_params(&prm);
+    EvmSkelC *S = new EvmSkelC();
+    std::string err;
+    int rc = evm::load_skeleton_constants(skeleton_path, prm, *S, err);
+    if (rc != EVM_OK) { delete S; return fail(rc, err); }
+    unsigned long long h = 1469598103934665603ull;
+    const unsigned char *b = reinterpret_cast<const unsigned char *>(S);
+    for (size_t i = 0; i < sizeof(EvmSkelC); i++) { h ^= b[i]; h *= 1099511628211ull; }
+    delete S;
+    *h_out = h;
     return EVM_OK;
 }
 

@@ -1105,7 +1105,7 @@ DEV float mt_uniform01(const Ctx &c) {
 
 // RobotWalk::reset_engine up to the settle steps (robot_walk.cpp:76-96, item.cpp:77-86)
 DEV void repose(const Ctx &c) {
-    const float angle_limit = (float) 3.14159265358979323846 * 2.f / 3.f;
+    const float angle_limit = c_skel.reset_angle_limit;
     const float half = angle_limit / 2.f;
     const float yaw = xs_(xm(mt_uniform01(c), angle_limit), half);
     const float roll = xs_(xm(mt_uniform01(c), angle_limit), half);
@@ -1202,12 +1202,13 @@ DEV void observe(const Ctx &c, float *obs, float *reward, uint8_t *done) {
         o[k + 3] = SC(c_skel.sc_mobs + 4 * mi + 3);
     }
     if (c.wave != 0) return;
-    const float vz = GS(lin, 3 * root + 2);
+    // robot_walk.cpp:61-68: the root's z velocity; robot_jump.cpp:71-80: max(vy, 0) + vz and a strict fail test
+    const float vz = c_skel.env_kind == 1 ? fmaxf(GS(lin, 3 * root + 1), 0.f) + GS(lin, 3 * root + 2) : GS(lin, 3 * root + 2);
     int remaining = c.d.remaining[c.env], cs = c.d.curr_step[c.env];
     if (vz < c_skel.min_vel) remaining -= 1;
     else if (vz >= c_skel.target_vel) remaining += 1;
     const bool win = cs >= c_skel.max_steps;
-    const bool fail = remaining <= 0;
+    const bool fail = c_skel.env_kind == 1 ? remaining < 0 : remaining <= 0;
     c.d.remaining[c.env] = remaining;
     c.d.curr_step[c.env] = cs + 1;
     reward[c.env] = vz;
@@ -1554,7 +1555,7 @@ __global__ __launch_bounds__(64 * EVM_NW) void k_env_step(EnvDev d, const float 
         if (lead && (d.flags[c.env] & EVM_FLAG_DONE)) {
             repose(c);
             d.flags[c.env] &= ~EVM_FLAG_DONE;
-            d.settle_left[c.env] = 2 * c_skel.reset_frames;
+            d.settle_left[c.env] = c_skel.settle_steps;
             GS(stat, 1) += 1;
         }
         __syncthreads();

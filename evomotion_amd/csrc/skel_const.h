@@ -95,6 +95,9 @@ struct EvmSkelC {
     float root_pos[3];
     float min_vel, target_vel;
     int max_steps, init_remaining, reset_frames;
+    int env_kind;          // 0 robot_walk, 1 robot_jump (EvmEnvParams::env_kind)
+    int settle_steps;      // physics steps inside reset(): 2 * reset_frames (robot_walk.cpp:98-103) or reset_frames (robot_jump.cpp:104)
+    float reset_angle_limit;  // pi * 2 / 3 (robot_walk.cpp:80) or pi / 3 (robot_jump.cpp:89)
     // scratch layout (offsets in floats-per-env)
     int sc_r, sc_ext, sc_ms, sc_pt, sc_mobs, sc_h, sc_f, sc_s, sc_p, sc_c, sc_total;
     float sched_cycles;  // host estimate of the 10 sweeps under the schedule's cost model (information only)

@@ -1,6 +1,7 @@
 #include "skeleton_host.h"
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -122,16 +123,24 @@ void copy_rows(const float m[3][3], float out[9]) {
         for (int j = 0; j < 3; j++) out[3 * i + j] = m[i][j];
 }
 
-}  // namespace
-
-int load_skeleton_constants(const char *path, const EvmEnvParams &prm, EvmSkelC &S, std::string &err) {
-    std::ifstream f(path ? path : "");
-    if (!f) { err = std::string("cannot open skeleton fixture: ") + (path ? path : "(null)"); return EVM_E_RUNTIME; }
+// ---- input formats --------------------------------------------------------------------------------------------
+struct RawSkeleton {
     std::string root_name;
     std::vector<RawMember> members;
     std::vector<RawCon> cons;
     std::vector<RawMuscle> muscles;
     std::vector<RawShape> shapes;
+};
+
+// (1) the decoded text fixture written by tools/decode_skeleton.py
+int parse_fixture(const char *path, RawSkeleton &R, std::string &err) {
+    std::ifstream f(path ? path : "");
+    if (!f) { err = std::string("cannot open skeleton fixture: ") + (path ? path : "(null)"); return EVM_E_RUNTIME; }
+    std::string &root_name = R.root_name;
+    std::vector<RawMember> &members = R.members;
+    std::vector<RawCon> &cons = R.cons;
+    std::vector<RawMuscle> &muscles = R.muscles;
+    std::vector<RawShape> &shapes = R.shapes;
     std::string line;
     int pts_left = 0;
     while (std::getline(f, line)) {
@@ -160,7 +169,7 @@ int load_skeleton_constants(const char *path, const EvmEnvParams &prm, EvmSkelC 
             RawCon c;
             c.type = kw == "hinge" ? 0 : 1;
             ss >> c.name >> c.parent >> c.child;
-            if (!next_floats(ss, c.v, c.type == 0 ? 14 : 14)) { err = "malformed constraint line"; return EVM_E_RUNTIME; }
+            if (!next_floats(ss, c.v, 14)) { err = "malformed constraint line"; return EVM_E_RUNTIME; }
             cons.push_back(c);
         } else if (kw == "muscle") {
             RawMuscle m;
@@ -181,6 +190,258 @@ int load_skeleton_constants(const char *path, const EvmEnvParams &prm, EvmSkelC 
             return EVM_E_RUNTIME;
         }
     }
+    return EVM_OK;
+}
+
+// (2) the reference's own skeleton format: JSON written by JsonSerializer (evo_motion_model/src/json_serializer.cpp,
+// read back at :113-168; skeleton layout evo_motion_model/src/robot/skeleton.cpp:27-53, member.cpp / constraint.cpp /
+// muscle.cpp deserialising constructors) with every float as a 32-character IEEE-754 bit string
+// (converter.cpp:138-147), plus the collision hulls from Wavefront OBJ files (shapes.cpp:24-56).
+struct JVal {
+    enum Kind { Null, Bool, Num, Str, Arr, Obj } kind = Null;
+    bool b = false;
+    double num = 0;
+    std::string str;
+    std::vector<JVal> arr;
+    std::vector<std::pair<std::string, JVal>> obj;
+    const JVal *get(const std::string &k) const {
+        for (auto &kv : obj) if (kv.first == k) return &kv.second;
+        return nullptr;
+    }
+};
+struct JParser {
+    const std::string &t;
+    size_t i = 0;
+    std::string err;
+    explicit JParser(const std::string &text) : t(text) {}
+    void ws() { while (i < t.size() && (t[i] == ' ' || t[i] == '\n' || t[i] == '\t' || t[i] == '\r')) i++; }
+    bool fail(const std::string &m) { if (err.empty()) err = m + " at byte " + std::to_string(i); return false; }
+    bool parse_string(std::string &out) {
+        if (t[i] != '"') return fail("expected string");
+        i++;
+        out.clear();
+        while (i < t.size() && t[i] != '"') {
+            if (t[i] == '\\') {
+                if (++i >= t.size()) return fail("bad escape");
+                switch (t[i]) {
+                    case 'n': out += '\n'; break;
+                    case 't': out += '\t'; break;
+                    case 'r': out += '\r'; break;
+                    case 'b': out += '\b'; break;
+                    case 'f': out += '\f'; break;
+                    case 'u': if (i + 4 >= t.size()) return fail("bad \\u escape"); out += '?'; i += 4; break;
+                    default: out += t[i];
+                }
+                i++;
+            } else out += t[i++];
+        }
+        if (i >= t.size()) return fail("unterminated string");
+        i++;
+        return true;
+    }
+    bool parse(JVal &v) {
+        ws();
+        if (i >= t.size()) return fail("unexpected end");
+        const char c = t[i];
+        if (c == '{') {
+            v.kind = JVal::Obj;
+            i++; ws();
+            if (i < t.size() && t[i] == '}') { i++; return true; }
+            for (;;) {
+                ws();
+                std::string k;
+                if (!parse_string(k)) return false;
+                ws();
+                if (i >= t.size() || t[i] != ':') return fail("expected ':'");
+                i++;
+                JVal child;
+                if (!parse(child)) return false;
+                v.obj.emplace_back(std::move(k), std::move(child));
+                ws();
+                if (i < t.size() && t[i] == ',') { i++; continue; }
+                if (i < t.size() && t[i] == '}') { i++; return true; }
+                return fail("expected ',' or '}'");
+            }
+        }
+        if (c == '[') {
+            v.kind = JVal::Arr;
+            i++; ws();
+            if (i < t.size() && t[i] == ']') { i++; return true; }
+            for (;;) {
+                JVal child;
+                if (!parse(child)) return false;
+                v.arr.push_back(std::move(child));
+                ws();
+                if (i < t.size() && t[i] == ',') { i++; continue; }
+                if (i < t.size() && t[i] == ']') { i++; return true; }
+                return fail("expected ',' or ']'");
+            }
+        }
+        if (c == '"') { v.kind = JVal::Str; return parse_string(v.str); }
+        if (t.compare(i, 4, "true") == 0) { v.kind = JVal::Bool; v.b = true; i += 4; return true; }
+        if (t.compare(i, 5, "false") == 0) { v.kind = JVal::Bool; v.b = false; i += 5; return true; }
+        if (t.compare(i, 4, "null") == 0) { v.kind = JVal::Null; i += 4; return true; }
+        char *end = nullptr;
+        v.num = strtod(t.c_str() + i, &end);
+        if (end == t.c_str() + i) return fail("unexpected character");
+        v.kind = JVal::Num;
+        i = (size_t) (end - t.c_str());
+        return true;
+    }
+};
+
+// binary_string_to_float (converter.cpp:138-147): 32 characters '0'/'1', most significant bit first
+bool bits_to_float(const JVal *v, float &out) {
+    if (!v || v->kind != JVal::Str || v->str.size() != 32) return false;
+    uint32_t u = 0;
+    for (char ch : v->str) {
+        if (ch != '0' && ch != '1') return false;
+        u = (u << 1) | (uint32_t) (ch == '1');
+    }
+    memcpy(&out, &u, 4);
+    return true;
+}
+bool read_vec3(const JVal *o, float out[3]) {
+    return o && o->kind == JVal::Obj && bits_to_float(o->get("x"), out[0]) && bits_to_float(o->get("y"), out[1]) &&
+           bits_to_float(o->get("z"), out[2]);
+}
+bool read_quat(const JVal *o, float out[4]) {  // (w, x, y, z), the order of JsonDeserializer::read_quat
+    return o && o->kind == JVal::Obj && bits_to_float(o->get("w"), out[0]) && bits_to_float(o->get("x"), out[1]) &&
+           bits_to_float(o->get("y"), out[2]) && bits_to_float(o->get("z"), out[3]);
+}
+bool read_str(const JVal *v, std::string &out) {
+    if (!v || v->kind != JVal::Str) return false;
+    out = v->str;
+    return true;
+}
+
+// ObjShape (shapes.cpp:24-56): 'v' lines parsed with stof, one hull point per face corner in face order; duplicates
+// are then dropped keeping the FIRST occurrence, which preserves every first-strict-extremum support scan over the list.
+int load_obj_hull(const std::string &file, RawShape &shape, std::string &err) {
+    std::ifstream f(file);
+    if (!f) { err = "cannot open hull file: " + file; return EVM_E_RUNTIME; }
+    std::vector<float> verts;
+    std::vector<int> order;
+    std::string line;
+    auto split = [](const std::string &s, char d) {
+        std::vector<std::string> out;
+        std::stringstream ss(s);
+        std::string item;
+        while (std::getline(ss, item, d)) out.push_back(item);
+        return out;
+    };
+    while (std::getline(f, line)) {
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        const auto tok = split(line, ' ');
+        if (tok.empty()) continue;
+        if (tok[0] == "v") {
+            if (tok.size() < 4) { err = "malformed vertex in " + file; return EVM_E_RUNTIME; }
+            for (int a = 1; a <= 3; a++) verts.push_back(strtof(tok[a].c_str(), nullptr));
+        } else if (tok[0] == "f") {
+            if (tok.size() < 4) { err = "malformed face in " + file; return EVM_E_RUNTIME; }
+            for (int a = 1; a <= 3; a++) order.push_back(atoi(split(tok[a], '/')[0].c_str()) - 1);
+        }
+    }
+    std::map<std::array<uint32_t, 3>, int> seen;
+    for (int idx : order) {
+        if (idx < 0 || (size_t) (3 * idx + 2) >= verts.size()) { err = "face index out of range in " + file; return EVM_E_RUNTIME; }
+        std::array<uint32_t, 3> key;
+        memcpy(key.data(), &verts[3 * idx], 12);
+        for (auto &k : key) if (k == 0x80000000u) k = 0;  // -0 and +0 are the same point
+        if (seen.emplace(key, 1).second) shape.pts.insert(shape.pts.end(), verts.begin() + 3 * idx, verts.begin() + 3 * idx + 3);
+    }
+    if (shape.pts.empty()) { err = "no faces in " + file; return EVM_E_RUNTIME; }
+    return EVM_OK;
+}
+
+int parse_json_skeleton(const char *path, RawSkeleton &R, std::string &err) {
+    std::ifstream f(path);
+    if (!f) { err = std::string("cannot open skeleton json: ") + path; return EVM_E_RUNTIME; }
+    std::stringstream buf;
+    buf << f.rdbuf();
+    const std::string text = buf.str();
+    JParser P(text);
+    JVal root;
+    if (!P.parse(root) || root.kind != JVal::Obj) { err = "skeleton json: " + (P.err.empty() ? std::string("not an object") : P.err); return EVM_E_RUNTIME; }
+    auto bad = [&](const std::string &what) { err = "skeleton json: missing or malformed " + what; return EVM_E_RUNTIME; };
+    if (!read_str(root.get("root_name"), R.root_name)) return bad("root_name");
+    const JVal *jm = root.get("members"), *jc = root.get("constraints"), *jmu = root.get("muscles");
+    if (!jm || jm->kind != JVal::Arr || !jc || jc->kind != JVal::Arr || !jmu || jmu->kind != JVal::Arr) return bad("members / constraints / muscles");
+    for (auto &m : jm->arr) {
+        RawMember r;
+        const JVal *ign = m.get("ignore_collision");
+        if (!read_str(m.get("name"), r.name) || !read_str(m.get("shape"), r.shape) || !bits_to_float(m.get("mass"), r.mass) ||
+            !bits_to_float(m.get("friction"), r.friction) || !read_vec3(m.get("translation"), r.t) ||
+            !read_quat(m.get("rotation"), r.q) || !read_vec3(m.get("scale"), r.scale) || !ign || ign->kind != JVal::Bool)
+            return bad("member " + r.name);
+        r.ignore = ign->b ? 1 : 0;
+        R.members.push_back(r);
+    }
+    for (auto &c : jc->arr) {
+        RawCon r;
+        std::string type;
+        if (!read_str(c.get("type"), type) || !read_str(c.get("name"), r.name) || !read_str(c.get("parent_name"), r.parent) ||
+            !read_str(c.get("child_name"), r.child)) return bad("constraint header");
+        if (type == "hinge") {
+            r.type = 0;
+            const JVal *lim = c.get("limit_radian");
+            if (!read_vec3(c.get("pivot_in_parent"), r.v) || !read_vec3(c.get("pivot_in_child"), r.v + 3) ||
+                !read_vec3(c.get("axis_in_parent"), r.v + 6) || !read_vec3(c.get("axis_in_child"), r.v + 9) || !lim ||
+                !bits_to_float(lim->get("min"), r.v[12]) || !bits_to_float(lim->get("max"), r.v[13])) return bad("hinge " + r.name);
+        } else if (type == "fixed") {
+            r.type = 1;
+            const JVal *fp = c.get("frame_in_parent"), *fc = c.get("frame_in_child");
+            if (!fp || !fc || !read_vec3(fp->get("translation"), r.v) || !read_quat(fp->get("rotation"), r.v + 3) ||
+                !read_vec3(fc->get("translation"), r.v + 7) || !read_quat(fc->get("rotation"), r.v + 10)) return bad("fixed " + r.name);
+        } else {
+            err = "skeleton json: unknown constraint type " + type;
+            return EVM_E_RUNTIME;
+        }
+        R.cons.push_back(r);
+    }
+    for (auto &m : jmu->arr) {
+        RawMuscle r;
+        if (!read_str(m.get("name"), r.name) || !read_str(m.get("item_a"), r.a) || !read_str(m.get("item_b"), r.b) ||
+            !bits_to_float(m.get("attach_mass"), r.mass) || !read_vec3(m.get("attach_scale"), r.scale) ||
+            !read_vec3(m.get("pos_in_a"), r.pa) || !read_vec3(m.get("pos_in_b"), r.pb) || !bits_to_float(m.get("force"), r.force) ||
+            !bits_to_float(m.get("speed"), r.speed)) return bad("muscle " + r.name);
+        R.muscles.push_back(r);
+    }
+    // hulls: <dir of the json>/../obj/<shape>.obj (the reference's resources layout), else next to the json
+    std::string dir = path;
+    const size_t slash = dir.find_last_of('/');
+    dir = slash == std::string::npos ? std::string(".") : dir.substr(0, slash);
+    std::vector<std::string> names;
+    for (auto &m : R.members) if (std::find(names.begin(), names.end(), m.shape) == names.end()) names.push_back(m.shape);
+    if (!R.muscles.empty() && std::find(names.begin(), names.end(), std::string("sphere")) == names.end()) names.push_back("sphere");
+    for (auto &n : names) {
+        RawShape sh;
+        sh.name = n;
+        std::string file = dir + "/../obj/" + n + ".obj";
+        if (!std::ifstream(file)) file = dir + "/obj/" + n + ".obj";
+        if (!std::ifstream(file)) file = dir + "/" + n + ".obj";
+        const int rc = load_obj_hull(file, sh, err);
+        if (rc) return rc;
+        R.shapes.push_back(std::move(sh));
+    }
+    return EVM_OK;
+}
+
+}  // namespace
+
+int load_skeleton_constants(const char *path, const EvmEnvParams &prm, EvmSkelC &S, std::string &err) {
+    RawSkeleton RAW;
+    {
+        const std::string p = path ? path : "";
+        const bool is_json = p.size() > 5 && p.compare(p.size() - 5, 5, ".json") == 0;
+        const int rc = is_json ? parse_json_skeleton(p.c_str(), RAW, err) : parse_fixture(path, RAW, err);
+        if (rc) return rc;
+    }
+    std::string &root_name = RAW.root_name;
+    std::vector<RawMember> &members = RAW.members;
+    std::vector<RawCon> &cons = RAW.cons;
+    std::vector<RawMuscle> &muscles = RAW.muscles;
+    std::vector<RawShape> &shapes = RAW.shapes;
     std::map<std::string, int> member_id, shape_id;
     for (size_t i = 0; i < members.size(); i++) member_id[members[i].name] = (int) i;
     for (size_t i = 0; i < shapes.size(); i++) shape_id[shapes[i].name] = (int) i;
@@ -215,6 +476,9 @@ int load_skeleton_constants(const char *path, const EvmEnvParams &prm, EvmSkelC 
     S.max_steps = (int) (prm.max_episode_seconds / kDt);
     S.init_remaining = (int) (prm.initial_remaining_seconds / kDt);
     S.reset_frames = prm.reset_frames;
+    S.env_kind = prm.env_kind;
+    S.settle_steps = prm.env_kind == 1 ? prm.reset_frames : 2 * prm.reset_frames;
+    S.reset_angle_limit = prm.env_kind == 1 ? (float) 3.14159265358979323846 / 3.f : (float) 3.14159265358979323846 * 2.f / 3.f;
 
     // ---- bodies: members, then (attach_a, attach_b) per muscle ----
     std::vector<Mat> M0(nb);

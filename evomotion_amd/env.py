@@ -32,19 +32,46 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+# RobotJumpFactory parameter names and defaults (env_factory.cpp:91-100)
+_JUMP_DEFAULTS = {
+    "skeleton_json_path": _lib.DEFAULT_SKELETON,
+    "minimal_velocity": 0.1,
+    "target_velocity": 0.5,
+    "max_seconds": 30.0,
+    "initial_seconds": 1.0,
+    "reset_seconds": 1.0 / 6.0,
+}
+
+
+def get_environment(env_name, n_envs, seed=1234, device=0, parameters=None):
+    """get_environment_factory(env_name, parameters)->get_env(num_threads, seed) (environment.h:96-97, env_factory.cpp:109-120)
+    for n_envs environments; unknown names raise ValueError like the reference's std::invalid_argument."""
+    if env_name == "robot_walk":
+        return VecRobotWalk(n_envs, seed, device, parameters)
+    if env_name == "robot_jump":
+        return VecRobotJump(n_envs, seed, device, parameters)
+    raise ValueError(env_name)
+
+
 class VecRobotWalk:
-    def __init__(self, n_envs, seed=1234, device=0, parameters=None):
+    ENV_KIND = 0
+
+    def _parameters(self, parameters):
         prm = dict(_PARAM_DEFAULTS)
         for k, v in (parameters or {}).items():
             if k not in prm:
                 raise ValueError(k)
             prm[k] = type(_PARAM_DEFAULTS[k])(v)
+        return prm
+
+    def __init__(self, n_envs, seed=1234, device=0, parameters=None):
+        prm = self._parameters(parameters)
         if not torch.cuda.is_available():
             raise _lib.EvmError("VecRobotWalk needs a HIP device (no CPU fallback)")
         self.device = torch.device("cuda", device)
         self.n_envs = int(n_envs)
         p = EvmEnvParams(prm["initial_remaining_seconds"], prm["max_episode_seconds"], prm["target_velocity"],
-                         prm["minimal_velocity"], prm["reset_frames"])
+                         prm["minimal_velocity"], prm["reset_frames"], self.ENV_KIND)
         self._h = ctypes.c_void_p()
         torch.cuda.set_device(self.device)
         check(lib.evm_env_create(prm["skeleton_json_path"].encode(), self.n_envs, device, seed, ctypes.byref(p),
@@ -161,3 +188,20 @@ class VecRobotWalk:
         ms, n = ctypes.c_float(), ctypes.c_int()
         check(lib.evm_env_timing_end(self._h, self._stream(), ctypes.byref(ms), ctypes.byref(n)))
         return ms.value, n.value
+
+
+class VecRobotJump(VecRobotWalk):
+    """robot_jump (evo_motion_model/src/env/robot_jump.cpp): the same skeleton, world and step; reward max(vy, 0) + vz,
+    fail on remaining < 0, reset angles within pi/3 and int(reset_seconds / dt) settle steps."""
+    ENV_KIND = 1
+
+    def _parameters(self, parameters):
+        prm = dict(_JUMP_DEFAULTS)
+        for k, v in (parameters or {}).items():
+            if k not in prm:
+                raise ValueError(k)
+            prm[k] = type(_JUMP_DEFAULTS[k])(v)
+        dt = np.float32(1.0) / np.float32(60.0)
+        return dict(skeleton_json_path=prm["skeleton_json_path"], initial_remaining_seconds=prm["initial_seconds"],
+                    max_episode_seconds=prm["max_seconds"], target_velocity=prm["target_velocity"],
+                    minimal_velocity=prm["minimal_velocity"], reset_frames=int(np.float32(prm["reset_seconds"]) / dt))

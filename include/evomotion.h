@@ -38,10 +38,16 @@ typedef struct EvmEnvParams {
     float target_velocity;           /* 0.5  */
     float minimal_velocity;          /* 0.1  */
     int reset_frames;                /* 30   */
+    int env_kind;                    /* 0 = robot_walk, 1 = robot_jump (evo_motion_model/src/env/robot_jump.cpp:66-110:
+                                        reward max(vy, 0) + vz, fail on remaining < 0, reset angles within pi/3, and
+                                        reset_frames = int(reset_seconds / dt) = 10 settle steps in one loop) */
 } EvmEnvParams;
 
 const char *evm_last_error(void);
-void evm_env_default_params(EvmEnvParams *out);
+void evm_env_default_params(EvmEnvParams *out);   /* robot_walk */
+/* get_environment_factory(name, {}) defaults (env_factory.cpp:74-100,109-120): "robot_walk" or "robot_jump";
+ * EVM_E_INVALID for any other name (std::invalid_argument, env_factory.cpp:118). */
+int evm_env_default_params_for(const char *env_name, EvmEnvParams *out);
 
 /*
  * Replaces get_environment_factory("robot_walk", params)->get_env(num_threads, seed)
@@ -108,6 +114,12 @@ int evm_env_debug_physics_steps(EvmEnv *env, int n_steps, const uint8_t *d_mask)
  * counts[10] = nb nm nhinge nfixed nmuscle state_dim action_dim root max_steps initial_remaining;
  * h_out (may be NULL) = per body the 19 floats of evm_env_get_body_constants; capacity 64 bodies. */
 int evm_skeleton_probe(const char *skeleton_path, int *counts, float *h_out);
+/* Host-only: digest of every constant the loader derives from a skeleton file.  `skeleton_path` of every evm_* entry
+ * point is either the decoded text fixture (*.skel) or the reference's own format: a skeleton JSON
+ * (evo_motion_model/src/json_serializer.cpp:113-168; floats as 32-character bit strings, converter.cpp:138-147) whose
+ * hulls are read from <json dir>/../obj/<shape>.obj (shapes.cpp:24-56) — the `skeleton_json_path` parameter of
+ * RobotWalkFactory (env_factory.cpp:74-83). */
+int evm_skeleton_digest(const char *skeleton_path, unsigned long long *h_out);
 /* Host-only: the Gauss-Seidel visit list (Bullet order) and the per-wave dataflow schedule derived from it.
  * dims[4] = nvisit, nlevels, n_waves, cap; visits [nvisit,4] = type, body a, body b, need (needA | needB << 16);
  * sched [n_waves, cap] = joint visit index, or 0x4000 | member for that member's contact rows, -1 = past the end. */

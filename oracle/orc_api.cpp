@@ -29,6 +29,22 @@ void *orc_env_create(const char *skel_path, int seed, float initial_remaining_se
     if (!w->init(s, seed, p, g_err)) { delete w; return nullptr; }
     return w;
 }
+// the same with the environment kind: 0 robot_walk, 1 robot_jump
+void *orc_env_create_kind(const char *skel_path, int seed, float initial_remaining_seconds, float max_episode_seconds,
+                          float target_velocity, float minimal_velocity, int reset_frames, int env_kind) {
+    SkeletonDef s;
+    if (!load_skeleton(skel_path, s, g_err)) return nullptr;
+    EnvParams p;
+    p.initial_remaining_seconds = initial_remaining_seconds;
+    p.max_episode_seconds = max_episode_seconds;
+    p.target_velocity = target_velocity;
+    p.minimal_velocity = minimal_velocity;
+    p.reset_frames = reset_frames;
+    p.env_kind = env_kind;
+    World *w = new World();
+    if (!w->init(s, seed, p, g_err)) { delete w; return nullptr; }
+    return w;
+}
 void orc_env_destroy(void *h) { delete (World *) h; }
 int orc_env_obs_dim(void *h) { return ((World *) h)->obs_dim(); }
 int orc_env_act_dim(void *h) { return ((World *) h)->act_dim(); }

@@ -1,4 +1,6 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY (see orc_world.h header for scope, citations and parity status).
+#include <algorithm>
+
 #include "orc_world.h"
 
 #include <array>
@@ -1019,12 +1021,13 @@ void World::compute_step(float *obs, float *reward, int *done) {
         obs[k++] = p2ps[2 * i].applied;
         obs[k++] = p2ps[2 * i + 1].applied;
     }
-    float lin_vel_z = bodies[root].lin.z;
+    // robot_walk.cpp:61-68: the root's z velocity; robot_jump.cpp:71-80: max(vy, 0) + vz and a strict fail test
+    float lin_vel_z = prm.env_kind == 1 ? std::max(bodies[root].lin.y, 0.f) + bodies[root].lin.z : bodies[root].lin.z;
     *reward = lin_vel_z;
     if (lin_vel_z < prm.minimal_velocity) remaining_steps -= 1;
     else if (lin_vel_z >= prm.target_velocity) remaining_steps += 1;
     bool win = curr_step >= max_steps;
-    bool fail = remaining_steps <= 0;
+    bool fail = prm.env_kind == 1 ? remaining_steps < 0 : remaining_steps <= 0;
     *done = (win | fail) ? 1 : 0;
     curr_step += 1;
 }
@@ -1034,7 +1037,7 @@ void World::compute_step(float *obs, float *reward, int *done) {
 // ------------------------------------------------------------------------------------------------
 void World::reset_begin() {
     const V3 root_pos(1.f, 0.25f, 2.f);
-    const float angle_limit = (float) M_PI * 2.f / 3.f;
+    const float angle_limit = prm.env_kind == 1 ? (float) M_PI / 3.f : (float) M_PI * 2.f / 3.f;  // robot_jump.cpp:89
     float yaw = rng.uniform01() * angle_limit - angle_limit / 2.f;
     float roll = rng.uniform01() * angle_limit - angle_limit / 2.f;
     float pitch = rng.uniform01() * angle_limit - angle_limit / 2.f;
@@ -1059,7 +1062,8 @@ void World::reset(float *obs, float *reward, int *done) {
     for (int i = 0; i < prm.reset_frames; i++) physics_step();
     curr_step = 0;
     remaining_steps = (int) (prm.initial_remaining_seconds / DT);
-    for (int i = 0; i < prm.reset_frames; i++) physics_step();
+    if (prm.env_kind == 0)  // robot_walk.cpp:98-103 settles twice; robot_jump.cpp:104-107 once
+        for (int i = 0; i < prm.reset_frames; i++) physics_step();
     compute_step(obs, reward, done);
 }
 

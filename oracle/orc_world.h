@@ -77,6 +77,8 @@ struct EnvParams {
     float target_velocity = 0.5f;
     float minimal_velocity = 0.1f;
     int reset_frames = 30;
+    int env_kind = 0;  // 0 robot_walk (robot_walk.cpp), 1 robot_jump (robot_jump.cpp:66-110): reward max(vy,0)+vz, fail on
+                       // remaining < 0, reset yaw/roll/pitch within pi/3, `reset_frames` settle steps in ONE loop
 };
 
 struct ManifoldPoint {

@@ -26,6 +26,8 @@ def load():
     L.orc_last_error.restype = ctypes.c_char_p
     L.orc_env_create.restype = vp
     L.orc_env_create.argtypes = [ctypes.c_char_p, ctypes.c_int] + [ctypes.c_float] * 4 + [ctypes.c_int]
+    L.orc_env_create_kind.restype = vp
+    L.orc_env_create_kind.argtypes = [ctypes.c_char_p, ctypes.c_int] + [ctypes.c_float] * 4 + [ctypes.c_int, ctypes.c_int]
     L.orc_env_destroy.argtypes = [vp]
     for f in ["orc_env_obs_dim", "orc_env_act_dim", "orc_env_num_bodies", "orc_env_num_members", "orc_env_state_size"]:
         getattr(L, f).argtypes = [vp]
@@ -52,10 +54,10 @@ class OracleEnv:
     """One scalar oracle environment (reference semantics: reset() / do_step(action))."""
 
     def __init__(self, seed=1234, skeleton=SKEL, initial_remaining_seconds=1.0, max_episode_seconds=30.0,
-                 target_velocity=0.5, minimal_velocity=0.1, reset_frames=30, lib=None):
+                 target_velocity=0.5, minimal_velocity=0.1, reset_frames=30, lib=None, env_kind=0):
         self.L = lib or load()
-        self.h = self.L.orc_env_create(skeleton.encode(), seed, initial_remaining_seconds, max_episode_seconds,
-                                       target_velocity, minimal_velocity, reset_frames)
+        self.h = self.L.orc_env_create_kind(skeleton.encode(), seed, initial_remaining_seconds, max_episode_seconds,
+                                            target_velocity, minimal_velocity, reset_frames, env_kind)
         if not self.h:
             raise RuntimeError(self.L.orc_last_error().decode())
         self.obs_dim = self.L.orc_env_obs_dim(self.h)
@@ -105,6 +107,9 @@ class OracleEnv:
         c = np.zeros(5, np.int32)
         self.L.orc_env_get_counters(self.h, c.ctypes.data_as(ip))
         return dict(curr_step=int(c[0]), remaining_steps=int(c[1]), max_steps=int(c[2]), contacts=int(c[3]), joint_rows=int(c[4]))
+
+    def set_counters(self, curr_step, remaining):
+        self.L.orc_env_set_counters(self.h, int(curr_step), int(remaining))
 
     def state_size(self):
         return self.L.orc_env_state_size(self.h)

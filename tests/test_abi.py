@@ -61,3 +61,75 @@ def test_fixture_matches_decoded_reference_values():
     assert q == [0.9375, 0.0, 0.375, 0.0]  # deliberately NOT unit length
     shapes = {l.split()[1]: (int(l.split()[2]), int(l.split()[3])) for l in lines if l.startswith("shape ")}
     assert shapes["cube"] == (8, 36) and shapes["feet"][1] == 2778 and shapes["sphere"] == (482, 2880)
+
+
+# ---- the reference's own skeleton format (JSON + OBJ) ------------------------------------------------------------
+def _digest(hip_lib, path):
+    h = ctypes.c_ulonglong()
+    hip_lib.check(hip_lib.lib.evm_skeleton_digest(str(path).encode(), ctypes.byref(h)))
+    return h.value
+
+
+def _chain_spec():
+    members = [dict(name="body", mass=2.0, scale=(0.4, 0.2, 0.5), q=(0.9375, 0, 0.375, 0))]  # non-unit quaternion
+    cons, mus = [], []
+    for k in range(4):
+        members.append(dict(name=f"seg{k}", mass=0.25, t=(0.65 + 0.5 * k, 0, 0), scale=(0.2, 0.1, 0.1), shape="feet" if k == 3 else "cube"))
+        parent = "body" if k == 0 else f"seg{k-1}"
+        pp = (0.4, 0, 0) if k == 0 else (0.25, 0, 0)
+        if k % 2 == 0:
+            cons.append(dict(type="hinge", name=f"c{k}", parent=parent, child=f"seg{k}", pivot_p=pp, pivot_c=(-0.25, 0, 0),
+                             axis_p=(0, 0, 1), axis_c=(0, 0, 1), lo=-1.0, hi=1.0))
+        else:
+            cons.append(dict(type="fixed", name=f"c{k}", parent=parent, child=f"seg{k}", tp=pp, tc=(-0.25, 0, 0), qc=(0.9375, 0.25, 0, 0)))
+    mus.append(dict(name="m0", a="body", b="seg0", pos_a=(0.2, 0.15, 0), pos_b=(0, 0.1, 0)))
+    mus.append(dict(name="m1", a="seg1", b="seg3", pos_a=(0, 0.1, 0), pos_b=(0, 0.1, 0)))
+    return members, cons, mus
+
+
+def test_json_and_fixture_loaders_derive_identical_constants(hip_lib, tmp_path):
+    from conftest import write_skeleton, write_skeleton_json
+    members, cons, mus = _chain_spec()
+    skel = write_skeleton(tmp_path / "chain.skel", members, cons, mus)
+    js = write_skeleton_json(str(tmp_path / "res"), members, cons, mus)
+    assert _digest(hip_lib, skel) == _digest(hip_lib, js)
+    cnt = (ctypes.c_int * 10)()
+    hip_lib.check(hip_lib.lib.evm_skeleton_probe(js.encode(), cnt, None))
+    assert list(cnt)[:7] == [9, 5, 2, 2, 2, 19 * 5 + 8, 2]
+
+
+@pytest.mark.skipif(not os.path.isfile("/root/reference/evo_motion_model/resources/skeleton/new_format_spider.json"),
+                    reason="the reference's data files are only in the authoring container")
+def test_reference_json_and_obj_files_give_the_committed_fixture(hip_lib):
+    ref = "/root/reference/evo_motion_model/resources/skeleton/new_format_spider.json"
+    assert _digest(hip_lib, ref) == _digest(hip_lib, hip_lib.DEFAULT_SKELETON)
+
+
+def test_json_loader_errors(hip_lib, tmp_path):
+    from conftest import write_skeleton_json
+    members, cons, mus = _chain_spec()
+    js = write_skeleton_json(str(tmp_path / "res"), members, cons, mus)
+    cnt = (ctypes.c_int * 10)()
+    text = open(js).read()
+    bad = tmp_path / "res" / "skeleton" / "bad.json"
+    bad.write_text(text[: len(text) // 2])  # truncated document
+    assert hip_lib.lib.evm_skeleton_probe(str(bad).encode(), cnt, None) == -2 and b"skeleton json" in hip_lib.lib.evm_last_error()
+    bad.write_text(text.replace('"hinge"', '"slider"', 1))
+    assert hip_lib.lib.evm_skeleton_probe(str(bad).encode(), cnt, None) == -2 and b"unknown constraint type" in hip_lib.lib.evm_last_error()
+    bad.write_text(text.replace('"00111111100000000000000000000000"', '"0011111110000000000000000000000"', 1))  # 31 bits
+    assert hip_lib.lib.evm_skeleton_probe(str(bad).encode(), cnt, None) == -2
+    bad.write_text(text.replace('"parent_name": "body"', '"parent_name": "nobody"', 1))
+    assert hip_lib.lib.evm_skeleton_probe(str(bad).encode(), cnt, None) == -2 and b"not found" in hip_lib.lib.evm_last_error()
+    os.remove(tmp_path / "res" / "obj" / "feet.obj")
+    assert hip_lib.lib.evm_skeleton_probe(js.encode(), cnt, None) == -2 and b"cannot open hull file" in hip_lib.lib.evm_last_error()
+
+
+def test_default_params_by_environment_name(hip_lib):
+    P = hip_lib.EvmEnvParams
+    w, j, x = P(), P(), P()
+    hip_lib.check(hip_lib.lib.evm_env_default_params_for(b"robot_walk", ctypes.byref(w)))
+    hip_lib.check(hip_lib.lib.evm_env_default_params_for(b"robot_jump", ctypes.byref(j)))
+    assert (w.reset_frames, w.env_kind, j.reset_frames, j.env_kind) == (30, 0, 10, 1)
+    assert w.initial_remaining_seconds == j.initial_remaining_seconds == 1.0 and w.max_episode_seconds == j.max_episode_seconds == 30.0
+    assert hip_lib.lib.evm_env_default_params_for(b"robot_fly", ctypes.byref(x)) == -1  # std::invalid_argument(env_name)
+    assert b"robot_fly" in hip_lib.lib.evm_last_error()

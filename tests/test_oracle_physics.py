@@ -112,3 +112,34 @@ def test_muscle_motor_direction_and_saturation(orc_lib):
         # applied impulse is either the saturated motor row (64 N / 60 Hz) or the ~0 angular-limit row
         assert np.all((np.abs(np.abs(imp) - 64.0 / 60.0) < 1e-3) | (np.abs(imp) < 1.07))
     assert (lens[1.0] > lens[-1.0]).sum() >= 10  # positive action extends the muscle (btSliderConstraint sign)
+
+
+def test_robot_jump_oracle_semantics(orc_lib):
+    """robot_jump.cpp:66-110 against robot_walk: reward, fail test, reset angle range and settle count."""
+    import orc as _orc
+    walk = _orc.OracleEnv(seed=5, lib=orc_lib)
+    jump = _orc.OracleEnv(seed=5, reset_frames=10, env_kind=1, lib=orc_lib)
+    # same RNG stream, angles scaled by (pi/3) / (2 pi/3): the reset rotation of jump is the "half-angle" one
+    walk.reset_begin(); jump.reset_begin()
+    bw, bj = walk.get_state(), jump.get_state()
+    Ew, Ej = bw[13 * 41 + 1:13 * 41 + 10].reshape(3, 3), bj[13 * 41 + 1:13 * 41 + 10].reshape(3, 3)
+    # yaw/pitch/roll are exactly halved (power-of-two ratio of the two limits): compare through the matrix entry -sin(pitch)
+    assert abs(np.arcsin(-Ej[1, 2]) * 2 - np.arcsin(-Ew[1, 2])) < 1e-6
+    assert abs(np.arcsin(-Ej[1, 2])) <= np.pi / 6 + 1e-6
+    obs, reward, done = jump.reset()
+    c = jump.counters()
+    assert c["curr_step"] == 1 and c["max_steps"] == 1799 and c["remaining_steps"] in (58, 59, 60)
+    root_lin = jump.get_state()[7:10]
+    assert abs(reward - (max(root_lin[1], 0.0) + root_lin[2])) < 1e-7
+    # strict fail test: remaining 1 -> 0 is not a failure for robot_jump, it is for robot_walk
+    for env, expect in ((jump, False), (walk, True)):
+        env.reset()
+        env.set_counters(5, 1)
+        blob_ = env.get_state()
+        blob_[7:10] = 0.0  # root at rest: below minimal_velocity
+        blob_[-2:] = (5, 1)
+        env.set_state(blob_)
+        out = np.zeros(env.obs_dim, np.float32)
+        r, d = _orc.ctypes.c_float(), _orc.ctypes.c_int()
+        env.L.orc_env_compute_step(env.h, out.ctypes.data_as(_orc.fp), _orc.ctypes.byref(r), _orc.ctypes.byref(d))
+        assert env.counters()["remaining_steps"] == 0 and bool(d.value) == expect
