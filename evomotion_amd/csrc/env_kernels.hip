@@ -81,12 +81,15 @@ DEV Ctx make_ctx(const EnvDev &d, float *lds) {
 
 // Wait until body b has been written `expect` times (monotonic counter, workgroup-scope acquire).  Bounded:
 // a schedule bug must not hang the GPU; on timeout the diagnostic slot is poisoned and the wave goes on.
+#ifndef EVM_SPIN_HOT
+#define EVM_SPIN_HOT 4
+#endif
 DEV void wait_version(const Ctx &c, int b, int expect) {
     int *ver = LVER(c);
     int spins = 0;
     while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&ver[b], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < expect) {
-        __builtin_amdgcn_s_sleep(1);
-        if (++spins > (1 << 22)) { c.t.diag[c.lane] = -1.f; break; }
+        if (++spins > EVM_SPIN_HOT) __builtin_amdgcn_s_sleep(1);
+        if (spins > (1 << 22)) { c.t.diag[c.lane] = -1.f; break; }
     }
 }
 // both bodies of a joint visit with ONE LDS round trip: two relaxed polls in flight together, one acquire fence
@@ -98,8 +101,8 @@ DEV void wait_versions2(const Ctx &c, int a, int expA, int b, int expB) {
         const int va = __hip_atomic_load(&ver[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const int vb = __hip_atomic_load(&ver[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (__builtin_amdgcn_readfirstlane(va) >= expA && __builtin_amdgcn_readfirstlane(vb) >= expB) break;
-        __builtin_amdgcn_s_sleep(1);
-        if (++spins > (1 << 22)) { c.t.diag[c.lane] = -1.f; break; }
+        if (++spins > EVM_SPIN_HOT) __builtin_amdgcn_s_sleep(1);  // poll back to back first: a hop is usually imminent
+        if (spins > (1 << 22)) { c.t.diag[c.lane] = -1.f; break; }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
@@ -259,12 +262,13 @@ DEV void store_bodypd(const Ctx &c, int a, int b, const BodyPD &k) {
 }
 // One Gauss-Seidel row on the pair.  With axp = (ax, -ax): c = rel x axp gives (relA x ax, -(relB x ax)), and
 // d = axp . dl + c . da gives (J_A . delta_A, J_B . delta_B) exactly as the two scalar sides did.
-template <bool LIN, bool BOUNDED>
+// ISO: both bodies have an isotropic inverse inertia k * identity (attach spheres), kept in Q.I.xx
+template <bool LIN, bool BOUNDED, bool ISO = false>
 DEV float row_iter(F3 ax, const F3P &rel, BodyPD &Q, float jd, float rhs, float lo, float hi, float &applied) {
     const F3P axp = f3p(p2(ax.x, -ax.x), p2(ax.y, -ax.y), p2(ax.z, -ax.z));
     const F3P cc = LIN ? cross(rel, axp) : axp;
     const P2 d = LIN ? dot(axp, Q.dl) + dot(cc, Q.da) : dot(cc, Q.da);
-    const F3P ang = mul(Q.I, cc);
+    const F3P ang = ISO ? cc * Q.I.xx : mul(Q.I, cc);
     float dI = rhs;
     dI -= d.x * jd;
     dI -= d.y * jd;
@@ -625,6 +629,7 @@ DEV void slider_setup(const Ctx &c, int mi, bool powered_in, float target_vel) {
     rec_store<0, EVM_S_STRIDE / 4>(c, c_skel.sc_s + EVM_S_STRIDE * mi, rec);
     SC(c_skel.sc_mobs + 4 * mi) = lin_pos;  // btSliderConstraint::getLinearPos(), MuscleState
 }
+template <bool ISO>
 DEV float slider_solve(const Ctx &c, const EvmVisitC &V, const Blk42 &kk, const S33P &I) {
     const int s = V.slot;
     const F3 p = KV3(kk, 0), q = KV3(kk, 3), ax1 = KV3(kk, 6), p2_ = KV3(kk, 9), q2 = KV3(kk, 12);
@@ -636,12 +641,12 @@ DEV float slider_solve(const Ctx &c, const EvmVisitC &V, const Blk42 &kk, const 
     BodyPD Q = load_bodypd(c, V.a, V.b, V.imA, V.imB, I);
     const F3P rel = pair(relA, relB);
     float res = 0.f;
-    res = fmaxf(res, fabsf(row_iter<false, false>(p, rel, Q, KV(kk, 21), KV(kk, 27), 0.f, 0.f, ap[0])));
-    res = fmaxf(res, fabsf(row_iter<false, false>(q, rel, Q, KV(kk, 22), KV(kk, 28), 0.f, 0.f, ap[1])));
-    res = fmaxf(res, fabsf(row_iter<true, false>(p2_, rel, Q, KV(kk, 23), KV(kk, 29), 0.f, 0.f, ap[2])));
-    res = fmaxf(res, fabsf(row_iter<true, false>(q2, rel, Q, KV(kk, 24), KV(kk, 30), 0.f, 0.f, ap[3])));
-    if (KV(kk, 25) != 0.f) res = fmaxf(res, fabsf(row_iter<true, true>(ax1, rel, Q, KV(kk, 25), KV(kk, 31), lo, hi_, ap[4])));
-    if (KV(kk, 26) != 0.f) res = fmaxf(res, fabsf(row_iter<false, false>(ax1, rel, Q, KV(kk, 26), KV(kk, 32), 0.f, 0.f, ap[5])));
+    res = fmaxf(res, fabsf(row_iter<false, false, ISO>(p, rel, Q, KV(kk, 21), KV(kk, 27), 0.f, 0.f, ap[0])));
+    res = fmaxf(res, fabsf(row_iter<false, false, ISO>(q, rel, Q, KV(kk, 22), KV(kk, 28), 0.f, 0.f, ap[1])));
+    res = fmaxf(res, fabsf(row_iter<true, false, ISO>(p2_, rel, Q, KV(kk, 23), KV(kk, 29), 0.f, 0.f, ap[2])));
+    res = fmaxf(res, fabsf(row_iter<true, false, ISO>(q2, rel, Q, KV(kk, 24), KV(kk, 30), 0.f, 0.f, ap[3])));
+    if (KV(kk, 25) != 0.f) res = fmaxf(res, fabsf(row_iter<true, true, ISO>(ax1, rel, Q, KV(kk, 25), KV(kk, 31), lo, hi_, ap[4])));
+    if (KV(kk, 26) != 0.f) res = fmaxf(res, fabsf(row_iter<false, false, ISO>(ax1, rel, Q, KV(kk, 26), KV(kk, 32), 0.f, 0.f, ap[5])));
     store_bodypd(c, V.a, V.b, Q);
     {
         float w[EVM_S_STRIDE];
@@ -1249,7 +1254,12 @@ DEV void physics_step(const Ctx &c, int flags) {
         const Q4 q0 = q4(GS(quat, 4 * b), GS(quat, 4 * b + 1), GS(quat, 4 * b + 2), GS(quat, 4 * b + 3));
         M33 R = mat_from_quat(q0);
         const F3 invI = load_f3(BC.inv_inertia);
-        S33 I = inertia_world(R, invI);
+        // attach spheres: R diag(k, k, k) R^T = k R R^T = k * identity for any rotation.  (Their gyroscopic term
+        // w x (I w) is zero in exact arithmetic, but Bullet's implicit formula divides its rounding noise by I —
+        // about 1e-7 |w|^2 rad/s per step — and that noise is part of the reference's trajectory: it stays.)
+        S33 I;
+        if (BC.isotropic) { I.xx = invI.x; I.xy = 0.f; I.xz = 0.f; I.yy = invI.x; I.yz = 0.f; I.zz = invI.x; }
+        else I = inertia_world(R, invI);
         if (any_pending) {
             // first step after reset(): transform = E * M0 (non-orthonormal) and the inverse
             // inertia tensor is still the one of the last integrated transform
@@ -1331,11 +1341,11 @@ DEV void physics_step(const Ctx &c, int flags) {
 
     // ---- projected Gauss-Seidel sweeps ----
     // A wave walks its slice of the level schedule (EvmSkelC::sched); a workgroup barrier closes each level.
-    auto solve = [&](const EvmVisitC &V, const Blk42 &k, const S33P &I) -> float {
+    auto solve = [&](const EvmVisitC &V, const Blk42 &k, const S33P &I, bool iso) -> float {
         switch (V.type) {
             case 0: return hinge_solve(c, V, k, I);
             case 1: return fixed_solve(c, V, k, I);
-            case 2: return slider_solve(c, V, k, I);
+            case 2: return iso ? slider_solve<true>(c, V, k, I) : slider_solve<false>(c, V, k, I);
             default: return p2p_solve(c, V, k, I);
         }
     };
@@ -1369,7 +1379,16 @@ DEV void physics_step(const Ctx &c, int flags) {
 #ifdef EVM_STAMPS2
         const unsigned long long t0 = __builtin_amdgcn_s_memtime();
 #endif
-        const S33P I = load_inertia_pair(c, V.a, V.b);
+        S33P I;
+        const bool iso = V.type == 2 && !any_pending && c_skel.body[V.a].isotropic && c_skel.body[V.b].isotropic;
+        if (iso) {
+            // both bodies of a muscle slider are attach spheres: inverse inertia k * identity, straight from the skeleton
+            I.xx = p2(c_skel.body[V.a].inv_inertia[0], c_skel.body[V.b].inv_inertia[0]);
+            I.xy = I.xz = I.yz = p2(0.f, 0.f);
+            I.yy = I.zz = I.xx;
+        } else {
+            I = load_inertia_pair(c, V.a, V.b);
+        }
         wait_versions2(c, V.a, expA, V.b, expB);
 #ifdef EVM_STAMPS2
         const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -1377,7 +1396,7 @@ DEV void physics_step(const Ctx &c, int flags) {
 #ifdef EVM_STAMPS3
         const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
 #endif
-        const float r = solve(V, k, I);
+        const float r = solve(V, k, I, iso);
         publish_version(c, V.a, expA + 1);
         publish_version(c, V.b, expB + 1);
 #ifdef EVM_STAMPS3

@@ -29,6 +29,7 @@ struct EvmBodyC {
     float ext_force_y;  // (gravity_force * inv_mass) * dt, y component (x = z = 0)
     float mass, friction;
     int per_sweep;  // visits touching this body in one sweep (joint visits + 1 contact visit for members)
+    int isotropic;  // inv_inertia x == y == z (the attach spheres): world inverse inertia = k * R R^T = k * identity
     float m0[9];  // first_model_matrix basis, btMatrix3x3 rows (may be non-orthonormal: SURVEY App. A)
     float t0[3];  // first_model_matrix origin
 };

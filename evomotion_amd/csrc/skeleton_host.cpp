@@ -687,6 +687,8 @@ int load_skeleton_constants(const char *path, const EvmEnvParams &prm, EvmSkelC 
             cnt[S.visit[i].b]++;
         }
         for (int b = 0; b < nb; b++) S.body[b].per_sweep = cnt[b] + (b < nm ? 1 : 0);
+        for (int b = 0; b < nb; b++)
+            S.body[b].isotropic = S.body[b].inv_inertia[0] == S.body[b].inv_inertia[1] && S.body[b].inv_inertia[1] == S.body[b].inv_inertia[2];
     }
     S.nvisit = nv;
 

@@ -413,6 +413,7 @@ def test_robot_jump_matches_oracle(torch_mod, orc_lib):
         for i, o in enumerate(orcs):
             if outs[i][2]:
                 o.reset()
+    print("robot_jump teacher-forced worst:", worst)
     assert worst["pos"] < 5e-6 and worst["lin"] < 5e-4 and worst["rew"] < 1e-4 and worst["done"] == 0, worst
     # rollout form: a finished env spends exactly 10 calls in reset (9 settle + the emission)
     env2 = get_environment("robot_jump", 64, seed=7, parameters=dict(initial_seconds=0.05))
