@@ -299,14 +299,14 @@ DEV void blk_load_quads(const f32x4 *p, Blk42 &b) {
 #pragma unroll
     for (int q = Q0; q < Q1; q++) b.q[q] = p[q << 6];
 }
-DEV void blk_load(const Ctx &c, const EvmVisitC &v, Blk42 &b) {
+DEV void blk_load(const Ctx &c, const EvmEntryC &v, Blk42 &b, int nslots) {
     const f32x4 *p = rec_quads(c, v.slot);
     blk_load_quads<0, 4>(p, b);
-    if (v.nslots > 16) {  // wave-uniform: p2p records are 4 quads, hinges 9, fixed / slider 11, contacts 12
+    if (nslots > 16) {  // wave-uniform: p2p records are 4 quads, hinges 9, fixed / slider 11, contacts 12
         blk_load_quads<4, 9>(p, b);
-        if (v.nslots > 36) {
+        if (nslots > 36) {
             blk_load_quads<9, 11>(p, b);
-            if (v.nslots > 44) blk_load_quads<11, 12>(p, b);
+            if (nslots > 44) blk_load_quads<11, 12>(p, b);
         }
     }
 }
@@ -396,14 +396,13 @@ DEV void hinge_setup(const Ctx &c, int hi) {
     rec[27] = 0.f; rec[34] = lo; rec[35] = hi_;
     rec_store<0, EVM_H_STRIDE / 4>(c, c_skel.sc_h + EVM_H_STRIDE * hi, rec);
 }
-DEV float hinge_solve(const Ctx &c, const EvmVisitC &V, const Blk42 &k, const S33P &I) {
+DEV float hinge_solve(const Ctx &c, const EvmEntryC &V, const Blk42 &k, BodyPD &Q) {
     const int s = V.slot;
     const F3 relA = KV3(k, 0), relB = KV3(k, 3), p = KV3(k, 6), q = KV3(k, 9), ax1 = KV3(k, 12);
     float ap[6];
 #pragma unroll
     for (int r = 0; r < 6; r++) ap[r] = KV(k, 28 + r);
     const float lo = KV(k, 34), hi_ = KV(k, 35);
-    BodyPD Q = load_bodypd(c, V.a, V.b, V.imA, V.imB, I);
     const F3P rel = pair(relA, relB);
     float res = 0.f;
     res = fmaxf(res, fabsf(row_iter<true, false>(p, rel, Q, KV(k, 15), KV(k, 21), 0.f, 0.f, ap[0])));
@@ -483,13 +482,12 @@ DEV void fixed_setup(const Ctx &c, int fi) {
     rec[42] = 0.f; rec[43] = 0.f;
     rec_store<0, EVM_F_STRIDE / 4>(c, c_skel.sc_f + EVM_F_STRIDE * fi, rec);
 }
-DEV float fixed_solve(const Ctx &c, const EvmVisitC &V, const Blk42 &k, const S33P &I) {
+DEV float fixed_solve(const Ctx &c, const EvmEntryC &V, const Blk42 &k, BodyPD &Q) {
     const int s = V.slot;
     const F3 relA = KV3(k, 0), relB = KV3(k, 3);
     float ap[6];
 #pragma unroll
     for (int r = 0; r < 6; r++) ap[r] = KV(k, 36 + r);
-    BodyPD Q = load_bodypd(c, V.a, V.b, V.imA, V.imB, I);
     const F3P rel = pair(relA, relB);
     float res = 0.f;
 #pragma unroll
@@ -630,7 +628,7 @@ DEV void slider_setup(const Ctx &c, int mi, bool powered_in, float target_vel) {
     SC(c_skel.sc_mobs + 4 * mi) = lin_pos;  // btSliderConstraint::getLinearPos(), MuscleState
 }
 template <bool ISO>
-DEV float slider_solve(const Ctx &c, const EvmVisitC &V, const Blk42 &kk, const S33P &I) {
+DEV float slider_solve(const Ctx &c, const EvmEntryC &V, const Blk42 &kk, BodyPD &Q) {
     const int s = V.slot;
     const F3 p = KV3(kk, 0), q = KV3(kk, 3), ax1 = KV3(kk, 6), p2_ = KV3(kk, 9), q2 = KV3(kk, 12);
     const F3 relA = KV3(kk, 15), relB = KV3(kk, 18);
@@ -638,7 +636,6 @@ DEV float slider_solve(const Ctx &c, const EvmVisitC &V, const Blk42 &kk, const 
 #pragma unroll
     for (int r = 0; r < 6; r++) ap[r] = KV(kk, 36 + r);
     const float lo = KV(kk, 33), hi_ = KV(kk, 34);
-    BodyPD Q = load_bodypd(c, V.a, V.b, V.imA, V.imB, I);
     const F3P rel = pair(relA, relB);
     float res = 0.f;
     res = fmaxf(res, fabsf(row_iter<false, false, ISO>(p, rel, Q, KV(kk, 21), KV(kk, 27), 0.f, 0.f, ap[0])));
@@ -680,16 +677,10 @@ DEV void p2p_setup(const Ctx &c, int mi, int which) {
 }
 // p2p rows along the world axes.  The pivot in the attach sphere is the origin (muscle.cpp:52,55), so the
 // sphere-side lever arm a2 is exactly zero: body B only takes the linear part.
-DEV float p2p_solve(const Ctx &c, const EvmVisitC &V, const Blk42 &kk, const S33P &I) {
+DEV float p2p_solve(const Ctx &c, const EvmEntryC &V, const Blk42 &kk, BodyD &A, F3 &dlB) {
     const int ba = V.a, bb = V.b;
     const int s = V.slot;
     const F3 a1 = KV3(kk, 0);
-    BodyD A;
-    A.dl = f3(LDV(ba, 0), LDV(ba, 1), LDV(ba, 2));
-    A.da = f3(LDV(ba, 3), LDV(ba, 4), LDV(ba, 5));
-    A.I.xx = I.xx.x; A.I.xy = I.xy.x; A.I.xz = I.xz.x; A.I.yy = I.yy.x; A.I.yz = I.yz.x; A.I.zz = I.zz.x;
-    A.im = V.imA;
-    F3 dlB = f3(LDV(bb, 0), LDV(bb, 1), LDV(bb, 2));
     const float imB = V.imB;
     float ap0 = KV(kk, 12), ap1 = KV(kk, 13), ap2 = KV(kk, 14);
     float res = 0.f;
@@ -1014,14 +1005,9 @@ DEV void contact_setup(const Ctx &c, int m, int n) {
 }
 
 // Gauss-Seidel rows of member m's contact points; k = the member's record, requested one schedule entry ahead
-DEV float contact_iter(const Ctx &c, int m, const Blk42 &k, const S33 &I) {
+DEV float contact_iter(const Ctx &c, int m, const Blk42 &k, BodyD &D) {
     const EvmMemberC &MB = c_skel.member[m];
     const int rec = c_skel.sc_c + EVM_CM_STRIDE * m;
-    BodyD D;
-    D.dl = f3(LDV(m, 0), LDV(m, 1), LDV(m, 2));
-    D.da = f3(LDV(m, 3), LDV(m, 4), LDV(m, 5));
-    D.I = I;
-    D.im = c_skel.body[m].inv_mass;
     float res = 0.f;
     float apn[4];
     float w[EVM_CM_STRIDE];
@@ -1341,49 +1327,32 @@ DEV void physics_step(const Ctx &c, int flags) {
 
     // ---- projected Gauss-Seidel sweeps ----
     // A wave walks its slice of the level schedule (EvmSkelC::sched); a workgroup barrier closes each level.
-    auto solve = [&](const EvmVisitC &V, const Blk42 &k, const S33P &I, bool iso) -> float {
-        switch (V.type) {
-            case 0: return hinge_solve(c, V, k, I);
-            case 1: return fixed_solve(c, V, k, I);
-            case 2: return iso ? slider_solve<true>(c, V, k, I) : slider_solve<false>(c, V, k, I);
-            default: return p2p_solve(c, V, k, I);
-        }
-    };
     const int ns = c_skel.nsched[W];
     const int *sched = c_skel.sched[W];
     float res = 0.f;
     // Dataflow sweep.  Visits that share no body commute exactly, so the only ordering that matters is, per body,
-    // the order of the visits that touch it.  Every body carries a version counter in LDS (= how many visits
-    // have written it); a visit waits until its two bodies have reached the versions it expects (the number of
-    // earlier visits in Bullet order that touch them, plus a per-sweep stride), solves, and publishes the new
-    // versions with release semantics.  No workgroup barrier inside a sweep: the four leg chains drift freely
-    // and only the real dependency chain (the visits on the root body) is serial.  Each wave walks its slice of
-    // the level-sorted schedule, so the globally lowest unfinished visit is always at the head of some wave's
-    // list and cannot be blocked: no deadlock.  The record of the wave's next visit is requested before the
-    // current one is solved (two register blocks, ping-pong, unrolled by two so no block is ever copied).
-    // schedule entry -> visit descriptor; a member's contact rows are a pseudo visit (type 4) on its 48-float record
-    auto entry_visit = [&](int e) -> EvmVisitC {
-        if (!(e & EVM_SCHED_CONTACT)) return c_skel.visit[e];
-        EvmVisitC v;
-        const int m = e & (EVM_SCHED_CONTACT - 1);
-        v.type = 4; v.slot = c_skel.sc_c + EVM_CM_STRIDE * m; v.a = m; v.b = m; v.imA = 0.f; v.imB = 0.f;
-        v.nslots = (cmask & (1u << m)) ? EVM_CM_STRIDE : 0; v.need = 0;
-        return v;
-    };
+    // the order of the visits that touch it.  Every body carries a version counter in LDS (= how many visits have
+    // written it); a visit waits until its two bodies have reached the versions it expects, solves, and publishes the
+    // new versions.  No workgroup barrier inside or between sweeps; every wave's list follows one global topological
+    // order, so the globally lowest unfinished entry is always at the head of some wave's list: no deadlock.
+    // `after_loads` runs once the entry's LDS reads have landed and before its rows (a stretch of pure VALU work): the
+    // place to issue the scalar load of a later descriptor — SMEM and LDS share lgkmcnt and every LDS wait is a full
+    // lgkmcnt(0), so a scalar load issued anywhere else is waited for almost immediately.
 #ifdef EVM_STAMPS2
     unsigned long long t_wait = 0, t_solve = 0;
+    const unsigned long long t_loop0 = __builtin_amdgcn_s_memtime();
 #endif
-    auto run_visit = [&](const EvmVisitC &V, const Blk42 &k, int it) -> float {
-        const int expA = it * c_skel.body[V.a].per_sweep + (V.need & 0xffff);
-        const int expB = it * c_skel.body[V.b].per_sweep + (V.need >> 16);
+    auto run_visit = [&](const EvmEntryC &V, const Blk42 &k, int it, auto &&after_loads) -> float {
+        const int expA = it * V.psA + (V.need & 0xffff);
+        const int expB = it * V.psB + (V.need >> 16);
 #ifdef EVM_STAMPS2
         const unsigned long long t0 = __builtin_amdgcn_s_memtime();
 #endif
         S33P I;
-        const bool iso = V.type == 2 && !any_pending && c_skel.body[V.a].isotropic && c_skel.body[V.b].isotropic;
+        const bool iso = V.iso && !any_pending;
         if (iso) {
-            // both bodies of a muscle slider are attach spheres: inverse inertia k * identity, straight from the skeleton
-            I.xx = p2(c_skel.body[V.a].inv_inertia[0], c_skel.body[V.b].inv_inertia[0]);
+            // both bodies of a muscle slider are attach spheres: inverse inertia k * identity, straight from the descriptor
+            I.xx = p2(V.kA, V.kB);
             I.xy = I.xz = I.yz = p2(0.f, 0.f);
             I.yy = I.zz = I.xx;
         } else {
@@ -1396,7 +1365,27 @@ DEV void physics_step(const Ctx &c, int flags) {
 #ifdef EVM_STAMPS3
         const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
 #endif
-        const float r = solve(V, k, I, iso);
+        float r;
+        if (V.type == 3) {
+            BodyD A;
+            A.dl = f3(LDV(V.a, 0), LDV(V.a, 1), LDV(V.a, 2));
+            A.da = f3(LDV(V.a, 3), LDV(V.a, 4), LDV(V.a, 5));
+            A.I.xx = I.xx.x; A.I.xy = I.xy.x; A.I.xz = I.xz.x; A.I.yy = I.yy.x; A.I.yz = I.yz.x; A.I.zz = I.zz.x;
+            A.im = V.imA;
+            F3 dlB = f3(LDV(V.b, 0), LDV(V.b, 1), LDV(V.b, 2));
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+            after_loads();
+            r = p2p_solve(c, V, k, A, dlB);
+        } else {
+            BodyPD Q = load_bodypd(c, V.a, V.b, V.imA, V.imB, I);
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+            after_loads();
+            switch (V.type) {
+                case 0: r = hinge_solve(c, V, k, Q); break;
+                case 1: r = fixed_solve(c, V, k, Q); break;
+                default: r = iso ? slider_solve<true>(c, V, k, Q) : slider_solve<false>(c, V, k, Q); break;
+            }
+        }
         publish_version(c, V.a, expA + 1);
         publish_version(c, V.b, expB + 1);
 #ifdef EVM_STAMPS3
@@ -1412,12 +1401,13 @@ DEV void physics_step(const Ctx &c, int flags) {
         return r;
     };
     // contact rows of a member: after all of its joint visits of this sweep, before the next sweep's
-    auto run_contact = [&](int m, int it, const Blk42 &k) -> float {
-        const int ps = c_skel.body[m].per_sweep;
+    auto run_contact = [&](const EvmEntryC &V, int it, const Blk42 &k, auto &&after_loads) -> float {
+        const int m = V.a, ps = V.psA;
 #ifdef EVM_STAMPS2
         const unsigned long long t0 = __builtin_amdgcn_s_memtime();
 #endif
-        const S33 I = lds_inertia(c, m);
+        BodyD D;
+        D.I = lds_inertia(c, m);
         wait_version(c, m, it * ps + ps - 1);
 #ifdef EVM_STAMPS2
         const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -1426,12 +1416,20 @@ DEV void physics_step(const Ctx &c, int flags) {
 #ifdef EVM_STAMPS3
         const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
 #endif
-        if (cmask & (1u << m)) r = contact_iter(c, m, k, I);
+        const bool active = (cmask & (1u << m)) != 0;
+        if (active) {
+            D.dl = f3(LDV(m, 0), LDV(m, 1), LDV(m, 2));
+            D.da = f3(LDV(m, 3), LDV(m, 4), LDV(m, 5));
+            D.im = c_skel.body[m].inv_mass;
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+        after_loads();
+        if (active) r = contact_iter(c, m, k, D);
         publish_version(c, m, (it + 1) * ps);
 #ifdef EVM_STAMPS3
         {
             const unsigned long long dt = __builtin_amdgcn_s_memtime() - ts0;
-            if (cmask & (1u << m)) { t_type[4] += dt; n_type[4]++; } else { t_type[5] += dt; n_type[5]++; }
+            if (active) { t_type[4] += dt; n_type[4]++; } else { t_type[5] += dt; n_type[5]++; }
         }
 #endif
 #ifdef EVM_STAMPS2
@@ -1439,9 +1437,12 @@ DEV void physics_step(const Ctx &c, int flags) {
 #endif
         return r;
     };
-    auto run_entry = [&](int e, const EvmVisitC &V, const Blk42 &k, int it) -> float {
-        return (e & EVM_SCHED_CONTACT) ? run_contact(e & (EVM_SCHED_CONTACT - 1), it, k) : run_visit(V, k, it);
+    auto run_entry = [&](const EvmEntryC &V, const Blk42 &k, int it, auto &&after_loads) -> float {
+        return V.type == 4 ? run_contact(V, it, k, after_loads) : run_visit(V, k, it, after_loads);
     };
+    // a member without a cached point in any lane of the tile has nothing to prefetch
+    auto entry_slots = [&](const EvmEntryC &V) { return (V.type == 4 && !(cmask & (1u << V.a))) ? 0 : V.nslots; };
+    const EvmEntryC *stream = c_skel.wsched[W];
     // The wave's entries of all NUM_ITER sweeps form one stream (no barrier between sweeps: the version counters
     // carry the sweep number).  Three-stage software pipeline over the stream: the descriptor (scalar loads) of
     // entry j + 2 and the record (vector loads, two register blocks in ping-pong) of entry j + 1 are requested
@@ -1449,47 +1450,49 @@ DEV void physics_step(const Ctx &c, int flags) {
     if (ns == 1) {
         // a record may only be requested after the wave's previous run of the same entry has stored it; with a
         // single entry that is the immediately preceding one, so there is nothing to overlap
-        const int e = sched[0];
-        const EvmVisitC v = entry_visit(e);
+        const EvmEntryC v = stream[0];
         for (int it = 0; it < NUM_ITER; it++) {
             Blk42 k;
-            blk_load(c, v, k);
-            res = run_entry(e, v, k, it);
+            blk_load(c, v, k, entry_slots(v));
+            res = run_entry(v, k, it, [] {});
         }
     } else if (ns > 1) {
         const int T = NUM_ITER * ns;
         int f_i = 0, f_it = 0;  // stream position of the next descriptor to fetch
-        auto fetch = [&](int &e, EvmVisitC &v, int &it_) {
-            e = sched[f_i];
-            v = entry_visit(e);
+        auto fetch = [&](EvmEntryC &v, int &it_) {
+            v = stream[f_i];  // one s_load_dwordx16; its address depends on the stream position only
             it_ = f_it;
             if (++f_i == ns) { f_i = 0; f_it++; }  // runs past the end by up to three entries: fetched, never run
         };
         Blk42 ka, kb;
-        int e0, e1, e2, e3, it0, it1, it2, it3;
-        EvmVisitC v0, v1, v2, v3;
-        fetch(e0, v0, it0);
-        fetch(e1, v1, it1);
-        blk_load(c, v0, ka);
+        int it0, it1, it2, it3;
+        EvmEntryC v0, v1, v2, v3;
+        fetch(v0, it0);
+        fetch(v1, it1);
+        blk_load(c, v0, ka, entry_slots(v0));
         for (int j = 0; j < T; j += 2) {
-            blk_load(c, v1, kb);
-            fetch(e2, v2, it2);
+            blk_load(c, v1, kb, entry_slots(v1));
             {
-                const float r = run_entry(e0, v0, ka, it0);
+                const float r = run_entry(v0, ka, it0, [&] { fetch(v2, it2); });
                 if (it0 == NUM_ITER - 1) res = fmaxf(res, r);
             }
-            blk_load(c, v2, ka);
-            fetch(e3, v3, it3);
+            blk_load(c, v2, ka, entry_slots(v2));
             if (j + 1 < T) {
-                const float r = run_entry(e1, v1, kb, it1);
+                const float r = run_entry(v1, kb, it1, [&] { fetch(v3, it3); });
                 if (it1 == NUM_ITER - 1) res = fmaxf(res, r);
+            } else {
+                fetch(v3, it3);
             }
-            e0 = e2; v0 = v2; it0 = it2;
-            e1 = e3; v1 = v3; it1 = it3;
+            v0 = v2; it0 = it2;
+            v1 = v3; it1 = it3;
         }
     }
 #ifdef EVM_STAMPS2
+#ifdef EVM_STAMPS4  // whole entry stream of the wave vs the time inside its entries (difference = per-entry overhead)
+    if (c.lane == 0) { c.d.stamps[(size_t) blockIdx.x * 16 + 2 * W] = __builtin_amdgcn_s_memtime() - t_loop0; c.d.stamps[(size_t) blockIdx.x * 16 + 2 * W + 1] = t_wait + t_solve; }
+#else
     if (c.lane == 0) { c.d.stamps[(size_t) blockIdx.x * 16 + 2 * W] = t_wait; c.d.stamps[(size_t) blockIdx.x * 16 + 2 * W + 1] = t_solve; }
+#endif
 #endif
 #ifdef EVM_STAMPS3
     __syncthreads();

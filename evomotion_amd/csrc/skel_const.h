@@ -85,6 +85,19 @@ struct EvmScanC {
 #define EVM_SCHED_BARRIER 0x8000
 #define EVM_SCHED_CONTACT 0x4000   // entry = EVM_SCHED_CONTACT | member: the member's contact rows of this sweep
 
+// One entry of a wave's sweep stream, self-contained (64 bytes = one s_load_dwordx16 at an index that depends on
+// nothing but the stream position): a joint visit, or a member's contact rows (type 4, a = b = member).
+struct EvmEntryC {
+    int type, slot, a, b;
+    float imA, imB;
+    int nslots, need;
+    int psA, psB;   // EvmBodyC::per_sweep of the two bodies (version stride per sweep)
+    int iso;        // muscle slider between two isotropic bodies: scalar inverse inertias kA, kB
+    float kA, kB;
+    int pad[3];
+};
+#define EVM_MAX_WAVE_ENTRIES 48
+
 struct EvmSkelC {
     int nb, nm, nh, nf, nmus, root;
     int obs_dim, act_dim;
@@ -112,6 +125,7 @@ struct EvmSkelC {
     int nlevels;
     int nsched[EVM_NW];
     int sched[EVM_NW][EVM_MAX_SCHED];
+    EvmEntryC wsched[EVM_NW][EVM_MAX_WAVE_ENTRIES];  // the same lists as self-contained descriptors (what the kernel walks)
     int member_wave[EVM_MAX_MEMBERS];  // which wave maintains the manifold and builds the contact rows of member m
     int nscan;
     EvmScanC scan[EVM_MAX_SCAN];

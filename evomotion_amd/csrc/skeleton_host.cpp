@@ -820,8 +820,22 @@ int load_skeleton_constants(const char *path, const EvmEnvParams &prm, EvmSkelC 
         for (int w = 0; w < EVM_NW; w++) S.nsched[w] = 0;
         for (int i : topo) {
             const int w = wave_of[i];
-            if (S.nsched[w] >= EVM_MAX_SCHED) { err = "sweep schedule overflow"; return EVM_E_UNSUPPORTED; }
-            S.sched[w][S.nsched[w]++] = items[i].entry;
+            if (S.nsched[w] >= EVM_MAX_SCHED || S.nsched[w] >= EVM_MAX_WAVE_ENTRIES) { err = "sweep schedule overflow"; return EVM_E_UNSUPPORTED; }
+            EvmEntryC &e = S.wsched[w][S.nsched[w]];
+            memset(&e, 0, sizeof(e));
+            const int code = items[i].entry;
+            if (code & EVM_SCHED_CONTACT) {
+                const int m = code & (EVM_SCHED_CONTACT - 1);
+                e.type = 4; e.slot = S.sc_c + EVM_CM_STRIDE * m; e.a = e.b = m; e.nslots = EVM_CM_STRIDE;
+                e.psA = e.psB = S.body[m].per_sweep;
+            } else {
+                const EvmVisitC &v = S.visit[code];
+                e.type = v.type; e.slot = v.slot; e.a = v.a; e.b = v.b; e.imA = v.imA; e.imB = v.imB; e.nslots = v.nslots;
+                e.need = v.need; e.psA = S.body[v.a].per_sweep; e.psB = S.body[v.b].per_sweep;
+                e.iso = v.type == 2 && S.body[v.a].isotropic && S.body[v.b].isotropic;
+                e.kA = S.body[v.a].inv_inertia[0]; e.kB = S.body[v.b].inv_inertia[0];
+            }
+            S.sched[w][S.nsched[w]++] = code;
         }
         // hull scans -> waves (longest first); a hull of more than 64 vertices is cut into two slices
         S.nscan = 0;
