@@ -251,7 +251,7 @@ DEV BodyPD load_bodypd(const Ctx &c, int a, int b, float imA, float imB, const S
     k.dl = f3p(p2(LDV(a, 0), LDV(b, 0)), p2(LDV(a, 1), LDV(b, 1)), p2(LDV(a, 2), LDV(b, 2)));
     k.da = f3p(p2(LDV(a, 3), LDV(b, 3)), p2(LDV(a, 4), LDV(b, 4)), p2(LDV(a, 5), LDV(b, 5)));
     k.I = I;
-    k.im = p2(imA, imB);
+    k.im = p2(imA, -imB);  // imS of row_iter
     return k;
 }
 DEV void store_bodypd(const Ctx &c, int a, int b, const BodyPD &k) {
@@ -260,15 +260,25 @@ DEV void store_bodypd(const Ctx &c, int a, int b, const BodyPD &k) {
     LDV(b, 0) = k.dl.x.y; LDV(b, 1) = k.dl.y.y; LDV(b, 2) = k.dl.z.y;
     LDV(b, 3) = k.da.x.y; LDV(b, 4) = k.da.y.y; LDV(b, 5) = k.da.z.y;
 }
-// One Gauss-Seidel row on the pair.  With axp = (ax, -ax): c = rel x axp gives (relA x ax, -(relB x ax)), and
-// d = axp . dl + c . da gives (J_A . delta_A, J_B . delta_B) exactly as the two scalar sides did.
+// One Gauss-Seidel row on the (A, B) pair.  The B side of a row is the A side with the axis negated; the sign is folded
+// into per-visit constants instead of per-row negations: relS = (relA, -relB) (stored that way in the record) and
+// imS = (1/mA, -1/mB).  With A = (ax, ax): c = relS x A = (relA x ax, -(relB x ax)); t = A . dl gives the two linear
+// projections, the B one entering with a minus sign (a free neg_hi modifier); the updates use A * (imS * dI) and, for
+// angular rows, w * (dI, -dI) with w = I A.  Every value equals the two scalar sides' bit for bit.
 // ISO: both bodies have an isotropic inverse inertia k * identity (attach spheres), kept in Q.I.xx
 template <bool LIN, bool BOUNDED, bool ISO = false>
-DEV float row_iter(F3 ax, const F3P &rel, BodyPD &Q, float jd, float rhs, float lo, float hi, float &applied) {
-    const F3P axp = f3p(p2(ax.x, -ax.x), p2(ax.y, -ax.y), p2(ax.z, -ax.z));
-    const F3P cc = LIN ? cross(rel, axp) : axp;
-    const P2 d = LIN ? dot(axp, Q.dl) + dot(cc, Q.da) : dot(cc, Q.da);
-    const F3P ang = ISO ? cc * Q.I.xx : mul(Q.I, cc);
+DEV float row_iter(F3 ax, const F3P &relS, BodyPD &Q, float jd, float rhs, float lo, float hi, float &applied) {
+    const F3P A = f3p(p2(ax.x, ax.x), p2(ax.y, ax.y), p2(ax.z, ax.z));
+    F3P cc;
+    P2 d;
+    if (LIN) {
+        cc = cross(relS, A);
+        const P2 t = dot(A, Q.dl), u = dot(cc, Q.da);
+        d = p2(t.x, -t.y) + u;
+    } else {
+        const P2 t = dot(A, Q.da);
+        d = p2(t.x, -t.y);
+    }
     float dI = rhs;
     dI -= d.x * jd;
     dI -= d.y * jd;
@@ -278,8 +288,14 @@ DEV float row_iter(F3 ax, const F3P &rel, BodyPD &Q, float jd, float rhs, float 
         else if (sum > hi) { dI = hi - applied; applied = hi; }
         else applied = sum;
     } else applied = sum;
-    if (LIN) Q.dl = Q.dl + axp * (Q.im * dI);
-    Q.da = Q.da + ang * dI;
+    if (LIN) {
+        const F3P ang = ISO ? cc * Q.I.xx : mul(Q.I, cc);
+        Q.dl = Q.dl + A * (Q.im * dI);
+        Q.da = Q.da + ang * dI;
+    } else {
+        const F3P w = ISO ? A * Q.I.xx : mul(Q.I, A);
+        Q.da = Q.da + w * p2(dI, -dI);
+    }
     return dI;
 }
 
@@ -390,7 +406,8 @@ DEV void hinge_setup(const Ctx &c, int hi) {
         row_setup<false>(ax1, relA, relB, A, B, err, jd[5], rhs[5]);
     }
     float rec[EVM_H_STRIDE];
-    put3(rec, 0, relA); put3(rec, 3, relB); put3(rec, 6, p); put3(rec, 9, q); put3(rec, 12, ax1);
+    rec[0] = relA.x; rec[1] = -relB.x; rec[2] = relA.y; rec[3] = -relB.y; rec[4] = relA.z; rec[5] = -relB.z;  // relS pairs
+    put3(rec, 6, p); put3(rec, 9, q); put3(rec, 12, ax1);
 #pragma unroll
     for (int r = 0; r < 6; r++) { rec[15 + r] = jd[r]; rec[21 + r] = rhs[r]; rec[28 + r] = 0.f; }
     rec[27] = 0.f; rec[34] = lo; rec[35] = hi_;
@@ -398,12 +415,12 @@ DEV void hinge_setup(const Ctx &c, int hi) {
 }
 DEV float hinge_solve(const Ctx &c, const EvmEntryC &V, const Blk42 &k, BodyPD &Q) {
     const int s = V.slot;
-    const F3 relA = KV3(k, 0), relB = KV3(k, 3), p = KV3(k, 6), q = KV3(k, 9), ax1 = KV3(k, 12);
+    const F3 p = KV3(k, 6), q = KV3(k, 9), ax1 = KV3(k, 12);
     float ap[6];
 #pragma unroll
     for (int r = 0; r < 6; r++) ap[r] = KV(k, 28 + r);
     const float lo = KV(k, 34), hi_ = KV(k, 35);
-    const F3P rel = pair(relA, relB);
+    const F3P rel = f3p(p2(KV(k, 0), KV(k, 1)), p2(KV(k, 2), KV(k, 3)), p2(KV(k, 4), KV(k, 5)));  // (relA, -relB) pairs
     float res = 0.f;
     res = fmaxf(res, fabsf(row_iter<true, false>(p, rel, Q, KV(k, 15), KV(k, 21), 0.f, 0.f, ap[0])));
     res = fmaxf(res, fabsf(row_iter<true, false>(q, rel, Q, KV(k, 16), KV(k, 22), 0.f, 0.f, ap[1])));
@@ -474,7 +491,7 @@ DEV void fixed_setup(const Ctx &c, int fi) {
     row_setup<true>(l1, relA, relB, A, B, k * linDiff.y * 1.f, jd[4], rhs[4]);
     row_setup<true>(l2, relA, relB, A, B, k * linDiff.z * 1.f, jd[5], rhs[5]);
     float rec[EVM_F_STRIDE];
-    put3(rec, 0, relA); put3(rec, 3, relB);
+    rec[0] = relA.x; rec[1] = -relB.x; rec[2] = relA.y; rec[3] = -relB.y; rec[4] = relA.z; rec[5] = -relB.z;  // relS pairs
     put3(rec, 6, a0); put3(rec, 9, a1); put3(rec, 12, a2);
     put3(rec, 15, l0); put3(rec, 18, l1); put3(rec, 21, l2);
 #pragma unroll
@@ -484,11 +501,10 @@ DEV void fixed_setup(const Ctx &c, int fi) {
 }
 DEV float fixed_solve(const Ctx &c, const EvmEntryC &V, const Blk42 &k, BodyPD &Q) {
     const int s = V.slot;
-    const F3 relA = KV3(k, 0), relB = KV3(k, 3);
     float ap[6];
 #pragma unroll
     for (int r = 0; r < 6; r++) ap[r] = KV(k, 36 + r);
-    const F3P rel = pair(relA, relB);
+    const F3P rel = f3p(p2(KV(k, 0), KV(k, 1)), p2(KV(k, 2), KV(k, 3)), p2(KV(k, 4), KV(k, 5)));  // (relA, -relB) pairs
     float res = 0.f;
 #pragma unroll
     for (int r = 0; r < 3; r++)
@@ -619,8 +635,8 @@ DEV void slider_setup(const Ctx &c, int mi, bool powered_in, float target_vel) {
         row_setup<false>(ax1, relA, relB, A, B, err, jd[5], rhs[5]);
     }
     float rec[EVM_S_STRIDE];
-    put3(rec, 0, p); put3(rec, 3, q); put3(rec, 6, ax1); put3(rec, 9, p2); put3(rec, 12, q2);
-    put3(rec, 15, relA); put3(rec, 18, relB);
+    rec[0] = relA.x; rec[1] = -relB.x; rec[2] = relA.y; rec[3] = -relB.y; rec[4] = relA.z; rec[5] = -relB.z;  // relS pairs
+    put3(rec, 6, p); put3(rec, 9, q); put3(rec, 12, ax1); put3(rec, 15, p2); put3(rec, 18, q2);
 #pragma unroll
     for (int r = 0; r < 6; r++) { rec[21 + r] = jd[r]; rec[27 + r] = rhs[r]; rec[36 + r] = 0.f; }
     rec[33] = lo; rec[34] = hi_; rec[35] = 0.f; rec[42] = 0.f; rec[43] = 0.f;
@@ -630,13 +646,12 @@ DEV void slider_setup(const Ctx &c, int mi, bool powered_in, float target_vel) {
 template <bool ISO>
 DEV float slider_solve(const Ctx &c, const EvmEntryC &V, const Blk42 &kk, BodyPD &Q) {
     const int s = V.slot;
-    const F3 p = KV3(kk, 0), q = KV3(kk, 3), ax1 = KV3(kk, 6), p2_ = KV3(kk, 9), q2 = KV3(kk, 12);
-    const F3 relA = KV3(kk, 15), relB = KV3(kk, 18);
+    const F3 p = KV3(kk, 6), q = KV3(kk, 9), ax1 = KV3(kk, 12), p2_ = KV3(kk, 15), q2 = KV3(kk, 18);
     float ap[6];
 #pragma unroll
     for (int r = 0; r < 6; r++) ap[r] = KV(kk, 36 + r);
     const float lo = KV(kk, 33), hi_ = KV(kk, 34);
-    const F3P rel = pair(relA, relB);
+    const F3P rel = f3p(p2(KV(kk, 0), KV(kk, 1)), p2(KV(kk, 2), KV(kk, 3)), p2(KV(kk, 4), KV(kk, 5)));  // (relA, -relB) pairs
     float res = 0.f;
     res = fmaxf(res, fabsf(row_iter<false, false, ISO>(p, rel, Q, KV(kk, 21), KV(kk, 27), 0.f, 0.f, ap[0])));
     res = fmaxf(res, fabsf(row_iter<false, false, ISO>(q, rel, Q, KV(kk, 22), KV(kk, 28), 0.f, 0.f, ap[1])));

@@ -16,9 +16,9 @@
 // 4q..4q+3 of lane l sit together at float offset (base + 4q) * 64 + 4 l, so a wave moves a quad with one
 // global_load/store_dwordx4 (1 KiB contiguous).  The accumulated impulses ("applied") start on a quad boundary
 // because every sweep visit writes them back.
-#define EVM_H_STRIDE 36   // hinge : relA3 relB3 p3 q3 ax3 | jd6 15 | rhs6 21 | pad 27 | applied6 28 | lo 34 hi 35
-#define EVM_F_STRIDE 44   // fixed : relA3 relB3 angax9 linax9 | jd6 24 | rhs6 30 | applied6 36 | pad2
-#define EVM_S_STRIDE 44   // slider: p3 q3 ax3 p2_3 q2_3 relA3 relB3 | jd6 21 | rhs6 27 | lo 33 hi 34 | pad 35 | applied6 36 | pad2
+#define EVM_H_STRIDE 36   // hinge : relS6 = (relA, -relB) interleaved | p3 q3 ax3 | jd6 15 | rhs6 21 | pad 27 | applied6 28 | lo 34 hi 35
+#define EVM_F_STRIDE 44   // fixed : relS6 | angax9 linax9 | jd6 24 | rhs6 30 | applied6 36 | pad2
+#define EVM_S_STRIDE 44   // slider: relS6 | p3 q3 ax3 p2_3 q2_3 | jd6 21 | rhs6 27 | lo 33 hi 34 | pad 35 | applied6 36 | pad2
 #define EVM_P_STRIDE 16   // p2p   : a1_3 a2_3 | jd3 6 | rhs3 9 | applied3 12 | pad
 #define EVM_C_STRIDE 10   // contact point: rel3 lat3 | jd_n rhs_n jd_f rhs_f
 #define EVM_CM_STRIDE 48  // contact record of a member: 4 points x EVM_C_STRIDE, then 4 x (applied normal, applied lateral)
