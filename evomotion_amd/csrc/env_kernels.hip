@@ -1231,115 +1231,93 @@ DEV void observe(const Ctx &c, float *obs, float *reward, uint8_t *done) {
 #define STAMP(i) do { } while (0)
 #endif
 
-DEV void physics_step(const Ctx &c, int flags) {
-    // Four waves (one per SIMD of the CU) work on the SAME 64 environments and share the LDS tile.  Work items
-    // of a phase that touch disjoint bodies are dealt to the waves; __syncthreads() closes every phase.  The
-    // Gauss-Seidel sweep keeps Bullet's order up to exact commutation (level schedule in EvmSkelC::sched).
+// one body at the start of a step: world basis, world inverse inertia and zeroed solver deltas into the tile
+// (LDS, or its global staging copy in the split pipeline), implicit gyroscopic impulse
+DEV void body_prepare(const Ctx &c, int b, bool pending, bool any_pending, const M33 &E) {
+    const EvmBodyC &BC = c_skel.body[b];
+    const Q4 q0 = q4(GS(quat, 4 * b), GS(quat, 4 * b + 1), GS(quat, 4 * b + 2), GS(quat, 4 * b + 3));
+    M33 R = mat_from_quat(q0);
+    const F3 invI = load_f3(BC.inv_inertia);
+    // attach spheres: R diag(k, k, k) R^T = k R R^T = k * identity for any rotation.  (Their gyroscopic term
+    // w x (I w) is zero in exact arithmetic, but Bullet's implicit formula divides its rounding noise by I —
+    // about 1e-7 |w|^2 rad/s per step — and that noise is part of the reference's trajectory: it stays.)
+    S33 I;
+    if (BC.isotropic) { I.xx = invI.x; I.xy = 0.f; I.xz = 0.f; I.yy = invI.x; I.yz = 0.f; I.zz = invI.x; }
+    else I = inertia_world(R, invI);
+    if (any_pending) {
+        // first step after reset(): transform = E * M0 (non-orthonormal) and the inverse
+        // inertia tensor is still the one of the last integrated transform
+        const M33 Rp = glm_mul_basis(E, load_m33(BC.m0));
+        S33 Ip;
+        Ip.xx = GS(iinv_stale, 6 * b); Ip.xy = GS(iinv_stale, 6 * b + 1); Ip.xz = GS(iinv_stale, 6 * b + 2);
+        Ip.yy = GS(iinv_stale, 6 * b + 3); Ip.yz = GS(iinv_stale, 6 * b + 4); Ip.zz = GS(iinv_stale, 6 * b + 5);
+        if (pending) { R = Rp; I = Ip; }
+    }
+    SSC3(c_skel.sc_r + 9 * b, R.r0); SSC3(c_skel.sc_r + 9 * b + 3, R.r1); SSC3(c_skel.sc_r + 9 * b + 6, R.r2);
+    LII(b, 0) = I.xx; LII(b, 1) = I.xy; LII(b, 2) = I.xz; LII(b, 3) = I.yy; LII(b, 4) = I.yz; LII(b, 5) = I.zz;
+#pragma unroll
+    for (int k = 0; k < 6; k++) LDV(b, k) = 0.f;
+    LVER(c)[b] = 0;
+    // btRigidBody::computeGyroscopicImpulseImplicit_Body
+    const F3 omega1 = G3(ang, 3 * b);
+    const F3 idl = f3(1.f / invI.x, 1.f / invI.y, 1.f / invI.z);
+    const Q4 q = quat_from_mat(R);
+    F3 ob = quat_rotate(qinv(q), omega1);
+    const F3 ibo = f3(idl.x * ob.x, idl.y * ob.y, idl.z * ob.z);
+    const F3 f = cross(ob, ibo) * DT_F;
+    // J = Ib + (skew(ob) * Ib - skew(Ib ob)) * dt
+    const M33 s0 = m33(f3(0.f, -ob.z, ob.y), f3(ob.z, 0.f, -ob.x), f3(-ob.y, ob.x, 0.f));
+    const M33 s1 = m33(f3(0.f, -ibo.z, ibo.y), f3(ibo.z, 0.f, -ibo.x), f3(-ibo.y, ibo.x, 0.f));
+    M33 J;
+    J.r0 = f3(idl.x, 0.f, 0.f) + (f3(s0.r0.x * idl.x, s0.r0.y * idl.y, s0.r0.z * idl.z) - s1.r0) * DT_F;
+    J.r1 = f3(0.f, idl.y, 0.f) + (f3(s0.r1.x * idl.x, s0.r1.y * idl.y, s0.r1.z * idl.z) - s1.r1) * DT_F;
+    J.r2 = f3(0.f, 0.f, idl.z) + (f3(s0.r2.x * idl.x, s0.r2.y * idl.y, s0.r2.z * idl.z) - s1.r2) * DT_F;
+    const F3 c1 = col0(J), c2 = col1(J), c3 = col2(J);
+    const float det = dot(c1, cross(c2, c3));
+    F3 od = f3(0.f, 0.f, 0.f);
+    if (fabsf(det) > EVM_EPS)
+        od = f3(dot(f, cross(c2, c3)) / det, dot(c1, cross(f, c3)) / det, dot(c1, cross(c2, f)) / det);
+    ob = ob - od;
+    const F3 omega2 = quat_rotate(q, ob);
+    SSC3(c_skel.sc_ext + 3 * b, omega2 - omega1);
+}
+
+// one body at the end of a step: velocities += solver deltas, split-impulse pose correction, transform integration
+DEV void body_integrate(const Ctx &c, int b) {
+    F3 o = G3(pos, 3 * b);
+    M33 R = m33(SC3(c_skel.sc_r + 9 * b), SC3(c_skel.sc_r + 9 * b + 3), SC3(c_skel.sc_r + 9 * b + 6));
+    const F3 dl = f3(LDV(b, 0), LDV(b, 1), LDV(b, 2)), da = f3(LDV(b, 3), LDV(b, 4), LDV(b, 5));
+    F3 lin = G3(lin, 3 * b) + dl;
+    F3 ang = G3(ang, 3 * b) + da;
+    if (b < c_skel.nm) {
+        const F3 push = SC3(c_skel.sc_pt + 6 * b), turn = SC3(c_skel.sc_pt + 6 * b + 3);
+        const bool nz = push.x != 0.f || push.y != 0.f || push.z != 0.f || turn.x != 0.f || turn.y != 0.f || turn.z != 0.f;
+        if (__any(nz)) {
+            F3 o2; Q4 q2;
+            integrate_transform(o, R, push, turn * SPLIT_TURN_ERP_F, DT_F, o2, q2);
+            if (nz) { o = o2; R = mat_from_quat(q2); }
+        }
+    }
+    lin = lin + f3(0.f, c_skel.body[b].ext_force_y, 0.f);
+    ang = ang + SC3(c_skel.sc_ext + 3 * b);
+    F3 o2; Q4 q2;
+    integrate_transform(o, R, lin, ang, DT_F, o2, q2);
+    S3(pos, 3 * b, o2);
+    GS(quat, 4 * b) = q2.x; GS(quat, 4 * b + 1) = q2.y; GS(quat, 4 * b + 2) = q2.z; GS(quat, 4 * b + 3) = q2.w;
+    S3(lin, 3 * b, lin);
+    S3(ang, 3 * b, ang);
+    if (b < c_skel.nm) SSC3(c_skel.sc_ms + 3 * b, o2 + lin * (0.f - DT_F));  // btDefaultMotionState, one step behind
+}
+
+// the NUM_ITER projected Gauss-Seidel sweeps of one tile (whole workgroup; tile state in LDS), then the per-constraint
+// readbacks.  cmask: members with a cached contact point in any lane of the tile.
+DEV void sweeps_run(const Ctx &c, bool any_pending, unsigned cmask, int ncontact) {
     const int W = c.wave;
-    STAMP(0);
 #ifdef EVM_STAMPS3
     if (W == 0 && c.lane < 16) c.d.stamps[(size_t) blockIdx.x * 16 + c.lane] = 0;
     unsigned long long t_type[6] = {0, 0, 0, 0, 0, 0};
     unsigned n_type[6] = {0, 0, 0, 0, 0, 0};
 #endif
-    const bool pending = (flags & EVM_FLAG_PENDING) != 0;
-    const bool powered = (flags & EVM_FLAG_POWERED) != 0;
-    const bool any_pending = __any(pending);
-    M33 E;
-    if (any_pending)
-        E = m33(f3(GS(E, 0), GS(E, 1), GS(E, 2)), f3(GS(E, 3), GS(E, 4), GS(E, 5)), f3(GS(E, 6), GS(E, 7), GS(E, 8)));
-
-    // ---- bodies: world basis, inverse inertia tile -> LDS, implicit gyroscopic impulse, zero deltas ----
-    for (int b = W; b < c_skel.nb; b += EVM_NW) {
-        const EvmBodyC &BC = c_skel.body[b];
-        const Q4 q0 = q4(GS(quat, 4 * b), GS(quat, 4 * b + 1), GS(quat, 4 * b + 2), GS(quat, 4 * b + 3));
-        M33 R = mat_from_quat(q0);
-        const F3 invI = load_f3(BC.inv_inertia);
-        // attach spheres: R diag(k, k, k) R^T = k R R^T = k * identity for any rotation.  (Their gyroscopic term
-        // w x (I w) is zero in exact arithmetic, but Bullet's implicit formula divides its rounding noise by I —
-        // about 1e-7 |w|^2 rad/s per step — and that noise is part of the reference's trajectory: it stays.)
-        S33 I;
-        if (BC.isotropic) { I.xx = invI.x; I.xy = 0.f; I.xz = 0.f; I.yy = invI.x; I.yz = 0.f; I.zz = invI.x; }
-        else I = inertia_world(R, invI);
-        if (any_pending) {
-            // first step after reset(): transform = E * M0 (non-orthonormal) and the inverse
-            // inertia tensor is still the one of the last integrated transform
-            const M33 Rp = glm_mul_basis(E, load_m33(BC.m0));
-            S33 Ip;
-            Ip.xx = GS(iinv_stale, 6 * b); Ip.xy = GS(iinv_stale, 6 * b + 1); Ip.xz = GS(iinv_stale, 6 * b + 2);
-            Ip.yy = GS(iinv_stale, 6 * b + 3); Ip.yz = GS(iinv_stale, 6 * b + 4); Ip.zz = GS(iinv_stale, 6 * b + 5);
-            if (pending) { R = Rp; I = Ip; }
-        }
-        SSC3(c_skel.sc_r + 9 * b, R.r0); SSC3(c_skel.sc_r + 9 * b + 3, R.r1); SSC3(c_skel.sc_r + 9 * b + 6, R.r2);
-        LII(b, 0) = I.xx; LII(b, 1) = I.xy; LII(b, 2) = I.xz; LII(b, 3) = I.yy; LII(b, 4) = I.yz; LII(b, 5) = I.zz;
-#pragma unroll
-        for (int k = 0; k < 6; k++) LDV(b, k) = 0.f;
-        LVER(c)[b] = 0;
-        // btRigidBody::computeGyroscopicImpulseImplicit_Body
-        const F3 omega1 = G3(ang, 3 * b);
-        const F3 idl = f3(1.f / invI.x, 1.f / invI.y, 1.f / invI.z);
-        const Q4 q = quat_from_mat(R);
-        F3 ob = quat_rotate(qinv(q), omega1);
-        const F3 ibo = f3(idl.x * ob.x, idl.y * ob.y, idl.z * ob.z);
-        const F3 f = cross(ob, ibo) * DT_F;
-        // J = Ib + (skew(ob) * Ib - skew(Ib ob)) * dt
-        const M33 s0 = m33(f3(0.f, -ob.z, ob.y), f3(ob.z, 0.f, -ob.x), f3(-ob.y, ob.x, 0.f));
-        const M33 s1 = m33(f3(0.f, -ibo.z, ibo.y), f3(ibo.z, 0.f, -ibo.x), f3(-ibo.y, ibo.x, 0.f));
-        M33 J;
-        J.r0 = f3(idl.x, 0.f, 0.f) + (f3(s0.r0.x * idl.x, s0.r0.y * idl.y, s0.r0.z * idl.z) - s1.r0) * DT_F;
-        J.r1 = f3(0.f, idl.y, 0.f) + (f3(s0.r1.x * idl.x, s0.r1.y * idl.y, s0.r1.z * idl.z) - s1.r1) * DT_F;
-        J.r2 = f3(0.f, 0.f, idl.z) + (f3(s0.r2.x * idl.x, s0.r2.y * idl.y, s0.r2.z * idl.z) - s1.r2) * DT_F;
-        const F3 c1 = col0(J), c2 = col1(J), c3 = col2(J);
-        const float det = dot(c1, cross(c2, c3));
-        F3 od = f3(0.f, 0.f, 0.f);
-        if (fabsf(det) > EVM_EPS)
-            od = f3(dot(f, cross(c2, c3)) / det, dot(c1, cross(f, c3)) / det, dot(c1, cross(c2, f)) / det);
-        ob = ob - od;
-        const F3 omega2 = quat_rotate(q, ob);
-        SSC3(c_skel.sc_ext + 3 * b, omega2 - omega1);
-    }
-    __syncthreads();
-    STAMP(1);
-
-    // ---- collision: hull vs floor plane, persistent manifolds (members dealt to waves by hull size) ----
-    for (int i = 0; i < c_skel.nscan; i++)
-        if (c_skel.scan[i].wave == W) hull_scan(c, i);
-    STAMP(9);   // wave 0: its own scans done
-    __syncthreads();
-    STAMP(10);  // all scans done
-    for (int m = 0; m < c_skel.nm; m++)
-        if (c_skel.member_wave[m] == W && c_skel.member[m].contact_response) contact_update(c, m);
-    STAMP(11);  // wave 0: its manifolds done
-    __syncthreads();
-    int ncontact = 0;
-    unsigned cmask = 0;  // wave-uniform: members with a cached point in any lane
-    for (int m = 0; m < c_skel.nm; m++) {
-        const int n = GS(mfn, m);
-        ncontact += n;
-        if (__any(n > 0)) cmask |= 1u << m;
-    }
-    STAMP(2);
-
-    // ---- joint rows: every constraint's record is independent of the others ----
-    for (int v = W; v < c_skel.nvisit; v += EVM_NW) {
-        const EvmVisitC &V = c_skel.visit[v];
-        switch (V.type) {
-            case 0: hinge_setup(c, (V.slot - c_skel.sc_h) / EVM_H_STRIDE); break;
-            case 1: fixed_setup(c, (V.slot - c_skel.sc_f) / EVM_F_STRIDE); break;
-            case 2: { const int mi = (V.slot - c_skel.sc_s) / EVM_S_STRIDE; slider_setup(c, mi, powered, GS(target, mi)); break; }
-            default: { const int k = (V.slot - c_skel.sc_p) / EVM_P_STRIDE; p2p_setup(c, k >> 1, k & 1); break; }
-        }
-    }
-    STAMP(3);
-    // ---- contact rows: setup + warm start + split impulse (touches the member's own deltas only) ----
-    for (int m = 0; m < c_skel.nm; m++) {
-        if (c_skel.member_wave[m] != W) continue;
-        if (cmask & (1u << m)) contact_setup(c, m, GS(mfn, m));
-        else { SSC3(c_skel.sc_pt + 6 * m, f3(0.f, 0.f, 0.f)); SSC3(c_skel.sc_pt + 6 * m + 3, f3(0.f, 0.f, 0.f)); }
-    }
-    __syncthreads();
-    STAMP(4);
-
     // ---- projected Gauss-Seidel sweeps ----
     // A wave walks its slice of the level schedule (EvmSkelC::sched); a workgroup barrier closes each level.
     const int ns = c_skel.nsched[W];
@@ -1542,33 +1520,69 @@ DEV void physics_step(const Ctx &c, int flags) {
         SC(c_skel.sc_mobs + 4 * mi + 3) = RC(c_skel.sc_p + EVM_P_STRIDE * (2 * mi + 1), 14);
     }
     STAMP(6);
+}
+
+DEV void physics_step(const Ctx &c, int flags) {
+    // Four waves (one per SIMD of the CU) work on the SAME 64 environments and share the LDS tile.  Work items
+    // of a phase that touch disjoint bodies are dealt to the waves; __syncthreads() closes every phase.  The
+    // Gauss-Seidel sweep keeps Bullet's order up to exact commutation (level schedule in EvmSkelC::sched).
+    const int W = c.wave;
+    STAMP(0);
+    const bool pending = (flags & EVM_FLAG_PENDING) != 0;
+    const bool powered = (flags & EVM_FLAG_POWERED) != 0;
+    const bool any_pending = __any(pending);
+    M33 E;
+    if (any_pending)
+        E = m33(f3(GS(E, 0), GS(E, 1), GS(E, 2)), f3(GS(E, 3), GS(E, 4), GS(E, 5)), f3(GS(E, 6), GS(E, 7), GS(E, 8)));
+
+    // ---- bodies: world basis, inverse inertia tile -> LDS, implicit gyroscopic impulse, zero deltas ----
+    for (int b = W; b < c_skel.nb; b += EVM_NW) body_prepare(c, b, pending, any_pending, E);
+    __syncthreads();
+    STAMP(1);
+
+    // ---- collision: hull vs floor plane, persistent manifolds (members dealt to waves by hull size) ----
+    for (int i = 0; i < c_skel.nscan; i++)
+        if (c_skel.scan[i].wave == W) hull_scan(c, i);
+    STAMP(9);   // wave 0: its own scans done
+    __syncthreads();
+    STAMP(10);  // all scans done
+    for (int m = 0; m < c_skel.nm; m++)
+        if (c_skel.member_wave[m] == W && c_skel.member[m].contact_response) contact_update(c, m);
+    STAMP(11);  // wave 0: its manifolds done
+    __syncthreads();
+    int ncontact = 0;
+    unsigned cmask = 0;  // wave-uniform: members with a cached point in any lane
+    for (int m = 0; m < c_skel.nm; m++) {
+        const int n = GS(mfn, m);
+        ncontact += n;
+        if (__any(n > 0)) cmask |= 1u << m;
+    }
+    STAMP(2);
+
+    // ---- joint rows: every constraint's record is independent of the others ----
+    for (int v = W; v < c_skel.nvisit; v += EVM_NW) {
+        const EvmVisitC &V = c_skel.visit[v];
+        switch (V.type) {
+            case 0: hinge_setup(c, (V.slot - c_skel.sc_h) / EVM_H_STRIDE); break;
+            case 1: fixed_setup(c, (V.slot - c_skel.sc_f) / EVM_F_STRIDE); break;
+            case 2: { const int mi = (V.slot - c_skel.sc_s) / EVM_S_STRIDE; slider_setup(c, mi, powered, GS(target, mi)); break; }
+            default: { const int k = (V.slot - c_skel.sc_p) / EVM_P_STRIDE; p2p_setup(c, k >> 1, k & 1); break; }
+        }
+    }
+    STAMP(3);
+    // ---- contact rows: setup + warm start + split impulse (touches the member's own deltas only) ----
+    for (int m = 0; m < c_skel.nm; m++) {
+        if (c_skel.member_wave[m] != W) continue;
+        if (cmask & (1u << m)) contact_setup(c, m, GS(mfn, m));
+        else { SSC3(c_skel.sc_pt + 6 * m, f3(0.f, 0.f, 0.f)); SSC3(c_skel.sc_pt + 6 * m + 3, f3(0.f, 0.f, 0.f)); }
+    }
+    __syncthreads();
+    STAMP(4);
+
+    sweeps_run(c, any_pending, cmask, ncontact);
 
     // ---- write back velocities, split-impulse pose correction, integrate transforms ----
-    for (int b = W; b < c_skel.nb; b += EVM_NW) {
-        F3 o = G3(pos, 3 * b);
-        M33 R = m33(SC3(c_skel.sc_r + 9 * b), SC3(c_skel.sc_r + 9 * b + 3), SC3(c_skel.sc_r + 9 * b + 6));
-        const F3 dl = f3(LDV(b, 0), LDV(b, 1), LDV(b, 2)), da = f3(LDV(b, 3), LDV(b, 4), LDV(b, 5));
-        F3 lin = G3(lin, 3 * b) + dl;
-        F3 ang = G3(ang, 3 * b) + da;
-        if (b < c_skel.nm) {
-            const F3 push = SC3(c_skel.sc_pt + 6 * b), turn = SC3(c_skel.sc_pt + 6 * b + 3);
-            const bool nz = push.x != 0.f || push.y != 0.f || push.z != 0.f || turn.x != 0.f || turn.y != 0.f || turn.z != 0.f;
-            if (__any(nz)) {
-                F3 o2; Q4 q2;
-                integrate_transform(o, R, push, turn * SPLIT_TURN_ERP_F, DT_F, o2, q2);
-                if (nz) { o = o2; R = mat_from_quat(q2); }
-            }
-        }
-        lin = lin + f3(0.f, c_skel.body[b].ext_force_y, 0.f);
-        ang = ang + SC3(c_skel.sc_ext + 3 * b);
-        F3 o2; Q4 q2;
-        integrate_transform(o, R, lin, ang, DT_F, o2, q2);
-        S3(pos, 3 * b, o2);
-        GS(quat, 4 * b) = q2.x; GS(quat, 4 * b + 1) = q2.y; GS(quat, 4 * b + 2) = q2.z; GS(quat, 4 * b + 3) = q2.w;
-        S3(lin, 3 * b, lin);
-        S3(ang, 3 * b, ang);
-        if (b < c_skel.nm) SSC3(c_skel.sc_ms + 3 * b, o2 + lin * (0.f - DT_F));  // btDefaultMotionState, one step behind
-    }
+    for (int b = W; b < c_skel.nb; b += EVM_NW) body_integrate(c, b);
     __syncthreads();
     STAMP(7);
 }
