@@ -211,8 +211,11 @@ DEV void plane_space(F3 n, F3 &p, F3 &q) {
 }
 
 // btTransformUtil::integrateTransform on (origin, basis) -> (origin', unit quaternion')
+// position part of btTransformUtil::integrateTransform, with the contraction spelled out so that every kernel that
+// evaluates it (the integrating wave, and the sweeps kernel predicting the root's motion state) gets the same bits
+DEV F3 integ_pos(F3 o, F3 lin, float dt) { return f3(fmaf(lin.x, dt, o.x), fmaf(lin.y, dt, o.y), fmaf(lin.z, dt, o.z)); }
 DEV void integrate_transform(F3 o, const M33 &R, F3 lin, F3 ang, float dt, F3 &o2, Q4 &q2) {
-    o2 = o + lin * dt;
+    o2 = integ_pos(o, lin, dt);
     const float a2 = len2(ang);
     float fAngle = 0.f;
     if (a2 > EVM_EPS) fAngle = sqrtf(a2);
@@ -231,5 +234,50 @@ DEV void integrate_transform(F3 o, const M33 &R, F3 lin, F3 ang, float dt, F3 &o
     }
     q2 = p;  // (a zero-length product cannot occur for finite inputs: |dorn| ~ 1, |orn0| ~ 1)
 }
+
+// ---- no-contraction copies ------------------------------------------------------------------------------------
+// btRigidBody::computeGyroscopicImpulseImplicit_Body is ill-conditioned for the (isotropic) attach spheres: the exact
+// torque w x (I w) is zero, what the formula returns is its rounding noise divided by I — about 1e-7 |w|^2 rad/s, i.e.
+// 1e-3 rad/s on a sphere spinning at 100 rad/s.  Which noise comes out depends on where the compiler fuses multiplies
+// into adds, and that differs from kernel to kernel.  These copies are compiled without contraction (like the CPU
+// oracle), so every kernel that prepares a body produces the same impulse.
+#pragma clang fp contract(off)
+namespace nc {
+DEV F3 add(F3 a, F3 b) { return f3(a.x + b.x, a.y + b.y, a.z + b.z); }
+DEV F3 sub(F3 a, F3 b) { return f3(a.x - b.x, a.y - b.y, a.z - b.z); }
+DEV F3 scale(F3 a, float s) { return f3(a.x * s, a.y * s, a.z * s); }
+DEV float dot(F3 a, F3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+DEV F3 cross(F3 a, F3 b) { return f3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+DEV Q4 qmul(Q4 a, Q4 b) {
+    return q4(a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y, a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z,
+              a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x, a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z);
+}
+DEV Q4 qmulv(Q4 q, F3 w) {
+    return q4(q.w * w.x + q.y * w.z - q.z * w.y, q.w * w.y + q.z * w.x - q.x * w.z, q.w * w.z + q.x * w.y - q.y * w.x,
+              -q.x * w.x - q.y * w.y - q.z * w.z);
+}
+DEV F3 quat_rotate(Q4 r, F3 v) {
+    const Q4 t = nc::qmul(nc::qmulv(r, v), q4(-r.x, -r.y, -r.z, r.w));
+    return f3(t.x, t.y, t.z);
+}
+// omega2 - omega1 of computeGyroscopicImpulseImplicit_Body; q = the body's rotation, idl = local inertia diagonal
+DEV F3 gyro_impulse(Q4 q, F3 idl, F3 omega1, float dt) {
+    F3 ob = nc::quat_rotate(q4(-q.x, -q.y, -q.z, q.w), omega1);
+    const F3 ibo = f3(idl.x * ob.x, idl.y * ob.y, idl.z * ob.z);
+    const F3 f = nc::scale(nc::cross(ob, ibo), dt);
+    // J = Ib + (skew(ob) * Ib - skew(Ib ob)) * dt, rows
+    const F3 j0 = nc::add(f3(idl.x, 0.f, 0.f), nc::scale(nc::sub(f3(0.f * idl.x, -ob.z * idl.y, ob.y * idl.z), f3(0.f, -ibo.z, ibo.y)), dt));
+    const F3 j1 = nc::add(f3(0.f, idl.y, 0.f), nc::scale(nc::sub(f3(ob.z * idl.x, 0.f * idl.y, -ob.x * idl.z), f3(ibo.z, 0.f, -ibo.x)), dt));
+    const F3 j2 = nc::add(f3(0.f, 0.f, idl.z), nc::scale(nc::sub(f3(-ob.y * idl.x, ob.x * idl.y, 0.f * idl.z), f3(-ibo.y, ibo.x, 0.f)), dt));
+    const F3 c1 = f3(j0.x, j1.x, j2.x), c2 = f3(j0.y, j1.y, j2.y), c3 = f3(j0.z, j1.z, j2.z);
+    const float det = nc::dot(c1, nc::cross(c2, c3));
+    F3 od = f3(0.f, 0.f, 0.f);
+    if (fabsf(det) > 1.1920929e-07f)
+        od = f3(nc::dot(f, nc::cross(c2, c3)) / det, nc::dot(c1, nc::cross(f, c3)) / det, nc::dot(c1, nc::cross(c2, f)) / det);
+    ob = nc::sub(ob, od);
+    return nc::sub(nc::quat_rotate(q, ob), omega1);
+}
+}  // namespace nc
+#pragma clang fp contract(fast)
 
 }  // namespace evm

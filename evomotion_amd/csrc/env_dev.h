@@ -29,11 +29,14 @@ struct EnvDev {
     float *diag;                    // [2][n]
     unsigned long long *stamps;     // [n/64][16] phase clock stamps (diagnostic builds with -DEVM_STAMPS only)
     int *stat;                      // [2][n]     do_step transitions emitted, resets started (rollout form)
+    float *gtile;                   // [n/64][tile_floats] global staging copy of the LDS tile (split pipeline)
+    int tile_floats;                // step_lds_bytes / 4
 };
 
 hipError_t upload_skeleton(const EvmSkelC *h, hipStream_t s);
 size_t step_lds_bytes(int nb, int nscan);
-hipError_t launch_step(const EnvDev &d, size_t lds_bytes, int mode, const float *action, float *obs, float *reward,
+// split = 1: pre / sweeps / post kernels (the throughput phases spread over the whole chip); 0: one monolithic kernel
+hipError_t launch_step(const EnvDev &d, size_t lds_bytes, int split, int mode, const float *action, float *obs, float *reward,
                        uint8_t *done, uint8_t *valid, const uint8_t *mask, hipStream_t s);
 hipError_t launch_repose(const EnvDev &d, const uint8_t *mask, hipStream_t s);
 hipError_t launch_init(const EnvDev &d, uint64_t seed, hipStream_t s);

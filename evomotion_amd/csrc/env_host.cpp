@@ -45,6 +45,7 @@ struct EvmEnv {
     bool timing;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pairs;  // one pair per timed launch
     size_t ev_used;
+    int split;  // 1: split pipeline (default), 0: monolithic step kernel (EVM_MONOLITHIC=1 in the environment: A/B runs)
 };
 
 static const EvmEnv *g_skel_owner = nullptr;
@@ -99,6 +100,7 @@ int evm_env_create(const char *skeleton_path, int n_envs, int device, uint64_t s
     env->timing = false;
     env->timed_launches = 0;
     env->ev_used = 0;
+    { const char *m = getenv("EVM_MONOLITHIC"); env->split = (m && m[0] == '1') ? 0 : 1; }
     std::string err;
     int rc = evm::load_skeleton_constants(skeleton_path, prm, env->skel, err);
     if (rc != EVM_OK) { delete env; return fail(rc, err); }
@@ -109,6 +111,7 @@ int evm_env_create(const char *skeleton_path, int n_envs, int device, uint64_t s
 
     const size_t n = ((size_t) n_envs + 63) / 64 * 64;
     env->d.n = (int) n;
+    env->d.tile_floats = (int) (evm::step_lds_bytes(S.nb, S.nscan) / 4);
     env->d.n_real = n_envs;
     struct Seg { void **p; size_t count; };
     std::vector<Seg> segs = {
@@ -118,7 +121,8 @@ int evm_env_create(const char *skeleton_path, int n_envs, int device, uint64_t s
         {(void **) &env->d.flags, 1}, {(void **) &env->d.curr_step, 1}, {(void **) &env->d.remaining, 1},
         {(void **) &env->d.settle_left, 1}, {(void **) &env->d.E, 9}, {(void **) &env->d.iinv_stale, 6u * S.nb},
         {(void **) &env->d.mt, 624}, {(void **) &env->d.mt_idx, 1}, {(void **) &env->d.scratch, (size_t) S.sc_total},
-        {(void **) &env->d.diag, 2}, {(void **) &env->d.stat, 2}, {(void **) &env->d.stamps, 1}};  // stamps: 16 u64 per tile = 128 B <= 256 B
+        {(void **) &env->d.diag, 2}, {(void **) &env->d.stat, 2}, {(void **) &env->d.stamps, 1},
+        {(void **) &env->d.gtile, evm::step_lds_bytes(S.nb, S.nscan) / 4 / 64}};  // stamps: 16 u64 per tile = 128 B <= 256 B
     size_t total = 0;
     for (auto &s : segs) total += s.count * n * 4;
     he = hipMalloc(&env->arena, total);
@@ -177,7 +181,7 @@ static int step_launch(EvmEnv *env, int mode, const float *a, float *obs, float 
         }
         HIP_TRY(hipEventRecord(env->ev_pairs[env->ev_used].first, s));
     }
-    HIP_TRY(evm::launch_step(env->d, evm::step_lds_bytes(env->skel.nb, env->skel.nscan), mode, a, obs, rew, done, valid, mask, s));
+    HIP_TRY(evm::launch_step(env->d, evm::step_lds_bytes(env->skel.nb, env->skel.nscan), env->split, mode, a, obs, rew, done, valid, mask, s));
     if (env->timing) {
         HIP_TRY(hipEventRecord(env->ev_pairs[env->ev_used].second, s));
         env->ev_used++;

@@ -774,11 +774,10 @@ DEV void store_mp(const Ctx &c, int m, int slot, const MPoint &p) {
 // multiply/add sequence.  Two vertices per packed instruction (pair layout of EvmSkelC::hull); the coordinates
 // are wave-uniform and arrive as wide scalar loads, four pairs per trip.  Even and odd vertices keep separate
 // running minima, merged at the end (lower value first, then lower index).
-DEV void hull_scan(const Ctx &c, int si) {
+DEV void hull_scan(const Ctx &c, int si, F3 r1) {
     const EvmScanC &S = c_skel.scan[si];
     const int m = S.member;
     const EvmMemberC &MB = c_skel.member[m];
-    const F3 r1 = SC3(c_skel.sc_r + 9 * m + 3);
     const float oy = GS(pos, 3 * m + 1);
     const P2 rx = p2(r1.x, r1.x), ry = p2(r1.y, r1.y), rz = p2(r1.z, r1.z), oyp = p2(oy, oy);
     const float *hp = c_skel.hull + 3 * (MB.hull_off + S.begin);  // 6 floats per vertex pair
@@ -1168,46 +1167,45 @@ DEV void euler_zyx(Q4 q, float &yaw, float &pitch, float &roll) {
     }
 }
 
-DEV void observe(const Ctx &c, float *obs, float *reward, uint8_t *done) {
+// the 19-value block of member m (proprioception_state.cpp:23-58,86-112); root_ms = the root's motion-state origin
+DEV void observe_member(const Ctx &c, int m, float *obs, F3 root_ms) {
     float *o = obs + (size_t) c.env * c_skel.obs_dim;
     const float PI_F = (float) 3.14159265358979323846;
+    const int k = 19 * c_skel.state_index[m];
+    const Q4 qs = q4(GS(quat, 4 * m), GS(quat, 4 * m + 1), GS(quat, 4 * m + 2), GS(quat, 4 * m + 3));
+    const Q4 q = quat_from_mat(mat_from_quat(qs));  // getWorldTransform().getRotation()
+    float yaw, pitch, roll;
+    euler_zyx(q, yaw, pitch, roll);
+    const F3 lv = G3(lin, 3 * m), av = G3(ang, 3 * m);
+    const F3 ll = G3(hist, 6 * m), la = G3(hist, 6 * m + 3);
+    const F3 dl = ll - lv, da = la - av;
+    S3(hist, 6 * m, lv); S3(hist, 6 * m + 3, av);
+    o[k + 0] = yaw / PI_F; o[k + 1] = pitch / PI_F; o[k + 2] = roll / PI_F;
+    o[k + 3] = lv.x; o[k + 4] = lv.y; o[k + 5] = lv.z;
+    o[k + 6] = av.x / PI_F; o[k + 7] = av.y / PI_F; o[k + 8] = av.z / PI_F;
+    o[k + 9] = dl.x; o[k + 10] = dl.y; o[k + 11] = dl.z;
+    o[k + 12] = da.x / PI_F; o[k + 13] = da.y / PI_F; o[k + 14] = da.z / PI_F;
+    o[k + 15] = 0.f;  // floor_touched is never raised after construction (proprioception_state.cpp:18,39-40)
+    if (m == c_skel.root) {
+        const F3 p = G3(pos, 3 * m);
+        o[k + 16] = logf(sqrtf(dot(p, p)) + 1.f);
+        o[k + 17] = p.y;
+        o[k + 18] = atan2f(p.z, p.x);
+    } else {
+        const F3 d = SC3(c_skel.sc_ms + 3 * m) - root_ms;
+        o[k + 16] = d.x; o[k + 17] = d.y; o[k + 18] = d.z;
+    }
+}
+DEV void observe_muscle(const Ctx &c, int mi, float *obs) {  // MuscleState (proprioception_state.cpp:124-129)
+    float *o = obs + (size_t) c.env * c_skel.obs_dim + 19 * c_skel.nm + 4 * mi;
+    o[0] = SC(c_skel.sc_mobs + 4 * mi + 0);
+    o[1] = SC(c_skel.sc_mobs + 4 * mi + 1);
+    o[2] = SC(c_skel.sc_mobs + 4 * mi + 2);
+    o[3] = SC(c_skel.sc_mobs + 4 * mi + 3);
+}
+// reward, counters, termination (robot_walk.cpp:61-72 / robot_jump.cpp:71-84): one writer per env
+DEV void observe_tail(const Ctx &c, float *reward, uint8_t *done) {
     const int root = c_skel.root;
-    const F3 root_ms = SC3(c_skel.sc_ms + 3 * root);
-    for (int si = c.wave; si < c_skel.nm; si += EVM_NW) {  // state blocks are independent: dealt to the waves
-        const int m = c_skel.state_member[si];
-        const int k = 19 * si;
-        const Q4 qs = q4(GS(quat, 4 * m), GS(quat, 4 * m + 1), GS(quat, 4 * m + 2), GS(quat, 4 * m + 3));
-        const Q4 q = quat_from_mat(mat_from_quat(qs));  // getWorldTransform().getRotation()
-        float yaw, pitch, roll;
-        euler_zyx(q, yaw, pitch, roll);
-        const F3 lv = G3(lin, 3 * m), av = G3(ang, 3 * m);
-        const F3 ll = G3(hist, 6 * m), la = G3(hist, 6 * m + 3);
-        const F3 dl = ll - lv, da = la - av;
-        S3(hist, 6 * m, lv); S3(hist, 6 * m + 3, av);
-        o[k + 0] = yaw / PI_F; o[k + 1] = pitch / PI_F; o[k + 2] = roll / PI_F;
-        o[k + 3] = lv.x; o[k + 4] = lv.y; o[k + 5] = lv.z;
-        o[k + 6] = av.x / PI_F; o[k + 7] = av.y / PI_F; o[k + 8] = av.z / PI_F;
-        o[k + 9] = dl.x; o[k + 10] = dl.y; o[k + 11] = dl.z;
-        o[k + 12] = da.x / PI_F; o[k + 13] = da.y / PI_F; o[k + 14] = da.z / PI_F;
-        o[k + 15] = 0.f;  // floor_touched is never raised after construction (proprioception_state.cpp:18,39-40)
-        if (m == root) {
-            const F3 p = G3(pos, 3 * m);
-            o[k + 16] = logf(sqrtf(dot(p, p)) + 1.f);
-            o[k + 17] = p.y;
-            o[k + 18] = atan2f(p.z, p.x);
-        } else {
-            const F3 d = SC3(c_skel.sc_ms + 3 * m) - root_ms;
-            o[k + 16] = d.x; o[k + 17] = d.y; o[k + 18] = d.z;
-        }
-    }
-    for (int mi = c.wave; mi < c_skel.nmus; mi += EVM_NW) {
-        const int k = 19 * c_skel.nm + 4 * mi;
-        o[k + 0] = SC(c_skel.sc_mobs + 4 * mi + 0);
-        o[k + 1] = SC(c_skel.sc_mobs + 4 * mi + 1);
-        o[k + 2] = SC(c_skel.sc_mobs + 4 * mi + 2);
-        o[k + 3] = SC(c_skel.sc_mobs + 4 * mi + 3);
-    }
-    if (c.wave != 0) return;
     // robot_walk.cpp:61-68: the root's z velocity; robot_jump.cpp:71-80: max(vy, 0) + vz and a strict fail test
     const float vz = c_skel.env_kind == 1 ? fmaxf(GS(lin, 3 * root + 1), 0.f) + GS(lin, 3 * root + 2) : GS(lin, 3 * root + 2);
     int remaining = c.d.remaining[c.env], cs = c.d.curr_step[c.env];
@@ -1219,6 +1217,12 @@ DEV void observe(const Ctx &c, float *obs, float *reward, uint8_t *done) {
     c.d.curr_step[c.env] = cs + 1;
     reward[c.env] = vz;
     done[c.env] = (win | fail) ? 1 : 0;
+}
+DEV void observe(const Ctx &c, float *obs, float *reward, uint8_t *done) {  // monolithic kernel: dealt to its waves
+    const F3 root_ms = SC3(c_skel.sc_ms + 3 * c_skel.root);
+    for (int m = c.wave; m < c_skel.nm; m += EVM_NW) observe_member(c, m, obs, root_ms);
+    for (int mi = c.wave; mi < c_skel.nmus; mi += EVM_NW) observe_muscle(c, mi, obs);
+    if (c.wave == 0) observe_tail(c, reward, done);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1258,28 +1262,9 @@ DEV void body_prepare(const Ctx &c, int b, bool pending, bool any_pending, const
 #pragma unroll
     for (int k = 0; k < 6; k++) LDV(b, k) = 0.f;
     LVER(c)[b] = 0;
-    // btRigidBody::computeGyroscopicImpulseImplicit_Body
-    const F3 omega1 = G3(ang, 3 * b);
+    // btRigidBody::computeGyroscopicImpulseImplicit_Body (contraction-free: see dev_math.h, namespace nc)
     const F3 idl = f3(1.f / invI.x, 1.f / invI.y, 1.f / invI.z);
-    const Q4 q = quat_from_mat(R);
-    F3 ob = quat_rotate(qinv(q), omega1);
-    const F3 ibo = f3(idl.x * ob.x, idl.y * ob.y, idl.z * ob.z);
-    const F3 f = cross(ob, ibo) * DT_F;
-    // J = Ib + (skew(ob) * Ib - skew(Ib ob)) * dt
-    const M33 s0 = m33(f3(0.f, -ob.z, ob.y), f3(ob.z, 0.f, -ob.x), f3(-ob.y, ob.x, 0.f));
-    const M33 s1 = m33(f3(0.f, -ibo.z, ibo.y), f3(ibo.z, 0.f, -ibo.x), f3(-ibo.y, ibo.x, 0.f));
-    M33 J;
-    J.r0 = f3(idl.x, 0.f, 0.f) + (f3(s0.r0.x * idl.x, s0.r0.y * idl.y, s0.r0.z * idl.z) - s1.r0) * DT_F;
-    J.r1 = f3(0.f, idl.y, 0.f) + (f3(s0.r1.x * idl.x, s0.r1.y * idl.y, s0.r1.z * idl.z) - s1.r1) * DT_F;
-    J.r2 = f3(0.f, 0.f, idl.z) + (f3(s0.r2.x * idl.x, s0.r2.y * idl.y, s0.r2.z * idl.z) - s1.r2) * DT_F;
-    const F3 c1 = col0(J), c2 = col1(J), c3 = col2(J);
-    const float det = dot(c1, cross(c2, c3));
-    F3 od = f3(0.f, 0.f, 0.f);
-    if (fabsf(det) > EVM_EPS)
-        od = f3(dot(f, cross(c2, c3)) / det, dot(c1, cross(f, c3)) / det, dot(c1, cross(c2, f)) / det);
-    ob = ob - od;
-    const F3 omega2 = quat_rotate(q, ob);
-    SSC3(c_skel.sc_ext + 3 * b, omega2 - omega1);
+    SSC3(c_skel.sc_ext + 3 * b, nc::gyro_impulse(quat_from_mat(R), idl, G3(ang, 3 * b), DT_F));
 }
 
 // one body at the end of a step: velocities += solver deltas, split-impulse pose correction, transform integration
@@ -1306,7 +1291,7 @@ DEV void body_integrate(const Ctx &c, int b) {
     GS(quat, 4 * b) = q2.x; GS(quat, 4 * b + 1) = q2.y; GS(quat, 4 * b + 2) = q2.z; GS(quat, 4 * b + 3) = q2.w;
     S3(lin, 3 * b, lin);
     S3(ang, 3 * b, ang);
-    if (b < c_skel.nm) SSC3(c_skel.sc_ms + 3 * b, o2 + lin * (0.f - DT_F));  // btDefaultMotionState, one step behind
+    if (b < c_skel.nm) SSC3(c_skel.sc_ms + 3 * b, integ_pos(o2, lin, 0.f - DT_F));  // btDefaultMotionState, one step behind
 }
 
 // the NUM_ITER projected Gauss-Seidel sweeps of one tile (whole workgroup; tile state in LDS), then the per-constraint
@@ -1542,7 +1527,7 @@ DEV void physics_step(const Ctx &c, int flags) {
 
     // ---- collision: hull vs floor plane, persistent manifolds (members dealt to waves by hull size) ----
     for (int i = 0; i < c_skel.nscan; i++)
-        if (c_skel.scan[i].wave == W) hull_scan(c, i);
+        if (c_skel.scan[i].wave == W) hull_scan(c, i, SC3(c_skel.sc_r + 9 * c_skel.scan[i].member + 3));
     STAMP(9);   // wave 0: its own scans done
     __syncthreads();
     STAMP(10);  // all scans done
@@ -1641,6 +1626,195 @@ __global__ __launch_bounds__(64 * EVM_NW) void k_env_step(EnvDev d, const float 
     if (lead) d.flags[c.env] = flags;
 }
 
+// =================================================================================================================
+// Split pipeline.  At the mandated 4096 envs/GPU the monolithic kernel occupies 64 of the 256 CUs, and 40 % of its time
+// goes to phases that are embarrassingly parallel over bodies / constraints / members.  Here those phases run as
+// separate launches over (tile, part) grids that fill the chip; only the Gauss-Seidel sweeps stay one workgroup per
+// tile.  The tile that the sweeps keep in LDS (solver deltas, world inverse inertia, scan minima) has a global staging
+// copy of identical layout (EnvDev::gtile): the pre kernels fill it through the same LII / LDV / LPART accessors
+// (Ctx::lds points at it), the sweeps kernel loads it into LDS and stores the final deltas back, the post kernel
+// integrates from it.
+//   k_split_prologue  (rollout form only) in-band reset of finished envs: one wave per tile
+//   k_split_pre_a     bodies (basis, inertia, gyroscopic impulse) and hull-scan slices          items independent
+//   k_split_pre_b     joint records (+ muscle targets from the action), manifolds + contact rows items independent
+//   k_split_sweeps    10 sweeps + readbacks + the root's next motion state
+//   k_split_post      integration; each member's observation block by the wave that integrated it; the root's wave
+//                     also does reward / termination / rollout bookkeeping
+// =================================================================================================================
+#define EVM_SPLIT_WAVES 4  // waves per workgroup of the pre / post kernels
+
+DEV float *tile_stage(const EnvDev &d) { return d.gtile + (size_t) blockIdx.x * d.tile_floats; }
+struct LaneState {
+    int flags;
+    bool pending, any_pending, settling;
+    int settle0;
+    M33 E;
+};
+template <int MODE>
+DEV LaneState lane_state(const Ctx &c) {
+    LaneState L;
+    L.flags = c.d.flags[c.env];
+    L.pending = (L.flags & EVM_FLAG_PENDING) != 0;
+    L.any_pending = __any(L.pending);
+    L.settle0 = (MODE & 4) ? c.d.settle_left[c.env] : 0;
+    L.settling = L.settle0 > 0;
+    if (L.any_pending)
+        L.E = m33(f3(GS(E, 0), GS(E, 1), GS(E, 2)), f3(GS(E, 3), GS(E, 4), GS(E, 5)), f3(GS(E, 6), GS(E, 7), GS(E, 8)));
+    return L;
+}
+// lanes outside the batch / the mask drop out (whole waves of a tile agree: every wave owns the same lanes)
+#define EVM_SPLIT_GUARD()                      \
+    if (c.env >= d.n_real) return;             \
+    if (mask && !mask[c.env]) return;
+
+__global__ __launch_bounds__(64) void k_split_prologue(EnvDev d, const uint8_t *__restrict__ mask) {
+    Ctx c = make_ctx(d, nullptr);
+    EVM_SPLIT_GUARD()
+    if (d.flags[c.env] & EVM_FLAG_DONE) {
+        repose(c);
+        d.flags[c.env] &= ~EVM_FLAG_DONE;
+        d.settle_left[c.env] = c_skel.settle_steps;
+        GS(stat, 1) += 1;
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64 * EVM_SPLIT_WAVES) void k_split_pre_a(EnvDev d, const uint8_t *__restrict__ mask) {
+    Ctx c = make_ctx(d, tile_stage(d));
+    EVM_SPLIT_GUARD()
+    const LaneState L = lane_state<MODE>(c);
+    const int vw = blockIdx.y * EVM_SPLIT_WAVES + c.wave, nvw = gridDim.y * EVM_SPLIT_WAVES;
+    for (int b = vw; b < c_skel.nb; b += nvw) body_prepare(c, b, L.pending, L.any_pending, L.E);
+    for (int i = vw; i < c_skel.nscan; i += nvw) {
+        // the scan needs row 1 of the member's basis; the bodies are being prepared by other waves, so it is rebuilt here
+        const int m = c_skel.scan[i].member;
+        M33 R = mat_from_quat(q4(GS(quat, 4 * m), GS(quat, 4 * m + 1), GS(quat, 4 * m + 2), GS(quat, 4 * m + 3)));
+        if (L.any_pending) {
+            const M33 Rp = glm_mul_basis(L.E, load_m33(c_skel.body[m].m0));
+            if (L.pending) R = Rp;
+        }
+        hull_scan(c, i, R.r1);
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64 * EVM_SPLIT_WAVES) void k_split_pre_b(EnvDev d, const float *__restrict__ action,
+                                                                        const uint8_t *__restrict__ mask) {
+    Ctx c = make_ctx(d, tile_stage(d));
+    EVM_SPLIT_GUARD()
+    const LaneState L = lane_state<MODE>(c);
+    const int vw = blockIdx.y * EVM_SPLIT_WAVES + c.wave, nvw = gridDim.y * EVM_SPLIT_WAVES;
+    const bool powered = (L.flags & EVM_FLAG_POWERED) != 0 || ((MODE & 1) && !L.settling);
+    for (int v = vw; v < c_skel.nvisit; v += nvw) {
+        const EvmVisitC &V = c_skel.visit[v];
+        switch (V.type) {
+            case 0: hinge_setup(c, (V.slot - c_skel.sc_h) / EVM_H_STRIDE); break;
+            case 1: fixed_setup(c, (V.slot - c_skel.sc_f) / EVM_F_STRIDE); break;
+            case 2: {
+                const int mi = (V.slot - c_skel.sc_s) / EVM_S_STRIDE;
+                if ((MODE & 1) && !L.settling)  // MuscleController::on_input -> Muscle::contract
+                    GS(target, mi) = action[(size_t) c.env * c_skel.nmus + mi] * c_skel.muscle[mi].speed;
+                slider_setup(c, mi, powered, GS(target, mi));
+                break;
+            }
+            default: { const int k = (V.slot - c_skel.sc_p) / EVM_P_STRIDE; p2p_setup(c, k >> 1, k & 1); break; }
+        }
+    }
+    // members: manifold maintenance, then the contact rows (warm start lands in the member's own deltas)
+    for (int m = vw; m < c_skel.nm; m += nvw) {
+        int n = 0;
+        if (c_skel.member[m].contact_response) n = contact_update(c, m);
+        if (__any(n > 0)) contact_setup(c, m, GS(mfn, m));
+        else { SSC3(c_skel.sc_pt + 6 * m, f3(0.f, 0.f, 0.f)); SSC3(c_skel.sc_pt + 6 * m + 3, f3(0.f, 0.f, 0.f)); }
+    }
+}
+
+__global__ __launch_bounds__(64 * EVM_NW) void k_split_sweeps(EnvDev d, const uint8_t *__restrict__ mask) {
+    extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
+    Ctx c = make_ctx(d, lds_dyn);
+    EVM_SPLIT_GUARD()
+    const bool any_pending = __any((d.flags[c.env] & EVM_FLAG_PENDING) != 0);
+    // tile: staging copy -> LDS (solver deltas with the contact warm start, world inverse inertia); versions start at 0
+    {
+        const float *g = tile_stage(d);
+        const int nfl = c_skel.nb * 12;  // slots of 64 lanes
+        for (int k = c.wave; k < nfl; k += EVM_NW) c.lds[(k << 6) + c.lane] = g[(k << 6) + c.lane];
+        if (c.wave == 0) for (int b = 0; b < c_skel.nb; b++) LVER(c)[b] = 0;  // every live lane writes: a ragged tile may have one
+    }
+    int ncontact = 0;
+    unsigned cmask = 0;  // wave-uniform: members with a cached point in any lane
+    for (int m = 0; m < c_skel.nm; m++) {
+        const int n = GS(mfn, m);
+        ncontact += n;
+        if (__any(n > 0)) cmask |= 1u << m;
+    }
+    __syncthreads();
+    sweeps_run(c, any_pending, cmask, ncontact);
+    __syncthreads();
+    {   // final deltas -> staging copy
+        float *g = tile_stage(d);
+        const int nfl = c_skel.nb * 6;
+        for (int k = c.wave; k < nfl; k += EVM_NW) g[(k << 6) + c.lane] = c.lds[(k << 6) + c.lane];
+    }
+    if (c.wave == 0) {
+        SC(c_skel.sc_snap) = __int_as_float(d.flags[c.env]);
+        SC(c_skel.sc_snap + 1) = __int_as_float(d.settle_left[c.env]);
+        // the root's motion-state origin after this step, for every member's observation block (the post kernel's
+        // waves integrate different bodies concurrently and cannot read each other's results)
+        const int b = c_skel.root;
+        F3 o = G3(pos, 3 * b);
+        const F3 dl = f3(LDV(b, 0), LDV(b, 1), LDV(b, 2));
+        F3 lin = G3(lin, 3 * b) + dl;
+        const F3 push = SC3(c_skel.sc_pt + 6 * b), turn = SC3(c_skel.sc_pt + 6 * b + 3);
+        const bool nz = push.x != 0.f || push.y != 0.f || push.z != 0.f || turn.x != 0.f || turn.y != 0.f || turn.z != 0.f;
+        if (nz) o = integ_pos(o, push, DT_F);
+        lin = lin + f3(0.f, c_skel.body[b].ext_force_y, 0.f);
+        const F3 o2 = integ_pos(o, lin, DT_F);
+        SSC3(c_skel.sc_rootms, integ_pos(o2, lin, 0.f - DT_F));
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64 * EVM_SPLIT_WAVES) void k_split_post(EnvDev d, float *obs, float *reward, uint8_t *done,
+                                                                       uint8_t *valid, const uint8_t *__restrict__ mask) {
+    Ctx c = make_ctx(d, tile_stage(d));
+    EVM_SPLIT_GUARD()
+    LaneState L;  // from the snapshot taken by the sweeps kernel: the live values are rewritten below by the root's wave
+    L.flags = __float_as_int(SC(c_skel.sc_snap));
+    L.settle0 = (MODE & 4) ? __float_as_int(SC(c_skel.sc_snap + 1)) : 0;
+    L.settling = L.settle0 > 0;
+    const int vw = blockIdx.y * EVM_SPLIT_WAVES + c.wave, nvw = gridDim.y * EVM_SPLIT_WAVES;
+    bool do_observe = (MODE & 2) != 0;
+    if ((MODE & 4) && L.settling) do_observe = L.settle0 == 1;
+    const bool any_observe = __any(do_observe);
+    F3 root_ms = f3(0.f, 0.f, 0.f);
+    if (any_observe) root_ms = SC3(c_skel.sc_rootms);
+    for (int b = vw; b < c_skel.nb; b += nvw) {
+        body_integrate(c, b);
+        if (b < c_skel.nm && do_observe) observe_member(c, b, obs, root_ms);
+        if (b == c_skel.root) {
+            // one writer per env: reward / termination / counters / rollout bookkeeping
+            int flags = L.flags & ~EVM_FLAG_PENDING;
+            if ((MODE & 1) && !L.settling) {
+                flags |= EVM_FLAG_POWERED;
+                if (MODE & 4) GS(stat, 0) += 1;
+            }
+            if (MODE & 4) {
+                if (L.settling) d.settle_left[c.env] = L.settle0 - 1;
+                valid[c.env] = do_observe ? (L.settling ? 2 : 1) : 0;  // 1 = do_step transition, 2 = reset()'s own step
+            }
+            if (do_observe) {
+                observe_tail(c, reward, done);
+                if ((MODE & 4) && done[c.env]) flags |= EVM_FLAG_DONE;
+            }
+            d.flags[c.env] = flags;
+        }
+    }
+    if (any_observe)
+        for (int mi = vw; mi < c_skel.nmus; mi += nvw)
+            if (do_observe) observe_muscle(c, mi, obs);
+}
+
 __global__ __launch_bounds__(64) void k_env_repose(EnvDev d, const uint8_t *__restrict__ mask) {
     Ctx c = make_ctx(d, nullptr);
     if (c.env >= d.n_real) return;
@@ -1731,8 +1905,42 @@ static hipError_t launch_mode(const EnvDev &d, size_t lds, const float *action, 
     hipLaunchKernelGGL((k_env_step<MODE>), dim3(d.n / 64), dim3(64 * EVM_NW), lds, s, d, action, obs, reward, done, valid, mask);
     return hipGetLastError();
 }
-hipError_t launch_step(const EnvDev &d, size_t lds_bytes, int mode, const float *action, float *obs, float *reward, uint8_t *done,
-                       uint8_t *valid, const uint8_t *mask, hipStream_t s) {
+template <int MODE>
+static hipError_t launch_split(const EnvDev &d, size_t lds, const float *action, float *obs, float *reward, uint8_t *done,
+                               uint8_t *valid, const uint8_t *mask, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_split_sweeps),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int) (160 * 1024));
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int tiles = d.n / 64;
+    // enough (tile, part) workgroups to cover the chip a few times over at small batches, one part at large ones
+    int parts = (2048 + tiles * EVM_SPLIT_WAVES - 1) / (tiles * EVM_SPLIT_WAVES);
+    if (parts < 1) parts = 1;
+    if (parts > 16) parts = 16;
+    const dim3 gp(tiles, parts), bp(64 * EVM_SPLIT_WAVES);
+    if (MODE & 4) hipLaunchKernelGGL(k_split_prologue, dim3(tiles), dim3(64), 0, s, d, mask);
+    hipLaunchKernelGGL((k_split_pre_a<MODE>), gp, bp, 0, s, d, mask);
+    hipLaunchKernelGGL((k_split_pre_b<MODE>), gp, bp, 0, s, d, action, mask);
+    hipLaunchKernelGGL(k_split_sweeps, dim3(tiles), dim3(64 * EVM_NW), lds, s, d, mask);
+    hipLaunchKernelGGL((k_split_post<MODE>), gp, bp, 0, s, d, obs, reward, done, valid, mask);
+    return hipGetLastError();
+}
+hipError_t launch_step(const EnvDev &d, size_t lds_bytes, int split, int mode, const float *action, float *obs, float *reward,
+                       uint8_t *done, uint8_t *valid, const uint8_t *mask, hipStream_t s) {
+    if (split) {
+        // the sweeps kernel keeps only the body tiles and the version counters in LDS (no scan minima)
+        const size_t lds = lds_bytes;  // same layout as the staging copy
+        switch (mode) {
+            case 0: return launch_split<0>(d, lds, action, obs, reward, done, valid, mask, s);
+            case 2: return launch_split<2>(d, lds, action, obs, reward, done, valid, mask, s);
+            case 3: return launch_split<3>(d, lds, action, obs, reward, done, valid, mask, s);
+            case 7: return launch_split<7>(d, lds, action, obs, reward, done, valid, mask, s);
+            default: return hipErrorInvalidValue;
+        }
+    }
     switch (mode) {
         case 0: return launch_mode<0>(d, lds_bytes, action, obs, reward, done, valid, mask, s);
         case 2: return launch_mode<2>(d, lds_bytes, action, obs, reward, done, valid, mask, s);

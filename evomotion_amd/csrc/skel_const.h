@@ -75,13 +75,14 @@ struct EvmVisitC {
 
 #define EVM_MAX_SCHED (EVM_MAX_VISITS + 64)
 #define EVM_SCHED_NONE 0x7fff
-// One slice of a member's hull for the deepest-vertex scan.  Large hulls are cut in two so that the scans of the
-// four 451-vertex feet fill all eight waves; the slices' (minimum, index) pairs meet in LDS.
+// One slice of a member's hull for the deepest-vertex scan.  Hulls are cut into slices of at most 64 vertices so that
+// the scans of the four 451-vertex feet spread over every wave that is available; the slices' (minimum, index) pairs
+// meet in the tile (LDS, or its global staging copy in the split pipeline).
 struct EvmScanC {
     int member, begin, end;  // vertices [begin, end) of the member's hull, begin even
     int wave;
 };
-#define EVM_MAX_SCAN (2 * EVM_MAX_MEMBERS)
+#define EVM_MAX_SCAN 96
 #define EVM_SCHED_BARRIER 0x8000
 #define EVM_SCHED_CONTACT 0x4000   // entry = EVM_SCHED_CONTACT | member: the member's contact rows of this sweep
 
@@ -102,6 +103,7 @@ struct EvmSkelC {
     int nb, nm, nh, nf, nmus, root;
     int obs_dim, act_dim;
     int state_member[EVM_MAX_MEMBERS];  // observation order: root first (skeleton.cpp:140-160)
+    int state_index[EVM_MAX_MEMBERS];   // inverse: member -> position of its 19-value block
     int ncon;                                        // skeleton constraints in file order (skeleton.cpp:77-82)
     int con_type[EVM_MAX_HINGES + EVM_MAX_FIXED];    // 0 hinge, 1 fixed
     int con_idx[EVM_MAX_HINGES + EVM_MAX_FIXED];
@@ -114,6 +116,10 @@ struct EvmSkelC {
     float reset_angle_limit;  // pi * 2 / 3 (robot_walk.cpp:80) or pi / 3 (robot_jump.cpp:89)
     // scratch layout (offsets in floats-per-env)
     int sc_r, sc_ext, sc_ms, sc_pt, sc_mobs, sc_h, sc_f, sc_s, sc_p, sc_c, sc_total;
+    int sc_snap;           // 2 ints (as float bits): flags and settle_left as they were when the step began — the post kernel's
+                           // waves read these while the root's wave rewrites the live values
+    int sc_rootms;         // 3 floats: the root's motion-state origin after this step (split pipeline: written by the sweeps
+                           // kernel, read by every observation block)
     float sched_cycles;  // host estimate of the 10 sweeps under the schedule's cost model (information only)
     int nvisit;
     EvmVisitC visit[EVM_MAX_VISITS];

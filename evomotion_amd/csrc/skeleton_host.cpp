@@ -468,6 +468,7 @@ int load_skeleton_constants(const char *path, const EvmEnvParams &prm, EvmSkelC 
         S.state_member[k++] = S.root;
         for (int i = 0; i < nm; i++)
             if (i != S.root) S.state_member[k++] = i;
+        for (int i = 0; i < nm; i++) S.state_index[S.state_member[i]] = i;
     }
     S.floor_o[0] = 0.f; S.floor_o[1] = -2.f; S.floor_o[2] = 2.f;  // robot_walk.cpp:24
     S.floor_top_y = S.floor_o[1] + 1.0f * 1.f;
@@ -652,6 +653,8 @@ int load_skeleton_constants(const char *path, const EvmEnvParams &prm, EvmSkelC 
     S.sc_s = o; o += EVM_S_STRIDE * nmus;
     S.sc_p = o; o += EVM_P_STRIDE * 2 * nmus;
     S.sc_c = o; o += EVM_CM_STRIDE * nm;
+    S.sc_rootms = o; o += 4;
+    S.sc_snap = o; o += 4;
     S.sc_total = o;
 
     // ---- sweep visit list (Bullet order: skeleton constraints, then slider / p2p_a / p2p_b per muscle) ----
@@ -843,12 +846,14 @@ int load_skeleton_constants(const char *path, const EvmEnvParams &prm, EvmSkelC 
             S.member[m].scan_first = S.nscan;
             const int n = S.member[m].hull_n;
             if (S.member[m].contact_response) {
-                if (n > 64) {
-                    const int h = ((n / 2) + 1) & ~1;
-                    S.scan[S.nscan++] = {m, 0, h, 0};
-                    S.scan[S.nscan++] = {m, h, n, 0};
-                } else {
-                    S.scan[S.nscan++] = {m, 0, n, 0};
+                const int parts = (n + 63) / 64;
+                int begin = 0;
+                for (int k = 0; k < parts; k++) {
+                    int end = k == parts - 1 ? n : ((((k + 1) * n) / parts) + 1) & ~1;  // even boundaries (vertex pairs)
+                    if (end > n) end = n;
+                    if (S.nscan >= EVM_MAX_SCAN) { err = "too many hull slices"; return EVM_E_UNSUPPORTED; }
+                    if (end > begin) S.scan[S.nscan++] = {m, begin, end, 0};
+                    begin = end;
                 }
             }
             S.member[m].scan_count = S.nscan - S.member[m].scan_first;
