@@ -1108,8 +1108,8 @@ DEV float mt_uniform01(const Ctx &c) {
     return r;
 }
 
-// RobotWalk::reset_engine up to the settle steps (robot_walk.cpp:76-96, item.cpp:77-86)
-DEV void repose(const Ctx &c) {
+// reset rotation: 3 RNG draws -> glm::eulerAngleYXZ (robot_walk.cpp:80-86)
+DEV M33 repose_draw(const Ctx &c) {
     const float angle_limit = c_skel.reset_angle_limit;
     const float half = angle_limit / 2.f;
     const float yaw = xs_(xm(mt_uniform01(c), angle_limit), half);
@@ -1120,29 +1120,32 @@ DEV void repose(const Ctx &c) {
     const float ch = (float) cos((double) yaw), sh = (float) sin((double) yaw), cp = (float) cos((double) pitch),
                 sp = (float) sin((double) pitch), cb = (float) cos((double) roll), sb = (float) sin((double) roll);
     // glm::eulerAngleYXZ(yaw, pitch, roll), stored as rows, every operation individually rounded
-    const M33 E = m33(f3(xa(xm(ch, cb), xm(xm(sh, sp), sb)), xa(xm(-ch, sb), xm(xm(sh, sp), cb)), xm(sh, cp)),
-                      f3(xm(sb, cp), xm(cb, cp), -sp),
-                      f3(xa(xm(-sh, cb), xm(xm(ch, sp), sb)), xa(xm(sb, sh), xm(xm(ch, sp), cb)), xm(ch, cp)));
-    const int flags = c.d.flags[c.env];
-    const bool was_pending = (flags & EVM_FLAG_PENDING) != 0;
-    const F3 e0 = col0(E), e1 = col1(E), e2 = col2(E);
-    for (int b = 0; b < c_skel.nb; b++) {
-        if (!was_pending) {  // the world inverse inertia tensor stays that of the last integrated transform
-            const Q4 q = q4(GS(quat, 4 * b), GS(quat, 4 * b + 1), GS(quat, 4 * b + 2), GS(quat, 4 * b + 3));
-            const S33 I = inertia_world(mat_from_quat(q), load_f3(c_skel.body[b].inv_inertia));
-            GS(iinv_stale, 6 * b) = I.xx; GS(iinv_stale, 6 * b + 1) = I.xy; GS(iinv_stale, 6 * b + 2) = I.xz;
-            GS(iinv_stale, 6 * b + 3) = I.yy; GS(iinv_stale, 6 * b + 4) = I.yz; GS(iinv_stale, 6 * b + 5) = I.zz;
-        }
-        const F3 t0 = load_f3(c_skel.body[b].t0);
-        const F3 rp = load_f3(c_skel.root_pos);
-        const F3 o = f3(xa(xa(xa(xm(e0.x, t0.x), xm(e1.x, t0.y)), xm(e2.x, t0.z)), rp.x),
-                        xa(xa(xa(xm(e0.y, t0.x), xm(e1.y, t0.y)), xm(e2.y, t0.z)), rp.y),
-                        xa(xa(xa(xm(e0.z, t0.x), xm(e1.z, t0.y)), xm(e2.z, t0.z)), rp.z));
-        S3(pos, 3 * b, o);
-        S3(lin, 3 * b, f3(0.f, 0.f, 0.f));
-        S3(ang, 3 * b, f3(0.f, 0.f, 0.f));
-        if (b < c_skel.nm) SSC3(c_skel.sc_ms + 3 * b, o);  // motion state := new transform (item.cpp:81)
+    return m33(f3(xa(xm(ch, cb), xm(xm(sh, sp), sb)), xa(xm(-ch, sb), xm(xm(sh, sp), cb)), xm(sh, cp)),
+               f3(xm(sb, cp), xm(cb, cp), -sp),
+               f3(xa(xm(-sh, cb), xm(xm(ch, sp), sb)), xa(xm(sb, sh), xm(xm(ch, sp), cb)), xm(ch, cp)));
+}
+// one body of RigidBodyItem::reset (item.cpp:77-86): new origin E t0 + root_pos, zero velocities; the world inverse inertia
+// tensor stays that of the last integrated transform
+DEV void repose_body(const Ctx &c, int b, const M33 &E, bool was_pending) {
+    if (!was_pending) {
+        const Q4 q = q4(GS(quat, 4 * b), GS(quat, 4 * b + 1), GS(quat, 4 * b + 2), GS(quat, 4 * b + 3));
+        const S33 I = inertia_world(mat_from_quat(q), load_f3(c_skel.body[b].inv_inertia));
+        GS(iinv_stale, 6 * b) = I.xx; GS(iinv_stale, 6 * b + 1) = I.xy; GS(iinv_stale, 6 * b + 2) = I.xz;
+        GS(iinv_stale, 6 * b + 3) = I.yy; GS(iinv_stale, 6 * b + 4) = I.yz; GS(iinv_stale, 6 * b + 5) = I.zz;
     }
+    const F3 e0 = col0(E), e1 = col1(E), e2 = col2(E);
+    const F3 t0 = load_f3(c_skel.body[b].t0);
+    const F3 rp = load_f3(c_skel.root_pos);
+    const F3 o = f3(xa(xa(xa(xm(e0.x, t0.x), xm(e1.x, t0.y)), xm(e2.x, t0.z)), rp.x),
+                    xa(xa(xa(xm(e0.y, t0.x), xm(e1.y, t0.y)), xm(e2.y, t0.z)), rp.y),
+                    xa(xa(xa(xm(e0.z, t0.x), xm(e1.z, t0.y)), xm(e2.z, t0.z)), rp.z));
+    S3(pos, 3 * b, o);
+    S3(lin, 3 * b, f3(0.f, 0.f, 0.f));
+    S3(ang, 3 * b, f3(0.f, 0.f, 0.f));
+    if (b < c_skel.nm) SSC3(c_skel.sc_ms + 3 * b, o);  // motion state := new transform (item.cpp:81)
+}
+// per-env bookkeeping of a reset: manifolds dropped, rotation kept for the first step, counters
+DEV void repose_finish(const Ctx &c, const M33 &E, int flags) {
     for (int m = 0; m < c_skel.nm; m++) GS(mfn, m) = 0;
     GS(E, 0) = E.r0.x; GS(E, 1) = E.r0.y; GS(E, 2) = E.r0.z;
     GS(E, 3) = E.r1.x; GS(E, 4) = E.r1.y; GS(E, 5) = E.r1.z;
@@ -1150,6 +1153,14 @@ DEV void repose(const Ctx &c) {
     c.d.flags[c.env] = flags | EVM_FLAG_PENDING;
     c.d.curr_step[c.env] = 0;                       // robot_walk.cpp:100-101 (nothing reads them in between)
     c.d.remaining[c.env] = c_skel.init_remaining;
+}
+// RobotWalk::reset_engine up to the settle steps (robot_walk.cpp:76-96, item.cpp:77-86), one lane
+DEV void repose(const Ctx &c) {
+    const M33 E = repose_draw(c);
+    const int flags = c.d.flags[c.env];
+    const bool was_pending = (flags & EVM_FLAG_PENDING) != 0;
+    for (int b = 0; b < c_skel.nb; b++) repose_body(c, b, E, was_pending);
+    repose_finish(c, E, flags);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1667,14 +1678,30 @@ DEV LaneState lane_state(const Ctx &c) {
     if (c.env >= d.n_real) return;             \
     if (mask && !mask[c.env]) return;
 
-__global__ __launch_bounds__(64) void k_split_prologue(EnvDev d, const uint8_t *__restrict__ mask) {
+__global__ __launch_bounds__(64 * EVM_NW) void k_split_prologue(EnvDev d, const uint8_t *__restrict__ mask) {
+    __shared__ float sE[9 * 64];
     Ctx c = make_ctx(d, nullptr);
     EVM_SPLIT_GUARD()
-    if (d.flags[c.env] & EVM_FLAG_DONE) {
-        repose(c);
-        d.flags[c.env] &= ~EVM_FLAG_DONE;
-        d.settle_left[c.env] = c_skel.settle_steps;
-        GS(stat, 1) += 1;
+    const int flags = d.flags[c.env];
+    const bool fin = (flags & EVM_FLAG_DONE) != 0;
+    if (!__any(fin)) return;  // wave-uniform, and the same in every wave of the tile
+    if (c.wave == 0 && fin) {  // the RNG stream and the rotation: one wave; the 41 bodies: all of them
+        const M33 E = repose_draw(c);
+        sE[0 * 64 + c.lane] = E.r0.x; sE[1 * 64 + c.lane] = E.r0.y; sE[2 * 64 + c.lane] = E.r0.z;
+        sE[3 * 64 + c.lane] = E.r1.x; sE[4 * 64 + c.lane] = E.r1.y; sE[5 * 64 + c.lane] = E.r1.z;
+        sE[6 * 64 + c.lane] = E.r2.x; sE[7 * 64 + c.lane] = E.r2.y; sE[8 * 64 + c.lane] = E.r2.z;
+    }
+    __syncthreads();
+    if (fin) {
+        const M33 E = m33(f3(sE[c.lane], sE[64 + c.lane], sE[128 + c.lane]), f3(sE[192 + c.lane], sE[256 + c.lane], sE[320 + c.lane]),
+                          f3(sE[384 + c.lane], sE[448 + c.lane], sE[512 + c.lane]));
+        const bool was_pending = (flags & EVM_FLAG_PENDING) != 0;
+        for (int b = c.wave; b < c_skel.nb; b += EVM_NW) repose_body(c, b, E, was_pending);
+        if (c.wave == 0) {
+            repose_finish(c, E, flags & ~EVM_FLAG_DONE);
+            d.settle_left[c.env] = c_skel.settle_steps;
+            GS(stat, 1) += 1;
+        }
     }
 }
 
@@ -1684,8 +1711,10 @@ __global__ __launch_bounds__(64 * EVM_SPLIT_WAVES) void k_split_pre_a(EnvDev d, 
     EVM_SPLIT_GUARD()
     const LaneState L = lane_state<MODE>(c);
     const int vw = blockIdx.y * EVM_SPLIT_WAVES + c.wave, nvw = gridDim.y * EVM_SPLIT_WAVES;
-    for (int b = vw; b < c_skel.nb; b += nvw) body_prepare(c, b, L.pending, L.any_pending, L.E);
-    for (int i = vw; i < c_skel.nscan; i += nvw) {
+    // one item list (bodies, then scan slices) dealt round robin, so that no wave gets the head of both
+    for (int j = vw; j < c_skel.nb + c_skel.nscan; j += nvw) {
+        if (j < c_skel.nb) { body_prepare(c, j, L.pending, L.any_pending, L.E); continue; }
+        const int i = j - c_skel.nb;
         // the scan needs row 1 of the member's basis; the bodies are being prepared by other waves, so it is rebuilt here
         const int m = c_skel.scan[i].member;
         M33 R = mat_from_quat(q4(GS(quat, 4 * m), GS(quat, 4 * m + 1), GS(quat, 4 * m + 2), GS(quat, 4 * m + 3)));
@@ -1705,8 +1734,18 @@ __global__ __launch_bounds__(64 * EVM_SPLIT_WAVES) void k_split_pre_b(EnvDev d, 
     const LaneState L = lane_state<MODE>(c);
     const int vw = blockIdx.y * EVM_SPLIT_WAVES + c.wave, nvw = gridDim.y * EVM_SPLIT_WAVES;
     const bool powered = (L.flags & EVM_FLAG_POWERED) != 0 || ((MODE & 1) && !L.settling);
-    for (int v = vw; v < c_skel.nvisit; v += nvw) {
-        const EvmVisitC &V = c_skel.visit[v];
+    // one item list: members first (manifold + contact rows, the longest items), then the joint visits
+    for (int j = vw; j < c_skel.nm + c_skel.nvisit; j += nvw) {
+        if (j < c_skel.nm) {
+            // manifold maintenance, then the contact rows (warm start lands in the member's own deltas)
+            const int m = j;
+            int n = 0;
+            if (c_skel.member[m].contact_response) n = contact_update(c, m);
+            if (__any(n > 0)) contact_setup(c, m, GS(mfn, m));
+            else { SSC3(c_skel.sc_pt + 6 * m, f3(0.f, 0.f, 0.f)); SSC3(c_skel.sc_pt + 6 * m + 3, f3(0.f, 0.f, 0.f)); }
+            continue;
+        }
+        const EvmVisitC &V = c_skel.visit[j - c_skel.nm];
         switch (V.type) {
             case 0: hinge_setup(c, (V.slot - c_skel.sc_h) / EVM_H_STRIDE); break;
             case 1: fixed_setup(c, (V.slot - c_skel.sc_f) / EVM_F_STRIDE); break;
@@ -1719,13 +1758,6 @@ __global__ __launch_bounds__(64 * EVM_SPLIT_WAVES) void k_split_pre_b(EnvDev d, 
             }
             default: { const int k = (V.slot - c_skel.sc_p) / EVM_P_STRIDE; p2p_setup(c, k >> 1, k & 1); break; }
         }
-    }
-    // members: manifold maintenance, then the contact rows (warm start lands in the member's own deltas)
-    for (int m = vw; m < c_skel.nm; m += nvw) {
-        int n = 0;
-        if (c_skel.member[m].contact_response) n = contact_update(c, m);
-        if (__any(n > 0)) contact_setup(c, m, GS(mfn, m));
-        else { SSC3(c_skel.sc_pt + 6 * m, f3(0.f, 0.f, 0.f)); SSC3(c_skel.sc_pt + 6 * m + 3, f3(0.f, 0.f, 0.f)); }
     }
 }
 
@@ -1921,7 +1953,7 @@ static hipError_t launch_split(const EnvDev &d, size_t lds, const float *action,
     if (parts < 1) parts = 1;
     if (parts > 16) parts = 16;
     const dim3 gp(tiles, parts), bp(64 * EVM_SPLIT_WAVES);
-    if (MODE & 4) hipLaunchKernelGGL(k_split_prologue, dim3(tiles), dim3(64), 0, s, d, mask);
+    if (MODE & 4) hipLaunchKernelGGL(k_split_prologue, dim3(tiles), dim3(64 * EVM_NW), 0, s, d, mask);
     hipLaunchKernelGGL((k_split_pre_a<MODE>), gp, bp, 0, s, d, mask);
     hipLaunchKernelGGL((k_split_pre_b<MODE>), gp, bp, 0, s, d, action, mask);
     hipLaunchKernelGGL(k_split_sweeps, dim3(tiles), dim3(64 * EVM_NW), lds, s, d, mask);
