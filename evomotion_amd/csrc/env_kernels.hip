@@ -817,7 +817,7 @@ DEV void hull_scan(const Ctx &c, int si, F3 r1) {
 }
 
 // manifold maintenance for member m from the scanned deepest vertex; returns the number of cached points afterwards
-DEV int contact_update(const Ctx &c, int m) {
+DEV int contact_update(const Ctx &c, int m, MPoint *pts_out = nullptr) {
     const EvmMemberC &MB = c_skel.member[m];
     const F3 o = G3(pos, 3 * m);
     const M33 R = m33(SC3(c_skel.sc_r + 9 * m), SC3(c_skel.sc_r + 9 * m + 3), SC3(c_skel.sc_r + 9 * m + 6));
@@ -919,12 +919,14 @@ DEV int contact_update(const Ctx &c, int m) {
     REFRESH_SLOT(0, p0)
 #undef REFRESH_SLOT
     store_mp(c, m, 0, p0); store_mp(c, m, 1, p1); store_mp(c, m, 2, p2); store_mp(c, m, 3, p3);
+    if (pts_out) { pts_out[0] = p0; pts_out[1] = p1; pts_out[2] = p2; pts_out[3] = p3; }
     GS(mfn, m) = n;
     return n;
 }
 
 // contact rows of member m: setup, warm start, split-impulse recovery (all of it touches body m only)
-DEV void contact_setup(const Ctx &c, int m, int n) {
+// pts: the member's four manifold points when the caller still has them in registers (split pipeline), else re-read
+DEV void contact_setup(const Ctx &c, int m, int n, const MPoint *pts = nullptr) {
     const EvmMemberC &MB = c_skel.member[m];
     const BodyK B = load_bodyk(c, m);
     BodyD D = load_bodyd(c, m);
@@ -942,8 +944,8 @@ DEV void contact_setup(const Ctx &c, int m, int n) {
     for (int j = 0; j < 4; j++) {
         pjd[j] = 0.f; prhs[j] = 0.f; ppush[j] = 0.f; pc2[j] = f3(0, 0, 0); pang[j] = f3(0, 0, 0);
         if (j < n) {
-            const F3 lb = f3(MFP(m, j, 3), MFP(m, j, 4), MFP(m, j, 5));
-            const float dist = MFP(m, j, 6);
+            const F3 lb = pts ? pts[j].lb : f3(MFP(m, j, 3), MFP(m, j, 4), MFP(m, j, 5));
+            const float dist = pts ? pts[j].dist : MFP(m, j, 6);
             const F3 posB = mul(B.R, lb) + B.o;
             const F3 rel = posB - B.o;
             // convertContact: relative velocity of the contact point (static body A contributes 0)
@@ -958,7 +960,7 @@ DEV void contact_setup(const Ctx &c, int m, int n) {
             const float denom1 = B.im + dot(nrm, vec);
             const float jd = 1.0f / (0.f + denom1 + 0.f);
             const F3 n2 = -nrm;
-            const float applied = MFP(m, j, 7) * WARM_F;
+            const float applied = (pts ? pts[j].ap : MFP(m, j, 7)) * WARM_F;
             // warm start: internalApplyImpulse(-n2 * invMass, -angB, -applied)
             D.dl = D.dl + ((-n2) * B.im) * (-applied);
             D.da = D.da + (-angB) * (-applied);
@@ -985,7 +987,7 @@ DEV void contact_setup(const Ctx &c, int m, int n) {
             const float fjd = 1.0f / (0.f + (B.im + dot(lat, fvec)));
             const float fv2 = dot(fn2, B.v) + dot(fc2, B.w_raw);  // no external torque impulse here
             const float frhs = (0.f - (0.f + fv2)) * fjd;
-            const float fapplied = MFP(m, j, 8) * WARM_F;
+            const float fapplied = (pts ? pts[j].apl : MFP(m, j, 8)) * WARM_F;
             D.dl = D.dl + ((-fn2) * B.im) * (-fapplied);
             D.da = D.da + (-fangB) * (-fapplied);
             put3(rec, EVM_C_STRIDE * j, rel); put3(rec, EVM_C_STRIDE * j + 3, lat);
@@ -1178,34 +1180,59 @@ DEV void euler_zyx(Q4 q, float &yaw, float &pitch, float &roll) {
     }
 }
 
+struct BodyState {  // a body right after integration
+    F3 o, lin, ang, ms;
+    Q4 q;
+};
 // the 19-value block of member m (proprioception_state.cpp:23-58,86-112); root_ms = the root's motion-state origin
-DEV void observe_member(const Ctx &c, int m, float *obs, F3 root_ms) {
-    float *o = obs + (size_t) c.env * c_skel.obs_dim;
+DEV void member_values(const Ctx &c, int m, F3 root_ms, float (&v)[19], const BodyState *st = nullptr) {
     const float PI_F = (float) 3.14159265358979323846;
-    const int k = 19 * c_skel.state_index[m];
-    const Q4 qs = q4(GS(quat, 4 * m), GS(quat, 4 * m + 1), GS(quat, 4 * m + 2), GS(quat, 4 * m + 3));
+    // st: the member's freshly integrated state when the caller still has it in registers, else read back
+    const Q4 qs = st ? st->q : q4(GS(quat, 4 * m), GS(quat, 4 * m + 1), GS(quat, 4 * m + 2), GS(quat, 4 * m + 3));
     const Q4 q = quat_from_mat(mat_from_quat(qs));  // getWorldTransform().getRotation()
     float yaw, pitch, roll;
     euler_zyx(q, yaw, pitch, roll);
-    const F3 lv = G3(lin, 3 * m), av = G3(ang, 3 * m);
+    const F3 lv = st ? st->lin : G3(lin, 3 * m), av = st ? st->ang : G3(ang, 3 * m);
     const F3 ll = G3(hist, 6 * m), la = G3(hist, 6 * m + 3);
     const F3 dl = ll - lv, da = la - av;
     S3(hist, 6 * m, lv); S3(hist, 6 * m + 3, av);
-    o[k + 0] = yaw / PI_F; o[k + 1] = pitch / PI_F; o[k + 2] = roll / PI_F;
-    o[k + 3] = lv.x; o[k + 4] = lv.y; o[k + 5] = lv.z;
-    o[k + 6] = av.x / PI_F; o[k + 7] = av.y / PI_F; o[k + 8] = av.z / PI_F;
-    o[k + 9] = dl.x; o[k + 10] = dl.y; o[k + 11] = dl.z;
-    o[k + 12] = da.x / PI_F; o[k + 13] = da.y / PI_F; o[k + 14] = da.z / PI_F;
-    o[k + 15] = 0.f;  // floor_touched is never raised after construction (proprioception_state.cpp:18,39-40)
+    v[0] = yaw / PI_F; v[1] = pitch / PI_F; v[2] = roll / PI_F;
+    v[3] = lv.x; v[4] = lv.y; v[5] = lv.z;
+    v[6] = av.x / PI_F; v[7] = av.y / PI_F; v[8] = av.z / PI_F;
+    v[9] = dl.x; v[10] = dl.y; v[11] = dl.z;
+    v[12] = da.x / PI_F; v[13] = da.y / PI_F; v[14] = da.z / PI_F;
+    v[15] = 0.f;  // floor_touched is never raised after construction (proprioception_state.cpp:18,39-40)
     if (m == c_skel.root) {
-        const F3 p = G3(pos, 3 * m);
-        o[k + 16] = logf(sqrtf(dot(p, p)) + 1.f);
-        o[k + 17] = p.y;
-        o[k + 18] = atan2f(p.z, p.x);
+        const F3 p = st ? st->o : G3(pos, 3 * m);
+        v[16] = logf(sqrtf(dot(p, p)) + 1.f);
+        v[17] = p.y;
+        v[18] = atan2f(p.z, p.x);
     } else {
-        const F3 d = SC3(c_skel.sc_ms + 3 * m) - root_ms;
-        o[k + 16] = d.x; o[k + 17] = d.y; o[k + 18] = d.z;
+        const F3 d = (st ? st->ms : SC3(c_skel.sc_ms + 3 * m)) - root_ms;
+        v[16] = d.x; v[17] = d.y; v[18] = d.z;
     }
+}
+DEV void observe_member(const Ctx &c, int m, float *obs, F3 root_ms) {
+    float v[19];
+    member_values(c, m, root_ms, v);
+    float *o = obs + (size_t) c.env * c_skel.obs_dim + 19 * c_skel.state_index[m];
+#pragma unroll
+    for (int k = 0; k < 19; k++) o[k] = v[k];
+}
+// A K-value block of all 64 envs of a full tile, written row-contiguously: the values cross lanes through a wave-private
+// LDS buffer [K][64] so that consecutive lanes write consecutive floats of an env's row (K-float runs) instead of one
+// float per 1 484-byte row each.  `who` = ballot of the envs that emit an observation in this call.
+template <int K>
+DEV void store_block_rows(const Ctx &c, float *obs, int col0, const float (&v)[K], float *buf, unsigned long long who) {
+#pragma unroll
+    for (int k = 0; k < K; k++) buf[(k << 6) + c.lane] = v[k];
+    __builtin_amdgcn_wave_barrier();
+    float *tile_obs = obs + (size_t) (c.env - c.lane) * c_skel.obs_dim + col0;
+    for (int idx = c.lane; idx < K * 64; idx += 64) {
+        const int e = idx / K, k = idx - e * K;
+        if ((who >> e) & 1ull) tile_obs[(size_t) e * c_skel.obs_dim + k] = buf[(k << 6) + e];
+    }
+    __builtin_amdgcn_wave_barrier();
 }
 DEV void observe_muscle(const Ctx &c, int mi, float *obs) {  // MuscleState (proprioception_state.cpp:124-129)
     float *o = obs + (size_t) c.env * c_skel.obs_dim + 19 * c_skel.nm + 4 * mi;
@@ -1279,7 +1306,7 @@ DEV void body_prepare(const Ctx &c, int b, bool pending, bool any_pending, const
 }
 
 // one body at the end of a step: velocities += solver deltas, split-impulse pose correction, transform integration
-DEV void body_integrate(const Ctx &c, int b) {
+DEV BodyState body_integrate(const Ctx &c, int b) {
     F3 o = G3(pos, 3 * b);
     M33 R = m33(SC3(c_skel.sc_r + 9 * b), SC3(c_skel.sc_r + 9 * b + 3), SC3(c_skel.sc_r + 9 * b + 6));
     const F3 dl = f3(LDV(b, 0), LDV(b, 1), LDV(b, 2)), da = f3(LDV(b, 3), LDV(b, 4), LDV(b, 5));
@@ -1302,7 +1329,11 @@ DEV void body_integrate(const Ctx &c, int b) {
     GS(quat, 4 * b) = q2.x; GS(quat, 4 * b + 1) = q2.y; GS(quat, 4 * b + 2) = q2.z; GS(quat, 4 * b + 3) = q2.w;
     S3(lin, 3 * b, lin);
     S3(ang, 3 * b, ang);
-    if (b < c_skel.nm) SSC3(c_skel.sc_ms + 3 * b, integ_pos(o2, lin, 0.f - DT_F));  // btDefaultMotionState, one step behind
+    BodyState st;
+    st.o = o2; st.q = q2; st.lin = lin; st.ang = ang;
+    st.ms = integ_pos(o2, lin, 0.f - DT_F);  // btDefaultMotionState, one step behind
+    if (b < c_skel.nm) SSC3(c_skel.sc_ms + 3 * b, st.ms);
+    return st;
 }
 
 // the NUM_ITER projected Gauss-Seidel sweeps of one tile (whole workgroup; tile state in LDS), then the per-constraint
@@ -1740,8 +1771,9 @@ __global__ __launch_bounds__(64 * EVM_SPLIT_WAVES) void k_split_pre_b(EnvDev d, 
             // manifold maintenance, then the contact rows (warm start lands in the member's own deltas)
             const int m = j;
             int n = 0;
-            if (c_skel.member[m].contact_response) n = contact_update(c, m);
-            if (__any(n > 0)) contact_setup(c, m, GS(mfn, m));
+            MPoint pts[4];
+            if (c_skel.member[m].contact_response) n = contact_update(c, m, pts);
+            if (__any(n > 0)) contact_setup(c, m, n, pts);
             else { SSC3(c_skel.sc_pt + 6 * m, f3(0.f, 0.f, 0.f)); SSC3(c_skel.sc_pt + 6 * m + 3, f3(0.f, 0.f, 0.f)); }
             continue;
         }
@@ -1819,11 +1851,25 @@ __global__ __launch_bounds__(64 * EVM_SPLIT_WAVES) void k_split_post(EnvDev d, f
     bool do_observe = (MODE & 2) != 0;
     if ((MODE & 4) && L.settling) do_observe = L.settle0 == 1;
     const bool any_observe = __any(do_observe);
+    __shared__ float sbuf[EVM_SPLIT_WAVES][19 * 64];
+    float *buf = sbuf[c.wave];
+    const unsigned long long who = __ballot(do_observe);
+    const bool full_tile = __popcll(__ballot(true)) == 64;  // every lane is a live env: lanes can write each other's rows
     F3 root_ms = f3(0.f, 0.f, 0.f);
     if (any_observe) root_ms = SC3(c_skel.sc_rootms);
     for (int b = vw; b < c_skel.nb; b += nvw) {
-        body_integrate(c, b);
-        if (b < c_skel.nm && do_observe) observe_member(c, b, obs, root_ms);
+        const BodyState st = body_integrate(c, b);
+        if (b < c_skel.nm && any_observe) {
+            float v[19];
+            if (do_observe) member_values(c, b, root_ms, v, &st);
+            if (full_tile) {
+                store_block_rows<19>(c, obs, 19 * c_skel.state_index[b], v, buf, who);
+            } else if (do_observe) {
+                float *o = obs + (size_t) c.env * c_skel.obs_dim + 19 * c_skel.state_index[b];
+#pragma unroll
+                for (int k = 0; k < 19; k++) o[k] = v[k];
+            }
+        }
         if (b == c_skel.root) {
             // one writer per env: reward / termination / counters / rollout bookkeeping
             int flags = L.flags & ~EVM_FLAG_PENDING;
@@ -1843,8 +1889,15 @@ __global__ __launch_bounds__(64 * EVM_SPLIT_WAVES) void k_split_post(EnvDev d, f
         }
     }
     if (any_observe)
-        for (int mi = vw; mi < c_skel.nmus; mi += nvw)
-            if (do_observe) observe_muscle(c, mi, obs);
+        for (int mi = vw; mi < c_skel.nmus; mi += nvw) {
+            if (full_tile) {
+                float v[4] = {SC(c_skel.sc_mobs + 4 * mi + 0), SC(c_skel.sc_mobs + 4 * mi + 1), SC(c_skel.sc_mobs + 4 * mi + 2),
+                              SC(c_skel.sc_mobs + 4 * mi + 3)};
+                store_block_rows<4>(c, obs, 19 * c_skel.nm + 4 * mi, v, buf, who);
+            } else if (do_observe) {
+                observe_muscle(c, mi, obs);
+            }
+        }
 }
 
 __global__ __launch_bounds__(64) void k_env_repose(EnvDev d, const uint8_t *__restrict__ mask) {
@@ -1949,9 +2002,11 @@ static hipError_t launch_split(const EnvDev &d, size_t lds, const float *action,
     }
     const int tiles = d.n / 64;
     // enough (tile, part) workgroups to cover the chip a few times over at small batches, one part at large ones
-    int parts = (2048 + tiles * EVM_SPLIT_WAVES - 1) / (tiles * EVM_SPLIT_WAVES);
+    static int target_waves = 0;
+    if (!target_waves) { const char *e = getenv("EVM_SPLIT_TARGET_WAVES"); target_waves = e ? atoi(e) : 4608; if (target_waves < 64) target_waves = 4608; }
+    int parts = (target_waves + tiles * EVM_SPLIT_WAVES - 1) / (tiles * EVM_SPLIT_WAVES);
     if (parts < 1) parts = 1;
-    if (parts > 16) parts = 16;
+    if (parts > 32) parts = 32;
     const dim3 gp(tiles, parts), bp(64 * EVM_SPLIT_WAVES);
     if (MODE & 4) hipLaunchKernelGGL(k_split_prologue, dim3(tiles), dim3(64 * EVM_NW), 0, s, d, mask);
     hipLaunchKernelGGL((k_split_pre_a<MODE>), gp, bp, 0, s, d, mask);
