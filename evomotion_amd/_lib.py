@@ -80,6 +80,7 @@ def _load():
     lib.evm_replay_timing_end.argtypes = [vp, vp, fp, ip, fp, ip]
     lib.evm_env_timing_begin.argtypes = [vp, vp]
     lib.evm_env_timing_end.argtypes = [vp, vp, fp, ip]
+    lib.evm_env_timing_end_detail.argtypes = [vp, vp, fp, ip, fp]
     return lib
 
 

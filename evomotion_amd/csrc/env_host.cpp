@@ -45,7 +45,8 @@ struct EvmEnv {
     bool timing;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pairs;  // one pair per timed launch
     size_t ev_used;
-    int split;  // 1: split pipeline (default), 0: monolithic step kernel (EVM_MONOLITHIC=1 in the environment: A/B runs)
+    int split;  // -1: by batch size (default), 1: split pipeline, 0: monolithic step kernel (EVM_MONOLITHIC=0/1 forces: A/B runs)
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_sweeps;  // timed launches: around the sweeps kernel of the split pipeline
 };
 
 static const EvmEnv *g_skel_owner = nullptr;
@@ -100,7 +101,7 @@ int evm_env_create(const char *skeleton_path, int n_envs, int device, uint64_t s
     env->timing = false;
     env->timed_launches = 0;
     env->ev_used = 0;
-    { const char *m = getenv("EVM_MONOLITHIC"); env->split = (m && m[0] == '1') ? 0 : 1; }
+    { const char *m = getenv("EVM_MONOLITHIC"); env->split = !m ? -1 : (m[0] == '1' ? 0 : 1); }
     std::string err;
     int rc = evm::load_skeleton_constants(skeleton_path, prm, env->skel, err);
     if (rc != EVM_OK) { delete env; return fail(rc, err); }
@@ -150,6 +151,7 @@ void evm_env_destroy(EvmEnv *env) {
     (void) hipEventDestroy(env->ev0);
     (void) hipEventDestroy(env->ev1);
     for (auto &pr : env->ev_pairs) { (void) hipEventDestroy(pr.first); (void) hipEventDestroy(pr.second); }
+    for (auto &pr : env->ev_sweeps) { (void) hipEventDestroy(pr.first); (void) hipEventDestroy(pr.second); }
     delete env;
 }
 
@@ -178,10 +180,18 @@ static int step_launch(EvmEnv *env, int mode, const float *a, float *obs, float 
             HIP_TRY(hipEventCreate(&a0));
             HIP_TRY(hipEventCreate(&a1));
             env->ev_pairs.push_back({a0, a1});
+            hipEvent_t b0, b1;
+            HIP_TRY(hipEventCreate(&b0));
+            HIP_TRY(hipEventCreate(&b1));
+            env->ev_sweeps.push_back({b0, b1});
         }
         HIP_TRY(hipEventRecord(env->ev_pairs[env->ev_used].first, s));
     }
-    HIP_TRY(evm::launch_step(env->d, evm::step_lds_bytes(env->skel.nb, env->skel.nscan), env->split, mode, a, obs, rew, done, valid, mask, s));
+    HIP_TRY(evm::launch_step(env->d, evm::step_lds_bytes(env->skel.nb, env->skel.nscan), env->split, mode, a, obs, rew, done, valid, mask, s,
+                             // every 8th timed step also brackets its sweeps kernel (an event between two kernels costs a
+                             // bubble of a few microseconds: sampled, so that the timed region is not perturbed)
+                             (env->timing && env->ev_used % 8 == 0) ? env->ev_sweeps[env->ev_used].first : nullptr,
+                             (env->timing && env->ev_used % 8 == 0) ? env->ev_sweeps[env->ev_used].second : nullptr));
     if (env->timing) {
         HIP_TRY(hipEventRecord(env->ev_pairs[env->ev_used].second, s));
         env->ev_used++;
@@ -499,6 +509,24 @@ int evm_env_timing_end(EvmEnv *env, void *stream, float *ms_total, int *n_launch
     if (ms_total) *ms_total = ms;
     if (n_launches) *n_launches = env->timed_launches;
     return EVM_OK;
+}
+// the same, and in addition the summed duration of the sweeps kernel (k_split_sweeps) of those launches; 0 when the
+// monolithic kernel ran (the sweeps are then a phase inside it)
+int evm_env_timing_end_detail(EvmEnv *env, void *stream, float *ms_total, int *n_launches, float *ms_sweeps) {
+    if (!env) return fail(EVM_E_INVALID, "env is null");
+    HIP_TRY(hipStreamSynchronize((hipStream_t) stream));
+    float sw = 0.f;
+    const bool split = env->split < 0 ? env->d.n / 64 <= 128 : env->split == 1;
+    if (split) {
+        int ns = 0;
+        for (size_t i = 0; i < env->ev_used; i += 8) {
+            float t = 0.f;
+            if (hipEventElapsedTime(&t, env->ev_sweeps[i].first, env->ev_sweeps[i].second) == hipSuccess) { sw += t; ns++; }
+        }
+        if (ns > 0) sw = sw / ns * (float) env->ev_used;  // sampled every 8th step, scaled to all of them
+    }
+    if (ms_sweeps) *ms_sweeps = sw;
+    return evm_env_timing_end(env, stream, ms_total, n_launches);
 }
 
 }  // extern "C"

@@ -189,6 +189,12 @@ class VecRobotWalk:
         check(lib.evm_env_timing_end(self._h, self._stream(), ctypes.byref(ms), ctypes.byref(n)))
         return ms.value, n.value
 
+    def timing_end_detail(self):
+        """(ms of whole steps, steps, ms inside the sweeps kernel — 0 when the monolithic kernel ran)"""
+        ms, n, sw = ctypes.c_float(), ctypes.c_int(), ctypes.c_float()
+        check(lib.evm_env_timing_end_detail(self._h, self._stream(), ctypes.byref(ms), ctypes.byref(n), ctypes.byref(sw)))
+        return ms.value, n.value, sw.value
+
 
 class VecRobotJump(VecRobotWalk):
     """robot_jump (evo_motion_model/src/env/robot_jump.cpp): the same skeleton, world and step; reward max(vy, 0) + vz,

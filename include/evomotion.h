@@ -141,6 +141,10 @@ int evm_env_get_stamps(EvmEnv *env, unsigned long long *h_out);
  * duration (ms) and the number of launches. */
 int evm_env_timing_begin(EvmEnv *env, void *stream);
 int evm_env_timing_end(EvmEnv *env, void *stream, float *ms_total, int *n_launches);
+/* A step is a short pipeline of kernels (reset prologue, two setup kernels, the Gauss-Seidel sweeps, integration +
+ * observation) up to 8192 envs, one monolithic kernel above; ms_total covers the whole step, ms_sweeps the sweeps kernel
+ * alone (the dominant one; 0 for the monolithic form). */
+int evm_env_timing_end_detail(EvmEnv *env, void *stream, float *ms_total, int *n_launches, float *ms_sweeps);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Agent side of the rollout: PpoGaeAgent::act for a whole batch
