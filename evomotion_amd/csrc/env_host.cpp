@@ -174,7 +174,10 @@ static int step_launch(EvmEnv *env, int mode, const float *a, float *obs, float 
                        const uint8_t *mask, hipStream_t s) {
     int rc = ensure_skeleton(env, s);
     if (rc != EVM_OK) return rc;
-    if (env->timing) {
+    // timed region: every 4th step is bracketed by an event pair (an event between two launches costs a bubble of a few
+    // microseconds on the stream, so the steps are sampled rather than all instrumented)
+    const bool sample = env->timing && (env->timed_launches % 4 == 0);
+    if (sample) {
         if (env->ev_used == env->ev_pairs.size()) {
             hipEvent_t a0, a1;
             HIP_TRY(hipEventCreate(&a0));
@@ -188,15 +191,14 @@ static int step_launch(EvmEnv *env, int mode, const float *a, float *obs, float 
         HIP_TRY(hipEventRecord(env->ev_pairs[env->ev_used].first, s));
     }
     HIP_TRY(evm::launch_step(env->d, evm::step_lds_bytes(env->skel.nb, env->skel.nscan), env->split, mode, a, obs, rew, done, valid, mask, s,
-                             // every 8th timed step also brackets its sweeps kernel (an event between two kernels costs a
-                             // bubble of a few microseconds: sampled, so that the timed region is not perturbed)
-                             (env->timing && env->ev_used % 8 == 0) ? env->ev_sweeps[env->ev_used].first : nullptr,
-                             (env->timing && env->ev_used % 8 == 0) ? env->ev_sweeps[env->ev_used].second : nullptr));
-    if (env->timing) {
+                             // every 8th step also brackets its sweeps kernel
+                             (sample && env->ev_used % 2 == 0) ? env->ev_sweeps[env->ev_used].first : nullptr,
+                             (sample && env->ev_used % 2 == 0) ? env->ev_sweeps[env->ev_used].second : nullptr));
+    if (sample) {
         HIP_TRY(hipEventRecord(env->ev_pairs[env->ev_used].second, s));
         env->ev_used++;
-        env->timed_launches++;
     }
+    if (env->timing) env->timed_launches++;
     return EVM_OK;
 }
 
@@ -505,6 +507,7 @@ int evm_env_timing_end(EvmEnv *env, void *stream, float *ms_total, int *n_launch
         HIP_TRY(hipEventElapsedTime(&t, env->ev_pairs[i].first, env->ev_pairs[i].second));
         ms += t;
     }
+    if (env->ev_used > 0) ms = ms / (float) env->ev_used * (float) env->timed_launches;  // sampled steps, scaled to all
     env->timing = false;
     if (ms_total) *ms_total = ms;
     if (n_launches) *n_launches = env->timed_launches;
@@ -519,11 +522,11 @@ int evm_env_timing_end_detail(EvmEnv *env, void *stream, float *ms_total, int *n
     const bool split = env->split < 0 ? env->d.n / 64 <= 128 : env->split == 1;
     if (split) {
         int ns = 0;
-        for (size_t i = 0; i < env->ev_used; i += 8) {
+        for (size_t i = 0; i < env->ev_used; i += 2) {
             float t = 0.f;
             if (hipEventElapsedTime(&t, env->ev_sweeps[i].first, env->ev_sweeps[i].second) == hipSuccess) { sw += t; ns++; }
         }
-        if (ns > 0) sw = sw / ns * (float) env->ev_used;  // sampled every 8th step, scaled to all of them
+        if (ns > 0) sw = sw / ns * (float) env->timed_launches;  // sampled every 8th step, scaled to all of them
     }
     if (ms_sweeps) *ms_sweeps = sw;
     return evm_env_timing_end(env, stream, ms_total, n_launches);
