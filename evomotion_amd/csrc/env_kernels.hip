@@ -1765,8 +1765,21 @@ __global__ __launch_bounds__(64 * EVM_SPLIT_WAVES) void k_split_pre_b(EnvDev d, 
     const LaneState L = lane_state<MODE>(c);
     const int vw = blockIdx.y * EVM_SPLIT_WAVES + c.wave, nvw = gridDim.y * EVM_SPLIT_WAVES;
     const bool powered = (L.flags & EVM_FLAG_POWERED) != 0 || ((MODE & 1) && !L.settling);
+#ifdef EVM_STAMPS5
+    int s5_kind = -1;
+    unsigned long long s5_t0 = 0;
+#endif
     // one item list: members first (manifold + contact rows, the longest items), then the joint visits
     for (int j = vw; j < c_skel.nm + c_skel.nvisit; j += nvw) {
+#ifdef EVM_STAMPS5  // diagnostic: longest item of each kind, per tile (cycles); tools/stamps5.py
+        {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            if (s5_kind >= 0 && c.lane == 0) atomicMax(&c.d.stamps[(size_t) blockIdx.x * 16 + s5_kind], now - s5_t0);
+            s5_kind = j < c_skel.nm ? (c_skel.member[j].hull_n > 64 ? 5 : 4) : c_skel.visit[j - c_skel.nm].type;
+            s5_t0 = now;
+        }
+#endif
+
         if (j < c_skel.nm) {
             // manifold maintenance, then the contact rows (warm start lands in the member's own deltas)
             const int m = j;
@@ -1791,6 +1804,9 @@ __global__ __launch_bounds__(64 * EVM_SPLIT_WAVES) void k_split_pre_b(EnvDev d, 
             default: { const int k = (V.slot - c_skel.sc_p) / EVM_P_STRIDE; p2p_setup(c, k >> 1, k & 1); break; }
         }
     }
+#ifdef EVM_STAMPS5
+    if (s5_kind >= 0 && c.lane == 0) atomicMax(&c.d.stamps[(size_t) blockIdx.x * 16 + s5_kind], __builtin_amdgcn_s_memtime() - s5_t0);
+#endif
 }
 
 __global__ __launch_bounds__(64 * EVM_NW) void k_split_sweeps(EnvDev d, const uint8_t *__restrict__ mask) {
