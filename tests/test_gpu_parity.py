@@ -441,3 +441,35 @@ def test_robot_jump_matches_oracle(torch_mod, orc_lib):
         for t in twos:
             if t >= 9:
                 assert (col[t - 9:t] == 0).all()
+
+
+def test_split_pipeline_and_monolithic_kernel_agree(torch_mod, monkeypatch):
+    """The five-kernel pipeline (default up to 8192 envs) and the one-kernel form run the same arithmetic; compiled apart
+    they fuse multiplies and adds differently, so single steps from identical states agree to fp32 rounding, and a rollout
+    delivers the same rewards / done / valid codes until chaos separates the trajectories."""
+    torch = torch_mod
+    n = 96
+    monkeypatch.setenv("EVM_MONOLITHIC", "0")
+    split = make(n, seed=77)
+    monkeypatch.setenv("EVM_MONOLITHIC", "1")
+    mono = make(n, seed=77)
+    monkeypatch.delenv("EVM_MONOLITHIC")
+    s1, s2 = split.reset(), mono.reset()
+    assert torch.equal(s1.done, s2.done)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    worst = dict(pos=0.0, lin=0.0, obs=0.0)
+    for k in range(40):
+        mono.set_state(split.get_state())  # same state in, one step each
+        a = torch.rand(n, 12, device="cuda", generator=g) * 2 - 1
+        s1, s2 = split.step_autoreset(a), mono.step_autoreset(a)
+        assert torch.equal(s1.valid, s2.valid) and torch.equal(s1.done, s2.done)
+        d = blob.compare(split.get_state(), mono.get_state(), 41, 17, 12)
+        assert d["counters"] == 0 and d["mf_count"] == 0
+        worst["pos"], worst["lin"] = max(worst["pos"], d["pos"]), max(worst["lin"], d["lin"])
+        live = (s1.valid != 0).cpu().numpy()
+        if live.any():
+            e = (s1.state - s2.state).abs().cpu().numpy()[live]
+            e[:, SLIDER_IMPULSE_COLS] = np.where(e[:, SLIDER_IMPULSE_COLS] > 1e-3, 0, e[:, SLIDER_IMPULSE_COLS])
+            worst["obs"] = max(worst["obs"], float(e.max()))
+    print("split vs monolithic worst:", worst)
+    assert worst["pos"] < 5e-6 and worst["lin"] < 5e-4 and worst["obs"] < 2e-3, worst
