@@ -774,11 +774,10 @@ DEV void store_mp(const Ctx &c, int m, int slot, const MPoint &p) {
 // multiply/add sequence.  Two vertices per packed instruction (pair layout of EvmSkelC::hull); the coordinates
 // are wave-uniform and arrive as wide scalar loads, four pairs per trip.  Even and odd vertices keep separate
 // running minima, merged at the end (lower value first, then lower index).
-DEV void hull_scan(const Ctx &c, int si, F3 r1) {
+DEV void hull_scan(const Ctx &c, int si, F3 r1, float oy) {
     const EvmScanC &S = c_skel.scan[si];
     const int m = S.member;
     const EvmMemberC &MB = c_skel.member[m];
-    const float oy = GS(pos, 3 * m + 1);
     const P2 rx = p2(r1.x, r1.x), ry = p2(r1.y, r1.y), rz = p2(r1.z, r1.z), oyp = p2(oy, oy);
     const float *hp = c_skel.hull + 3 * (MB.hull_off + S.begin);  // 6 floats per vertex pair
     const int np = (S.end - S.begin + 1) >> 1;
@@ -817,7 +816,8 @@ DEV void hull_scan(const Ctx &c, int si, F3 r1) {
 }
 
 // manifold maintenance for member m from the scanned deepest vertex; returns the number of cached points afterwards
-DEV int contact_update(const Ctx &c, int m, MPoint *pts_out = nullptr) {
+// drop: lanes whose env starts a reset with this step (their cached points are discarded: removeRigidBody/addRigidBody)
+DEV int contact_update(const Ctx &c, int m, MPoint *pts_out = nullptr, bool drop = false) {
     const EvmMemberC &MB = c_skel.member[m];
     const F3 o = G3(pos, 3 * m);
     const M33 R = m33(SC3(c_skel.sc_r + 9 * m), SC3(c_skel.sc_r + 9 * m + 3), SC3(c_skel.sc_r + 9 * m + 6));
@@ -829,11 +829,14 @@ DEV int contact_update(const Ctx &c, int m, MPoint *pts_out = nullptr) {
         if (b2 < best) { best = b2; bi = i2; }
     }
     const float *hp = c_skel.hull;
-    int n = GS(mfn, m);
+    int n = drop ? 0 : GS(mfn, m);
     const float thr = MB.break_thr;
     const float depth = (best - c_skel.floor_top_y) - (MARGIN_F + MARGIN_F);
     const bool add = !(depth > thr);
-    if (!__any(add || n > 0)) return 0;
+    if (!__any(add || n > 0)) {
+        if (__any(drop)) GS(mfn, m) = n;  // n == 0 in every lane here
+        return 0;
+    }
 
     MPoint p0 = load_mp(c, m, 0), p1 = load_mp(c, m, 1), p2 = load_mp(c, m, 2), p3 = load_mp(c, m, 3);
     const F3 fo = load_f3(c_skel.floor_o);
@@ -1110,13 +1113,32 @@ DEV float mt_uniform01(const Ctx &c) {
     return r;
 }
 
-// reset rotation: 3 RNG draws -> glm::eulerAngleYXZ (robot_walk.cpp:80-86)
-DEV M33 repose_draw(const Ctx &c) {
+// the k-th (k = 0..2) upcoming draw of the stream WITHOUT consuming it (the split pipeline learns the rotation of a reset
+// one kernel before the wave that owns the stream advances it).  Past the end of the block the value is what the
+// in-place regeneration will put there: new[j] = old[j + 397] ^ twist(old[j], old[j + 1]), j <= 2.
+DEV float mt_peek01(const Ctx &c, int k) {
+    const int p = c.d.mt_idx[c.env] + k;
+    const uint32_t *mt = c.t.mt + c.lane;
+    uint32_t y;
+    if (p < 624) y = mt[p << 6];
+    else {
+        const int j = p - 624;
+        const uint32_t a = mt[j << 6], b = mt[(j + 1) << 6];
+        const uint32_t t = (a & 0x80000000u) | (b & 0x7fffffffu);
+        y = mt[(j + 397) << 6] ^ (t >> 1) ^ ((t & 1u) ? 0x9908b0dfu : 0u);
+    }
+    y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+    float r = xm((float) y, 2.3283064365386963e-10f);
+    if (r >= 1.0f) r = 0.99999994f;
+    return r;
+}
+// reset rotation from its three uniform draws -> glm::eulerAngleYXZ (robot_walk.cpp:80-86)
+DEV M33 repose_rotation(float u0, float u1, float u2) {
     const float angle_limit = c_skel.reset_angle_limit;
     const float half = angle_limit / 2.f;
-    const float yaw = xs_(xm(mt_uniform01(c), angle_limit), half);
-    const float roll = xs_(xm(mt_uniform01(c), angle_limit), half);
-    const float pitch = xs_(xm(mt_uniform01(c), angle_limit), half);
+    const float yaw = xs_(xm(u0, angle_limit), half);
+    const float roll = xs_(xm(u1, angle_limit), half);
+    const float pitch = xs_(xm(u2, angle_limit), half);
     // sin/cos through fp64 so that the fp32 results are the correctly rounded ones (what glibc returns for
     // all but a handful of arguments); 6 evaluations per reset.
     const float ch = (float) cos((double) yaw), sh = (float) sin((double) yaw), cp = (float) cos((double) pitch),
@@ -1125,6 +1147,10 @@ DEV M33 repose_draw(const Ctx &c) {
     return m33(f3(xa(xm(ch, cb), xm(xm(sh, sp), sb)), xa(xm(-ch, sb), xm(xm(sh, sp), cb)), xm(sh, cp)),
                f3(xm(sb, cp), xm(cb, cp), -sp),
                f3(xa(xm(-sh, cb), xm(xm(ch, sp), sb)), xa(xm(sb, sh), xm(xm(ch, sp), cb)), xm(ch, cp)));
+}
+DEV M33 repose_draw(const Ctx &c) {  // consumes three draws
+    const float u0 = mt_uniform01(c), u1 = mt_uniform01(c), u2 = mt_uniform01(c);
+    return repose_rotation(u0, u1, u2);
 }
 // one body of RigidBodyItem::reset (item.cpp:77-86): new origin E t0 + root_pos, zero velocities; the world inverse inertia
 // tensor stays that of the last integrated transform
@@ -1147,8 +1173,9 @@ DEV void repose_body(const Ctx &c, int b, const M33 &E, bool was_pending) {
     if (b < c_skel.nm) SSC3(c_skel.sc_ms + 3 * b, o);  // motion state := new transform (item.cpp:81)
 }
 // per-env bookkeeping of a reset: manifolds dropped, rotation kept for the first step, counters
-DEV void repose_finish(const Ctx &c, const M33 &E, int flags) {
-    for (int m = 0; m < c_skel.nm; m++) GS(mfn, m) = 0;
+DEV void repose_finish(const Ctx &c, const M33 &E, int flags, bool drop_manifolds = true) {
+    if (drop_manifolds)
+        for (int m = 0; m < c_skel.nm; m++) GS(mfn, m) = 0;
     GS(E, 0) = E.r0.x; GS(E, 1) = E.r0.y; GS(E, 2) = E.r0.z;
     GS(E, 3) = E.r1.x; GS(E, 4) = E.r1.y; GS(E, 5) = E.r1.z;
     GS(E, 6) = E.r2.x; GS(E, 7) = E.r2.y; GS(E, 8) = E.r2.z;
@@ -1569,7 +1596,7 @@ DEV void physics_step(const Ctx &c, int flags) {
 
     // ---- collision: hull vs floor plane, persistent manifolds (members dealt to waves by hull size) ----
     for (int i = 0; i < c_skel.nscan; i++)
-        if (c_skel.scan[i].wave == W) hull_scan(c, i, SC3(c_skel.sc_r + 9 * c_skel.scan[i].member + 3));
+        if (c_skel.scan[i].wave == W) hull_scan(c, i, SC3(c_skel.sc_r + 9 * c_skel.scan[i].member + 3), GS(pos, 3 * c_skel.scan[i].member + 1));
     STAMP(9);   // wave 0: its own scans done
     __syncthreads();
     STAMP(10);  // all scans done
@@ -1676,7 +1703,6 @@ __global__ __launch_bounds__(64 * EVM_NW) void k_env_step(EnvDev d, const float 
 // copy of identical layout (EnvDev::gtile): the pre kernels fill it through the same LII / LDV / LPART accessors
 // (Ctx::lds points at it), the sweeps kernel loads it into LDS and stores the final deltas back, the post kernel
 // integrates from it.
-//   k_split_prologue  (rollout form only) in-band reset of finished envs: one wave per tile
 //   k_split_pre_a     bodies (basis, inertia, gyroscopic impulse) and hull-scan slices          items independent
 //   k_split_pre_b     joint records (+ muscle targets from the action), manifolds + contact rows items independent
 //   k_split_sweeps    10 sweeps + readbacks + the root's next motion state
@@ -1686,55 +1712,41 @@ __global__ __launch_bounds__(64 * EVM_NW) void k_env_step(EnvDev d, const float 
 #define EVM_SPLIT_WAVES 4  // waves per workgroup of the pre / post kernels
 
 DEV float *tile_stage(const EnvDev &d) { return d.gtile + (size_t) blockIdx.x * d.tile_floats; }
+// Per-lane view of the step that is starting.  In the rollout form an env whose last transition was terminal (DONE)
+// begins its reset with this call: nothing is written for that before the sweeps kernel (a single workgroup per tile, so
+// there is one writer and no reader left); the setup kernels derive the state the reset will produce ("effective"):
+// pending with the rotation the post kernel drew ahead (sc_nexte), settle counter at its start value, manifolds dropped.
 struct LaneState {
-    int flags;
-    bool pending, any_pending, settling;
-    int settle0;
-    M33 E;
+    int flags;            // live flags (not yet updated for a starting reset)
+    bool fin;             // a reset starts with this call
+    bool was_pending;     // PENDING before that
+    bool pending, any_pending, settling;   // effective
+    int settle0;                           // effective
+    M33 E;                                 // effective reset rotation (valid where pending)
 };
 template <int MODE>
 DEV LaneState lane_state(const Ctx &c) {
     LaneState L;
     L.flags = c.d.flags[c.env];
-    L.pending = (L.flags & EVM_FLAG_PENDING) != 0;
+    L.fin = (MODE & 4) && (L.flags & EVM_FLAG_DONE) != 0;
+    L.was_pending = (L.flags & EVM_FLAG_PENDING) != 0;
+    L.pending = L.was_pending || L.fin;
     L.any_pending = __any(L.pending);
-    L.settle0 = (MODE & 4) ? c.d.settle_left[c.env] : 0;
+    L.settle0 = (MODE & 4) ? (L.fin ? c_skel.settle_steps : c.d.settle_left[c.env]) : 0;
     L.settling = L.settle0 > 0;
-    if (L.any_pending)
+    if (L.any_pending) {
         L.E = m33(f3(GS(E, 0), GS(E, 1), GS(E, 2)), f3(GS(E, 3), GS(E, 4), GS(E, 5)), f3(GS(E, 6), GS(E, 7), GS(E, 8)));
+        if (__any(L.fin)) {
+            const M33 N = m33(SC3(c_skel.sc_nexte), SC3(c_skel.sc_nexte + 3), SC3(c_skel.sc_nexte + 6));
+            if (L.fin) L.E = N;
+        }
+    }
     return L;
 }
 // lanes outside the batch / the mask drop out (whole waves of a tile agree: every wave owns the same lanes)
 #define EVM_SPLIT_GUARD()                      \
     if (c.env >= d.n_real) return;             \
     if (mask && !mask[c.env]) return;
-
-__global__ __launch_bounds__(64 * EVM_NW) void k_split_prologue(EnvDev d, const uint8_t *__restrict__ mask) {
-    __shared__ float sE[9 * 64];
-    Ctx c = make_ctx(d, nullptr);
-    EVM_SPLIT_GUARD()
-    const int flags = d.flags[c.env];
-    const bool fin = (flags & EVM_FLAG_DONE) != 0;
-    if (!__any(fin)) return;  // wave-uniform, and the same in every wave of the tile
-    if (c.wave == 0 && fin) {  // the RNG stream and the rotation: one wave; the 41 bodies: all of them
-        const M33 E = repose_draw(c);
-        sE[0 * 64 + c.lane] = E.r0.x; sE[1 * 64 + c.lane] = E.r0.y; sE[2 * 64 + c.lane] = E.r0.z;
-        sE[3 * 64 + c.lane] = E.r1.x; sE[4 * 64 + c.lane] = E.r1.y; sE[5 * 64 + c.lane] = E.r1.z;
-        sE[6 * 64 + c.lane] = E.r2.x; sE[7 * 64 + c.lane] = E.r2.y; sE[8 * 64 + c.lane] = E.r2.z;
-    }
-    __syncthreads();
-    if (fin) {
-        const M33 E = m33(f3(sE[c.lane], sE[64 + c.lane], sE[128 + c.lane]), f3(sE[192 + c.lane], sE[256 + c.lane], sE[320 + c.lane]),
-                          f3(sE[384 + c.lane], sE[448 + c.lane], sE[512 + c.lane]));
-        const bool was_pending = (flags & EVM_FLAG_PENDING) != 0;
-        for (int b = c.wave; b < c_skel.nb; b += EVM_NW) repose_body(c, b, E, was_pending);
-        if (c.wave == 0) {
-            repose_finish(c, E, flags & ~EVM_FLAG_DONE);
-            d.settle_left[c.env] = c_skel.settle_steps;
-            GS(stat, 1) += 1;
-        }
-    }
-}
 
 template <int MODE>
 __global__ __launch_bounds__(64 * EVM_SPLIT_WAVES) void k_split_pre_a(EnvDev d, const uint8_t *__restrict__ mask) {
@@ -1744,7 +1756,11 @@ __global__ __launch_bounds__(64 * EVM_SPLIT_WAVES) void k_split_pre_a(EnvDev d, 
     const int vw = blockIdx.y * EVM_SPLIT_WAVES + c.wave, nvw = gridDim.y * EVM_SPLIT_WAVES;
     // one item list (bodies, then scan slices) dealt round robin, so that no wave gets the head of both
     for (int j = vw; j < c_skel.nb + c_skel.nscan; j += nvw) {
-        if (j < c_skel.nb) { body_prepare(c, j, L.pending, L.any_pending, L.E); continue; }
+        if (j < c_skel.nb) {
+            if (__any(L.fin)) { if (L.fin) repose_body(c, j, L.E, L.was_pending); }  // RigidBodyItem::reset of a starting reset
+            body_prepare(c, j, L.pending, L.any_pending, L.E);
+            continue;
+        }
         const int i = j - c_skel.nb;
         // the scan needs row 1 of the member's basis; the bodies are being prepared by other waves, so it is rebuilt here
         const int m = c_skel.scan[i].member;
@@ -1753,7 +1769,14 @@ __global__ __launch_bounds__(64 * EVM_SPLIT_WAVES) void k_split_pre_a(EnvDev d, 
             const M33 Rp = glm_mul_basis(L.E, load_m33(c_skel.body[m].m0));
             if (L.pending) R = Rp;
         }
-        hull_scan(c, i, R.r1);
+        float oy = GS(pos, 3 * m + 1);
+        if (__any(L.fin)) {  // the member's origin after the re-pose (another wave is writing it right now)
+            const F3 e0 = col0(L.E), e1 = col1(L.E), e2 = col2(L.E);
+            const F3 t0 = load_f3(c_skel.body[m].t0);
+            const float ry = xa(xa(xa(xm(e0.y, t0.x), xm(e1.y, t0.y)), xm(e2.y, t0.z)), c_skel.root_pos[1]);
+            if (L.fin) oy = ry;
+        }
+        hull_scan(c, i, R.r1, oy);
     }
 }
 
@@ -1785,7 +1808,8 @@ __global__ __launch_bounds__(64 * EVM_SPLIT_WAVES) void k_split_pre_b(EnvDev d, 
             const int m = j;
             int n = 0;
             MPoint pts[4];
-            if (c_skel.member[m].contact_response) n = contact_update(c, m, pts);
+            if (c_skel.member[m].contact_response) n = contact_update(c, m, pts, L.fin);
+            else if (__any(L.fin)) { if (L.fin) GS(mfn, m) = 0; }
             if (__any(n > 0)) contact_setup(c, m, n, pts);
             else { SSC3(c_skel.sc_pt + 6 * m, f3(0.f, 0.f, 0.f)); SSC3(c_skel.sc_pt + 6 * m + 3, f3(0.f, 0.f, 0.f)); }
             continue;
@@ -1809,11 +1833,13 @@ __global__ __launch_bounds__(64 * EVM_SPLIT_WAVES) void k_split_pre_b(EnvDev d, 
 #endif
 }
 
-__global__ __launch_bounds__(64 * EVM_NW) void k_split_sweeps(EnvDev d, const uint8_t *__restrict__ mask) {
+__global__ __launch_bounds__(64 * EVM_NW) void k_split_sweeps(EnvDev d, const uint8_t *__restrict__ mask, int autoreset) {
     extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
     Ctx c = make_ctx(d, lds_dyn);
     EVM_SPLIT_GUARD()
-    const bool any_pending = __any((d.flags[c.env] & EVM_FLAG_PENDING) != 0);
+    const int flags_in = d.flags[c.env];
+    const bool fin = autoreset && (flags_in & EVM_FLAG_DONE) != 0;  // a reset starts with this step (see LaneState)
+    const bool any_pending = __any((flags_in & EVM_FLAG_PENDING) != 0 || fin);
     // tile: staging copy -> LDS (solver deltas with the contact warm start, world inverse inertia); versions start at 0
     {
         const float *g = tile_stage(d);
@@ -1837,6 +1863,16 @@ __global__ __launch_bounds__(64 * EVM_NW) void k_split_sweeps(EnvDev d, const ui
         for (int k = c.wave; k < nfl; k += EVM_NW) g[(k << 6) + c.lane] = c.lds[(k << 6) + c.lane];
     }
     if (c.wave == 0) {
+        if (__any(fin)) {
+            // the one writer of a starting reset's bookkeeping (RobotWalk::reset_engine): the stream advances by the
+            // three draws whose rotation the setup kernels already used, flags / counters / settle count are set
+            if (fin) {
+                const M33 E = repose_draw(c);
+                repose_finish(c, E, flags_in & ~EVM_FLAG_DONE, false);  // the manifolds were dropped by the setup kernel
+                d.settle_left[c.env] = c_skel.settle_steps;
+                GS(stat, 1) += 1;
+            }
+        }
         SC(c_skel.sc_snap) = __int_as_float(d.flags[c.env]);
         SC(c_skel.sc_snap + 1) = __int_as_float(d.settle_left[c.env]);
         // the root's motion-state origin after this step, for every member's observation block (the post kernel's
@@ -1897,11 +1933,17 @@ __global__ __launch_bounds__(64 * EVM_SPLIT_WAVES) void k_split_post(EnvDev d, f
                 if (L.settling) d.settle_left[c.env] = L.settle0 - 1;
                 valid[c.env] = do_observe ? (L.settling ? 2 : 1) : 0;  // 1 = do_step transition, 2 = reset()'s own step
             }
+            bool fin_next = false;
             if (do_observe) {
                 observe_tail(c, reward, done);
-                if ((MODE & 4) && done[c.env]) flags |= EVM_FLAG_DONE;
+                if ((MODE & 4) && done[c.env]) { flags |= EVM_FLAG_DONE; fin_next = true; }
             }
             d.flags[c.env] = flags;
+            if ((MODE & 4) && __any(fin_next)) {
+                // the next call starts this env's reset: draw its rotation ahead (read-only) for that call's setup kernels
+                const M33 N = repose_rotation(mt_peek01(c, 0), mt_peek01(c, 1), mt_peek01(c, 2));
+                if (fin_next) { SSC3(c_skel.sc_nexte, N.r0); SSC3(c_skel.sc_nexte + 3, N.r1); SSC3(c_skel.sc_nexte + 6, N.r2); }
+            }
         }
     }
     if (any_observe)
@@ -2024,11 +2066,10 @@ static hipError_t launch_split(const EnvDev &d, size_t lds, const float *action,
     if (parts < 1) parts = 1;
     if (parts > 32) parts = 32;
     const dim3 gp(tiles, parts), bp(64 * EVM_SPLIT_WAVES);
-    if (MODE & 4) hipLaunchKernelGGL(k_split_prologue, dim3(tiles), dim3(64 * EVM_NW), 0, s, d, mask);
     hipLaunchKernelGGL((k_split_pre_a<MODE>), gp, bp, 0, s, d, mask);
     hipLaunchKernelGGL((k_split_pre_b<MODE>), gp, bp, 0, s, d, action, mask);
     if (e0) (void) hipEventRecord(e0, s);
-    hipLaunchKernelGGL(k_split_sweeps, dim3(tiles), dim3(64 * EVM_NW), lds, s, d, mask);
+    hipLaunchKernelGGL(k_split_sweeps, dim3(tiles), dim3(64 * EVM_NW), lds, s, d, mask, (MODE & 4) ? 1 : 0);
     if (e1) (void) hipEventRecord(e1, s);
     hipLaunchKernelGGL((k_split_post<MODE>), gp, bp, 0, s, d, obs, reward, done, valid, mask);
     return hipGetLastError();

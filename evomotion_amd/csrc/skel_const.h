@@ -118,6 +118,8 @@ struct EvmSkelC {
     int sc_r, sc_ext, sc_ms, sc_pt, sc_mobs, sc_h, sc_f, sc_s, sc_p, sc_c, sc_total;
     int sc_snap;           // 2 ints (as float bits): flags and settle_left as they were when the step began — the post kernel's
                            // waves read these while the root's wave rewrites the live values
+    int sc_nexte;          // 9 floats: rotation of the reset an env that just finished will start at its next call (drawn
+                           // read-only from its RNG stream by the post kernel; consumed by the next call's kernels)
     int sc_rootms;         // 3 floats: the root's motion-state origin after this step (split pipeline: written by the sweeps
                            // kernel, read by every observation block)
     float sched_cycles;  // host estimate of the 10 sweeps under the schedule's cost model (information only)

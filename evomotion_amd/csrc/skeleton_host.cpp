@@ -655,6 +655,7 @@ int load_skeleton_constants(const char *path, const EvmEnvParams &prm, EvmSkelC 
     S.sc_c = o; o += EVM_CM_STRIDE * nm;
     S.sc_rootms = o; o += 4;
     S.sc_snap = o; o += 4;
+    S.sc_nexte = o; o += 12;
     S.sc_total = o;
 
     // ---- sweep visit list (Bullet order: skeleton constraints, then slider / p2p_a / p2p_b per muscle) ----
