@@ -659,7 +659,7 @@ DEV float slider_solve(const Ctx &c, const EvmEntryC &V, const Blk42 &kk, BodyPD
     res = fmaxf(res, fabsf(row_iter<true, false, ISO>(q2, rel, Q, KV(kk, 24), KV(kk, 30), 0.f, 0.f, ap[3])));
     if (KV(kk, 25) != 0.f) res = fmaxf(res, fabsf(row_iter<true, true, ISO>(ax1, rel, Q, KV(kk, 25), KV(kk, 31), lo, hi_, ap[4])));
     if (KV(kk, 26) != 0.f) res = fmaxf(res, fabsf(row_iter<false, false, ISO>(ax1, rel, Q, KV(kk, 26), KV(kk, 32), 0.f, 0.f, ap[5])));
-    store_bodypd(c, V.a, V.b, Q);
+    // the sphere pair stays in the caller's registers for the two p2p constraints that follow
     {
         float w[EVM_S_STRIDE];
 #pragma unroll
@@ -692,11 +692,12 @@ DEV void p2p_setup(const Ctx &c, int mi, int which) {
 }
 // p2p rows along the world axes.  The pivot in the attach sphere is the origin (muscle.cpp:52,55), so the
 // sphere-side lever arm a2 is exactly zero: body B only takes the linear part.
-DEV float p2p_solve(const Ctx &c, const EvmEntryC &V, const Blk42 &kk, BodyD &A, F3 &dlB) {
-    const int ba = V.a, bb = V.b;
-    const int s = V.slot;
+// kk: the p2p record (4 quads), A: the member, dlB: the attach sphere's linear delta (kept by the caller), s: record slot
+struct Blk16 {
+    f32x4 q[4];
+};
+DEV float p2p_solve(const Ctx &c, int s, const Blk16 &kk, BodyD &A, F3 &dlB, float imB) {
     const F3 a1 = KV3(kk, 0);
-    const float imB = V.imB;
     float ap0 = KV(kk, 12), ap1 = KV(kk, 13), ap2 = KV(kk, 14);
     float res = 0.f;
     {   // x: c1 = a1 x e_x = (0, a1.z, -a1.y)
@@ -729,8 +730,6 @@ DEV float p2p_solve(const Ctx &c, const EvmEntryC &V, const Blk42 &kk, BodyD &A,
         A.dl.z += A.im * dI; A.da = A.da + angA * dI; dlB.z -= imB * dI;
         res = fmaxf(res, fabsf(dI));
     }
-    store_bodyd(c, ba, A);
-    LDV(bb, 0) = dlB.x; LDV(bb, 1) = dlB.y; LDV(bb, 2) = dlB.z;
     {
         float w[EVM_P_STRIDE];
         w[12] = ap0; w[13] = ap1; w[14] = ap2; w[15] = 0.f;
@@ -1374,8 +1373,7 @@ DEV void sweeps_run(const Ctx &c, bool any_pending, unsigned cmask, int ncontact
 #endif
     // ---- projected Gauss-Seidel sweeps ----
     // A wave walks its slice of the level schedule (EvmSkelC::sched); a workgroup barrier closes each level.
-    const int ns = c_skel.nsched[W];
-    const int *sched = c_skel.sched[W];
+    const int ns = c_skel.nwsched[W];
     float res = 0.f;
     // Dataflow sweep.  Visits that share no body commute exactly, so the only ordering that matters is, per body,
     // the order of the visits that touch it.  Every body carries a version counter in LDS (= how many visits have
@@ -1395,16 +1393,7 @@ DEV void sweeps_run(const Ctx &c, bool any_pending, unsigned cmask, int ncontact
 #ifdef EVM_STAMPS2
         const unsigned long long t0 = __builtin_amdgcn_s_memtime();
 #endif
-        S33P I;
-        const bool iso = V.iso && !any_pending;
-        if (iso) {
-            // both bodies of a muscle slider are attach spheres: inverse inertia k * identity, straight from the descriptor
-            I.xx = p2(V.kA, V.kB);
-            I.xy = I.xz = I.yz = p2(0.f, 0.f);
-            I.yy = I.zz = I.xx;
-        } else {
-            I = load_inertia_pair(c, V.a, V.b);
-        }
+        const S33P I = load_inertia_pair(c, V.a, V.b);
         wait_versions2(c, V.a, expA, V.b, expB);
 #ifdef EVM_STAMPS2
         const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -1413,25 +1402,11 @@ DEV void sweeps_run(const Ctx &c, bool any_pending, unsigned cmask, int ncontact
         const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
 #endif
         float r;
-        if (V.type == 3) {
-            BodyD A;
-            A.dl = f3(LDV(V.a, 0), LDV(V.a, 1), LDV(V.a, 2));
-            A.da = f3(LDV(V.a, 3), LDV(V.a, 4), LDV(V.a, 5));
-            A.I.xx = I.xx.x; A.I.xy = I.xy.x; A.I.xz = I.xz.x; A.I.yy = I.yy.x; A.I.yz = I.yz.x; A.I.zz = I.zz.x;
-            A.im = V.imA;
-            F3 dlB = f3(LDV(V.b, 0), LDV(V.b, 1), LDV(V.b, 2));
-            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
-            after_loads();
-            r = p2p_solve(c, V, k, A, dlB);
-        } else {
+        {
             BodyPD Q = load_bodypd(c, V.a, V.b, V.imA, V.imB, I);
             __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
             after_loads();
-            switch (V.type) {
-                case 0: r = hinge_solve(c, V, k, Q); break;
-                case 1: r = fixed_solve(c, V, k, Q); break;
-                default: r = iso ? slider_solve<true>(c, V, k, Q) : slider_solve<false>(c, V, k, Q); break;
-            }
+            r = V.type == 0 ? hinge_solve(c, V, k, Q) : fixed_solve(c, V, k, Q);
         }
         publish_version(c, V.a, expA + 1);
         publish_version(c, V.b, expB + 1);
@@ -1439,11 +1414,92 @@ DEV void sweeps_run(const Ctx &c, bool any_pending, unsigned cmask, int ncontact
         {
             const unsigned long long dt = __builtin_amdgcn_s_memtime() - ts0;
 #pragma unroll
-            for (int q = 0; q < 4; q++) if (V.type == q) { t_type[q] += dt; n_type[q]++; }
+            for (int q = 0; q < 2; q++) if (V.type == q) { t_type[q] += dt; n_type[q]++; }
         }
 #endif
 #ifdef EVM_STAMPS2
         t_wait += t1 - t0; t_solve += __builtin_amdgcn_s_memtime() - t1;
+#endif
+        return r;
+    };
+    // A whole muscle (type 5): slider between the two attach spheres, then the p2p of each sphere to its member, in Bullet's
+    // order.  The spheres are touched by nothing else: no version counters, one LDS load at the start and one store at the
+    // end.  The slider rows need nothing from outside, so they run before the entry waits for member a; member b is waited
+    // for only after a's rows are done and published.
+    auto run_muscle = [&](const EvmEntryC &V, const Blk42 &k, int it, auto &&after_loads) -> float {
+        const int sa = V.spheres & 0xffff, sb = V.spheres >> 16;
+        const int expA = it * V.psA + (V.need & 0xffff);
+        const int expB = it * V.psB + (V.need >> 16);
+#if defined(EVM_STAMPS2) || defined(EVM_STAMPS3)
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#endif
+        // the two p2p records: requested now, needed after the slider rows
+        Blk16 ra, rb;
+        {
+            const int mi = (V.slot - c_skel.sc_s) / EVM_S_STRIDE;
+            const f32x4 *pa = rec_quads(c, c_skel.sc_p + EVM_P_STRIDE * (2 * mi)), *pb = rec_quads(c, c_skel.sc_p + EVM_P_STRIDE * (2 * mi + 1));
+#pragma unroll
+            for (int q = 0; q < 4; q++) { ra.q[q] = pa[q << 6]; rb.q[q] = pb[q << 6]; }
+        }
+        const bool iso = V.iso && !any_pending;
+        S33P I;
+        if (iso) {  // inverse inertia k * identity, straight from the descriptor
+            I.xx = p2(V.kA, V.kB);
+            I.xy = I.xz = I.yz = p2(0.f, 0.f);
+            I.yy = I.zz = I.xx;
+        } else {
+            I = load_inertia_pair(c, sa, sb);
+        }
+        BodyPD Q = load_bodypd(c, sa, sb, V.imSa, V.imSb, I);
+        const S33 Ia = lds_inertia(c, V.a), Ib = lds_inertia(c, V.b);  // the members' tensors: constant during the sweeps
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+        after_loads();
+        float r = iso ? slider_solve<true>(c, V, k, Q) : slider_solve<false>(c, V, k, Q);
+        const int mi = (V.slot - c_skel.sc_s) / EVM_S_STRIDE;
+        unsigned long long twait = 0;
+        {   // p2p(a, sa)
+#ifdef EVM_STAMPS2
+            const unsigned long long w0 = __builtin_amdgcn_s_memtime();
+#endif
+            wait_version(c, V.a, expA);
+#ifdef EVM_STAMPS2
+            twait += __builtin_amdgcn_s_memtime() - w0;
+#endif
+            BodyD A;
+            A.dl = f3(LDV(V.a, 0), LDV(V.a, 1), LDV(V.a, 2));
+            A.da = f3(LDV(V.a, 3), LDV(V.a, 4), LDV(V.a, 5));
+            A.I = Ia; A.im = V.imA;
+            F3 dlS = lo(Q.dl);
+            r = fmaxf(r, p2p_solve(c, c_skel.sc_p + EVM_P_STRIDE * (2 * mi), ra, A, dlS, V.imSa));
+            store_bodyd(c, V.a, A);
+            publish_version(c, V.a, expA + 1);
+            Q.dl.x.x = dlS.x; Q.dl.y.x = dlS.y; Q.dl.z.x = dlS.z;
+        }
+        {   // p2p(b, sb)
+#ifdef EVM_STAMPS2
+            const unsigned long long w0 = __builtin_amdgcn_s_memtime();
+#endif
+            wait_version(c, V.b, expB);
+#ifdef EVM_STAMPS2
+            twait += __builtin_amdgcn_s_memtime() - w0;
+#endif
+            BodyD B;
+            B.dl = f3(LDV(V.b, 0), LDV(V.b, 1), LDV(V.b, 2));
+            B.da = f3(LDV(V.b, 3), LDV(V.b, 4), LDV(V.b, 5));
+            B.I = Ib; B.im = V.imB;
+            F3 dlS = hi(Q.dl);
+            r = fmaxf(r, p2p_solve(c, c_skel.sc_p + EVM_P_STRIDE * (2 * mi + 1), rb, B, dlS, V.imSb));
+            store_bodyd(c, V.b, B);
+            publish_version(c, V.b, expB + 1);
+            Q.dl.x.y = dlS.x; Q.dl.y.y = dlS.y; Q.dl.z.y = dlS.z;
+        }
+        // the spheres' deltas: imS sign convention of the pair (im = (1/m, -1/m)) does not touch dl / da themselves
+        store_bodypd(c, sa, sb, Q);
+#ifdef EVM_STAMPS3
+        { t_type[2] += __builtin_amdgcn_s_memtime() - t0; n_type[2]++; }
+#endif
+#ifdef EVM_STAMPS2
+        t_wait += twait; t_solve += __builtin_amdgcn_s_memtime() - t0 - twait;
 #endif
         return r;
     };
@@ -1485,7 +1541,7 @@ DEV void sweeps_run(const Ctx &c, bool any_pending, unsigned cmask, int ncontact
         return r;
     };
     auto run_entry = [&](const EvmEntryC &V, const Blk42 &k, int it, auto &&after_loads) -> float {
-        return V.type == 4 ? run_contact(V, it, k, after_loads) : run_visit(V, k, it, after_loads);
+        return V.type == 4 ? run_contact(V, it, k, after_loads) : (V.type == 5 ? run_muscle(V, k, it, after_loads) : run_visit(V, k, it, after_loads));
     };
     // a member without a cached point in any lane of the tile has nothing to prefetch
     auto entry_slots = [&](const EvmEntryC &V) { return (V.type == 4 && !(cmask & (1u << V.a))) ? 0 : V.nslots; };
@@ -1560,9 +1616,8 @@ DEV void sweeps_run(const Ctx &c, bool any_pending, unsigned cmask, int ncontact
 
     // ---- contact impulses back into the manifolds (by the wave that ran the member's contact rows) ----
     for (int i = 0; i < ns; i++) {
-        const int e = sched[i];
-        if ((e & EVM_SCHED_CONTACT) && (cmask & (1u << (e & (EVM_SCHED_CONTACT - 1)))))
-            contact_writeback(c, e & (EVM_SCHED_CONTACT - 1), GS(mfn, e & (EVM_SCHED_CONTACT - 1)));
+        const EvmEntryC &V = c_skel.wsched[W][i];
+        if (V.type == 4 && (cmask & (1u << V.a))) contact_writeback(c, V.a, GS(mfn, V.a));
     }
     // ---- muscle readbacks: getAppliedImpulse() = impulse of the last row written back ----
     for (int mi = W; mi < c_skel.nmus; mi += EVM_NW) {

@@ -85,17 +85,25 @@ struct EvmScanC {
 #define EVM_MAX_SCAN 96
 #define EVM_SCHED_BARRIER 0x8000
 #define EVM_SCHED_CONTACT 0x4000   // entry = EVM_SCHED_CONTACT | member: the member's contact rows of this sweep
+#define EVM_SCHED_MUSCLE 0x2000    // host scheduler only: muscle k = its three visits (slider, p2p_a, p2p_b) as one item
 
 // One entry of a wave's sweep stream, self-contained (64 bytes = one s_load_dwordx16 at an index that depends on
-// nothing but the stream position): a joint visit, or a member's contact rows (type 4, a = b = member).
+// nothing but the stream position):
+//   type 0 / 1   hinge / fixed visit on bodies (a, b)
+//   type 4       a member's contact rows (a = b = member)
+//   type 5       a whole muscle: slider(sa, sb), p2p(a, sa), p2p(b, sb) in Bullet's order.  The two attach spheres are
+//                touched by nothing else, so they need no version counters and stay in registers across the three; only
+//                the members a and b are waited for, each right before its own p2p rows.  slot = the slider's record,
+//                the p2p records follow at sc_p + 2 k EVM_P_STRIDE.
 struct EvmEntryC {
     int type, slot, a, b;
-    float imA, imB;
-    int nslots, need;
-    int psA, psB;   // EvmBodyC::per_sweep of the two bodies (version stride per sweep)
-    int iso;        // muscle slider between two isotropic bodies: scalar inverse inertias kA, kB
+    float imA, imB;     // inverse masses of a and b
+    int nslots, need;   // need = versions a (low 16 bits) and b must have reached within the sweep
+    int psA, psB;       // EvmBodyC::per_sweep of a and b (version stride per sweep)
+    int iso;            // type 5: both spheres isotropic, scalar inverse inertias kA, kB
     float kA, kB;
-    int pad[3];
+    int spheres;        // type 5: sa | sb << 16
+    float imSa, imSb;   // type 5: inverse masses of the spheres
 };
 #define EVM_MAX_WAVE_ENTRIES 48
 
@@ -132,6 +140,7 @@ struct EvmSkelC {
     // Entry = joint visit index, or EVM_SCHED_CONTACT | member.
     int nlevels;
     int nsched[EVM_NW];
+    int nwsched[EVM_NW];  // entries of wsched (a muscle is one entry there, three codes in sched)
     int sched[EVM_NW][EVM_MAX_SCHED];
     EvmEntryC wsched[EVM_NW][EVM_MAX_WAVE_ENTRIES];  // the same lists as self-contained descriptors (what the kernel walks)
     int member_wave[EVM_MAX_MEMBERS];  // which wave maintains the manifold and builds the contact rows of member m

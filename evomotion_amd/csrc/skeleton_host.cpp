@@ -708,7 +708,7 @@ int load_skeleton_constants(const char *path, const EvmEnvParams &prm, EvmSkelC 
         }
         S.nlevels = nlev;
         // items: joint visits in Bullet order, then one contact item per member (after all its joint visits)
-        struct Item { int a, b; float cost; int entry; };
+        struct Item { int a, b; float cost; int entry; float pre, ca, cb; };  // muscle: pre before any wait, ca / cb after a / b
         std::vector<Item> items;
         // measured on MI355X (tools/stamps3.py, cycles with two waves per SIMD): hinge 1750, fixed 1650, slider 2150,
         // p2p 900, a member's contact rows 1800 (with random actions some env of a 64-env tile touches the ground
@@ -716,8 +716,13 @@ int load_skeleton_constants(const char *path, const EvmEnvParams &prm, EvmSkelC 
         // (descriptor + record prefetch issue), ~300 for a dependency that crosses waves
         const float ovh = 600.f;
         const float cost_of[4] = {1750.f + ovh, 1650.f + ovh, 2150.f + ovh, 900.f + ovh};
-        for (int i = 0; i < nv; i++) items.push_back({S.visit[i].a, S.visit[i].b, cost_of[S.visit[i].type], i});
-        for (int m = 0; m < nm; m++) items.push_back({m, m, 1800.f + ovh, EVM_SCHED_CONTACT | m});
+        // a muscle (slider, p2p_a, p2p_b: consecutive in Bullet's order, skeleton.cpp:83-89) is ONE item on the members its
+        // two p2p constraints attach to; the attach spheres are private to it
+        const int nskel = nv - 3 * nmus;  // skeleton constraints come first in the visit list
+        for (int i = 0; i < nskel; i++) items.push_back({S.visit[i].a, S.visit[i].b, cost_of[S.visit[i].type], i, 0.f, 0.f, 0.f});
+        for (int k = 0; k < nmus; k++)
+            items.push_back({S.visit[nskel + 3 * k + 1].a, S.visit[nskel + 3 * k + 2].a, 2150.f + 2 * 800.f + ovh, EVM_SCHED_MUSCLE | k, 2150.f + ovh, 800.f, 800.f});
+        for (int m = 0; m < nm; m++) items.push_back({m, m, 1800.f + ovh, EVM_SCHED_CONTACT | m, 0.f, 0.f, 0.f});
         const int ni = (int) items.size();
         const float hop = 300.f;
         std::vector<std::vector<int>> preds(ni), succs(ni);
@@ -775,6 +780,21 @@ int load_skeleton_constants(const char *path, const EvmEnvParams &prm, EvmSkelC 
             for (int sweep = 0; sweep < 10; sweep++)
                 for (int i : topo) {
                     const int w = asg[i];
+                    if (items[i].entry & EVM_SCHED_MUSCLE) {
+                        // the slider rows touch only the private spheres; member a is waited for after them, member b
+                        // after a's rows
+                        float t = wave_t[w] + items[i].pre;
+                        const int ab[2] = {items[i].a, items[i].b};
+                        const float cc[2] = {items[i].ca, items[i].cb};
+                        for (int q = 0; q < 2; q++) {
+                            const float r = ready[ab[q]] + ((lastw[ab[q]] >= 0 && lastw[ab[q]] != w) ? hop : 0.f);
+                            t = std::max(t, r) + cc[q];
+                            ready[ab[q]] = t;
+                            lastw[ab[q]] = w;
+                        }
+                        wave_t[w] = t;
+                        continue;
+                    }
                     float st = wave_t[w];
                     for (int body : {items[i].a, items[i].b}) {
                         const float r = ready[body] + ((lastw[body] >= 0 && lastw[body] != w) ? hop : 0.f);
@@ -821,25 +841,36 @@ int load_skeleton_constants(const char *path, const EvmEnvParams &prm, EvmSkelC 
             }
         }
         S.sched_cycles = best_total;
-        for (int w = 0; w < EVM_NW; w++) S.nsched[w] = 0;
+        for (int w = 0; w < EVM_NW; w++) S.nsched[w] = S.nwsched[w] = 0;
         for (int i : topo) {
             const int w = wave_of[i];
-            if (S.nsched[w] >= EVM_MAX_SCHED || S.nsched[w] >= EVM_MAX_WAVE_ENTRIES) { err = "sweep schedule overflow"; return EVM_E_UNSUPPORTED; }
-            EvmEntryC &e = S.wsched[w][S.nsched[w]];
+            if (S.nsched[w] + 3 > EVM_MAX_SCHED || S.nwsched[w] >= EVM_MAX_WAVE_ENTRIES) { err = "sweep schedule overflow"; return EVM_E_UNSUPPORTED; }
+            EvmEntryC &e = S.wsched[w][S.nwsched[w]++];
             memset(&e, 0, sizeof(e));
             const int code = items[i].entry;
             if (code & EVM_SCHED_CONTACT) {
                 const int m = code & (EVM_SCHED_CONTACT - 1);
                 e.type = 4; e.slot = S.sc_c + EVM_CM_STRIDE * m; e.a = e.b = m; e.nslots = EVM_CM_STRIDE;
                 e.psA = e.psB = S.body[m].per_sweep;
+                S.sched[w][S.nsched[w]++] = code;
+            } else if (code & EVM_SCHED_MUSCLE) {
+                const int k = code & (EVM_SCHED_MUSCLE - 1);
+                const EvmVisitC &sl = S.visit[nskel + 3 * k], &pa = S.visit[nskel + 3 * k + 1], &pb = S.visit[nskel + 3 * k + 2];
+                e.type = 5; e.slot = sl.slot; e.nslots = sl.nslots;
+                e.a = pa.a; e.b = pb.a; e.imA = pa.imA; e.imB = pb.imA;
+                e.need = (pa.need & 0xffff) | ((pb.need & 0xffff) << 16);
+                e.psA = S.body[pa.a].per_sweep; e.psB = S.body[pb.a].per_sweep;
+                e.spheres = sl.a | (sl.b << 16);
+                e.imSa = sl.imA; e.imSb = sl.imB;
+                e.iso = S.body[sl.a].isotropic && S.body[sl.b].isotropic;
+                e.kA = S.body[sl.a].inv_inertia[0]; e.kB = S.body[sl.b].inv_inertia[0];
+                for (int q = 0; q < 3; q++) S.sched[w][S.nsched[w]++] = nskel + 3 * k + q;  // the three visits, for the record
             } else {
                 const EvmVisitC &v = S.visit[code];
                 e.type = v.type; e.slot = v.slot; e.a = v.a; e.b = v.b; e.imA = v.imA; e.imB = v.imB; e.nslots = v.nslots;
                 e.need = v.need; e.psA = S.body[v.a].per_sweep; e.psB = S.body[v.b].per_sweep;
-                e.iso = v.type == 2 && S.body[v.a].isotropic && S.body[v.b].isotropic;
-                e.kA = S.body[v.a].inv_inertia[0]; e.kB = S.body[v.b].inv_inertia[0];
+                S.sched[w][S.nsched[w]++] = code;
             }
-            S.sched[w][S.nsched[w]++] = code;
         }
         // hull scans -> waves (longest first); a hull of more than 64 vertices is cut into two slices
         S.nscan = 0;
