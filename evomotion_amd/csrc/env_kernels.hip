@@ -1458,11 +1458,11 @@ DEV void sweeps_run(const Ctx &c, bool any_pending, unsigned cmask, int ncontact
         const int mi = (V.slot - c_skel.sc_s) / EVM_S_STRIDE;
         unsigned long long twait = 0;
         {   // p2p(a, sa)
-#ifdef EVM_STAMPS2
+#if defined(EVM_STAMPS2) || defined(EVM_STAMPS3)
             const unsigned long long w0 = __builtin_amdgcn_s_memtime();
 #endif
             wait_version(c, V.a, expA);
-#ifdef EVM_STAMPS2
+#if defined(EVM_STAMPS2) || defined(EVM_STAMPS3)
             twait += __builtin_amdgcn_s_memtime() - w0;
 #endif
             BodyD A;
@@ -1476,11 +1476,11 @@ DEV void sweeps_run(const Ctx &c, bool any_pending, unsigned cmask, int ncontact
             Q.dl.x.x = dlS.x; Q.dl.y.x = dlS.y; Q.dl.z.x = dlS.z;
         }
         {   // p2p(b, sb)
-#ifdef EVM_STAMPS2
+#if defined(EVM_STAMPS2) || defined(EVM_STAMPS3)
             const unsigned long long w0 = __builtin_amdgcn_s_memtime();
 #endif
             wait_version(c, V.b, expB);
-#ifdef EVM_STAMPS2
+#if defined(EVM_STAMPS2) || defined(EVM_STAMPS3)
             twait += __builtin_amdgcn_s_memtime() - w0;
 #endif
             BodyD B;
@@ -1496,7 +1496,7 @@ DEV void sweeps_run(const Ctx &c, bool any_pending, unsigned cmask, int ncontact
         // the spheres' deltas: imS sign convention of the pair (im = (1/m, -1/m)) does not touch dl / da themselves
         store_bodypd(c, sa, sb, Q);
 #ifdef EVM_STAMPS3
-        { t_type[2] += __builtin_amdgcn_s_memtime() - t0; n_type[2]++; }
+        { t_type[2] += __builtin_amdgcn_s_memtime() - t0 - twait; n_type[2]++; t_type[3] += twait; n_type[3]++; }
 #endif
 #ifdef EVM_STAMPS2
         t_wait += twait; t_solve += __builtin_amdgcn_s_memtime() - t0 - twait;

@@ -710,19 +710,19 @@ int load_skeleton_constants(const char *path, const EvmEnvParams &prm, EvmSkelC 
         // items: joint visits in Bullet order, then one contact item per member (after all its joint visits)
         struct Item { int a, b; float cost; int entry; float pre, ca, cb; };  // muscle: pre before any wait, ca / cb after a / b
         std::vector<Item> items;
-        // measured on MI355X (tools/stamps3.py, cycles with two waves per SIMD): hinge 1750, fixed 1650, slider 2150,
-        // p2p 900, a member's contact rows 1800 (with random actions some env of a 64-env tile touches the ground
+        // measured on MI355X (tools/stamps3.py, cycles with two waves per SIMD): hinge 1500, fixed 1300, a whole muscle
+        // 3550 (slider rows ~1950, then ~800 per p2p), a member's contact rows 2050 (with random actions some env of a 64-env tile touches the ground
         // with nearly every member, so every member is costed as active); ~600 cycles of per-entry overhead
         // (descriptor + record prefetch issue), ~300 for a dependency that crosses waves
         const float ovh = 600.f;
-        const float cost_of[4] = {1750.f + ovh, 1650.f + ovh, 2150.f + ovh, 900.f + ovh};
+        const float cost_of[4] = {1500.f + ovh, 1300.f + ovh, 2150.f + ovh, 900.f + ovh};
         // a muscle (slider, p2p_a, p2p_b: consecutive in Bullet's order, skeleton.cpp:83-89) is ONE item on the members its
         // two p2p constraints attach to; the attach spheres are private to it
         const int nskel = nv - 3 * nmus;  // skeleton constraints come first in the visit list
         for (int i = 0; i < nskel; i++) items.push_back({S.visit[i].a, S.visit[i].b, cost_of[S.visit[i].type], i, 0.f, 0.f, 0.f});
         for (int k = 0; k < nmus; k++)
-            items.push_back({S.visit[nskel + 3 * k + 1].a, S.visit[nskel + 3 * k + 2].a, 2150.f + 2 * 800.f + ovh, EVM_SCHED_MUSCLE | k, 2150.f + ovh, 800.f, 800.f});
-        for (int m = 0; m < nm; m++) items.push_back({m, m, 1800.f + ovh, EVM_SCHED_CONTACT | m, 0.f, 0.f, 0.f});
+            items.push_back({S.visit[nskel + 3 * k + 1].a, S.visit[nskel + 3 * k + 2].a, 3550.f + ovh, EVM_SCHED_MUSCLE | k, 1950.f + ovh, 800.f, 800.f});
+        for (int m = 0; m < nm; m++) items.push_back({m, m, 2050.f + ovh, EVM_SCHED_CONTACT | m, 0.f, 0.f, 0.f});
         const int ni = (int) items.size();
         const float hop = 300.f;
         std::vector<std::vector<int>> preds(ni), succs(ni);

@@ -16,5 +16,5 @@ for k in range(K + 70):
         st = (ctypes.c_ulonglong * (n // 64 * 16))()
         check(lib.evm_env_get_stamps(env._h, st))
         acc += np.array(st, dtype=np.uint64).reshape(-1, 8, 2)[:, :6].astype(np.float64).sum(axis=0)
-for q, name in enumerate(["hinge", "fixed", "muscle (slider + 2 p2p)", "-", "contact(active)", "contact(idle)"]):
+for q, name in enumerate(["hinge", "fixed", "muscle (work)", "muscle (waits)", "contact(active)", "contact(idle)"]):
     print("%-16s %8.0f cycles/entry   %6.1f entries per tile-step" % (name, acc[q, 0] / max(acc[q, 1], 1), acc[q, 1] / K / (n // 64)))
