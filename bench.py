@@ -68,6 +68,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                     "the N>1 path with several ranks on ONE GPU)")
     ap.add_argument("--no-update", action="store_true", help="ppo mode: rollout only")
+    ap.add_argument("--ppo-update", choices=["hip", "torch"], default="hip",
+                    help="ppo mode: the update in the HIP trainer (csrc/ppo_kernels.hip) or through PyTorch-ROCm autograd")
     args = ap.parse_args()
 
     import torch
@@ -108,7 +110,7 @@ def main():
     if args.mode == "ppo":
         from evomotion_amd import VecPpoGaeAgent
         agent = VecPpoGaeAgent(1234, [env.state_dim], [env.action_dim], hidden_size=256, device=local_rank,
-                               horizon=args.horizon, epoch=8, learning_rate=1e-3)
+                               horizon=args.horizon, epoch=8, learning_rate=1e-3, update=args.ppo_update)
 
     sac = None
     if args.mode == "sac":
@@ -148,6 +150,13 @@ def main():
     rp = sac.replay.timing_end() if sac is not None else None
     barrier()
     t1 = time.perf_counter()
+    ppo_ms, ppo_epochs = 0.0, 0
+    if agent is not None and not args.no_update and args.ppo_update == "hip":
+        # one more update outside the timed region, with HIP events around each epoch (the events synchronise)
+        agent._trainer.timing(True)
+        agent.update()
+        ppo_ms, ppo_epochs = agent._trainer.timing(False)
+        torch.cuda.synchronize()
     if agent is not None:
         args.steps = n_launch
     elapsed = t1 - t0
@@ -185,7 +194,9 @@ def main():
                              "rollout form with in-band reset (configs[1])" % (n, world)) if agent is None else
                             ("robot_walk, %d envs/GPU on %d MI355X, PPO hidden_size=256, fused MFMA actor-critic forward "
                              "in the rollout, horizon %d, %s (configs[2])" % (n, world, args.horizon,
-                              "rollout only" if args.no_update else "PyTorch-ROCm PPO update (epoch 8) every horizon")),
+                              "rollout only" if args.no_update else
+                              ("HIP PPO update (fp32 MFMA forward / backward / weight gradients, epoch 8) every horizon" if args.ppo_update == "hip"
+                               else "PyTorch-ROCm PPO update (epoch 8) every horizon"))),
                 "envs_per_gpu": n,
                 "physics_steps_per_s": world * n * args.steps / elapsed,
                 "do_step_fraction": env_steps / (world * n * args.steps),
@@ -231,6 +242,18 @@ def main():
             out["roofline_policy"] = {"bound": "mfma", "achieved": tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                                       "frac": tf / VALU_PEAK_TFLOPS, "traffic": None, "kernel": "k_policy_forward",
                                       "launch_ms": pol_ms, "note": "fp32-input MFMA (v_mfma_f32_32x32x2_f32), dense fp32 matrix peak"}
+        if agent is not None and ppo_epochs:
+            ep_ms = ppo_ms / ppo_epochs
+            rows = n * args.horizon
+            # GEMM FLOP of one epoch, both networks: forward 654 848 per row + backward: the Linear(256,256)
+            # dgrad and the three weight-gradient GEMMs per network (no dgrad into the observations)
+            S_, A_ = env.state_dim, env.action_dim
+            bwd = 2.0 * (2 * 256 * 256 + 256 * 256 + S_ * 256) * 2 + 2.0 * (2 * (2 * A_) * 256 + 2 * 256)
+            tf = (654848.0 + bwd) * rows / (ep_ms * 1e-3) / 1e12
+            out["roofline_ppo_update"] = {"bound": "mfma", "achieved": tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                          "frac": tf / VALU_PEAK_TFLOPS, "traffic": None, "launch_ms": ep_ms, "rows": rows,
+                                          "kernel": "k_ppo_forward + k_ppo_loss_* + k_ppo_backward + k_ppo_wgrad (x6) + reductions + k_ppo_adam: one epoch",
+                                          "note": "HIP events around evm_ppo_grads .. evm_ppo_apply; fp32-input MFMA, dense fp32 matrix peak"}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

@@ -78,6 +78,20 @@ def _load():
     lib.evm_replay_sample.argtypes = [vp, ctypes.c_int, ctypes.c_uint64, vp, vp, vp, vp, vp, vp, vp]
     lib.evm_replay_timing_begin.argtypes = [vp]
     lib.evm_replay_timing_end.argtypes = [vp, vp, fp, ip, fp, ip]
+    dp = ctypes.POINTER(ctypes.c_double)
+    lib.evm_ppo_create.argtypes = [vp, ctypes.c_size_t, ctypes.POINTER(vp)]
+    lib.evm_ppo_destroy.argtypes = [vp]
+    lib.evm_ppo_destroy.restype = None
+    lib.evm_ppo_set_params.argtypes = [vp, vp, vp, ctypes.c_int, vp]
+    lib.evm_ppo_copy.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]
+    lib.evm_ppo_adam_step.argtypes = [vp, ctypes.c_int, ctypes.c_int, ip]
+    lib.evm_ppo_gae.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp, ctypes.c_float, ctypes.c_float, vp, vp, vp]
+    lib.evm_ppo_gae_normalize.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp]
+    lib.evm_ppo_grads.argtypes = [vp, ctypes.c_size_t, vp, vp, vp, vp, vp, vp, ctypes.c_double, ctypes.c_float, ctypes.c_float,
+                                  ctypes.c_float, vp]
+    lib.evm_ppo_apply.argtypes = [vp, ctypes.c_float, ctypes.c_float, vp]
+    lib.evm_ppo_losses.argtypes = [vp, dp, dp, vp]
+    lib.evm_ppo_timing.argtypes = [vp, ctypes.c_int, fp, ip]
     lib.evm_env_timing_begin.argtypes = [vp, vp]
     lib.evm_env_timing_end.argtypes = [vp, vp, fp, ip]
     lib.evm_env_timing_end_detail.argtypes = [vp, vp, fp, ip, fp]

@@ -325,7 +325,11 @@ class VecPpoGaeAgent:
 
     def __init__(self, seed, state_space, action_space, hidden_size=256, gamma=0.99, lam=0.95, epsilon=0.2,
                  entropy_factor=0.01, critic_loss_factor=0.5, epoch=8, learning_rate=1e-3, clip_grad_norm=0.5,
-                 device=0, horizon=32):
+                 device=0, horizon=32, update="hip"):
+        """update = "hip": PpoGaeAgent::train runs in the HIP trainer (ppo.py, csrc/ppo_kernels.hip), which owns the master
+        weights and Adam state; "torch": the same update through PyTorch-ROCm autograd (ppo_train), kept for comparison."""
+        if update not in ("hip", "torch"):
+            raise ValueError("update must be 'hip' or 'torch'")
         torch.manual_seed(seed)
         self.device = torch.device("cuda", device)
         self.actor = ActorModule(state_space, action_space, hidden_size).to(self.device)
@@ -339,6 +343,49 @@ class VecPpoGaeAgent:
         self.horizon = horizon
         self.seed = seed
         self._buf = None
+        self.update_mode = update
+        self.learning_rate = learning_rate
+        self._trainer = None
+        self._modules_stale = False
+
+    def _get_trainer(self, rows):
+        from .ppo import FusedPpoTrainer
+        if self._trainer is None or self._trainer.max_rows < rows:
+            if self._trainer is not None:
+                self.sync_modules()
+                self._trainer.close()
+            self._trainer = FusedPpoTrainer(self.fused, rows)
+            self._push_to_trainer()
+        return self._trainer
+
+    def _push_to_trainer(self):
+        """modules + torch optimiser states -> the trainer (construction, load())"""
+        from .ppo import EXP_AVG, EXP_AVG_SQ
+        tr = self._trainer
+        tr.set_modules(self.actor, self.critic, reset_optimizer=True)
+        for net, mod, opt in ((0, self.actor, self.actor_opt), (1, self.critic, self.critic_opt)):
+            ps = list(mod.parameters())
+            if all(p in opt.state and "exp_avg" in opt.state[p] for p in ps):
+                tr.load_vector(EXP_AVG, net, torch.cat([opt.state[p]["exp_avg"].reshape(-1) for p in ps]))
+                tr.load_vector(EXP_AVG_SQ, net, torch.cat([opt.state[p]["exp_avg_sq"].reshape(-1) for p in ps]))
+                tr.adam_step(net, int(float(opt.state[ps[0]]["step"])))
+
+    def sync_modules(self):
+        """the trainer's weights and Adam state -> the torch modules / optimisers (save(), evaluation in torch)"""
+        if self._trainer is None or not self._modules_stale:
+            return
+        from .ppo import EXP_AVG, EXP_AVG_SQ
+        tr = self._trainer
+        tr.params_into(self.actor, self.critic)
+        for net, mod, opt in ((0, self.actor, self.actor_opt), (1, self.critic, self.critic_opt)):
+            m, v, step = tr.vector(EXP_AVG, net), tr.vector(EXP_AVG_SQ, net), tr.adam_step(net)
+            o = 0
+            for p in mod.parameters():
+                n = p.numel()
+                opt.state[p] = dict(step=torch.tensor(float(step)), exp_avg=m[o:o + n].view_as(p).clone(),
+                                    exp_avg_sq=v[o:o + n].view_as(p).clone())
+                o += n
+        self._modules_stale = False
 
     def count_parameters(self):
         return count_parameters(self.actor, self.critic)
@@ -349,6 +396,7 @@ class VecPpoGaeAgent:
         addresses of the saving process (checkpoint.py)."""
         from .checkpoint import save_th
         import os
+        self.sync_modules()
         save_th(self.actor, os.path.join(output_folder_path, "actor.th"))
         save_th(self.critic, os.path.join(output_folder_path, "critic.th"))
         torch.save(self.actor_opt.state_dict(), os.path.join(output_folder_path, "actor_optimizer.pt"))
@@ -365,6 +413,9 @@ class VecPpoGaeAgent:
             if os.path.isfile(f):
                 opt.load_state_dict(torch.load(f, map_location=self.device))
         self.fused.load_modules(self.actor, self.critic)
+        if self._trainer is not None:
+            self._push_to_trainer()
+        self._modules_stale = False
 
     def rollout(self, env, last=None):
         """`horizon` calls of policy forward + evm_env_step_autoreset; everything stays on the device."""
@@ -390,6 +441,16 @@ class VecPpoGaeAgent:
 
     def update(self):
         b = self._buf
+        if self.update_mode == "hip":
+            T, N = b["rewards"].shape
+            tr = self._get_trainer(T * N)
+            mask = (b["valid_u8"] == 1).to(torch.uint8)
+            hp = self.hp
+            out = tr.train(b["states"], b["actions"], b["rewards"], b["done_u8"], b["logp"], b["values"], b["next_values"], mask,
+                           hp["gamma"], hp["lam"], hp["epsilon"], hp["entropy_factor"], hp["critic_loss_factor"], hp["epoch"],
+                           self.learning_rate, hp["clip_grad_norm"])
+            self._modules_stale = True
+            return out
         # [T,N] -> the reference's [B,T,1] layout; only do_step transitions (valid == 1) are trained on: settle
         # calls (0) and reset()'s own emission (2) are not transitions
         tr = lambda x: x.transpose(0, 1).contiguous()

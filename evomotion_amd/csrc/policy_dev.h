@@ -3,6 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <utility>
+#include <vector>
+
 namespace evm {
 
 struct NetDev {
@@ -26,3 +29,15 @@ hipError_t launch_policy_forward(const PolicyDev &p, int n, const float *obs, co
                                  hipStream_t s);
 
 }  // namespace evm
+
+// the handle behind evm_policy_* (policy_host.cpp); the PPO trainer (ppo_host.cpp) repacks its weights
+struct EvmPolicy {
+    int S, A, H, K1pad, device;
+    float *arena;
+    size_t arena_floats;
+    evm::PolicyDev dev;
+    uint64_t counter;
+    bool timing;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pairs;
+    size_t ev_used;
+};

@@ -15,16 +15,6 @@ thread_local std::string g_perr;
 extern "C" const char *evm_last_error(void);
 namespace evm { void set_last_error(const std::string &m); }
 
-struct EvmPolicy {
-    int S, A, H, K1pad, device;
-    float *arena;
-    size_t arena_floats;
-    evm::PolicyDev dev;
-    uint64_t counter;
-    bool timing;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pairs;
-    size_t ev_used;
-};
 
 static int pfail(int code, const std::string &m) { evm::set_last_error(m); return code; }
 

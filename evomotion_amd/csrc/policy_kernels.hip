@@ -16,92 +16,15 @@
 #include <stdint.h>
 
 #include "policy_dev.h"
+#include "mlp_tile.h"
 
 namespace evm {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-#define PT 256        // threads per workgroup (4 waves)
 #define RT 1          // 32-row MFMA tiles per wave: a workgroup owns TM = 32 RT rows.  RT = 1 puts the 4096-env batch
                       // of BASELINE configs[2] on 2 x 128 = 256 workgroups, one per CU (RT = 2 left half the chip idle)
 #define TM (32 * RT)
 #define PARTS (PT / TM)   // threads sharing a row in the row-wise epilogues
 #define RUN (256 / PARTS) // stored activations per thread (a contiguous run of the k-split row)
-#define K1 384        // padded input width of layer 1 (371 -> 384), fixed by the host packer
-#define ALD1 (K1 + 4) // k-split observation tile row stride
-#define ALD2 (256 + 4) // k-split activation tile row stride
-#define HIDX(row, c) ((row) * ALD2 + ((c) & 1) * 128 + ((c) >> 1))
-
-// Mish(x) = x tanh(softplus(x)).  With n = e^x: tanh(log(1 + n)) = n (n + 2) / (n (n + 2) + 2), all terms positive
-// (no cancellation), one exp and one division instead of exp + log1p + tanh (which cost ~300 VALU instructions per
-// value and were 40 % of the kernel).  x > 20: the ratio is 1 to fp32 precision and e^x would overflow at 88.
-__device__ __forceinline__ float mish_f(float x) {
-    const float n = __expf(fminf(x, 20.f));
-    const float m = n * (n + 2.f);
-    return x * __fdividef(m, m + 2.f);
-}
-__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
-__device__ __forceinline__ float theta_f(float x) { return 0.5f * (1.0f + erff(x / 1.41421356237309504880f)); }
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-// Operand packing for v_mfma_f32_32x32x2_f32: lane l = (j = l & 31, h = l >> 5) needs A[row j][k = 2s + h] and
-// B[k = 2s + h][col j] for k-step s.  Both operands are stored "k-split" so that FOUR consecutive k-steps of a
-// lane are 16 contiguous bytes:
-//   weights (global, packed on the host):  Wp[s4][col 0..255][h 0..1][t 0..3] = W[col][k = 2 (4 s4 + t) + h]
-//       -> one global_load_dwordx4 per lane per 4 k-steps, 1 KiB contiguous per wave instruction
-//   activations / observations (LDS):      As[row][h][kk] with k = 2 kk + h, row stride ALD floats
-//       -> one ds_read_b128 per lane per 4 k-steps
-// ALD = 2 * KH + 4 with KH = K/2 (a multiple of 4): the +4 skews rows by one 16-byte slot so that the 16-lane groups
-// of ds_read_b128 hit distinct slots.
-template <int K>
-__device__ __forceinline__ void dense_layer(const float *as, int ald, const float *__restrict__ Wp, int wave, int lane,
-                                            f32x16 (&acc)[RT][2]) {
-#pragma unroll
-    for (int i = 0; i < RT; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-    const int aj = lane & 31, ah = lane >> 5;
-    const int col = wave * 64 + aj;
-    constexpr int KH = K / 2;
-    const float *ap = as + aj * ald + ah * KH;
-    const float *b0p = Wp + ((size_t) col * 2 + ah) * 4;
-    const float *b1p = Wp + ((size_t) (col + 32) * 2 + ah) * 4;
-    // Software pipeline, 4-deep register ring: the operands of block s4 + 3 are requested before the 8 RT MFMAs of
-    // block s4 issue, i.e. ~1500 cycles ahead — more than an L2 hit.  (Left to itself the compiler issued each
-    // block's loads right before its own MFMAs and waited on them: the kernel ran at half speed.)
-    constexpr int NB = K / 8;
-    static_assert(NB % 4 == 0, "K must be a multiple of 32");
-    f32x4 a[4][RT], b0[4], b1[4];
-#define EVM_LOADQ(q, s)                                                                                   \
-    {                                                                                                     \
-        _Pragma("unroll") for (int i = 0; i < RT; i++) a[q][i] =                                        \
-            *reinterpret_cast<const f32x4 *>(ap + i * 32 * ald + 4 * (s));                                \
-        b0[q] = *reinterpret_cast<const f32x4 *>(b0p + (size_t) (s) * 2048);                              \
-        b1[q] = *reinterpret_cast<const f32x4 *>(b1p + (size_t) (s) * 2048);                              \
-    }
-    EVM_LOADQ(0, 0) EVM_LOADQ(1, 1) EVM_LOADQ(2, 2)
-    __builtin_amdgcn_sched_barrier(0);
-    for (int s4 = 0; s4 < NB; s4 += 4) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int sn = min(s4 + q + 3, NB - 1);  // the last three requests re-read the final block (harmless)
-            EVM_LOADQ((q + 3) & 3, sn)
-            __builtin_amdgcn_sched_barrier(0);  // keep the requests ahead of this block's MFMAs
-#pragma unroll
-            for (int t = 0; t < 4; t++)
-#pragma unroll
-                for (int i = 0; i < RT; i++) {
-                    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][i][t], b0[q][t], acc[i][0], 0, 0, 0);
-                    acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][i][t], b1[q][t], acc[i][1], 0, 0, 0);
-                }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-#undef EVM_LOADQ
-}
 
 // bias + Mish into the activation tile, then LayerNorm(256) per row
 __device__ __forceinline__ void epilogue_mish_ln(f32x16 (&acc)[RT][2], const float *__restrict__ bias,
@@ -176,54 +99,13 @@ __global__ __launch_bounds__(PT) void k_policy_forward(PolicyDev p, int n, const
     const int row0 = blockIdx.x * TM;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const NetDev &N = net == 0 ? p.actor : p.critic;
-    {   // stage the TM x S observation tile once, zero padded to K1 columns, k-split in LDS
-        const int S = p.S;
-        const size_t base = (size_t) row0 * S;
-        const int tile = TM * S;  // floats; rows of the tile are contiguous in memory
-        if (row0 + TM <= n && (tile & 3) == 0 && ((reinterpret_cast<uintptr_t>(obs + base)) & 15) == 0) {
-            // full, 16-byte aligned tile: flat float4 loads, all in flight together
-            const f32x4 *src = reinterpret_cast<const f32x4 *>(obs + base);
-            const int nq = tile >> 2;
-            constexpr int NIT = (TM * K1 / 4 + PT - 1) / PT;  // upper bound (S <= K1)
-            f32x4 v[NIT];
-#pragma unroll
-            for (int it = 0; it < NIT; it++) {
-                const int q = it * PT + (int) threadIdx.x;
-                v[it] = src[min(q, nq - 1)];
-            }
-#pragma unroll
-            for (int it = 0; it < NIT; it++) {
-                const int q = it * PT + (int) threadIdx.x;
-                if (q < nq) {
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        const int e = 4 * q + u, r = e / S, k = e - r * S;
-                        xs[r * ALD1 + (k & 1) * (K1 / 2) + (k >> 1)] = v[it][u];
-                    }
-                }
-            }
-            for (int e = threadIdx.x; e < TM * (K1 - S); e += PT) {
-                const int r = e / (K1 - S), k = S + e % (K1 - S);
-                xs[r * ALD1 + (k & 1) * (K1 / 2) + (k >> 1)] = 0.f;
-            }
-        } else {
-            // ragged last tile or unaligned caller buffer: scalar loads, clamped address + select (no branches)
-            const size_t last = (size_t) n * S - 1;
-            for (int e = threadIdx.x; e < TM * K1; e += PT) {
-                const int r = e / K1, k = e % K1;
-                const bool ok = row0 + r < n && k < S;
-                const size_t g = base + (size_t) r * S + k;
-                const float v = obs[g < last ? g : last];
-                xs[r * ALD1 + (k & 1) * (K1 / 2) + (k >> 1)] = ok ? v : 0.f;
-            }
-        }
-    }
+    stage_rows_ksplit<TM>(xs, obs, row0, n, p.S);
     __syncthreads();
     f32x16 acc[RT][2];
-    dense_layer<K1>(xs, ALD1, N.w1t, wave, lane, acc);
+    dense_layer<K1, RT>(xs, ALD1, N.w1t, wave, lane, acc);
     __syncthreads();  // every wave has finished reading the observation tile
     epilogue_mish_ln(acc, N.b1, N.g1, N.be1, hb, wave, lane);
-    dense_layer<256>(hb, ALD2, N.w2t, wave, lane, acc);
+    dense_layer<256, RT>(hb, ALD2, N.w2t, wave, lane, acc);
     __syncthreads();  // every wave has finished reading the layer-1 activations
     epilogue_mish_ln(acc, N.b2, N.g2, N.be2, hb, wave, lane);
 

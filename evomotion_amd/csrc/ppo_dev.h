@@ -1,0 +1,53 @@
+// Device-side buffers and launchers of the PPO update (ppo_kernels.hip; C ABI in ppo_host.cpp).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "policy_dev.h"
+
+namespace evm {
+
+// one network's training state.  Parameters, gradients and Adam moments are flat fp32 vectors in the reference's
+// named_parameters() order (the layout evm_policy_set_weights takes); activations are row-major [rows][256].
+struct PpoNet {
+    float *theta, *grad, *m, *v;  // [n_params]
+    size_t n_params;
+    float *w2d;                   // Linear(256,256) weight packed for the dgrad GEMM: B[k = out j][col = in i]
+    float *z1, *a1, *z2, *a2;     // pre-Mish and post-LayerNorm activations of the two hidden layers
+    float *st;                    // [rows][4]: LayerNorm mean, rstd of layer 1, of layer 2
+    float *head;                  // actor: [rows][2A] = mu, sigma (after tanh / softplus); critic: [rows] values
+    float *dh;                    // [rows][32] gradient of the loss w.r.t. the head pre-activations
+    float *dz1, *dz2;             // gradients w.r.t. z1, z2
+    float *colpart;               // [tiles][7][256] per-tile column sums (LayerNorm / bias gradients)
+    float *colpart2;              // [64][7][256] second reduction level
+    float *wpart;                 // split-K partials of the weight gradients
+    float *norm;                  // [1] gradient norm of the net
+    int step;                     // Adam step count
+};
+
+struct PpoDev {
+    int S, A;
+    size_t max_rows;
+    PpoNet actor, critic;
+    double *loss;   // [2] actor, critic loss sums of the last evm_ppo_grads call
+    double *gae;    // [3] n, mean, M2 of the raw advantages
+};
+
+constexpr int PPO_SK = 64;       // split-K chunks of the weight-gradient GEMMs
+constexpr int PPO_COLSLOTS = 7;  // dgamma2, dbeta2, dbias2, dgamma1, dbeta1, dbias1, dbias_heads
+
+hipError_t launch_ppo_pack_w2d(const PpoNet &n, int S, hipStream_t s);
+hipError_t launch_ppo_forward(const PolicyDev &p, const PpoDev &d, size_t rows, const float *states, hipStream_t s);
+hipError_t launch_ppo_loss(const PpoDev &d, size_t rows, const float *actions, const float *logp_old, const float *adv,
+                           const float *returns, const uint8_t *mask, double inv_rows, float epsilon, float entropy_factor,
+                           float critic_loss_factor, hipStream_t s);
+hipError_t launch_ppo_backward(const PolicyDev &p, const PpoDev &d, size_t rows, hipStream_t s);
+hipError_t launch_ppo_wgrads(const PpoDev &d, size_t rows, const float *states, hipStream_t s);
+hipError_t launch_ppo_apply(const PolicyDev &p, PpoDev &d, float lr, float clip_grad_norm, hipStream_t s);
+hipError_t launch_ppo_gae_scan(const PpoDev &d, int T, int N, const float *rewards, const uint8_t *done, const float *curr_values,
+                               const float *next_values, const uint8_t *mask, float gamma, float lam, float *adv, hipStream_t s);
+hipError_t launch_ppo_gae_finish(int T, int N, const double *stats, const float *curr_values, const uint8_t *mask, float *adv,
+                                 float *returns, hipStream_t s);
+size_t ppo_wpart_floats();
+
+}  // namespace evm

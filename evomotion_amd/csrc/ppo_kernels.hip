@@ -1,0 +1,760 @@
+// PPO / GAE update on the device (gfx950, fp32 MFMA): replaces the PyTorch-ROCm autograd pass of
+//   PpoGaeAgent::train                    evo_motion_networks/src/agents/ppo_gae.cpp:117-190
+//   ActorModule / CriticModule            evo_motion_networks/src/networks/actor.cpp:9-48, critic.cpp:8-35
+//   truncated_normal_log_pdf / _entropy   evo_motion_networks/src/functions.cpp:94-128
+//   clip_grad_norm_ + torch::optim::Adam  ppo_gae.cpp:170-186
+//
+// One epoch = k_ppo_forward (both networks, activations kept) -> k_ppo_loss_* (loss + gradient at the head
+// pre-activations) -> k_ppo_backward (per 32-row tile: heads, LayerNorm, Mish, the Linear(256,256) dgrad on MFMA)
+// -> k_ppo_wgrad (weight gradients: split-K MFMA GEMMs over the rows) + reductions -> gradient norm, clip, Adam and
+// the repack of the new weights into the operand layout of the forward kernels.  Every reduction runs in a fixed
+// order: the update is deterministic.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mlp_tile.h"
+#include "ppo_dev.h"
+
+namespace evm {
+
+#define PRT 1  // 32-row MFMA tiles per wave in the training kernels (TM = 32 rows per workgroup)
+
+// ---------------------------------------------------------------------------------------------------------
+// tile helpers (k-split activation tile [TM][ALD2] <-> row-major [rows][256] in HBM)
+// ---------------------------------------------------------------------------------------------------------
+template <int TM_>
+__device__ __forceinline__ void tile_load(float *T, const float *__restrict__ src, int row0, int n) {
+    constexpr int NIT = TM_ * 64 / PT;
+    f32x4 v[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+        const int e = it * PT + (int) threadIdx.x, r = e >> 6, c4 = (e & 63) * 4;
+        const int gr = row0 + r;
+        v[it] = *reinterpret_cast<const f32x4 *>(src + (size_t) (gr < n ? gr : n - 1) * 256 + c4);
+        if (gr >= n) v[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+        const int e = it * PT + (int) threadIdx.x, r = e >> 6, c4 = (e & 63) * 4;
+#pragma unroll
+        for (int u = 0; u < 4; u++) T[HIDX(r, c4 + u)] = v[it][u];
+    }
+}
+// thread = column: coalesced 1 KiB rows
+template <int TM_>
+__device__ __forceinline__ void tile_store(const float *T, float *__restrict__ dst, int row0, int n) {
+    const int c = threadIdx.x;
+#pragma unroll 8
+    for (int r = 0; r < TM_; r++)
+        if (row0 + r < n) dst[(size_t) (row0 + r) * 256 + c] = T[HIDX(r, c)];
+}
+template <int TM_>
+__device__ __forceinline__ float tile_colsum(const float *T) {
+    const int c = threadIdx.x;
+    float s = 0.f;
+#pragma unroll 8
+    for (int r = 0; r < TM_; r++) s += T[HIDX(r, c)];
+    return s;
+}
+// MFMA accumulators (C layout: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)) -> tile, plus a per-column bias
+template <int RT>
+__device__ __forceinline__ void acc_to_tile(const f32x16 (&acc)[RT][2], const float *__restrict__ bias, float *T, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < RT; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int c = wave * 64 + j * 32 + (lane & 31);
+            const float b = bias ? bias[c] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                T[HIDX(row, c)] = acc[i][j][r] + b;
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// forward with the activations kept
+// ---------------------------------------------------------------------------------------------------------
+// z = acc + bias -> HBM; Mish + LayerNorm per row -> tile and HBM; (mean, rstd) -> st[row][st_off..]
+template <int RT>
+__device__ __forceinline__ void train_epilogue(const f32x16 (&acc)[RT][2], const float *__restrict__ bias,
+                                               const float *__restrict__ gamma, const float *__restrict__ beta, float *hb,
+                                               int wave, int lane, int row0, int n, float *zg, float *ag, float *st, int st_off) {
+    constexpr int TM = 32 * RT, PARTS = PT / TM, RUN = 256 / PARTS;
+    acc_to_tile<RT>(acc, bias, hb, wave, lane);
+    __syncthreads();
+    tile_store<TM>(hb, zg, row0, n);
+    __syncthreads();
+    const int t = threadIdx.x, row = t / PARTS, part = t % PARTS;
+    f32x4 *hr = reinterpret_cast<f32x4 *>(hb + row * ALD2 + part * RUN);
+    f32x4 x[RUN / 4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < RUN / 4; i++) {
+        x[i] = hr[i];
+#pragma unroll
+        for (int u = 0; u < 4; u++) x[i][u] = mish_f(x[i][u]);
+        s += (x[i][0] + x[i][1]) + (x[i][2] + x[i][3]);
+    }
+#pragma unroll
+    for (int m = 1; m < PARTS; m <<= 1) s += __shfl_xor(s, m);
+    const float mean = s / 256.f;
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < RUN / 4; i++)
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const float d = x[i][u] - mean; v += d * d; }
+#pragma unroll
+    for (int m = 1; m < PARTS; m <<= 1) v += __shfl_xor(v, m);
+    const float rstd = 1.0f / sqrtf(v / 256.f + 1e-5f);
+    if (part == 0 && row0 + row < n) {
+        st[(size_t) (row0 + row) * 4 + st_off] = mean;
+        st[(size_t) (row0 + row) * 4 + st_off + 1] = rstd;
+    }
+#pragma unroll
+    for (int i = 0; i < RUN / 4; i++) {
+        f32x4 y;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int q = part * RUN + 4 * i + u;
+            const int c = 2 * (q & 127) + (q >> 7);
+            y[u] = (x[i][u] - mean) * rstd * gamma[c] + beta[c];
+        }
+        hr[i] = y;
+    }
+    __syncthreads();
+    tile_store<TM>(hb, ag, row0, n);
+}
+
+template <int RT>
+__global__ __launch_bounds__(PT) void k_ppo_forward(PolicyDev p, PpoDev d, int n, const float *__restrict__ states) {
+    constexpr int TM = 32 * RT, PARTS = PT / TM, RUN = 256 / PARTS;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *xs = sm, *hb = sm;
+    const int net = blockIdx.y;
+    const int row0 = blockIdx.x * TM;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const NetDev &N = net == 0 ? p.actor : p.critic;
+    const PpoNet &B = net == 0 ? d.actor : d.critic;
+    stage_rows_ksplit<TM>(xs, states, row0, n, p.S);
+    __syncthreads();
+    f32x16 acc[RT][2];
+    dense_layer<K1, RT>(xs, ALD1, N.w1t, wave, lane, acc);
+    __syncthreads();
+    train_epilogue<RT>(acc, N.b1, N.g1, N.be1, hb, wave, lane, row0, n, B.z1, B.a1, B.st, 0);
+    dense_layer<256, RT>(hb, ALD2, N.w2t, wave, lane, acc);
+    __syncthreads();
+    train_epilogue<RT>(acc, N.b2, N.g2, N.be2, hb, wave, lane, row0, n, B.z2, B.a2, B.st, 2);
+
+    // heads, as in k_policy_forward
+    const int t = threadIdx.x, row = t / PARTS, part = t % PARTS;
+    const int gr = row0 + row;
+    const int A = p.A;
+    const int nout = net == 1 ? 1 : 2 * A;
+    float *wl = sm + TM * ALD2;
+    float *hs = wl + 32 * 256;
+    for (int e = threadIdx.x; e < nout * 256; e += PT) {
+        const int c = e & 255;
+        wl[(e & ~255) + (c & 1) * 128 + (c >> 1)] = N.wh[e];
+    }
+    __syncthreads();
+    {
+        const f32x4 *hr = reinterpret_cast<const f32x4 *>(hb + row * ALD2 + part * RUN);
+        f32x4 x[RUN / 4];
+#pragma unroll
+        for (int i = 0; i < RUN / 4; i++) x[i] = hr[i];
+        for (int o = 0; o < nout; o++) {
+            const f32x4 *wr = reinterpret_cast<const f32x4 *>(wl + o * 256 + part * RUN);
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < RUN / 4; i++) {
+                const f32x4 w = wr[i];
+                sum += (x[i][0] * w[0] + x[i][1] * w[1]) + (x[i][2] * w[2] + x[i][3] * w[3]);
+            }
+#pragma unroll
+            for (int m = 1; m < PARTS; m <<= 1) sum += __shfl_xor(sum, m);
+            if (part == 0) hs[row * 32 + o] = sum + N.bh[o];
+        }
+    }
+    if (net == 1) {
+        if (part == 0 && gr < n) B.head[gr] = hs[row * 32];
+        return;
+    }
+    __syncthreads();
+    for (int a = part; a < A; a += PARTS) {
+        if (gr >= n) continue;
+        B.head[(size_t) gr * 2 * A + a] = tanhf(hs[row * 32 + a]);
+        B.head[(size_t) gr * 2 * A + A + a] = softplus_f(hs[row * 32 + A + a]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// losses and their gradients at the head pre-activations
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double block_sum_double(double v, double *sh) {
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    double s = 0.0;
+    for (int i = 0; i < nw; i++) s += sh[i];
+    return s;
+}
+
+// clipped surrogate + entropy bonus (ppo_gae.cpp:155-166); 32 threads per row, thread o < A owns action dimension o.
+// inv_count = 1 / (masked rows of ALL ranks x A): the loss is the mean over the selected elements.
+__global__ __launch_bounds__(256) void k_ppo_loss_actor(PpoDev d, int n, const float *__restrict__ actions,
+                                                        const float *__restrict__ logp_old, const float *__restrict__ adv,
+                                                        const uint8_t *__restrict__ mask, float inv_count, float eps, float ef) {
+    __shared__ double sh[4];
+    const size_t tg = (size_t) blockIdx.x * 256 + threadIdx.x;
+    const size_t row = tg >> 5;
+    const int o = (int) (tg & 31), A = d.A;
+    float lsum = 0.f;
+    if (row < (size_t) n) {
+        float *dh = d.actor.dh + row * 32;
+        if (o < A) {
+            float g_mu = 0.f, g_sg = 0.f;
+            if (mask[row]) {
+                const float mu = d.actor.head[row * 2 * A + o], sg = d.actor.head[row * 2 * A + A + o];
+                const float x = actions[row * A + o], lpo = logp_old[row * A + o], Adv = adv[row];
+                const float INV_SQRT_2PI = 0.39894228040143267794f;
+                const float s = fminf(fmaxf(sg, 1e-6f), 1e6f);
+                const float cs = (sg >= 1e-6f && sg <= 1e6f) ? 1.f : 0.f;
+                const float is = 1.0f / s;
+                const float ar = (-1.f - mu) / s, br = (1.f - mu) / s;
+                const float al = fminf(fmaxf(ar, -5.f), 5.f), be = fminf(fmaxf(br, -5.f), 5.f);
+                const float ca = (ar >= -5.f && ar <= 5.f) ? 1.f : 0.f, cb = (br >= -5.f && br <= 5.f) ? 1.f : 0.f;
+                const float ta = theta_f(al), tb = theta_f(be);
+                const float Z = tb - ta, iZ = 1.0f / Z;
+                const float pa = expf(-0.5f * al * al) * INV_SQRT_2PI, pb = expf(-0.5f * be * be) * INV_SQRT_2PI;
+                const float q = (x - mu) / s;
+                const float lp = -0.91893853320467274178f - logf(s) - 0.5f * (q * q) - logf(Z);
+                const float Nn = al * pa - be * pb;
+                const float ent = logf(4.13273135412249293846f * s * Z) + 0.5f * Nn / Z;  // sqrt(2 pi e)
+                const float ratio = expf(lp - lpo);
+                const float s1 = ratio * Adv;
+                const float s2 = fminf(fmaxf(ratio, 1.f - eps), 1.f + eps) * Adv;
+                lsum = -(fminf(s1, s2) + ef * ent) * inv_count;
+                // torch.min(s1, s2): the gradient goes to the smaller one, half each on a tie; clamp passes it inside [lo, hi]
+                const float w1 = s1 < s2 ? 1.f : (s1 == s2 ? 0.5f : 0.f);
+                const float w2 = s2 < s1 ? 1.f : (s1 == s2 ? 0.5f : 0.f);
+                const float inside = (ratio >= 1.f - eps && ratio <= 1.f + eps) ? 1.f : 0.f;
+                const float dlp = -inv_count * Adv * (w1 + w2 * inside) * ratio;
+                const float dent = -inv_count * ef;
+                const float lp_mu = q * is + iZ * is * (pb * cb - pa * ca);
+                const float lp_s = (q * q - 1.f) * is + iZ * is * (pb * be * cb - pa * al * ca);
+                const float e_al = -pa * iZ + 0.5f * (pa * (1.f - al * al) * iZ + Nn * pa * iZ * iZ);
+                const float e_be = pb * iZ + 0.5f * (-pb * (1.f - be * be) * iZ - Nn * pb * iZ * iZ);
+                const float ent_mu = -(e_al * ca + e_be * cb) * is;
+                const float ent_s = is - (e_al * ca * al + e_be * cb * be) * is;
+                g_mu = (dlp * lp_mu + dent * ent_mu) * (1.f - mu * mu);            // tanh'
+                g_sg = (dlp * lp_s + dent * ent_s) * cs * (-expm1f(-sg));          // softplus' = sigmoid(pre) = 1 - e^-sigma
+            }
+            dh[o] = g_mu;
+            dh[A + o] = g_sg;
+        } else if (o >= 2 * A) {
+            dh[o] = 0.f;
+        }
+    }
+    const double tot = block_sum_double((double) lsum, sh);
+    if (threadIdx.x == 0 && tot != 0.0) atomicAdd(d.loss, tot);
+}
+
+// critic_loss_factor * mean((value - returns)^2) over the selected rows (ppo_gae.cpp:176-179)
+__global__ __launch_bounds__(256) void k_ppo_loss_critic(PpoDev d, int n, const float *__restrict__ returns,
+                                                         const uint8_t *__restrict__ mask, float inv_rows, float cf) {
+    __shared__ double sh[4];
+    const size_t row = (size_t) blockIdx.x * 256 + threadIdx.x;
+    float lsum = 0.f;
+    if (row < (size_t) n) {
+        float dv = 0.f;
+        if (mask[row]) {
+            const float diff = d.critic.head[row] - returns[row];
+            lsum = cf * diff * diff * inv_rows;
+            dv = cf * 2.f * diff * inv_rows;
+        }
+        d.critic.dh[row * 32] = dv;
+    }
+    const double tot = block_sum_double((double) lsum, sh);
+    if (threadIdx.x == 0 && tot != 0.0) atomicAdd(d.loss + 1, tot);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// backward through heads, LayerNorm, Mish and the second Linear for one 32-row tile
+// ---------------------------------------------------------------------------------------------------------
+// thread (row, part): gradient w.r.t. the layer's pre-activation z from the gradient w.r.t. its LayerNorm output.
+//   da[i]: d loss / d a (LayerNorm output) of the thread's run; Tz: the z tile.  Leaves  Tz <- da * xhat  (the terms of
+//   dgamma) and returns d loss / d z in dz[].
+template <int RUN, int PARTS>
+__device__ __forceinline__ void ln_mish_backward(float (&da)[RUN], float *Tz, int row, int part, float mean, float rstd,
+                                                 const float *__restrict__ gamma, float (&dz)[RUN]) {
+    float xh[RUN], mp[RUN];
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < RUN; i++) {
+        const int q = part * RUN + i;
+        const int c = 2 * (q & 127) + (q >> 7);
+        const float z = Tz[row * ALD2 + q];
+        const float nn = __expf(fminf(z, 20.f));
+        const float mm = nn * (nn + 2.f);
+        const float tt = __fdividef(mm, mm + 2.f);  // tanh(softplus(z))
+        mp[i] = tt + z * (1.f - tt * tt) * __fdividef(nn, 1.f + nn);  // Mish'(z) = tanh(sp) + z sigmoid(z) (1 - tanh(sp)^2)
+        xh[i] = (z * tt - mean) * rstd;
+        const float gy = da[i] * gamma[c];
+        c1 += gy;
+        c2 += gy * xh[i];
+        dz[i] = gy;
+    }
+#pragma unroll
+    for (int m = 1; m < PARTS; m <<= 1) { c1 += __shfl_xor(c1, m); c2 += __shfl_xor(c2, m); }
+    c1 *= (1.f / 256.f);
+    c2 *= (1.f / 256.f);
+#pragma unroll
+    for (int i = 0; i < RUN; i++) {
+        const int q = part * RUN + i;
+        Tz[row * ALD2 + q] = da[i] * xh[i];
+        dz[i] = rstd * (dz[i] - c1 - xh[i] * c2) * mp[i];
+    }
+}
+
+template <int RT>
+__global__ __launch_bounds__(PT) void k_ppo_backward(PolicyDev p, PpoDev d, int n) {
+    constexpr int TM = 32 * RT, PARTS = PT / TM, RUN = 256 / PARTS;
+    constexpr int TD = TM * ALD2 > 32 * 256 + TM * 32 ? TM * ALD2 : 32 * 256 + TM * 32;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *Tz = sm;             // z tile, then scratch for the column sums
+    float *Td = sm + TM * ALD2; // gradient tile (A operand of the dgrad GEMM); first life: head weights + dh tile
+    float *wl = Td, *dhs = Td + 32 * 256;
+    (void) TD;
+    const int net = blockIdx.y;
+    const int row0 = blockIdx.x * TM;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int t = threadIdx.x, row = t / PARTS, part = t % PARTS;
+    const int gr = row0 + row;
+    const NetDev &N = net == 0 ? p.actor : p.critic;
+    const PpoNet &B = net == 0 ? d.actor : d.critic;
+    const int nout = net == 1 ? 1 : 2 * p.A;
+    float colacc[PPO_COLSLOTS];
+#pragma unroll
+    for (int k = 0; k < PPO_COLSLOTS; k++) colacc[k] = 0.f;
+
+    for (int e = threadIdx.x; e < nout * 256; e += PT) {
+        const int c = e & 255;
+        wl[(e & ~255) + (c & 1) * 128 + (c >> 1)] = N.wh[e];
+    }
+    for (int e = threadIdx.x; e < TM * 32; e += PT) {
+        const int r = e >> 5, o = e & 31;
+        dhs[e] = (row0 + r < n && o < nout) ? B.dh[(size_t) (row0 + r) * 32 + o] : 0.f;
+    }
+    tile_load<TM>(Tz, B.z2, row0, n);
+    __syncthreads();
+    if (t < 32) {  // head bias gradient: column sums of the dh tile
+        float s = 0.f;
+        for (int r = 0; r < TM; r++) s += dhs[r * 32 + t];
+        colacc[6] = s;
+    }
+    float da[RUN], dz[RUN];
+    {   // d a2 = dh * W_heads
+#pragma unroll
+        for (int i = 0; i < RUN; i++) da[i] = 0.f;
+        for (int o = 0; o < nout; o++) {
+            const float g = dhs[row * 32 + o];
+            const f32x4 *wr = reinterpret_cast<const f32x4 *>(wl + o * 256 + part * RUN);
+#pragma unroll
+            for (int i = 0; i < RUN / 4; i++) {
+                const f32x4 w = wr[i];
+#pragma unroll
+                for (int u = 0; u < 4; u++) da[4 * i + u] += g * w[u];
+            }
+        }
+    }
+    const float mean2 = gr < n ? B.st[(size_t) gr * 4 + 2] : 0.f, rstd2 = gr < n ? B.st[(size_t) gr * 4 + 3] : 0.f;
+    __syncthreads();  // everyone is done with wl / dhs: Td may be overwritten
+    ln_mish_backward<RUN, PARTS>(da, Tz, row, part, mean2, rstd2, N.g2, dz);
+#pragma unroll
+    for (int i = 0; i < RUN; i++) Td[row * ALD2 + part * RUN + i] = da[i];
+    __syncthreads();
+    colacc[0] = tile_colsum<TM>(Tz);  // dgamma2 = sum da * xhat
+    colacc[1] = tile_colsum<TM>(Td);  // dbeta2 = sum da
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < RUN; i++) Td[row * ALD2 + part * RUN + i] = dz[i];
+    tile_load<TM>(Tz, B.z1, row0, n);  // Tz is free again: the layer-1 pre-activations
+    __syncthreads();
+    colacc[2] = tile_colsum<TM>(Td);  // dbias2 = sum dz2
+    tile_store<TM>(Td, B.dz2, row0, n);
+    // d a1 = dz2 * W2  (B operand: the dgrad packing of W2)
+    f32x16 acc[RT][2];
+    dense_layer<256, RT>(Td, ALD2, B.w2d, wave, lane, acc);
+    __syncthreads();
+    acc_to_tile<RT>(acc, nullptr, Td, wave, lane);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < RUN; i++) da[i] = Td[row * ALD2 + part * RUN + i];
+    const float mean1 = gr < n ? B.st[(size_t) gr * 4] : 0.f, rstd1 = gr < n ? B.st[(size_t) gr * 4 + 1] : 0.f;
+    ln_mish_backward<RUN, PARTS>(da, Tz, row, part, mean1, rstd1, N.g1, dz);
+    __syncthreads();
+    colacc[3] = tile_colsum<TM>(Tz);
+    colacc[4] = tile_colsum<TM>(Td);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < RUN; i++) Td[row * ALD2 + part * RUN + i] = dz[i];
+    __syncthreads();
+    colacc[5] = tile_colsum<TM>(Td);
+    tile_store<TM>(Td, B.dz1, row0, n);
+    float *cp = B.colpart + (size_t) blockIdx.x * PPO_COLSLOTS * 256;
+#pragma unroll
+    for (int k = 0; k < PPO_COLSLOTS; k++) cp[k * 256 + t] = colacc[k];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// weight gradients: C[i][j] = sum_m P[m][i] Q[m][j], split over row chunks (blockIdx.y), 128 x 128 tile per workgroup
+// ---------------------------------------------------------------------------------------------------------
+template <bool ALIGNED>
+__device__ __forceinline__ void wg_fetch(f32x4 (&r)[4], const float *__restrict__ X, int ld, int ncols, int c0, int m0, int m_end) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int e = u * PT + (int) threadIdx.x, rr = e >> 5, c4 = (e & 31) * 4;
+        const int m = m0 + rr, c = c0 + c4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (m < m_end) {
+            const float *src = X + (size_t) m * ld + c;
+            if (ALIGNED) {
+                if (c < ncols) v = *reinterpret_cast<const f32x4 *>(src);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) if (c + k < ncols) v[k] = src[k];
+            }
+        }
+        r[u] = v;
+    }
+}
+__device__ __forceinline__ void wg_stash(const f32x4 (&r)[4], float *S) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int e = u * PT + (int) threadIdx.x;
+        reinterpret_cast<f32x4 *>(S)[e] = r[u];  // [32 rows][128 cols], row major
+    }
+}
+template <bool PA, bool QA>
+__global__ __launch_bounds__(PT) void k_ppo_wgrad(const float *__restrict__ P, int ldp, int np, const float *__restrict__ Q, int ldq,
+                                                  int nq, int M, int rows_per_chunk, int i_tiles, float *__restrict__ part, int I, int ldo) {
+    __shared__ __attribute__((aligned(16))) float Ps[2][32 * 128];
+    __shared__ __attribute__((aligned(16))) float Qs[2][32 * 128];
+    const int it = blockIdx.x % i_tiles, jt = blockIdx.x / i_tiles;
+    const int i0 = it * 128, j0 = jt * 128;
+    const int m_begin = blockIdx.y * rows_per_chunk;
+    const int m_end = min(M, m_begin + rows_per_chunk);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+    f32x4 pr[4], qr[4];
+    wg_fetch<PA>(pr, P, ldp, np, i0, m_begin, m_end);
+    wg_fetch<QA>(qr, Q, ldq, nq, j0, m_begin, m_end);
+    wg_stash(pr, Ps[0]);
+    wg_stash(qr, Qs[0]);
+    __syncthreads();
+    int buf = 0;
+    for (int m0 = m_begin; m0 < m_end; m0 += 32) {
+        const bool more = m0 + 32 < m_end;
+        if (more) {
+            wg_fetch<PA>(pr, P, ldp, np, i0, m0 + 32, m_end);
+            wg_fetch<QA>(qr, Q, ldq, nq, j0, m0 + 32, m_end);
+        }
+        const float *ps = Ps[buf] + wi * 64 + li, *qs = Qs[buf] + wj * 64 + li;
+#pragma unroll
+        for (int s = 0; s < 16; s++) {
+            const int k = 2 * s + lh;
+            const float a0 = ps[k * 128], a1 = ps[k * 128 + 32];
+            const float b0 = qs[k * 128], b1 = qs[k * 128 + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (more) {
+            wg_stash(pr, Ps[buf ^ 1]);
+            wg_stash(qr, Qs[buf ^ 1]);
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+    float *out = part + (size_t) blockIdx.y * I * ldo;
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+            const int j = j0 + wj * 64 + b * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int i = i0 + wi * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (i < I && j < ldo) out[(size_t) i * ldo + j] = acc[a][b][r];
+            }
+        }
+}
+
+// sum of the split-K partials -> the flat gradient (rows >= split_row land `extra` floats further: the actor's sigma head)
+__global__ __launch_bounds__(256) void k_ppo_wreduce(const float *__restrict__ part, int sk, int I, int ldo, int J, float *__restrict__ dst,
+                                                     int dst_ld, int split_row, int extra) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= I * J) return;
+    const int i = e / J, j = e - i * J;
+    float s = 0.f;
+    for (int k = 0; k < sk; k++) s += part[((size_t) k * I + i) * ldo + j];
+    dst[(size_t) i * dst_ld + j + (i >= split_row ? extra : 0)] = s;
+}
+
+// column-sum partials: [tiles][W] -> [groups][W] (group g sums tiles g, g + groups, ...)
+__global__ __launch_bounds__(256) void k_ppo_colreduce(const float *__restrict__ src, int tiles, int W, float *__restrict__ dst) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= W) return;
+    float s = 0.f;
+    for (int k = blockIdx.y; k < tiles; k += gridDim.y) s += src[(size_t) k * W + e];
+    dst[(size_t) blockIdx.y * W + e] = s;
+}
+// [groups][7][256] -> the flat gradient slots
+struct ColSlots { int off[PPO_COLSLOTS]; int A; int actor; int sg_extra; };
+__global__ __launch_bounds__(256) void k_ppo_colfinish(const float *__restrict__ src, int groups, ColSlots cs, float *__restrict__ grad) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= PPO_COLSLOTS * 256) return;
+    const int slot = e >> 8, c = e & 255;
+    float s = 0.f;
+    for (int k = 0; k < groups; k++) s += src[(size_t) k * PPO_COLSLOTS * 256 + e];
+    if (slot < 6) { grad[cs.off[slot] + c] = s; return; }
+    if (cs.actor) {
+        if (c < cs.A) grad[cs.off[6] + c] = s;                                  // mu.0.bias
+        else if (c < 2 * cs.A) grad[cs.off[6] + cs.sg_extra + (c - cs.A)] = s;  // sigma.0.bias
+    } else if (c == 0) {
+        grad[cs.off[6]] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// clip_grad_norm_ + Adam (torch::optim::Adam defaults: betas 0.9 / 0.999, eps 1e-8, no weight decay)
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_ppo_sqnorm(PpoDev d) {
+    __shared__ double sh[16];
+    const PpoNet &B = blockIdx.x == 0 ? d.actor : d.critic;
+    double s = 0.0;
+    for (size_t i = threadIdx.x; i < B.n_params; i += 1024) { const double g = B.grad[i]; s += g * g; }
+    const double tot = block_sum_double(s, sh);
+    if (threadIdx.x == 0) B.norm[0] = (float) sqrt(tot);
+}
+__global__ __launch_bounds__(256) void k_ppo_adam(PpoDev d, float max_norm, float lr, float bc1_a, float bc2s_a, float bc1_c, float bc2s_c) {
+    const PpoNet &B = blockIdx.y == 0 ? d.actor : d.critic;
+    const size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
+    if (i >= B.n_params) return;
+    const float bc1 = blockIdx.y == 0 ? bc1_a : bc1_c, bc2s = blockIdx.y == 0 ? bc2s_a : bc2s_c;
+    const float coef = fminf(max_norm / (B.norm[0] + 1e-6f), 1.0f);
+    const float g = B.grad[i] * coef;
+    const float m = B.m[i] + (g - B.m[i]) * 0.1f;           // exp_avg.lerp_(grad, 1 - beta1)
+    const float v = B.v[i] * 0.999f + (g * g) * 0.001f;    // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+    B.m[i] = m;
+    B.v[i] = v;
+    const float denom = sqrtf(v) / bc2s + 1e-8f;
+    B.theta[i] -= (lr / bc1) * (m / denom);
+}
+
+// Linear(256,256) weight -> the B operand of the dgrad GEMM: B[k = j][col = i] = W2[j][i], k-split as in mlp_tile.h
+__global__ __launch_bounds__(256) void k_ppo_pack_w2d(const float *__restrict__ w2, float *__restrict__ w2d) {
+    const int e = blockIdx.x * 256 + threadIdx.x;  // e = j * 256 + i
+    const int k = e >> 8, col = e & 255;
+    const int st = k >> 1, h = k & 1, s4 = st >> 2, tt = st & 3;
+    w2d[(((size_t) s4 * 256 + col) * 2 + h) * 4 + tt] = w2[e];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// GAE (ppo_gae.cpp:127-150), time-major [T][N] rollouts
+// ---------------------------------------------------------------------------------------------------------
+#pragma clang fp contract(off)
+__global__ __launch_bounds__(1024) void k_ppo_gae_scan(int T, int N, const float *__restrict__ rewards, const uint8_t *__restrict__ done,
+                                                       const float *__restrict__ cv, const float *__restrict__ nv,
+                                                       const uint8_t *__restrict__ mask, float gamma, float gl, float *__restrict__ adv,
+                                                       double *__restrict__ stats) {
+    __shared__ double sh[16];
+    double cnt = 0.0, sum = 0.0;
+    for (int n = threadIdx.x; n < N; n += 1024) {
+        float g = 0.f;
+        for (int t = T - 1; t >= 0; t--) {
+            const size_t i = (size_t) t * N + n;
+            const float m = mask[i] ? 1.f : 0.f;
+            const float nd = (mask[i] && !done[i]) ? 1.f : 0.f;  // 1 - done, with done forced to 1 outside the mask
+            const float delta = rewards[i] + (nd * gamma) * nv[i] - cv[i];
+            g = delta * m + (gl * nd) * g;
+            g = g * m;
+            adv[i] = g;
+            if (mask[i]) { cnt += 1.0; sum += (double) g; }
+        }
+    }
+    const double n_all = block_sum_double(cnt, sh);
+    const double s_all = block_sum_double(sum, sh);
+    const double mean = n_all > 0.0 ? s_all / n_all : 0.0;
+    double m2 = 0.0;
+    for (int n = threadIdx.x; n < N; n += 1024)
+        for (int t = 0; t < T; t++) {
+            const size_t i = (size_t) t * N + n;
+            if (mask[i]) { const double dd = (double) adv[i] - mean; m2 += dd * dd; }
+        }
+    const double m2_all = block_sum_double(m2, sh);
+    if (threadIdx.x == 0) { stats[0] = n_all; stats[1] = mean; stats[2] = m2_all; }
+}
+__global__ __launch_bounds__(256) void k_ppo_gae_finish(size_t total, const double *__restrict__ stats, const float *__restrict__ cv,
+                                                        float *__restrict__ adv, float *__restrict__ returns) {
+    const size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const float mean = (float) stats[1];
+    const float sd = (float) sqrt(stats[2] / fmax(stats[0] - 1.0, 1.0));
+    const float a = (adv[i] - mean) / (sd + 1e-8f);
+    adv[i] = a;
+    returns[i] = a + cv[i];  // returns = NORMALISED advantages + V (ppo_gae.cpp:150)
+}
+#pragma clang fp contract(fast)
+
+// ---------------------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------------------
+static size_t fwd_lds_bytes() {
+    constexpr int TM = 32 * PRT;
+    const size_t a = (size_t) TM * ALD1, b = (size_t) TM * ALD2 + 32 * 256 + TM * 32;
+    return (a > b ? a : b) * sizeof(float);
+}
+static size_t bwd_lds_bytes() {
+    constexpr int TM = 32 * PRT;
+    const size_t td = (size_t) TM * ALD2 > (size_t) 32 * 256 + TM * 32 ? (size_t) TM * ALD2 : (size_t) 32 * 256 + TM * 32;
+    return ((size_t) TM * ALD2 + td) * sizeof(float);
+}
+size_t ppo_wpart_floats() { return (size_t) PPO_SK * 256 * 384; }
+
+hipError_t launch_ppo_pack_w2d(const PpoNet &n, int S, hipStream_t s) {
+    const float *w2 = n.theta + (size_t) 256 * S + 3 * 256;
+    hipLaunchKernelGGL(k_ppo_pack_w2d, dim3(256), dim3(256), 0, s, w2, n.w2d);
+    return hipGetLastError();
+}
+
+hipError_t launch_ppo_forward(const PolicyDev &p, const PpoDev &d, size_t rows, const float *states, hipStream_t s) {
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ppo_forward<PRT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int) fwd_lds_bytes());
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ppo_backward<PRT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int) bwd_lds_bytes());
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    constexpr int TM = 32 * PRT;
+    dim3 grid((unsigned) ((rows + TM - 1) / TM), 2);
+    hipLaunchKernelGGL(k_ppo_forward<PRT>, grid, dim3(PT), fwd_lds_bytes(), s, p, d, (int) rows, states);
+    return hipGetLastError();
+}
+
+hipError_t launch_ppo_loss(const PpoDev &d, size_t rows, const float *actions, const float *logp_old, const float *adv,
+                           const float *returns, const uint8_t *mask, double inv_rows, float epsilon, float entropy_factor,
+                           float critic_loss_factor, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(d.loss, 0, 2 * sizeof(double), s);
+    if (e != hipSuccess) return e;
+    const float inv_count = (float) (inv_rows / (double) d.A);
+    hipLaunchKernelGGL(k_ppo_loss_actor, dim3((unsigned) ((rows * 32 + 255) / 256)), dim3(256), 0, s, d, (int) rows, actions, logp_old,
+                       adv, mask, inv_count, epsilon, entropy_factor);
+    hipLaunchKernelGGL(k_ppo_loss_critic, dim3((unsigned) ((rows + 255) / 256)), dim3(256), 0, s, d, (int) rows, returns, mask,
+                       (float) inv_rows, critic_loss_factor);
+    return hipGetLastError();
+}
+
+hipError_t launch_ppo_backward(const PolicyDev &p, const PpoDev &d, size_t rows, hipStream_t s) {
+    constexpr int TM = 32 * PRT;
+    dim3 grid((unsigned) ((rows + TM - 1) / TM), 2);
+    hipLaunchKernelGGL(k_ppo_backward<PRT>, grid, dim3(PT), bwd_lds_bytes(), s, p, d, (int) rows);
+    return hipGetLastError();
+}
+
+static void wgrad_one(const float *P, int ldp, int np, bool pa, const float *Q, int ldq, int nq, bool qa, int M, float *part, int I, int J,
+                      float *dst, int dst_ld, int split_row, int extra, hipStream_t s) {
+    const int ldo = (J + 127) / 128 * 128;
+    int chunks = (M + 31) / 32;
+    if (chunks > PPO_SK) chunks = PPO_SK;
+    int rpc = ((M + chunks - 1) / chunks + 31) / 32 * 32;
+    chunks = (M + rpc - 1) / rpc;
+    const int i_tiles = (I + 127) / 128, j_tiles = ldo / 128;
+    dim3 grid(i_tiles * j_tiles, chunks);
+    if (pa && qa) hipLaunchKernelGGL((k_ppo_wgrad<true, true>), grid, dim3(PT), 0, s, P, ldp, np, Q, ldq, nq, M, rpc, i_tiles, part, I, ldo);
+    else if (pa) hipLaunchKernelGGL((k_ppo_wgrad<true, false>), grid, dim3(PT), 0, s, P, ldp, np, Q, ldq, nq, M, rpc, i_tiles, part, I, ldo);
+    else hipLaunchKernelGGL((k_ppo_wgrad<false, false>), grid, dim3(PT), 0, s, P, ldp, np, Q, ldq, nq, M, rpc, i_tiles, part, I, ldo);
+    hipLaunchKernelGGL(k_ppo_wreduce, dim3((I * J + 255) / 256), dim3(256), 0, s, part, chunks, I, ldo, J, dst, dst_ld, split_row, extra);
+}
+
+hipError_t launch_ppo_wgrads(const PpoDev &d, size_t rows, const float *states, hipStream_t s) {
+    constexpr int TM = 32 * PRT;
+    const int S = d.S, A = d.A, M = (int) rows;
+    const int tiles = (int) ((rows + TM - 1) / TM);
+    const bool sa = (S % 4 == 0) && ((reinterpret_cast<uintptr_t>(states) & 15) == 0);
+    for (int net = 0; net < 2; net++) {
+        const PpoNet &B = net == 0 ? d.actor : d.critic;
+        const size_t o_w1 = 0, o_b1 = (size_t) 256 * S, o_g1 = o_b1 + 256, o_be1 = o_g1 + 256, o_w2 = o_be1 + 256;
+        const size_t o_b2 = o_w2 + 65536, o_g2 = o_b2 + 256, o_be2 = o_g2 + 256, o_h = o_be2 + 256;
+        // head.0.weight [256][S] = dz1^T states; head.3.weight [256][256] = dz2^T a1; heads [nout][256] = dh^T a2
+        wgrad_one(B.dz1, 256, 256, true, states, S, S, sa, M, B.wpart, 256, S, B.grad + o_w1, S, 1 << 30, 0, s);
+        wgrad_one(B.dz2, 256, 256, true, B.a1, 256, 256, true, M, B.wpart, 256, 256, B.grad + o_w2, 256, 1 << 30, 0, s);
+        ColSlots cs;
+        cs.off[0] = (int) o_g2; cs.off[1] = (int) o_be2; cs.off[2] = (int) o_b2;
+        cs.off[3] = (int) o_g1; cs.off[4] = (int) o_be1; cs.off[5] = (int) o_b1;
+        cs.A = A; cs.actor = net == 0;
+        if (net == 0) {
+            // mu.0.weight [A][256], mu.0.bias [A], sigma.0.weight [A][256], sigma.0.bias [A]
+            wgrad_one(B.dh, 32, 32, true, B.a2, 256, 256, true, M, B.wpart, 2 * A, 256, B.grad + o_h, 256, A, A, s);
+            cs.off[6] = (int) (o_h + (size_t) A * 256);
+            cs.sg_extra = A * 256 + A;
+        } else {
+            wgrad_one(B.dh, 32, 32, true, B.a2, 256, 256, true, M, B.wpart, 1, 256, B.grad + o_h, 256, 1 << 30, 0, s);
+            cs.off[6] = (int) (o_h + 256);
+            cs.sg_extra = 0;
+        }
+        const int W = PPO_COLSLOTS * 256;
+        const int groups = tiles < 64 ? tiles : 64;
+        hipLaunchKernelGGL(k_ppo_colreduce, dim3((W + 255) / 256, groups), dim3(256), 0, s, B.colpart, tiles, W, B.colpart2);
+        hipLaunchKernelGGL(k_ppo_colfinish, dim3((W + 255) / 256), dim3(256), 0, s, B.colpart2, groups, cs, B.grad);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_ppo_apply(const PolicyDev &p, PpoDev &d, float lr, float clip_grad_norm, hipStream_t s) {
+    d.actor.step++;
+    d.critic.step++;
+    auto bc1 = [](int t) { return (float) (1.0 - pow(0.9, (double) t)); };
+    auto bc2s = [](int t) { return (float) sqrt(1.0 - pow(0.999, (double) t)); };
+    hipLaunchKernelGGL(k_ppo_sqnorm, dim3(2), dim3(1024), 0, s, d);
+    const size_t nmax = d.actor.n_params > d.critic.n_params ? d.actor.n_params : d.critic.n_params;
+    hipLaunchKernelGGL(k_ppo_adam, dim3((unsigned) ((nmax + 255) / 256), 2), dim3(256), 0, s, d, clip_grad_norm, lr, bc1(d.actor.step),
+                       bc2s(d.actor.step), bc1(d.critic.step), bc2s(d.critic.step));
+    hipError_t e = launch_policy_pack(p.actor, p.S, p.A, true, d.actor.theta, s);
+    if (e == hipSuccess) e = launch_policy_pack(p.critic, p.S, p.A, false, d.critic.theta, s);
+    if (e == hipSuccess) e = launch_ppo_pack_w2d(d.actor, p.S, s);
+    if (e == hipSuccess) e = launch_ppo_pack_w2d(d.critic, p.S, s);
+    return e;
+}
+
+hipError_t launch_ppo_gae_scan(const PpoDev &d, int T, int N, const float *rewards, const uint8_t *done, const float *curr_values,
+                               const float *next_values, const uint8_t *mask, float gamma, float lam, float *adv, hipStream_t s) {
+    const float gl = (float) ((double) gamma * (double) lam);
+    hipLaunchKernelGGL(k_ppo_gae_scan, dim3(1), dim3(1024), 0, s, T, N, rewards, done, curr_values, next_values, mask, gamma, gl, adv, d.gae);
+    return hipGetLastError();
+}
+hipError_t launch_ppo_gae_finish(int T, int N, const double *stats, const float *curr_values, const uint8_t *mask, float *adv,
+                                 float *returns, hipStream_t s) {
+    (void) mask;
+    const size_t total = (size_t) T * N;
+    hipLaunchKernelGGL(k_ppo_gae_finish, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, s, total, stats, curr_values, adv, returns);
+    return hipGetLastError();
+}
+
+}  // namespace evm

@@ -196,6 +196,55 @@ int evm_replay_sample(EvmReplay *rb, int batch, uint64_t seed, float *d_states, 
 int evm_replay_timing_begin(EvmReplay *rb);
 int evm_replay_timing_end(EvmReplay *rb, void *stream, float *ms_push, int *n_push, float *ms_sample, int *n_sample);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * PPO / GAE update: PpoGaeAgent::train (evo_motion_networks/src/agents/ppo_gae.cpp:117-190) on
+ * the device — GAE scan and normalisation (:127-150), clipped surrogate + entropy bonus and the critic's squared
+ * error (:155-179), the backward pass of ActorModule / CriticModule (networks/actor.cpp:9-48, critic.cpp:8-35),
+ * clip_grad_norm_ and one Adam step per network (:170-186), all fp32.  The trainer owns the master parameters,
+ * gradients and Adam moments as flat vectors in named_parameters() order and writes every new set of weights
+ * straight into `policy` (the operand layout of evm_policy_forward), so the next rollout needs no upload.
+ * Rollouts are time-major: [horizon][n_envs] (rows = horizon * n_envs).
+ * ------------------------------------------------------------------------------------------------------- */
+typedef struct EvmPpo EvmPpo;
+/* `policy` is borrowed and must outlive the trainer; max_rows bounds `rows` of evm_ppo_grads (activations are kept
+ * for the backward pass: about 6.3 KiB of HBM per row and network). */
+int evm_ppo_create(EvmPolicy *policy, size_t max_rows, EvmPpo **out);
+void evm_ppo_destroy(EvmPpo *q);
+/* flat DEVICE parameter vectors (evm_policy_param_counts floats each); reset_optimizer != 0 zeroes the Adam moments and
+ * step counts (a freshly constructed torch::optim::Adam, ppo_gae.cpp:22-25) */
+int evm_ppo_set_params(EvmPpo *q, const float *d_actor, const float *d_critic, int reset_optimizer, void *stream);
+/* what: 0 parameters, 1 gradients, 2 Adam exp_avg, 3 Adam exp_avg_sq; net: 0 actor, 1 critic.  to_trainer == 0 copies
+ * the trainer's vector to d_buf, 1 copies d_buf into the trainer (gradients after an all-reduce, moments of a loaded
+ * checkpoint; parameters go through evm_ppo_set_params). */
+int evm_ppo_copy(EvmPpo *q, int what, int net, int to_trainer, float *d_buf, void *stream);
+/* Adam step count of a network: set when set_step >= 0, returned in *step */
+int evm_ppo_adam_step(EvmPpo *q, int net, int set_step, int *step);
+/* Raw advantages of ppo_gae.cpp:134-146 into d_adv [horizon][n_envs]; d_mask = 1 for a trained transition (done is
+ * taken as 1 outside the mask, exactly like the reference's padding).  d_stats (optional, DEVICE double[3]) receives
+ * (count, mean, sum of squared deviations) of the selected advantages, for merging over ranks. */
+int evm_ppo_gae(EvmPpo *q, int horizon, int n_envs, const float *d_rewards, const uint8_t *d_done, const float *d_curr_values,
+                const float *d_next_values, const uint8_t *d_mask, float gamma, float lam, float *d_adv, double *d_stats,
+                void *stream);
+/* adv = (adv - mean) / (std + 1e-8) with the unbiased std, returns = adv + V (ppo_gae.cpp:148-150).  d_stats == NULL
+ * uses the statistics of this trainer's last evm_ppo_gae. */
+int evm_ppo_gae_normalize(EvmPpo *q, int horizon, int n_envs, const double *d_stats, const float *d_curr_values, float *d_adv,
+                          float *d_returns, void *stream);
+/* Forward, losses and backward of both networks over `rows` transitions: gradients land in the trainer (evm_ppo_copy).
+ * n_selected_global = number of rows with d_mask == 1 over ALL ranks (the losses are means over them, so summing the
+ * ranks' gradients gives the global gradient).  d_states [rows, S], d_actions / d_logp_old [rows, A], d_adv /
+ * d_returns [rows], d_mask [rows]. */
+int evm_ppo_grads(EvmPpo *q, size_t rows, const float *d_states, const float *d_actions, const float *d_logp_old, const float *d_adv,
+                  const float *d_returns, const uint8_t *d_mask, double n_selected_global, float epsilon, float entropy_factor,
+                  float critic_loss_factor, void *stream);
+/* clip_grad_norm_(clip_grad_norm) and Adam(lr, betas 0.9 / 0.999, eps 1e-8) for both networks, then the new weights into
+ * `policy` */
+int evm_ppo_apply(EvmPpo *q, float learning_rate, float clip_grad_norm, void *stream);
+/* this rank's share of the actor / critic loss of the last evm_ppo_grads (synchronises the stream) */
+int evm_ppo_losses(EvmPpo *q, double *h_actor_loss, double *h_critic_loss, void *stream);
+/* returns the milliseconds (HIP events, evm_ppo_grads .. evm_ppo_apply) and epochs accumulated since the last call, then
+ * switches the measurement on or off */
+int evm_ppo_timing(EvmPpo *q, int enable, float *ms_total, int *n_epochs);
+
 #ifdef __cplusplus
 }
 #endif

@@ -224,4 +224,5 @@ def test_rollout_and_update_smoke():
         assert torch.isfinite(buf["states"]).all() and set(buf["valid"].unique().tolist()) <= {0.0, 1.0, 2.0}
         al, cl = agent.update()
         assert np.isfinite(al) and np.isfinite(cl)
+    agent.sync_modules()  # the HIP trainer owns the weights; the torch modules are refreshed on demand
     assert not torch.equal(w0, agent.actor.head[0].weight)
