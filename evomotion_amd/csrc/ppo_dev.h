@@ -21,7 +21,7 @@ struct PpoNet {
     float *colpart;               // [tiles][7][256] per-tile column sums (LayerNorm / bias gradients)
     float *colpart2;              // [64][7][256] second reduction level
     float *wpart;                 // split-K partials of the weight gradients
-    float *norm;                  // [1] gradient norm of the net
+    double *normp;                // [PPO_NORM_PARTS] partial sums of squared gradients
     int step;                     // Adam step count
 };
 
@@ -29,14 +29,17 @@ struct PpoDev {
     int S, A;
     size_t max_rows;
     PpoNet actor, critic;
+    float *xpad;    // [max_rows][384] observations, zero padded (staged once per update)
     double *loss;   // [2] actor, critic loss sums of the last evm_ppo_grads call
     double *gae;    // [3] n, mean, M2 of the raw advantages
 };
 
 constexpr int PPO_SK = 64;       // split-K chunks of the weight-gradient GEMMs
+constexpr int PPO_NORM_PARTS = 32;
 constexpr int PPO_COLSLOTS = 7;  // dgamma2, dbeta2, dbias2, dgamma1, dbeta1, dbias1, dbias_heads
 
 hipError_t launch_ppo_pack_w2d(const PpoNet &n, int S, hipStream_t s);
+hipError_t launch_ppo_pad(const PpoDev &d, size_t rows, const float *states, hipStream_t s);
 hipError_t launch_ppo_forward(const PolicyDev &p, const PpoDev &d, size_t rows, const float *states, hipStream_t s);
 hipError_t launch_ppo_loss(const PpoDev &d, size_t rows, const float *actions, const float *logp_old, const float *adv,
                            const float *returns, const uint8_t *mask, double inv_rows, float epsilon, float entropy_factor,

@@ -19,6 +19,7 @@ struct EvmPpo {
     bool timing;
     float ms_acc;
     int n_timed;
+    size_t staged_rows;  // rows of the observation copy made by the last evm_ppo_grads
 };
 
 static int qfail(int code, const std::string &m) { evm::set_last_error(m); return code; }
@@ -34,7 +35,7 @@ int evm_ppo_create(EvmPolicy *policy, size_t max_rows, EvmPpo **out) {
     EvmPpo *q = new EvmPpo();
     q->policy = policy;
     q->have_params = false;
-    q->timing = false; q->ms_acc = 0.f; q->n_timed = 0;
+    q->timing = false; q->ms_acc = 0.f; q->n_timed = 0; q->staged_rows = 0;
     q->ev0 = q->ev1 = nullptr;
     evm::PpoDev &d = q->dev;
     d.S = policy->S; d.A = policy->A; d.max_rows = max_rows;
@@ -64,10 +65,11 @@ int evm_ppo_create(EvmPolicy *policy, size_t max_rows, EvmPpo **out) {
         n.colpart = (float *) alloc(tiles * evm::PPO_COLSLOTS * 256 * 4);
         n.colpart2 = (float *) alloc((size_t) 64 * evm::PPO_COLSLOTS * 256 * 4);
         n.wpart = (float *) alloc(evm::ppo_wpart_floats() * 4);
-        n.norm = (float *) alloc(4);
+        n.normp = (double *) alloc(evm::PPO_NORM_PARTS * sizeof(double));
     };
     make(d.actor, na, (size_t) 2 * d.A);
     make(d.critic, nc, 1);
+    d.xpad = (float *) alloc(max_rows * 384 * 4);
     d.loss = (double *) alloc(2 * sizeof(double));
     d.gae = (double *) alloc(3 * sizeof(double));
     if (ok && (hipEventCreate(&q->ev0) != hipSuccess || hipEventCreate(&q->ev1) != hipSuccess)) ok = false;
@@ -155,7 +157,7 @@ int evm_ppo_gae_normalize(EvmPpo *q, int horizon, int n_envs, const double *d_st
 
 int evm_ppo_grads(EvmPpo *q, size_t rows, const float *d_states, const float *d_actions, const float *d_logp_old, const float *d_adv,
                   const float *d_returns, const uint8_t *d_mask, double n_selected_global, float epsilon, float entropy_factor,
-                  float critic_loss_factor, void *stream) {
+                  float critic_loss_factor, int states_unchanged, void *stream) {
     if (!q || !d_states || !d_actions || !d_logp_old || !d_adv || !d_returns || !d_mask) return qfail(EVM_E_INVALID, "null argument");
     if (!q->have_params) return qfail(EVM_E_INVALID, "evm_ppo_set_params has not been called");
     if (rows < 1 || rows > q->dev.max_rows) return qfail(EVM_E_INVALID, "rows exceeds the trainer's capacity");
@@ -163,7 +165,12 @@ int evm_ppo_grads(EvmPpo *q, size_t rows, const float *d_states, const float *d_
     hipStream_t s = (hipStream_t) stream;
     if (q->timing) (void) hipEventRecord(q->ev0, s);
     const evm::PolicyDev &p = q->policy->dev;
-    hipError_t e = evm::launch_ppo_forward(p, q->dev, rows, d_states, s);
+    hipError_t e = hipSuccess;
+    if (!states_unchanged || rows != q->staged_rows) {
+        e = evm::launch_ppo_pad(q->dev, rows, d_states, s);
+        q->staged_rows = rows;
+    }
+    if (e == hipSuccess) e = evm::launch_ppo_forward(p, q->dev, rows, d_states, s);
     if (e == hipSuccess) e = evm::launch_ppo_loss(q->dev, rows, d_actions, d_logp_old, d_adv, d_returns, d_mask, 1.0 / n_selected_global,
                                                   epsilon, entropy_factor, critic_loss_factor, s);
     if (e == hipSuccess) e = evm::launch_ppo_backward(p, q->dev, rows, s);

@@ -137,7 +137,7 @@ __global__ __launch_bounds__(PT) void k_ppo_forward(PolicyDev p, PpoDev d, int n
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const NetDev &N = net == 0 ? p.actor : p.critic;
     const PpoNet &B = net == 0 ? d.actor : d.critic;
-    stage_rows_ksplit<TM>(xs, states, row0, n, p.S);
+    stage_rows_ksplit<TM>(xs, states, row0, n, K1);  // the padded copy: [n][K1]
     __syncthreads();
     f32x16 acc[RT][2];
     dense_layer<K1, RT>(xs, ALD1, N.w1t, wave, lane, acc);
@@ -203,23 +203,38 @@ __device__ __forceinline__ double block_sum_double(double v, double *sh) {
     return s;
 }
 
-// clipped surrogate + entropy bonus (ppo_gae.cpp:155-166); 32 threads per row, thread o < A owns action dimension o.
+// one float per thread -> one double atomicAdd per workgroup
+__device__ __forceinline__ void block_accumulate(float v, double *dst, float *sh) {
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < nw; i++) s += (double) sh[i];
+        if (s != 0.0) atomicAdd(dst, s);
+    }
+}
+
+// clipped surrogate + entropy bonus (ppo_gae.cpp:155-166); one thread per (row, action dimension).
 // inv_count = 1 / (masked rows of ALL ranks x A): the loss is the mean over the selected elements.
+// dh columns >= 2A are zero from the allocation and never written.
 __global__ __launch_bounds__(256) void k_ppo_loss_actor(PpoDev d, int n, const float *__restrict__ actions,
                                                         const float *__restrict__ logp_old, const float *__restrict__ adv,
                                                         const uint8_t *__restrict__ mask, float inv_count, float eps, float ef) {
-    __shared__ double sh[4];
-    const size_t tg = (size_t) blockIdx.x * 256 + threadIdx.x;
-    const size_t row = tg >> 5;
-    const int o = (int) (tg & 31), A = d.A;
+    __shared__ float sh[4];
+    const int A = d.A;
+    const size_t e = (size_t) blockIdx.x * 256 + threadIdx.x;
     float lsum = 0.f;
-    if (row < (size_t) n) {
+    if (e < (size_t) n * A) {
+        const size_t row = e / A;
+        const int o = (int) (e - row * A);
         float *dh = d.actor.dh + row * 32;
-        if (o < A) {
+        {
             float g_mu = 0.f, g_sg = 0.f;
             if (mask[row]) {
                 const float mu = d.actor.head[row * 2 * A + o], sg = d.actor.head[row * 2 * A + A + o];
-                const float x = actions[row * A + o], lpo = logp_old[row * A + o], Adv = adv[row];
+                const float x = actions[e], lpo = logp_old[e], Adv = adv[row];
                 const float INV_SQRT_2PI = 0.39894228040143267794f;
                 const float s = fminf(fmaxf(sg, 1e-6f), 1e6f);
                 const float cs = (sg >= 1e-6f && sg <= 1e6f) ? 1.f : 0.f;
@@ -255,18 +270,15 @@ __global__ __launch_bounds__(256) void k_ppo_loss_actor(PpoDev d, int n, const f
             }
             dh[o] = g_mu;
             dh[A + o] = g_sg;
-        } else if (o >= 2 * A) {
-            dh[o] = 0.f;
         }
     }
-    const double tot = block_sum_double((double) lsum, sh);
-    if (threadIdx.x == 0 && tot != 0.0) atomicAdd(d.loss, tot);
+    block_accumulate(lsum, d.loss, sh);
 }
 
 // critic_loss_factor * mean((value - returns)^2) over the selected rows (ppo_gae.cpp:176-179)
 __global__ __launch_bounds__(256) void k_ppo_loss_critic(PpoDev d, int n, const float *__restrict__ returns,
                                                          const uint8_t *__restrict__ mask, float inv_rows, float cf) {
-    __shared__ double sh[4];
+    __shared__ float sh[4];
     const size_t row = (size_t) blockIdx.x * 256 + threadIdx.x;
     float lsum = 0.f;
     if (row < (size_t) n) {
@@ -278,19 +290,18 @@ __global__ __launch_bounds__(256) void k_ppo_loss_critic(PpoDev d, int n, const 
         }
         d.critic.dh[row * 32] = dv;
     }
-    const double tot = block_sum_double((double) lsum, sh);
-    if (threadIdx.x == 0 && tot != 0.0) atomicAdd(d.loss + 1, tot);
+    block_accumulate(lsum, d.loss + 1, sh);
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // backward through heads, LayerNorm, Mish and the second Linear for one 32-row tile
 // ---------------------------------------------------------------------------------------------------------
 // thread (row, part): gradient w.r.t. the layer's pre-activation z from the gradient w.r.t. its LayerNorm output.
-//   da[i]: d loss / d a (LayerNorm output) of the thread's run; Tz: the z tile.  Leaves  Tz <- da * xhat  (the terms of
-//   dgamma) and returns d loss / d z in dz[].
+//   g[i]: in d loss / d a (LayerNorm output) of the thread's run, out d loss / d z; Tz: the z tile, left holding
+//   da * xhat (the terms of dgamma).
 template <int RUN, int PARTS>
-__device__ __forceinline__ void ln_mish_backward(float (&da)[RUN], float *Tz, int row, int part, float mean, float rstd,
-                                                 const float *__restrict__ gamma, float (&dz)[RUN]) {
+__device__ __forceinline__ void ln_mish_backward(float (&g)[RUN], float *Tz, int row, int part, float mean, float rstd,
+                                                 const float *__restrict__ gamma) {
     float xh[RUN], mp[RUN];
     float c1 = 0.f, c2 = 0.f;
 #pragma unroll
@@ -303,25 +314,22 @@ __device__ __forceinline__ void ln_mish_backward(float (&da)[RUN], float *Tz, in
         const float tt = __fdividef(mm, mm + 2.f);  // tanh(softplus(z))
         mp[i] = tt + z * (1.f - tt * tt) * __fdividef(nn, 1.f + nn);  // Mish'(z) = tanh(sp) + z sigmoid(z) (1 - tanh(sp)^2)
         xh[i] = (z * tt - mean) * rstd;
-        const float gy = da[i] * gamma[c];
+        Tz[row * ALD2 + q] = g[i] * xh[i];
+        const float gy = g[i] * gamma[c];
         c1 += gy;
         c2 += gy * xh[i];
-        dz[i] = gy;
+        g[i] = gy;
     }
 #pragma unroll
     for (int m = 1; m < PARTS; m <<= 1) { c1 += __shfl_xor(c1, m); c2 += __shfl_xor(c2, m); }
     c1 *= (1.f / 256.f);
     c2 *= (1.f / 256.f);
 #pragma unroll
-    for (int i = 0; i < RUN; i++) {
-        const int q = part * RUN + i;
-        Tz[row * ALD2 + q] = da[i] * xh[i];
-        dz[i] = rstd * (dz[i] - c1 - xh[i] * c2) * mp[i];
-    }
+    for (int i = 0; i < RUN; i++) g[i] = rstd * (g[i] - c1 - xh[i] * c2) * mp[i];
 }
 
 template <int RT>
-__global__ __launch_bounds__(PT) void k_ppo_backward(PolicyDev p, PpoDev d, int n) {
+__global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_ppo_backward(PolicyDev p, PpoDev d, int n) {
     constexpr int TM = 32 * RT, PARTS = PT / TM, RUN = 256 / PARTS;
     constexpr int TD = TM * ALD2 > 32 * 256 + TM * 32 ? TM * ALD2 : 32 * 256 + TM * 32;
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -356,7 +364,7 @@ __global__ __launch_bounds__(PT) void k_ppo_backward(PolicyDev p, PpoDev d, int 
         for (int r = 0; r < TM; r++) s += dhs[r * 32 + t];
         colacc[6] = s;
     }
-    float da[RUN], dz[RUN];
+    float da[RUN];
     {   // d a2 = dh * W_heads
 #pragma unroll
         for (int i = 0; i < RUN; i++) da[i] = 0.f;
@@ -373,15 +381,15 @@ __global__ __launch_bounds__(PT) void k_ppo_backward(PolicyDev p, PpoDev d, int 
     }
     const float mean2 = gr < n ? B.st[(size_t) gr * 4 + 2] : 0.f, rstd2 = gr < n ? B.st[(size_t) gr * 4 + 3] : 0.f;
     __syncthreads();  // everyone is done with wl / dhs: Td may be overwritten
-    ln_mish_backward<RUN, PARTS>(da, Tz, row, part, mean2, rstd2, N.g2, dz);
 #pragma unroll
     for (int i = 0; i < RUN; i++) Td[row * ALD2 + part * RUN + i] = da[i];
+    ln_mish_backward<RUN, PARTS>(da, Tz, row, part, mean2, rstd2, N.g2);  // da <- dz2
     __syncthreads();
     colacc[0] = tile_colsum<TM>(Tz);  // dgamma2 = sum da * xhat
     colacc[1] = tile_colsum<TM>(Td);  // dbeta2 = sum da
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < RUN; i++) Td[row * ALD2 + part * RUN + i] = dz[i];
+    for (int i = 0; i < RUN; i++) Td[row * ALD2 + part * RUN + i] = da[i];
     tile_load<TM>(Tz, B.z1, row0, n);  // Tz is free again: the layer-1 pre-activations
     __syncthreads();
     colacc[2] = tile_colsum<TM>(Td);  // dbias2 = sum dz2
@@ -395,13 +403,13 @@ __global__ __launch_bounds__(PT) void k_ppo_backward(PolicyDev p, PpoDev d, int 
 #pragma unroll
     for (int i = 0; i < RUN; i++) da[i] = Td[row * ALD2 + part * RUN + i];
     const float mean1 = gr < n ? B.st[(size_t) gr * 4] : 0.f, rstd1 = gr < n ? B.st[(size_t) gr * 4 + 1] : 0.f;
-    ln_mish_backward<RUN, PARTS>(da, Tz, row, part, mean1, rstd1, N.g1, dz);
+    ln_mish_backward<RUN, PARTS>(da, Tz, row, part, mean1, rstd1, N.g1);  // da <- dz1
     __syncthreads();
     colacc[3] = tile_colsum<TM>(Tz);
     colacc[4] = tile_colsum<TM>(Td);
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < RUN; i++) Td[row * ALD2 + part * RUN + i] = dz[i];
+    for (int i = 0; i < RUN; i++) Td[row * ALD2 + part * RUN + i] = da[i];
     __syncthreads();
     colacc[5] = tile_colsum<TM>(Td);
     tile_store<TM>(Td, B.dz1, row0, n);
@@ -503,6 +511,70 @@ __global__ __launch_bounds__(PT) void k_ppo_wgrad(const float *__restrict__ P, i
         }
 }
 
+// the heads' weight gradient: C[o][j] = sum_m dh[m][o] a2[m][j], 32 x 256 per workgroup (one 32-row MFMA tile, each wave
+// 64 columns), split over row chunks like k_ppo_wgrad
+__global__ __launch_bounds__(PT) void k_ppo_wgrad_heads(const float *__restrict__ P, const float *__restrict__ Q, int M, int rows_per_chunk,
+                                                        float *__restrict__ part, int I) {
+    __shared__ __attribute__((aligned(16))) float Ps[2][32 * 32];
+    __shared__ __attribute__((aligned(16))) float Qs[2][32 * 256];
+    const int m_begin = blockIdx.y * rows_per_chunk;
+    const int m_end = min(M, m_begin + rows_per_chunk);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int li = lane & 31, lh = lane >> 5;
+    const int t = threadIdx.x;
+    f32x16 acc[2];
+#pragma unroll
+    for (int b = 0; b < 2; b++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[b][r] = 0.f;
+    f32x4 pr, qr[8];
+    auto fetch = [&](int m0) {
+        {   // dh rows: 32 x 32 floats = 256 float4
+            const int rr = t >> 3, c4 = (t & 7) * 4, m = m0 + rr;
+            pr = m < m_end ? *reinterpret_cast<const f32x4 *>(P + (size_t) m * 32 + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {  // a2 rows: 32 x 256 floats = 2048 float4
+            const int e = u * PT + t, rr = e >> 6, c4 = (e & 63) * 4, m = m0 + rr;
+            qr[u] = m < m_end ? *reinterpret_cast<const f32x4 *>(Q + (size_t) m * 256 + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto stash = [&](int buf) {
+        reinterpret_cast<f32x4 *>(Ps[buf])[t] = pr;
+#pragma unroll
+        for (int u = 0; u < 8; u++) reinterpret_cast<f32x4 *>(Qs[buf])[u * PT + t] = qr[u];
+    };
+    fetch(m_begin);
+    stash(0);
+    __syncthreads();
+    int buf = 0;
+    for (int m0 = m_begin; m0 < m_end; m0 += 32) {
+        const bool more = m0 + 32 < m_end;
+        if (more) fetch(m0 + 32);
+        const float *ps = Ps[buf] + li, *qs = Qs[buf] + wave * 64 + li;
+#pragma unroll
+        for (int s = 0; s < 16; s++) {
+            const int k = 2 * s + lh;
+            const float a0 = ps[k * 32];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, qs[k * 256], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, qs[k * 256 + 32], acc[1], 0, 0, 0);
+        }
+        if (more) stash(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    float *out = part + (size_t) blockIdx.y * I * 256;
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+        const int j = wave * 64 + b * 32 + li;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (i < I) out[(size_t) i * 256 + j] = acc[b][r];
+        }
+    }
+}
+
 // sum of the split-K partials -> the flat gradient (rows >= split_row land `extra` floats further: the actor's sigma head)
 __global__ __launch_bounds__(256) void k_ppo_wreduce(const float *__restrict__ part, int sk, int I, int ldo, int J, float *__restrict__ dst,
                                                      int dst_ld, int split_row, int extra) {
@@ -542,20 +614,26 @@ __global__ __launch_bounds__(256) void k_ppo_colfinish(const float *__restrict__
 // ---------------------------------------------------------------------------------------------------------
 // clip_grad_norm_ + Adam (torch::optim::Adam defaults: betas 0.9 / 0.999, eps 1e-8, no weight decay)
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_ppo_sqnorm(PpoDev d) {
-    __shared__ double sh[16];
-    const PpoNet &B = blockIdx.x == 0 ? d.actor : d.critic;
+__global__ __launch_bounds__(256) void k_ppo_sqnorm(PpoDev d) {  // grid (PPO_NORM_PARTS, 2): fixed partition, fixed order
+    __shared__ double sh[4];
+    const PpoNet &B = blockIdx.y == 0 ? d.actor : d.critic;
     double s = 0.0;
-    for (size_t i = threadIdx.x; i < B.n_params; i += 1024) { const double g = B.grad[i]; s += g * g; }
+    for (size_t i = (size_t) blockIdx.x * 256 + threadIdx.x; i < B.n_params; i += (size_t) PPO_NORM_PARTS * 256) {
+        const double g = B.grad[i];
+        s += g * g;
+    }
     const double tot = block_sum_double(s, sh);
-    if (threadIdx.x == 0) B.norm[0] = (float) sqrt(tot);
+    if (threadIdx.x == 0) B.normp[blockIdx.x] = tot;
 }
 __global__ __launch_bounds__(256) void k_ppo_adam(PpoDev d, float max_norm, float lr, float bc1_a, float bc2s_a, float bc1_c, float bc2s_c) {
     const PpoNet &B = blockIdx.y == 0 ? d.actor : d.critic;
     const size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
-    if (i >= B.n_params) return;
     const float bc1 = blockIdx.y == 0 ? bc1_a : bc1_c, bc2s = blockIdx.y == 0 ? bc2s_a : bc2s_c;
-    const float coef = fminf(max_norm / (B.norm[0] + 1e-6f), 1.0f);
+    double sq = 0.0;
+#pragma unroll 8
+    for (int k = 0; k < PPO_NORM_PARTS; k++) sq += B.normp[k];
+    const float coef = fminf(max_norm / ((float) sqrt(sq) + 1e-6f), 1.0f);
+    if (i >= B.n_params) return;
     const float g = B.grad[i] * coef;
     const float m = B.m[i] + (g - B.m[i]) * 0.1f;           // exp_avg.lerp_(grad, 1 - beta1)
     const float v = B.v[i] * 0.999f + (g * g) * 0.001f;    // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
@@ -641,6 +719,19 @@ hipError_t launch_ppo_pack_w2d(const PpoNet &n, int S, hipStream_t s) {
     return hipGetLastError();
 }
 
+// observations -> [rows][K1] with zero padding: 16-byte aligned rows for the forward staging and the weight-gradient GEMM
+__global__ __launch_bounds__(256) void k_ppo_pad(const float *__restrict__ src, int S, size_t rows, float *__restrict__ dst) {
+    const size_t e = (size_t) blockIdx.x * 256 + threadIdx.x;
+    if (e >= rows * K1) return;
+    const size_t r = e / K1;
+    const int c = (int) (e - r * K1);
+    dst[e] = c < S ? src[r * S + c] : 0.f;
+}
+hipError_t launch_ppo_pad(const PpoDev &d, size_t rows, const float *states, hipStream_t s) {
+    hipLaunchKernelGGL(k_ppo_pad, dim3((unsigned) ((rows * K1 + 255) / 256)), dim3(256), 0, s, states, d.S, rows, d.xpad);
+    return hipGetLastError();
+}
+
 hipError_t launch_ppo_forward(const PolicyDev &p, const PpoDev &d, size_t rows, const float *states, hipStream_t s) {
     static bool attr = false;
     if (!attr) {
@@ -654,7 +745,8 @@ hipError_t launch_ppo_forward(const PolicyDev &p, const PpoDev &d, size_t rows, 
     }
     constexpr int TM = 32 * PRT;
     dim3 grid((unsigned) ((rows + TM - 1) / TM), 2);
-    hipLaunchKernelGGL(k_ppo_forward<PRT>, grid, dim3(PT), fwd_lds_bytes(), s, p, d, (int) rows, states);
+    (void) states;
+    hipLaunchKernelGGL(k_ppo_forward<PRT>, grid, dim3(PT), fwd_lds_bytes(), s, p, d, (int) rows, d.xpad);
     return hipGetLastError();
 }
 
@@ -664,7 +756,7 @@ hipError_t launch_ppo_loss(const PpoDev &d, size_t rows, const float *actions, c
     hipError_t e = hipMemsetAsync(d.loss, 0, 2 * sizeof(double), s);
     if (e != hipSuccess) return e;
     const float inv_count = (float) (inv_rows / (double) d.A);
-    hipLaunchKernelGGL(k_ppo_loss_actor, dim3((unsigned) ((rows * 32 + 255) / 256)), dim3(256), 0, s, d, (int) rows, actions, logp_old,
+    hipLaunchKernelGGL(k_ppo_loss_actor, dim3((unsigned) ((rows * d.A + 255) / 256)), dim3(256), 0, s, d, (int) rows, actions, logp_old,
                        adv, mask, inv_count, epsilon, entropy_factor);
     hipLaunchKernelGGL(k_ppo_loss_critic, dim3((unsigned) ((rows + 255) / 256)), dim3(256), 0, s, d, (int) rows, returns, mask,
                        (float) inv_rows, critic_loss_factor);
@@ -693,17 +785,26 @@ static void wgrad_one(const float *P, int ldp, int np, bool pa, const float *Q, 
     hipLaunchKernelGGL(k_ppo_wreduce, dim3((I * J + 255) / 256), dim3(256), 0, s, part, chunks, I, ldo, J, dst, dst_ld, split_row, extra);
 }
 
+static void wgrad_heads(const PpoNet &B, int M, int I, float *dst, int split_row, int extra, hipStream_t s) {
+    int chunks = (M + 31) / 32;
+    if (chunks > 4 * PPO_SK) chunks = 4 * PPO_SK;  // a workgroup's tile is small: more row chunks to fill the chip
+    int rpc = ((M + chunks - 1) / chunks + 31) / 32 * 32;
+    chunks = (M + rpc - 1) / rpc;
+    hipLaunchKernelGGL(k_ppo_wgrad_heads, dim3(1, chunks), dim3(PT), 0, s, B.dh, B.a2, M, rpc, B.wpart, I);
+    hipLaunchKernelGGL(k_ppo_wreduce, dim3((I * 256 + 255) / 256), dim3(256), 0, s, B.wpart, chunks, I, 256, 256, dst, 256, split_row, extra);
+}
+
 hipError_t launch_ppo_wgrads(const PpoDev &d, size_t rows, const float *states, hipStream_t s) {
     constexpr int TM = 32 * PRT;
     const int S = d.S, A = d.A, M = (int) rows;
     const int tiles = (int) ((rows + TM - 1) / TM);
-    const bool sa = (S % 4 == 0) && ((reinterpret_cast<uintptr_t>(states) & 15) == 0);
+    (void) states;
     for (int net = 0; net < 2; net++) {
         const PpoNet &B = net == 0 ? d.actor : d.critic;
         const size_t o_w1 = 0, o_b1 = (size_t) 256 * S, o_g1 = o_b1 + 256, o_be1 = o_g1 + 256, o_w2 = o_be1 + 256;
         const size_t o_b2 = o_w2 + 65536, o_g2 = o_b2 + 256, o_be2 = o_g2 + 256, o_h = o_be2 + 256;
         // head.0.weight [256][S] = dz1^T states; head.3.weight [256][256] = dz2^T a1; heads [nout][256] = dh^T a2
-        wgrad_one(B.dz1, 256, 256, true, states, S, S, sa, M, B.wpart, 256, S, B.grad + o_w1, S, 1 << 30, 0, s);
+        wgrad_one(B.dz1, 256, 256, true, d.xpad, K1, K1, true, M, B.wpart, 256, S, B.grad + o_w1, S, 1 << 30, 0, s);
         wgrad_one(B.dz2, 256, 256, true, B.a1, 256, 256, true, M, B.wpart, 256, 256, B.grad + o_w2, 256, 1 << 30, 0, s);
         ColSlots cs;
         cs.off[0] = (int) o_g2; cs.off[1] = (int) o_be2; cs.off[2] = (int) o_b2;
@@ -711,11 +812,11 @@ hipError_t launch_ppo_wgrads(const PpoDev &d, size_t rows, const float *states, 
         cs.A = A; cs.actor = net == 0;
         if (net == 0) {
             // mu.0.weight [A][256], mu.0.bias [A], sigma.0.weight [A][256], sigma.0.bias [A]
-            wgrad_one(B.dh, 32, 32, true, B.a2, 256, 256, true, M, B.wpart, 2 * A, 256, B.grad + o_h, 256, A, A, s);
+            wgrad_heads(B, M, 2 * A, B.grad + o_h, A, A, s);
             cs.off[6] = (int) (o_h + (size_t) A * 256);
             cs.sg_extra = A * 256 + A;
         } else {
-            wgrad_one(B.dh, 32, 32, true, B.a2, 256, 256, true, M, B.wpart, 1, 256, B.grad + o_h, 256, 1 << 30, 0, s);
+            wgrad_heads(B, M, 1, B.grad + o_h, 1 << 30, 0, s);
             cs.off[6] = (int) (o_h + 256);
             cs.sg_extra = 0;
         }
@@ -732,7 +833,7 @@ hipError_t launch_ppo_apply(const PolicyDev &p, PpoDev &d, float lr, float clip_
     d.critic.step++;
     auto bc1 = [](int t) { return (float) (1.0 - pow(0.9, (double) t)); };
     auto bc2s = [](int t) { return (float) sqrt(1.0 - pow(0.999, (double) t)); };
-    hipLaunchKernelGGL(k_ppo_sqnorm, dim3(2), dim3(1024), 0, s, d);
+    hipLaunchKernelGGL(k_ppo_sqnorm, dim3(PPO_NORM_PARTS, 2), dim3(256), 0, s, d);
     const size_t nmax = d.actor.n_params > d.critic.n_params ? d.actor.n_params : d.critic.n_params;
     hipLaunchKernelGGL(k_ppo_adam, dim3((unsigned) ((nmax + 255) / 256), 2), dim3(256), 0, s, d, clip_grad_norm, lr, bc1(d.actor.step),
                        bc2s(d.actor.step), bc1(d.critic.step), bc2s(d.critic.step));

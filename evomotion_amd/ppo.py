@@ -114,14 +114,16 @@ class FusedPpoTrainer:
         return adv, ret, n_glob
 
     def epoch(self, states, actions, logp_old, adv, returns, mask_u8, n_selected_global, epsilon, entropy_factor,
-              critic_loss_factor, learning_rate, clip_grad_norm):
+              critic_loss_factor, learning_rate, clip_grad_norm, states_unchanged=False):
+        """one forward / backward / optimiser step over the rows; states_unchanged: `states` holds what it held in the previous
+        call (later epochs of one train call), the trainer reuses its aligned copy"""
         rows = states.shape[0]
         assert rows <= self.max_rows
         for t in (states, actions, logp_old, adv, returns, mask_u8):
             assert t.is_cuda and t.is_contiguous()
         s = self._stream()
         check(lib.evm_ppo_grads(self._h, rows, _ptr(states), _ptr(actions), _ptr(logp_old), _ptr(adv), _ptr(returns), _ptr(mask_u8),
-                                float(n_selected_global), epsilon, entropy_factor, critic_loss_factor, s))
+                                float(n_selected_global), epsilon, entropy_factor, critic_loss_factor, 1 if states_unchanged else 0, s))
         if _dist_ready():
             for net in (ACTOR, CRITIC):
                 g = self.vector(GRADS, net)
@@ -144,9 +146,9 @@ class FusedPpoTrainer:
             return float("nan"), float("nan")
         S, A = states.shape[-1], actions.shape[-1]
         st, ac, lp = states.reshape(T * N, S), actions.reshape(T * N, A), logp_old.reshape(T * N, A)
-        for _ in range(epoch):
+        for ep in range(epoch):
             self.epoch(st, ac, lp, adv.reshape(-1), ret.reshape(-1), mask_u8.reshape(-1), n_glob, epsilon, entropy_factor,
-                       critic_loss_factor, learning_rate, clip_grad_norm)
+                       critic_loss_factor, learning_rate, clip_grad_norm, states_unchanged=ep > 0)
         return self.losses()
 
     def timing(self, enable):

@@ -207,7 +207,7 @@ int evm_replay_timing_end(EvmReplay *rb, void *stream, float *ms_push, int *n_pu
  * ------------------------------------------------------------------------------------------------------- */
 typedef struct EvmPpo EvmPpo;
 /* `policy` is borrowed and must outlive the trainer; max_rows bounds `rows` of evm_ppo_grads (activations are kept
- * for the backward pass: about 6.3 KiB of HBM per row and network). */
+ * for the backward pass: about 6.3 KiB of HBM per row and network, plus 1.5 KiB per row for the aligned observations). */
 int evm_ppo_create(EvmPolicy *policy, size_t max_rows, EvmPpo **out);
 void evm_ppo_destroy(EvmPpo *q);
 /* flat DEVICE parameter vectors (evm_policy_param_counts floats each); reset_optimizer != 0 zeroes the Adam moments and
@@ -232,10 +232,11 @@ int evm_ppo_gae_normalize(EvmPpo *q, int horizon, int n_envs, const double *d_st
 /* Forward, losses and backward of both networks over `rows` transitions: gradients land in the trainer (evm_ppo_copy).
  * n_selected_global = number of rows with d_mask == 1 over ALL ranks (the losses are means over them, so summing the
  * ranks' gradients gives the global gradient).  d_states [rows, S], d_actions / d_logp_old [rows, A], d_adv /
- * d_returns [rows], d_mask [rows]. */
+ * d_returns [rows], d_mask [rows].  states_unchanged != 0: d_states holds what it held in the previous call (the later
+ * epochs of one train call) and the trainer's 16-byte aligned copy of it is reused. */
 int evm_ppo_grads(EvmPpo *q, size_t rows, const float *d_states, const float *d_actions, const float *d_logp_old, const float *d_adv,
                   const float *d_returns, const uint8_t *d_mask, double n_selected_global, float epsilon, float entropy_factor,
-                  float critic_loss_factor, void *stream);
+                  float critic_loss_factor, int states_unchanged, void *stream);
 /* clip_grad_norm_(clip_grad_norm) and Adam(lr, betas 0.9 / 0.999, eps 1e-8) for both networks, then the new weights into
  * `policy` */
 int evm_ppo_apply(EvmPpo *q, float learning_rate, float clip_grad_norm, void *stream);

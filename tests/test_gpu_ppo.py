@@ -128,7 +128,7 @@ def test_gradients_match_autograd(rows):
     from evomotion_amd._lib import lib, check
     from evomotion_amd.ppo import _ptr
     check(lib.evm_ppo_grads(tr._h, rows, _ptr(states), _ptr(actions), _ptr(logp_old), _ptr(adv), _ptr(returns), _ptr(mask), n_glob,
-                            HP["epsilon"], HP["entropy_factor"], HP["critic_loss_factor"], tr._stream()))
+                            HP["epsilon"], HP["entropy_factor"], HP["critic_loss_factor"], 0, tr._stream()))
     ga, gc = tr.vector(GRADS, ACTOR), tr.vector(GRADS, CRITIC)
     la, lc = tr.losses()
     ra, rc, rla, rlc = _torch_grads(actor, critic, states, actions, logp_old, adv, returns, mask, n_glob)
@@ -197,7 +197,7 @@ def test_epochs_in_lock_step_with_autograd_and_adam():
     for ep in range(4):
         tr.params_into(actor, critic)
         check(lib.evm_ppo_grads(tr._h, rows, _ptr(st), _ptr(ac), _ptr(logp), _ptr(adv.reshape(-1)), _ptr(ret.reshape(-1)),
-                                _ptr(mask.reshape(-1)), ng, HP["epsilon"], HP["entropy_factor"], HP["critic_loss_factor"], tr._stream()))
+                                _ptr(mask.reshape(-1)), ng, HP["epsilon"], HP["entropy_factor"], HP["critic_loss_factor"], 0, tr._stream()))
         ga, gc = tr.vector(GRADS, ACTOR), tr.vector(GRADS, CRITIC)
         ra, rc, la, lc = _torch_grads(actor, critic, st, ac, logp, adv.reshape(-1), ret.reshape(-1), mask.reshape(-1), ng)
         assert float((ga - ra).abs().max()) <= 2e-5 * float(ra.abs().max()), ep

@@ -24,7 +24,7 @@ print("n", ng, "adv err", float((tm(adv.squeeze(-1)) - adv_m)[tm(mask.squeeze(-1
 rows = 28
 st = tm(t("ppo_states")).reshape(rows, 371); ac = tm(t("ppo_actions")).reshape(rows, 12); lp = tm(t("ppo_log_prob")).reshape(rows, 12)
 mk8 = tm(mask.squeeze(-1)).to(torch.uint8).reshape(-1)
-check(lib.evm_ppo_grads(tr._h, rows, _ptr(st), _ptr(ac), _ptr(lp), _ptr(adv_m.reshape(-1)), _ptr(ret_m.reshape(-1)), _ptr(mk8), ng, HP["epsilon"], HP["entropy_factor"], HP["critic_loss_factor"], tr._stream()))
+check(lib.evm_ppo_grads(tr._h, rows, _ptr(st), _ptr(ac), _ptr(lp), _ptr(adv_m.reshape(-1)), _ptr(ret_m.reshape(-1)), _ptr(mk8), ng, HP["epsilon"], HP["entropy_factor"], HP["critic_loss_factor"], 0, tr._stream()))
 ga, gc = tr.vector(GRADS, ACTOR), tr.vector(GRADS, CRITIC)
 ra, rc, la, lc = T._torch_grads(a2, c2, st, ac, lp, adv_m.reshape(-1), ret_m.reshape(-1), mk8, ng)
 for flat, ref, mod, nm in ((ga, ra, a2, "actor"), (gc, rc, c2, "critic")):

@@ -21,7 +21,7 @@ st, ac, lp = states.reshape(rows, 371), actions.reshape(rows, 12), logp.reshape(
 for ep in range(4):
     tr.params_into(actor, critic)
     check(lib.evm_ppo_grads(tr._h, rows, _ptr(st), _ptr(ac), _ptr(lp), _ptr(adv.reshape(-1)), _ptr(ret.reshape(-1)), _ptr(mask.reshape(-1)), ng,
-                            HP["epsilon"], HP["entropy_factor"], HP["critic_loss_factor"], tr._stream()))
+                            HP["epsilon"], HP["entropy_factor"], HP["critic_loss_factor"], 0, tr._stream()))
     ga, gc = tr.vector(GRADS, ACTOR), tr.vector(GRADS, CRITIC)
     ra, rc, la, lc = T._torch_grads(actor, critic, st, ac, lp, adv.reshape(-1), ret.reshape(-1), mask.reshape(-1), ng)
     print("epoch", ep, "norms %.6f %.6f | max grad err actor %.3e critic %.3e | max |g| %.3e %.3e" % (float(ra.norm()), float(rc.norm()), float((ga-ra).abs().max()), float((gc-rc).abs().max()), float(ra.abs().max()), float(rc.abs().max())))
