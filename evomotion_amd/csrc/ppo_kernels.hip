@@ -76,6 +76,28 @@ __device__ __forceinline__ void acc_to_tile(const f32x16 (&acc)[RT][2], const fl
 // ---------------------------------------------------------------------------------------------------------
 // forward with the activations kept
 // ---------------------------------------------------------------------------------------------------------
+// TM x K1 tile of the padded observations [n][K1] (16-byte aligned rows) -> k-split LDS tile (row stride ALD1)
+template <int TM_>
+__device__ __forceinline__ void stage_padded_ksplit(float *xs, const float *__restrict__ xp, int row0, int n) {
+    constexpr int NIT = TM_ * K1 / 4 / PT;
+    static_assert(TM_ * K1 / 4 % PT == 0, "tile must divide among the threads");
+    f32x4 v[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+        const int q = it * PT + (int) threadIdx.x, r = q / (K1 / 4), c4 = (q - r * (K1 / 4)) * 4;
+        const int gr = row0 + r;
+        v[it] = *reinterpret_cast<const f32x4 *>(xp + (size_t) (gr < n ? gr : n - 1) * K1 + c4);
+        if (gr >= n) v[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+        const int q = it * PT + (int) threadIdx.x, r = q / (K1 / 4), c4 = (q - r * (K1 / 4)) * 4;
+        // k = c4 .. c4 + 3: even k -> first half, odd k -> second half of the k-split row
+        float *dst = xs + r * ALD1 + (c4 >> 1);
+        dst[0] = v[it][0]; dst[K1 / 2] = v[it][1]; dst[1] = v[it][2]; dst[K1 / 2 + 1] = v[it][3];
+    }
+}
+
 // z = acc + bias -> HBM; Mish + LayerNorm per row -> tile and HBM; (mean, rstd) -> st[row][st_off..]
 template <int RT>
 __device__ __forceinline__ void train_epilogue(const f32x16 (&acc)[RT][2], const float *__restrict__ bias,
@@ -137,7 +159,7 @@ __global__ __launch_bounds__(PT) void k_ppo_forward(PolicyDev p, PpoDev d, int n
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const NetDev &N = net == 0 ? p.actor : p.critic;
     const PpoNet &B = net == 0 ? d.actor : d.critic;
-    stage_rows_ksplit<TM>(xs, states, row0, n, K1);  // the padded copy: [n][K1]
+    stage_padded_ksplit<TM>(xs, states, row0, n);  // the padded copy: [n][K1]
     __syncthreads();
     f32x16 acc[RT][2];
     dense_layer<K1, RT>(xs, ALD1, N.w1t, wave, lane, acc);
@@ -582,7 +604,17 @@ __global__ __launch_bounds__(256) void k_ppo_wreduce(const float *__restrict__ p
     if (e >= I * J) return;
     const int i = e / J, j = e - i * J;
     float s = 0.f;
-    for (int k = 0; k < sk; k++) s += part[((size_t) k * I + i) * ldo + j];
+    const float *src = part + (size_t) i * ldo + j;
+    const size_t stride = (size_t) I * ldo;
+    int k = 0;
+    for (; k + 8 <= sk; k += 8) {  // eight loads in flight; the additions stay in chunk order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = src[(size_t) (k + u) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; u++) s += v[u];
+    }
+    for (; k < sk; k++) s += src[(size_t) k * stride];
     dst[(size_t) i * dst_ld + j + (i >= split_row ? extra : 0)] = s;
 }
 
@@ -591,7 +623,16 @@ __global__ __launch_bounds__(256) void k_ppo_colreduce(const float *__restrict__
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= W) return;
     float s = 0.f;
-    for (int k = blockIdx.y; k < tiles; k += gridDim.y) s += src[(size_t) k * W + e];
+    int k = blockIdx.y;
+    const int g = gridDim.y;
+    for (; k + 7 * g < tiles; k += 8 * g) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = src[(size_t) (k + u * g) * W + e];
+#pragma unroll
+        for (int u = 0; u < 8; u++) s += v[u];
+    }
+    for (; k < tiles; k += g) s += src[(size_t) k * W + e];
     dst[(size_t) blockIdx.y * W + e] = s;
 }
 // [groups][7][256] -> the flat gradient slots
