@@ -24,7 +24,7 @@ VALU_PEAK_TFLOPS = 157.3
 def measured_traffic(n):
     """HBM-side bytes per launch of the dynamics kernel, from the committed PMC profile of this exact workload
     (rocprofv3 cannot run inside the timed bench); None when the batch size differs from the profiled one."""
-    path = os.path.join(ROOT, "profiles", "r1d_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r1e_traffic.json")
     try:
         with open(path) as f:
             t = json.load(f)
@@ -205,13 +205,13 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n),
-                "kernel": ("k_split_sweeps (dominant) + k_split_prologue / pre_a / pre_b / post: one step" if ms_sweeps > 0 else "k_env_step<7>"),
+                "kernel": ("k_split_sweeps (dominant) + k_split_pre_a / pre_b / post: one step" if ms_sweeps > 0 else "k_env_step<7>"),
                 "launch_ms": launch_ms, "dominant_kernel_ms": (ms_sweeps / max(n_launch, 1)) if ms_sweeps > 0 else launch_ms,
-                "note": "algorithmic 8300 B per env physics step x %d envs per step; a step is a pipeline of five kernels up to "
+                "note": "algorithmic 8300 B per env physics step x %d envs per step; a step is a pipeline of four kernels up to "
                         "8192 envs (launch_ms = all of them, HIP events on the launch stream; dominant_kernel_ms = the Gauss-Seidel "
                         "sweeps kernel alone), one monolithic kernel above; fp32-VALU/latency bound (about 50 FLOP per algorithmic "
                         "byte); traffic = memory-side bytes per step from the committed rocprofv3 PMC passes "
-                        "(profiles/r1d_traffic.json; per-sweep re-reads of the constraint records overflow the 4 MB L2 and are "
+                        "(profiles/r1e_traffic.json; per-sweep re-reads of the constraint records overflow the 4 MB L2 and are "
                         "served by the Infinity Cache), see DESIGN.md" % n,
             },
         }

@@ -19,6 +19,28 @@ def _dist_ready():
     return torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
 
 
+def _via_host():
+    """RCCL ("nccl") exchanges device tensors directly; the gloo rehearsal of the N > 1 path goes through host copies"""
+    return torch.distributed.get_backend() != "nccl"
+
+
+def _all_reduce_sum(t):
+    if _via_host():
+        h = t.cpu()
+        torch.distributed.all_reduce(h)
+        t.copy_(h)
+    else:
+        torch.distributed.all_reduce(t)
+
+
+def _all_gather(t):
+    w = torch.distributed.get_world_size()
+    src = t.cpu() if _via_host() else t
+    out = [torch.zeros_like(src) for _ in range(w)]
+    torch.distributed.all_gather(out, src)
+    return [o.to(t.device) for o in out]
+
+
 class FusedPpoTrainer:
     """fused: the FusedActorCritic whose weights the trainer keeps up to date (borrowed; must outlive the trainer)."""
 
@@ -94,8 +116,7 @@ class FusedPpoTrainer:
                               gamma, lam, _ptr(adv), _ptr(self._stats), s))
         n_glob = None
         if _dist_ready():
-            allt = [torch.zeros_like(self._stats) for _ in range(torch.distributed.get_world_size())]
-            torch.distributed.all_gather(allt, self._stats)
+            allt = _all_gather(self._stats)
             n, mean, m2 = allt[0]
             for t in allt[1:]:  # Chan's merge, same order on every rank
                 nb, mb, m2b = t
@@ -127,7 +148,7 @@ class FusedPpoTrainer:
         if _dist_ready():
             for net in (ACTOR, CRITIC):
                 g = self.vector(GRADS, net)
-                torch.distributed.all_reduce(g)  # the losses are normalised by the global count: SUM is the global gradient
+                _all_reduce_sum(g)  # the losses are normalised by the global count: SUM is the global gradient
                 check(lib.evm_ppo_copy(self._h, GRADS, net, 1, _ptr(g), s))
                 torch.cuda.current_stream(self.device).synchronize()
         check(lib.evm_ppo_apply(self._h, learning_rate, clip_grad_norm, s))
