@@ -104,9 +104,22 @@ __device__ __forceinline__ void train_epilogue(const f32x16 (&acc)[RT][2], const
                                                const float *__restrict__ gamma, const float *__restrict__ beta, float *hb,
                                                int wave, int lane, int row0, int n, float *zg, float *ag, float *st, int st_off) {
     constexpr int TM = 32 * RT, PARTS = PT / TM, RUN = 256 / PARTS;
-    acc_to_tile<RT>(acc, bias, hb, wave, lane);
-    __syncthreads();
-    tile_store<TM>(hb, zg, row0, n);
+    // z = acc + bias: to the tile for the row phase and straight to HBM from the accumulators (C layout: the 32 lanes of
+    // a half wave hold 32 consecutive columns of one row = 128 contiguous bytes)
+#pragma unroll
+    for (int i = 0; i < RT; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int c = wave * 64 + j * 32 + (lane & 31);
+            const float b = bias[c];
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const float z = acc[i][j][r] + b;
+                hb[HIDX(row, c)] = z;
+                if (row0 + row < n) zg[(size_t) (row0 + row) * 256 + c] = z;
+            }
+        }
     __syncthreads();
     const int t = threadIdx.x, row = t / PARTS, part = t % PARTS;
     f32x4 *hr = reinterpret_cast<f32x4 *>(hb + row * ALD2 + part * RUN);
@@ -752,7 +765,7 @@ static size_t bwd_lds_bytes() {
     const size_t td = (size_t) TM * ALD2 > (size_t) 32 * 256 + TM * 32 ? (size_t) TM * ALD2 : (size_t) 32 * 256 + TM * 32;
     return ((size_t) TM * ALD2 + td) * sizeof(float);
 }
-size_t ppo_wpart_floats() { return (size_t) PPO_SK * 256 * 384; }
+size_t ppo_wpart_floats() { return (size_t) 128 * 256 * 256 > (size_t) 86 * 256 * 384 ? (size_t) 128 * 256 * 256 : (size_t) 86 * 256 * 384; }
 
 hipError_t launch_ppo_pack_w2d(const PpoNet &n, int S, hipStream_t s) {
     const float *w2 = n.theta + (size_t) 256 * S + 3 * 256;
@@ -815,7 +828,8 @@ static void wgrad_one(const float *P, int ldp, int np, bool pa, const float *Q, 
                       float *dst, int dst_ld, int split_row, int extra, hipStream_t s) {
     const int ldo = (J + 127) / 128 * 128;
     int chunks = (M + 31) / 32;
-    if (chunks > PPO_SK) chunks = PPO_SK;
+    const int want = 512 / (((I + 127) / 128) * (ldo / 128));  // two workgroups per CU (64 KB of LDS each)
+    if (chunks > want) chunks = want;
     int rpc = ((M + chunks - 1) / chunks + 31) / 32 * 32;
     chunks = (M + rpc - 1) / rpc;
     const int i_tiles = (I + 127) / 128, j_tiles = ldo / 128;
