@@ -13,6 +13,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define ALD1 (K1 + 4) // k-split observation tile row stride
 #define ALD2 (256 + 4) // k-split activation tile row stride
 #define HIDX(row, c) ((row) * ALD2 + ((c) & 1) * 128 + ((c) >> 1))
+#define QCOL(q) (2 * ((q) & 127) + ((q) >> 7))  // column held at stored position q of a k-split activation row
+// Row phases (LayerNorm, heads): thread (row, part) owns the 16-byte chunks i * PARTS + part (i = 0 .. RUN / 4 - 1) of its
+// k-split row, so the PARTS threads of a row read consecutive chunks — a contiguous run per thread would put all of them
+// on the same LDS banks (row stride 260 floats, run 32 floats: an 8-way conflict)
+#define CHUNK(i, part, PARTS_) ((i) * (PARTS_) + (part))
 
 // Mish(x) = x tanh(softplus(x)).  With n = e^x: tanh(log(1 + n)) = n (n + 2) / (n (n + 2) + 2), all terms positive
 // (no cancellation), one exp and one division instead of exp + log1p + tanh (which cost ~300 VALU instructions per

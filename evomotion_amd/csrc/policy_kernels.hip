@@ -44,14 +44,14 @@ __device__ __forceinline__ void epilogue_mish_ln(f32x16 (&acc)[RT][2], const flo
             }
         }
     __syncthreads();
-    // LayerNorm: PARTS threads per row, each owning a contiguous RUN of the k-split row (which columns a thread
-    // holds does not matter for the statistics); element q of the stored row is column 2 (q & 127) + (q >> 7)
+    // LayerNorm: PARTS threads per row, each owning RUN / 4 interleaved 16-byte chunks of the k-split row (which columns a
+    // thread holds does not matter for the statistics); element q of the stored row is column QCOL(q)
     const int t = threadIdx.x, row = t / PARTS, part = t % PARTS;
-    f32x4 *hr = reinterpret_cast<f32x4 *>(hb + row * ALD2 + part * RUN);
+    f32x4 *hr = reinterpret_cast<f32x4 *>(hb + row * ALD2);
     f32x4 x[RUN / 4];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < RUN / 4; i++) { x[i] = hr[i]; s += (x[i][0] + x[i][1]) + (x[i][2] + x[i][3]); }
+    for (int i = 0; i < RUN / 4; i++) { x[i] = hr[CHUNK(i, part, PARTS)]; s += (x[i][0] + x[i][1]) + (x[i][2] + x[i][3]); }
 #pragma unroll
     for (int m = 1; m < PARTS; m <<= 1) s += __shfl_xor(s, m);
     const float mean = s / 256.f;
@@ -68,11 +68,10 @@ __device__ __forceinline__ void epilogue_mish_ln(f32x16 (&acc)[RT][2], const flo
         f32x4 y;
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const int q = part * RUN + 4 * i + u;
-            const int c = 2 * (q & 127) + (q >> 7);
+            const int c = QCOL(4 * CHUNK(i, part, PARTS) + u);
             y[u] = (x[i][u] - mean) * rstd * gamma[c] + beta[c];
         }
-        hr[i] = y;
+        hr[CHUNK(i, part, PARTS)] = y;
     }
     __syncthreads();
 }
@@ -124,16 +123,16 @@ __global__ __launch_bounds__(PT) void k_policy_forward(PolicyDev p, int n, const
     }
     __syncthreads();
     {
-        const f32x4 *hr = reinterpret_cast<const f32x4 *>(hb + row * ALD2 + part * RUN);
+        const f32x4 *hr = reinterpret_cast<const f32x4 *>(hb + row * ALD2);
         f32x4 x[RUN / 4];
 #pragma unroll
-        for (int i = 0; i < RUN / 4; i++) x[i] = hr[i];
+        for (int i = 0; i < RUN / 4; i++) x[i] = hr[CHUNK(i, part, PARTS)];
         for (int o = 0; o < nout; o++) {
-            const f32x4 *wr = reinterpret_cast<const f32x4 *>(wl + o * 256 + part * RUN);
+            const f32x4 *wr = reinterpret_cast<const f32x4 *>(wl + o * 256);
             float sum = 0.f;
 #pragma unroll
             for (int i = 0; i < RUN / 4; i++) {
-                const f32x4 w = wr[i];
+                const f32x4 w = wr[CHUNK(i, part, PARTS)];
                 sum += (x[i][0] * w[0] + x[i][1] * w[1]) + (x[i][2] * w[2] + x[i][3] * w[3]);
             }
 #pragma unroll

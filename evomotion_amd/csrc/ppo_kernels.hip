@@ -18,42 +18,49 @@
 namespace evm {
 
 #define PRT 1  // 32-row MFMA tiles per wave in the training kernels (TM = 32 rows per workgroup)
+#define HEAD_PASS 12  // head outputs staged per pass in the forward: keeps its LDS at 49 KB = three workgroups per CU
 
 // ---------------------------------------------------------------------------------------------------------
 // tile helpers (k-split activation tile [TM][ALD2] <-> row-major [rows][256] in HBM)
 // ---------------------------------------------------------------------------------------------------------
+// Thread t moves the column pair (2k, 2k + 1), k = t & 127, of the rows r = (t >> 7), + 2, ...: 8 contiguous bytes per lane
+// in HBM (512 B per wave instruction) and the two k-split halves [k], [128 + k] in LDS (conflict free).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int TM_>
 __device__ __forceinline__ void tile_load(float *T, const float *__restrict__ src, int row0, int n) {
-    constexpr int NIT = TM_ * 64 / PT;
-    f32x4 v[NIT];
+    const int k = threadIdx.x & 127, r0 = threadIdx.x >> 7;
+    f32x2 v[TM_ / 2];
 #pragma unroll
-    for (int it = 0; it < NIT; it++) {
-        const int e = it * PT + (int) threadIdx.x, r = e >> 6, c4 = (e & 63) * 4;
-        const int gr = row0 + r;
-        v[it] = *reinterpret_cast<const f32x4 *>(src + (size_t) (gr < n ? gr : n - 1) * 256 + c4);
-        if (gr >= n) v[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < TM_ / 2; j++) {
+        const int gr = row0 + r0 + 2 * j;
+        v[j] = *reinterpret_cast<const f32x2 *>(src + (size_t) (gr < n ? gr : n - 1) * 256 + 2 * k);
+        if (gr >= n) v[j] = f32x2{0.f, 0.f};
     }
 #pragma unroll
-    for (int it = 0; it < NIT; it++) {
-        const int e = it * PT + (int) threadIdx.x, r = e >> 6, c4 = (e & 63) * 4;
-#pragma unroll
-        for (int u = 0; u < 4; u++) T[HIDX(r, c4 + u)] = v[it][u];
+    for (int j = 0; j < TM_ / 2; j++) {
+        float *d = T + (r0 + 2 * j) * ALD2 + k;
+        d[0] = v[j][0];
+        d[128] = v[j][1];
     }
 }
-// thread = column: coalesced 1 KiB rows
 template <int TM_>
 __device__ __forceinline__ void tile_store(const float *T, float *__restrict__ dst, int row0, int n) {
-    const int c = threadIdx.x;
+    const int k = threadIdx.x & 127, r0 = threadIdx.x >> 7;
 #pragma unroll 8
-    for (int r = 0; r < TM_; r++)
-        if (row0 + r < n) dst[(size_t) (row0 + r) * 256 + c] = T[HIDX(r, c)];
+    for (int j = 0; j < TM_ / 2; j++) {
+        const int r = r0 + 2 * j;
+        const float *sp = T + r * ALD2 + k;
+        const f32x2 v = {sp[0], sp[128]};
+        if (row0 + r < n) *reinterpret_cast<f32x2 *>(dst + (size_t) (row0 + r) * 256 + 2 * k) = v;
+    }
 }
+// thread t sums the stored position t of every row: column QCOL(t)
 template <int TM_>
 __device__ __forceinline__ float tile_colsum(const float *T) {
-    const int c = threadIdx.x;
+    const int q = threadIdx.x;
     float s = 0.f;
 #pragma unroll 8
-    for (int r = 0; r < TM_; r++) s += T[HIDX(r, c)];
+    for (int r = 0; r < TM_; r++) s += T[r * ALD2 + q];
     return s;
 }
 // MFMA accumulators (C layout: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)) -> tile, plus a per-column bias
@@ -122,12 +129,12 @@ __device__ __forceinline__ void train_epilogue(const f32x16 (&acc)[RT][2], const
         }
     __syncthreads();
     const int t = threadIdx.x, row = t / PARTS, part = t % PARTS;
-    f32x4 *hr = reinterpret_cast<f32x4 *>(hb + row * ALD2 + part * RUN);
+    f32x4 *hr = reinterpret_cast<f32x4 *>(hb + row * ALD2);
     f32x4 x[RUN / 4];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < RUN / 4; i++) {
-        x[i] = hr[i];
+        x[i] = hr[CHUNK(i, part, PARTS)];
 #pragma unroll
         for (int u = 0; u < 4; u++) x[i][u] = mish_f(x[i][u]);
         s += (x[i][0] + x[i][1]) + (x[i][2] + x[i][3]);
@@ -152,11 +159,10 @@ __device__ __forceinline__ void train_epilogue(const f32x16 (&acc)[RT][2], const
         f32x4 y;
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const int q = part * RUN + 4 * i + u;
-            const int c = 2 * (q & 127) + (q >> 7);
+            const int c = QCOL(4 * CHUNK(i, part, PARTS) + u);
             y[u] = (x[i][u] - mean) * rstd * gamma[c] + beta[c];
         }
-        hr[i] = y;
+        hr[CHUNK(i, part, PARTS)] = y;
     }
     __syncthreads();
     tile_store<TM>(hb, ag, row0, n);
@@ -187,29 +193,33 @@ __global__ __launch_bounds__(PT) void k_ppo_forward(PolicyDev p, PpoDev d, int n
     const int gr = row0 + row;
     const int A = p.A;
     const int nout = net == 1 ? 1 : 2 * A;
-    float *wl = sm + TM * ALD2;
-    float *hs = wl + 32 * 256;
-    for (int e = threadIdx.x; e < nout * 256; e += PT) {
-        const int c = e & 255;
-        wl[(e & ~255) + (c & 1) * 128 + (c >> 1)] = N.wh[e];
-    }
-    __syncthreads();
+    float *wl = sm + TM * ALD2;          // [HEAD_PASS][256] head weights, k-split
+    float *hs = wl + HEAD_PASS * 256;    // [TM][32] pre-activations
     {
-        const f32x4 *hr = reinterpret_cast<const f32x4 *>(hb + row * ALD2 + part * RUN);
+        const f32x4 *hr = reinterpret_cast<const f32x4 *>(hb + row * ALD2);
         f32x4 x[RUN / 4];
 #pragma unroll
-        for (int i = 0; i < RUN / 4; i++) x[i] = hr[i];
-        for (int o = 0; o < nout; o++) {
-            const f32x4 *wr = reinterpret_cast<const f32x4 *>(wl + o * 256 + part * RUN);
-            float sum = 0.f;
-#pragma unroll
-            for (int i = 0; i < RUN / 4; i++) {
-                const f32x4 w = wr[i];
-                sum += (x[i][0] * w[0] + x[i][1] * w[1]) + (x[i][2] * w[2] + x[i][3] * w[3]);
+        for (int i = 0; i < RUN / 4; i++) x[i] = hr[CHUNK(i, part, PARTS)];
+        for (int o0 = 0; o0 < nout; o0 += HEAD_PASS) {
+            const int no = min(HEAD_PASS, nout - o0);
+            __syncthreads();  // the previous pass has been consumed (first pass: the activation tile is complete)
+            for (int e = threadIdx.x; e < no * 256; e += PT) {
+                const int c = e & 255;
+                wl[(e & ~255) + (c & 1) * 128 + (c >> 1)] = N.wh[o0 * 256 + e];
             }
+            __syncthreads();
+            for (int o = 0; o < no; o++) {
+                const f32x4 *wr = reinterpret_cast<const f32x4 *>(wl + o * 256);
+                float sum = 0.f;
 #pragma unroll
-            for (int m = 1; m < PARTS; m <<= 1) sum += __shfl_xor(sum, m);
-            if (part == 0) hs[row * 32 + o] = sum + N.bh[o];
+                for (int i = 0; i < RUN / 4; i++) {
+                    const f32x4 w = wr[CHUNK(i, part, PARTS)];
+                    sum += (x[i][0] * w[0] + x[i][1] * w[1]) + (x[i][2] * w[2] + x[i][3] * w[3]);
+                }
+#pragma unroll
+                for (int m = 1; m < PARTS; m <<= 1) sum += __shfl_xor(sum, m);
+                if (part == 0) hs[row * 32 + o0 + o] = sum + N.bh[o0 + o];
+            }
         }
     }
     if (net == 1) {
@@ -341,8 +351,8 @@ __device__ __forceinline__ void ln_mish_backward(float (&g)[RUN], float *Tz, int
     float c1 = 0.f, c2 = 0.f;
 #pragma unroll
     for (int i = 0; i < RUN; i++) {
-        const int q = part * RUN + i;
-        const int c = 2 * (q & 127) + (q >> 7);
+        const int q = 4 * CHUNK(i >> 2, part, PARTS) + (i & 3);
+        const int c = QCOL(q);
         const float z = Tz[row * ALD2 + q];
         const float nn = __expf(fminf(z, 20.f));
         const float mm = nn * (nn + 2.f);
@@ -405,10 +415,10 @@ __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         for (int i = 0; i < RUN; i++) da[i] = 0.f;
         for (int o = 0; o < nout; o++) {
             const float g = dhs[row * 32 + o];
-            const f32x4 *wr = reinterpret_cast<const f32x4 *>(wl + o * 256 + part * RUN);
+            const f32x4 *wr = reinterpret_cast<const f32x4 *>(wl + o * 256);
 #pragma unroll
             for (int i = 0; i < RUN / 4; i++) {
-                const f32x4 w = wr[i];
+                const f32x4 w = wr[CHUNK(i, part, PARTS)];
 #pragma unroll
                 for (int u = 0; u < 4; u++) da[4 * i + u] += g * w[u];
             }
@@ -417,14 +427,14 @@ __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const float mean2 = gr < n ? B.st[(size_t) gr * 4 + 2] : 0.f, rstd2 = gr < n ? B.st[(size_t) gr * 4 + 3] : 0.f;
     __syncthreads();  // everyone is done with wl / dhs: Td may be overwritten
 #pragma unroll
-    for (int i = 0; i < RUN; i++) Td[row * ALD2 + part * RUN + i] = da[i];
+    for (int i = 0; i < RUN; i++) Td[row * ALD2 + 4 * CHUNK(i >> 2, part, PARTS) + (i & 3)] = da[i];
     ln_mish_backward<RUN, PARTS>(da, Tz, row, part, mean2, rstd2, N.g2);  // da <- dz2
     __syncthreads();
     colacc[0] = tile_colsum<TM>(Tz);  // dgamma2 = sum da * xhat
     colacc[1] = tile_colsum<TM>(Td);  // dbeta2 = sum da
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < RUN; i++) Td[row * ALD2 + part * RUN + i] = da[i];
+    for (int i = 0; i < RUN; i++) Td[row * ALD2 + 4 * CHUNK(i >> 2, part, PARTS) + (i & 3)] = da[i];
     tile_load<TM>(Tz, B.z1, row0, n);  // Tz is free again: the layer-1 pre-activations
     __syncthreads();
     colacc[2] = tile_colsum<TM>(Td);  // dbias2 = sum dz2
@@ -436,7 +446,7 @@ __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     acc_to_tile<RT>(acc, nullptr, Td, wave, lane);
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < RUN; i++) da[i] = Td[row * ALD2 + part * RUN + i];
+    for (int i = 0; i < RUN; i++) da[i] = Td[row * ALD2 + 4 * CHUNK(i >> 2, part, PARTS) + (i & 3)];
     const float mean1 = gr < n ? B.st[(size_t) gr * 4] : 0.f, rstd1 = gr < n ? B.st[(size_t) gr * 4 + 1] : 0.f;
     ln_mish_backward<RUN, PARTS>(da, Tz, row, part, mean1, rstd1, N.g1);  // da <- dz1
     __syncthreads();
@@ -444,13 +454,14 @@ __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     colacc[4] = tile_colsum<TM>(Td);
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < RUN; i++) Td[row * ALD2 + part * RUN + i] = da[i];
+    for (int i = 0; i < RUN; i++) Td[row * ALD2 + 4 * CHUNK(i >> 2, part, PARTS) + (i & 3)] = da[i];
     __syncthreads();
     colacc[5] = tile_colsum<TM>(Td);
     tile_store<TM>(Td, B.dz1, row0, n);
     float *cp = B.colpart + (size_t) blockIdx.x * PPO_COLSLOTS * 256;
 #pragma unroll
-    for (int k = 0; k < PPO_COLSLOTS; k++) cp[k * 256 + t] = colacc[k];
+    for (int k = 0; k < PPO_COLSLOTS - 1; k++) cp[k * 256 + QCOL(t)] = colacc[k];  // tile_colsum: thread t holds column QCOL(t)
+    cp[6 * 256 + t] = colacc[6];
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -757,7 +768,7 @@ __global__ __launch_bounds__(256) void k_ppo_gae_finish(size_t total, const doub
 // ---------------------------------------------------------------------------------------------------------
 static size_t fwd_lds_bytes() {
     constexpr int TM = 32 * PRT;
-    const size_t a = (size_t) TM * ALD1, b = (size_t) TM * ALD2 + 32 * 256 + TM * 32;
+    const size_t a = (size_t) TM * ALD1, b = (size_t) TM * ALD2 + HEAD_PASS * 256 + TM * 32;
     return (a > b ? a : b) * sizeof(float);
 }
 static size_t bwd_lds_bytes() {
