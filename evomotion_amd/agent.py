@@ -422,19 +422,21 @@ class VecPpoGaeAgent:
         T, N, S, A = self.horizon, env.n_envs, env.state_dim, env.action_dim
         if self._buf is None:
             z = lambda *s, **k: torch.zeros(*s, device=self.device, **k)
-            self._buf = dict(states=z(T, N, S), actions=z(T, N, A), logp=z(T, N, A), values=z(T, N), rewards=z(T, N),
+            # states[t] = the observation acted on at step t; the env writes observation t + 1 straight into states[t + 1]
+            self._buf = dict(states_all=z(T + 1, N, S), actions=z(T, N, A), logp=z(T, N, A), values=z(T, N), rewards=z(T, N),
                              done=z(T, N), valid=z(T, N), next_values=z(T, N), done_u8=z(T, N, dtype=torch.uint8),
                              valid_u8=z(T, N, dtype=torch.uint8), scratch=(z(N, A), z(N, A), z(N)))
         b = self._buf
-        obs = env.obs
+        b["states"] = b["states_all"][:T]
+        b["states_all"][0].copy_(env.obs)  # one copy per horizon
         for t in range(T):
-            # two launches and one copy per step: the kernels write straight into the rows of the rollout buffer
-            b["states"][t].copy_(obs)
-            self.fused.forward(obs, seed=self.seed, out=(b["actions"][t], b["logp"][t], b["values"][t]))
-            env.step_autoreset(b["actions"][t], reward_out=b["rewards"][t], done_out=b["done_u8"][t], valid_out=b["valid_u8"][t])
+            # two launches per step, no copies: the kernels read and write the rows of the rollout buffer
+            self.fused.forward(b["states_all"][t], seed=self.seed, out=(b["actions"][t], b["logp"][t], b["values"][t]))
+            env.step_autoreset(b["actions"][t], reward_out=b["rewards"][t], done_out=b["done_u8"][t], valid_out=b["valid_u8"][t],
+                               obs_out=b["states_all"][t + 1])
         b["done"].copy_(b["done_u8"])
         b["valid"].copy_(b["valid_u8"])
-        _, _, last_v = self.fused.forward(obs, seed=self.seed, out=b["scratch"])
+        _, _, last_v = self.fused.forward(b["states_all"][T], seed=self.seed, out=b["scratch"])
         b["next_values"][:-1] = b["values"][1:]
         b["next_values"][-1] = last_v
         return b

@@ -126,10 +126,14 @@ class VecRobotWalk:
         check(lib.evm_env_step(self._h, _ptr(action), _ptr(self.obs), _ptr(self.reward), _ptr(self.done), self._stream()))
         return Step(self.obs, self.reward, self.done)
 
-    def step_autoreset(self, action, reward_out=None, done_out=None, valid_out=None):
+    def step_autoreset(self, action, reward_out=None, done_out=None, valid_out=None, obs_out=None):
         """`*_out`: contiguous [n_envs] device tensors (f32 / u8 / u8), e.g. rows of a rollout buffer, written directly by
-        the kernel instead of the env's own buffers (no copies in the rollout loop)."""
+        the kernel instead of the env's own buffers (no copies in the rollout loop).  obs_out [n_envs, state_dim] f32
+        becomes `self.obs` (the next observation lands in the caller's rollout buffer)."""
         action = self._action(action)
+        if obs_out is not None:
+            assert obs_out.dtype == torch.float32 and obs_out.is_contiguous() and tuple(obs_out.shape) == (self.n_envs, self.state_dim)
+            self.obs = obs_out
         r = self.reward if reward_out is None else reward_out
         d = self.done if done_out is None else done_out
         v = self.valid if valid_out is None else valid_out
