@@ -53,8 +53,10 @@ def hard_update(to, frm):
 def soft_update(to, frm, tau):
     """to <- tau * from + (1 - tau) * to, with the reference's double-precision (1.0 - tau) (functions.cpp:169)."""
     with torch.no_grad():
-        for (_, t), (_, f) in zip(to.named_parameters(), frm.named_parameters()):
-            t.copy_(tau * f + (1.0 - tau) * t)
+        ts, fs = [t for _, t in to.named_parameters()], [f for _, f in frm.named_parameters()]
+        # two multi-tensor launches instead of four per parameter: t <- (1 - tau) t, then t <- t + tau f
+        torch._foreach_mul_(ts, 1.0 - tau)
+        torch._foreach_add_(ts, fs, alpha=tau)
 
 
 def sac_train(actor, critic_1, critic_2, target_critic_1, target_critic_2, entropy, actor_opt, critic_1_opt, critic_2_opt,
