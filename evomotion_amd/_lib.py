@@ -92,6 +92,17 @@ def _load():
     lib.evm_ppo_apply.argtypes = [vp, ctypes.c_float, ctypes.c_float, vp]
     lib.evm_ppo_losses.argtypes = [vp, dp, dp, vp]
     lib.evm_ppo_timing.argtypes = [vp, ctypes.c_int, fp, ip]
+    lib.evm_q_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(vp)]
+    lib.evm_q_destroy.argtypes = [vp]
+    lib.evm_q_destroy.restype = None
+    lib.evm_q_param_count.argtypes = [vp, ctypes.POINTER(ctypes.c_size_t)]
+    lib.evm_q_copy.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]
+    lib.evm_q_adam_step.argtypes = [vp, ctypes.c_int, ctypes.c_int, ip]
+    lib.evm_q_forward.argtypes = [vp, ctypes.c_uint, ctypes.c_size_t, vp, vp, ctypes.POINTER(vp), vp]
+    lib.evm_q_grads.argtypes = [vp, ctypes.c_size_t, vp, vp, vp, vp]
+    lib.evm_q_apply.argtypes = [vp, ctypes.c_float, vp]
+    lib.evm_q_soft_update.argtypes = [vp, ctypes.c_float, vp]
+    lib.evm_q_losses.argtypes = [vp, vp, vp]
     lib.evm_env_timing_begin.argtypes = [vp, vp]
     lib.evm_env_timing_end.argtypes = [vp, vp, fp, ip]
     lib.evm_env_timing_end_detail.argtypes = [vp, vp, fp, ip, fp]

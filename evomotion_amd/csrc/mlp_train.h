@@ -1,0 +1,223 @@
+// Device pieces shared by the training kernels (ppo_kernels.hip: actor / critic of PPO; q_kernels.hip: the twin Q
+// networks of SAC): tile moves between HBM and the k-split LDS layout, the forward epilogue that keeps activations,
+// the LayerNorm / Mish backward of a row, block reductions.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mlp_tile.h"
+
+namespace evm {
+
+#define PRT 1  // 32-row MFMA tiles per wave in the training kernels (TM = 32 rows per workgroup)
+#define HEAD_PASS 12  // head outputs staged per pass in the forward: keeps its LDS at 49 KB = three workgroups per CU
+
+// ---------------------------------------------------------------------------------------------------------
+// tile helpers (k-split activation tile [TM][ALD2] <-> row-major [rows][256] in HBM)
+// ---------------------------------------------------------------------------------------------------------
+// Thread t moves the column pair (2k, 2k + 1), k = t & 127, of the rows r = (t >> 7), + 2, ...: 8 contiguous bytes per lane
+// in HBM (512 B per wave instruction) and the two k-split halves [k], [128 + k] in LDS (conflict free).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int TM_>
+__device__ __forceinline__ void tile_load(float *T, const float *__restrict__ src, int row0, int n) {
+    const int k = threadIdx.x & 127, r0 = threadIdx.x >> 7;
+    f32x2 v[TM_ / 2];
+#pragma unroll
+    for (int j = 0; j < TM_ / 2; j++) {
+        const int gr = row0 + r0 + 2 * j;
+        v[j] = *reinterpret_cast<const f32x2 *>(src + (size_t) (gr < n ? gr : n - 1) * 256 + 2 * k);
+        if (gr >= n) v[j] = f32x2{0.f, 0.f};
+    }
+#pragma unroll
+    for (int j = 0; j < TM_ / 2; j++) {
+        float *d = T + (r0 + 2 * j) * ALD2 + k;
+        d[0] = v[j][0];
+        d[128] = v[j][1];
+    }
+}
+template <int TM_>
+__device__ __forceinline__ void tile_store(const float *T, float *__restrict__ dst, int row0, int n) {
+    const int k = threadIdx.x & 127, r0 = threadIdx.x >> 7;
+#pragma unroll 8
+    for (int j = 0; j < TM_ / 2; j++) {
+        const int r = r0 + 2 * j;
+        const float *sp = T + r * ALD2 + k;
+        const f32x2 v = {sp[0], sp[128]};
+        if (row0 + r < n) *reinterpret_cast<f32x2 *>(dst + (size_t) (row0 + r) * 256 + 2 * k) = v;
+    }
+}
+// thread t sums the stored position t of every row: column QCOL(t)
+template <int TM_>
+__device__ __forceinline__ float tile_colsum(const float *T) {
+    const int q = threadIdx.x;
+    float s = 0.f;
+#pragma unroll 8
+    for (int r = 0; r < TM_; r++) s += T[r * ALD2 + q];
+    return s;
+}
+// MFMA accumulators (C layout: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)) -> tile, plus a per-column bias
+template <int RT>
+__device__ __forceinline__ void acc_to_tile(const f32x16 (&acc)[RT][2], const float *__restrict__ bias, float *T, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < RT; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int c = wave * 64 + j * 32 + (lane & 31);
+            const float b = bias ? bias[c] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                T[HIDX(row, c)] = acc[i][j][r] + b;
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// forward with the activations kept
+// ---------------------------------------------------------------------------------------------------------
+// TM x K1 tile of the padded observations [n][K1] (16-byte aligned rows) -> k-split LDS tile (row stride ALD1)
+template <int TM_>
+__device__ __forceinline__ void stage_padded_ksplit(float *xs, const float *__restrict__ xp, int row0, int n) {
+    constexpr int NIT = TM_ * K1 / 4 / PT;
+    static_assert(TM_ * K1 / 4 % PT == 0, "tile must divide among the threads");
+    f32x4 v[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+        const int q = it * PT + (int) threadIdx.x, r = q / (K1 / 4), c4 = (q - r * (K1 / 4)) * 4;
+        const int gr = row0 + r;
+        v[it] = *reinterpret_cast<const f32x4 *>(xp + (size_t) (gr < n ? gr : n - 1) * K1 + c4);
+        if (gr >= n) v[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+        const int q = it * PT + (int) threadIdx.x, r = q / (K1 / 4), c4 = (q - r * (K1 / 4)) * 4;
+        // k = c4 .. c4 + 3: even k -> first half, odd k -> second half of the k-split row
+        float *dst = xs + r * ALD1 + (c4 >> 1);
+        dst[0] = v[it][0]; dst[K1 / 2] = v[it][1]; dst[1] = v[it][2]; dst[K1 / 2 + 1] = v[it][3];
+    }
+}
+
+// z = acc + bias -> HBM; Mish + LayerNorm per row -> tile and HBM; (mean, rstd) -> st[row * st_stride + st_off ..];
+// zg / ag / st may be NULL (a forward that keeps nothing)
+template <int RT>
+__device__ __forceinline__ void train_epilogue(const f32x16 (&acc)[RT][2], const float *__restrict__ bias,
+                                               const float *__restrict__ gamma, const float *__restrict__ beta, float *hb,
+                                               int wave, int lane, int row0, int n, float *zg, float *ag, float *st, int st_off, int st_stride) {
+    constexpr int TM = 32 * RT, PARTS = PT / TM, RUN = 256 / PARTS;
+    // z = acc + bias: to the tile for the row phase and straight to HBM from the accumulators (C layout: the 32 lanes of
+    // a half wave hold 32 consecutive columns of one row = 128 contiguous bytes)
+#pragma unroll
+    for (int i = 0; i < RT; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int c = wave * 64 + j * 32 + (lane & 31);
+            const float b = bias[c];
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const float z = acc[i][j][r] + b;
+                hb[HIDX(row, c)] = z;
+                if (zg && row0 + row < n) zg[(size_t) (row0 + row) * 256 + c] = z;
+            }
+        }
+    __syncthreads();
+    const int t = threadIdx.x, row = t / PARTS, part = t % PARTS;
+    f32x4 *hr = reinterpret_cast<f32x4 *>(hb + row * ALD2);
+    f32x4 x[RUN / 4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < RUN / 4; i++) {
+        x[i] = hr[CHUNK(i, part, PARTS)];
+#pragma unroll
+        for (int u = 0; u < 4; u++) x[i][u] = mish_f(x[i][u]);
+        s += (x[i][0] + x[i][1]) + (x[i][2] + x[i][3]);
+    }
+#pragma unroll
+    for (int m = 1; m < PARTS; m <<= 1) s += __shfl_xor(s, m);
+    const float mean = s / 256.f;
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < RUN / 4; i++)
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const float d = x[i][u] - mean; v += d * d; }
+#pragma unroll
+    for (int m = 1; m < PARTS; m <<= 1) v += __shfl_xor(v, m);
+    const float rstd = 1.0f / sqrtf(v / 256.f + 1e-5f);
+    if (st && part == 0 && row0 + row < n) {
+        st[(size_t) (row0 + row) * st_stride + st_off] = mean;
+        st[(size_t) (row0 + row) * st_stride + st_off + 1] = rstd;
+    }
+#pragma unroll
+    for (int i = 0; i < RUN / 4; i++) {
+        f32x4 y;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int c = QCOL(4 * CHUNK(i, part, PARTS) + u);
+            y[u] = (x[i][u] - mean) * rstd * gamma[c] + beta[c];
+        }
+        hr[CHUNK(i, part, PARTS)] = y;
+    }
+    __syncthreads();
+    if (ag) tile_store<TM>(hb, ag, row0, n);
+}
+
+
+__device__ __forceinline__ double block_sum_double(double v, double *sh) {
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    double s = 0.0;
+    for (int i = 0; i < nw; i++) s += sh[i];
+    return s;
+}
+
+// one float per thread -> one double atomicAdd per workgroup
+__device__ __forceinline__ void block_accumulate(float v, double *dst, float *sh) {
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < nw; i++) s += (double) sh[i];
+        if (s != 0.0) atomicAdd(dst, s);
+    }
+}
+
+
+// thread (row, part): gradient w.r.t. the layer's pre-activation z from the gradient w.r.t. its LayerNorm output.
+//   g[i]: in d loss / d a (LayerNorm output) of the thread's run, out d loss / d z; Tz: the z tile, left holding
+//   da * xhat (the terms of dgamma).
+template <int RUN, int PARTS>
+__device__ __forceinline__ void ln_mish_backward(float (&g)[RUN], float *Tz, int row, int part, float mean, float rstd,
+                                                 const float *__restrict__ gamma) {
+    float xh[RUN], mp[RUN];
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < RUN; i++) {
+        const int q = 4 * CHUNK(i >> 2, part, PARTS) + (i & 3);
+        const int c = QCOL(q);
+        const float z = Tz[row * ALD2 + q];
+        const float nn = __expf(fminf(z, 20.f));
+        const float mm = nn * (nn + 2.f);
+        const float tt = __fdividef(mm, mm + 2.f);  // tanh(softplus(z))
+        mp[i] = tt + z * (1.f - tt * tt) * __fdividef(nn, 1.f + nn);  // Mish'(z) = tanh(sp) + z sigmoid(z) (1 - tanh(sp)^2)
+        xh[i] = (z * tt - mean) * rstd;
+        Tz[row * ALD2 + q] = g[i] * xh[i];
+        const float gy = g[i] * gamma[c];
+        c1 += gy;
+        c2 += gy * xh[i];
+        g[i] = gy;
+    }
+#pragma unroll
+    for (int m = 1; m < PARTS; m <<= 1) { c1 += __shfl_xor(c1, m); c2 += __shfl_xor(c2, m); }
+    c1 *= (1.f / 256.f);
+    c2 *= (1.f / 256.f);
+#pragma unroll
+    for (int i = 0; i < RUN; i++) g[i] = rstd * (g[i] - c1 - xh[i] * c2) * mp[i];
+}
+
+
+}  // namespace evm

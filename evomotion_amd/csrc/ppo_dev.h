@@ -52,5 +52,12 @@ hipError_t launch_ppo_gae_scan(const PpoDev &d, int T, int N, const float *rewar
 hipError_t launch_ppo_gae_finish(int T, int N, const double *stats, const float *curr_values, const uint8_t *mask, float *adv,
                                  float *returns, hipStream_t s);
 size_t ppo_wpart_floats();
+// generic pieces reused by the Q-network trainer (q_kernels.hip)
+//   C[i][j] = sum_m P[m][i] Q[m][j] (split-K MFMA, partials in `part`) -> dst[i * dst_ld + j (+ extra for i >= split_row)]
+void wgrad_one(const float *P, int ldp, int np, bool pa, const float *Q, int ldq, int nq, bool qa, int M, float *part, int I, int J,
+               float *dst, int dst_ld, int split_row, int extra, hipStream_t s);
+void wgrad_heads(const float *dh, const float *a_last, float *wpart, int M, int I, float *dst, int split_row, int extra, hipStream_t s);
+int launch_colreduce(const float *colpart, int tiles, int W, float *colpart2, hipStream_t s);  // returns the number of groups
+hipError_t launch_pad_rows(const float *src, int S, size_t rows, float *dst, hipStream_t s);   // [rows][S] -> [rows][384]
 
 }  // namespace evm

@@ -1,0 +1,323 @@
+// Twin Q networks of SAC on fp32 MFMA (gfx950): forward of critics and target critics, the critics' mse update
+// (backward, weight gradients, Adam) and the soft target update.  Replaces the PyTorch-ROCm pass over
+//   QNetworkModule                           evo_motion_networks/src/networks/q_net.cpp:8-43
+//   SoftActorCriticAgent::train (critics)    evo_motion_networks/src/agents/soft_actor_critic.cpp:100-127
+//   soft_update                              evo_motion_networks/src/functions.cpp:161-171
+// The tiles, epilogues and weight-gradient GEMMs are those of the PPO update (mlp_train.h, ppo_kernels.hip).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mlp_tile.h"
+#include "mlp_train.h"
+#include "ppo_dev.h"
+#include "q_dev.h"
+
+namespace evm {
+
+// ---------------------------------------------------------------------------------------------------------
+// operand layouts
+// ---------------------------------------------------------------------------------------------------------
+// flat parameters -> wt[l] (forward: B[k = in][col = out] = W[out][in]) and wd[l] (dgrad: B[k = out][col = in] = W[out][in])
+__global__ __launch_bounds__(256) void k_q_pack(QNet n, int SA) {
+    const size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
+    const size_t n_w0 = (size_t) 256 * SA;
+    auto put = [](float *dst, int k, int col, float v) {
+        const int st = k >> 1, h = k & 1, s4 = st >> 2, tt = st & 3;
+        dst[(((size_t) s4 * 256 + col) * 2 + h) * 4 + tt] = v;
+    };
+    if (i < n_w0) {
+        const int out = (int) (i / SA), in = (int) (i % SA);
+        put(n.wt[0], in, out, n.theta[n.o_w[0] + i]);
+        return;
+    }
+    size_t j = i - n_w0;
+    for (int l = 1; l < Q_LAYERS; l++) {
+        if (j < 65536) {
+            const int out = (int) (j >> 8), in = (int) (j & 255);
+            const float v = n.theta[n.o_w[l] + j];
+            put(n.wt[l], in, out, v);
+            if (n.wd[l]) put(n.wd[l], out, in, v);
+            return;
+        }
+        j -= 65536;
+    }
+}
+
+// [state, action] rows, zero padded to K1 columns
+__global__ __launch_bounds__(256) void k_q_concat(const float *__restrict__ states, const float *__restrict__ actions, int S, int A,
+                                                  size_t rows, float *__restrict__ dst) {
+    const size_t e = (size_t) blockIdx.x * 256 + threadIdx.x;
+    if (e >= rows * K1) return;
+    const size_t r = e / K1;
+    const int c = (int) (e - r * K1);
+    dst[e] = c < S ? states[r * S + c] : (c < S + A ? actions[r * A + (c - S)] : 0.f);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// forward: three Linear -> Mish -> LayerNorm blocks and Linear(256, 1)
+// ---------------------------------------------------------------------------------------------------------
+struct QSel { int idx[4]; int count; };
+template <int RT>
+__global__ __launch_bounds__(PT) void k_q_forward(QDev d, QSel sel, int n, int keep) {
+    constexpr int TM = 32 * RT, PARTS = PT / TM, RUN = 256 / PARTS;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *xs = sm, *hb = sm;
+    const QNet &N = d.net[sel.idx[blockIdx.y]];
+    const int row0 = blockIdx.x * TM;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool kp = keep != 0 && N.z[0] != nullptr;
+    stage_padded_ksplit<TM>(xs, d.xq, row0, n);
+    __syncthreads();
+    f32x16 acc[RT][2];
+    dense_layer<K1, RT>(xs, ALD1, N.wt[0], wave, lane, acc);
+    __syncthreads();
+    train_epilogue<RT>(acc, N.theta + N.o_b[0], N.theta + N.o_g[0], N.theta + N.o_be[0], hb, wave, lane, row0, n, kp ? N.z[0] : nullptr,
+                       kp ? N.a[0] : nullptr, kp ? N.st : nullptr, 0, 2 * Q_LAYERS);
+#pragma unroll
+    for (int l = 1; l < Q_LAYERS; l++) {
+        dense_layer<256, RT>(hb, ALD2, N.wt[l], wave, lane, acc);
+        __syncthreads();
+        train_epilogue<RT>(acc, N.theta + N.o_b[l], N.theta + N.o_g[l], N.theta + N.o_be[l], hb, wave, lane, row0, n,
+                           kp ? N.z[l] : nullptr, kp ? N.a[l] : nullptr, kp ? N.st : nullptr, 2 * l, 2 * Q_LAYERS);
+    }
+    // head: one output; thread (row, part) takes its chunks against the weight row (read from the flat parameters: the
+    // stored position q of the k-split row is column QCOL(q))
+    const int t = threadIdx.x, row = t / PARTS, part = t % PARTS;
+    const f32x4 *hr = reinterpret_cast<const f32x4 *>(hb + row * ALD2);
+    const float *wh = N.theta + N.o_wh;
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < RUN / 4; i++) {
+        const f32x4 x = hr[CHUNK(i, part, PARTS)];
+#pragma unroll
+        for (int u = 0; u < 4; u++) sum += x[u] * wh[QCOL(4 * CHUNK(i, part, PARTS) + u)];
+    }
+#pragma unroll
+    for (int m = 1; m < PARTS; m <<= 1) sum += __shfl_xor(sum, m);
+    if (part == 0 && row0 + row < n) N.q[row0 + row] = sum + N.theta[N.o_bh];
+}
+
+// mse_loss(q, target) = mean((q - target)^2) (soft_actor_critic.cpp:118-127): gradient 2 (q - target) / rows at the head
+__global__ __launch_bounds__(256) void k_q_loss(QDev d, int n, const float *__restrict__ target, float inv_rows) {
+    __shared__ float sh[4];
+    const size_t row = (size_t) blockIdx.x * 256 + threadIdx.x;
+    const QNet &N = d.net[blockIdx.y];
+    float lsum = 0.f;
+    if (row < (size_t) n) {
+        const float diff = N.q[row] - target[row];
+        lsum = diff * diff * inv_rows;
+        N.dh[row * 32] = 2.f * diff * inv_rows;
+    }
+    block_accumulate(lsum, d.loss + blockIdx.y, sh);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// backward of one 32-row tile through the head and the three blocks
+// ---------------------------------------------------------------------------------------------------------
+template <int RT>
+__global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_q_backward(QDev d, int n) {
+    constexpr int TM = 32 * RT, PARTS = PT / TM, RUN = 256 / PARTS;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *Tz = sm;
+    float *Td = sm + TM * ALD2;
+    const QNet &N = d.net[blockIdx.y];
+    const int row0 = blockIdx.x * TM;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int t = threadIdx.x, row = t / PARTS, part = t % PARTS;
+    const int gr = row0 + row;
+    float colacc[Q_COLSLOTS];
+#pragma unroll
+    for (int k = 0; k < Q_COLSLOTS; k++) colacc[k] = 0.f;
+    tile_load<TM>(Tz, N.z[Q_LAYERS - 1], row0, n);
+    // d a3 = dh * w_head (one output)
+    const float g = gr < n ? N.dh[(size_t) gr * 32] : 0.f;
+    float da[RUN];
+    {
+        const float *wh = N.theta + N.o_wh;
+#pragma unroll
+        for (int i = 0; i < RUN; i++) da[i] = g * wh[QCOL(4 * CHUNK(i >> 2, part, PARTS) + (i & 3))];
+    }
+    {   // head bias gradient: sum of dh over the tile's rows, by thread 0's wave (rows of the tile = 32: one per lane pair)
+        float s = (part == 0) ? g : 0.f;
+        for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+        __shared__ float hsum[4];
+        if (lane == 0) hsum[wave] = s;
+        __syncthreads();
+        if (t == 0) colacc[3 * Q_LAYERS] = (hsum[0] + hsum[1]) + (hsum[2] + hsum[3]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int l = Q_LAYERS - 1; l >= 0; l--) {
+        const int s0 = 3 * (Q_LAYERS - 1 - l);
+        const float mean = gr < n ? N.st[(size_t) gr * 2 * Q_LAYERS + 2 * l] : 0.f;
+        const float rstd = gr < n ? N.st[(size_t) gr * 2 * Q_LAYERS + 2 * l + 1] : 0.f;
+        // Tz holds z_l, da the gradient w.r.t. the LayerNorm output a_l (for l < last it is already in Td: the dgrad's result)
+        if (l == Q_LAYERS - 1) {
+#pragma unroll
+            for (int i = 0; i < RUN; i++) Td[row * ALD2 + 4 * CHUNK(i >> 2, part, PARTS) + (i & 3)] = da[i];
+        }
+        ln_mish_backward<RUN, PARTS>(da, Tz, row, part, mean, rstd, N.theta + N.o_g[l]);  // da <- dz_l, Tz <- da * xhat
+        __syncthreads();
+        colacc[s0] = tile_colsum<TM>(Tz);      // dgamma_l
+        colacc[s0 + 1] = tile_colsum<TM>(Td);  // dbeta_l
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < RUN; i++) Td[row * ALD2 + 4 * CHUNK(i >> 2, part, PARTS) + (i & 3)] = da[i];
+        if (l > 0) tile_load<TM>(Tz, N.z[l - 1], row0, n);
+        __syncthreads();
+        colacc[s0 + 2] = tile_colsum<TM>(Td);  // dbias_l
+        tile_store<TM>(Td, N.dz[l], row0, n);
+        if (l > 0) {
+            f32x16 acc[RT][2];
+            dense_layer<256, RT>(Td, ALD2, N.wd[l], wave, lane, acc);  // d a_{l-1} = dz_l * W_l
+            __syncthreads();
+            acc_to_tile<RT>(acc, nullptr, Td, wave, lane);
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < RUN; i++) da[i] = Td[row * ALD2 + 4 * CHUNK(i >> 2, part, PARTS) + (i & 3)];
+        }
+    }
+    float *cp = N.colpart + (size_t) blockIdx.x * Q_COLSLOTS * 256;
+#pragma unroll
+    for (int k = 0; k < Q_COLSLOTS - 1; k++) cp[k * 256 + QCOL(t)] = colacc[k];
+    cp[(Q_COLSLOTS - 1) * 256 + t] = colacc[Q_COLSLOTS - 1];  // only position 0 is used
+}
+
+struct QColSlots { int off[Q_COLSLOTS]; };
+__global__ __launch_bounds__(256) void k_q_colfinish(const float *__restrict__ src, int groups, QColSlots cs, float *__restrict__ grad) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= Q_COLSLOTS * 256) return;
+    const int slot = e >> 8, c = e & 255;
+    float s = 0.f;
+    for (int k = 0; k < groups; k++) s += src[(size_t) k * Q_COLSLOTS * 256 + e];
+    if (slot < Q_COLSLOTS - 1) grad[cs.off[slot] + c] = s;
+    else if (c == 0) grad[cs.off[slot]] = s;
+}
+
+// torch::optim::Adam (defaults), step count on the device; grid.y = critic
+__global__ __launch_bounds__(256) void k_q_adam(QDev d, float lr) {
+    const QNet &N = d.net[blockIdx.y];
+    const size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
+    if (i >= N.n_params) return;
+    const int step = N.step[0] + 1;
+    const float bc1 = (float) (1.0 - pow(0.9, (double) step));
+    const float bc2s = (float) sqrt(1.0 - pow(0.999, (double) step));
+    const float g = N.grad[i];
+    const float m = N.m[i] + (g - N.m[i]) * 0.1f;
+    const float v = N.v[i] * 0.999f + (g * g) * 0.001f;
+    N.m[i] = m;
+    N.v[i] = v;
+    N.theta[i] -= (lr / bc1) * (m / (sqrtf(v) / bc2s + 1e-8f));
+}
+__global__ void k_q_step_inc(QDev d) {
+    if (threadIdx.x < 2) d.net[threadIdx.x].step[0] += 1;
+}
+
+// to <- tau * from + (1 - tau) * to, each product rounded to fp32 like the reference's tensor expression (functions.cpp:169)
+#pragma clang fp contract(off)
+__global__ __launch_bounds__(256) void k_q_soft(QDev d, float tau, float one_minus_tau) {
+    const QNet &T = d.net[2 + blockIdx.y], &F = d.net[blockIdx.y];
+    const size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
+    if (i >= T.n_params) return;
+    const float a = tau * F.theta[i];
+    const float b = one_minus_tau * T.theta[i];
+    T.theta[i] = a + b;
+}
+#pragma clang fp contract(fast)
+
+// ---------------------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------------------
+static size_t q_fwd_lds() {
+    constexpr int TM = 32 * PRT;
+    const size_t a = (size_t) TM * ALD1, b = (size_t) TM * ALD2;
+    return (a > b ? a : b) * sizeof(float);
+}
+static size_t q_bwd_lds() {
+    constexpr int TM = 32 * PRT;
+    return (size_t) 2 * TM * ALD2 * sizeof(float);
+}
+size_t q_wpart_floats() { return ppo_wpart_floats(); }
+
+static hipError_t q_attrs() {
+    static bool done = false;
+    if (done) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_q_forward<PRT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) q_fwd_lds());
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_q_backward<PRT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) q_bwd_lds());
+    done = e == hipSuccess;
+    return e;
+}
+
+hipError_t launch_q_pack(const QDev &d, int which, hipStream_t s) {
+    const QNet &N = d.net[which];
+    const size_t total = (size_t) 256 * (d.S + d.A) + (size_t) (Q_LAYERS - 1) * 65536;
+    hipLaunchKernelGGL(k_q_pack, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, s, N, d.S + d.A);
+    return hipGetLastError();
+}
+hipError_t launch_q_concat(const QDev &d, size_t rows, const float *states, const float *actions, hipStream_t s) {
+    hipLaunchKernelGGL(k_q_concat, dim3((unsigned) ((rows * K1 + 255) / 256)), dim3(256), 0, s, states, actions, d.S, d.A, rows, d.xq);
+    return hipGetLastError();
+}
+hipError_t launch_q_forward(const QDev &d, unsigned nets, size_t rows, int keep, hipStream_t s) {
+    hipError_t e = q_attrs();
+    if (e != hipSuccess) return e;
+    QSel sel;
+    sel.count = 0;
+    for (int i = 0; i < 4; i++) if (nets & (1u << i)) sel.idx[sel.count++] = i;
+    if (!sel.count) return hipSuccess;
+    constexpr int TM = 32 * PRT;
+    hipLaunchKernelGGL(k_q_forward<PRT>, dim3((unsigned) ((rows + TM - 1) / TM), sel.count), dim3(PT), q_fwd_lds(), s, d, sel, (int) rows, keep);
+    return hipGetLastError();
+}
+hipError_t launch_q_loss(const QDev &d, size_t rows, const float *target_q, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(d.loss, 0, 2 * sizeof(double), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_q_loss, dim3((unsigned) ((rows + 255) / 256), 2), dim3(256), 0, s, d, (int) rows, target_q, (float) (1.0 / (double) rows));
+    return hipGetLastError();
+}
+hipError_t launch_q_backward(const QDev &d, size_t rows, hipStream_t s) {
+    hipError_t e = q_attrs();
+    if (e != hipSuccess) return e;
+    constexpr int TM = 32 * PRT;
+    hipLaunchKernelGGL(k_q_backward<PRT>, dim3((unsigned) ((rows + TM - 1) / TM), 2), dim3(PT), q_bwd_lds(), s, d, (int) rows);
+    return hipGetLastError();
+}
+hipError_t launch_q_wgrads(const QDev &d, size_t rows, hipStream_t s) {
+    constexpr int TM = 32 * PRT;
+    const int M = (int) rows, SA = d.S + d.A;
+    const int tiles = (int) ((rows + TM - 1) / TM);
+    for (int c = 0; c < 2; c++) {
+        const QNet &N = d.net[c];
+        // layer 0: dz0^T [state, action]; layers 1, 2: dz_l^T a_{l-1}; head: dh^T a_2
+        wgrad_one(N.dz[0], 256, 256, true, d.xq, K1, K1, true, M, N.wpart, 256, SA, N.grad + N.o_w[0], SA, 1 << 30, 0, s);
+        for (int l = 1; l < Q_LAYERS; l++)
+            wgrad_one(N.dz[l], 256, 256, true, N.a[l - 1], 256, 256, true, M, N.wpart, 256, 256, N.grad + N.o_w[l], 256, 1 << 30, 0, s);
+        wgrad_heads(N.dh, N.a[Q_LAYERS - 1], N.wpart, M, 1, N.grad + N.o_wh, 1 << 30, 0, s);
+        QColSlots cs;
+        for (int l = Q_LAYERS - 1; l >= 0; l--) {
+            const int s0 = 3 * (Q_LAYERS - 1 - l);
+            cs.off[s0] = (int) N.o_g[l]; cs.off[s0 + 1] = (int) N.o_be[l]; cs.off[s0 + 2] = (int) N.o_b[l];
+        }
+        cs.off[3 * Q_LAYERS] = (int) N.o_bh;
+        const int W = Q_COLSLOTS * 256;
+        const int groups = launch_colreduce(N.colpart, tiles, W, N.colpart2, s);
+        hipLaunchKernelGGL(k_q_colfinish, dim3((W + 255) / 256), dim3(256), 0, s, N.colpart2, groups, cs, N.grad);
+    }
+    return hipGetLastError();
+}
+hipError_t launch_q_adam(const QDev &d, float lr, hipStream_t s) {
+    hipLaunchKernelGGL(k_q_adam, dim3((unsigned) ((d.net[0].n_params + 255) / 256), 2), dim3(256), 0, s, d, lr);
+    hipLaunchKernelGGL(k_q_step_inc, dim3(1), dim3(64), 0, s, d);
+    hipError_t e = launch_q_pack(d, 0, s);
+    if (e == hipSuccess) e = launch_q_pack(d, 1, s);
+    return e;
+}
+hipError_t launch_q_soft_update(const QDev &d, float tau, hipStream_t s) {
+    const float omt = (float) (1.0 - (double) tau);
+    hipLaunchKernelGGL(k_q_soft, dim3((unsigned) ((d.net[0].n_params + 255) / 256), 2), dim3(256), 0, s, d, tau, omt);
+    hipError_t e = launch_q_pack(d, 2, s);
+    if (e == hipSuccess) e = launch_q_pack(d, 3, s);
+    return e;
+}
+
+}  // namespace evm

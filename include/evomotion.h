@@ -246,6 +246,33 @@ int evm_ppo_losses(EvmPpo *q, double *h_actor_loss, double *h_critic_loss, void 
  * switches the measurement on or off */
 int evm_ppo_timing(EvmPpo *q, int enable, float *ms_total, int *n_epochs);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * Twin Q networks of SAC: critic_1 / critic_2 and their target networks of SoftActorCriticAgent
+ * (evo_motion_networks/src/agents/soft_actor_critic.cpp:20-45) as fp32 MFMA kernels — QNetworkModule forward
+ * (networks/q_net.cpp:8-43), the critics' mse update (:100-127: backward, weight gradients, Adam) and soft_update
+ * (functions.cpp:161-171).  Networks are numbered 0 critic_1, 1 critic_2, 2 target_critic_1, 3 target_critic_2;
+ * parameters are flat fp32 vectors in named_parameters() order (q_network.0.weight [256][S+A] ... q_network.9.bias).
+ * ------------------------------------------------------------------------------------------------------- */
+typedef struct EvmQ EvmQ;
+int evm_q_create(int state_dim, int action_dim, int hidden_size, size_t max_rows, int device, EvmQ **out);
+void evm_q_destroy(EvmQ *q);
+int evm_q_param_count(const EvmQ *q, size_t *n); /* 231 681 for robot_walk */
+/* what: 0 parameters (any network), 1 gradients, 2 Adam exp_avg, 3 Adam exp_avg_sq (critics only).  to_trainer == 0
+ * copies the trainer's vector to d_buf, 1 copies d_buf in (parameters are repacked for the kernels). */
+int evm_q_copy(EvmQ *q, int what, int net, int to_trainer, float *d_buf, void *stream);
+/* Adam step count of critic `net` (kept on the device): set when set_step >= 0, else read (synchronises) */
+int evm_q_adam_step(EvmQ *q, int net, int set_step, int *step);
+/* Q(states, actions) of the networks selected by the bit mask `nets` into d_out[net] ([rows] f32 each) */
+int evm_q_forward(EvmQ *q, unsigned nets, size_t rows, const float *d_states, const float *d_actions, float *const *d_out, void *stream);
+/* gradients of mse_loss(critic_i(states, actions), target_q), i = 1, 2, into the trainer (evm_q_copy what = 1) */
+int evm_q_grads(EvmQ *q, size_t rows, const float *d_states, const float *d_actions, const float *d_target_q, void *stream);
+/* one Adam step (torch defaults, no clipping) of both critics */
+int evm_q_apply(EvmQ *q, float learning_rate, void *stream);
+/* target_i <- tau * critic_i + (1 - tau) * target_i */
+int evm_q_soft_update(EvmQ *q, float tau, void *stream);
+/* DEVICE double[2]: the critics' losses of the last evm_q_grads */
+int evm_q_losses(EvmQ *q, double *d_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

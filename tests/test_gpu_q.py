@@ -1,0 +1,132 @@
+"""Twin Q networks on the device (evm_q_*) against the torch mirror of QNetworkModule (itself pinned to the reference's
+golden vectors in tests/test_sac_host.py) and against those golden vectors directly."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import agent_oracle as ao  # noqa: E402
+import golden_io  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _nets(seed=0):
+    import torch
+    from evomotion_amd import sac
+    torch.manual_seed(seed)
+    nets = [sac.QNetworkModule([371], [12], 256).cuda() for _ in range(4)]
+    with torch.no_grad():
+        for m in nets:
+            for mod in m.modules():
+                if isinstance(mod, torch.nn.LayerNorm):
+                    mod.weight.add_(0.3 * torch.randn_like(mod.weight))
+                    mod.bias.add_(0.2 * torch.randn_like(mod.bias))
+    return nets
+
+
+def _trainer(nets, rows):
+    from evomotion_amd.qnet import FusedTwinQ
+    tq = FusedTwinQ(371, 12, 256, rows, 0)
+    for i, m in enumerate(nets):
+        tq.load_module(i, m)
+    return tq
+
+
+def _batch(rows, seed=1):
+    import torch
+    g = torch.Generator(device="cuda"); g.manual_seed(seed)
+    states = (torch.rand(rows, 371, device="cuda", generator=g) * 2 - 1) * 1.5
+    actions = torch.rand(rows, 12, device="cuda", generator=g) * 2 - 1
+    target = torch.randn(rows, device="cuda", generator=g)
+    return states, actions, target
+
+
+def test_q_forward_matches_reference_golden():
+    import torch
+    from evomotion_amd.qnet import FusedTwinQ
+    gold = golden_io.load(os.path.join(ROOT, "tests", "golden", "sac_golden.txt"))
+    tq = FusedTwinQ(371, 12, 256, 64, 0)
+    p = ao.pattern_params(ao.Q_SHAPES, 300)
+    flat = torch.from_numpy(np.concatenate([p[n].ravel() for n, _ in ao.Q_SHAPES]))
+    tq.load_vector(0, 0, flat)
+    s, a = torch.from_numpy(gold["sac_states"]).cuda(), torch.from_numpy(gold["sac_actions"]).cuda()
+    q = tq.forward([0], s, a)[0]
+    np.testing.assert_allclose(q.cpu().numpy(), gold["q1_before"].ravel(), atol=5e-5)
+
+
+@pytest.mark.parametrize("rows", [1000, 4096])
+def test_q_forward_all_networks(rows):
+    import torch
+    nets = _nets()
+    tq = _trainer(nets, rows)
+    states, actions, _ = _batch(rows)
+    got = tq.forward([0, 1, 2, 3], states, actions)
+    with torch.no_grad():
+        for i, m in enumerate(nets):
+            ref = m(states, actions).squeeze(-1)
+            np.testing.assert_allclose(got[i].cpu().numpy(), ref.cpu().numpy(), atol=5e-5)
+
+
+@pytest.mark.parametrize("rows", [1000, 4096])
+def test_q_update_in_lock_step_with_autograd_and_adam(rows):
+    """three critic updates: gradients against autograd at identical weights, the Adam step against torch.optim.Adam"""
+    import torch
+    from evomotion_amd.qnet import GRADS, PARAMS
+    nets = _nets(seed=3)
+    tq = _trainer(nets, rows)
+    opts = [torch.optim.Adam(nets[i].parameters(), lr=1e-3) for i in range(2)]
+    for it in range(3):
+        states, actions, target = _batch(rows, seed=10 + it)
+        tq.grads(states, actions, target)
+        losses = tq.losses().cpu().numpy()
+        for i in range(2):
+            m = nets[i]
+            opts[i].zero_grad()
+            loss = torch.nn.functional.mse_loss(m(states, actions), target.unsqueeze(-1))
+            loss.backward()
+            ref = torch.cat([p.grad.reshape(-1) for p in m.parameters()])
+            got = tq.vector(GRADS, i)
+            assert abs(losses[i] - float(loss)) < 2e-5 * max(1.0, abs(float(loss)))
+            o = 0
+            for name, p in m.named_parameters():
+                n = p.numel()
+                a, b = got[o:o + n], ref[o:o + n]
+                assert float((a - b).abs().max()) <= 2e-4 * float(b.abs().max()) + 1e-8, (it, i, name)
+                o += n
+            assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), (it, i)
+        tq.apply(1e-3)
+        for i in range(2):
+            opts[i].step()
+            d = (tq.vector(PARAMS, i) - torch.cat([p.detach().reshape(-1) for p in nets[i].parameters()])).abs()
+            assert float(d.max()) <= 1.1e-3 and float((d > 2e-5).float().mean()) < 2e-4, (it, i, float(d.max()))
+            # continue from identical weights (the step is ill-conditioned only where |g| ~ 1e-8)
+            flat = tq.vector(PARAMS, i)
+            o = 0
+            with torch.no_grad():
+                for p in nets[i].parameters():
+                    p.copy_(flat[o:o + p.numel()].view_as(p))
+                    o += p.numel()
+        assert tq.adam_step(0) == tq.adam_step(1) == it + 1
+
+
+def test_q_soft_update():
+    import torch
+    from evomotion_amd import sac
+    from evomotion_amd.qnet import PARAMS
+    nets = _nets(seed=5)
+    tq = _trainer(nets, 64)
+    tq.soft_update(0.005)
+    for i in range(2):
+        sac.soft_update(nets[2 + i], nets[i], 0.005)
+        ref = torch.cat([p.detach().reshape(-1) for p in nets[2 + i].parameters()])
+        np.testing.assert_allclose(tq.vector(PARAMS, 2 + i).cpu().numpy(), ref.cpu().numpy(), atol=1e-7, rtol=1e-6)
+    # the repacked targets are what the forward uses
+    states, actions, _ = _batch(64)
+    got = tq.forward([2, 3], states, actions)
+    with torch.no_grad():
+        for i in (2, 3):
+            np.testing.assert_allclose(got[i].cpu().numpy(), nets[i](states, actions).squeeze(-1).cpu().numpy(), atol=5e-5)
