@@ -68,6 +68,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                     "the N>1 path with several ranks on ONE GPU)")
     ap.add_argument("--no-update", action="store_true", help="ppo mode: rollout only")
+    ap.add_argument("--sac-update", choices=["hip", "torch"], default="hip",
+                    help="sac mode: twin-Q side of the update in the HIP trainer (csrc/q_kernels.hip) or everything through autograd")
     ap.add_argument("--ppo-update", choices=["hip", "torch"], default="hip",
                     help="ppo mode: the update in the HIP trainer (csrc/ppo_kernels.hip) or through PyTorch-ROCm autograd")
     args = ap.parse_args()
@@ -116,7 +118,8 @@ def main():
     if args.mode == "sac":
         from evomotion_amd import VecSacAgent
         sac = VecSacAgent(1234, [env.state_dim], [env.action_dim], batch_size=args.sac_batch, epoch=1, learning_rate=1e-3,
-                          replay_buffer_size=args.replay_slots, train_every=args.train_every, n_envs=n, device=local_rank)
+                          replay_buffer_size=args.replay_slots, train_every=args.train_every, n_envs=n, device=local_rank,
+                          update=args.sac_update)
 
     def run(k_steps, offset=0):
         if sac is not None:
@@ -189,7 +192,9 @@ def main():
             "config": {
                 "workload": ("robot_walk, %d envs/GPU on %d MI355X, SAC: fused MFMA actor forward, device replay ring of %d "
                              "slots, %s (configs[4])" % (n, world, args.replay_slots, "rollout + ring only" if args.no_update else
-                              "PyTorch-ROCm SAC update (batch %d) every %d steps" % (args.sac_batch, args.train_every))) if sac is not None else
+                              ("SAC update (batch %d) every %d steps: twin Q networks, targets and soft update in HIP (fp32 MFMA), actor / entropy steps "
+                               "on PyTorch-ROCm, one HIP graph" if args.sac_update == "hip" else "PyTorch-ROCm SAC update (batch %d) every %d steps, one HIP graph")
+                              % (args.sac_batch, args.train_every))) if sac is not None else
                             ("robot_walk, %d envs/GPU on %d MI355X, HIP dynamics only, uniform random actions, "
                              "rollout form with in-band reset (configs[1])" % (n, world)) if agent is None else
                             ("robot_walk, %d envs/GPU on %d MI355X, PPO hidden_size=256, fused MFMA actor-critic forward "

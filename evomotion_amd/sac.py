@@ -108,7 +108,13 @@ class VecSacAgent:
 
     def __init__(self, seed, state_space, action_space, actor_hidden_size=256, critic_hidden_size=256, batch_size=256,
                  epoch=1, learning_rate=1e-3, gamma=0.99, tau=0.005, replay_buffer_size=1024, train_every=4, n_envs=4096,
-                 device=0, use_graph=True):
+                 device=0, use_graph=True, update="hip"):
+        """update = "hip": the twin critics, their targets, the critics' mse update and the soft update run in the HIP Q
+        trainer (qnet.py, csrc/q_kernels.hip), the target actions come from the fused policy kernel; the actor and entropy
+        steps stay on PyTorch-ROCm autograd (through torch views of the trainer's critic weights).  "torch": everything
+        through autograd (sac_train), kept for comparison."""
+        if update not in ("hip", "torch"):
+            raise ValueError("update must be 'hip' or 'torch'")
         from .agent import FusedActorCritic, _all_reduce_grads_mean
         from .replay import ReplayRing
         torch.manual_seed(seed)
@@ -140,6 +146,92 @@ class VecSacAgent:
         B, S, A = batch_size, state_space[0], action_space[0]
         z = lambda *sh: torch.zeros(*sh, device=self.device)
         self._batch = (z(B, S), z(B, A), z(B), z(B), z(B, S))
+        self.update_mode = update
+        self.learning_rate = learning_rate
+        self.twinq = None
+        if update == "hip":
+            from .qnet import FusedTwinQ
+            self.twinq = FusedTwinQ(S, A, critic_hidden_size, B, device)
+            self._push_critics()
+            self._tq_out = {2: z(B), 3: z(B)}
+            self._next_act = (z(B, A), z(B, A), None)
+
+    def _push_critics(self):
+        """modules -> the HIP trainer; the critics' torch parameters become views of flat buffers the trainer's weights are
+        copied into after each update (the actor step differentiates through them w.r.t. the action only)"""
+        mods = (self.critic_1, self.critic_2, self.target_critic_1, self.target_critic_2)
+        for i, m in enumerate(mods):
+            self.twinq.load_module(i, m)
+        self._critic_flat = []
+        for m in mods[:2]:
+            flat = torch.cat([p.detach().reshape(-1) for p in m.parameters()]).contiguous()
+            o = 0
+            for p in m.parameters():
+                p.data = flat[o:o + p.numel()].view_as(p)
+                p.requires_grad_(False)
+                o += p.numel()
+            self._critic_flat.append(flat)
+
+    def sync_modules(self):
+        """the trainer's critic / target weights -> the torch modules (save(), evaluation)"""
+        if self.twinq is None:
+            return
+        from .qnet import PARAMS
+        for i, m in enumerate((self.critic_1, self.critic_2, self.target_critic_1, self.target_critic_2)):
+            flat = self.twinq.vector(PARAMS, i)
+            o = 0
+            with torch.no_grad():
+                for p in m.parameters():
+                    p.copy_(flat[o:o + p.numel()].view_as(p))
+                    o += p.numel()
+
+    def _train_once_hip(self):
+        """SoftActorCriticAgent::train (soft_actor_critic.cpp:93-170) with the Q side on the device"""
+        from .agent import truncated_normal_log_pdf, truncated_normal_sample
+        from .qnet import GRADS, PARAMS
+        s, a, r, d, n = self._batch
+        B = s.shape[0]
+        # targets (:100-116): next action ~ actor(next state) from the fused policy kernel, twin target Q, entropy term
+        u_next = torch.rand(B, self.fused.A, device=self.device)
+        next_action, next_logp, _ = self.fused.forward(n, uniform=u_next, actor_only=True, out=self._next_act)
+        tq = self.twinq.forward((2, 3), n, next_action, out=self._tq_out)
+        alpha = self.entropy.alpha().detach()
+        target_q = (r + (1.0 - d) * self.gamma * (torch.min(tq[2], tq[3]) - alpha * next_logp.sum(-1))).contiguous()
+        # critics (:118-127)
+        self.twinq.grads(s, a, target_q)
+        if not self.use_graph and torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            w = torch.distributed.get_world_size()
+            for i in (0, 1):
+                g = self.twinq.vector(GRADS, i)
+                if torch.distributed.get_backend() != "nccl":
+                    h = g.cpu(); torch.distributed.all_reduce(h); g.copy_(h)
+                else:
+                    torch.distributed.all_reduce(g)
+                self.twinq.load_vector(GRADS, i, g / w)
+        self.twinq.apply(self.learning_rate)
+        for i in (0, 1):
+            self.twinq.vector(PARAMS, i, out=self._critic_flat[i])
+        # actor and entropy (:129-164) through autograd; the critics are constants here
+        mu, sigma = self.actor(s)
+        curr_action = truncated_normal_sample(mu, sigma, -1.0, 1.0)
+        curr_logp = truncated_normal_log_pdf(curr_action, mu, sigma, -1.0, 1.0).sum(-1, keepdim=True)
+        q = torch.min(self.critic_1(s, curr_action), self.critic_2(s, curr_action))
+        loss_actor = torch.mean(alpha * curr_logp - q)
+        self.actor_opt.zero_grad()
+        loss_actor.backward()
+        if not self.use_graph:
+            self._grad_hook(list(self.actor.parameters()))
+        self.actor_opt.step()
+        loss_entropy = -torch.mean(self.entropy.log_alpha * (curr_logp.detach() + self.target_entropy))
+        self.entropy_opt.zero_grad()
+        loss_entropy.backward()
+        if not self.use_graph:
+            self._grad_hook(list(self.entropy.parameters()))
+        self.entropy_opt.step()
+        self.twinq.soft_update(self.tau)
+        self.fused.set_actor(self.actor)  # the next target actions come from the updated actor
+        lq = self.twinq.losses()
+        return dict(actor=loss_actor.detach(), critic_1=lq[0], critic_2=lq[1], entropy=loss_entropy.detach())
 
     def count_parameters(self):
         from .agent import count_parameters
@@ -157,6 +249,8 @@ class VecSacAgent:
         return st
 
     def _train_once(self):
+        if self.update_mode == "hip":
+            return self._train_once_hip()
         s, a, r, d, n = self._batch
         return sac_train(self.actor, self.critic_1, self.critic_2, self.target_critic_1, self.target_critic_2, self.entropy,
                          self.actor_opt, self.critic_1_opt, self.critic_2_opt, self.entropy_opt, s, a, r.unsqueeze(-1),
@@ -179,6 +273,7 @@ class VecSacAgent:
                 self._graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self._graph):
                     self.last_losses = self._train_once()
+                self._graph.replay()  # capturing records the launches without running them
                 self.train_steps += 2
             else:
                 self._graph.replay()
@@ -189,6 +284,7 @@ class VecSacAgent:
         """SoftActorCriticAgent::save (soft_actor_critic.cpp:181-201): module archives in the reference's format."""
         import os
         from .checkpoint import save_th
+        self.sync_modules()
         for m, f in ((self.actor, "actor.th"), (self.critic_1, "critic_1.th"), (self.target_critic_1, "target_critic_1.th"),
                      (self.critic_2, "critic_2.th"), (self.target_critic_2, "target_critic_2.th"), (self.entropy, "entropy.th")):
             save_th(m, os.path.join(folder, f))
@@ -200,3 +296,5 @@ class VecSacAgent:
                      (self.critic_2, "critic_2.th"), (self.target_critic_2, "target_critic_2.th"), (self.entropy, "entropy.th")):
             load_into(m, os.path.join(folder, f))
         self.fused.set_actor(self.actor)
+        if self.twinq is not None:
+            self._push_critics()

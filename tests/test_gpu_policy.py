@@ -183,7 +183,8 @@ def test_sac_agent_smoke_and_graph_replay_matches_eager():
     n = 128
     env = VecRobotWalk(n, seed=5)
     env.reset()
-    ag = VecSacAgent(11, [371], [12], batch_size=64, epoch=1, replay_buffer_size=16, train_every=2, n_envs=n, use_graph=True)
+    ag = VecSacAgent(11, [371], [12], batch_size=64, epoch=1, replay_buffer_size=16, train_every=2, n_envs=n, use_graph=True,
+                     update="torch")
     assert ag.count_parameters() == 1094941
     for _ in range(12):
         st = ag.step(env)
@@ -191,7 +192,8 @@ def test_sac_agent_smoke_and_graph_replay_matches_eager():
     assert all(torch.isfinite(p).all() for p in ag.actor.parameters())
     assert torch.isfinite(st.state).all() and float(st.state.abs().max()) > 0
     # graph vs eager on a cloned agent state
-    eager = VecSacAgent(11, [371], [12], batch_size=64, epoch=1, replay_buffer_size=16, train_every=2, n_envs=n, use_graph=False)
+    eager = VecSacAgent(11, [371], [12], batch_size=64, epoch=1, replay_buffer_size=16, train_every=2, n_envs=n, use_graph=False,
+                        update="torch")
     for dst, src in ((eager.actor, ag.actor), (eager.critic_1, ag.critic_1), (eager.critic_2, ag.critic_2),
                      (eager.target_critic_1, ag.target_critic_1), (eager.target_critic_2, ag.target_critic_2), (eager.entropy, ag.entropy)):
         dst.load_state_dict(src.state_dict())
@@ -226,3 +228,66 @@ def test_rollout_and_update_smoke():
         assert np.isfinite(al) and np.isfinite(cl)
     agent.sync_modules()  # the HIP trainer owns the weights; the torch modules are refreshed on demand
     assert not torch.equal(w0, agent.actor.head[0].weight)
+
+
+def _flat(m):
+    import torch
+    return torch.cat([p.detach().reshape(-1) for p in m.parameters()])
+
+
+def test_sac_hip_update_matches_torch_update():
+    """one SoftActorCriticAgent::train call: the HIP Q side (targets, critics, soft update) + autograd actor / entropy steps
+    against the all-autograd sac_train from the same weights, batch and uniform draws"""
+    import torch
+    from evomotion_amd import VecSacAgent
+    from evomotion_amd.qnet import PARAMS
+    kw = dict(batch_size=512, epoch=1, replay_buffer_size=4, train_every=2, n_envs=64, use_graph=False)
+    hip = VecSacAgent(21, [371], [12], update="hip", **kw)
+    ref = VecSacAgent(21, [371], [12], update="torch", **kw)
+    assert all(torch.equal(a, b) for a, b in zip(hip.actor.parameters(), ref.actor.parameters()))
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    s = (torch.rand(512, 371, device="cuda", generator=g) * 2 - 1) * 1.5
+    a = torch.rand(512, 12, device="cuda", generator=g) * 2 - 1
+    r = torch.rand(512, device="cuda", generator=g) * 2 - 1
+    d = (torch.rand(512, device="cuda", generator=g) < 0.1).float()
+    n = (torch.rand(512, 371, device="cuda", generator=g) * 2 - 1) * 1.5
+    for ag in (hip, ref):
+        for dst, src in zip(ag._batch, (s, a, r, d, n)):
+            dst.copy_(src)
+    for it in range(2):
+        torch.manual_seed(100 + it); lh = hip._train_once()
+        torch.manual_seed(100 + it); lr_ = ref._train_once()
+        for k in ("critic_1", "critic_2", "actor", "entropy"):
+            assert abs(float(lh[k]) - float(lr_[k])) < 2e-4 * max(1.0, abs(float(lr_[k]))), (it, k, float(lh[k]), float(lr_[k]))
+    pairs = [(hip.twinq.vector(PARAMS, 0), _flat(ref.critic_1)), (hip.twinq.vector(PARAMS, 1), _flat(ref.critic_2)),
+             (hip.twinq.vector(PARAMS, 2), _flat(ref.target_critic_1)), (hip.twinq.vector(PARAMS, 3), _flat(ref.target_critic_2)),
+             (_flat(hip.actor), _flat(ref.actor)), (_flat(hip.entropy), _flat(ref.entropy))]
+    for i, (x, y) in enumerate(pairs):
+        dd = (x - y).abs()
+        # two Adam steps of 1e-3: rounding-level gradient differences move a parameter only where |g| ~ 1e-8
+        assert float(dd.max()) <= 2.1e-3 and float((dd > 5e-5).float().mean()) < 1e-3, (i, float(dd.max()), float((dd > 5e-5).float().mean()))
+    # the critics' torch views follow the trainer; the fused policy kernel has the new actor
+    assert torch.equal(_flat(hip.critic_1), hip.twinq.vector(PARAMS, 0))
+    hip.sync_modules()
+    assert torch.equal(_flat(hip.target_critic_2), hip.twinq.vector(PARAMS, 3))
+
+
+def test_sac_hip_agent_graph_replay():
+    """act + ring + the hybrid update captured into a HIP graph: runs, moves the weights, keeps them finite"""
+    import torch
+    from evomotion_amd import VecRobotWalk, VecSacAgent
+    from evomotion_amd.qnet import PARAMS
+    n = 128
+    env = VecRobotWalk(n, seed=5)
+    env.reset()
+    ag = VecSacAgent(11, [371], [12], batch_size=64, epoch=1, replay_buffer_size=16, train_every=2, n_envs=n, use_graph=True)
+    assert ag.update_mode == "hip"
+    w0 = ag.twinq.vector(PARAMS, 0).clone()
+    t0 = ag.twinq.vector(PARAMS, 2).clone()
+    for _ in range(12):
+        st = ag.step(env)
+    assert ag._graph is not None and ag.train_steps >= 5
+    w1, t1 = ag.twinq.vector(PARAMS, 0), ag.twinq.vector(PARAMS, 2)
+    assert torch.isfinite(w1).all() and torch.isfinite(t1).all() and not torch.equal(w0, w1) and not torch.equal(t0, t1)
+    assert ag.twinq.adam_step(0) == ag.train_steps  # the device step counter advanced once per (replayed) update
+    assert all(torch.isfinite(p).all() for p in ag.actor.parameters())
