@@ -103,6 +103,11 @@ def _load():
     lib.evm_q_apply.argtypes = [vp, ctypes.c_float, vp]
     lib.evm_q_soft_update.argtypes = [vp, ctypes.c_float, vp]
     lib.evm_q_losses.argtypes = [vp, vp, vp]
+    lib.evm_q_action_grad.argtypes = [vp, ctypes.c_size_t, vp, vp, vp, vp, vp]
+    lib.evm_sac_sample.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp, vp]
+    lib.evm_sac_actor_grad.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.evm_ppo_actor_forward.argtypes = [vp, ctypes.c_size_t, vp, vp, vp, vp]
+    lib.evm_ppo_actor_backward.argtypes = [vp, ctypes.c_size_t, vp, vp, vp]
     lib.evm_env_timing_begin.argtypes = [vp, vp]
     lib.evm_env_timing_end.argtypes = [vp, vp, fp, ip]
     lib.evm_env_timing_end_detail.argtypes = [vp, vp, fp, ip, fp]

@@ -40,12 +40,14 @@ constexpr int PPO_COLSLOTS = 7;  // dgamma2, dbeta2, dbias2, dgamma1, dbeta1, db
 
 hipError_t launch_ppo_pack_w2d(const PpoNet &n, int S, hipStream_t s);
 hipError_t launch_ppo_pad(const PpoDev &d, size_t rows, const float *states, hipStream_t s);
-hipError_t launch_ppo_forward(const PolicyDev &p, const PpoDev &d, size_t rows, const float *states, hipStream_t s);
+hipError_t launch_ppo_forward(const PolicyDev &p, const PpoDev &d, size_t rows, const float *states, hipStream_t s, int nets = 2);
+hipError_t launch_actor_head_grad(const PpoDev &d, size_t rows, const float *dmu, const float *dsigma, hipStream_t s);
+hipError_t launch_actor_head_out(const PpoDev &d, size_t rows, float *mu, float *sigma, hipStream_t s);
 hipError_t launch_ppo_loss(const PpoDev &d, size_t rows, const float *actions, const float *logp_old, const float *adv,
                            const float *returns, const uint8_t *mask, double inv_rows, float epsilon, float entropy_factor,
                            float critic_loss_factor, hipStream_t s);
-hipError_t launch_ppo_backward(const PolicyDev &p, const PpoDev &d, size_t rows, hipStream_t s);
-hipError_t launch_ppo_wgrads(const PpoDev &d, size_t rows, const float *states, hipStream_t s);
+hipError_t launch_ppo_backward(const PolicyDev &p, const PpoDev &d, size_t rows, hipStream_t s, int nets = 2);
+hipError_t launch_ppo_wgrads(const PpoDev &d, size_t rows, const float *states, hipStream_t s, int nets = 2);
 hipError_t launch_ppo_apply(const PolicyDev &p, PpoDev &d, float lr, float clip_grad_norm, hipStream_t s);
 hipError_t launch_ppo_gae_scan(const PpoDev &d, int T, int N, const float *rewards, const uint8_t *done, const float *curr_values,
                                const float *next_values, const uint8_t *mask, float gamma, float lam, float *adv, hipStream_t s);

@@ -179,6 +179,31 @@ int evm_ppo_grads(EvmPpo *q, size_t rows, const float *d_states, const float *d_
     return EVM_OK;
 }
 
+// SAC shares ActorModule with PPO: the same kernels run its actor step, with the loss gradient supplied by the caller.
+int evm_ppo_actor_forward(EvmPpo *q, size_t rows, const float *d_states, float *d_mu, float *d_sigma, void *stream) {
+    if (!q || !d_states || !d_mu || !d_sigma) return qfail(EVM_E_INVALID, "null argument");
+    if (!q->have_params) return qfail(EVM_E_INVALID, "evm_ppo_set_params has not been called");
+    if (rows < 1 || rows > q->dev.max_rows) return qfail(EVM_E_INVALID, "rows exceeds the trainer's capacity");
+    hipStream_t s = (hipStream_t) stream;
+    hipError_t e = evm::launch_ppo_pad(q->dev, rows, d_states, s);
+    q->staged_rows = rows;
+    if (e == hipSuccess) e = evm::launch_ppo_forward(q->policy->dev, q->dev, rows, d_states, s, 1);
+    if (e == hipSuccess) e = evm::launch_actor_head_out(q->dev, rows, d_mu, d_sigma, s);
+    if (e != hipSuccess) return qfail(EVM_E_HIP, std::string("actor forward: ") + hipGetErrorString(e));
+    return EVM_OK;
+}
+
+int evm_ppo_actor_backward(EvmPpo *q, size_t rows, const float *d_dmu, const float *d_dsigma, void *stream) {
+    if (!q || !d_dmu || !d_dsigma) return qfail(EVM_E_INVALID, "null argument");
+    if (rows < 1 || rows != q->staged_rows) return qfail(EVM_E_INVALID, "rows differs from the preceding evm_ppo_actor_forward");
+    hipStream_t s = (hipStream_t) stream;
+    hipError_t e = evm::launch_actor_head_grad(q->dev, rows, d_dmu, d_dsigma, s);
+    if (e == hipSuccess) e = evm::launch_ppo_backward(q->policy->dev, q->dev, rows, s, 1);
+    if (e == hipSuccess) e = evm::launch_ppo_wgrads(q->dev, rows, nullptr, s, 1);
+    if (e != hipSuccess) return qfail(EVM_E_HIP, std::string("actor backward: ") + hipGetErrorString(e));
+    return EVM_OK;
+}
+
 int evm_ppo_apply(EvmPpo *q, float learning_rate, float clip_grad_norm, void *stream) {
     if (!q) return qfail(EVM_E_INVALID, "trainer is null");
     hipStream_t s = (hipStream_t) stream;

@@ -147,6 +147,36 @@ __global__ __launch_bounds__(256) void k_ppo_loss_actor(PpoDev d, int n, const f
     block_accumulate(lsum, d.loss, sh);
 }
 
+// SAC's actor step: gradients w.r.t. (mu, sigma) supplied by the caller -> gradients at the head pre-activations
+__global__ __launch_bounds__(256) void k_actor_head_grad(PpoDev d, int n, const float *__restrict__ dmu, const float *__restrict__ dsigma) {
+    const int A = d.A;
+    const size_t e = (size_t) blockIdx.x * 256 + threadIdx.x;
+    if (e >= (size_t) n * A) return;
+    const size_t row = e / A;
+    const int o = (int) (e - row * A);
+    const float mu = d.actor.head[row * 2 * A + o], sg = d.actor.head[row * 2 * A + A + o];
+    float *dh = d.actor.dh + row * 32;
+    dh[o] = dmu[e] * (1.f - mu * mu);        // tanh'
+    dh[A + o] = dsigma[e] * (-expm1f(-sg));  // softplus' = sigmoid(pre) = 1 - e^-sigma
+}
+__global__ __launch_bounds__(256) void k_actor_head_out(PpoDev d, int n, float *__restrict__ mu, float *__restrict__ sigma) {
+    const int A = d.A;
+    const size_t e = (size_t) blockIdx.x * 256 + threadIdx.x;
+    if (e >= (size_t) n * A) return;
+    const size_t row = e / A;
+    const int o = (int) (e - row * A);
+    mu[e] = d.actor.head[row * 2 * A + o];
+    sigma[e] = d.actor.head[row * 2 * A + A + o];
+}
+hipError_t launch_actor_head_grad(const PpoDev &d, size_t rows, const float *dmu, const float *dsigma, hipStream_t s) {
+    hipLaunchKernelGGL(k_actor_head_grad, dim3((unsigned) ((rows * d.A + 255) / 256)), dim3(256), 0, s, d, (int) rows, dmu, dsigma);
+    return hipGetLastError();
+}
+hipError_t launch_actor_head_out(const PpoDev &d, size_t rows, float *mu, float *sigma, hipStream_t s) {
+    hipLaunchKernelGGL(k_actor_head_out, dim3((unsigned) ((rows * d.A + 255) / 256)), dim3(256), 0, s, d, (int) rows, mu, sigma);
+    return hipGetLastError();
+}
+
 // critic_loss_factor * mean((value - returns)^2) over the selected rows (ppo_gae.cpp:176-179)
 __global__ __launch_bounds__(256) void k_ppo_loss_critic(PpoDev d, int n, const float *__restrict__ returns,
                                                          const uint8_t *__restrict__ mask, float inv_rows, float cf) {
@@ -592,7 +622,7 @@ hipError_t launch_ppo_pad(const PpoDev &d, size_t rows, const float *states, hip
     return hipGetLastError();
 }
 
-hipError_t launch_ppo_forward(const PolicyDev &p, const PpoDev &d, size_t rows, const float *states, hipStream_t s) {
+hipError_t launch_ppo_forward(const PolicyDev &p, const PpoDev &d, size_t rows, const float *states, hipStream_t s, int nets) {
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ppo_forward<PRT>),
@@ -604,7 +634,7 @@ hipError_t launch_ppo_forward(const PolicyDev &p, const PpoDev &d, size_t rows, 
         attr = true;
     }
     constexpr int TM = 32 * PRT;
-    dim3 grid((unsigned) ((rows + TM - 1) / TM), 2);
+    dim3 grid((unsigned) ((rows + TM - 1) / TM), nets);
     (void) states;
     hipLaunchKernelGGL(k_ppo_forward<PRT>, grid, dim3(PT), fwd_lds_bytes(), s, p, d, (int) rows, d.xpad);
     return hipGetLastError();
@@ -623,9 +653,9 @@ hipError_t launch_ppo_loss(const PpoDev &d, size_t rows, const float *actions, c
     return hipGetLastError();
 }
 
-hipError_t launch_ppo_backward(const PolicyDev &p, const PpoDev &d, size_t rows, hipStream_t s) {
+hipError_t launch_ppo_backward(const PolicyDev &p, const PpoDev &d, size_t rows, hipStream_t s, int nets) {
     constexpr int TM = 32 * PRT;
-    dim3 grid((unsigned) ((rows + TM - 1) / TM), 2);
+    dim3 grid((unsigned) ((rows + TM - 1) / TM), nets);
     hipLaunchKernelGGL(k_ppo_backward<PRT>, grid, dim3(PT), bwd_lds_bytes(), s, p, d, (int) rows);
     return hipGetLastError();
 }
@@ -665,12 +695,12 @@ hipError_t launch_pad_rows(const float *src, int S, size_t rows, float *dst, hip
     return hipGetLastError();
 }
 
-hipError_t launch_ppo_wgrads(const PpoDev &d, size_t rows, const float *states, hipStream_t s) {
+hipError_t launch_ppo_wgrads(const PpoDev &d, size_t rows, const float *states, hipStream_t s, int nets) {
     constexpr int TM = 32 * PRT;
     const int S = d.S, A = d.A, M = (int) rows;
     const int tiles = (int) ((rows + TM - 1) / TM);
     (void) states;
-    for (int net = 0; net < 2; net++) {
+    for (int net = 0; net < nets; net++) {
         const PpoNet &B = net == 0 ? d.actor : d.critic;
         const size_t o_w1 = 0, o_b1 = (size_t) 256 * S, o_g1 = o_b1 + 256, o_be1 = o_g1 + 256, o_w2 = o_be1 + 256;
         const size_t o_b2 = o_w2 + 65536, o_g2 = o_b2 + 256, o_be2 = o_g2 + 256, o_h = o_be2 + 256;

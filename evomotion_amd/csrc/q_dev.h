@@ -44,5 +44,9 @@ hipError_t launch_q_wgrads(const QDev &d, size_t rows, hipStream_t s);
 hipError_t launch_q_adam(const QDev &d, float lr, hipStream_t s);                   // both critics, then repack
 hipError_t launch_q_soft_update(const QDev &d, float tau, hipStream_t s);           // targets, then repack
 size_t q_wpart_floats();
+hipError_t launch_sac_sample(int rows, int A, const float *mu, const float *sigma, const float *u, float *action, float *logp_sum, hipStream_t s);
+hipError_t launch_sac_actor_grad(int rows, int A, const float *mu, const float *sigma, const float *u, const float *dqda,
+                                 const float *log_alpha, float *dmu, float *dsigma, hipStream_t s);
+hipError_t launch_q_action_grad(const QDev &d, size_t rows, float *qmin, float *dqda, hipStream_t s);
 
 }  // namespace evm

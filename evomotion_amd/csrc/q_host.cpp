@@ -183,6 +183,42 @@ int evm_q_soft_update(EvmQ *q, float tau, void *stream) {
     return EVM_OK;
 }
 
+// SAC actor step, Q side (soft_actor_critic.cpp:136-140): min(critic_1, critic_2)(states, actions) into d_qmin [rows] and the
+// gradient of -mean(min q) w.r.t. the actions into d_dqda [rows][A]
+int evm_q_action_grad(EvmQ *q, size_t rows, const float *d_states, const float *d_actions, float *d_qmin, float *d_dqda, void *stream) {
+    if (!q || !d_states || !d_actions || !d_qmin || !d_dqda) return zfail(EVM_E_INVALID, "null argument");
+    if (rows < 1 || rows > q->dev.max_rows) return zfail(EVM_E_INVALID, "rows exceeds the trainer's capacity");
+    if (q_ready(q, 3u) != EVM_OK) return EVM_E_INVALID;
+    hipStream_t s = (hipStream_t) stream;
+    hipError_t e = evm::launch_q_concat(q->dev, rows, d_states, d_actions, s);
+    if (e == hipSuccess) e = evm::launch_q_action_grad(q->dev, rows, d_qmin, d_dqda, s);
+    if (e != hipSuccess) return zfail(EVM_E_HIP, std::string("q action grad: ") + hipGetErrorString(e));
+    return EVM_OK;
+}
+
+// truncated_normal_sample(mu, sigma, -1, 1) with the supplied uniform draws and the summed truncated_normal_log_pdf of the
+// sample (functions.cpp:53-68,94-111; soft_actor_critic.cpp:131-135).  [rows][A] inputs, d_action [rows][A], d_logp_sum [rows]
+int evm_sac_sample(int rows, int action_dim, const float *d_mu, const float *d_sigma, const float *d_uniform, float *d_action,
+                   float *d_logp_sum, void *stream) {
+    if (!d_mu || !d_sigma || !d_uniform || !d_action || !d_logp_sum) return zfail(EVM_E_INVALID, "null argument");
+    if (rows < 1 || action_dim < 1) return zfail(EVM_E_INVALID, "empty batch");
+    hipError_t e = evm::launch_sac_sample(rows, action_dim, d_mu, d_sigma, d_uniform, d_action, d_logp_sum, (hipStream_t) stream);
+    if (e != hipSuccess) return zfail(EVM_E_HIP, std::string("sac sample: ") + hipGetErrorString(e));
+    return EVM_OK;
+}
+
+// gradient of  mean(exp(log_alpha) * logp_sum - min q)  w.r.t. (mu, sigma), the action being the reparameterised sample
+// (soft_actor_critic.cpp:129-142); d_dqda from evm_q_action_grad, d_log_alpha a DEVICE scalar
+int evm_sac_actor_grad(int rows, int action_dim, const float *d_mu, const float *d_sigma, const float *d_uniform, const float *d_dqda,
+                       const float *d_log_alpha, float *d_dmu, float *d_dsigma, void *stream) {
+    if (!d_mu || !d_sigma || !d_uniform || !d_dqda || !d_log_alpha || !d_dmu || !d_dsigma) return zfail(EVM_E_INVALID, "null argument");
+    if (rows < 1 || action_dim < 1) return zfail(EVM_E_INVALID, "empty batch");
+    hipError_t e = evm::launch_sac_actor_grad(rows, action_dim, d_mu, d_sigma, d_uniform, d_dqda, d_log_alpha, d_dmu, d_dsigma,
+                                              (hipStream_t) stream);
+    if (e != hipSuccess) return zfail(EVM_E_HIP, std::string("sac actor grad: ") + hipGetErrorString(e));
+    return EVM_OK;
+}
+
 // DEVICE double[2]: the two critics' mse losses of the last evm_q_grads
 int evm_q_losses(EvmQ *q, double *d_out, void *stream) {
     if (!q || !d_out) return zfail(EVM_E_INVALID, "null argument");

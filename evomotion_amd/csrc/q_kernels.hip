@@ -226,6 +226,108 @@ __global__ __launch_bounds__(256) void k_q_soft(QDev d, float tau, float one_min
 #pragma clang fp contract(fast)
 
 // ---------------------------------------------------------------------------------------------------------
+// SAC actor step (soft_actor_critic.cpp:129-153): reparameterised sample, min of the twin critics, their gradient
+// w.r.t. the action, and the gradient of  mean(alpha * sum_d log_pdf - min q)  w.r.t. (mu, sigma)
+// ---------------------------------------------------------------------------------------------------------
+struct TnTerms {  // truncated normal on [-1, 1] at (mu, sigma) with the uniform draw u (functions.cpp:53-68,94-111)
+    float s, is, cs, al, be, ca, cb, pa, pb, Z, w, pw, raw, act, cact;
+};
+__device__ __forceinline__ TnTerms tn_terms(float mu, float sg, float u) {
+    TnTerms t;
+    const float INV_SQRT_2PI = 0.39894228040143267794f;
+    t.s = fminf(fmaxf(sg, 1e-6f), 1e6f);
+    t.cs = (sg >= 1e-6f && sg <= 1e6f) ? 1.f : 0.f;
+    t.is = 1.0f / t.s;
+    const float ar = (-1.f - mu) / t.s, br = (1.f - mu) / t.s;
+    t.al = fminf(fmaxf(ar, -5.f), 5.f);
+    t.be = fminf(fmaxf(br, -5.f), 5.f);
+    t.ca = (ar >= -5.f && ar <= 5.f) ? 1.f : 0.f;
+    t.cb = (br >= -5.f && br <= 5.f) ? 1.f : 0.f;
+    const float ta = theta_f(t.al), tb = theta_f(t.be);
+    t.Z = tb - ta;
+    t.pa = expf(-0.5f * t.al * t.al) * INV_SQRT_2PI;
+    t.pb = expf(-0.5f * t.be * t.be) * INV_SQRT_2PI;
+    const float cdf = fminf(fmaxf(ta + u * (tb - ta), 0.f), 1.f);
+    t.w = 1.41421356237309504880f * erfinvf(2.0f * cdf - 1.0f);  // standard-normal quantile of cdf
+    t.pw = expf(-0.5f * t.w * t.w) * INV_SQRT_2PI;
+    t.raw = t.w * t.s + mu;
+    t.act = fminf(fmaxf(t.raw, -1.f), 1.f);
+    t.cact = (t.raw >= -1.f && t.raw <= 1.f) ? 1.f : 0.f;
+    return t;
+}
+// action [rows][A], logp_sum [rows] (one thread per row)
+__global__ __launch_bounds__(256) void k_sac_sample(int n, int A, const float *__restrict__ mu, const float *__restrict__ sigma,
+                                                    const float *__restrict__ u, float *__restrict__ action, float *__restrict__ logp_sum) {
+    const size_t row = (size_t) blockIdx.x * 256 + threadIdx.x;
+    if (row >= (size_t) n) return;
+    float sum = 0.f;
+    for (int o = 0; o < A; o++) {
+        const size_t e = row * A + o;
+        const TnTerms t = tn_terms(mu[e], sigma[e], u[e]);
+        const float q = (t.act - mu[e]) / t.s;
+        sum += -0.91893853320467274178f - logf(t.s) - 0.5f * (q * q) - logf(t.Z);
+        action[e] = t.act;
+    }
+    logp_sum[row] = sum;
+}
+// min(q1, q2) and the head gradients of  -mean(min q): torch.min sends the gradient to the smaller, half each on a tie
+__global__ __launch_bounds__(256) void k_q_min_grad(QDev d, int n, float inv_rows, float *__restrict__ qmin) {
+    const size_t row = (size_t) blockIdx.x * 256 + threadIdx.x;
+    if (row >= (size_t) n) return;
+    const float q1 = d.net[0].q[row], q2 = d.net[1].q[row];
+    qmin[row] = fminf(q1, q2);
+    const float w1 = q1 < q2 ? 1.f : (q1 == q2 ? 0.5f : 0.f);
+    d.net[0].dh[row * 32] = -inv_rows * w1;
+    d.net[1].dh[row * 32] = -inv_rows * (1.f - w1);
+}
+// d loss / d action = sum over the critics of dz0 . W0[:, S + a]   (one thread per (row, a))
+__global__ __launch_bounds__(256) void k_q_input_grad(QDev d, int n, float *__restrict__ dqda) {
+    const int A = d.A, SA = d.S + d.A;
+    const size_t e = (size_t) blockIdx.x * 256 + threadIdx.x;
+    if (e >= (size_t) n * A) return;
+    const size_t row = e / A;
+    const int a = (int) (e - row * A);
+    float sum = 0.f;
+    for (int c = 0; c < 2; c++) {
+        const QNet &N = d.net[c];
+        const float *dz = N.dz[0] + row * 256;
+        const float *w = N.theta + N.o_w[0] + d.S + a;
+        float s = 0.f;
+#pragma unroll 8
+        for (int j = 0; j < 256; j++) s += dz[j] * w[(size_t) j * SA];
+        sum += s;
+    }
+    dqda[e] = sum;
+}
+// d/d(mu, sigma) of  mean_rows(alpha * sum_d logp_d - q),  action = sample(mu, sigma, u) differentiated through
+// (dqda already carries the -1/rows of the q term)
+__global__ __launch_bounds__(256) void k_sac_actor_grad(int n, int A, const float *__restrict__ mu, const float *__restrict__ sigma,
+                                                        const float *__restrict__ u, const float *__restrict__ dqda,
+                                                        const float *__restrict__ log_alpha, float inv_rows, float *__restrict__ dmu,
+                                                        float *__restrict__ dsigma) {
+    const size_t e = (size_t) blockIdx.x * 256 + threadIdx.x;
+    if (e >= (size_t) n * A) return;
+    const float alpha = expf(log_alpha[0]);
+    const float m = mu[e];
+    const TnTerms t = tn_terms(m, sigma[e], u[e]);
+    const float iZ = 1.0f / t.Z;
+    const float q = (t.act - m) * t.is;
+    // d action / d mu, d sigma (through the clamp to [-1, 1], the quantile w(cdf) and cdf(alpha, beta))
+    const float ipw = 1.0f / t.pw;
+    const float A1 = (1.f - u[e]) * t.pa * t.ca, B1 = u[e] * t.pb * t.cb;
+    const float da_dmu = t.cact * (1.f - (A1 + B1) * ipw);
+    const float da_ds = t.cact * (t.w - (A1 * t.al + B1 * t.be) * ipw);
+    // log pdf: partials at fixed action, and w.r.t. the action
+    const float lp_mu = q * t.is + iZ * t.is * (t.pb * t.cb - t.pa * t.ca);
+    const float lp_s = (q * q - 1.f) * t.is + iZ * t.is * (t.pb * t.be * t.cb - t.pa * t.al * t.ca);
+    const float lp_a = -q * t.is;
+    const float k = alpha * inv_rows;
+    const float g_a = k * lp_a + dqda[e];
+    dmu[e] = k * lp_mu + g_a * da_dmu;
+    dsigma[e] = (k * lp_s + g_a * da_ds) * t.cs;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------------
 static size_t q_fwd_lds() {
@@ -318,6 +420,27 @@ hipError_t launch_q_soft_update(const QDev &d, float tau, hipStream_t s) {
     hipError_t e = launch_q_pack(d, 2, s);
     if (e == hipSuccess) e = launch_q_pack(d, 3, s);
     return e;
+}
+
+hipError_t launch_sac_sample(int rows, int A, const float *mu, const float *sigma, const float *u, float *action, float *logp_sum, hipStream_t s) {
+    hipLaunchKernelGGL(k_sac_sample, dim3((rows + 255) / 256), dim3(256), 0, s, rows, A, mu, sigma, u, action, logp_sum);
+    return hipGetLastError();
+}
+hipError_t launch_sac_actor_grad(int rows, int A, const float *mu, const float *sigma, const float *u, const float *dqda,
+                                 const float *log_alpha, float *dmu, float *dsigma, hipStream_t s) {
+    hipLaunchKernelGGL(k_sac_actor_grad, dim3((unsigned) (((size_t) rows * A + 255) / 256)), dim3(256), 0, s, rows, A, mu, sigma, u, dqda,
+                       log_alpha, (float) (1.0 / (double) rows), dmu, dsigma);
+    return hipGetLastError();
+}
+// critics' forward (kept), min, backward to the first layer, gradient w.r.t. the action columns of the input
+hipError_t launch_q_action_grad(const QDev &d, size_t rows, float *qmin, float *dqda, hipStream_t s) {
+    hipError_t e = launch_q_forward(d, 3u, rows, 1, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_q_min_grad, dim3((unsigned) ((rows + 255) / 256)), dim3(256), 0, s, d, (int) rows, (float) (1.0 / (double) rows), qmin);
+    e = launch_q_backward(d, rows, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_q_input_grad, dim3((unsigned) ((rows * d.A + 255) / 256)), dim3(256), 0, s, d, (int) rows, dqda);
+    return hipGetLastError();
 }
 
 }  // namespace evm

@@ -78,8 +78,9 @@ class FusedPpoTrainer:
         check(lib.evm_ppo_set_params(self._h, _ptr(a), _ptr(c), 1 if reset_optimizer else 0, self._stream()))
         torch.cuda.current_stream(self.device).synchronize()  # a, c may be freed
 
-    def vector(self, what, net):
-        out = torch.empty(self.n_params[net], device=self.device)
+    def vector(self, what, net, out=None):
+        if out is None:
+            out = torch.empty(self.n_params[net], device=self.device)
         check(lib.evm_ppo_copy(self._h, what, net, 0, _ptr(out), self._stream()))
         return out
 
@@ -152,6 +153,22 @@ class FusedPpoTrainer:
                 check(lib.evm_ppo_copy(self._h, GRADS, net, 1, _ptr(g), s))
                 torch.cuda.current_stream(self.device).synchronize()
         check(lib.evm_ppo_apply(self._h, learning_rate, clip_grad_norm, s))
+
+    # ---- SAC's actor step on the same kernels ----------------------------------------------------------------------
+    def actor_forward(self, states, mu=None, sigma=None):
+        rows = states.shape[0]
+        A = self.fused.A
+        mu = torch.empty(rows, A, device=self.device) if mu is None else mu
+        sigma = torch.empty(rows, A, device=self.device) if sigma is None else sigma
+        check(lib.evm_ppo_actor_forward(self._h, rows, _ptr(states), _ptr(mu), _ptr(sigma), self._stream()))
+        return mu, sigma
+
+    def actor_backward(self, dmu, dsigma):
+        check(lib.evm_ppo_actor_backward(self._h, dmu.shape[0], _ptr(dmu), _ptr(dsigma), self._stream()))
+
+    def set_flat(self, actor_flat, critic_flat, reset_optimizer=False):
+        """flat device parameter vectors -> trainer and rollout kernel, asynchronously on the current stream"""
+        check(lib.evm_ppo_set_params(self._h, _ptr(actor_flat), _ptr(critic_flat), 1 if reset_optimizer else 0, self._stream()))
 
     def losses(self):
         a, c = ctypes.c_double(), ctypes.c_double()

@@ -88,7 +88,35 @@ class FusedTwinQ:
     def soft_update(self, tau):
         check(lib.evm_q_soft_update(self._h, tau, self._stream()))
 
+    def action_grad(self, states, actions, qmin=None, dqda=None):
+        """min(critic_1, critic_2)(states, actions) [rows] and d(-mean(min q)) / d actions [rows, A]"""
+        rows = states.shape[0]
+        qmin = torch.empty(rows, device=self.device) if qmin is None else qmin
+        dqda = torch.empty(rows, self.A, device=self.device) if dqda is None else dqda
+        check(lib.evm_q_action_grad(self._h, rows, _ptr(states), _ptr(actions), _ptr(qmin), _ptr(dqda), self._stream()))
+        return qmin, dqda
+
     def losses(self):
         """device tensor [2] (float64): the critics' mse losses of the last grads()"""
         check(lib.evm_q_losses(self._h, _ptr(self._loss), self._stream()))
         return self._loss
+
+
+def sac_sample(mu, sigma, u, action=None, logp_sum=None):
+    """truncated_normal_sample(mu, sigma, -1, 1; u) and the summed log-pdf of the sample (device kernels)"""
+    rows, A = mu.shape
+    action = torch.empty_like(mu) if action is None else action
+    logp_sum = torch.empty(rows, device=mu.device) if logp_sum is None else logp_sum
+    stream = ctypes.c_void_p(torch.cuda.current_stream(mu.device).cuda_stream)
+    check(lib.evm_sac_sample(rows, A, _ptr(mu), _ptr(sigma), _ptr(u), _ptr(action), _ptr(logp_sum), stream))
+    return action, logp_sum
+
+
+def sac_actor_grad(mu, sigma, u, dqda, log_alpha, dmu=None, dsigma=None):
+    """d mean(alpha * logp_sum - min q) / d (mu, sigma) through the reparameterised sample"""
+    rows, A = mu.shape
+    dmu = torch.empty_like(mu) if dmu is None else dmu
+    dsigma = torch.empty_like(mu) if dsigma is None else dsigma
+    stream = ctypes.c_void_p(torch.cuda.current_stream(mu.device).cuda_stream)
+    check(lib.evm_sac_actor_grad(rows, A, _ptr(mu), _ptr(sigma), _ptr(u), _ptr(dqda), _ptr(log_alpha), _ptr(dmu), _ptr(dsigma), stream))
+    return dmu, dsigma

@@ -109,10 +109,11 @@ class VecSacAgent:
     def __init__(self, seed, state_space, action_space, actor_hidden_size=256, critic_hidden_size=256, batch_size=256,
                  epoch=1, learning_rate=1e-3, gamma=0.99, tau=0.005, replay_buffer_size=1024, train_every=4, n_envs=4096,
                  device=0, use_graph=True, update="hip"):
-        """update = "hip": the twin critics, their targets, the critics' mse update and the soft update run in the HIP Q
-        trainer (qnet.py, csrc/q_kernels.hip), the target actions come from the fused policy kernel; the actor and entropy
-        steps stay on PyTorch-ROCm autograd (through torch views of the trainer's critic weights).  "torch": everything
-        through autograd (sac_train), kept for comparison."""
+        """update = "hip": SoftActorCriticAgent::train on the device — target actions from the fused policy kernel, the twin
+        critics, their targets, the critics' mse update and the soft update in the HIP Q trainer (qnet.py,
+        csrc/q_kernels.hip), the actor step (forward, reparameterised sample, action gradient through the critics,
+        backward) on the same MLP kernels; PyTorch keeps the Adam steps of the actor and of the entropy parameter and the
+        target arithmetic.  "torch": everything through autograd (sac_train), kept for comparison."""
         if update not in ("hip", "torch"):
             raise ValueError("update must be 'hip' or 'torch'")
         from .agent import FusedActorCritic, _all_reduce_grads_mean
@@ -155,6 +156,25 @@ class VecSacAgent:
             self._push_critics()
             self._tq_out = {2: z(B), 3: z(B)}
             self._next_act = (z(B, A), z(B, A), None)
+            # the actor step runs on the PPO trainer's actor kernels (same ActorModule); its critic slot is unused
+            from .ppo import FusedPpoTrainer
+            self._actor_tr = FusedPpoTrainer(self.fused, B)
+            self._critic_dummy = z(self._actor_tr.n_params[1])
+            self._abuf = dict(mu=z(B, A), sigma=z(B, A), action=z(B, A), logp=z(B), qmin=z(B), dqda=z(B, A), dmu=z(B, A), dsigma=z(B, A))
+            self._push_actor()
+
+    def _push_actor(self):
+        """the actor's torch parameters and gradients become views of two flat buffers: the trainer reads the first and
+        writes the second, torch's Adam steps in between"""
+        ps = list(self.actor.parameters())
+        self._actor_flat = torch.cat([p.detach().reshape(-1) for p in ps]).contiguous()
+        self._actor_grad = torch.zeros_like(self._actor_flat)
+        o = 0
+        for p in ps:
+            p.data = self._actor_flat[o:o + p.numel()].view_as(p)
+            p.grad = self._actor_grad[o:o + p.numel()].view_as(p)
+            o += p.numel()
+        self._actor_tr.set_flat(self._actor_flat, self._critic_dummy, reset_optimizer=True)
 
     def _push_critics(self):
         """modules -> the HIP trainer; the critics' torch parameters become views of flat buffers the trainer's weights are
@@ -211,25 +231,32 @@ class VecSacAgent:
         self.twinq.apply(self.learning_rate)
         for i in (0, 1):
             self.twinq.vector(PARAMS, i, out=self._critic_flat[i])
-        # actor and entropy (:129-164) through autograd; the critics are constants here
-        mu, sigma = self.actor(s)
-        curr_action = truncated_normal_sample(mu, sigma, -1.0, 1.0)
-        curr_logp = truncated_normal_log_pdf(curr_action, mu, sigma, -1.0, 1.0).sum(-1, keepdim=True)
-        q = torch.min(self.critic_1(s, curr_action), self.critic_2(s, curr_action))
-        loss_actor = torch.mean(alpha * curr_logp - q)
-        self.actor_opt.zero_grad()
-        loss_actor.backward()
+        # actor (:129-153): forward, reparameterised sample, twin-critic action gradient, loss gradient and backward on the
+        # device; torch's Adam steps the flat parameter buffer
+        from .ppo import GRADS as PGRADS, ACTOR
+        from .qnet import sac_actor_grad, sac_sample
+        ab = self._abuf
+        u_curr = torch.rand(B, self.fused.A, device=self.device)
+        self._actor_tr.actor_forward(s, ab["mu"], ab["sigma"])
+        sac_sample(ab["mu"], ab["sigma"], u_curr, ab["action"], ab["logp"])
+        self.twinq.action_grad(s, ab["action"], ab["qmin"], ab["dqda"])
+        sac_actor_grad(ab["mu"], ab["sigma"], u_curr, ab["dqda"], self.entropy.log_alpha.detach(), ab["dmu"], ab["dsigma"])
+        self._actor_tr.actor_backward(ab["dmu"], ab["dsigma"])
+        self._actor_tr.vector(PGRADS, ACTOR, out=self._actor_grad)
         if not self.use_graph:
             self._grad_hook(list(self.actor.parameters()))
         self.actor_opt.step()
-        loss_entropy = -torch.mean(self.entropy.log_alpha * (curr_logp.detach() + self.target_entropy))
+        loss_actor = torch.mean(alpha * ab["logp"] - ab["qmin"])
+        # entropy parameter (:155-164)
+        loss_entropy = -torch.mean(self.entropy.log_alpha * (ab["logp"] + self.target_entropy))
         self.entropy_opt.zero_grad()
         loss_entropy.backward()
         if not self.use_graph:
             self._grad_hook(list(self.entropy.parameters()))
         self.entropy_opt.step()
         self.twinq.soft_update(self.tau)
-        self.fused.set_actor(self.actor)  # the next target actions come from the updated actor
+        # new actor weights -> trainer and rollout kernel (the next target actions and the rollout use them)
+        self._actor_tr.set_flat(self._actor_flat, self._critic_dummy)
         lq = self.twinq.losses()
         return dict(actor=loss_actor.detach(), critic_1=lq[0], critic_2=lq[1], entropy=loss_entropy.detach())
 
@@ -278,7 +305,8 @@ class VecSacAgent:
             else:
                 self._graph.replay()
             self.train_steps += 1
-        self.fused.set_actor(self.actor)
+        if self.update_mode != "hip":  # (the device path has already repacked the actor for the rollout kernel)
+            self.fused.set_actor(self.actor)
 
     def save(self, folder):
         """SoftActorCriticAgent::save (soft_actor_critic.cpp:181-201): module archives in the reference's format."""
@@ -298,3 +326,4 @@ class VecSacAgent:
         self.fused.set_actor(self.actor)
         if self.twinq is not None:
             self._push_critics()
+            self._push_actor()

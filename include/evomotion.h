@@ -237,6 +237,10 @@ int evm_ppo_gae_normalize(EvmPpo *q, int horizon, int n_envs, const double *d_st
 int evm_ppo_grads(EvmPpo *q, size_t rows, const float *d_states, const float *d_actions, const float *d_logp_old, const float *d_adv,
                   const float *d_returns, const uint8_t *d_mask, double n_selected_global, float epsilon, float entropy_factor,
                   float critic_loss_factor, int states_unchanged, void *stream);
+/* SAC's actor is the same ActorModule: forward keeping the activations (mu, sigma [rows, A] out), then backward + weight
+ * gradients from d loss / d(mu, sigma) supplied by the caller (evm_sac_actor_grad); gradients via evm_ppo_copy(1, 0, ...) */
+int evm_ppo_actor_forward(EvmPpo *q, size_t rows, const float *d_states, float *d_mu, float *d_sigma, void *stream);
+int evm_ppo_actor_backward(EvmPpo *q, size_t rows, const float *d_dmu, const float *d_dsigma, void *stream);
 /* clip_grad_norm_(clip_grad_norm) and Adam(lr, betas 0.9 / 0.999, eps 1e-8) for both networks, then the new weights into
  * `policy` */
 int evm_ppo_apply(EvmPpo *q, float learning_rate, float clip_grad_norm, void *stream);
@@ -270,6 +274,17 @@ int evm_q_grads(EvmQ *q, size_t rows, const float *d_states, const float *d_acti
 int evm_q_apply(EvmQ *q, float learning_rate, void *stream);
 /* target_i <- tau * critic_i + (1 - tau) * target_i */
 int evm_q_soft_update(EvmQ *q, float tau, void *stream);
+/* SAC actor step, Q side (soft_actor_critic.cpp:136-140): min(critic_1, critic_2)(states, actions) into d_qmin [rows] and the
+ * gradient of -mean(min q) w.r.t. the actions into d_dqda [rows, A] (critics' forward, backward to their first layer) */
+int evm_q_action_grad(EvmQ *q, size_t rows, const float *d_states, const float *d_actions, float *d_qmin, float *d_dqda, void *stream);
+/* truncated_normal_sample(mu, sigma, -1, 1) with the supplied uniform draws and the summed truncated_normal_log_pdf of the
+ * sample (functions.cpp:53-68,94-111; soft_actor_critic.cpp:131-135): [rows, A] in, d_action [rows, A], d_logp_sum [rows] */
+int evm_sac_sample(int rows, int action_dim, const float *d_mu, const float *d_sigma, const float *d_uniform, float *d_action,
+                   float *d_logp_sum, void *stream);
+/* gradient of mean(exp(log_alpha) * logp_sum - min q) w.r.t. (mu, sigma), the action being the reparameterised sample
+ * (soft_actor_critic.cpp:129-142); d_dqda from evm_q_action_grad, d_log_alpha a DEVICE scalar; outputs [rows, A] */
+int evm_sac_actor_grad(int rows, int action_dim, const float *d_mu, const float *d_sigma, const float *d_uniform, const float *d_dqda,
+                       const float *d_log_alpha, float *d_dmu, float *d_dsigma, void *stream);
 /* DEVICE double[2]: the critics' losses of the last evm_q_grads */
 int evm_q_losses(EvmQ *q, double *d_out, void *stream);
 

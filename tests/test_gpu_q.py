@@ -130,3 +130,56 @@ def test_q_soft_update():
     with torch.no_grad():
         for i in (2, 3):
             np.testing.assert_allclose(got[i].cpu().numpy(), nets[i](states, actions).squeeze(-1).cpu().numpy(), atol=5e-5)
+
+
+def test_sac_actor_step_gradients_match_autograd():
+    """soft_actor_critic.cpp:129-142 through the device path (actor forward, sample, twin-critic action gradient, loss
+    gradient, actor backward) against autograd of the same expression"""
+    import torch
+    from evomotion_amd import FusedActorCritic, agent
+    from evomotion_amd.ppo import FusedPpoTrainer, GRADS, ACTOR
+    from evomotion_amd.qnet import sac_actor_grad, sac_sample
+    rows = 1000
+    torch.manual_seed(2)
+    actor = agent.ActorModule([371], [12], 256).cuda()
+    critic_dummy = agent.CriticModule([371], 256).cuda()
+    with torch.no_grad():  # a spread of sigmas: some truncation bounds clamp at +-5, some do not
+        actor.sigma[0].bias.add_(torch.linspace(-3, 1, 12, device="cuda"))
+    nets = _nets(seed=4)
+    tq = _trainer(nets, rows)
+    f = FusedActorCritic(371, 12, 256, 0)
+    tr = FusedPpoTrainer(f, rows)
+    tr.set_modules(actor, critic_dummy)
+    states, _, _ = _batch(rows, seed=7)
+    g = torch.Generator(device="cuda"); g.manual_seed(8)
+    u = torch.rand(rows, 12, device="cuda", generator=g)
+    log_alpha = torch.tensor([-0.7], device="cuda")
+    # device path
+    mu, sigma = tr.actor_forward(states)
+    action, logp_sum = sac_sample(mu, sigma, u)
+    qmin, dqda = tq.action_grad(states, action)
+    dmu, dsigma = sac_actor_grad(mu, sigma, u, dqda, log_alpha)
+    tr.actor_backward(dmu, dsigma)
+    got = tr.vector(GRADS, ACTOR)
+    # autograd
+    for m in nets[:2]:
+        for p in m.parameters():
+            p.requires_grad_(False)
+    rmu, rsig = actor(states)
+    ract = agent.truncated_normal_sample(rmu, rsig, u=u)
+    rlogp = agent.truncated_normal_log_pdf(ract, rmu, rsig).sum(-1, keepdim=True)
+    rq = torch.min(nets[0](states, ract), nets[1](states, ract))
+    loss = torch.mean(log_alpha.exp() * rlogp - rq)
+    loss.backward()
+    ref = torch.cat([p.grad.reshape(-1) for p in actor.parameters()])
+    np.testing.assert_allclose(mu.cpu().numpy(), rmu.detach().cpu().numpy(), atol=2e-5)
+    np.testing.assert_allclose(action.cpu().numpy(), ract.detach().cpu().numpy(), atol=5e-5)
+    np.testing.assert_allclose(logp_sum.cpu().numpy(), rlogp.detach().squeeze(-1).cpu().numpy(), atol=5e-4, rtol=1e-4)
+    np.testing.assert_allclose(qmin.cpu().numpy(), rq.detach().squeeze(-1).cpu().numpy(), atol=1e-4)
+    o = 0
+    for name, p in actor.named_parameters():
+        n = p.numel()
+        a, b = got[o:o + n], ref[o:o + n]
+        assert float((a - b).abs().max()) <= 1e-3 * float(b.abs().max()) + 1e-8, (name, float((a - b).abs().max()), float(b.abs().max()))
+        o += n
+    assert float((got - ref).abs().max()) <= 2e-4 * float(ref.abs().max())
