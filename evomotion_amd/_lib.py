@@ -108,6 +108,9 @@ def _load():
     lib.evm_sac_actor_grad.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.evm_ppo_actor_forward.argtypes = [vp, ctypes.c_size_t, vp, vp, vp, vp]
     lib.evm_ppo_actor_backward.argtypes = [vp, ctypes.c_size_t, vp, vp, vp]
+    lib.evm_ppo_actor_apply.argtypes = [vp, ctypes.c_float, vp]
+    lib.evm_sac_target_q.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp, vp, ctypes.c_float, vp, vp]
+    lib.evm_sac_entropy_step.argtypes = [ctypes.c_int, vp, vp, ctypes.c_float, ctypes.c_float, vp, vp, vp, vp, vp]
     lib.evm_env_timing_begin.argtypes = [vp, vp]
     lib.evm_env_timing_end.argtypes = [vp, vp, fp, ip]
     lib.evm_env_timing_end_detail.argtypes = [vp, vp, fp, ip, fp]

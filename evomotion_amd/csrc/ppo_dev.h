@@ -32,6 +32,7 @@ struct PpoDev {
     float *xpad;    // [max_rows][384] observations, zero padded (staged once per update)
     double *loss;   // [2] actor, critic loss sums of the last evm_ppo_grads call
     double *gae;    // [3] n, mean, M2 of the raw advantages
+    int *step_dev;  // [1] device-side Adam step count of the actor (evm_ppo_actor_apply: SAC's captured update)
 };
 
 constexpr int PPO_SK = 64;       // split-K chunks of the weight-gradient GEMMs
@@ -48,6 +49,7 @@ hipError_t launch_ppo_loss(const PpoDev &d, size_t rows, const float *actions, c
                            float critic_loss_factor, hipStream_t s);
 hipError_t launch_ppo_backward(const PolicyDev &p, const PpoDev &d, size_t rows, hipStream_t s, int nets = 2);
 hipError_t launch_ppo_wgrads(const PpoDev &d, size_t rows, const float *states, hipStream_t s, int nets = 2);
+hipError_t launch_actor_apply(const PolicyDev &p, const PpoDev &d, float lr, hipStream_t s);
 hipError_t launch_ppo_apply(const PolicyDev &p, PpoDev &d, float lr, float clip_grad_norm, hipStream_t s);
 hipError_t launch_ppo_gae_scan(const PpoDev &d, int T, int N, const float *rewards, const uint8_t *done, const float *curr_values,
                                const float *next_values, const uint8_t *mask, float gamma, float lam, float *adv, hipStream_t s);

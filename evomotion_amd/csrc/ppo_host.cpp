@@ -72,6 +72,7 @@ int evm_ppo_create(EvmPolicy *policy, size_t max_rows, EvmPpo **out) {
     d.xpad = (float *) alloc(max_rows * 384 * 4);
     d.loss = (double *) alloc(2 * sizeof(double));
     d.gae = (double *) alloc(3 * sizeof(double));
+    d.step_dev = (int *) alloc(sizeof(int));
     if (ok && (hipEventCreate(&q->ev0) != hipSuccess || hipEventCreate(&q->ev1) != hipSuccess)) ok = false;
     if (!ok) {
         for (void *p : q->allocs) (void) hipFree(p);
@@ -97,6 +98,7 @@ int evm_ppo_set_params(EvmPpo *q, const float *d_actor, const float *d_critic, i
     hipError_t e = hipMemcpyAsync(d.actor.theta, d_actor, d.actor.n_params * 4, hipMemcpyDeviceToDevice, s);
     if (e == hipSuccess) e = hipMemcpyAsync(d.critic.theta, d_critic, d.critic.n_params * 4, hipMemcpyDeviceToDevice, s);
     if (e == hipSuccess && reset_optimizer) {
+        if (e == hipSuccess) e = hipMemsetAsync(d.step_dev, 0, sizeof(int), s);
         for (evm::PpoNet *n : {&d.actor, &d.critic}) {
             n->step = 0;
             if (e == hipSuccess) e = hipMemsetAsync(n->m, 0, n->n_params * 4, s);
@@ -201,6 +203,16 @@ int evm_ppo_actor_backward(EvmPpo *q, size_t rows, const float *d_dmu, const flo
     if (e == hipSuccess) e = evm::launch_ppo_backward(q->policy->dev, q->dev, rows, s, 1);
     if (e == hipSuccess) e = evm::launch_ppo_wgrads(q->dev, rows, nullptr, s, 1);
     if (e != hipSuccess) return qfail(EVM_E_HIP, std::string("actor backward: ") + hipGetErrorString(e));
+    return EVM_OK;
+}
+
+// Adam step of the actor alone (no clipping) with a DEVICE step counter, then the new weights into `policy`: SAC's actor
+// step (soft_actor_critic.cpp:144-153), replayable from a captured HIP graph.  reset_optimizer of evm_ppo_set_params zeroes
+// the counter.
+int evm_ppo_actor_apply(EvmPpo *q, float learning_rate, void *stream) {
+    if (!q) return qfail(EVM_E_INVALID, "trainer is null");
+    hipError_t e = evm::launch_actor_apply(q->policy->dev, q->dev, learning_rate, (hipStream_t) stream);
+    if (e != hipSuccess) return qfail(EVM_E_HIP, std::string("actor apply: ") + hipGetErrorString(e));
     return EVM_OK;
 }
 

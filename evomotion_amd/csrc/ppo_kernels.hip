@@ -533,6 +533,32 @@ __global__ __launch_bounds__(256) void k_ppo_adam(PpoDev d, float max_norm, floa
     B.theta[i] -= (lr / bc1) * (m / denom);
 }
 
+// the actor alone, no clipping, step count on the device (SAC's actor step inside a captured graph)
+__global__ __launch_bounds__(256) void k_actor_adam_dev(PpoDev d, float lr) {
+    const PpoNet &B = d.actor;
+    const size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
+    if (i >= B.n_params) return;
+    const int step = d.step_dev[0] + 1;
+    const float bc1 = (float) (1.0 - pow(0.9, (double) step));
+    const float bc2s = (float) sqrt(1.0 - pow(0.999, (double) step));
+    const float g = B.grad[i];
+    const float m = B.m[i] + (g - B.m[i]) * 0.1f;
+    const float v = B.v[i] * 0.999f + (g * g) * 0.001f;
+    B.m[i] = m;
+    B.v[i] = v;
+    B.theta[i] -= (lr / bc1) * (m / (sqrtf(v) / bc2s + 1e-8f));
+}
+__global__ void k_actor_step_inc(PpoDev d) {
+    if (threadIdx.x == 0) d.step_dev[0] += 1;
+}
+hipError_t launch_actor_apply(const PolicyDev &p, const PpoDev &d, float lr, hipStream_t s) {
+    hipLaunchKernelGGL(k_actor_adam_dev, dim3((unsigned) ((d.actor.n_params + 255) / 256)), dim3(256), 0, s, d, lr);
+    hipLaunchKernelGGL(k_actor_step_inc, dim3(1), dim3(64), 0, s, d);
+    hipError_t e = launch_policy_pack(p.actor, p.S, p.A, true, d.actor.theta, s);
+    if (e == hipSuccess) e = launch_ppo_pack_w2d(d.actor, p.S, s);
+    return e;
+}
+
 // Linear(256,256) weight -> the B operand of the dgrad GEMM: B[k = j][col = i] = W2[j][i], k-split as in mlp_tile.h
 __global__ __launch_bounds__(256) void k_ppo_pack_w2d(const float *__restrict__ w2, float *__restrict__ w2d) {
     const int e = blockIdx.x * 256 + threadIdx.x;  // e = j * 256 + i

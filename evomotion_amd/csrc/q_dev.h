@@ -47,6 +47,10 @@ size_t q_wpart_floats();
 hipError_t launch_sac_sample(int rows, int A, const float *mu, const float *sigma, const float *u, float *action, float *logp_sum, hipStream_t s);
 hipError_t launch_sac_actor_grad(int rows, int A, const float *mu, const float *sigma, const float *u, const float *dqda,
                                  const float *log_alpha, float *dmu, float *dsigma, hipStream_t s);
+hipError_t launch_sac_target(int rows, int A, const float *r, const float *done, const float *tq1, const float *tq2, const float *next_logp,
+                             const float *log_alpha, float gamma, float *out, hipStream_t s);
+hipError_t launch_sac_entropy(int rows, const float *logp_sum, const float *qmin, float target_entropy, float lr, float *log_alpha,
+                              float *state, int *step, float *losses, hipStream_t s);
 hipError_t launch_q_action_grad(const QDev &d, size_t rows, float *qmin, float *dqda, hipStream_t s);
 
 }  // namespace evm

@@ -219,6 +219,30 @@ int evm_sac_actor_grad(int rows, int action_dim, const float *d_mu, const float 
     return EVM_OK;
 }
 
+// target_q [rows] = r + (1 - done) * gamma * (min(tq1, tq2) - exp(log_alpha) * sum_a next_logp[., a])   (soft_actor_critic.cpp:108-116)
+int evm_sac_target_q(int rows, int action_dim, const float *d_rewards, const float *d_done, const float *d_tq1, const float *d_tq2,
+                     const float *d_next_logp, const float *d_log_alpha, float gamma, float *d_target_q, void *stream) {
+    if (!d_rewards || !d_done || !d_tq1 || !d_tq2 || !d_next_logp || !d_log_alpha || !d_target_q) return zfail(EVM_E_INVALID, "null argument");
+    if (rows < 1 || action_dim < 1) return zfail(EVM_E_INVALID, "empty batch");
+    hipError_t e = evm::launch_sac_target(rows, action_dim, d_rewards, d_done, d_tq1, d_tq2, d_next_logp, d_log_alpha, gamma, d_target_q,
+                                          (hipStream_t) stream);
+    if (e != hipSuccess) return zfail(EVM_E_HIP, std::string("sac target: ") + hipGetErrorString(e));
+    return EVM_OK;
+}
+
+// Adam step of the entropy parameter on  -mean(log_alpha * (logp_sum + target_entropy))  (soft_actor_critic.cpp:155-164).
+// d_log_alpha [1], d_adam_state [2] = exp_avg, exp_avg_sq, d_adam_step [1] (int) live in caller memory on the device;
+// d_losses [2] receives the actor loss mean(alpha * logp_sum - qmin) and the entropy loss, both before the step.
+int evm_sac_entropy_step(int rows, const float *d_logp_sum, const float *d_qmin, float target_entropy, float learning_rate,
+                         float *d_log_alpha, float *d_adam_state, int *d_adam_step, float *d_losses, void *stream) {
+    if (!d_logp_sum || !d_qmin || !d_log_alpha || !d_adam_state || !d_adam_step || !d_losses) return zfail(EVM_E_INVALID, "null argument");
+    if (rows < 1) return zfail(EVM_E_INVALID, "empty batch");
+    hipError_t e = evm::launch_sac_entropy(rows, d_logp_sum, d_qmin, target_entropy, learning_rate, d_log_alpha, d_adam_state, d_adam_step,
+                                           d_losses, (hipStream_t) stream);
+    if (e != hipSuccess) return zfail(EVM_E_HIP, std::string("sac entropy step: ") + hipGetErrorString(e));
+    return EVM_OK;
+}
+
 // DEVICE double[2]: the two critics' mse losses of the last evm_q_grads
 int evm_q_losses(EvmQ *q, double *d_out, void *stream) {
     if (!q || !d_out) return zfail(EVM_E_INVALID, "null argument");

@@ -327,6 +327,50 @@ __global__ __launch_bounds__(256) void k_sac_actor_grad(int n, int A, const floa
     dsigma[e] = (k * lp_s + g_a * da_ds) * t.cs;
 }
 
+// target_q = r + (1 - done) * gamma * (min(tq1, tq2) - alpha * sum_a next_logp)   (soft_actor_critic.cpp:108-116), each
+// operation rounded like the reference's tensor expression
+#pragma clang fp contract(off)
+__global__ __launch_bounds__(256) void k_sac_target(int n, int A, const float *__restrict__ r, const float *__restrict__ done,
+                                                   const float *__restrict__ tq1, const float *__restrict__ tq2,
+                                                   const float *__restrict__ next_logp, const float *__restrict__ log_alpha, float gamma,
+                                                   float *__restrict__ out) {
+    const size_t row = (size_t) blockIdx.x * 256 + threadIdx.x;
+    if (row >= (size_t) n) return;
+    float lp = 0.f;
+    for (int a = 0; a < A; a++) lp += next_logp[row * A + a];
+    const float alpha = expf(log_alpha[0]);
+    const float tv = fminf(tq1[row], tq2[row]) - alpha * lp;
+    out[row] = r[row] + ((1.0f - done[row]) * gamma) * tv;
+}
+#pragma clang fp contract(fast)
+
+// entropy parameter (soft_actor_critic.cpp:155-164): loss = -mean(log_alpha * (logp_sum + target_entropy)), one Adam step on the
+// scalar (state: exp_avg, exp_avg_sq, step on the device); also the actor loss value mean(alpha * logp_sum - qmin).  One block.
+__global__ __launch_bounds__(1024) void k_sac_entropy(int n, const float *__restrict__ logp_sum, const float *__restrict__ qmin,
+                                                      float target_entropy, float lr, float *log_alpha, float *state, int *step,
+                                                      float *__restrict__ losses) {
+    __shared__ double sh[16];
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = threadIdx.x; i < n; i += 1024) { s1 += (double) logp_sum[i]; s2 += (double) qmin[i]; }
+    const double mean_lp = block_sum_double(s1, sh) / n;
+    const double mean_q = block_sum_double(s2, sh) / n;
+    if (threadIdx.x == 0) {
+        const float la = log_alpha[0];
+        losses[0] = (float) ((double) expf(la) * mean_lp - mean_q);          // actor loss (with the alpha used in this update)
+        losses[1] = (float) (-(double) la * (mean_lp + (double) target_entropy));  // entropy loss
+        const float g = (float) (-(mean_lp + (double) target_entropy));
+        const int t = step[0] + 1;
+        const float bc1 = (float) (1.0 - pow(0.9, (double) t));
+        const float bc2s = (float) sqrt(1.0 - pow(0.999, (double) t));
+        const float m = state[0] + (g - state[0]) * 0.1f;
+        const float v = state[1] * 0.999f + (g * g) * 0.001f;
+        state[0] = m;
+        state[1] = v;
+        step[0] = t;
+        log_alpha[0] = la - (lr / bc1) * (m / (sqrtf(v) / bc2s + 1e-8f));
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------------
@@ -440,6 +484,17 @@ hipError_t launch_q_action_grad(const QDev &d, size_t rows, float *qmin, float *
     e = launch_q_backward(d, rows, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_q_input_grad, dim3((unsigned) ((rows * d.A + 255) / 256)), dim3(256), 0, s, d, (int) rows, dqda);
+    return hipGetLastError();
+}
+
+hipError_t launch_sac_target(int rows, int A, const float *r, const float *done, const float *tq1, const float *tq2, const float *next_logp,
+                             const float *log_alpha, float gamma, float *out, hipStream_t s) {
+    hipLaunchKernelGGL(k_sac_target, dim3((rows + 255) / 256), dim3(256), 0, s, rows, A, r, done, tq1, tq2, next_logp, log_alpha, gamma, out);
+    return hipGetLastError();
+}
+hipError_t launch_sac_entropy(int rows, const float *logp_sum, const float *qmin, float target_entropy, float lr, float *log_alpha,
+                              float *state, int *step, float *losses, hipStream_t s) {
+    hipLaunchKernelGGL(k_sac_entropy, dim3(1), dim3(1024), 0, s, rows, logp_sum, qmin, target_entropy, lr, log_alpha, state, step, losses);
     return hipGetLastError();
 }
 

@@ -166,6 +166,10 @@ class FusedPpoTrainer:
     def actor_backward(self, dmu, dsigma):
         check(lib.evm_ppo_actor_backward(self._h, dmu.shape[0], _ptr(dmu), _ptr(dsigma), self._stream()))
 
+    def actor_apply(self, learning_rate):
+        """Adam step of the actor alone, step counter on the device (replayable from a captured graph)"""
+        check(lib.evm_ppo_actor_apply(self._h, learning_rate, self._stream()))
+
     def set_flat(self, actor_flat, critic_flat, reset_optimizer=False):
         """flat device parameter vectors -> trainer and rollout kernel, asynchronously on the current stream"""
         check(lib.evm_ppo_set_params(self._h, _ptr(actor_flat), _ptr(critic_flat), 1 if reset_optimizer else 0, self._stream()))

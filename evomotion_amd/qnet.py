@@ -120,3 +120,19 @@ def sac_actor_grad(mu, sigma, u, dqda, log_alpha, dmu=None, dsigma=None):
     stream = ctypes.c_void_p(torch.cuda.current_stream(mu.device).cuda_stream)
     check(lib.evm_sac_actor_grad(rows, A, _ptr(mu), _ptr(sigma), _ptr(u), _ptr(dqda), _ptr(log_alpha), _ptr(dmu), _ptr(dsigma), stream))
     return dmu, dsigma
+
+
+def sac_target_q(rewards, done, tq1, tq2, next_logp, log_alpha, gamma, out=None):
+    """r + (1 - done) * gamma * (min(tq1, tq2) - alpha * sum_a next_logp)"""
+    rows, A = next_logp.shape
+    out = torch.empty(rows, device=rewards.device) if out is None else out
+    stream = ctypes.c_void_p(torch.cuda.current_stream(rewards.device).cuda_stream)
+    check(lib.evm_sac_target_q(rows, A, _ptr(rewards), _ptr(done), _ptr(tq1), _ptr(tq2), _ptr(next_logp), _ptr(log_alpha), gamma, _ptr(out), stream))
+    return out
+
+
+def sac_entropy_step(logp_sum, qmin, target_entropy, learning_rate, log_alpha, adam_state, adam_step, losses):
+    """one Adam step of log_alpha (in place); losses [2] <- actor loss, entropy loss"""
+    stream = ctypes.c_void_p(torch.cuda.current_stream(logp_sum.device).cuda_stream)
+    check(lib.evm_sac_entropy_step(logp_sum.numel(), _ptr(logp_sum), _ptr(qmin), target_entropy, learning_rate, _ptr(log_alpha),
+                                   _ptr(adam_state), _ptr(adam_step), _ptr(losses), stream))

@@ -160,43 +160,36 @@ class VecSacAgent:
             from .ppo import FusedPpoTrainer
             self._actor_tr = FusedPpoTrainer(self.fused, B)
             self._critic_dummy = z(self._actor_tr.n_params[1])
-            self._abuf = dict(mu=z(B, A), sigma=z(B, A), action=z(B, A), logp=z(B), qmin=z(B), dqda=z(B, A), dmu=z(B, A), dsigma=z(B, A))
+            self._abuf = dict(mu=z(B, A), sigma=z(B, A), action=z(B, A), logp=z(B), qmin=z(B), dqda=z(B, A), dmu=z(B, A), dsigma=z(B, A),
+                              target_q=z(B), losses=z(2))
+            self._ent_state = z(2)                                                   # Adam exp_avg, exp_avg_sq of log_alpha
+            self._ent_step = torch.zeros(1, device=self.device, dtype=torch.int32)
             self._push_actor()
 
     def _push_actor(self):
-        """the actor's torch parameters and gradients become views of two flat buffers: the trainer reads the first and
-        writes the second, torch's Adam steps in between"""
-        ps = list(self.actor.parameters())
-        self._actor_flat = torch.cat([p.detach().reshape(-1) for p in ps]).contiguous()
-        self._actor_grad = torch.zeros_like(self._actor_flat)
-        o = 0
-        for p in ps:
-            p.data = self._actor_flat[o:o + p.numel()].view_as(p)
-            p.grad = self._actor_grad[o:o + p.numel()].view_as(p)
-            o += p.numel()
-        self._actor_tr.set_flat(self._actor_flat, self._critic_dummy, reset_optimizer=True)
+        """the actor module -> the trainer, which owns its master weights and Adam state from here on (sync_modules() copies
+        them back)"""
+        flat = torch.cat([p.detach().reshape(-1) for p in self.actor.parameters()]).contiguous()
+        self._actor_tr.set_flat(flat, self._critic_dummy, reset_optimizer=True)
+        torch.cuda.current_stream(self.device).synchronize()
 
     def _push_critics(self):
-        """modules -> the HIP trainer; the critics' torch parameters become views of flat buffers the trainer's weights are
-        copied into after each update (the actor step differentiates through them w.r.t. the action only)"""
-        mods = (self.critic_1, self.critic_2, self.target_critic_1, self.target_critic_2)
-        for i, m in enumerate(mods):
+        """critic / target modules -> the HIP trainer, which owns their weights from here on"""
+        for i, m in enumerate((self.critic_1, self.critic_2, self.target_critic_1, self.target_critic_2)):
             self.twinq.load_module(i, m)
-        self._critic_flat = []
-        for m in mods[:2]:
-            flat = torch.cat([p.detach().reshape(-1) for p in m.parameters()]).contiguous()
-            o = 0
-            for p in m.parameters():
-                p.data = flat[o:o + p.numel()].view_as(p)
-                p.requires_grad_(False)
-                o += p.numel()
-            self._critic_flat.append(flat)
 
     def sync_modules(self):
-        """the trainer's critic / target weights -> the torch modules (save(), evaluation)"""
+        """the trainers' actor / critic / target weights -> the torch modules (save(), evaluation)"""
         if self.twinq is None:
             return
         from .qnet import PARAMS
+        from .ppo import PARAMS as PP, ACTOR
+        flat = self._actor_tr.vector(PP, ACTOR)
+        o = 0
+        with torch.no_grad():
+            for p in self.actor.parameters():
+                p.copy_(flat[o:o + p.numel()].view_as(p))
+                o += p.numel()
         for i, m in enumerate((self.critic_1, self.critic_2, self.target_critic_1, self.target_critic_2)):
             flat = self.twinq.vector(PARAMS, i)
             o = 0
@@ -205,60 +198,63 @@ class VecSacAgent:
                     p.copy_(flat[o:o + p.numel()].view_as(p))
                     o += p.numel()
 
-    def _train_once_hip(self):
-        """SoftActorCriticAgent::train (soft_actor_critic.cpp:93-170) with the Q side on the device"""
-        from .agent import truncated_normal_log_pdf, truncated_normal_sample
-        from .qnet import GRADS, PARAMS
+    def _train_once_hip(self, u_next=None, u_curr=None):
+        """SoftActorCriticAgent::train (soft_actor_critic.cpp:93-170) on the device; u_next / u_curr override the two
+        uniform draws (tests)"""
+        from .ppo import GRADS as PGRADS, ACTOR
+        from .qnet import GRADS, sac_actor_grad, sac_entropy_step, sac_sample, sac_target_q
         s, a, r, d, n = self._batch
-        B = s.shape[0]
+        B, A = s.shape[0], self.fused.A
+        ab = self._abuf
+        log_alpha = self.entropy.log_alpha.detach()
+        dist_on = (not self.use_graph and torch.distributed.is_available() and torch.distributed.is_initialized()
+                   and torch.distributed.get_world_size() > 1)
+
+        def all_reduce_mean(g):
+            if torch.distributed.get_backend() != "nccl":
+                h = g.cpu(); torch.distributed.all_reduce(h); g.copy_(h)
+            else:
+                torch.distributed.all_reduce(g)
+            return g / torch.distributed.get_world_size()
+
         # targets (:100-116): next action ~ actor(next state) from the fused policy kernel, twin target Q, entropy term
-        u_next = torch.rand(B, self.fused.A, device=self.device)
+        u_next = torch.rand(B, A, device=self.device) if u_next is None else u_next
         next_action, next_logp, _ = self.fused.forward(n, uniform=u_next, actor_only=True, out=self._next_act)
         tq = self.twinq.forward((2, 3), n, next_action, out=self._tq_out)
-        alpha = self.entropy.alpha().detach()
-        target_q = (r + (1.0 - d) * self.gamma * (torch.min(tq[2], tq[3]) - alpha * next_logp.sum(-1))).contiguous()
+        sac_target_q(r, d, tq[2], tq[3], next_logp, log_alpha, self.gamma, ab["target_q"])
         # critics (:118-127)
-        self.twinq.grads(s, a, target_q)
-        if not self.use_graph and torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
-            w = torch.distributed.get_world_size()
+        self.twinq.grads(s, a, ab["target_q"])
+        if dist_on:
             for i in (0, 1):
-                g = self.twinq.vector(GRADS, i)
-                if torch.distributed.get_backend() != "nccl":
-                    h = g.cpu(); torch.distributed.all_reduce(h); g.copy_(h)
-                else:
-                    torch.distributed.all_reduce(g)
-                self.twinq.load_vector(GRADS, i, g / w)
+                self.twinq.load_vector(GRADS, i, all_reduce_mean(self.twinq.vector(GRADS, i)))
         self.twinq.apply(self.learning_rate)
-        for i in (0, 1):
-            self.twinq.vector(PARAMS, i, out=self._critic_flat[i])
-        # actor (:129-153): forward, reparameterised sample, twin-critic action gradient, loss gradient and backward on the
-        # device; torch's Adam steps the flat parameter buffer
-        from .ppo import GRADS as PGRADS, ACTOR
-        from .qnet import sac_actor_grad, sac_sample
-        ab = self._abuf
-        u_curr = torch.rand(B, self.fused.A, device=self.device)
+        # actor (:129-153): forward, reparameterised sample, action gradient through the twin critics, loss gradient,
+        # backward, Adam
+        u_curr = torch.rand(B, A, device=self.device) if u_curr is None else u_curr
         self._actor_tr.actor_forward(s, ab["mu"], ab["sigma"])
         sac_sample(ab["mu"], ab["sigma"], u_curr, ab["action"], ab["logp"])
         self.twinq.action_grad(s, ab["action"], ab["qmin"], ab["dqda"])
-        sac_actor_grad(ab["mu"], ab["sigma"], u_curr, ab["dqda"], self.entropy.log_alpha.detach(), ab["dmu"], ab["dsigma"])
+        sac_actor_grad(ab["mu"], ab["sigma"], u_curr, ab["dqda"], log_alpha, ab["dmu"], ab["dsigma"])
         self._actor_tr.actor_backward(ab["dmu"], ab["dsigma"])
-        self._actor_tr.vector(PGRADS, ACTOR, out=self._actor_grad)
-        if not self.use_graph:
-            self._grad_hook(list(self.actor.parameters()))
-        self.actor_opt.step()
-        loss_actor = torch.mean(alpha * ab["logp"] - ab["qmin"])
-        # entropy parameter (:155-164)
-        loss_entropy = -torch.mean(self.entropy.log_alpha * (ab["logp"] + self.target_entropy))
-        self.entropy_opt.zero_grad()
-        loss_entropy.backward()
-        if not self.use_graph:
+        if dist_on:
+            self._actor_tr.load_vector(PGRADS, ACTOR, all_reduce_mean(self._actor_tr.vector(PGRADS, ACTOR)))
+        self._actor_tr.actor_apply(self.learning_rate)
+        # entropy parameter (:155-164) and the loss values
+        if dist_on:  # the parameter's gradient is a mean over the global batch: autograd + the gradient hook
+            alpha = log_alpha.exp()
+            loss_actor = torch.mean(alpha * ab["logp"] - ab["qmin"])
+            loss_entropy = -torch.mean(self.entropy.log_alpha * (ab["logp"] + self.target_entropy))
+            self.entropy_opt.zero_grad()
+            loss_entropy.backward()
             self._grad_hook(list(self.entropy.parameters()))
-        self.entropy_opt.step()
+            self.entropy_opt.step()
+            ab["losses"].copy_(torch.stack([loss_actor.detach(), loss_entropy.detach()]))
+        else:
+            sac_entropy_step(ab["logp"], ab["qmin"], self.target_entropy, self.learning_rate, log_alpha, self._ent_state, self._ent_step,
+                             ab["losses"])
         self.twinq.soft_update(self.tau)
-        # new actor weights -> trainer and rollout kernel (the next target actions and the rollout use them)
-        self._actor_tr.set_flat(self._actor_flat, self._critic_dummy)
         lq = self.twinq.losses()
-        return dict(actor=loss_actor.detach(), critic_1=lq[0], critic_2=lq[1], entropy=loss_entropy.detach())
+        return dict(actor=ab["losses"][0], critic_1=lq[0], critic_2=lq[1], entropy=ab["losses"][1])
 
     def count_parameters(self):
         from .agent import count_parameters

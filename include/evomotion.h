@@ -241,6 +241,9 @@ int evm_ppo_grads(EvmPpo *q, size_t rows, const float *d_states, const float *d_
  * gradients from d loss / d(mu, sigma) supplied by the caller (evm_sac_actor_grad); gradients via evm_ppo_copy(1, 0, ...) */
 int evm_ppo_actor_forward(EvmPpo *q, size_t rows, const float *d_states, float *d_mu, float *d_sigma, void *stream);
 int evm_ppo_actor_backward(EvmPpo *q, size_t rows, const float *d_dmu, const float *d_dsigma, void *stream);
+/* Adam step (no clipping) of the actor alone with a DEVICE step counter (zeroed by evm_ppo_set_params with
+ * reset_optimizer), then the new weights into `policy`: replayable from a captured HIP graph */
+int evm_ppo_actor_apply(EvmPpo *q, float learning_rate, void *stream);
 /* clip_grad_norm_(clip_grad_norm) and Adam(lr, betas 0.9 / 0.999, eps 1e-8) for both networks, then the new weights into
  * `policy` */
 int evm_ppo_apply(EvmPpo *q, float learning_rate, float clip_grad_norm, void *stream);
@@ -285,6 +288,14 @@ int evm_sac_sample(int rows, int action_dim, const float *d_mu, const float *d_s
  * (soft_actor_critic.cpp:129-142); d_dqda from evm_q_action_grad, d_log_alpha a DEVICE scalar; outputs [rows, A] */
 int evm_sac_actor_grad(int rows, int action_dim, const float *d_mu, const float *d_sigma, const float *d_uniform, const float *d_dqda,
                        const float *d_log_alpha, float *d_dmu, float *d_dsigma, void *stream);
+/* target_q [rows] = r + (1 - done) * gamma * (min(tq1, tq2) - exp(log_alpha) * sum_a next_logp[., a])  (soft_actor_critic.cpp:108-116) */
+int evm_sac_target_q(int rows, int action_dim, const float *d_rewards, const float *d_done, const float *d_tq1, const float *d_tq2,
+                     const float *d_next_logp, const float *d_log_alpha, float gamma, float *d_target_q, void *stream);
+/* Adam step of the entropy parameter on -mean(log_alpha * (logp_sum + target_entropy)) (soft_actor_critic.cpp:155-164).
+ * d_log_alpha [1], d_adam_state [2] (exp_avg, exp_avg_sq) and d_adam_step [1] (int) are DEVICE memory of the caller;
+ * d_losses [2] receives the actor loss mean(alpha * logp_sum - qmin) and the entropy loss, both before the step. */
+int evm_sac_entropy_step(int rows, const float *d_logp_sum, const float *d_qmin, float target_entropy, float learning_rate,
+                         float *d_log_alpha, float *d_adam_state, int *d_adam_step, float *d_losses, void *stream);
 /* DEVICE double[2]: the critics' losses of the last evm_q_grads */
 int evm_q_losses(EvmQ *q, double *d_out, void *stream);
 

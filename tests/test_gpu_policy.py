@@ -259,6 +259,7 @@ def test_sac_hip_update_matches_torch_update():
         torch.manual_seed(100 + it); lr_ = ref._train_once()
         for k in ("critic_1", "critic_2", "actor", "entropy"):
             assert abs(float(lh[k]) - float(lr_[k])) < 2e-4 * max(1.0, abs(float(lr_[k]))), (it, k, float(lh[k]), float(lr_[k]))
+    hip.sync_modules()  # the trainers own the weights; the torch modules are refreshed on demand
     pairs = [(hip.twinq.vector(PARAMS, 0), _flat(ref.critic_1)), (hip.twinq.vector(PARAMS, 1), _flat(ref.critic_2)),
              (hip.twinq.vector(PARAMS, 2), _flat(ref.target_critic_1)), (hip.twinq.vector(PARAMS, 3), _flat(ref.target_critic_2)),
              (_flat(hip.actor), _flat(ref.actor)), (_flat(hip.entropy), _flat(ref.entropy))]
@@ -266,10 +267,16 @@ def test_sac_hip_update_matches_torch_update():
         dd = (x - y).abs()
         # two Adam steps of 1e-3: rounding-level gradient differences move a parameter only where |g| ~ 1e-8
         assert float(dd.max()) <= 2.1e-3 and float((dd > 5e-5).float().mean()) < 1e-3, (i, float(dd.max()), float((dd > 5e-5).float().mean()))
-    # the critics' torch views follow the trainer; the fused policy kernel has the new actor
     assert torch.equal(_flat(hip.critic_1), hip.twinq.vector(PARAMS, 0))
-    hip.sync_modules()
     assert torch.equal(_flat(hip.target_critic_2), hip.twinq.vector(PARAMS, 3))
+    # the rollout kernel already has the new actor
+    x = s[:64]
+    u = torch.full((64, 12), 0.5, device="cuda")
+    _, _, _, mu_k, _ = hip.fused.forward(x, uniform=u, want_dist=True, actor_only=True)
+    hip.actor.eval()
+    with torch.no_grad():
+        mu_t, _ = hip.actor(x)
+    np.testing.assert_allclose(mu_k.cpu().numpy(), mu_t.cpu().numpy(), atol=2e-5)
 
 
 def test_sac_hip_agent_graph_replay():
