@@ -183,3 +183,44 @@ def test_sac_actor_step_gradients_match_autograd():
         assert float((a - b).abs().max()) <= 1e-3 * float(b.abs().max()) + 1e-8, (name, float((a - b).abs().max()), float(b.abs().max()))
         o += n
     assert float((got - ref).abs().max()) <= 2e-4 * float(ref.abs().max())
+
+
+def test_sac_train_call_reproduces_reference_golden():
+    """the reference's own SoftActorCriticAgent::train call (tests/golden/sac_golden.txt: pattern weights, recorded uniform
+    draws) through the device path of VecSacAgent"""
+    import torch
+    from evomotion_amd import VecSacAgent
+    path = os.path.join(ROOT, "tests", "golden", "sac_golden.txt")
+    gold = golden_io.load(path)
+    sc = {l.split()[1]: float(l.split()[2]) for l in open(path) if l.startswith("scalar ")}
+    t = lambda k: torch.from_numpy(gold[k]).cuda()
+    rows = gold["sac_states"].shape[0]
+    ag = VecSacAgent(0, [371], [12], batch_size=rows, epoch=1, replay_buffer_size=4, train_every=2, n_envs=64, use_graph=False)
+    def load(module, shapes, base):
+        p = ao.pattern_params(shapes, base)
+        with torch.no_grad():
+            for n, tt in module.named_parameters():
+                tt.copy_(torch.from_numpy(p[n]))
+    load(ag.actor, ao.ACTOR_SHAPES, 100)
+    for m, base in zip((ag.critic_1, ag.critic_2, ag.target_critic_1, ag.target_critic_2), (300, 400, 500, 600)):
+        load(m, ao.Q_SHAPES, base)
+    ag._push_critics(); ag._push_actor()
+    assert abs(sc["target_entropy"] - ag.target_entropy) < 1e-9
+    for dst, k in zip(ag._batch, ("sac_states", "sac_actions", "sac_rewards", "sac_done", "sac_next_states")):
+        dst.copy_(t(k).reshape(dst.shape))
+    out = ag._train_once_hip(u_next=t("sac_u_next"), u_curr=t("sac_u_curr"))
+    assert abs(float(out["critic_1"]) - sc["loss_critic_1"]) < 2e-4 * abs(sc["loss_critic_1"])
+    assert abs(float(out["critic_2"]) - sc["loss_critic_2"]) < 2e-4 * abs(sc["loss_critic_2"])
+    assert abs(float(out["actor"]) - sc["loss_actor"]) < 2e-4 * abs(sc["loss_actor"])
+    assert abs(float(out["entropy"]) - sc["loss_entropy"]) < 1e-5
+    x, a = t("sac_states"), t("sac_actions")
+    u = torch.full((rows, 12), 0.5, device="cuda")
+    _, _, _, mu, sigma = ag.fused.forward(x, uniform=u, want_dist=True, actor_only=True)
+    np.testing.assert_allclose(mu.cpu().numpy(), gold["after_mu"], atol=1e-4)
+    np.testing.assert_allclose(sigma.cpu().numpy(), gold["after_sigma"], atol=1e-4, rtol=1e-4)
+    q = ag.twinq.forward([0, 1, 2, 3], x, a)
+    np.testing.assert_allclose(q[0].cpu().numpy(), gold["after_q1"].ravel(), atol=2e-4)
+    np.testing.assert_allclose(q[1].cpu().numpy(), gold["after_q2"].ravel(), atol=2e-4)
+    np.testing.assert_allclose(q[2].cpu().numpy(), gold["after_tq1"].ravel(), atol=1e-4)
+    np.testing.assert_allclose(q[3].cpu().numpy(), gold["after_tq2"].ravel(), atol=1e-4)
+    np.testing.assert_allclose(ag.entropy.log_alpha.detach().cpu().numpy(), gold["after_log_alpha"].ravel(), atol=2e-6)
