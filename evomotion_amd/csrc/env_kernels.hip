@@ -1532,6 +1532,9 @@ DEV void sweeps_run(const Ctx &c, bool any_pending, unsigned cmask, int ncontact
 #ifdef EVM_STAMPS3
         {
             const unsigned long long dt = __builtin_amdgcn_s_memtime() - ts0;
+#ifdef EVM_STAMPS3_HULL  // split the active contact entries by hull size (cubes vs the 509-vertex feet)
+            if (active && c_skel.member[m].hull_n <= 8) { t_type[3] += dt; n_type[3]++; } else
+#endif
             if (active) { t_type[4] += dt; n_type[4]++; } else { t_type[5] += dt; n_type[5]++; }
         }
 #endif
