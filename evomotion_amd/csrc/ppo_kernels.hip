@@ -201,12 +201,10 @@ __global__ __launch_bounds__(256) void k_ppo_loss_critic(PpoDev d, int n, const 
 template <int RT>
 __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_ppo_backward(PolicyDev p, PpoDev d, int n) {
     constexpr int TM = 32 * RT, PARTS = PT / TM, RUN = 256 / PARTS;
-    constexpr int TD = TM * ALD2 > 32 * 256 + TM * 32 ? TM * ALD2 : 32 * 256 + TM * 32;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float *Tz = sm;             // z tile, then scratch for the column sums
     float *Td = sm + TM * ALD2; // gradient tile (A operand of the dgrad GEMM); first life: head weights + dh tile
     float *wl = Td, *dhs = Td + 32 * 256;
-    (void) TD;
     const int net = blockIdx.y;
     const int row0 = blockIdx.x * TM;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
