@@ -1900,9 +1900,31 @@ __global__ __launch_bounds__(64 * EVM_NW) void k_split_sweeps(EnvDev d, const ui
     const bool any_pending = __any((flags_in & EVM_FLAG_PENDING) != 0 || fin);
     // tile: staging copy -> LDS (solver deltas with the contact warm start, world inverse inertia); versions start at 0
     {
+        // An attach sphere (isotropic, no contacts) starts every step with zero deltas, and its inertia tile is read only by
+        // the general muscle path (a step that follows a reset): neither is fetched otherwise.
         const float *g = tile_stage(d);
-        const int nfl = c_skel.nb * 12;  // slots of 64 lanes
-        for (int k = c.wave; k < nfl; k += EVM_NW) c.lds[(k << 6) + c.lane] = g[(k << 6) + c.lane];
+        const int nb6 = c_skel.nb * 6;
+        for (int b = c.wave; b < c_skel.nb; b += EVM_NW) {
+            const bool light = b >= c_skel.nm && c_skel.body[b].isotropic;
+            float v[12];
+            if (!light || any_pending) {
+#pragma unroll
+                for (int k = 0; k < 6; k++) v[6 + k] = g[((nb6 + b * 6 + k) << 6) + c.lane];
+            }
+            if (!light) {
+#pragma unroll
+                for (int k = 0; k < 6; k++) v[k] = g[((b * 6 + k) << 6) + c.lane];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 6; k++) v[k] = 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < 6; k++) c.lds[((b * 6 + k) << 6) + c.lane] = v[k];
+            if (!light || any_pending) {
+#pragma unroll
+                for (int k = 0; k < 6; k++) c.lds[((nb6 + b * 6 + k) << 6) + c.lane] = v[6 + k];
+            }
+        }
         if (c.wave == 0) for (int b = 0; b < c_skel.nb; b++) LVER(c)[b] = 0;  // every live lane writes: a ragged tile may have one
     }
     int ncontact = 0;
