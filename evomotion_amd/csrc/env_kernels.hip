@@ -1866,10 +1866,21 @@ __global__ __launch_bounds__(64 * EVM_SPLIT_WAVES) void k_split_pre_b(EnvDev d, 
             const int m = j;
             int n = 0;
             MPoint pts[4];
+#ifdef EVM_STAMPS5
+            const unsigned long long s5_a = __builtin_amdgcn_s_memtime();
+#endif
             if (c_skel.member[m].contact_response) n = contact_update(c, m, pts, L.fin);
             else if (__any(L.fin)) { if (L.fin) GS(mfn, m) = 0; }
-            if (__any(n > 0)) contact_setup(c, m, n, pts);
-            else { SSC3(c_skel.sc_pt + 6 * m, f3(0.f, 0.f, 0.f)); SSC3(c_skel.sc_pt + 6 * m + 3, f3(0.f, 0.f, 0.f)); }
+#ifdef EVM_STAMPS5  // slots 6 / 7: longest manifold update, longest contact-row setup of a member
+            const unsigned long long s5_b = __builtin_amdgcn_s_memtime();
+            if (c.lane == 0) atomicMax(&c.d.stamps[(size_t) blockIdx.x * 16 + 6], s5_b - s5_a);
+#endif
+            const bool touching = __any(n > 0);
+            if (touching) contact_setup(c, m, n, pts);
+#ifdef EVM_STAMPS5
+            if (c.lane == 0) atomicMax(&c.d.stamps[(size_t) blockIdx.x * 16 + 7], __builtin_amdgcn_s_memtime() - s5_b);
+#endif
+            if (!touching) { SSC3(c_skel.sc_pt + 6 * m, f3(0.f, 0.f, 0.f)); SSC3(c_skel.sc_pt + 6 * m + 3, f3(0.f, 0.f, 0.f)); }
             continue;
         }
         const EvmVisitC &V = c_skel.visit[j - c_skel.nm];

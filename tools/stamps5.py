@@ -21,7 +21,7 @@ for k in range(120):
     if k >= 70:
         st = (ctypes.c_ulonglong * (n // 64 * 16))()
         check(lib.evm_env_get_stamps(env._h, st))
-        acc.append(np.array(st, dtype=np.uint64).reshape(-1, 16)[:, :6].astype(np.float64))
+        acc.append(np.array(st, dtype=np.uint64).reshape(-1, 16)[:, :8].astype(np.float64))
 a = np.stack(acc)[-1]  # max since creation (never cleared): upper envelope
-for q, name in enumerate(["hinge", "fixed", "slider", "p2p", "member (cube hull)", "member (foot hull)"]):
+for q, name in enumerate(["hinge", "fixed", "slider", "p2p", "member (cube hull)", "member (foot hull)", "  manifold update", "  contact-row setup"]):
     print("%-20s longest item: median over tiles %8.0f cycles, max %8.0f" % (name, np.median(a[:, q]), a[:, q].max()))
