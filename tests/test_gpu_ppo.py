@@ -274,3 +274,44 @@ def test_agent_update_save_load_round_trip(tmp_path):
         assert ag._trainer.adam_step(net) == ag2._trainer.adam_step(net) == 4
         for what in (PARAMS, EXP_AVG, EXP_AVG_SQ):
             assert torch.equal(ag._trainer.vector(what, net), ag2._trainer.vector(what, net))
+
+
+def test_full_size_gradients_are_the_sum_of_their_halves():
+    """BASELINE size (4096 envs x horizon 32 = 131 072 rows): the losses are sums over rows divided by the global count, so
+    the gradient of the whole batch equals the sum of the gradients of its two halves (each computed with the global
+    count) — exercises the split-K reductions and every tile at full size without an oracle of that size."""
+    import torch
+    from evomotion_amd import agent
+    from evomotion_amd._lib import lib, check
+    from evomotion_amd.ppo import GRADS, ACTOR, CRITIC, _ptr
+    rows = 131072
+    actor, critic = _modules(seed=11)
+    f, tr = _trainer(actor, critic, rows)
+    g = torch.Generator(device="cuda"); g.manual_seed(12)
+    states = (torch.rand(rows, 371, device="cuda", generator=g) * 2 - 1) * 1.5
+    f.load_modules(actor, critic)
+    u = torch.rand(rows, 12, device="cuda", generator=g)
+    actions, logp, _ = f.forward(states, uniform=u)
+    logp_old = logp + 0.3 * (torch.rand(rows, 12, device="cuda", generator=g) * 2 - 1)
+    adv = torch.randn(rows, device="cuda", generator=g)
+    returns = torch.randn(rows, device="cuda", generator=g)
+    mask = (torch.rand(rows, device="cuda", generator=g) > 0.25).to(torch.uint8)
+    n_glob = float(mask.sum())
+
+    def grads(lo, hi):
+        check(lib.evm_ppo_grads(tr._h, hi - lo, _ptr(states[lo:hi]), _ptr(actions[lo:hi]), _ptr(logp_old[lo:hi]), _ptr(adv[lo:hi]),
+                                _ptr(returns[lo:hi]), _ptr(mask[lo:hi]), n_glob, HP["epsilon"], HP["entropy_factor"],
+                                HP["critic_loss_factor"], 0, tr._stream()))
+        la, lc = tr.losses()
+        return tr.vector(GRADS, ACTOR).clone(), tr.vector(GRADS, CRITIC).clone(), la, lc
+
+    fa, fc, la, lc = grads(0, rows)
+    ha1, hc1, la1, lc1 = grads(0, rows // 2)
+    ha2, hc2, la2, lc2 = grads(rows // 2, rows)
+    assert abs(la - (la1 + la2)) < 1e-6 * max(1.0, abs(la)) and abs(lc - (lc1 + lc2)) < 1e-6 * max(1.0, abs(lc))
+    for full, parts in ((fa, ha1 + ha2), (fc, hc1 + hc2)):
+        assert torch.isfinite(full).all()
+        assert float((full - parts).abs().max()) <= 2e-5 * float(full.abs().max())
+    # and the same call twice gives the same bits (fixed reduction order)
+    fa2, fc2, _, _ = grads(0, rows)
+    assert torch.equal(fa, fa2) and torch.equal(fc, fc2)
