@@ -72,6 +72,7 @@ int evm_ppo_create(EvmPolicy *policy, size_t max_rows, EvmPpo **out) {
     d.xpad = (float *) alloc(max_rows * 384 * 4);
     d.loss = (double *) alloc(2 * sizeof(double));
     d.gae = (double *) alloc(3 * sizeof(double));
+    d.gae_part = (double *) alloc(((max_rows + 255) / 256) * 3 * sizeof(double));
     d.step_dev = (int *) alloc(sizeof(int));
     if (ok && (hipEventCreate(&q->ev0) != hipSuccess || hipEventCreate(&q->ev1) != hipSuccess)) ok = false;
     if (!ok) {

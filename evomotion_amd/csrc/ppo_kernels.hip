@@ -569,13 +569,15 @@ __global__ __launch_bounds__(256) void k_ppo_pack_w2d(const float *__restrict__ 
 // GAE (ppo_gae.cpp:127-150), time-major [T][N] rollouts
 // ---------------------------------------------------------------------------------------------------------
 #pragma clang fp contract(off)
-__global__ __launch_bounds__(1024) void k_ppo_gae_scan(int T, int N, const float *__restrict__ rewards, const uint8_t *__restrict__ done,
-                                                       const float *__restrict__ cv, const float *__restrict__ nv,
-                                                       const uint8_t *__restrict__ mask, float gamma, float gl, float *__restrict__ adv,
-                                                       double *__restrict__ stats) {
-    __shared__ double sh[16];
+// one thread per env: backward scan over the horizon; per-block (count, sum) of the selected advantages
+__global__ __launch_bounds__(256) void k_ppo_gae_scan(int T, int N, const float *__restrict__ rewards, const uint8_t *__restrict__ done,
+                                                      const float *__restrict__ cv, const float *__restrict__ nv,
+                                                      const uint8_t *__restrict__ mask, float gamma, float gl, float *__restrict__ adv,
+                                                      double *__restrict__ part) {
+    __shared__ double sh[4];
+    const int n = blockIdx.x * 256 + threadIdx.x;
     double cnt = 0.0, sum = 0.0;
-    for (int n = threadIdx.x; n < N; n += 1024) {
+    if (n < N) {
         float g = 0.f;
         for (int t = T - 1; t >= 0; t--) {
             const size_t i = (size_t) t * N + n;
@@ -588,17 +590,37 @@ __global__ __launch_bounds__(1024) void k_ppo_gae_scan(int T, int N, const float
             if (mask[i]) { cnt += 1.0; sum += (double) g; }
         }
     }
-    const double n_all = block_sum_double(cnt, sh);
+    const double c_all = block_sum_double(cnt, sh);
     const double s_all = block_sum_double(sum, sh);
-    const double mean = n_all > 0.0 ? s_all / n_all : 0.0;
+    if (threadIdx.x == 0) { part[3 * blockIdx.x] = c_all; part[3 * blockIdx.x + 1] = s_all; }
+}
+// partials -> count and mean (fixed order)
+__global__ __launch_bounds__(64) void k_ppo_gae_mean(int nblocks, const double *__restrict__ part, double *__restrict__ stats) {
+    if (threadIdx.x != 0) return;
+    double c = 0.0, s = 0.0;
+    for (int b = 0; b < nblocks; b++) { c += part[3 * b]; s += part[3 * b + 1]; }
+    stats[0] = c;
+    stats[1] = c > 0.0 ? s / c : 0.0;
+}
+__global__ __launch_bounds__(256) void k_ppo_gae_m2(int T, int N, const uint8_t *__restrict__ mask, const float *__restrict__ adv,
+                                                    const double *__restrict__ stats, double *__restrict__ part) {
+    __shared__ double sh[4];
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const double mean = stats[1];
     double m2 = 0.0;
-    for (int n = threadIdx.x; n < N; n += 1024)
+    if (n < N)
         for (int t = 0; t < T; t++) {
             const size_t i = (size_t) t * N + n;
             if (mask[i]) { const double dd = (double) adv[i] - mean; m2 += dd * dd; }
         }
-    const double m2_all = block_sum_double(m2, sh);
-    if (threadIdx.x == 0) { stats[0] = n_all; stats[1] = mean; stats[2] = m2_all; }
+    const double all = block_sum_double(m2, sh);
+    if (threadIdx.x == 0) part[3 * blockIdx.x + 2] = all;
+}
+__global__ __launch_bounds__(64) void k_ppo_gae_m2sum(int nblocks, const double *__restrict__ part, double *__restrict__ stats) {
+    if (threadIdx.x != 0) return;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; b++) s += part[3 * b + 2];
+    stats[2] = s;
 }
 __global__ __launch_bounds__(256) void k_ppo_gae_finish(size_t total, const double *__restrict__ stats, const float *__restrict__ cv,
                                                         float *__restrict__ adv, float *__restrict__ returns) {
@@ -772,7 +794,11 @@ hipError_t launch_ppo_apply(const PolicyDev &p, PpoDev &d, float lr, float clip_
 hipError_t launch_ppo_gae_scan(const PpoDev &d, int T, int N, const float *rewards, const uint8_t *done, const float *curr_values,
                                const float *next_values, const uint8_t *mask, float gamma, float lam, float *adv, hipStream_t s) {
     const float gl = (float) ((double) gamma * (double) lam);
-    hipLaunchKernelGGL(k_ppo_gae_scan, dim3(1), dim3(1024), 0, s, T, N, rewards, done, curr_values, next_values, mask, gamma, gl, adv, d.gae);
+    const int nblocks = (N + 255) / 256;
+    hipLaunchKernelGGL(k_ppo_gae_scan, dim3(nblocks), dim3(256), 0, s, T, N, rewards, done, curr_values, next_values, mask, gamma, gl, adv, d.gae_part);
+    hipLaunchKernelGGL(k_ppo_gae_mean, dim3(1), dim3(64), 0, s, nblocks, d.gae_part, d.gae);
+    hipLaunchKernelGGL(k_ppo_gae_m2, dim3(nblocks), dim3(256), 0, s, T, N, mask, adv, d.gae, d.gae_part);
+    hipLaunchKernelGGL(k_ppo_gae_m2sum, dim3(1), dim3(64), 0, s, nblocks, d.gae_part, d.gae);
     return hipGetLastError();
 }
 hipError_t launch_ppo_gae_finish(int T, int N, const double *stats, const float *curr_values, const uint8_t *mask, float *adv,
