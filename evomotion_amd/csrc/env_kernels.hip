@@ -1838,8 +1838,11 @@ __global__ __launch_bounds__(64 * EVM_SPLIT_WAVES) void k_split_pre_a(EnvDev d, 
     }
 }
 
+#ifndef EVM_PRE_B_WAVES
+#define EVM_PRE_B_WAVES 3
+#endif
 template <int MODE>
-__global__ __launch_bounds__(64 * EVM_SPLIT_WAVES) void k_split_pre_b(EnvDev d, const float *__restrict__ action,
+__global__ __launch_bounds__(64 * EVM_SPLIT_WAVES) __attribute__((amdgpu_waves_per_eu(EVM_PRE_B_WAVES, EVM_PRE_B_WAVES))) void k_split_pre_b(EnvDev d, const float *__restrict__ action,
                                                                         const uint8_t *__restrict__ mask) {
     Ctx c = make_ctx(d, tile_stage(d));
     EVM_SPLIT_GUARD()
