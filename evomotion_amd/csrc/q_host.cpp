@@ -25,7 +25,7 @@ int evm_q_create(int state_dim, int action_dim, int hidden_size, size_t max_rows
     if (!out) return zfail(EVM_E_INVALID, "out is null");
     *out = nullptr;
     if (hidden_size != 256) return zfail(EVM_E_UNSUPPORTED, "the Q kernels are built for hidden_size = 256");
-    if (state_dim < 1 || action_dim < 1 || state_dim + action_dim > 384) return zfail(EVM_E_INVALID, "unsupported state / action size");
+    if (state_dim < 1 || action_dim < 1 || action_dim > 16 || state_dim + action_dim > 384) return zfail(EVM_E_INVALID, "unsupported state / action size");
     if (max_rows < 1 || max_rows > ((size_t) 1 << 30)) return zfail(EVM_E_INVALID, "max_rows out of range");
     if (hipSetDevice(device) != hipSuccess) return zfail(EVM_E_HIP, "hipSetDevice failed");
     EvmQ *q = new EvmQ();

@@ -280,24 +280,32 @@ __global__ __launch_bounds__(256) void k_q_min_grad(QDev d, int n, float inv_row
     d.net[0].dh[row * 32] = -inv_rows * w1;
     d.net[1].dh[row * 32] = -inv_rows * (1.f - w1);
 }
-// d loss / d action = sum over the critics of dz0 . W0[:, S + a]   (one thread per (row, a))
+// d loss / d action = sum over the critics of dz0 . W0[:, S + a].  A workgroup takes 16 rows: the action columns of both
+// first-layer weights are staged in LDS ([critic][a][j]), thread (row, a) walks its row of dz0 against them.
 __global__ __launch_bounds__(256) void k_q_input_grad(QDev d, int n, float *__restrict__ dqda) {
+    __shared__ float ws[2][16][256];
     const int A = d.A, SA = d.S + d.A;
-    const size_t e = (size_t) blockIdx.x * 256 + threadIdx.x;
-    if (e >= (size_t) n * A) return;
-    const size_t row = e / A;
-    const int a = (int) (e - row * A);
+    for (int e = threadIdx.x; e < 2 * A * 256; e += 256) {
+        const int c = e / (A * 256), r = e - c * (A * 256), a = r >> 8, j = r & 255;
+        ws[c][a][j] = d.net[c].theta[d.net[c].o_w[0] + (size_t) j * SA + d.S + a];
+    }
+    __syncthreads();
+    const int a = threadIdx.x & 15, lr = threadIdx.x >> 4;
+    const size_t row = (size_t) blockIdx.x * 16 + lr;
+    if (a >= A || row >= (size_t) n) return;
     float sum = 0.f;
     for (int c = 0; c < 2; c++) {
-        const QNet &N = d.net[c];
-        const float *dz = N.dz[0] + row * 256;
-        const float *w = N.theta + N.o_w[0] + d.S + a;
+        const f32x4 *dz = reinterpret_cast<const f32x4 *>(d.net[c].dz[0] + row * 256);
+        const f32x4 *w = reinterpret_cast<const f32x4 *>(ws[c][a]);
         float s = 0.f;
 #pragma unroll 8
-        for (int j = 0; j < 256; j++) s += dz[j] * w[(size_t) j * SA];
+        for (int j = 0; j < 64; j++) {
+            const f32x4 x = dz[j], y = w[j];
+            s += (x[0] * y[0] + x[1] * y[1]) + (x[2] * y[2] + x[3] * y[3]);
+        }
         sum += s;
     }
-    dqda[e] = sum;
+    dqda[row * A + a] = sum;
 }
 // d/d(mu, sigma) of  mean_rows(alpha * sum_d logp_d - q),  action = sample(mu, sigma, u) differentiated through
 // (dqda already carries the -1/rows of the q term)
@@ -483,7 +491,7 @@ hipError_t launch_q_action_grad(const QDev &d, size_t rows, float *qmin, float *
     hipLaunchKernelGGL(k_q_min_grad, dim3((unsigned) ((rows + 255) / 256)), dim3(256), 0, s, d, (int) rows, (float) (1.0 / (double) rows), qmin);
     e = launch_q_backward(d, rows, s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_q_input_grad, dim3((unsigned) ((rows * d.A + 255) / 256)), dim3(256), 0, s, d, (int) rows, dqda);
+    hipLaunchKernelGGL(k_q_input_grad, dim3((unsigned) ((rows + 15) / 16)), dim3(256), 0, s, d, (int) rows, dqda);
     return hipGetLastError();
 }
 
