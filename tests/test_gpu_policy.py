@@ -298,3 +298,29 @@ def test_sac_hip_agent_graph_replay():
     assert torch.isfinite(w1).all() and torch.isfinite(t1).all() and not torch.equal(w0, w1) and not torch.equal(t0, t1)
     assert ag.twinq.adam_step(0) == ag.train_steps  # the device step counter advanced once per (replayed) update
     assert all(torch.isfinite(p).all() for p in ag.actor.parameters())
+
+
+def test_sac_hip_agent_save_load_round_trip(tmp_path):
+    """SoftActorCriticAgent::save / load (soft_actor_critic.cpp:181-223) with the weights owned by the device trainers"""
+    import torch
+    from evomotion_amd import VecRobotWalk, VecSacAgent
+    from evomotion_amd.ppo import PARAMS as PP, ACTOR
+    from evomotion_amd.qnet import PARAMS
+    n = 64
+    env = VecRobotWalk(n, seed=9)
+    env.reset()
+    ag = VecSacAgent(5, [371], [12], batch_size=64, epoch=1, replay_buffer_size=8, train_every=2, n_envs=n, use_graph=False)
+    for _ in range(6):
+        ag.step(env)
+    assert ag.train_steps >= 2
+    ag.save(str(tmp_path))
+    ag2 = VecSacAgent(6, [371], [12], batch_size=64, epoch=1, replay_buffer_size=8, train_every=2, n_envs=n, use_graph=False)
+    ag2.load(str(tmp_path))
+    for i in range(4):
+        assert torch.equal(ag.twinq.vector(PARAMS, i), ag2.twinq.vector(PARAMS, i))
+    assert torch.equal(ag._actor_tr.vector(PP, ACTOR), ag2._actor_tr.vector(PP, ACTOR))
+    assert torch.equal(ag.entropy.log_alpha.detach(), ag2.entropy.log_alpha.detach())
+    x = torch.rand(32, 371, device="cuda") * 2 - 1
+    u = torch.rand(32, 12, device="cuda")
+    for r, o in zip(ag.fused.forward(x, uniform=u, actor_only=True)[:2], ag2.fused.forward(x, uniform=u, actor_only=True)[:2]):
+        assert torch.equal(r, o)
