@@ -18,19 +18,31 @@ sys.path.insert(0, ROOT)
 
 ALG_BYTES_PER_ENV_STEP = 8300  # SURVEY.md §8(d); breakdown in DESIGN.md
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
-VALU_PEAK_TFLOPS = 157.3
+VALU_PEAK_TFLOPS = 157.3       # fp32 vector peak = fp32 matrix peak on this part (MI355X_MICROARCH.md)
+# Algorithmic fp32 FLOP of one env physics step (fma = 2), from the row counts of DESIGN.md §2 — table in DESIGN.md §5:
+# 10 sweeps x (12 hinges x (3 lin + 2 ang rows) + 4 fixed x (3 ang + 3 lin) + 12 sliders x (2 ang + 2 lin + motor)
+# + 24 p2p x 3 rows + ~8 contact points x (normal + friction)) = 149.7 k, row set-up 23.6 k, bodies 8.3 k,
+# hull scans 13.4 k, integration + observation 7.4 k
+ALG_FLOP_PER_ENV_STEP = 202.4e3
+POLICY_FLOP_PER_ROW = 654848.0  # actor 333 312 + critic 321 536 GEMM FLOP per act
+PREROLL_CALLS = 192             # untimed, after stagger_episodes(): every env is past its first (staggered) episode
 
 
 def measured_traffic(n):
-    """HBM-side bytes per launch of the dynamics kernel, from the committed PMC profile of this exact workload
-    (rocprofv3 cannot run inside the timed bench); None when the batch size differs from the profiled one."""
-    path = os.path.join(ROOT, "profiles", "r1e_traffic.json")
-    try:
-        with open(path) as f:
-            t = json.load(f)
-        return t["traffic_bytes_per_launch"] if t["envs_per_launch"] == n else None
-    except (OSError, KeyError, ValueError):
-        return None
+    """HBM-side bytes per step of the dynamics pipeline, from the newest committed PMC profile of this exact workload
+    (profiles/r*_traffic.json; rocprofv3 cannot run inside the timed bench); None when the batch size differs from the
+    profiled one.  Returns (bytes, file name)."""
+    import glob
+    best = (None, None)
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json"))):
+        try:
+            with open(path) as f:
+                t = json.load(f)
+            if t["envs_per_launch"] == n:
+                best = (t["traffic_bytes_per_launch"], os.path.basename(path))
+        except (OSError, KeyError, ValueError):
+            pass
+    return best
 
 
 def cpu_baseline(seconds=12.0):
@@ -48,6 +60,63 @@ def cpu_baseline(seconds=12.0):
         "sample": f"{steps} do_step calls incl. {n_res.value} reset() (60 settle steps each), 1 env, 1 thread, "
                   f"{t:.1f} s of the scalar CPU restatement (oracle/); Bullet3 itself is not installed on this box",
     }
+
+
+def launch_ranks(n_ranks, argv, worker=None, timeout=None):
+    """`bench.py --gpus N` without a torchrun environment: start N fresh rank processes (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT set, as torch.distributed.run would) and relay rank 0's JSON line.  The parent never
+    imports torch or touches HIP, and the children are started with subprocess (never exec'd from a GPU process).
+    worker: command prefix of the rank program (tests pass a stub); default = this file.  Returns the exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = list(worker) if worker else [sys.executable, os.path.abspath(__file__)]
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen(cmd + list(argv), env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    t0 = time.time()
+    out0, rc = None, 0
+    try:
+        pending = set(range(n_ranks))
+        while pending:
+            for r in sorted(pending):
+                if r == 0 and out0 is None:
+                    # rank 0 prints one line at the very end; communicate() also reaps it
+                    try:
+                        out0, _ = procs[0].communicate(timeout=0.2)
+                    except subprocess.TimeoutExpired:
+                        pass
+                code = procs[r].poll()
+                if code is not None:
+                    pending.discard(r)
+                    if code != 0:
+                        rc = rc or code
+            if rc or (timeout and time.time() - t0 > timeout):
+                rc = rc or 124
+                break
+            time.sleep(0.05)
+    finally:
+        for p_ in procs:  # exact PIDs of our own children only
+            if p_.poll() is None:
+                p_.terminate()
+        for p_ in procs:
+            try:
+                p_.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p_.kill()
+    if rc:
+        sys.stderr.write("bench.py: a rank failed (exit code %d); no result line\n" % rc)
+        return rc
+    lines = [l for l in (out0 or b"").decode().splitlines() if l.strip()]
+    if not lines:
+        sys.stderr.write("bench.py: rank 0 printed nothing\n")
+        return 1
+    sys.stdout.write(lines[-1] + "\n")
+    return 0
 
 
 def main():
@@ -72,7 +141,12 @@ def main():
                     help="sac mode: twin-Q side of the update in the HIP trainer (csrc/q_kernels.hip) or everything through autograd")
     ap.add_argument("--ppo-update", choices=["hip", "torch"], default="hip",
                     help="ppo mode: the update in the HIP trainer (csrc/ppo_kernels.hip) or through PyTorch-ROCm autograd")
+    ap.add_argument("--no-stagger", action="store_true", help="skip the episode desynchronisation + pre-roll (all envs then "
+                    "leave reset() in lock step and a short run measures physics steps without any reset)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -80,6 +154,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: WORLD_SIZE=%d overrides --gpus %d\n" % (world, args.gpus))
     ndev = max(torch.cuda.device_count(), 1)
     dev_index = local_rank % ndev
     if world > 1:
@@ -91,16 +167,23 @@ def main():
     dev = torch.device("cuda", dev_index)
     local_rank = dev_index
 
-    from evomotion_amd import VecRobotWalk
+    from evomotion_amd import FusedActorCritic, RandomAgent, VecRobotWalk
+
+    # RCCL sanity: the ranks that take part in a real all_reduce over the NCCL (= RCCL) backend
+    rccl_ranks = None
+    if world > 1 and args.backend == "nccl":
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        rccl_ranks = int(ones.item())
 
     n = args.envs
     env = VecRobotWalk(n, seed=1234 + rank * n, device=local_rank)
-    env.reset()
-    # pre-generated action bank, cycled (uniform [-1,1), the reference's RandomAgent: debug_agents.cpp:28-30)
-    g = torch.Generator(device=dev)
-    g.manual_seed(1234 + rank)
+    st0 = env.reset()
+    # RandomAgent (debug_agents.cpp:28-30) fills an action bank resident in HBM, cycled by the rollout loop: config 2 times
+    # the dynamics, not the generator
+    random_agent = RandomAgent([env.action_dim], dev, seed=1234 + rank)
     bank = 64
-    actions = torch.rand(bank, n, env.action_dim, device=dev, generator=g) * 2.0 - 1.0
+    actions = torch.stack([random_agent.act(st0.state) for _ in range(bank)]).contiguous()
 
     def barrier():
         torch.cuda.synchronize()
@@ -137,6 +220,13 @@ def main():
                 agent.update()
             done_steps += args.horizon
 
+    if not args.no_stagger:
+        # episodes start in lock step (every env left reset() together): spread their phases over one episode + reset cycle
+        # and roll past the staggered first episodes, untimed and independent of --warmup, so that the timed region sees
+        # the steady-state mix of stepping and settling envs
+        env.stagger_episodes()
+        for i in range(PREROLL_CALLS):
+            env.step_autoreset(actions[i % bank])
     run(args.warmup)
     barrier()
     env.clear_stats()
@@ -162,6 +252,20 @@ def main():
         torch.cuda.synchronize()
     if agent is not None:
         args.steps = n_launch
+    # MFMA utilisation of the policy GEMM in every mode: in dynamics mode the fused actor-critic forward is timed here, outside
+    # the headline region, on the envs' current observations (50 launches, random-init weights of init.cpp:7-21)
+    if agent is None and sac is None and rank == 0:
+        from evomotion_amd import ActorModule, CriticModule
+        torch.manual_seed(1234)
+        pol = FusedActorCritic(env.state_dim, env.action_dim, 256, local_rank)
+        pol.load_modules(ActorModule([env.state_dim], [env.action_dim], 256).to(dev), CriticModule([env.state_dim], 256).to(dev))
+        for _ in range(5):
+            pol.forward(env.obs)
+        torch.cuda.synchronize()
+        pol.timing_begin()
+        for i in range(50):
+            pol.forward(env.obs, seed=i)
+        ms_policy, n_policy = pol.timing_end()
     elapsed = t1 - t0
     st = env.stats()
     tt = torch.tensor([elapsed, float(st["env_steps"]), float(st["resets"])], dtype=torch.float64,
@@ -207,19 +311,33 @@ def main():
                 "do_step_fraction": env_steps / (world * n * args.steps),
                 "resets_started": resets,
             },
+            "rccl_ranks": rccl_ranks,
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n),
+                "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n)[0], "traffic_source": measured_traffic(n)[1],
                 "kernel": ("k_split_sweeps (dominant) + k_split_pre_a / pre_b / post: one step" if ms_sweeps > 0 else "k_env_step<7>"),
                 "launch_ms": launch_ms, "dominant_kernel_ms": (ms_sweeps / max(n_launch, 1)) if ms_sweeps > 0 else launch_ms,
                 "note": "algorithmic 8300 B per env physics step x %d envs per step; a step is a pipeline of four kernels up to "
                         "8192 envs (launch_ms = all of them, HIP events on the launch stream; dominant_kernel_ms = the Gauss-Seidel "
                         "sweeps kernel alone), one monolithic kernel above; fp32-VALU/latency bound (about 50 FLOP per algorithmic "
                         "byte); traffic = memory-side bytes per step from the committed rocprofv3 PMC passes "
-                        "(profiles/r1e_traffic.json; per-sweep re-reads of the constraint records overflow the 4 MB L2 and are "
-                        "served by the Infinity Cache), see DESIGN.md" % n,
+                        "(traffic_source under profiles/), see DESIGN.md" % n,
             },
         }
+        valu_tf = ALG_FLOP_PER_ENV_STEP * phys_per_launch / (launch_ms * 1e-3) / 1e12
+        out["roofline_valu"] = {"bound": "valu", "achieved": valu_tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": valu_tf / VALU_PEAK_TFLOPS, "traffic": None, "launch_ms": launch_ms,
+                                "flop_per_env_step": ALG_FLOP_PER_ENV_STEP,
+                                "note": "algorithmic fp32 FLOP of one stepSimulation (row counts of DESIGN.md, fma = 2) x envs per "
+                                        "step / the same step time as `roofline`; peak = packed-fp32 VALU peak"}
+        if agent is None and sac is None and n_policy:
+            pol_ms = ms_policy / n_policy
+            tf = POLICY_FLOP_PER_ROW * n / (pol_ms * 1e-3) / 1e12
+            out["roofline_policy"] = {"bound": "mfma", "achieved": tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                      "frac": tf / VALU_PEAK_TFLOPS, "traffic": None, "kernel": "k_policy_forward",
+                                      "launch_ms": pol_ms, "rows": n,
+                                      "note": "50 launches after the timed region (not part of `value`); fp32-input MFMA, dense fp32 "
+                                              "matrix peak; 654 848 GEMM FLOP per row"}
         if sac is not None and n_policy:
             pol_ms = ms_policy / n_policy
             tf = 333312.0 * n / (pol_ms * 1e-3) / 1e12  # actor 333 312 GEMM FLOP per act
@@ -243,7 +361,7 @@ def main():
                                                  "kernel": "k_replay_plan + k_replay_gather"}
         if agent is not None and n_policy:
             pol_ms = ms_policy / n_policy
-            tf = 654848.0 * n / (pol_ms * 1e-3) / 1e12  # 654 848 GEMM FLOP per act
+            tf = POLICY_FLOP_PER_ROW * n / (pol_ms * 1e-3) / 1e12
             out["roofline_policy"] = {"bound": "mfma", "achieved": tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                                       "frac": tf / VALU_PEAK_TFLOPS, "traffic": None, "kernel": "k_policy_forward",
                                       "launch_ms": pol_ms, "note": "fp32-input MFMA (v_mfma_f32_32x32x2_f32), dense fp32 matrix peak"}
@@ -254,7 +372,7 @@ def main():
             # dgrad and the three weight-gradient GEMMs per network (no dgrad into the observations)
             S_, A_ = env.state_dim, env.action_dim
             bwd = 2.0 * (2 * 256 * 256 + 256 * 256 + S_ * 256) * 2 + 2.0 * (2 * (2 * A_) * 256 + 2 * 256)
-            tf = (654848.0 + bwd) * rows / (ep_ms * 1e-3) / 1e12
+            tf = (POLICY_FLOP_PER_ROW + bwd) * rows / (ep_ms * 1e-3) / 1e12
             out["roofline_ppo_update"] = {"bound": "mfma", "achieved": tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                                           "frac": tf / VALU_PEAK_TFLOPS, "traffic": None, "launch_ms": ep_ms, "rows": rows,
                                           "kernel": "k_ppo_forward + k_ppo_loss_* + k_ppo_backward + k_ppo_wgrad (x6) + reductions + k_ppo_adam: one epoch",

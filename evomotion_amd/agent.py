@@ -308,13 +308,47 @@ class FusedActorCritic:
 
 
 class RandomAgent:
-    """debug_agents.cpp:28-30: 2 * U[0,1)^A - 1, batched."""
+    """RandomAgent (debug_agents.cpp:7-30): act() = 2 * U[0,1)^A - 1 from the global torch generator, everything else a
+    no-op.  A 1-D state gives the reference's [A] action (same draws as the reference after torch.manual_seed on the
+    CPU, pinned in tests/test_agent_host.py); a [N, S] batch gives [N, A], one generator call for all envs.
+    `seed`: use a private generator on `device` instead of the global one (bench.py: one stream per rank)."""
 
-    def __init__(self, action_space, device):
-        self.A, self.device = action_space[0], device
+    def __init__(self, action_space, device="cpu", seed=None):
+        self.A, self.device = int(action_space[0]), torch.device(device)
+        self.generator = None
+        if seed is not None:
+            self.generator = torch.Generator(device=self.device)
+            self.generator.manual_seed(int(seed))
 
     def act(self, state, reward=None):
-        return 2.0 * torch.rand(state.shape[0], self.A, device=self.device) - 1.0
+        shape = (self.A,) if state.dim() == 1 else (state.shape[0], self.A)
+        return 2.0 * torch.rand(*shape, device=self.device, generator=self.generator) - 1.0
+
+    def done(self, state, reward=None):
+        pass
+
+    def save(self, output_folder_path):
+        pass
+
+    def load(self, input_folder_path):
+        pass
+
+    def get_metrics(self):
+        return []
+
+    def to(self, device):
+        self.device = torch.device(device)
+        if self.generator is not None:
+            seed = self.generator.initial_seed()
+            self.generator = torch.Generator(device=self.device)
+            self.generator.manual_seed(seed)
+        return self
+
+    def set_eval(self, eval_mode):
+        pass
+
+    def count_parameters(self):
+        return 0
 
 
 class VecPpoGaeAgent:

@@ -73,6 +73,8 @@ class VecRobotWalk:
         p = EvmEnvParams(prm["initial_remaining_seconds"], prm["max_episode_seconds"], prm["target_velocity"],
                          prm["minimal_velocity"], prm["reset_frames"], self.ENV_KIND)
         self._h = ctypes.c_void_p()
+        # int(initial_remaining_seconds / dt) in fp32 (robot_walk.cpp:30, SURVEY App. D: 59 for the default 1 s)
+        self._remaining0 = int(np.float32(prm["initial_remaining_seconds"]) / (np.float32(1.0) / np.float32(60.0)))
         torch.cuda.set_device(self.device)
         check(lib.evm_env_create(prm["skeleton_json_path"].encode(), self.n_envs, device, seed, ctypes.byref(p),
                                  ctypes.byref(self._h)))
@@ -160,6 +162,18 @@ class VecRobotWalk:
         blob = np.ascontiguousarray(blob, np.float32)
         assert blob.shape == (self.n_envs, self.state_size())
         check(lib.evm_env_set_state(self._h, blob.ctypes.data_as(ctypes.POINTER(ctypes.c_float))))
+
+    def stagger_episodes(self, period=None):
+        """Spread the envs' episode phases.  Envs created together leave reset() in lock step and, under random actions,
+        fail within a step of each other (~59 do_step calls, then 60 settle calls): for a long time the whole batch is
+        either stepping or settling.  This sets every env's `remaining_steps` budget (robot_walk.cpp:64-68) to a value
+        spread evenly over one episode + reset cycle, so that first episodes end at evenly spread calls; every later
+        episode is an ordinary one.  A vectorisation helper (the single-env reference has nothing to desynchronise)."""
+        if period is None:
+            period = 2 * (self._remaining0 + 1)
+        blob = self.get_state()
+        blob[:, -1] = 1 + (np.arange(self.n_envs) * 7919 % period)  # remaining_steps is the blob's last float
+        self.set_state(blob)
 
     def debug_reset_begin(self, mask=None):
         check(lib.evm_env_debug_reset_begin(self._h, _ptr(mask)))

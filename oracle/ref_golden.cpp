@@ -20,6 +20,7 @@
 #define private public
 #include <evo_motion_networks/agents/ppo_gae.h>
 #undef private
+#include <evo_motion_networks/agents/debug_agents.h>
 #include <evo_motion_networks/functions.h>
 #include <evo_motion_networks/networks/actor.h>
 #include <evo_motion_networks/networks/critic.h>
@@ -129,6 +130,14 @@ int main() {
         auto [v1] = agent.critic->forward(X);
         dump("ppo_after_mu", m1); dump("ppo_after_sigma", s1); dump("ppo_after_value", v1);
         dump("ppo_after_actor_w0_row0", agent.actor->named_parameters()["head.0.weight"][0]);
+    }
+    // RandomAgent::act (debug_agents.cpp:28-30): the first three actions after manual_seed(1234)
+    {
+        at::manual_seed(1234);
+        RandomAgent ra({A});
+        std::vector<torch::Tensor> acts;
+        for (int i = 0; i < 3; i++) acts.push_back(ra.act(X[0], 0.f));
+        dump("random_agent_actions", torch::stack(acts));
     }
     return 0;
 }

@@ -110,3 +110,22 @@ def test_one_train_call_matches_reference(gold, agent_mod):
     np.testing.assert_allclose(actor.head[0].weight[0].detach().numpy(), gold["ppo_after_actor_w0_row0"], atol=2e-6)
     # and it really moved (lr 1e-3, 2 Adam steps)
     assert np.abs(mu.numpy() - gold["mu"]).max() > 1e-4
+
+
+def test_random_agent_matches_reference_golden(gold, agent_mod):
+    """RandomAgent::act (debug_agents.cpp:28-30): first three actions after manual_seed(1234), recorded from the compiled
+    reference by oracle/ref_golden.cpp (-0.9420, -0.1962, -0.4803, ...).  Same generator, same draws: exact."""
+    torch.manual_seed(1234)
+    ra = agent_mod.RandomAgent([12], "cpu")
+    state = torch.zeros(371)
+    acts = torch.stack([ra.act(state, 0.0) for _ in range(3)]).numpy()
+    assert acts.shape == (3, 12)
+    np.testing.assert_array_equal(acts, gold["random_agent_actions"])
+    assert abs(float(acts[0, 0]) + 0.9420) < 1e-4 and abs(float(acts[0, 2]) + 0.4803) < 1e-4
+    # interface of DebugAgent (debug_agents.cpp:7-23): no parameters, no metrics, no-op done/save/load
+    assert ra.count_parameters() == 0 and ra.get_metrics() == []
+    ra.done(state, 0.0); ra.save("/nonexistent"); ra.load("/nonexistent"); ra.set_eval(True)
+    # batched form: [N, A] in [-1, 1), private generator reproducible
+    a = agent_mod.RandomAgent([12], "cpu", seed=7).act(torch.zeros(64, 371))
+    b = agent_mod.RandomAgent([12], "cpu", seed=7).act(torch.zeros(64, 371))
+    assert a.shape == (64, 12) and torch.equal(a, b) and float(a.min()) >= -1.0 and float(a.max()) < 1.0

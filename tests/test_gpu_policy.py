@@ -324,3 +324,26 @@ def test_sac_hip_agent_save_load_round_trip(tmp_path):
     u = torch.rand(32, 12, device="cuda")
     for r, o in zip(ag.fused.forward(x, uniform=u, actor_only=True)[:2], ag2.fused.forward(x, uniform=u, actor_only=True)[:2]):
         assert torch.equal(r, o)
+
+
+def test_random_agent_on_device():
+    """RandomAgent (debug_agents.cpp:28-30) at the headline batch: shape, range, determinism per seed, different seeds differ,
+    and the env accepts its actions as they are (device-resident, contiguous fp32)."""
+    import torch
+    from evomotion_amd import RandomAgent, VecRobotWalk
+    st = torch.zeros(4096, 371, device="cuda")
+    a = RandomAgent([12], "cuda", seed=1234).act(st)
+    b = RandomAgent([12], "cuda", seed=1234).act(st)
+    c = RandomAgent([12], "cuda", seed=1235).act(st)
+    assert a.shape == (4096, 12) and a.dtype == torch.float32 and a.is_cuda and a.is_contiguous()
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    assert float(a.min()) >= -1.0 and float(a.max()) < 1.0
+    assert abs(float(a.mean())) < 0.02 and abs(float(a.var()) - 1.0 / 3.0) < 0.02  # U[-1, 1)
+    ra = RandomAgent([12], "cuda", seed=5)
+    a1, a2 = ra.act(st), ra.act(st)
+    assert not torch.equal(a1, a2)  # the stream advances
+    env = VecRobotWalk(64, seed=3, device=0)
+    s0 = env.reset()
+    s1 = env.do_step(RandomAgent([12], "cuda", seed=9).act(s0.state))
+    assert torch.isfinite(s1.state).all()
+    env.close()
