@@ -31,6 +31,8 @@ struct EnvDev {
     int *stat;                      // [2][n]     do_step transitions emitted, resets started (rollout form)
     float *gtile;                   // [n/64][tile_floats] global staging copy of the LDS tile (split pipeline)
     int tile_floats;                // step_lds_bytes / 4
+    const EvmGSchedC *gs;           // lane-group sweep schedule (device copy), or null: the 64-env tile sweeps kernel runs
+    int g_waves, g_lds;             // waves per 16-env workgroup and dynamic LDS bytes of k_sweeps_g
 };
 
 hipError_t upload_skeleton(const EvmSkelC *h, hipStream_t s);

@@ -47,6 +47,7 @@ struct EvmEnv {
     size_t ev_used;
     int split;  // -1: by batch size (default), 1: split pipeline, 0: monolithic step kernel (EVM_MONOLITHIC=0/1 forces: A/B runs)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_sweeps;  // timed launches: around the sweeps kernel of the split pipeline
+    void *gsched;  // device copy of the lane-group sweep schedule (EvmGSchedC), or null
 };
 
 static const EvmEnv *g_skel_owner = nullptr;
@@ -134,6 +135,29 @@ int evm_env_create(const char *skeleton_path, int n_envs, int device, uint64_t s
     for (auto &s : segs) { *s.p = base; base += s.count * n * 4; }
     hipEventCreate(&env->ev0);
     hipEventCreate(&env->ev1);
+    // Sweeps kernel of the split pipeline: the lane-group kernel (16-env workgroups, joint records resident in LDS) when the
+    // skeleton's records fit its LDS image, else the 64-env tile kernel.  EVM_SWEEPS=tile forces the latter, EVM_G_WAVES=1..4
+    // sets the waves per 16-env workgroup (A/B runs).
+    env->gsched = nullptr;
+    {
+        const char *sw = getenv("EVM_SWEEPS");
+        const char *gw = getenv("EVM_G_WAVES");
+        int nw = gw ? atoi(gw) : 1;
+        if (nw < 1 || nw > EVM_G_MAX_WAVES) nw = 1;
+        if (!(sw && sw[0] == 't')) {
+            EvmGSchedC *G = new EvmGSchedC();
+            std::string gerr;
+            if (evm::build_group_schedule(S, nw, *G, gerr) == EVM_OK) {
+                he = hipMalloc(&env->gsched, sizeof(EvmGSchedC));
+                if (he == hipSuccess) he = hipMemcpy(env->gsched, G, sizeof(EvmGSchedC), hipMemcpyHostToDevice);
+                if (he != hipSuccess) { delete G; evm_env_destroy(env); return fail(EVM_E_HIP, std::string("group schedule: ") + hipGetErrorString(he)); }
+                env->d.gs = (const EvmGSchedC *) env->gsched;
+                env->d.g_waves = G->nwaves;
+                env->d.g_lds = G->lds_bytes;
+            }
+            delete G;
+        }
+    }
     g_skel_owner = nullptr;
     rc = ensure_skeleton(env, 0);
     if (rc != EVM_OK) { evm_env_destroy(env); return rc; }
@@ -148,6 +172,7 @@ void evm_env_destroy(EvmEnv *env) {
     if (!env) return;
     if (g_skel_owner == env) g_skel_owner = nullptr;
     if (env->arena) hipFree(env->arena);
+    if (env->gsched) hipFree(env->gsched);
     (void) hipEventDestroy(env->ev0);
     (void) hipEventDestroy(env->ev1);
     for (auto &pr : env->ev_pairs) { (void) hipEventDestroy(pr.first); (void) hipEventDestroy(pr.second); }
@@ -312,6 +337,30 @@ int evm_skeleton_schedule(const char *skeleton_path, int *dims, int *visits, int
         visits[4 * i + 3] = S->visit[i].need;
     }
     delete S;
+    return EVM_OK;
+}
+
+int evm_skeleton_group_schedule(const char *skeleton_path, int n_waves, int *dims, int *entries, int cap) {
+    EvmEnvParams prm;
+    evm_env_default_params(&prm);
+    EvmSkelC *S = new EvmSkelC();
+    EvmGSchedC *G = new EvmGSchedC();
+    std::string err;
+    int rc = evm::load_skeleton_constants(skeleton_path, prm, *S, err);
+    if (rc == EVM_OK) rc = evm::build_group_schedule(*S, n_waves, *G, err);
+    if (rc != EVM_OK) { delete S; delete G; return fail(rc, err); }
+    if (dims) { dims[0] = G->total; dims[1] = G->nwaves; dims[2] = G->lds_bytes; dims[3] = (int) G->est_cycles; }
+    for (int w = 0; w < G->nwaves && entries; w++)
+        for (int k = G->first[w]; k < G->first[w] + G->count[w] && k < cap; k++) {
+            int *o = entries + (size_t) k * (2 + 5 * EVM_G_SLOTS);
+            o[0] = w | ((G->entry[k].order & 0xffff) << 8); o[1] = G->entry[k].type;
+            for (int q = 0; q < EVM_G_SLOTS; q++) {
+                const EvmGSlotC &sl = G->slot[k][q];
+                o[2 + 5 * q] = sl.rec; o[3 + 5 * q] = sl.a; o[4 + 5 * q] = sl.b; o[5 + 5 * q] = sl.need; o[6 + 5 * q] = sl.ps;
+            }
+        }
+    delete S;
+    delete G;
     return EVM_OK;
 }
 

@@ -413,10 +413,9 @@ DEV void hinge_setup(const Ctx &c, int hi) {
     rec[27] = 0.f; rec[34] = lo; rec[35] = hi_;
     rec_store<0, EVM_H_STRIDE / 4>(c, c_skel.sc_h + EVM_H_STRIDE * hi, rec);
 }
-DEV float hinge_solve(const Ctx &c, const EvmEntryC &V, const Blk42 &k, BodyPD &Q) {
-    const int s = V.slot;
+// the rows of one hinge visit on registers: k = the record, Q = the two bodies, ap = accumulated impulses (in: the record's)
+DEV float hinge_rows(const Blk42 &k, BodyPD &Q, float (&ap)[6]) {
     const F3 p = KV3(k, 6), q = KV3(k, 9), ax1 = KV3(k, 12);
-    float ap[6];
 #pragma unroll
     for (int r = 0; r < 6; r++) ap[r] = KV(k, 28 + r);
     const float lo = KV(k, 34), hi_ = KV(k, 35);
@@ -428,12 +427,18 @@ DEV float hinge_solve(const Ctx &c, const EvmEntryC &V, const Blk42 &k, BodyPD &
     res = fmaxf(res, fabsf(row_iter<false, false>(p, rel, Q, KV(k, 18), KV(k, 24), 0.f, 0.f, ap[3])));
     res = fmaxf(res, fabsf(row_iter<false, false>(q, rel, Q, KV(k, 19), KV(k, 25), 0.f, 0.f, ap[4])));
     if (KV(k, 20) != 0.f) res = fmaxf(res, fabsf(row_iter<false, true>(ax1, rel, Q, KV(k, 20), KV(k, 26), lo, hi_, ap[5])));
+    return res;
+}
+DEV float hinge_solve(const Ctx &c, const EvmEntryC &V, const Blk42 &k, BodyPD &Q) {
+    const int s = V.slot;
+    float ap[6];
+    const float res = hinge_rows(k, Q, ap);
     store_bodypd(c, V.a, V.b, Q);
     {
         float w[EVM_H_STRIDE];
 #pragma unroll
         for (int r = 0; r < 6; r++) w[28 + r] = ap[r];
-        w[34] = lo; w[35] = hi_;
+        w[34] = KV(k, 34); w[35] = KV(k, 35);
         rec_store<7, 9>(c, s, w);
     }
     return res;
@@ -499,9 +504,7 @@ DEV void fixed_setup(const Ctx &c, int fi) {
     rec[42] = 0.f; rec[43] = 0.f;
     rec_store<0, EVM_F_STRIDE / 4>(c, c_skel.sc_f + EVM_F_STRIDE * fi, rec);
 }
-DEV float fixed_solve(const Ctx &c, const EvmEntryC &V, const Blk42 &k, BodyPD &Q) {
-    const int s = V.slot;
-    float ap[6];
+DEV float fixed_rows(const Blk42 &k, BodyPD &Q, float (&ap)[6]) {
 #pragma unroll
     for (int r = 0; r < 6; r++) ap[r] = KV(k, 36 + r);
     const F3P rel = f3p(p2(KV(k, 0), KV(k, 1)), p2(KV(k, 2), KV(k, 3)), p2(KV(k, 4), KV(k, 5)));  // (relA, -relB) pairs
@@ -512,6 +515,12 @@ DEV float fixed_solve(const Ctx &c, const EvmEntryC &V, const Blk42 &k, BodyPD &
 #pragma unroll
     for (int r = 0; r < 3; r++)
         res = fmaxf(res, fabsf(row_iter<true, false>(KV3(k, 15 + 3 * r), rel, Q, KV(k, 27 + r), KV(k, 33 + r), 0.f, 0.f, ap[3 + r])));
+    return res;
+}
+DEV float fixed_solve(const Ctx &c, const EvmEntryC &V, const Blk42 &k, BodyPD &Q) {
+    const int s = V.slot;
+    float ap[6];
+    const float res = fixed_rows(k, Q, ap);
     store_bodypd(c, V.a, V.b, Q);
     {
         float w[EVM_F_STRIDE];
@@ -644,10 +653,8 @@ DEV void slider_setup(const Ctx &c, int mi, bool powered_in, float target_vel) {
     SC(c_skel.sc_mobs + 4 * mi) = lin_pos;  // btSliderConstraint::getLinearPos(), MuscleState
 }
 template <bool ISO>
-DEV float slider_solve(const Ctx &c, const EvmEntryC &V, const Blk42 &kk, BodyPD &Q) {
-    const int s = V.slot;
+DEV float slider_rows(const Blk42 &kk, BodyPD &Q, float (&ap)[6]) {
     const F3 p = KV3(kk, 6), q = KV3(kk, 9), ax1 = KV3(kk, 12), p2_ = KV3(kk, 15), q2 = KV3(kk, 18);
-    float ap[6];
 #pragma unroll
     for (int r = 0; r < 6; r++) ap[r] = KV(kk, 36 + r);
     const float lo = KV(kk, 33), hi_ = KV(kk, 34);
@@ -659,6 +666,13 @@ DEV float slider_solve(const Ctx &c, const EvmEntryC &V, const Blk42 &kk, BodyPD
     res = fmaxf(res, fabsf(row_iter<true, false, ISO>(q2, rel, Q, KV(kk, 24), KV(kk, 30), 0.f, 0.f, ap[3])));
     if (KV(kk, 25) != 0.f) res = fmaxf(res, fabsf(row_iter<true, true, ISO>(ax1, rel, Q, KV(kk, 25), KV(kk, 31), lo, hi_, ap[4])));
     if (KV(kk, 26) != 0.f) res = fmaxf(res, fabsf(row_iter<false, false, ISO>(ax1, rel, Q, KV(kk, 26), KV(kk, 32), 0.f, 0.f, ap[5])));
+    return res;
+}
+template <bool ISO>
+DEV float slider_solve(const Ctx &c, const EvmEntryC &V, const Blk42 &kk, BodyPD &Q) {
+    const int s = V.slot;
+    float ap[6];
+    const float res = slider_rows<ISO>(kk, Q, ap);
     // the sphere pair stays in the caller's registers for the two p2p constraints that follow
     {
         float w[EVM_S_STRIDE];
@@ -696,9 +710,9 @@ DEV void p2p_setup(const Ctx &c, int mi, int which) {
 struct Blk16 {
     f32x4 q[4];
 };
-DEV float p2p_solve(const Ctx &c, int s, const Blk16 &kk, BodyD &A, F3 &dlB, float imB) {
+DEV float p2p_rows(const Blk16 &kk, BodyD &A, F3 &dlB, float imB, float &ap0, float &ap1, float &ap2) {
     const F3 a1 = KV3(kk, 0);
-    float ap0 = KV(kk, 12), ap1 = KV(kk, 13), ap2 = KV(kk, 14);
+    ap0 = KV(kk, 12); ap1 = KV(kk, 13); ap2 = KV(kk, 14);
     float res = 0.f;
     {   // x: c1 = a1 x e_x = (0, a1.z, -a1.y)
         const F3 angA = f3(A.I.xy * a1.z - A.I.xz * a1.y, A.I.yy * a1.z - A.I.yz * a1.y, A.I.yz * a1.z - A.I.zz * a1.y);
@@ -730,6 +744,11 @@ DEV float p2p_solve(const Ctx &c, int s, const Blk16 &kk, BodyD &A, F3 &dlB, flo
         A.dl.z += A.im * dI; A.da = A.da + angA * dI; dlB.z -= imB * dI;
         res = fmaxf(res, fabsf(dI));
     }
+    return res;
+}
+DEV float p2p_solve(const Ctx &c, int s, const Blk16 &kk, BodyD &A, F3 &dlB, float imB) {
+    float ap0, ap1, ap2;
+    const float res = p2p_rows(kk, A, dlB, imB, ap0, ap1, ap2);
     {
         float w[EVM_P_STRIDE];
         w[12] = ap0; w[13] = ap1; w[14] = ap2; w[15] = 0.f;
@@ -1023,12 +1042,10 @@ DEV void contact_setup(const Ctx &c, int m, int n, const MPoint *pts = nullptr) 
 }
 
 // Gauss-Seidel rows of member m's contact points; k = the member's record, requested one schedule entry ahead
-DEV float contact_iter(const Ctx &c, int m, const Blk42 &k, BodyD &D) {
-    const EvmMemberC &MB = c_skel.member[m];
-    const int rec = c_skel.sc_c + EVM_CM_STRIDE * m;
+// rows only: w[40..47] = the accumulated impulses after the visit
+DEV float contact_rows(const Blk42 &k, BodyD &D, float mu, float (&w)[EVM_CM_STRIDE]) {
     float res = 0.f;
     float apn[4];
-    float w[EVM_CM_STRIDE];
 #pragma unroll
     for (int i = 40; i < EVM_CM_STRIDE; i++) w[i] = KV(k, i);
 #pragma unroll
@@ -1063,7 +1080,7 @@ DEV float contact_iter(const Ctx &c, int m, const Blk42 &k, BodyD &D) {
             const F3 n2 = -lat;
             const F3 c2 = cross(rel, n2);
             const F3 angB = mul(D.I, c2);
-            const float lim = MB.mu * apn[j];
+            const float lim = mu * apn[j];
             float ap = KV(k, 41 + 2 * j);
             float dI = rhs;
             const float d2 = dot(n2, D.dl) + dot(c2, D.da);
@@ -1078,8 +1095,13 @@ DEV float contact_iter(const Ctx &c, int m, const Blk42 &k, BodyD &D) {
             res = fmaxf(res, fabsf(dI));
         }
     }
+    return res;
+}
+DEV float contact_iter(const Ctx &c, int m, const Blk42 &k, BodyD &D) {
+    float w[EVM_CM_STRIDE];
+    const float res = contact_rows(k, D, c_skel.member[m].mu, w);
     store_bodyd(c, m, D);
-    rec_store<10, 12>(c, rec, w);
+    rec_store<10, 12>(c, c_skel.sc_c + EVM_CM_STRIDE * m, w);
     return res;
 }
 // after the sweeps: the accumulated impulses go back into the persistent manifold (warm start of the next step)
@@ -2119,6 +2141,10 @@ __global__ __launch_bounds__(64) void k_env_poses(EnvDev d, float *out) {
     }
 }
 
+}  // namespace evm
+#include "sweep_groups.h"
+namespace evm {
+
 // ---------------------------------------------------------------------------------------------
 // host-callable launchers (used by env_host.cpp)
 // ---------------------------------------------------------------------------------------------
@@ -2163,7 +2189,18 @@ static hipError_t launch_split(const EnvDev &d, size_t lds, const float *action,
     hipLaunchKernelGGL((k_split_pre_a<MODE>), gp, bp, 0, s, d, mask);
     hipLaunchKernelGGL((k_split_pre_b<MODE>), gp, bp, 0, s, d, action, mask);
     if (e0) (void) hipEventRecord(e0, s);
-    hipLaunchKernelGGL(k_split_sweeps, dim3(tiles), dim3(64 * EVM_NW), lds, s, d, mask, (MODE & 4) ? 1 : 0);
+    if (d.gs) {
+        static bool attr_g = false;
+        if (!attr_g) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweeps_g),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int) (160 * 1024));
+            if (e != hipSuccess) return e;
+            attr_g = true;
+        }
+        hipLaunchKernelGGL(k_sweeps_g, dim3(tiles * (64 / EVM_G_ENVS)), dim3(64 * d.g_waves), (size_t) d.g_lds, s, d, mask, (MODE & 4) ? 1 : 0);
+    } else {
+        hipLaunchKernelGGL(k_split_sweeps, dim3(tiles), dim3(64 * EVM_NW), lds, s, d, mask, (MODE & 4) ? 1 : 0);
+    }
     if (e1) (void) hipEventRecord(e1, s);
     hipLaunchKernelGGL((k_split_post<MODE>), gp, bp, 0, s, d, obs, reward, done, valid, mask);
     return hipGetLastError();

@@ -155,3 +155,43 @@ struct EvmSkelC {
     // (two vertices per packed multiply/add in the scan); a hull with an odd count repeats its last vertex
     float hull[EVM_MAX_HULL_PTS * 3];
 };
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Lane-group sweep schedule (k_sweeps_g, the sweeps kernel of the split pipeline).  A wavefront there is
+// EVM_G_SLOTS lane groups x 16 environments: every group works on a DIFFERENT constraint of the same type for the same 16
+// environments, so one instruction stream serves up to four constraints (the four legs of the spider give exactly that).
+// A "group entry" = up to four visits of one type that share no body; the host packs one sweep's visits (Bullet order) into
+// group entries such that, for every body, the entries that touch it keep Bullet's order, and deals the entries to the
+// kernel's waves.  The table lives in global memory (one copy per EvmEnv) and is staged into LDS by the kernel.
+#define EVM_G_SLOTS 4
+#define EVM_G_ENVS 16
+#define EVM_G_MAX_ENTRIES 96   // group entries of one sweep, all waves together
+#define EVM_G_MAX_WAVES 4
+struct EvmGSlotC {      // 32 bytes = two quads, read (broadcast) by the 16 lanes of one group
+    int rec;            // < 0: empty slot.  types 0-3: first quad of the constraint's record relative to the record image
+                        // (scratch slot - sc_h) / 4; type 4: first scratch slot of the member's contact record
+    int a, b;           // bodies (type 4: a = b = member; type 3: a = member, b = attach sphere)
+    float imA;
+    float imB;
+    int need;           // versions of a (low 16 bits) and b the visit waits for within its sweep
+    int ps;             // visits per sweep on a (low 16 bits) and on b
+    float aux;          // type 4: combined friction mu; type 2: 1 if both bodies are isotropic
+};
+struct EvmGEntryC {
+    int type;           // 0 hinge, 1 fixed, 2 slider, 3 p2p, 4 contact rows
+    int order;          // low 16 bits: position in the one global order of the sweep's entries (every wave's list is sorted by
+                        // it); high 16 bits: entries of the same class (joint / contact rows) that follow in the wave's list, + 1
+    int iso;            // type 2: every filled slot joins two isotropic bodies
+    int members;        // type 4: bit mask of the members in the entry
+};
+struct EvmGSchedC {
+    int nwaves;
+    int total;                          // entries of all waves; wave w owns entries [first[w], first[w] + count[w])
+    int first[EVM_G_MAX_WAVES], count[EVM_G_MAX_WAVES];
+    int nrq;                            // quads of the joint-record image per env: (sc_c - sc_h) / 4
+    int lds_bytes;                      // dynamic LDS of the kernel for this skeleton
+    float est_cycles;                   // host estimate of the ten sweeps (information only)
+    EvmGEntryC entry[EVM_G_MAX_ENTRIES];
+    EvmGSlotC slot[EVM_G_MAX_ENTRIES][EVM_G_SLOTS];
+};
+

@@ -913,4 +913,209 @@ int load_skeleton_constants(const char *path, const EvmEnvParams &prm, EvmSkelC 
     return EVM_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Lane-group sweep schedule (EvmGSchedC).  One sweep = the joint visits in Bullet's order (S.visit) followed by one
+// contact visit per responding member.  Two visits that share no body commute exactly, so the only order that matters
+// is, per body, the order of the visits that touch it (= Bullet's).  The schedule is built by list scheduling with
+// batching: whenever a wave is free, the most urgent visit whose predecessors are done (urgency = longest dependent
+// path through this sweep AND the next one: the sweeps run back to back, so the root body's chain of the next sweep
+// hangs on this sweep's leg visits) opens a group entry, which is filled with up to three more ready visits of the same
+// type that share no body with it.  Entries sorted by their simulated start time form one global order; every wave's list
+// follows it, which rules out deadlock on the version counters.  The result is then scored by simulating the ten
+// back-to-back sweeps and improved by moving entries between waves.
+// ---------------------------------------------------------------------------------------------------------------------
+int build_group_schedule(const EvmSkelC &S, int nwaves, EvmGSchedC &G, std::string &err) {
+    memset(&G, 0, sizeof(G));
+    if (nwaves < 1 || nwaves > EVM_G_MAX_WAVES) { err = "group schedule: bad wave count"; return EVM_E_INVALID; }
+    struct V { int type, a, b, rec; float imA, imB, aux; int needA, needB; };
+    std::vector<V> vs;
+    for (int i = 0; i < S.nvisit; i++) {
+        const EvmVisitC &v = S.visit[i];
+        float aux = 0.f;
+        if (v.type == 2) aux = (S.body[v.a].isotropic && S.body[v.b].isotropic) ? 1.f : 0.f;
+        vs.push_back({v.type, v.a, v.b, (v.slot - S.sc_h) / 4, v.imA, v.imB, aux, 0, 0});
+    }
+    for (int m = 0; m < S.nm; m++)
+        if (S.member[m].contact_response)
+            vs.push_back({4, m, m, S.sc_c + EVM_CM_STRIDE * m, S.body[m].inv_mass, S.body[m].inv_mass, S.member[m].mu, 0, 0});
+    const int nv = (int) vs.size();
+    std::vector<int> cnt(S.nb, 0);
+    for (auto &v : vs) {
+        v.needA = cnt[v.a];
+        v.needB = cnt[v.b];
+        cnt[v.a]++;
+        if (v.b != v.a) cnt[v.b]++;
+    }
+    // measured on MI355X (tools/gstamps.py, one wave per SIMD, cycles per group entry incl. its LDS round trips):
+    // hinge 1770, fixed 1700, slider 1900, p2p 1000, contact rows 2100; a dependency that crosses waves ~300
+    const float cost_of[5] = {1770.f, 1700.f, 1900.f, 1000.f, 2100.f}, hop = 300.f;
+    // ---- dependency graph of one sweep (+ the edges into the next sweep) ----
+    std::vector<std::vector<int>> preds(nv), succs(nv);
+    std::vector<int> first_on(S.nb, -1), last_on(S.nb, -1);
+    for (int i = 0; i < nv; i++)
+        for (int body : {vs[i].a, vs[i].b}) {
+            if (last_on[body] >= 0 && last_on[body] != i && (preds[i].empty() || preds[i].back() != last_on[body])) {
+                preds[i].push_back(last_on[body]);
+                succs[last_on[body]].push_back(i);
+            }
+            if (first_on[body] < 0) first_on[body] = i;
+            last_on[body] = i;
+        }
+    // bottom levels over two consecutive sweeps: bl1 = within the (last) sweep, bl0 = first sweep incl. the wrap edges
+    std::vector<float> bl1(nv, 0.f), bl0(nv, 0.f);
+    for (int i = nv - 1; i >= 0; i--) {
+        float m = 0.f;
+        for (int sidx : succs[i]) m = std::max(m, bl1[sidx]);
+        bl1[i] = cost_of[vs[i].type] + m;
+    }
+    for (int i = nv - 1; i >= 0; i--) {
+        float m = 0.f;
+        for (int sidx : succs[i]) m = std::max(m, bl0[sidx]);
+        for (int body : {vs[i].a, vs[i].b})
+            if (last_on[body] == i) m = std::max(m, bl1[first_on[body]]);  // this body's next visit is in the next sweep
+        bl0[i] = cost_of[vs[i].type] + m;
+    }
+    // ---- list scheduling with batching ----
+    struct Ent { int type, wave; float start; std::vector<int> vis; };
+    std::vector<Ent> ents;
+    {
+        std::vector<float> finish(nv, -1.f), wave_free(nwaves, 0.f);
+        std::vector<int> wave_of(nv, -1), npred(nv);
+        std::vector<char> placed(nv, 0);
+        for (int i = 0; i < nv; i++) npred[i] = (int) preds[i].size();
+        int left = nv;
+        auto ready_at = [&](int i, int w) {
+            float r = 0.f;
+            for (int pidx : preds[i]) r = std::max(r, finish[pidx] + (wave_of[pidx] != w ? hop : 0.f));
+            return r;
+        };
+        while (left > 0) {
+            int bv = -1, bw = 0;
+            float bstart = 1e30f;
+            for (int i = 0; i < nv; i++) {
+                if (placed[i] || npred[i] != 0) continue;
+                for (int w = 0; w < nwaves; w++) {
+                    const float st = std::max(wave_free[w], ready_at(i, w));
+                    const bool better = st < bstart - 1.f || (st < bstart + 1.f && bv >= 0 && bl0[i] > bl0[bv] + 0.5f);
+                    if (bv < 0 || better) { bv = i; bw = w; bstart = st; }
+                }
+            }
+            Ent e;
+            e.type = vs[bv].type; e.wave = bw; e.start = bstart;
+            e.vis.push_back(bv);
+            // fill: ready visits of the same type that share no body with the entry, most urgent first
+            for (int k = 1; k < EVM_G_SLOTS; k++) {
+                int pick = -1;
+                for (int i = 0; i < nv; i++) {
+                    if (placed[i] || npred[i] != 0 || vs[i].type != e.type) continue;
+                    bool clash = false;
+                    for (int u : e.vis) clash = clash || u == i || vs[u].a == vs[i].a || vs[u].a == vs[i].b || vs[u].b == vs[i].a || vs[u].b == vs[i].b;
+                    if (clash || ready_at(i, bw) > bstart + 1.f) continue;
+                    if (pick < 0 || bl0[i] > bl0[pick]) pick = i;
+                }
+                if (pick < 0) break;
+                e.vis.push_back(pick);
+            }
+            const float fin = bstart + cost_of[e.type];
+            for (int u : e.vis) {
+                placed[u] = 1; finish[u] = fin; wave_of[u] = bw; left--;
+                for (int sidx : succs[u]) npred[sidx]--;
+            }
+            wave_free[bw] = fin;
+            ents.push_back(e);
+        }
+    }
+    // one global order: by simulated start time (a linear extension of the dependencies; per wave already increasing)
+    std::stable_sort(ents.begin(), ents.end(), [](const Ent &x, const Ent &y) { return x.start < y.start; });
+    const int ne = (int) ents.size();
+    if (ne > EVM_G_MAX_ENTRIES) { err = "group schedule overflow"; return EVM_E_UNSUPPORTED; }
+    // ---- score: the ten back-to-back sweeps with fixed per-wave lists; improve by moving entries between waves ----
+    auto simulate = [&](const std::vector<int> &asg) -> float {
+        std::vector<float> wave_t(nwaves, 0.f), ready(S.nb, 0.f);
+        std::vector<int> lastw(S.nb, -1);
+        for (int sweep = 0; sweep < 10; sweep++)
+            for (int e = 0; e < ne; e++) {
+                const int w = asg[e];
+                float st = wave_t[w];
+                for (int i : ents[e].vis)
+                    for (int body : {vs[i].a, vs[i].b}) {
+                        const float r = ready[body] + ((lastw[body] >= 0 && lastw[body] != w) ? hop : 0.f);
+                        if (r > st) st = r;
+                    }
+                const float fn = st + cost_of[ents[e].type];
+                wave_t[w] = fn;
+                for (int i : ents[e].vis) { ready[vs[i].a] = ready[vs[i].b] = fn; lastw[vs[i].a] = lastw[vs[i].b] = w; }
+            }
+        float m = 0.f;
+        for (float t : wave_t) m = std::max(m, t);
+        return m;
+    };
+    std::vector<int> asg(ne);
+    for (int e = 0; e < ne; e++) asg[e] = ents[e].wave;
+    float best = simulate(asg);
+    if (nwaves > 1) {
+        for (int pass = 0; pass < 40; pass++) {
+            bool moved = false;
+            for (int e = 0; e < ne; e++) {
+                const int w0 = asg[e];
+                int bw = w0;
+                float bv = best;
+                for (int w = 0; w < nwaves; w++) {
+                    if (w == w0) continue;
+                    asg[e] = w;
+                    const float v = simulate(asg);
+                    if (v < bv - 0.5f) { bv = v; bw = w; }
+                }
+                asg[e] = bw;
+                if (bw != w0) { best = bv; moved = true; }
+            }
+            if (!moved) break;
+        }
+    }
+    // ---- tables ----
+    G.nwaves = nwaves;
+    G.total = ne;
+    G.est_cycles = best;
+    G.nrq = (S.sc_c - S.sc_h) / 4;
+    int k = 0;
+    for (int w = 0; w < nwaves; w++) {
+        G.first[w] = k;
+        for (int e = 0; e < ne; e++) {
+            if (asg[e] != w) continue;
+            EvmGEntryC &E = G.entry[k];
+            E.type = ents[e].type; E.order = e; E.iso = 1; E.members = 0;
+            for (int sidx = 0; sidx < EVM_G_SLOTS; sidx++) {
+                EvmGSlotC &sl = G.slot[k][sidx];
+                memset(&sl, 0, sizeof(sl));
+                sl.rec = -1;
+                if (sidx >= (int) ents[e].vis.size()) continue;
+                const V &v = vs[ents[e].vis[sidx]];
+                sl.rec = v.rec; sl.a = v.a; sl.b = v.b; sl.imA = v.imA; sl.imB = v.imB; sl.aux = v.aux;
+                sl.need = v.needA | (v.needB << 16);
+                sl.ps = cnt[v.a] | (cnt[v.b] << 16);
+                if (v.type == 2 && v.aux == 0.f) E.iso = 0;
+                if (v.type == 4) E.members |= 1 << v.a;
+            }
+            if (E.type != 2) E.iso = 0;
+            k++;
+        }
+        G.count[w] = k - G.first[w];
+        // run lengths: consecutive entries of one class (joint rows / contact rows) in this wave's list, in the high half of
+        // `order` (the kernel walks a run of contact entries as one software-pipelined block)
+        for (int q = G.first[w] + G.count[w] - 1, run = 0; q >= G.first[w]; q--) {
+            const bool same = q + 1 < G.first[w] + G.count[w] && (G.entry[q + 1].type == 4) == (G.entry[q].type == 4);
+            run = same ? run + 1 : 1;
+            G.entry[q].order |= run << 16;
+        }
+    }
+    // LDS image: per env (3 quads per body + the joint records), then the slot table (2 quads per slot) and the entry
+    // headers (1 quad each), the version counters and the per-env residuals
+    const size_t quads = (size_t) (3 * S.nb + G.nrq) * EVM_G_ENVS + (size_t) ne * (2 * EVM_G_SLOTS + 1);
+    const size_t bytes = quads * 16 + (size_t) ((S.nb + 3) / 4 * 4) * 4 + EVM_G_ENVS * 4;
+    G.lds_bytes = (int) bytes;
+    if (bytes > 160 * 1024) { err = "skeleton records exceed the LDS image of the lane-group sweeps"; return EVM_E_UNSUPPORTED; }
+    return EVM_OK;
+}
+
 }  // namespace evm

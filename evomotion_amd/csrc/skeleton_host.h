@@ -11,4 +11,7 @@
 namespace evm {
 // Returns EVM_OK or an EVM_E_* code with `err` filled.
 int load_skeleton_constants(const char *path, const EvmEnvParams &prm, EvmSkelC &out, std::string &err);
+// Lane-group sweep schedule for `nwaves` waves per 16-env workgroup (skel_const.h, EvmGSchedC); EVM_E_UNSUPPORTED when the
+// skeleton's records do not fit the LDS image (the caller then keeps the 64-env tile kernel).
+int build_group_schedule(const EvmSkelC &S, int nwaves, EvmGSchedC &out, std::string &err);
 }

@@ -124,6 +124,11 @@ int evm_skeleton_digest(const char *skeleton_path, unsigned long long *h_out);
  * dims[4] = nvisit, nlevels, n_waves, cap; visits [nvisit,4] = type, body a, body b, need (needA | needB << 16);
  * sched [n_waves, cap] = joint visit index, or 0x4000 | member for that member's contact rows, -1 = past the end. */
 int evm_skeleton_schedule(const char *skeleton_path, int *dims, int *visits, int *sched, int cap);
+/* Host-only: the lane-group sweep schedule of the split pipeline's sweeps kernel (one wavefront = 4 lane groups x 16 envs,
+ * every group on a different constraint of one type): dims[4] = entries, n_waves, LDS bytes, estimated cycles;
+ * entries [n, 2 + 5 * 4] = wave | global order << 8, type (0 hinge, 1 fixed, 2 slider, 3 p2p, 4 contact rows), then per slot
+ * record (-1 = empty), body a, body b, need (versions a | b << 16), visits per sweep (a | b << 16). */
+int evm_skeleton_group_schedule(const char *skeleton_path, int n_waves, int *dims, int *entries, int cap);
 /* Loader cross-check: per body 19 floats [mass, inv_mass, invI xyz, friction, break_thr, M0 rows(9), t0(3)] */
 int evm_env_get_body_constants(const EvmEnv *env, float *h_out);
 /* Per-env diagnostics of the last physics step: [max |delta impulse| of the last PGS iteration, contacts] */

@@ -96,3 +96,98 @@ def test_generic_skeleton_schedules(hip_lib, tmp_path):
     visits, sched, nlev, nw = schedule(hip_lib, path)
     assert len(visits) == 0 and nlev == 0
     check(visits, sched, nlev, nw, 1)
+
+
+# ---- lane-group schedule of the split pipeline's sweeps kernel (EvmGSchedC) -------------------------------------------
+def group_schedule(hip_lib, path, n_waves):
+    dims = (ctypes.c_int * 4)()
+    cap = 96
+    ent = np.full((cap, 22), -7, np.int32)
+    ip = ctypes.POINTER(ctypes.c_int)
+    hip_lib.check(hip_lib.lib.evm_skeleton_group_schedule(path.encode(), n_waves, dims, ent.ctypes.data_as(ip), cap))
+    total, nw, lds, cyc = list(dims)
+    return ent[:total], nw, lds, cyc
+
+
+def check_groups(visits, ent, nw, nm_contact):
+    """Group entries are a re-packing of Bullet's visit list: every visit exactly once; the four visits of an entry have one
+    type and share no body; per body the visits come in Bullet's order with the prefix-count versions the kernel waits for;
+    (dependencies) U (each wave's list order) has a linear extension (the global entry index), so waits cannot deadlock."""
+    nv = len(visits)
+    # Bullet order key of every visit: joints by (type, a, b) in visit-list order, contacts after
+    key = {}
+    for i, (t, a, b, need) in enumerate(visits):
+        key.setdefault((int(t), int(a), int(b)), []).append(i)
+    seen_joint, seen_contact = [], []
+    body_seq = {}   # body -> list of (global entry index, need, visit order key)
+    per_wave_last = {}
+    assert sorted(int(r[0]) >> 8 for r in ent) == list(range(len(ent)))
+    for row in ent:
+        w, k, ty = int(row[0]) & 0xFF, int(row[0]) >> 8, int(row[1])   # k = position in the one global order
+        assert 0 <= w < nw and 0 <= ty <= 4
+        assert per_wave_last.get(w, -1) < k      # a wave's list follows the global order
+        per_wave_last[w] = k
+        used = set()
+        filled = 0
+        for q in range(4):
+            rec, a, b, need, ps = [int(v) for v in row[2 + 5 * q: 7 + 5 * q]]
+            if rec < 0:
+                continue
+            filled += 1
+            bodies = {a, b}
+            assert not (bodies & used), "two visits of one entry share a body"
+            used |= bodies
+            if ty == 4:
+                assert a == b
+                seen_contact.append(a)
+                order = nv + a
+                body_seq.setdefault(a, []).append((k, need & 0xFFFF, order, ps & 0xFFFF))
+            else:
+                order = key[(ty, a, b)].pop(0)
+                seen_joint.append(order)
+                body_seq.setdefault(a, []).append((k, need & 0xFFFF, order, ps & 0xFFFF))
+                body_seq.setdefault(b, []).append((k, need >> 16, order, ps >> 16))
+        assert filled >= 1
+    assert sorted(seen_joint) == list(range(nv))
+    assert len(seen_contact) == len(set(seen_contact)) == nm_contact
+    for body, seq in body_seq.items():
+        seq.sort()
+        assert [s[2] for s in seq] == sorted(s[2] for s in seq), "Bullet's order broken on body %d" % body
+        assert len({s[0] for s in seq}) == len(seq)          # strictly increasing entries
+        assert [s[1] for s in seq] == list(range(len(seq)))  # version each visit waits for = visits before it
+        assert all(s[3] == len(seq) for s in seq)            # visits per sweep
+
+
+def test_spider_group_schedule(hip_lib):
+    visits, _, _, _ = schedule(hip_lib, hip_lib.DEFAULT_SKELETON)
+    for nw in (1, 2, 4):
+        ent, w, lds, cyc = group_schedule(hip_lib, hip_lib.DEFAULT_SKELETON, nw)
+        assert w == nw and lds <= 160 * 1024
+        check_groups(visits, ent, nw, 17)
+        # the four legs pack: far fewer entries than the 52 + 17 visits
+        assert len(ent) <= 40, len(ent)
+        print("group schedule, %d wave(s): %d entries, LDS %d B, estimate %d cycles" % (nw, len(ent), lds, cyc))
+
+
+def test_generic_group_schedule(hip_lib, tmp_path):
+    members = [dict(name="body", mass=2.0, scale=(0.4, 0.2, 0.5))]
+    cons, mus = [], []
+    for k in range(5):
+        members.append(dict(name=f"seg{k}", mass=0.25, t=(0.5 * (k + 1), 0, 0), scale=(0.2, 0.1, 0.1)))
+        parent = "body" if k == 0 else f"seg{k-1}"
+        if k % 2 == 0:
+            cons.append(dict(type="hinge", name=f"c{k}", parent=parent, child=f"seg{k}", pivot_p=(0.25, 0, 0), pivot_c=(-0.25, 0, 0),
+                             axis_p=(0, 0, 1), axis_c=(0, 0, 1), lo=-1.0, hi=1.0))
+        else:
+            cons.append(dict(type="fixed", name=f"c{k}", parent=parent, child=f"seg{k}", tp=(0.25, 0, 0), tc=(-0.25, 0, 0)))
+    mus.append(dict(name="m0", a="body", b="seg0", pos_a=(0.1, 0.1, 0), pos_b=(0, 0.1, 0)))
+    mus.append(dict(name="m1", a="seg1", b="seg3", pos_a=(0, 0.1, 0), pos_b=(0, 0.1, 0)))
+    path = write_skeleton(tmp_path / "chain.skel", members, cons, mus)
+    visits, _, _, _ = schedule(hip_lib, path)
+    for nw in (1, 3):
+        ent, w, lds, cyc = group_schedule(hip_lib, path, nw)
+        check_groups(visits, ent, nw, 6)
+    path = write_skeleton(tmp_path / "cube.skel", [dict(name="body", mass=1.0, scale=(0.2, 0.2, 0.2))])
+    visits, _, _, _ = schedule(hip_lib, path)
+    ent, w, lds, cyc = group_schedule(hip_lib, path, 1)
+    check_groups(visits, ent, 1, 1)

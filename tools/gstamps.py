@@ -1,0 +1,28 @@
+"""Diagnostic (-DEVM_GSTAMPS build of the library): cycles of the lane-group sweeps kernel by phase and by entry type
+(wave 0 of the first quarter of every 64-env tile).  Build + run on the GPU box:
+    make -C evomotion_amd/csrc stamps   (-> build/libevm_gstamps.so)
+    cp build/libevm_gstamps.so evomotion_amd/libevomotion_hip.so && python tools/gstamps.py"""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from evomotion_amd import VecRobotWalk
+from evomotion_amd._lib import lib, check
+n = 4096
+env = VecRobotWalk(n, seed=1234)
+env.reset()
+env.stagger_episodes()
+g = torch.Generator(device="cuda"); g.manual_seed(0)
+K = 40
+acc = np.zeros(16)
+for k in range(K + 200):
+    env.step_autoreset(torch.rand(n, 12, device="cuda", generator=g) * 2 - 1)
+    if k >= 200:
+        st = (ctypes.c_ulonglong * (n // 64 * 16))()
+        check(lib.evm_env_get_stamps(env._h, st))
+        acc += np.array(st, dtype=np.uint64).reshape(-1, 16).astype(np.float64).mean(axis=0)
+acc /= K
+for q, name in enumerate(["hinge", "fixed", "slider", "p2p", "contact"]):
+    print("%-8s %7.0f cycles/entry  %6.1f entries per step (wave 0)  %8.0f cycles per step" % (name, acc[2 * q] / max(acc[2 * q + 1], 1), acc[2 * q + 1], acc[2 * q]))
+print("prologue %.0f (table %.0f, records %.0f, bodies %.0f, manifold counts + barrier %.0f)  sweeps %.0f  epilogue %.0f cycles (wave 0)"
+      % (acc[10], acc[13], acc[14], acc[15], acc[10] - acc[13] - acc[14] - acc[15], acc[11], acc[12]))
