@@ -142,8 +142,8 @@ int evm_env_create(const char *skeleton_path, int n_envs, int device, uint64_t s
     {
         const char *sw = getenv("EVM_SWEEPS");
         const char *gw = getenv("EVM_G_WAVES");
-        int nw = gw ? atoi(gw) : 1;
-        if (nw < 1 || nw > EVM_G_MAX_WAVES) nw = 1;
+        int nw = gw ? atoi(gw) : EVM_G_MAX_WAVES;  // one wave per SIMD measured best (tools/ab_sweeps.sh)
+        if (nw < 1 || nw > EVM_G_MAX_WAVES) nw = EVM_G_MAX_WAVES;
         if (!(sw && sw[0] == 't')) {
             EvmGSchedC *G = new EvmGSchedC();
             std::string gerr;

@@ -948,79 +948,165 @@ int build_group_schedule(const EvmSkelC &S, int nwaves, EvmGSchedC &G, std::stri
         if (v.b != v.a) cnt[v.b]++;
     }
     // measured on MI355X (tools/gstamps.py, one wave per SIMD, cycles per group entry incl. its LDS round trips):
-    // hinge 1770, fixed 1700, slider 1900, p2p 1000, contact rows 2100; a dependency that crosses waves ~300
+    // hinge 1770, fixed 1700, slider 1900, p2p 1000, contact rows 2100; a dependency that crosses waves ~300;
+    // chain entries (below): ~600 + 1050 per hinge phase, ~450 + 420 per p2p phase
     const float cost_of[5] = {1770.f, 1700.f, 1900.f, 1000.f, 2100.f}, hop = 300.f;
-    // ---- dependency graph of one sweep (+ the edges into the next sweep) ----
-    std::vector<std::vector<int>> preds(nv), succs(nv);
-    std::vector<int> first_on(S.nb, -1), last_on(S.nb, -1);
-    for (int i = 0; i < nv; i++)
-        for (int body : {vs[i].a, vs[i].b}) {
-            if (last_on[body] >= 0 && last_on[body] != i && (preds[i].empty() || preds[i].back() != last_on[body])) {
-                preds[i].push_back(last_on[body]);
-                succs[last_on[body]].push_back(i);
+    // ---- items: single visits, and CHAINS = 3..4 consecutive visits of one type (hinge / p2p) on one shared body a with
+    // distinct second bodies (the spider's root: its four hinges, the four p2p constraints of its muscles).  A chain runs as
+    // one group entry whose lane groups take turns (sweep_groups.h, g_hinge_chain / g_p2p_chain).
+    struct Item { int type; std::vector<int> vis; float cost; };
+    std::vector<Item> items;
+    std::vector<int> item_of(nv, -1);
+    auto build_items = [&](bool with_chains) {
+        items.clear();
+        std::fill(item_of.begin(), item_of.end(), -1);
+        if (with_chains && !getenv("EVM_G_NOCHAIN")) {
+            for (int x = 0; x < S.nb; x++) {
+                std::vector<int> seq;
+                for (int i = 0; i < nv; i++) if (vs[i].a == x || vs[i].b == x) seq.push_back(i);
+                size_t p0 = 0;
+                while (p0 < seq.size()) {
+                    const int t = vs[seq[p0]].type;
+                    size_t p1 = p0;
+                    if ((t == 0 || t == 3) && vs[seq[p0]].a == x && item_of[seq[p0]] < 0) {
+                        p1 = p0 + 1;
+                        while (p1 < seq.size() && p1 - p0 < EVM_G_SLOTS && vs[seq[p1]].type == t && vs[seq[p1]].a == x && item_of[seq[p1]] < 0) {
+                            bool dup = false;
+                            for (size_t q = p0; q < p1; q++) dup = dup || vs[seq[q]].b == vs[seq[p1]].b;
+                            if (dup) break;
+                            p1++;
+                        }
+                    }
+                    if (p1 - p0 >= 3) {
+                        Item it;
+                        it.type = t == 0 ? 5 : 6;
+                        for (size_t q = p0; q < p1; q++) { it.vis.push_back(seq[q]); item_of[seq[q]] = (int) items.size(); }
+                        it.cost = t == 0 ? 600.f + 1050.f * (float) (p1 - p0) : 450.f + 420.f * (float) (p1 - p0);
+                        items.push_back(it);
+                        p0 = p1;
+                    } else p0++;
+                }
             }
-            if (first_on[body] < 0) first_on[body] = i;
-            last_on[body] = i;
         }
-    // bottom levels over two consecutive sweeps: bl1 = within the (last) sweep, bl0 = first sweep incl. the wrap edges
-    std::vector<float> bl1(nv, 0.f), bl0(nv, 0.f);
-    for (int i = nv - 1; i >= 0; i--) {
-        float m = 0.f;
-        for (int sidx : succs[i]) m = std::max(m, bl1[sidx]);
-        bl1[i] = cost_of[vs[i].type] + m;
+        for (int i = 0; i < nv; i++)
+            if (item_of[i] < 0) { item_of[i] = (int) items.size(); items.push_back({vs[i].type, {i}, cost_of[vs[i].type]}); }
+    };
+    std::vector<std::vector<int>> preds, succs;
+    std::vector<int> first_on(S.nb, -1), last_on(S.nb, -1);  // first / last ITEM on every body within a sweep
+    auto build_graph = [&]() -> bool {
+        const int ni = (int) items.size();
+        preds.assign(ni, {});
+        succs.assign(ni, {});
+        std::fill(first_on.begin(), first_on.end(), -1);
+        std::fill(last_on.begin(), last_on.end(), -1);
+        for (int i = 0; i < nv; i++) {  // Bullet order
+            const int me = item_of[i];
+            for (int body : {vs[i].a, vs[i].b}) {
+                const int pr = last_on[body];
+                if (pr >= 0 && pr != me && std::find(preds[me].begin(), preds[me].end(), pr) == preds[me].end()) {
+                    preds[me].push_back(pr);
+                    succs[pr].push_back(me);
+                }
+                if (first_on[body] < 0) first_on[body] = me;
+                last_on[body] = me;
+            }
+        }
+        // acyclic?  (a chain may swallow a visit's predecessor AND successor)
+        std::vector<int> indeg(ni);
+        for (int k = 0; k < ni; k++) indeg[k] = (int) preds[k].size();
+        std::vector<int> stack;
+        for (int k = 0; k < ni; k++) if (!indeg[k]) stack.push_back(k);
+        int seen = 0;
+        while (!stack.empty()) {
+            const int k = stack.back(); stack.pop_back(); seen++;
+            for (int y : succs[k]) if (--indeg[y] == 0) stack.push_back(y);
+        }
+        return seen == ni;
+    };
+    build_items(true);
+    if (!build_graph()) { build_items(false); build_graph(); }
+    const int ni = (int) items.size();
+    // bottom levels over two consecutive sweeps (items in topological order = by their first visit)
+    std::vector<int> topo(ni);
+    for (int k = 0; k < ni; k++) topo[k] = k;
+    {
+        // Kahn order
+        std::vector<int> indeg(ni), order;
+        for (int k = 0; k < ni; k++) indeg[k] = (int) preds[k].size();
+        std::vector<int> q;
+        for (int k = 0; k < ni; k++) if (!indeg[k]) q.push_back(k);
+        while (!q.empty()) { const int k = q.back(); q.pop_back(); order.push_back(k); for (int y : succs[k]) if (--indeg[y] == 0) q.push_back(y); }
+        topo = order;
     }
-    for (int i = nv - 1; i >= 0; i--) {
+    std::vector<float> bl1(ni, 0.f), bl0(ni, 0.f);
+    for (int t = ni - 1; t >= 0; t--) {
+        const int k = topo[t];
         float m = 0.f;
-        for (int sidx : succs[i]) m = std::max(m, bl0[sidx]);
-        for (int body : {vs[i].a, vs[i].b})
-            if (last_on[body] == i) m = std::max(m, bl1[first_on[body]]);  // this body's next visit is in the next sweep
-        bl0[i] = cost_of[vs[i].type] + m;
+        for (int y : succs[k]) m = std::max(m, bl1[y]);
+        bl1[k] = items[k].cost + m;
+    }
+    for (int t = ni - 1; t >= 0; t--) {
+        const int k = topo[t];
+        float m = 0.f;
+        for (int y : succs[k]) m = std::max(m, bl0[y]);
+        for (int u : items[k].vis)
+            for (int body : {vs[u].a, vs[u].b})
+                if (last_on[body] == k) m = std::max(m, bl1[first_on[body]]);  // this body's next visit is in the next sweep
+        bl0[k] = items[k].cost + m;
     }
     // ---- list scheduling with batching ----
-    struct Ent { int type, wave; float start; std::vector<int> vis; };
+    struct Ent { int type, wave; float start, cost; std::vector<int> vis; };
     std::vector<Ent> ents;
     {
-        std::vector<float> finish(nv, -1.f), wave_free(nwaves, 0.f);
-        std::vector<int> wave_of(nv, -1), npred(nv);
-        std::vector<char> placed(nv, 0);
-        for (int i = 0; i < nv; i++) npred[i] = (int) preds[i].size();
-        int left = nv;
-        auto ready_at = [&](int i, int w) {
+        std::vector<float> finish(ni, -1.f), wave_free(nwaves, 0.f);
+        std::vector<int> wave_of(ni, -1), npred(ni);
+        std::vector<char> placed(ni, 0);
+        for (int k = 0; k < ni; k++) npred[k] = (int) preds[k].size();
+        int left = ni;
+        auto ready_at = [&](int k, int w) {
             float r = 0.f;
-            for (int pidx : preds[i]) r = std::max(r, finish[pidx] + (wave_of[pidx] != w ? hop : 0.f));
+            for (int pidx : preds[k]) r = std::max(r, finish[pidx] + (wave_of[pidx] != w ? hop : 0.f));
             return r;
+        };
+        auto clash = [&](int k, const std::vector<int> &have) {
+            for (int h : have)
+                for (int u : items[h].vis)
+                    for (int v : items[k].vis)
+                        if (vs[u].a == vs[v].a || vs[u].a == vs[v].b || vs[u].b == vs[v].a || vs[u].b == vs[v].b) return true;
+            return false;
         };
         while (left > 0) {
             int bv = -1, bw = 0;
             float bstart = 1e30f;
-            for (int i = 0; i < nv; i++) {
-                if (placed[i] || npred[i] != 0) continue;
+            for (int k = 0; k < ni; k++) {
+                if (placed[k] || npred[k] != 0) continue;
                 for (int w = 0; w < nwaves; w++) {
-                    const float st = std::max(wave_free[w], ready_at(i, w));
-                    const bool better = st < bstart - 1.f || (st < bstart + 1.f && bv >= 0 && bl0[i] > bl0[bv] + 0.5f);
-                    if (bv < 0 || better) { bv = i; bw = w; bstart = st; }
+                    const float st = std::max(wave_free[w], ready_at(k, w));
+                    const bool better = st < bstart - 1.f || (st < bstart + 1.f && bv >= 0 && bl0[k] > bl0[bv] + 0.5f);
+                    if (bv < 0 || better) { bv = k; bw = w; bstart = st; }
+                }
+            }
+            std::vector<int> have = {bv};
+            if (items[bv].type < 5) {
+                // fill: ready single visits of the same type that share no body with the entry, most urgent first
+                for (int q = 1; q < EVM_G_SLOTS; q++) {
+                    int pick = -1;
+                    for (int k = 0; k < ni; k++) {
+                        if (placed[k] || npred[k] != 0 || items[k].type != items[bv].type) continue;
+                        if (std::find(have.begin(), have.end(), k) != have.end() || clash(k, have) || ready_at(k, bw) > bstart + 1.f) continue;
+                        if (pick < 0 || bl0[k] > bl0[pick]) pick = k;
+                    }
+                    if (pick < 0) break;
+                    have.push_back(pick);
                 }
             }
             Ent e;
-            e.type = vs[bv].type; e.wave = bw; e.start = bstart;
-            e.vis.push_back(bv);
-            // fill: ready visits of the same type that share no body with the entry, most urgent first
-            for (int k = 1; k < EVM_G_SLOTS; k++) {
-                int pick = -1;
-                for (int i = 0; i < nv; i++) {
-                    if (placed[i] || npred[i] != 0 || vs[i].type != e.type) continue;
-                    bool clash = false;
-                    for (int u : e.vis) clash = clash || u == i || vs[u].a == vs[i].a || vs[u].a == vs[i].b || vs[u].b == vs[i].a || vs[u].b == vs[i].b;
-                    if (clash || ready_at(i, bw) > bstart + 1.f) continue;
-                    if (pick < 0 || bl0[i] > bl0[pick]) pick = i;
-                }
-                if (pick < 0) break;
-                e.vis.push_back(pick);
-            }
-            const float fin = bstart + cost_of[e.type];
-            for (int u : e.vis) {
-                placed[u] = 1; finish[u] = fin; wave_of[u] = bw; left--;
-                for (int sidx : succs[u]) npred[sidx]--;
+            e.type = items[bv].type; e.wave = bw; e.start = bstart; e.cost = items[bv].cost;
+            const float fin = bstart + e.cost;
+            for (int h : have) {
+                for (int u : items[h].vis) e.vis.push_back(u);
+                placed[h] = 1; finish[h] = fin; wave_of[h] = bw; left--;
+                for (int y : succs[h]) npred[y]--;
             }
             wave_free[bw] = fin;
             ents.push_back(e);
@@ -1043,7 +1129,7 @@ int build_group_schedule(const EvmSkelC &S, int nwaves, EvmGSchedC &G, std::stri
                         const float r = ready[body] + ((lastw[body] >= 0 && lastw[body] != w) ? hop : 0.f);
                         if (r > st) st = r;
                     }
-                const float fn = st + cost_of[ents[e].type];
+                const float fn = st + ents[e].cost;
                 wave_t[w] = fn;
                 for (int i : ents[e].vis) { ready[vs[i].a] = ready[vs[i].b] = fn; lastw[vs[i].a] = lastw[vs[i].b] = w; }
             }
@@ -1098,6 +1184,7 @@ int build_group_schedule(const EvmSkelC &S, int nwaves, EvmGSchedC &G, std::stri
                 if (v.type == 4) E.members |= 1 << v.a;
             }
             if (E.type != 2) E.iso = 0;
+            if (E.type >= 5) E.iso = (int) ents[e].vis.size();  // chain entries: filled slots, in Bullet's order
             k++;
         }
         G.count[w] = k - G.first[w];

@@ -142,6 +142,70 @@ DEV float g_p2p(const GCtx &G, int rec, int a, int b, float imA, float imB) {
     x[0] = ap0; x[1] = ap1; x[2] = ap2; x[3] = 0.f; GQ(G, G.QR + rec + 3) = x;
     return res;
 }
+// Chain entries.  The visits of a chain entry are CONSECUTIVE visits on one shared body a (the spider's root: its four
+// hinges, then the four p2p constraints of the muscles attached to it), each with its own second body: they cannot run side
+// by side, but they can share one entry — one descriptor, one LDS round trip — and run as phases, lane group g in phase g
+// (the other groups masked off), with the shared body's deltas handed from group to group through the cross-lane network
+// instead of an LDS store / version hop / reload per visit.  nact = filled slots (slots 0..nact-1, in Bullet's order).
+DEV float g_bcast(float v, int src_lane) { return __shfl(v, src_lane); }
+DEV float g_hinge_chain(const GCtx &G, int rec, int a, int b, float imA, float imB, int nact) {
+    Blk42 k;
+    BodyPD Q;
+    if (rec >= 0) {
+        const f32x4 *p = &GQ(G, G.QR + rec);
+#pragma unroll
+        for (int i = 0; i < EVM_H_STRIDE / 4; i++) k.q[i] = p[i << 4];
+        Q = g_load_pair(G, a, b, imA, imB);  // every group reads the shared body; only group 0's copy is current in phase 0
+    }
+    float ap[6];
+    float res = 0.f;
+    for (int ph = 0; ph < nact; ph++) {
+        if (G.g == ph) res = hinge_rows(k, Q, ap);
+        const int src = (ph << 4) + G.e;  // the shared body's deltas after this phase, to every group
+        Q.dl.x.x = g_bcast(Q.dl.x.x, src); Q.dl.y.x = g_bcast(Q.dl.y.x, src); Q.dl.z.x = g_bcast(Q.dl.z.x, src);
+        Q.da.x.x = g_bcast(Q.da.x.x, src); Q.da.y.x = g_bcast(Q.da.y.x, src); Q.da.z.x = g_bcast(Q.da.z.x, src);
+    }
+    if (rec >= 0) {
+        f32x4 x;  // the second body and the impulses of this group's visit; the shared body once (group 0 holds the final values too)
+        x[0] = Q.dl.x.y; x[1] = Q.dl.y.y; x[2] = Q.dl.z.y; x[3] = Q.da.x.y; GQ(G, 3 * b) = x;
+        x[0] = Q.da.y.y; x[1] = Q.da.z.y; x[2] = Q.I.xx.y; x[3] = Q.I.xy.y; GQ(G, 3 * b + 1) = x;
+        g_store_applied6(G, G.QR + rec + 7, ap, KV(k, 34), KV(k, 35));
+        if (G.g == 0) {
+            x[0] = Q.dl.x.x; x[1] = Q.dl.y.x; x[2] = Q.dl.z.x; x[3] = Q.da.x.x; GQ(G, 3 * a) = x;
+            x[0] = Q.da.y.x; x[1] = Q.da.z.x; x[2] = Q.I.xx.x; x[3] = Q.I.xy.x; GQ(G, 3 * a + 1) = x;
+        }
+    }
+    return res;
+}
+// a = the shared member, b = this group's attach sphere
+DEV float g_p2p_chain(const GCtx &G, int rec, int a, int b, float imA, float imB, int nact) {
+    Blk16 kk;
+    BodyD A;
+    f32x4 s0;
+    if (rec >= 0) {
+        const f32x4 *p = &GQ(G, G.QR + rec);
+#pragma unroll
+        for (int i = 0; i < 4; i++) kk.q[i] = p[i << 4];
+        A = g_load_body(G, a, imA);
+        s0 = GQ(G, 3 * b);
+    }
+    F3 dlS = f3(s0[0], s0[1], s0[2]);
+    float ap0 = 0.f, ap1 = 0.f, ap2 = 0.f;
+    float res = 0.f;
+    for (int ph = 0; ph < nact; ph++) {
+        if (G.g == ph) res = p2p_rows(kk, A, dlS, imB, ap0, ap1, ap2);
+        const int src = (ph << 4) + G.e;
+        A.dl.x = g_bcast(A.dl.x, src); A.dl.y = g_bcast(A.dl.y, src); A.dl.z = g_bcast(A.dl.z, src);
+        A.da.x = g_bcast(A.da.x, src); A.da.y = g_bcast(A.da.y, src); A.da.z = g_bcast(A.da.z, src);
+    }
+    if (rec >= 0) {
+        f32x4 x;
+        x[0] = dlS.x; x[1] = dlS.y; x[2] = dlS.z; x[3] = s0[3]; GQ(G, 3 * b) = x;
+        x[0] = ap0; x[1] = ap1; x[2] = ap2; x[3] = 0.f; GQ(G, G.QR + rec + 3) = x;
+        if (G.g == 0) g_store_body(G, a, A);
+    }
+    return res;
+}
 // k = the member's contact record (global memory, requested an entry ahead); rec = its first scratch slot
 DEV float g_contact(const GCtx &G, const Ctx &c, const Blk42 &k, int rec, int m, float im, float mu) {
     BodyD D = g_load_body(G, m, im);
@@ -343,7 +407,18 @@ __global__ __launch_bounds__(64 * EVM_G_MAX_WAVES) void k_sweeps_g(EnvDev d, con
 #endif
                     const int ty = __builtin_amdgcn_readfirstlane(__float_as_int(cur.h[0]));
                     const int rec = __float_as_int(cur.d0[0]), a = __float_as_int(cur.d0[1]), b = __float_as_int(cur.d0[2]);
-                    if (rec >= 0) {
+                    if (ty >= 5) {
+                        // chain entry (5: hinges, 6: p2p): every lane takes part in the hand-over, filled slot or not
+                        const int nact = __builtin_amdgcn_readfirstlane(__float_as_int(cur.h[2]));
+                        const float imA = cur.d0[3], imB = cur.d1[0];
+                        const int need = __float_as_int(cur.d1[1]), ps = __float_as_int(cur.d1[2]);
+                        // the shared body: slot g's visit is the g-th of the run, so the run's first visit waits for
+                        // (its own count) = expA - g and the last one publishes expA - g + nact
+                        const int expA0 = it * (ps & 0xffff) + (need & 0xffff) - G.g, expB = it * (ps >> 16) + (need >> 16);
+                        if (rec >= 0) g_wait2(G, c, a, expA0, b, expB);
+                        const float r = ty == 5 ? g_hinge_chain(G, rec, a, b, imA, imB, nact) : g_p2p_chain(G, rec, a, b, imA, imB, nact);
+                        if (rec >= 0) { g_publish(G, a, expA0 + nact, b, expB + 1); rs = fmaxf(rs, r); }
+                    } else if (rec >= 0) {
                         const float imA = cur.d0[3], imB = cur.d1[0];
                         const int need = __float_as_int(cur.d1[1]), ps = __float_as_int(cur.d1[2]);
                         const int expA = it * (ps & 0xffff) + (need & 0xffff), expB = it * (ps >> 16) + (need >> 16);
@@ -360,7 +435,7 @@ __global__ __launch_bounds__(64 * EVM_G_MAX_WAVES) void k_sweeps_g(EnvDev d, con
                     }
 #ifdef EVM_GSTAMPS
 #pragma unroll
-                    for (int q = 0; q < 4; q++) if (ty == q) { gs_type[q] += __builtin_amdgcn_s_memtime() - gs_e0; gs_n[q]++; }
+                    for (int q = 0; q < 4; q++) if (ty == q || (q == 0 && ty == 5) || (q == 3 && ty == 6)) { gs_type[q] += __builtin_amdgcn_s_memtime() - gs_e0; gs_n[q]++; }
 #endif
                     cur = nxt;
                 }

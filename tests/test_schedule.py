@@ -124,17 +124,27 @@ def check_groups(visits, ent, nw, nm_contact):
     assert sorted(int(r[0]) >> 8 for r in ent) == list(range(len(ent)))
     for row in ent:
         w, k, ty = int(row[0]) & 0xFF, int(row[0]) >> 8, int(row[1])   # k = position in the one global order
-        assert 0 <= w < nw and 0 <= ty <= 4
+        assert 0 <= w < nw and 0 <= ty <= 6
         assert per_wave_last.get(w, -1) < k      # a wave's list follows the global order
         per_wave_last[w] = k
         used = set()
         filled = 0
+        chain = ty >= 5   # chain entry: consecutive visits on ONE shared body a, run as phases in slot order
+        ty = {5: 0, 6: 3}.get(ty, ty)
+        chain_a, chain_need = None, None
         for q in range(4):
             rec, a, b, need, ps = [int(v) for v in row[2 + 5 * q: 7 + 5 * q]]
             if rec < 0:
                 continue
+            assert filled == q, "filled slots come first"
             filled += 1
-            bodies = {a, b}
+            if chain:
+                if chain_a is None:
+                    chain_a, chain_need = a, need & 0xFFFF
+                assert a == chain_a and (need & 0xFFFF) == chain_need + q, "chain slots = consecutive visits on the shared body"
+                bodies = {b}
+            else:
+                bodies = {a, b}
             assert not (bodies & used), "two visits of one entry share a body"
             used |= bodies
             if ty == 4:
@@ -145,7 +155,7 @@ def check_groups(visits, ent, nw, nm_contact):
             else:
                 order = key[(ty, a, b)].pop(0)
                 seen_joint.append(order)
-                body_seq.setdefault(a, []).append((k, need & 0xFFFF, order, ps & 0xFFFF))
+                body_seq.setdefault(a, []).append((k + q / 8.0, need & 0xFFFF, order, ps & 0xFFFF))
                 body_seq.setdefault(b, []).append((k, need >> 16, order, ps >> 16))
         assert filled >= 1
     assert sorted(seen_joint) == list(range(nv))
@@ -153,7 +163,7 @@ def check_groups(visits, ent, nw, nm_contact):
     for body, seq in body_seq.items():
         seq.sort()
         assert [s[2] for s in seq] == sorted(s[2] for s in seq), "Bullet's order broken on body %d" % body
-        assert len({s[0] for s in seq}) == len(seq)          # strictly increasing entries
+        assert len({s[0] for s in seq}) == len(seq)          # strictly increasing entries (slots of a chain entry: in slot order)
         assert [s[1] for s in seq] == list(range(len(seq)))  # version each visit waits for = visits before it
         assert all(s[3] == len(seq) for s in seq)            # visits per sweep
 
