@@ -315,7 +315,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n)[0], "traffic_source": measured_traffic(n)[1],
-                "kernel": ("k_split_sweeps (dominant) + k_split_pre_a / pre_b / post: one step" if ms_sweeps > 0 else "k_env_step<7>"),
+                "kernel": ("k_sweeps_g (dominant: the Gauss-Seidel sweeps) + k_split_pre_a / pre_b / post: one step" if ms_sweeps > 0 else "k_env_step<7>"),
                 "launch_ms": launch_ms, "dominant_kernel_ms": (ms_sweeps / max(n_launch, 1)) if ms_sweeps > 0 else launch_ms,
                 "note": "algorithmic 8300 B per env physics step x %d envs per step; a step is a pipeline of four kernels up to "
                         "8192 envs (launch_ms = all of them, HIP events on the launch stream; dominant_kernel_ms = the Gauss-Seidel "
