@@ -87,3 +87,22 @@ def test_state_roundtrip(orc_lib):
     ob, rb, db = b.do_step(act)
     np.testing.assert_allclose(oa, ob, atol=2e-5)
     assert da == db
+
+
+def test_oracle_matches_its_committed_trace(orc_lib):
+    """tests/golden/physics_trace.txt is a SELF-PIN (written by tools/make_physics_trace.py from this same oracle): it does
+    not add evidence about Bullet3, it makes a silent drift of the restatement impossible.  Tolerance: libm's sinf / atan2f /
+    asinf may differ in the last place between glibc builds; contact-rich rollouts amplify that, so the early calls are
+    compared tightly and the whole trace loosely."""
+    import os
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_physics_trace as mpt
+    ref = np.loadtxt(os.path.join(ROOT, "tests", "golden", "physics_trace.txt"))
+    got = mpt.trace(lib=orc_lib)
+    assert got.shape == ref.shape == (mpt.N_ENV * mpt.N_STEP // mpt.EVERY, 10)
+    assert np.array_equal(got[:, :3], ref[:, :3])                      # env, call, done: the episode structure is exact
+    early = ref[:, 1] < 32
+    np.testing.assert_allclose(got[early, 3:], ref[early, 3:], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(got[:, 3:], ref[:, 3:], rtol=5e-2, atol=5e-2)

@@ -143,3 +143,46 @@ def test_robot_jump_oracle_semantics(orc_lib):
         r, d = _orc.ctypes.c_float(), _orc.ctypes.c_int()
         env.L.orc_env_compute_step(env.h, out.ctypes.data_as(_orc.fp), _orc.ctypes.byref(r), _orc.ctypes.byref(d))
         assert env.counters()["remaining_steps"] == 0 and bool(d.value) == expect
+
+
+# ---- known answers shared with the HIP path (tests/physics_cases.py; the same checks run in tests/test_gpu_physics.py) ----
+import physics_cases as pc  # noqa: E402
+
+
+def _world(skel, orc_lib):
+    return pc.OracleWorld(skel, lib=orc_lib)
+
+
+def test_known_answer_free_fall(orc_lib, tmp_path):
+    pc.check_free_fall(_world(pc.skel_cube(write_skeleton, tmp_path), orc_lib))
+
+
+def test_known_answer_momentum_of_a_free_spinning_box(orc_lib, tmp_path):
+    drift = pc.check_momentum_free_spinning_box(_world(pc.skel_cube(write_skeleton, tmp_path, scale=(0.1, 0.2, 0.3)), orc_lib))
+    print("angular momentum drift over 600 steps: %.3g" % drift)
+
+
+def test_known_answer_resting_box_has_four_contact_points(orc_lib, tmp_path):
+    pc.check_resting_box(_world(pc.skel_cube(write_skeleton, tmp_path), orc_lib))
+
+
+def test_known_answer_sliding_box_decelerates_at_mu_g(orc_lib, tmp_path):
+    first, dist, ideal = pc.check_sliding_friction(_world(pc.skel_cube(write_skeleton, tmp_path, scale=(0.5, 0.1, 0.5)), orc_lib))
+    print("first sliding step loses %.6f m/s (mu g dt = %.6f); stops after %.3f m (ideal %.3f m)" % (first, 0.25 * pc.G * pc.DT, dist, ideal))
+
+
+def test_known_answer_hinge_pendulum_period(orc_lib, tmp_path):
+    skel, base_y = pc.skel_pendulum(write_skeleton, tmp_path)
+    period, pred = pc.check_pendulum_period(_world(skel, orc_lib), base_y)
+    print("pendulum period %.4f s, predicted %.4f s" % (period, pred))
+
+
+def test_known_answer_slider_motor_reaches_target_velocity(orc_lib, tmp_path):
+    skel = pc.skel_two_masses(write_skeleton, tmp_path, mass=0.25, force=1.0e6, name="motor_free.skel")
+    pc.check_motor_reaches_target_velocity(_world(skel, orc_lib))
+
+
+def test_known_answer_slider_motor_saturates_at_64_newton(orc_lib, tmp_path):
+    skel = pc.skel_two_masses(write_skeleton, tmp_path, mass=1000.0, force=64.0, name="motor_sat.skel")
+    rel, pred = pc.check_motor_saturates_at_max_force(_world(skel, orc_lib))
+    print("relative velocity %.5f m/s, predicted %.5f m/s" % (rel, pred))

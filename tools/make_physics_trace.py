@@ -1,0 +1,44 @@
+"""Writes tests/golden/physics_trace.txt: a SELF-PIN of the CPU oracle (oracle/liborc.so) — 4 environments x 256 do_step
+calls with seeded uniform actions (resets included), every 4th call recorded.  It is not a reference output (Bullet3 cannot
+be built here): its purpose is that a refactor of the oracle cannot drift silently
+(tests/test_oracle_constants.py::test_oracle_matches_its_committed_trace).   python tools/make_physics_trace.py"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import orc  # noqa: E402
+
+N_ENV, N_STEP, EVERY = 4, 256, 4
+
+
+def trace(lib=None):
+    rows = []
+    for i in range(N_ENV):
+        e = orc.OracleEnv(seed=1234 + i, lib=lib)
+        obs, rew, done = e.reset()
+        rng = np.random.default_rng(100 + i)
+        for k in range(N_STEP):
+            a = rng.uniform(-1, 1, 12).astype(np.float32)
+            if done:
+                obs, rew, done = e.reset()
+            else:
+                obs, rew, done = e.do_step(a)
+            if k % EVERY == EVERY - 1:
+                p = e.poses()
+                rows.append([i, k, int(done), rew, float(p[0, 0]), float(p[0, 1]), float(p[0, 2]), float(np.abs(p[:17, :3]).sum()),
+                             float(obs[:19].sum()), float(np.abs(obs).sum())])
+    return np.array(rows, np.float64)
+
+
+if __name__ == "__main__":
+    t = trace()
+    out = os.path.join(ROOT, "tests", "golden", "physics_trace.txt")
+    with open(out, "w") as f:
+        f.write("# SELF-PIN of oracle/liborc.so (tools/make_physics_trace.py), not a Bullet3 output: env, call, done, reward, root xyz, "
+                "sum |member positions|, sum(root block of the observation), sum |observation|\n")
+        for r in t:
+            f.write("%d %d %d %s\n" % (r[0], r[1], r[2], " ".join("%.9g" % v for v in r[3:])))
+    print("wrote", out, t.shape)
