@@ -376,6 +376,10 @@ class VecPpoGaeAgent:
         self.fused.load_modules(self.actor, self.critic)
         self.horizon = horizon
         self.seed = seed
+        # weights share `seed` across ranks; the rollout's exploration noise must not (data-parallel replicas would explore alike)
+        self.noise_seed = seed
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            self.noise_seed = (seed ^ (torch.distributed.get_rank() * 0x9E3779B97F4A7C15)) & 0x7FFFFFFF
         self._buf = None
         self.update_mode = update
         self.learning_rate = learning_rate
@@ -442,10 +446,15 @@ class VecPpoGaeAgent:
         import os
         load_into(self.actor, os.path.join(input_folder_path, "actor.th"))
         load_into(self.critic, os.path.join(input_folder_path, "critic.th"))
+        import warnings
         for opt, name in ((self.actor_opt, "actor_optimizer.pt"), (self.critic_opt, "critic_optimizer.pt")):
             f = os.path.join(input_folder_path, name)
             if os.path.isfile(f):
                 opt.load_state_dict(torch.load(f, map_location=self.device))
+            elif os.path.isfile(f[:-3] + ".th"):
+                # written by the reference (ppo_gae.cpp:194,196): keyed by parameter addresses of the saving process
+                warnings.warn("%s: the reference's optimiser archive is not loaded; Adam moments and step count restart from zero"
+                              % (f[:-3] + ".th"))
         self.fused.load_modules(self.actor, self.critic)
         if self._trainer is not None:
             self._push_to_trainer()
@@ -465,12 +474,12 @@ class VecPpoGaeAgent:
         b["states_all"][0].copy_(env.obs)  # one copy per horizon
         for t in range(T):
             # two launches per step, no copies: the kernels read and write the rows of the rollout buffer
-            self.fused.forward(b["states_all"][t], seed=self.seed, out=(b["actions"][t], b["logp"][t], b["values"][t]))
+            self.fused.forward(b["states_all"][t], seed=self.noise_seed, out=(b["actions"][t], b["logp"][t], b["values"][t]))
             env.step_autoreset(b["actions"][t], reward_out=b["rewards"][t], done_out=b["done_u8"][t], valid_out=b["valid_u8"][t],
                                obs_out=b["states_all"][t + 1])
         b["done"].copy_(b["done_u8"])
         b["valid"].copy_(b["valid_u8"])
-        _, _, last_v = self.fused.forward(b["states_all"][T], seed=self.seed, out=b["scratch"])
+        _, _, last_v = self.fused.forward(b["states_all"][T], seed=self.noise_seed, out=b["scratch"])
         b["next_values"][:-1] = b["values"][1:]
         b["next_values"][-1] = last_v
         return b

@@ -129,7 +129,17 @@ int evm_ppo_copy(EvmPpo *q, int what, int net, int to_trainer, float *d_buf, voi
 }
 
 int evm_ppo_adam_step(EvmPpo *q, int net, int set_step, int *step) {
-    if (!q || (net != 0 && net != 1)) return qfail(EVM_E_INVALID, "bad argument");
+    if (!q || (net != 0 && net != 1 && net != 2)) return qfail(EVM_E_INVALID, "bad argument");
+    if (net == 2) {  // the actor's device-side counter (evm_ppo_actor_apply: SAC's captured update)
+        int h = set_step;
+        if (set_step >= 0) {
+            if (hipMemcpy(q->dev.step_dev, &h, sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return qfail(EVM_E_HIP, "step upload failed");
+        } else if (hipMemcpy(&h, q->dev.step_dev, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) {
+            return qfail(EVM_E_HIP, "step download failed");
+        }
+        if (step) *step = h;
+        return EVM_OK;
+    }
     evm::PpoNet &n = net == 0 ? q->dev.actor : q->dev.critic;
     if (set_step >= 0) n.step = set_step;
     if (step) *step = n.step;

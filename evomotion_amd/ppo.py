@@ -8,6 +8,7 @@ import torch
 from ._lib import lib, check
 
 PARAMS, GRADS, EXP_AVG, EXP_AVG_SQ = 0, 1, 2, 3
+ACTOR_DEV_STEP = 2  # adam_step(): the actor's device-side step counter (actor_apply, SAC)
 ACTOR, CRITIC = 0, 1
 
 

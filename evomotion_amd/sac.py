@@ -99,6 +99,14 @@ def sac_train(actor, critic_1, critic_2, target_critic_1, target_critic_2, entro
     return dict(actor=loss_actor.detach(), critic_1=loss_c1.detach(), critic_2=loss_c2.detach(), entropy=loss_entropy.detach())
 
 
+def _rank_seed(seed):
+    """Equal seeds on every rank give equal initial weights (needed) — and would give every data-parallel replica the same
+    uniform draws for exploration and replay sampling.  Mix the rank into the seed used for those."""
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        return (seed ^ (torch.distributed.get_rank() * 0x9E3779B97F4A7C15)) & 0x7FFFFFFF
+    return seed
+
+
 class VecSacAgent:
     """Vectorised SoftActorCriticAgent: one act() for all N envs (fused HIP actor forward), a device replay ring, and the
     reference's train() on batches drawn from it.  Parameter names follow agent_factory.cpp:112-119.
@@ -141,9 +149,11 @@ class VecSacAgent:
         self._prev = torch.empty(n_envs, state_space[0], device=self.device)
         self._act = (torch.empty(n_envs, action_space[0], device=self.device), torch.empty(n_envs, action_space[0], device=self.device), None)
         self.seed, self.global_step, self.train_steps = seed, 0, 0
+        self.noise_seed = _rank_seed(seed)  # weights share `seed` across ranks, exploration noise and replay draws do not
         self._grad_hook = _all_reduce_grads_mean
         self.last_losses = None
         self._graph = None
+        self._stored_margin, self._pushes_since_check = 0, 0  # has_enough(): see there
         B, S, A = batch_size, state_space[0], action_space[0]
         z = lambda *sh: torch.zeros(*sh, device=self.device)
         self._batch = (z(B, S), z(B, A), z(B), z(B), z(B, S))
@@ -263,13 +273,26 @@ class VecSacAgent:
     def step(self, env, train=True):
         """act() + do_step + replay add/update_last + check_train() for all envs (soft_actor_critic.cpp:47-91)."""
         self._prev.copy_(env.obs)
-        action, _, _ = self.fused.forward(self._prev, seed=self.seed, actor_only=True, out=self._act)
+        action, _, _ = self.fused.forward(self._prev, seed=self.noise_seed, actor_only=True, out=self._act)
         st = env.step_autoreset(action)
         self.replay.push(self._prev, action, st.reward, st.done, st.valid, st.state)
-        if train and self.global_step % self.train_every == self.train_every - 1:
+        self._pushes_since_check += 1
+        if train and self.global_step % self.train_every == self.train_every - 1 and self.has_enough():
             self.update()
         self.global_step += 1
         return st
+
+    def has_enough(self):
+        """ReplayBuffer::has_enough(batch_size) (soft_actor_critic.cpp:64): no update before the memory holds a batch — with
+        fewer stored transitions the sampler would repeat rows, with none it would hand zeros to four Adam steps.  The stored
+        count lives on the device (the ring compacts valid rows there); reading it is a stream synchronisation, so it is
+        read only when the last reading no longer guarantees a batch: one push changes the count by at most n_envs."""
+        if self._pushes_since_check * self.replay.N < self._stored_margin:
+            return True
+        stored = self.replay.stats()["transitions"]
+        self._stored_margin = max(stored - self.batch_size, 0)
+        self._pushes_since_check = 0
+        return stored >= self.batch_size
 
     def _train_once(self):
         if self.update_mode == "hip":
@@ -282,11 +305,14 @@ class VecSacAgent:
 
     def update(self):
         for e in range(self.epoch):
-            self.replay.sample(self.batch_size, seed=(self.seed << 32) ^ (self.train_steps * 1000003 + e), out=self._batch)
+            self.replay.sample(self.batch_size, seed=(self.noise_seed << 32) ^ (self.train_steps * 1000003 + e), out=self._batch)
             if not self.use_graph:
                 self.last_losses = self._train_once()
             elif self._graph is None:
-                # warm-up on a side stream (allocator, optimiser state), then capture one train() call
+                # warm-up on a side stream (allocator, optimiser state), then capture one train() call.  The warm-up calls are
+                # real Adam steps: weights, moments, step counters and the entropy parameter are put back afterwards, so that
+                # this first update is ONE train() call like every later one (soft_actor_critic.cpp:93-170)
+                snap = self._snapshot()
                 side = torch.cuda.Stream(self.device)
                 side.wait_stream(torch.cuda.current_stream(self.device))
                 with torch.cuda.stream(side):
@@ -296,25 +322,99 @@ class VecSacAgent:
                 self._graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self._graph):
                     self.last_losses = self._train_once()
+                self._restore(snap)
                 self._graph.replay()  # capturing records the launches without running them
-                self.train_steps += 2
             else:
                 self._graph.replay()
             self.train_steps += 1
         if self.update_mode != "hip":  # (the device path has already repacked the actor for the rollout kernel)
             self.fused.set_actor(self.actor)
 
+    _OPT_FILES = ("actor_optimizer.th", "critic_1_optimizer.th", "critic_2_optimizer.th", "entropy_optimizer.th")
+
+    def _snapshot(self):
+        mods = (self.actor, self.critic_1, self.critic_2, self.target_critic_1, self.target_critic_2, self.entropy)
+        snap = dict(opt=self.optimizer_state(), train_steps=self.train_steps)
+        if self.twinq is not None:
+            from .ppo import ACTOR, PARAMS as PP
+            from .qnet import PARAMS
+            snap["actor"] = self._actor_tr.vector(PP, ACTOR).clone()
+            snap["q"] = [self.twinq.vector(PARAMS, i).clone() for i in range(4)]
+            snap["log_alpha"] = self.entropy.log_alpha.detach().clone()
+        else:
+            snap["modules"] = [{k: v.clone() for k, v in m.state_dict().items()} for m in mods]
+        return snap
+
+    def _restore(self, snap):
+        mods = (self.actor, self.critic_1, self.critic_2, self.target_critic_1, self.target_critic_2, self.entropy)
+        if self.twinq is not None:
+            from .ppo import ACTOR, PARAMS as PP
+            from .qnet import PARAMS
+            self._actor_tr.set_flat(snap["actor"], self._critic_dummy, reset_optimizer=False)
+            for i in range(4):
+                self.twinq.load_vector(PARAMS, i, snap["q"][i])
+            with torch.no_grad():
+                self.entropy.log_alpha.copy_(snap["log_alpha"])
+        else:
+            for m, sd in zip(mods, snap["modules"]):
+                m.load_state_dict(sd)
+        self.load_optimizer_state(snap["opt"])
+        self.train_steps = snap["train_steps"]
+
     def save(self, folder):
-        """SoftActorCriticAgent::save (soft_actor_critic.cpp:181-201): module archives in the reference's format."""
+        """SoftActorCriticAgent::save (soft_actor_critic.cpp:181-201): module archives in the reference's format.  The four
+        Adam states (actor, two critics, entropy parameter) go to `sac_optimizers.pt` (torch.save): the reference's
+        `*_optimizer.th` archives are keyed by parameter addresses of the saving process (torch::optim::serialize), see
+        checkpoint.py — a folder written here runs in the reference's `infer`, which loads modules only."""
         import os
         from .checkpoint import save_th
         self.sync_modules()
         for m, f in ((self.actor, "actor.th"), (self.critic_1, "critic_1.th"), (self.target_critic_1, "target_critic_1.th"),
                      (self.critic_2, "critic_2.th"), (self.target_critic_2, "target_critic_2.th"), (self.entropy, "entropy.th")):
             save_th(m, os.path.join(folder, f))
+        torch.save(self.optimizer_state(), os.path.join(folder, "sac_optimizers.pt"))
+
+    def optimizer_state(self):
+        """Adam moments and step counts of the four optimisers, wherever they live (HIP trainers or torch.optim)"""
+        if self.twinq is None:
+            return dict(kind="torch", actor=self.actor_opt.state_dict(), critic_1=self.critic_1_opt.state_dict(),
+                        critic_2=self.critic_2_opt.state_dict(), entropy=self.entropy_opt.state_dict())
+        from .ppo import ACTOR, ACTOR_DEV_STEP, EXP_AVG, EXP_AVG_SQ
+        tr, tq = self._actor_tr, self.twinq
+        out = dict(kind="hip", train_steps=self.train_steps,
+                   actor=dict(m=tr.vector(EXP_AVG, ACTOR).cpu(), v=tr.vector(EXP_AVG_SQ, ACTOR).cpu(), step=tr.adam_step(ACTOR_DEV_STEP)),
+                   entropy=dict(state=self._ent_state.cpu(), step=int(self._ent_step.item())))
+        for i in (0, 1):
+            out["critic_%d" % (i + 1)] = dict(m=tq.vector(EXP_AVG, i).cpu(), v=tq.vector(EXP_AVG_SQ, i).cpu(), step=tq.adam_step(i))
+        return out
+
+    def load_optimizer_state(self, st):
+        if st["kind"] == "torch":
+            for k, opt in (("actor", self.actor_opt), ("critic_1", self.critic_1_opt), ("critic_2", self.critic_2_opt), ("entropy", self.entropy_opt)):
+                opt.load_state_dict(st[k])
+            return
+        if self.twinq is None:
+            raise RuntimeError("optimiser state of the HIP trainers cannot be loaded into the torch optimisers")
+        from .ppo import ACTOR, ACTOR_DEV_STEP, EXP_AVG, EXP_AVG_SQ
+        tr, tq = self._actor_tr, self.twinq
+        tr.load_vector(EXP_AVG, ACTOR, st["actor"]["m"].to(self.device))
+        tr.load_vector(EXP_AVG_SQ, ACTOR, st["actor"]["v"].to(self.device))
+        tr.adam_step(ACTOR_DEV_STEP, int(st["actor"]["step"]))
+        for i in (0, 1):
+            c = st["critic_%d" % (i + 1)]
+            tq.load_vector(EXP_AVG, i, c["m"].to(self.device))
+            tq.load_vector(EXP_AVG_SQ, i, c["v"].to(self.device))
+            tq.adam_step(i, int(c["step"]))
+        self._ent_state.copy_(st["entropy"]["state"].to(self.device))
+        self._ent_step.fill_(int(st["entropy"]["step"]))
+        self.train_steps = int(st.get("train_steps", self.train_steps))
 
     def load(self, folder):
+        """SoftActorCriticAgent::load (soft_actor_critic.cpp:203-223).  Optimiser state: restored from this package's
+        `sac_optimizers.pt` when present; a folder written by the REFERENCE carries `*_optimizer.th` archives that cannot be
+        consumed here (address-keyed) — that is said out loud, and the optimisers restart from zero moments."""
         import os
+        import warnings
         from .checkpoint import load_into
         for m, f in ((self.actor, "actor.th"), (self.critic_1, "critic_1.th"), (self.target_critic_1, "target_critic_1.th"),
                      (self.critic_2, "critic_2.th"), (self.target_critic_2, "target_critic_2.th"), (self.entropy, "entropy.th")):
@@ -323,3 +423,13 @@ class VecSacAgent:
         if self.twinq is not None:
             self._push_critics()
             self._push_actor()
+            self._ent_state.zero_()
+            self._ent_step.zero_()
+        own = os.path.join(folder, "sac_optimizers.pt")
+        if os.path.isfile(own):
+            self.load_optimizer_state(torch.load(own, map_location="cpu", weights_only=False))
+        else:
+            theirs = [f for f in self._OPT_FILES if os.path.isfile(os.path.join(folder, f))]
+            if theirs:
+                warnings.warn("%s: the reference's optimiser archives %s are keyed by parameter addresses and are not loaded; "
+                              "Adam moments and step counts restart from zero" % (folder, theirs))

@@ -222,7 +222,8 @@ int evm_ppo_set_params(EvmPpo *q, const float *d_actor, const float *d_critic, i
  * the trainer's vector to d_buf, 1 copies d_buf into the trainer (gradients after an all-reduce, moments of a loaded
  * checkpoint; parameters go through evm_ppo_set_params). */
 int evm_ppo_copy(EvmPpo *q, int what, int net, int to_trainer, float *d_buf, void *stream);
-/* Adam step count of a network: set when set_step >= 0, returned in *step */
+/* Adam step count of a network: set when set_step >= 0, returned in *step.  net 2 = the actor's device-side counter that
+ * evm_ppo_actor_apply advances (SAC's update inside a captured graph). */
 int evm_ppo_adam_step(EvmPpo *q, int net, int set_step, int *step);
 /* Raw advantages of ppo_gae.cpp:134-146 into d_adv [horizon][n_envs]; d_mask = 1 for a trained transition (done is
  * taken as 1 outside the mask, exactly like the reference's padding).  d_stats (optional, DEVICE double[3]) receives
