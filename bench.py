@@ -137,10 +137,6 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                     "the N>1 path with several ranks on ONE GPU)")
     ap.add_argument("--no-update", action="store_true", help="ppo mode: rollout only")
-    ap.add_argument("--sac-update", choices=["hip", "torch"], default="hip",
-                    help="sac mode: twin-Q side of the update in the HIP trainer (csrc/q_kernels.hip) or everything through autograd")
-    ap.add_argument("--ppo-update", choices=["hip", "torch"], default="hip",
-                    help="ppo mode: the update in the HIP trainer (csrc/ppo_kernels.hip) or through PyTorch-ROCm autograd")
     ap.add_argument("--no-stagger", action="store_true", help="skip the episode desynchronisation + pre-roll (all envs then "
                     "leave reset() in lock step and a short run measures physics steps without any reset)")
     args = ap.parse_args()
@@ -195,14 +191,13 @@ def main():
     if args.mode == "ppo":
         from evomotion_amd import VecPpoGaeAgent
         agent = VecPpoGaeAgent(1234, [env.state_dim], [env.action_dim], hidden_size=256, device=local_rank,
-                               horizon=args.horizon, epoch=8, learning_rate=1e-3, update=args.ppo_update)
+                               horizon=args.horizon, epoch=8, learning_rate=1e-3)
 
     sac = None
     if args.mode == "sac":
         from evomotion_amd import VecSacAgent
         sac = VecSacAgent(1234, [env.state_dim], [env.action_dim], batch_size=args.sac_batch, epoch=1, learning_rate=1e-3,
-                          replay_buffer_size=args.replay_slots, train_every=args.train_every, n_envs=n, device=local_rank,
-                          update=args.sac_update)
+                          replay_buffer_size=args.replay_slots, train_every=args.train_every, n_envs=n, device=local_rank)
 
     def run(k_steps, offset=0):
         if sac is not None:
@@ -244,7 +239,7 @@ def main():
     barrier()
     t1 = time.perf_counter()
     ppo_ms, ppo_epochs = 0.0, 0
-    if agent is not None and not args.no_update and args.ppo_update == "hip":
+    if agent is not None and not args.no_update:
         # one more update outside the timed region, with HIP events around each epoch (the events synchronise)
         agent._trainer.timing(True)
         agent.update()
@@ -296,16 +291,14 @@ def main():
             "config": {
                 "workload": ("robot_walk, %d envs/GPU on %d MI355X, SAC: fused MFMA actor forward, device replay ring of %d "
                              "slots, %s (configs[4])" % (n, world, args.replay_slots, "rollout + ring only" if args.no_update else
-                              ("SAC update (batch %d) every %d steps: twin Q networks, targets and soft update in HIP (fp32 MFMA), actor / entropy steps "
-                               "on PyTorch-ROCm, one HIP graph" if args.sac_update == "hip" else "PyTorch-ROCm SAC update (batch %d) every %d steps, one HIP graph")
-                              % (args.sac_batch, args.train_every))) if sac is not None else
+                              "SAC update (batch %d) every %d steps on the device (twin Q, targets, actor and entropy steps, fp32 MFMA), "
+                              "one HIP graph" % (args.sac_batch, args.train_every))) if sac is not None else
                             ("robot_walk, %d envs/GPU on %d MI355X, HIP dynamics only, uniform random actions, "
                              "rollout form with in-band reset (configs[1])" % (n, world)) if agent is None else
                             ("robot_walk, %d envs/GPU on %d MI355X, PPO hidden_size=256, fused MFMA actor-critic forward "
                              "in the rollout, horizon %d, %s (configs[2])" % (n, world, args.horizon,
                               "rollout only" if args.no_update else
-                              ("HIP PPO update (fp32 MFMA forward / backward / weight gradients, epoch 8) every horizon" if args.ppo_update == "hip"
-                               else "PyTorch-ROCm PPO update (epoch 8) every horizon"))),
+                              "HIP PPO update (fp32 MFMA forward / backward / weight gradients, epoch 8) every horizon")),
                 "envs_per_gpu": n,
                 "physics_steps_per_s": world * n * args.steps / elapsed,
                 "do_step_fraction": env_steps / (world * n * args.steps),

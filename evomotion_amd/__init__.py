@@ -6,7 +6,7 @@ and is never imported from here."""
 from ._lib import DEFAULT_SKELETON, EvmError, LIB_PATH  # noqa: F401
 from .env import RolloutStep, Step, VecRobotJump, VecRobotWalk, get_environment  # noqa: F401
 from .agent import (ActorModule, CriticModule, FusedActorCritic, RandomAgent, VecPpoGaeAgent,  # noqa: F401,E402
-                    ppo_train, gae_advantages, truncated_normal_log_pdf, truncated_normal_entropy, truncated_normal_sample)
+                    truncated_normal_log_pdf, truncated_normal_entropy, truncated_normal_sample)
 from .checkpoint import load_into, load_th, save_th  # noqa: F401,E402
 from .replay import ReplayRing  # noqa: F401,E402
-from .sac import EntropyParameter, QNetworkModule, VecSacAgent, sac_train  # noqa: F401,E402
+from .sac import EntropyParameter, QNetworkModule, VecSacAgent  # noqa: F401,E402

@@ -2,12 +2,13 @@
 
   ActorModule / CriticModule / init_weights   evo_motion_networks/src/networks/actor.cpp:9-48, critic.cpp:8-35, init.cpp:7-21
   truncated normal log-pdf / entropy          evo_motion_networks/src/functions.cpp:53-68,113-128
-  PpoGaeAgent::train                          evo_motion_networks/src/agents/ppo_gae.cpp:117-190
+  PpoGaeAgent::train                          evo_motion_networks/src/agents/ppo_gae.cpp:117-190  -> evm_ppo_* (ppo.py)
   PpoGaeAgent::act (batched, fused HIP)       evo_motion_networks/src/agents/ppo_gae.cpp:29-45  -> evm_policy_forward
   RandomAgent::act                            evo_motion_networks/src/agents/debug_agents.cpp:28-30
 
-The rollout forward is the fused MFMA kernel behind the C ABI (`FusedActorCritic`); the PPO update runs on
-PyTorch-ROCm autograd over the same parameters, with an RCCL exchange only here.
+The rollout forward is the fused MFMA kernel behind the C ABI (`FusedActorCritic`); the PPO update is the HIP trainer
+behind `evm_ppo_*` (ppo.py), with an RCCL exchange only there.  The PyTorch-autograd restatement of the update that the
+tests compare against lives in tests/torch_ref.py, not in the product.
 """
 import ctypes
 import math
@@ -105,121 +106,6 @@ def truncated_normal_sample(mu, sigma, lo=-1.0, hi=1.0, u=None):
         u = torch.rand(mu.shape, device=mu.device)
     cdf = torch.clamp(_theta(a) + u * (_theta(b) - _theta(a)), 0.0, 1.0)
     return torch.clamp(math.sqrt(2.0) * torch.erfinv(2.0 * cdf - 1.0) * s + mu, lo, hi)
-
-
-# ---- PPO / GAE update (ppo_gae.cpp:117-190) -----------------------------------------------------------------
-def _dist_ready():
-    return torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
-
-
-def masked_mean_std(x, mask):
-    """mean and unbiased std of x[mask] over ALL ranks (one all_gather of three numbers per rank; Chan's merge)."""
-    sel = torch.masked_select(x, mask)
-    if not _dist_ready():  # single process: literally the reference's two calls (ppo_gae.cpp:148-149)
-        return sel.mean(), sel.std(), torch.tensor(float(sel.numel()), device=x.device, dtype=torch.float64)
-    n = torch.tensor(float(sel.numel()), device=x.device, dtype=torch.float64)
-    mean = sel.double().mean() if sel.numel() else torch.zeros((), device=x.device, dtype=torch.float64)
-    m2 = ((sel.double() - mean) ** 2).sum() if sel.numel() else torch.zeros((), device=x.device, dtype=torch.float64)
-    if _dist_ready():
-        trip = torch.stack([n, mean, m2])
-        allt = [torch.zeros_like(trip) for _ in range(torch.distributed.get_world_size())]
-        torch.distributed.all_gather(allt, trip)
-        n, mean, m2 = allt[0]
-        for t in allt[1:]:
-            nb, mb, m2b = t
-            tot = n + nb
-            if float(tot) == 0:
-                continue
-            d = mb - mean
-            mean = mean + d * nb / tot
-            m2 = m2 + m2b + d * d * n * nb / tot
-            n = tot
-    std = torch.sqrt(m2 / torch.clamp(n - 1, min=1.0))
-    return mean.to(x.dtype), std.to(x.dtype), n
-
-
-def gae_advantages(rewards, done, curr_values, next_values, gamma, lam, mask=None):
-    """[B,T,1] tensors -> (mask, normalised advantages, returns).
-
-    mask=None reproduces the reference exactly: trajectories are padded with done = 1 and the mask is the
-    shifted done flag (ppo_gae.cpp:127-132).  The vectorised rollout passes an explicit transition mask instead
-    (rows contain settle steps in the middle, not only trailing padding); a masked step contributes nothing and
-    stops the backward recursion, which is what the shifted mask does for trailing padding."""
-    B, T = rewards.shape[:2]
-    explicit = mask is not None
-    if not explicit:
-        mask = torch.eq(torch.cat([torch.ones(B, 1, 1, device=rewards.device), (1.0 - done)[:, : T - 1]], 1), 1.0)
-    deltas = rewards + (1.0 - done) * gamma * next_values - curr_values
-    g = torch.zeros(B, 1, device=rewards.device)
-    adv = []
-    for t in range(T - 1, -1, -1):
-        g = deltas[:, t] * mask[:, t] + gamma * lam * (1.0 - done[:, t]) * g
-        if explicit:
-            g = g * mask[:, t]
-        adv.append(g)
-    adv = torch.stack(adv, 1).flip([1])
-    mean, std, _ = masked_mean_std(adv, mask)
-    adv = (adv - mean) / (std + 1e-8)
-    return mask, adv, adv + curr_values  # returns = NORMALISED advantages + V (SURVEY App. D.8)
-
-
-def _all_reduce_grads(params):
-    if not _dist_ready():
-        return
-    flat = torch.cat([p.grad.reshape(-1) for p in params])
-    torch.distributed.all_reduce(flat)  # losses are normalised by the global count, so SUM is the global gradient
-    o = 0
-    for p in params:
-        n = p.numel()
-        p.grad.copy_(flat[o:o + n].view_as(p))
-        o += n
-
-
-def _all_reduce_grads_mean(params):
-    """Losses that are local means (SAC, soft_actor_critic.cpp:127-153): equal shards per rank, so the global-mean
-    gradient is the rank average."""
-    if not _dist_ready():
-        return
-    _all_reduce_grads(params)
-    w = torch.distributed.get_world_size()
-    for p in params:
-        p.grad.div_(w)
-
-
-def ppo_train(actor, critic, actor_opt, critic_opt, states, actions, rewards, done, log_prob, curr_values, next_values,
-              gamma, lam, epsilon, entropy_factor, critic_loss_factor, epoch, clip_grad_norm, mask=None):
-    """One PpoGaeAgent::train() call on padded [B,T,*] tensors; returns the last (actor_loss, critic_loss)."""
-    actor.train()
-    critic.train()
-    mask, adv, returns = gae_advantages(rewards, done, curr_values, next_values, gamma, lam, mask)
-    adv, returns = adv.detach(), returns.detach()
-    n_local = mask.sum()
-    n_glob = n_local.double().clone()
-    if _dist_ready():
-        torch.distributed.all_reduce(n_glob)
-    scale = (n_local.double() / n_glob).float() if _dist_ready() else None
-    a_loss = c_loss = None
-    for _ in range(epoch):
-        mu, sigma = actor(states)
-        lp = truncated_normal_log_pdf(actions, mu, sigma)
-        ent = truncated_normal_entropy(mu, sigma)
-        value = critic(states)
-        ratios = torch.exp(lp - log_prob)
-        s1 = ratios * adv
-        s2 = torch.clamp(ratios, 1.0 - epsilon, 1.0 + epsilon) * adv
-        a_loss = -torch.mean(torch.masked_select(torch.min(s1, s2) + entropy_factor * ent, mask.expand_as(ent)))
-        actor_opt.zero_grad()
-        (a_loss * scale if scale is not None else a_loss).backward()
-        _all_reduce_grads(list(actor.parameters()))
-        nn.utils.clip_grad_norm_(actor.parameters(), clip_grad_norm)
-        actor_opt.step()
-        c_loss = critic_loss_factor * torch.mean(torch.masked_select(torch.pow(value - returns, 2.0), mask))
-        critic_opt.zero_grad()
-        (c_loss * scale if scale is not None else c_loss).backward()
-        _all_reduce_grads(list(critic.parameters()))
-        nn.utils.clip_grad_norm_(critic.parameters(), clip_grad_norm)
-        critic_opt.step()
-    return float(a_loss.detach()), float(c_loss.detach())
 
 
 # ---- fused rollout forward (HIP) ----------------------------------------------------------------------------
@@ -359,11 +245,9 @@ class VecPpoGaeAgent:
 
     def __init__(self, seed, state_space, action_space, hidden_size=256, gamma=0.99, lam=0.95, epsilon=0.2,
                  entropy_factor=0.01, critic_loss_factor=0.5, epoch=8, learning_rate=1e-3, clip_grad_norm=0.5,
-                 device=0, horizon=32, update="hip"):
-        """update = "hip": PpoGaeAgent::train runs in the HIP trainer (ppo.py, csrc/ppo_kernels.hip), which owns the master
-        weights and Adam state; "torch": the same update through PyTorch-ROCm autograd (ppo_train), kept for comparison."""
-        if update not in ("hip", "torch"):
-            raise ValueError("update must be 'hip' or 'torch'")
+                 device=0, horizon=32):
+        """PpoGaeAgent::train runs in the HIP trainer (ppo.py, csrc/ppo_kernels.hip), which owns the master weights and the
+        Adam state; the torch modules / optimisers below are the initialisation (init.cpp:7-21) and the checkpoint views."""
         torch.manual_seed(seed)
         self.device = torch.device("cuda", device)
         self.actor = ActorModule(state_space, action_space, hidden_size).to(self.device)
@@ -381,7 +265,6 @@ class VecPpoGaeAgent:
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             self.noise_seed = (seed ^ (torch.distributed.get_rank() * 0x9E3779B97F4A7C15)) & 0x7FFFFFFF
         self._buf = None
-        self.update_mode = update
         self.learning_rate = learning_rate
         self._trainer = None
         self._modules_stale = False
@@ -485,24 +368,15 @@ class VecPpoGaeAgent:
         return b
 
     def update(self):
+        """PpoGaeAgent::train (ppo_gae.cpp:117-190) on the device.  Only do_step transitions (valid == 1) are trained on:
+        settle calls (0) and reset()'s own emission (2) are not transitions."""
         b = self._buf
-        if self.update_mode == "hip":
-            T, N = b["rewards"].shape
-            tr = self._get_trainer(T * N)
-            mask = (b["valid_u8"] == 1).to(torch.uint8)
-            hp = self.hp
-            out = tr.train(b["states"], b["actions"], b["rewards"], b["done_u8"], b["logp"], b["values"], b["next_values"], mask,
-                           hp["gamma"], hp["lam"], hp["epsilon"], hp["entropy_factor"], hp["critic_loss_factor"], hp["epoch"],
-                           self.learning_rate, hp["clip_grad_norm"])
-            self._modules_stale = True
-            return out
-        # [T,N] -> the reference's [B,T,1] layout; only do_step transitions (valid == 1) are trained on: settle
-        # calls (0) and reset()'s own emission (2) are not transitions
-        tr = lambda x: x.transpose(0, 1).contiguous()
-        mask = tr(b["valid"]).unsqueeze(-1) == 1.0
-        done = torch.where(mask, tr(b["done"]).unsqueeze(-1), torch.ones((), device=self.device))
-        out = ppo_train(self.actor, self.critic, self.actor_opt, self.critic_opt, tr(b["states"]), tr(b["actions"]),
-                        tr(b["rewards"]).unsqueeze(-1), done, tr(b["logp"]), tr(b["values"]).unsqueeze(-1),
-                        tr(b["next_values"]).unsqueeze(-1), mask=mask, **self.hp)
-        self.fused.load_modules(self.actor, self.critic)
+        T, N = b["rewards"].shape
+        tr = self._get_trainer(T * N)
+        mask = (b["valid_u8"] == 1).to(torch.uint8)
+        hp = self.hp
+        out = tr.train(b["states"], b["actions"], b["rewards"], b["done_u8"], b["logp"], b["values"], b["next_values"], mask,
+                       hp["gamma"], hp["lam"], hp["epsilon"], hp["entropy_factor"], hp["critic_loss_factor"], hp["epoch"],
+                       self.learning_rate, hp["clip_grad_norm"])
+        self._modules_stale = True
         return out

@@ -7,15 +7,16 @@
   SoftActorCriticAgent::act      soft_actor_critic.cpp:47-62 (batched: fused HIP actor forward + device replay ring)
   ReplayBuffer                   evo_motion_networks/src/replay_buffer.cpp:16-52,146-153 -> evm_replay_* (HIP)
 
-The update runs on PyTorch-ROCm autograd over mirrors with the reference's parameter names and reproduces the
-reference's post-train() outputs (tests/golden/sac_golden.txt, tests/test_sac_host.py).
+The update runs on the device (qnet.py / csrc/q_kernels.hip and the PPO trainer's actor kernels); the module mirrors here
+carry the reference's parameter names for initialisation and checkpoints.  The PyTorch-autograd restatement of train() that
+the tests pin to the reference's golden call (tests/golden/sac_golden.txt) lives in tests/torch_ref.py.
 """
 import math
 
 import torch
 from torch import nn
 
-from .agent import ActorModule, init_weights, truncated_normal_log_pdf, truncated_normal_sample
+from .agent import ActorModule, init_weights
 
 
 class QNetworkModule(nn.Module):
@@ -59,46 +60,6 @@ def soft_update(to, frm, tau):
         torch._foreach_add_(ts, fs, alpha=tau)
 
 
-def sac_train(actor, critic_1, critic_2, target_critic_1, target_critic_2, entropy, actor_opt, critic_1_opt, critic_2_opt,
-              entropy_opt, states, actions, rewards, done, next_states, gamma, tau, target_entropy,
-              u_next=None, u_curr=None, grad_hook=None):
-    """One SoftActorCriticAgent::train() call (soft_actor_critic.cpp:93-170).  `u_next` / `u_curr` supply the two
-    at::rand draws; `grad_hook(params)` is called between backward and step (data-parallel all-reduce)."""
-    with torch.no_grad():
-        next_mu, next_sigma = actor(next_states)
-        next_action = truncated_normal_sample(next_mu, next_sigma, -1.0, 1.0, u=u_next)
-        next_logp = truncated_normal_log_pdf(next_action, next_mu, next_sigma, -1.0, 1.0).sum(-1, keepdim=True)
-        tq = torch.min(target_critic_1(next_states, next_action), target_critic_2(next_states, next_action))
-        target_v = tq - entropy.alpha() * next_logp
-        target_q = rewards + (1.0 - done) * gamma * target_v
-
-    def step(opt, loss, params):
-        opt.zero_grad()
-        loss.backward()
-        if grad_hook is not None:
-            grad_hook(params)
-        opt.step()
-
-    loss_c1 = torch.nn.functional.mse_loss(critic_1(states, actions), target_q)
-    step(critic_1_opt, loss_c1, list(critic_1.parameters()))
-    loss_c2 = torch.nn.functional.mse_loss(critic_2(states, actions), target_q)
-    step(critic_2_opt, loss_c2, list(critic_2.parameters()))
-
-    mu, sigma = actor(states)
-    curr_action = truncated_normal_sample(mu, sigma, -1.0, 1.0, u=u_curr)
-    curr_logp = truncated_normal_log_pdf(curr_action, mu, sigma, -1.0, 1.0).sum(-1, keepdim=True)
-    q = torch.min(critic_1(states, curr_action), critic_2(states, curr_action))
-    loss_actor = torch.mean(entropy.alpha().detach() * curr_logp - q)
-    step(actor_opt, loss_actor, list(actor.parameters()))
-
-    loss_entropy = -torch.mean(entropy.log_alpha * (curr_logp.detach() + target_entropy))
-    step(entropy_opt, loss_entropy, list(entropy.parameters()))
-
-    soft_update(target_critic_1, critic_1, tau)
-    soft_update(target_critic_2, critic_2, tau)
-    return dict(actor=loss_actor.detach(), critic_1=loss_c1.detach(), critic_2=loss_c2.detach(), entropy=loss_entropy.detach())
-
-
 def _rank_seed(seed):
     """Equal seeds on every rank give equal initial weights (needed) — and would give every data-parallel replica the same
     uniform draws for exploration and replay sampling.  Mix the rank into the seed used for those."""
@@ -116,15 +77,12 @@ class VecSacAgent:
 
     def __init__(self, seed, state_space, action_space, actor_hidden_size=256, critic_hidden_size=256, batch_size=256,
                  epoch=1, learning_rate=1e-3, gamma=0.99, tau=0.005, replay_buffer_size=1024, train_every=4, n_envs=4096,
-                 device=0, use_graph=True, update="hip"):
-        """update = "hip": SoftActorCriticAgent::train on the device — target actions from the fused policy kernel, the twin
-        critics, their targets, the critics' mse update and the soft update in the HIP Q trainer (qnet.py,
-        csrc/q_kernels.hip), the actor step (forward, reparameterised sample, action gradient through the critics,
-        backward) on the same MLP kernels; PyTorch keeps the Adam steps of the actor and of the entropy parameter and the
-        target arithmetic.  "torch": everything through autograd (sac_train), kept for comparison."""
-        if update not in ("hip", "torch"):
-            raise ValueError("update must be 'hip' or 'torch'")
-        from .agent import FusedActorCritic, _all_reduce_grads_mean
+                 device=0, use_graph=True):
+        """SoftActorCriticAgent::train runs on the device — target actions from the fused policy kernel, the twin critics,
+        their targets, the critics' mse update and the soft update in the HIP Q trainer (qnet.py, csrc/q_kernels.hip), the
+        actor step (forward, reparameterised sample, action gradient through the critics, backward, Adam) on the PPO
+        trainer's actor kernels, the entropy parameter's step in its own kernel."""
+        from .agent import FusedActorCritic
         from .replay import ReplayRing
         torch.manual_seed(seed)
         self.device = torch.device("cuda", device)
@@ -150,31 +108,27 @@ class VecSacAgent:
         self._act = (torch.empty(n_envs, action_space[0], device=self.device), torch.empty(n_envs, action_space[0], device=self.device), None)
         self.seed, self.global_step, self.train_steps = seed, 0, 0
         self.noise_seed = _rank_seed(seed)  # weights share `seed` across ranks, exploration noise and replay draws do not
-        self._grad_hook = _all_reduce_grads_mean
         self.last_losses = None
         self._graph = None
         self._stored_margin, self._pushes_since_check = 0, 0  # has_enough(): see there
         B, S, A = batch_size, state_space[0], action_space[0]
         z = lambda *sh: torch.zeros(*sh, device=self.device)
         self._batch = (z(B, S), z(B, A), z(B), z(B), z(B, S))
-        self.update_mode = update
         self.learning_rate = learning_rate
-        self.twinq = None
-        if update == "hip":
-            from .qnet import FusedTwinQ
-            self.twinq = FusedTwinQ(S, A, critic_hidden_size, B, device)
-            self._push_critics()
-            self._tq_out = {2: z(B), 3: z(B)}
-            self._next_act = (z(B, A), z(B, A), None)
-            # the actor step runs on the PPO trainer's actor kernels (same ActorModule); its critic slot is unused
-            from .ppo import FusedPpoTrainer
-            self._actor_tr = FusedPpoTrainer(self.fused, B)
-            self._critic_dummy = z(self._actor_tr.n_params[1])
-            self._abuf = dict(mu=z(B, A), sigma=z(B, A), action=z(B, A), logp=z(B), qmin=z(B), dqda=z(B, A), dmu=z(B, A), dsigma=z(B, A),
-                              target_q=z(B), losses=z(2))
-            self._ent_state = z(2)                                                   # Adam exp_avg, exp_avg_sq of log_alpha
-            self._ent_step = torch.zeros(1, device=self.device, dtype=torch.int32)
-            self._push_actor()
+        from .qnet import FusedTwinQ
+        self.twinq = FusedTwinQ(S, A, critic_hidden_size, B, device)
+        self._push_critics()
+        self._tq_out = {2: z(B), 3: z(B)}
+        self._next_act = (z(B, A), z(B, A), None)
+        # the actor step runs on the PPO trainer's actor kernels (same ActorModule); its critic slot is unused
+        from .ppo import FusedPpoTrainer
+        self._actor_tr = FusedPpoTrainer(self.fused, B)
+        self._critic_dummy = z(self._actor_tr.n_params[1])
+        self._abuf = dict(mu=z(B, A), sigma=z(B, A), action=z(B, A), logp=z(B), qmin=z(B), dqda=z(B, A), dmu=z(B, A), dsigma=z(B, A),
+                          target_q=z(B), losses=z(2))
+        self._ent_state = z(2)                                                   # Adam exp_avg, exp_avg_sq of log_alpha
+        self._ent_step = torch.zeros(1, device=self.device, dtype=torch.int32)
+        self._push_actor()
 
     def _push_actor(self):
         """the actor module -> the trainer, which owns its master weights and Adam state from here on (sync_modules() copies
@@ -190,8 +144,6 @@ class VecSacAgent:
 
     def sync_modules(self):
         """the trainers' actor / critic / target weights -> the torch modules (save(), evaluation)"""
-        if self.twinq is None:
-            return
         from .qnet import PARAMS
         from .ppo import PARAMS as PP, ACTOR
         flat = self._actor_tr.vector(PP, ACTOR)
@@ -256,7 +208,7 @@ class VecSacAgent:
             loss_entropy = -torch.mean(self.entropy.log_alpha * (ab["logp"] + self.target_entropy))
             self.entropy_opt.zero_grad()
             loss_entropy.backward()
-            self._grad_hook(list(self.entropy.parameters()))
+            self.entropy.log_alpha.grad.copy_(all_reduce_mean(self.entropy.log_alpha.grad))
             self.entropy_opt.step()
             ab["losses"].copy_(torch.stack([loss_actor.detach(), loss_entropy.detach()]))
         else:
@@ -295,13 +247,7 @@ class VecSacAgent:
         return stored >= self.batch_size
 
     def _train_once(self):
-        if self.update_mode == "hip":
-            return self._train_once_hip()
-        s, a, r, d, n = self._batch
-        return sac_train(self.actor, self.critic_1, self.critic_2, self.target_critic_1, self.target_critic_2, self.entropy,
-                         self.actor_opt, self.critic_1_opt, self.critic_2_opt, self.entropy_opt, s, a, r.unsqueeze(-1),
-                         d.unsqueeze(-1), n, self.gamma, self.tau, self.target_entropy,
-                         grad_hook=None if self.use_graph else self._grad_hook)
+        return self._train_once_hip()
 
     def update(self):
         for e in range(self.epoch):
@@ -327,37 +273,26 @@ class VecSacAgent:
             else:
                 self._graph.replay()
             self.train_steps += 1
-        if self.update_mode != "hip":  # (the device path has already repacked the actor for the rollout kernel)
-            self.fused.set_actor(self.actor)
 
     _OPT_FILES = ("actor_optimizer.th", "critic_1_optimizer.th", "critic_2_optimizer.th", "entropy_optimizer.th")
 
     def _snapshot(self):
-        mods = (self.actor, self.critic_1, self.critic_2, self.target_critic_1, self.target_critic_2, self.entropy)
         snap = dict(opt=self.optimizer_state(), train_steps=self.train_steps)
-        if self.twinq is not None:
-            from .ppo import ACTOR, PARAMS as PP
-            from .qnet import PARAMS
-            snap["actor"] = self._actor_tr.vector(PP, ACTOR).clone()
-            snap["q"] = [self.twinq.vector(PARAMS, i).clone() for i in range(4)]
-            snap["log_alpha"] = self.entropy.log_alpha.detach().clone()
-        else:
-            snap["modules"] = [{k: v.clone() for k, v in m.state_dict().items()} for m in mods]
+        from .ppo import ACTOR, PARAMS as PP
+        from .qnet import PARAMS
+        snap["actor"] = self._actor_tr.vector(PP, ACTOR).clone()
+        snap["q"] = [self.twinq.vector(PARAMS, i).clone() for i in range(4)]
+        snap["log_alpha"] = self.entropy.log_alpha.detach().clone()
         return snap
 
     def _restore(self, snap):
-        mods = (self.actor, self.critic_1, self.critic_2, self.target_critic_1, self.target_critic_2, self.entropy)
-        if self.twinq is not None:
-            from .ppo import ACTOR, PARAMS as PP
-            from .qnet import PARAMS
-            self._actor_tr.set_flat(snap["actor"], self._critic_dummy, reset_optimizer=False)
-            for i in range(4):
-                self.twinq.load_vector(PARAMS, i, snap["q"][i])
-            with torch.no_grad():
-                self.entropy.log_alpha.copy_(snap["log_alpha"])
-        else:
-            for m, sd in zip(mods, snap["modules"]):
-                m.load_state_dict(sd)
+        from .ppo import ACTOR, PARAMS as PP
+        from .qnet import PARAMS
+        self._actor_tr.set_flat(snap["actor"], self._critic_dummy, reset_optimizer=False)
+        for i in range(4):
+            self.twinq.load_vector(PARAMS, i, snap["q"][i])
+        with torch.no_grad():
+            self.entropy.log_alpha.copy_(snap["log_alpha"])
         self.load_optimizer_state(snap["opt"])
         self.train_steps = snap["train_steps"]
 
@@ -376,9 +311,6 @@ class VecSacAgent:
 
     def optimizer_state(self):
         """Adam moments and step counts of the four optimisers, wherever they live (HIP trainers or torch.optim)"""
-        if self.twinq is None:
-            return dict(kind="torch", actor=self.actor_opt.state_dict(), critic_1=self.critic_1_opt.state_dict(),
-                        critic_2=self.critic_2_opt.state_dict(), entropy=self.entropy_opt.state_dict())
         from .ppo import ACTOR, ACTOR_DEV_STEP, EXP_AVG, EXP_AVG_SQ
         tr, tq = self._actor_tr, self.twinq
         out = dict(kind="hip", train_steps=self.train_steps,
@@ -389,12 +321,6 @@ class VecSacAgent:
         return out
 
     def load_optimizer_state(self, st):
-        if st["kind"] == "torch":
-            for k, opt in (("actor", self.actor_opt), ("critic_1", self.critic_1_opt), ("critic_2", self.critic_2_opt), ("entropy", self.entropy_opt)):
-                opt.load_state_dict(st[k])
-            return
-        if self.twinq is None:
-            raise RuntimeError("optimiser state of the HIP trainers cannot be loaded into the torch optimisers")
         from .ppo import ACTOR, ACTOR_DEV_STEP, EXP_AVG, EXP_AVG_SQ
         tr, tq = self._actor_tr, self.twinq
         tr.load_vector(EXP_AVG, ACTOR, st["actor"]["m"].to(self.device))
@@ -420,11 +346,10 @@ class VecSacAgent:
                      (self.critic_2, "critic_2.th"), (self.target_critic_2, "target_critic_2.th"), (self.entropy, "entropy.th")):
             load_into(m, os.path.join(folder, f))
         self.fused.set_actor(self.actor)
-        if self.twinq is not None:
-            self._push_critics()
-            self._push_actor()
-            self._ent_state.zero_()
-            self._ent_step.zero_()
+        self._push_critics()
+        self._push_actor()
+        self._ent_state.zero_()
+        self._ent_step.zero_()
         own = os.path.join(folder, "sac_optimizers.pt")
         if os.path.isfile(own):
             self.load_optimizer_state(torch.load(own, map_location="cpu", weights_only=False))

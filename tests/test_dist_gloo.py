@@ -10,6 +10,9 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import torch_ref  # noqa: E402  (autograd restatements: the comparison side)
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -50,7 +53,7 @@ def _worker(rank, world, port, out):
     full = _make_batch(3, 8, 6)
     shard = {k: v[rank * 4:(rank + 1) * 4] for k, v in full.items()}  # envs are sharded by rank, nothing else
     a, c, oa, oc = _nets(agent)
-    agent.ppo_train(a, c, oa, oc, **shard, **HP)
+    torch_ref.ppo_train(a, c, oa, oc, **shard, **HP)
     flat = torch.cat([p.detach().reshape(-1) for p in list(a.parameters()) + list(c.parameters())])
     gathered = [torch.zeros_like(flat) for _ in range(world)]
     dist.all_gather(gathered, flat)
@@ -64,7 +67,7 @@ def test_two_rank_update_equals_single_process(hip_lib):
     torch.set_num_threads(1)
     full = _make_batch(3, 8, 6)
     a, c, oa, oc = _nets(agent)
-    agent.ppo_train(a, c, oa, oc, **full, **HP)
+    torch_ref.ppo_train(a, c, oa, oc, **full, **HP)
     ref = torch.cat([p.detach().reshape(-1) for p in list(a.parameters()) + list(c.parameters())]).numpy()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -112,9 +115,9 @@ def _sac_worker(rank, world, port, out):
     full = _sac_batch()
     shard = {k: v[rank * 8:(rank + 1) * 8] for k, v in full.items()}
     a, qs, e, opts = _sac_nets()
-    sac.sac_train(a, qs[0], qs[1], qs[2], qs[3], e, *opts, shard["states"], shard["actions"], shard["rewards"], shard["done"],
+    torch_ref.sac_train(a, qs[0], qs[1], qs[2], qs[3], e, *opts, shard["states"], shard["actions"], shard["rewards"], shard["done"],
                   shard["next_states"], 0.99, 0.005, -3.0, u_next=shard["u_next"], u_curr=shard["u_curr"],
-                  grad_hook=agent._all_reduce_grads_mean)
+                  grad_hook=torch_ref._all_reduce_grads_mean)
     flat = _sac_flat(a, qs, e)
     gathered = [torch.zeros_like(flat) for _ in range(world)]
     dist.all_gather(gathered, flat)
@@ -128,7 +131,7 @@ def test_two_rank_sac_update_equals_single_process(hip_lib):
     torch.set_num_threads(1)
     full = _sac_batch()
     a, qs, e, opts = _sac_nets()
-    sac.sac_train(a, qs[0], qs[1], qs[2], qs[3], e, *opts, full["states"], full["actions"], full["rewards"], full["done"],
+    torch_ref.sac_train(a, qs[0], qs[1], qs[2], qs[3], e, *opts, full["states"], full["actions"], full["rewards"], full["done"],
                   full["next_states"], 0.99, 0.005, -3.0, u_next=full["u_next"], u_curr=full["u_curr"])
     ref = _sac_flat(a, qs, e).numpy()
     ctx = mp.get_context("spawn")

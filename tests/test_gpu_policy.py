@@ -175,44 +175,6 @@ def test_device_side_weight_repack_equals_host_packing(fused):
         assert torch.equal(r, o)
 
 
-def test_sac_agent_smoke_and_graph_replay_matches_eager():
-    """VecSacAgent: act + ring + update for a few steps; the captured (HIP graph) update gives the same parameters as
-    the eager update from the same state, batch and draws."""
-    import torch
-    from evomotion_amd import VecRobotWalk, VecSacAgent
-    n = 128
-    env = VecRobotWalk(n, seed=5)
-    env.reset()
-    ag = VecSacAgent(11, [371], [12], batch_size=64, epoch=1, replay_buffer_size=16, train_every=2, n_envs=n, use_graph=True,
-                     update="torch")
-    assert ag.count_parameters() == 1094941
-    for _ in range(12):
-        st = ag.step(env)
-    assert ag.replay.stats()["pushes"] == 12 and ag.train_steps >= 5
-    assert all(torch.isfinite(p).all() for p in ag.actor.parameters())
-    assert torch.isfinite(st.state).all() and float(st.state.abs().max()) > 0
-    # graph vs eager on a cloned agent state
-    eager = VecSacAgent(11, [371], [12], batch_size=64, epoch=1, replay_buffer_size=16, train_every=2, n_envs=n, use_graph=False,
-                        update="torch")
-    for dst, src in ((eager.actor, ag.actor), (eager.critic_1, ag.critic_1), (eager.critic_2, ag.critic_2),
-                     (eager.target_critic_1, ag.target_critic_1), (eager.target_critic_2, ag.target_critic_2), (eager.entropy, ag.entropy)):
-        dst.load_state_dict(src.state_dict())
-    for dst, src in ((eager.actor_opt, ag.actor_opt), (eager.critic_1_opt, ag.critic_1_opt), (eager.critic_2_opt, ag.critic_2_opt),
-                     (eager.entropy_opt, ag.entropy_opt)):
-        sd = src.state_dict()
-        for st_ in sd["state"].values():
-            st_["step"] = st_["step"].detach().cpu() if torch.is_tensor(st_["step"]) else st_["step"]
-        dst.load_state_dict(sd)
-    for t_dst, t_src in zip(eager._batch, ag._batch):
-        t_dst.copy_(t_src)
-    torch.manual_seed(123); eager._train_once()
-    torch.manual_seed(123); ag._graph.replay()
-    # same batch; the uniform draws differ (graph-safe Philox offsets), so compare the critics, which do not use them
-    # beyond the target action: tolerance covers that stochastic target
-    for p, q in zip(eager.critic_1.parameters(), ag.critic_1.parameters()):
-        assert torch.isfinite(q).all() and float((p - q).abs().max()) < 5e-2
-
-
 def test_rollout_and_update_smoke():
     import torch
     from evomotion_amd import VecPpoGaeAgent, VecRobotWalk
@@ -236,27 +198,37 @@ def _flat(m):
 
 
 def test_sac_hip_update_matches_torch_update():
-    """one SoftActorCriticAgent::train call: the HIP Q side (targets, critics, soft update) + autograd actor / entropy steps
-    against the all-autograd sac_train from the same weights, batch and uniform draws"""
+    """two SoftActorCriticAgent::train calls on the device against the all-autograd restatement (tests/torch_ref.py::sac_train,
+    pinned on the CPU to the reference's golden train() call) from the same weights, batch and uniform draws"""
+    import copy
     import torch
+    import torch_ref
     from evomotion_amd import VecSacAgent
     from evomotion_amd.qnet import PARAMS
     kw = dict(batch_size=512, epoch=1, replay_buffer_size=4, train_every=2, n_envs=64, use_graph=False)
-    hip = VecSacAgent(21, [371], [12], update="hip", **kw)
-    ref = VecSacAgent(21, [371], [12], update="torch", **kw)
-    assert all(torch.equal(a, b) for a, b in zip(hip.actor.parameters(), ref.actor.parameters()))
+    hip = VecSacAgent(21, [371], [12], **kw)
+
+    class Ref:  # torch modules + torch.optim.Adam, the reference's own structure
+        pass
+    ref = Ref()
+    for name in ("actor", "critic_1", "critic_2", "target_critic_1", "target_critic_2", "entropy"):
+        setattr(ref, name, copy.deepcopy(getattr(hip, name)))
+    opts = [torch.optim.Adam(m.parameters(), lr=1e-3) for m in (ref.actor, ref.critic_1, ref.critic_2, ref.entropy)]
     g = torch.Generator(device="cuda"); g.manual_seed(3)
     s = (torch.rand(512, 371, device="cuda", generator=g) * 2 - 1) * 1.5
     a = torch.rand(512, 12, device="cuda", generator=g) * 2 - 1
     r = torch.rand(512, device="cuda", generator=g) * 2 - 1
     d = (torch.rand(512, device="cuda", generator=g) < 0.1).float()
     n = (torch.rand(512, 371, device="cuda", generator=g) * 2 - 1) * 1.5
-    for ag in (hip, ref):
-        for dst, src in zip(ag._batch, (s, a, r, d, n)):
-            dst.copy_(src)
+    for dst, src in zip(hip._batch, (s, a, r, d, n)):
+        dst.copy_(src)
     for it in range(2):
-        torch.manual_seed(100 + it); lh = hip._train_once()
-        torch.manual_seed(100 + it); lr_ = ref._train_once()
+        u_next = torch.rand(512, 12, device="cuda", generator=g)
+        u_curr = torch.rand(512, 12, device="cuda", generator=g)
+        lh = hip._train_once_hip(u_next=u_next, u_curr=u_curr)
+        lr_ = torch_ref.sac_train(ref.actor, ref.critic_1, ref.critic_2, ref.target_critic_1, ref.target_critic_2, ref.entropy,
+                                  opts[0], opts[1], opts[2], opts[3], s, a, r.unsqueeze(-1), d.unsqueeze(-1), n, hip.gamma, hip.tau,
+                                  hip.target_entropy, u_next=u_next, u_curr=u_curr)
         for k in ("critic_1", "critic_2", "actor", "entropy"):
             assert abs(float(lh[k]) - float(lr_[k])) < 2e-4 * max(1.0, abs(float(lr_[k]))), (it, k, float(lh[k]), float(lr_[k]))
     hip.sync_modules()  # the trainers own the weights; the torch modules are refreshed on demand
@@ -288,7 +260,6 @@ def test_sac_hip_agent_graph_replay():
     env = VecRobotWalk(n, seed=5)
     env.reset()
     ag = VecSacAgent(11, [371], [12], batch_size=64, epoch=1, replay_buffer_size=16, train_every=2, n_envs=n, use_graph=True)
-    assert ag.update_mode == "hip"
     w0 = ag.twinq.vector(PARAMS, 0).clone()
     t0 = ag.twinq.vector(PARAMS, 2).clone()
     for _ in range(12):

@@ -1,4 +1,4 @@
-"""PPO / GAE update on the device (evm_ppo_*) against PyTorch autograd of the reference's formulas (agent.ppo_train,
+"""PPO / GAE update on the device (evm_ppo_*) against PyTorch autograd of the reference's formulas (tests/torch_ref.py::ppo_train,
 itself pinned to the reference's golden train call in test_agent_host.py) and against that golden call directly."""
 import os
 import sys
@@ -10,6 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import agent_oracle as ao  # noqa: E402
 import golden_io  # noqa: E402
+import torch_ref  # noqa: E402  (tests/torch_ref.py: autograd restatement of PpoGaeAgent::train)
 
 pytestmark = pytest.mark.gpu
 
@@ -78,7 +79,7 @@ def test_gae_matches_torch():
     tb = lambda x: x.transpose(0, 1).contiguous().unsqueeze(-1)
     mb = tb(mask) == 1
     dn = torch.where(mb, tb(done).float(), torch.ones((), device="cuda"))
-    m2, a2, r2 = agent.gae_advantages(tb(rewards), dn, tb(values), tb(next_values), 0.99, 0.95, mask=mb)
+    m2, a2, r2 = torch_ref.gae_advantages(tb(rewards), dn, tb(values), tb(next_values), 0.99, 0.95, mask=mb)
     assert n_glob == float(mb.sum())
     sel = mb.squeeze(-1).transpose(0, 1)
     np.testing.assert_allclose(adv[sel].cpu().numpy(), a2.squeeze(-1).transpose(0, 1)[sel].cpu().numpy(), atol=2e-5)
@@ -212,7 +213,7 @@ def test_epochs_in_lock_step_with_autograd_and_adam():
 
 
 def test_update_matches_torch_update():
-    """the whole train() call (GAE + 3 epochs) against agent.ppo_train with torch.optim.Adam, both free-running.  The
+    """the whole train() call (GAE + 3 epochs) against torch_ref.ppo_train with torch.optim.Adam, both free-running.  The
     clipped surrogate is discontinuous in the weights and the networks amplify weight noise through two LayerNorms
     (tools/diag_ppo*.py), so after three epochs the outputs agree to ~1e-3, not to rounding."""
     import torch
@@ -234,7 +235,7 @@ def test_update_matches_torch_update():
     x = states[0, :256]
     with torch.no_grad():
         mu0, _ = actor(x)
-    ra, rc = agent.ppo_train(actor, critic, oa, oc, tb(states), tb(actions), tb(rewards).unsqueeze(-1), dn, tb(logp),
+    ra, rc = torch_ref.ppo_train(actor, critic, oa, oc, tb(states), tb(actions), tb(rewards).unsqueeze(-1), dn, tb(logp),
                              tb(values).unsqueeze(-1), tb(next_values).unsqueeze(-1), mask=mb, epoch=3, **HP)
     assert abs(la - ra) < 1e-4 * max(1.0, abs(ra)) and abs(lc - rc) < 1e-4 * max(1.0, abs(rc))
     _, _, value, mu, sigma = f.forward(x, uniform=torch.full((256, 12), 0.5, device="cuda"), want_dist=True)

@@ -64,7 +64,7 @@ def test_q_network_names_counts_and_forward(gold):
 
 
 def test_one_train_call_reproduces_the_reference(gold):
-    from evomotion_amd.sac import sac_train
+    from torch_ref import sac_train
     actor, (c1, c2, t1, t2), ent = build()
     opts = [torch.optim.Adam(m.parameters(), lr=1e-3) for m in (actor, c1, c2, ent)]
     t = lambda k: torch.from_numpy(gold[k])

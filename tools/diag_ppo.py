@@ -18,7 +18,8 @@ HP = T.HP
 # torch path (GPU)
 a2, c2 = copy.deepcopy(actor), copy.deepcopy(critic)
 # epoch-1 gradients
-mk, adv, ret = agent.gae_advantages(t("ppo_rewards"), done, t("ppo_curr_values"), t("ppo_next_values"), 0.99, 0.95)
+import torch_ref
+mk, adv, ret = torch_ref.gae_advantages(t("ppo_rewards"), done, t("ppo_curr_values"), t("ppo_next_values"), 0.99, 0.95)
 adv_m, ret_m, ng = tr.gae(tm(t("ppo_rewards").squeeze(-1)), tm(done.squeeze(-1)).to(torch.uint8), tm(t("ppo_curr_values").squeeze(-1)), tm(t("ppo_next_values").squeeze(-1)), tm(mask.squeeze(-1)).to(torch.uint8), 0.99, 0.95)
 print("n", ng, "adv err", float((tm(adv.squeeze(-1)) - adv_m)[tm(mask.squeeze(-1))].abs().max()))
 rows = 28
