@@ -123,7 +123,7 @@ int evm_env_create(const char *skeleton_path, int n_envs, int device, uint64_t s
         {(void **) &env->d.flags, 1}, {(void **) &env->d.curr_step, 1}, {(void **) &env->d.remaining, 1},
         {(void **) &env->d.settle_left, 1}, {(void **) &env->d.E, 9}, {(void **) &env->d.iinv_stale, 6u * S.nb},
         {(void **) &env->d.mt, 624}, {(void **) &env->d.mt_idx, 1}, {(void **) &env->d.scratch, (size_t) S.sc_total},
-        {(void **) &env->d.diag, 2}, {(void **) &env->d.stat, 2}, {(void **) &env->d.stamps, 1},
+        {(void **) &env->d.diag, 2}, {(void **) &env->d.stat, 2}, {(void **) &env->d.stamps, 1}, {(void **) &env->d.resid, 1},
         {(void **) &env->d.gtile, evm::step_lds_bytes(S.nb, S.nscan) / 4 / 64}};  // stamps: 16 u64 per tile = 128 B <= 256 B
     size_t total = 0;
     for (auto &s : segs) total += s.count * n * 4;
@@ -513,6 +513,17 @@ int evm_env_set_state(EvmEnv *env, const float *h_state) {
                         (size_t) 3 * S.nm * 256, (size_t) 3 * S.nm * 256, n / 64, hipMemcpyHostToDevice));
     HIP_TRY(uli(env->d.mfn, m.mfn)); HIP_TRY(uli(env->d.flags, m.flags));
     HIP_TRY(uli(env->d.curr_step, m.curr)); HIP_TRY(uli(env->d.remaining, m.rem));
+    return EVM_OK;
+}
+
+int evm_env_get_residual(EvmEnv *env, float *h_max, int clear, void *stream) {
+    if (!env) return fail(EVM_E_INVALID, "env is null");
+    hipStream_t s = (hipStream_t) stream;
+    int bits = 0;
+    HIP_TRY(hipMemcpyAsync(&bits, env->d.resid, sizeof(int), hipMemcpyDeviceToHost, s));
+    if (clear) HIP_TRY(hipMemsetAsync(env->d.resid, 0, sizeof(int), s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (h_max) memcpy(h_max, &bits, sizeof(float));
     return EVM_OK;
 }
 

@@ -1632,6 +1632,16 @@ DEV void sweeps_run(const Ctx &c, bool any_pending, unsigned cmask, int ncontact
         }
     }
 #endif
+    {   // batch-level residual: this wave's rows, max over its lanes, one atomic per wave
+        int r = __float_as_int(res);
+        const unsigned long long live = __ballot(true);  // lanes outside the batch / the mask have left the kernel
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const int other = __shfl_xor(r, o);
+            if ((live >> ((c.lane & 63) ^ o)) & 1ull) r = max(r, other);
+        }
+        if ((c.lane & 63) == (int) __builtin_ctzll(live)) atomicMax(c.d.resid, r);
+    }
     __syncthreads();
     STAMP(5);
     if (W == 0) {

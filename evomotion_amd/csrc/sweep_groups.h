@@ -495,6 +495,13 @@ __global__ __launch_bounds__(64 * EVM_G_MAX_WAVES) void k_sweeps_g(EnvDev d, con
         SC(c_skel.sc_mobs + 4 * mi + 3) = GQ(G, rp + 4 + 3)[2];   // field 14 of p2p_b
     }
     if (wave == 0 && G.g == 0) {
+        {   // batch-level residual: max over the 16 envs in the wave, one atomic per workgroup
+            if (lane == (int) __builtin_ctzll(__ballot(true))) {  // (envs that left the kernel keep a zero in resmax)
+                int r = 0;
+                for (int k = 0; k < EVM_G_ENVS; k++) r = max(r, resmax[k]);
+                atomicMax(d.resid, r);
+            }
+        }
         GS(diag, 0) = __int_as_float(resmax[G.e]);
         GS(diag, 1) = (float) ncontact;
         if (fin) {

@@ -191,6 +191,13 @@ class VecRobotWalk:
         check(lib.evm_env_get_diagnostics(self._h, _ptr(out), self._stream()))
         return out
 
+    def residual(self, clear=True):
+        """largest |delta impulse| a constraint row applied in the last of the 10 Gauss-Seidel sweeps, maximum over the whole
+        batch and over the physics steps since the last clear (device-side reduction)"""
+        out = ctypes.c_float()
+        check(lib.evm_env_get_residual(self._h, ctypes.byref(out), 1 if clear else 0, self._stream()))
+        return out.value
+
     def stats(self):
         out = (ctypes.c_longlong * 2)()
         check(lib.evm_env_get_stats(self._h, out))

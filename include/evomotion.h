@@ -134,6 +134,10 @@ int evm_env_get_body_constants(const EvmEnv *env, float *h_out);
 /* Per-env diagnostics of the last physics step: [max |delta impulse| of the last PGS iteration, contacts] */
 int evm_env_get_diagnostics(const EvmEnv *env, float *d_out /* [n_envs, 2] */, void *stream);
 
+/* Convergence diagnostic of the 10-sweep projected Gauss-Seidel solve, reduced over the whole batch on the device (per env
+ * in the wave, one atomic max per workgroup): the largest |delta impulse| any constraint row applied in its LAST sweep, maximum
+ * over all envs and all physics steps since the last clear.  Synchronises `stream`. */
+int evm_env_get_residual(EvmEnv *env, float *h_max_delta_impulse, int clear, void *stream);
 /* Rollout counters since the last clear, summed over envs: h_out[0] = do_step transitions emitted by
  * evm_env_step_autoreset (the reset()'s own step and settle calls are not counted), h_out[1] = resets started. */
 int evm_env_get_stats(EvmEnv *env, long long *h_out /* [2] */);
