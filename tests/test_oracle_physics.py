@@ -186,3 +186,22 @@ def test_known_answer_slider_motor_saturates_at_64_newton(orc_lib, tmp_path):
     skel = pc.skel_two_masses(write_skeleton, tmp_path, mass=1000.0, force=64.0, name="motor_sat.skel")
     rel, pred = pc.check_motor_saturates_at_max_force(_world(skel, orc_lib))
     print("relative velocity %.5f m/s, predicted %.5f m/s" % (rel, pred))
+
+
+def test_self_collision_rate_diagnostic(orc_lib):
+    """tools/self_collision_rate.py (oracle side): the measurement behind DESIGN.md's statement of the plane-contact deviation —
+    how often non-adjacent member pairs come within Bullet's collision margins.  Here only that the diagnostic runs and is
+    consistent; the rates of a long run are quoted in DESIGN.md §2."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import self_collision_rate as sc
+    names, hulls, adjacent = sc.load_members()
+    assert len(names) == 17 and len(adjacent) == 16 and [len(h) for h in hulls].count(8) == 13   # 13 cubes, 4 feet
+    r = sc.run(n_envs=1, steps=40, lib=orc_lib)
+    assert r["env_steps"] == 40 and r["touching_pairs"] <= r["aabb_pairs"]
+    assert r["steps_with_touching_pair"] <= r["steps_with_aabb_pair"] <= 40
+    # two far-apart unit cubes are separated, two overlapping ones are not
+    cube = hulls[0] / np.abs(hulls[0]).max(0)
+    I = np.eye(3)
+    assert sc.separated(cube, cube + np.array([3.0, 0, 0]), I, I, 0.08) and not sc.separated(cube, cube + np.array([1.9, 0, 0]), I, I, 0.08)
