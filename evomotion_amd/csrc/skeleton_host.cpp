@@ -949,7 +949,7 @@ int build_group_schedule(const EvmSkelC &S, int nwaves, EvmGSchedC &G, std::stri
     }
     // measured on MI355X (tools/gstamps.py, one wave per SIMD, cycles per group entry incl. its LDS round trips):
     // hinge 1770, fixed 1700, slider 1900, p2p 1000, contact rows 2100; a dependency that crosses waves ~300;
-    // chain entries (below): ~600 + 1050 per hinge phase, ~450 + 420 per p2p phase
+    // chain entries (below): ~700 + 1060 per hinge phase, ~600 + 600 per p2p phase (rows + the cross-lane hand-over)
     const float cost_of[5] = {1770.f, 1700.f, 1900.f, 1000.f, 2100.f}, hop = 300.f;
     // ---- items: single visits, and CHAINS = 3..4 consecutive visits of one type (hinge / p2p) on one shared body a with
     // distinct second bodies (the spider's root: its four hinges, the four p2p constraints of its muscles).  A chain runs as
@@ -981,7 +981,7 @@ int build_group_schedule(const EvmSkelC &S, int nwaves, EvmGSchedC &G, std::stri
                         Item it;
                         it.type = t == 0 ? 5 : 6;
                         for (size_t q = p0; q < p1; q++) { it.vis.push_back(seq[q]); item_of[seq[q]] = (int) items.size(); }
-                        it.cost = t == 0 ? 600.f + 1050.f * (float) (p1 - p0) : 450.f + 420.f * (float) (p1 - p0);
+                        it.cost = t == 0 ? 700.f + 1060.f * (float) (p1 - p0) : 600.f + 600.f * (float) (p1 - p0);
                         items.push_back(it);
                         p0 = p1;
                     } else p0++;
@@ -1117,6 +1117,7 @@ int build_group_schedule(const EvmSkelC &S, int nwaves, EvmGSchedC &G, std::stri
     const int ne = (int) ents.size();
     if (ne > EVM_G_MAX_ENTRIES) { err = "group schedule overflow"; return EVM_E_UNSUPPORTED; }
     // ---- score: the ten back-to-back sweeps with fixed per-wave lists; improve by moving entries between waves ----
+    const float balance_w = getenv("EVM_G_BALANCE") ? (float) atof(getenv("EVM_G_BALANCE")) : 0.f;  // (A/B knob)
     auto simulate = [&](const std::vector<int> &asg) -> float {
         std::vector<float> wave_t(nwaves, 0.f), ready(S.nb, 0.f);
         std::vector<int> lastw(S.nb, -1);
@@ -1135,7 +1136,13 @@ int build_group_schedule(const EvmSkelC &S, int nwaves, EvmGSchedC &G, std::stri
             }
         float m = 0.f;
         for (float t : wave_t) m = std::max(m, t);
-        return m;
+        // tie-break towards balanced waves: the cost model is approximate, and the busiest wave is the one that cannot absorb
+        // an entry that runs longer than modelled
+        std::vector<float> busy(nwaves, 0.f);
+        for (int e = 0; e < ne; e++) busy[asg[e]] += ents[e].cost;
+        float bmax = 0.f, bsum = 0.f;
+        for (float b : busy) { bmax = std::max(bmax, b); bsum += b; }
+        return m + balance_w * (bmax - bsum / (float) nwaves);
     };
     std::vector<int> asg(ne);
     for (int e = 0; e < ne; e++) asg[e] = ents[e].wave;

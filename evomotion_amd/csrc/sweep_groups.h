@@ -25,11 +25,23 @@ struct GCtx {
     int QR;      // first quad of the joint-record image
     int *ver;    // per-body version counters
     bool multi;  // more than one wave per workgroup: versions are live
+#ifdef EVM_GSTAMPS2
+    unsigned long long wait_cycles;
+#endif
 };
 #define GQ(G, qi) ((G).q[((qi) << 4) + (G).e])
 
+#ifdef EVM_GSTAMPS2
+__device__ unsigned long long g_wait_cycles_dummy;
+#define GWAIT_T0 const unsigned long long gw_t0 = __builtin_amdgcn_s_memtime();
+#define GWAIT_T1 G.wait_cycles += __builtin_amdgcn_s_memtime() - gw_t0;
+#else
+#define GWAIT_T0
+#define GWAIT_T1
+#endif
 DEV void g_wait2(GCtx &G, const Ctx &c, int a, int expA, int b, int expB) {
     if (!G.multi) return;
+    GWAIT_T0
     int spins = 0;
     for (;;) {
         const int va = __hip_atomic_load(&G.ver[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -40,6 +52,7 @@ DEV void g_wait2(GCtx &G, const Ctx &c, int a, int expA, int b, int expB) {
         if (spins > (1 << 16)) { c.t.diag[c.lane] = -1.f; G.multi = false; break; }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    GWAIT_T1
 }
 DEV void g_publish(const GCtx &G, int a, int va, int b, int vb) {
     if (G.ver == nullptr) return;
@@ -251,6 +264,9 @@ __global__ __launch_bounds__(64 * EVM_G_MAX_WAVES) void k_sweeps_g(EnvDev d, con
     G.e = lane & (EVM_G_ENVS - 1);
     G.g = lane >> 4;
     G.multi = nw > 1;  // (cleared by a wait that times out)
+#ifdef EVM_GSTAMPS2
+    G.wait_cycles = 0;
+#endif
     const int nb = c_skel.nb, nm = c_skel.nm;
     const int nrq = gs->nrq, total = gs->total;
     G.QR = 3 * nb;
@@ -267,8 +283,10 @@ __global__ __launch_bounds__(64 * EVM_G_MAX_WAVES) void k_sweeps_g(EnvDev d, con
         for (int i = threadIdx.x; i < total; i += blockDim.x) hdr[i] = hs[i];
         for (int i = threadIdx.x; i < ((nb + 3) & ~3) + EVM_G_ENVS; i += blockDim.x) ver_base[i] = 0;
     }
-#ifdef EVM_GSTAMPS  // diagnostic build (tools/gstamps.py): cycles per phase and per entry type, wave 0 of quarter 0
+#if defined(EVM_GSTAMPS) || defined(EVM_GSTAMPS2)  // diagnostic builds (tools/gstamps.py)
     const unsigned long long gs_t0 = __builtin_amdgcn_s_memtime();
+#endif
+#ifdef EVM_GSTAMPS  // cycles per phase and per entry type, wave 0 of quarter 0
     unsigned long long gs_type[5] = {0, 0, 0, 0, 0};
     unsigned gs_n[5] = {0, 0, 0, 0, 0};
 #endif
@@ -358,7 +376,7 @@ __global__ __launch_bounds__(64 * EVM_G_MAX_WAVES) void k_sweeps_g(EnvDev d, con
     }
     __syncthreads();
 
-#ifdef EVM_GSTAMPS
+#if defined(EVM_GSTAMPS) || defined(EVM_GSTAMPS2)
     const unsigned long long gs_t1 = __builtin_amdgcn_s_memtime();
 #endif
     // ---- the sweeps: this wave's group entries, NUM_ITER times over ----
@@ -463,7 +481,7 @@ __global__ __launch_bounds__(64 * EVM_G_MAX_WAVES) void k_sweeps_g(EnvDev d, con
         if (it == NUM_ITER - 1) res = rs;
     }
     atomicMax(&resmax[G.e], __float_as_int(res));
-#ifdef EVM_GSTAMPS
+#if defined(EVM_GSTAMPS) || defined(EVM_GSTAMPS2)
     const unsigned long long gs_t2 = __builtin_amdgcn_s_memtime();
 #endif
     __syncthreads();
@@ -527,7 +545,12 @@ __global__ __launch_bounds__(64 * EVM_G_MAX_WAVES) void k_sweeps_g(EnvDev d, con
         const F3 o2 = integ_pos(o, lin, DT_F);
         SSC3(c_skel.sc_rootms, integ_pos(o2, lin, 0.f - DT_F));
     }
-#ifdef EVM_GSTAMPS
+#ifdef EVM_GSTAMPS2  // per wave: cycles in the sweeps phase, cycles of it spent waiting for versions, entries run (tools/gstamps.py --waves)
+    if (sub == 0 && lane == (int) __builtin_ctzll(__ballot(true)) && wave < 4) {
+        unsigned long long *st = d.stamps + (size_t) tile64 * 16;
+        st[4 * wave] = gs_t2 - gs_t1; st[4 * wave + 1] = G.wait_cycles; st[4 * wave + 2] = (unsigned long long) count * NUM_ITER; st[4 * wave + 3] = gs_t1 - gs_t0;
+    }
+#elif defined(EVM_GSTAMPS)
     if (wave == 0 && sub == 0 && lane == 0) {
         unsigned long long *st = d.stamps + (size_t) tile64 * 16;
 #pragma unroll

@@ -22,6 +22,10 @@ for k in range(K + 200):
         check(lib.evm_env_get_stamps(env._h, st))
         acc += np.array(st, dtype=np.uint64).reshape(-1, 16).astype(np.float64).mean(axis=0)
 acc /= K
+if "--waves" in sys.argv:  # -DEVM_GSTAMPS2 build: per wave
+    for w in range(4):
+        print("wave %d: sweeps phase %.0f cycles, waiting for versions %.0f (%.0f %%), %d entries, prologue %.0f" % (w, acc[4 * w], acc[4 * w + 1], 100 * acc[4 * w + 1] / max(acc[4 * w], 1), acc[4 * w + 2], acc[4 * w + 3]))
+    sys.exit(0)
 for q, name in enumerate(["hinge", "fixed", "slider", "p2p", "contact"]):
     print("%-8s %7.0f cycles/entry  %6.1f entries per step (wave 0)  %8.0f cycles per step" % (name, acc[2 * q] / max(acc[2 * q + 1], 1), acc[2 * q + 1], acc[2 * q]))
 print("prologue %.0f (table %.0f, records %.0f, bodies %.0f, manifold counts + barrier %.0f)  sweeps %.0f  epilogue %.0f cycles (wave 0)"
