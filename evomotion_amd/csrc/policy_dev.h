@@ -15,6 +15,7 @@ struct NetDev {
     const float *b2, *g2, *be2;
     const float *wh;   // heads, row major [out][256]: actor = mu rows then sigma rows (2A), critic = 1 row
     const float *bh;
+    const float *whp;  // the same head weights as an MFMA B operand, 32 columns (rows of wh, zero beyond): [32][32][2][4]
 };
 struct PolicyDev {
     int S, A, K1pad;

@@ -30,7 +30,7 @@ int evm_policy_create(int state_dim, int action_dim, int hidden_size, int device
     p->S = state_dim; p->A = action_dim; p->H = hidden_size; p->device = device; p->counter = 0; p->timing = false; p->ev_used = 0;
     p->K1pad = 384;  // K1 of policy_kernels.hip
     const size_t per_net = (size_t) p->K1pad * 256 + 3 * 256 + 256 * 256 + 3 * 256;
-    p->arena_floats = 2 * per_net + ((size_t) 2 * action_dim * 256 + 2 * action_dim) + (256 + 1);
+    p->arena_floats = 2 * per_net + ((size_t) 2 * action_dim * 256 + 2 * action_dim) + (256 + 1) + 2 * 8192 + 4;
     if (hipMalloc((void **) &p->arena, p->arena_floats * 4) != hipSuccess) { delete p; return pfail(EVM_E_HIP, "hipMalloc failed"); }
     hipMemset(p->arena, 0, p->arena_floats * 4);
     float *b = p->arena;
@@ -41,8 +41,12 @@ int evm_policy_create(int state_dim, int action_dim, int hidden_size, int device
         n.b2 = b; b += 256; n.g2 = b; b += 256; n.be2 = b; b += 256;
         n.wh = b; b += head_w; n.bh = b; b += head_b;
     };
+    auto carve_packed = [&](evm::NetDev &n) { n.whp = b; b += 8192; };  // 16-byte aligned: behind everything else
     carve(p->dev.actor, (size_t) 2 * action_dim * 256, 2 * action_dim);
     carve(p->dev.critic, 256, 1);
+    b = p->arena + ((b - p->arena + 3) / 4) * 4;
+    carve_packed(p->dev.actor);
+    carve_packed(p->dev.critic);
     p->dev.S = state_dim; p->dev.A = action_dim; p->dev.K1pad = p->K1pad;
     *out = p;
     return EVM_OK;
@@ -106,7 +110,13 @@ int evm_policy_set_weights(EvmPolicy *p, const float *h_actor, size_t n_actor, c
             memcpy(wh, src, 256 * 4); src += 256;
             bh[0] = src[0];
         }
-        (void) heads;
+        // heads once more as the MFMA B operand of the head GEMM: 32 columns = head rows (zero beyond), k-split like w2t
+        float *whp = host.data() + (n.whp - p->arena);
+        for (int o = 0; o < heads; o++)
+            for (int k = 0; k < 256; k++) {
+                const int st = k >> 1, h = k & 1, s4 = st >> 2, t = st & 3;
+                whp[(((size_t) s4 * 32 + o) * 2 + h) * 4 + t] = wh[(size_t) o * 256 + k];
+            }
     };
     pack(p->dev.actor, h_actor, 2 * p->A, true);
     pack(p->dev.critic, h_critic, 1, false);

@@ -98,15 +98,27 @@ __global__ __launch_bounds__(PT) void k_policy_forward(PolicyDev p, int n, const
     const int row0 = blockIdx.x * TM;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const NetDev &N = net == 0 ? p.actor : p.critic;
+#ifdef EVM_PSTAMPS  // diagnostic build (tools/pstamps.py): phase clock stamps of wave 0, written over the mu output
+    unsigned long long ps_t[8];
+#define PSTAMP(i) ps_t[i] = __builtin_amdgcn_s_memtime();
+#else
+#define PSTAMP(i)
+#endif
+    PSTAMP(0)
     stage_rows_ksplit<TM>(xs, obs, row0, n, p.S);
     __syncthreads();
+    PSTAMP(1)
     f32x16 acc[RT][2];
     dense_layer<K1, RT>(xs, ALD1, N.w1t, wave, lane, acc);
     __syncthreads();  // every wave has finished reading the observation tile
+    PSTAMP(2)
     epilogue_mish_ln(acc, N.b1, N.g1, N.be1, hb, wave, lane);
+    PSTAMP(3)
     dense_layer<256, RT>(hb, ALD2, N.w2t, wave, lane, acc);
     __syncthreads();  // every wave has finished reading the layer-1 activations
+    PSTAMP(4)
     epilogue_mish_ln(acc, N.b2, N.g2, N.be2, hb, wave, lane);
+    PSTAMP(5)
 
     // heads: Linear(256, 1) for the critic, Linear(256, A) x 2 (mu, sigma) for the actor.  The head weights are
     // staged into the (dead) observation tile in the activations' k-split order; thread (row, part) takes its RUN
@@ -115,36 +127,47 @@ __global__ __launch_bounds__(PT) void k_policy_forward(PolicyDev p, int n, const
     const int gr = row0 + row;
     const int A = p.A;
     const int nout = net == 1 ? 1 : 2 * A;
-    float *wl = sm + TM * ALD2;  // [nout][256] k-split
-    float *hs = wl + 32 * 256;   // [TM][32] pre-activations
-    for (int e = threadIdx.x; e < nout * 256; e += PT) {
-        const int c = e & 255;
-        wl[(e & ~255) + (c & 1) * 128 + (c >> 1)] = N.wh[e];
+    // The head GEMM [TM x 256] x [256 x 32] on the matrix pipe too (as a row-wise dot product loop it was a quarter of the
+    // kernel): K is split over the four waves, the four partial 32 x 32 tiles meet in LDS.
+    static_assert(TM == 32, "the head GEMM is one 32-row MFMA tile");
+    float *hs4 = sm + TM * ALD2;     // [4 waves][32 rows][32 cols] partial sums
+    float *hs = hs4 + 4 * 32 * 32;   // [TM][32] pre-activations
+    {
+        f32x16 hacc;
+#pragma unroll
+        for (int r = 0; r < 16; r++) hacc[r] = 0.f;
+        const int aj = lane & 31, ah = lane >> 5;
+        const float *ap = hb + aj * ALD2 + ah * 128 + wave * 32;                      // this wave's k range: 64 wave .. 64 wave + 63
+        const float *bp = N.whp + ((size_t) (8 * wave) * 32 + aj) * 8 + ah * 4;
+        f32x4 a4[8], b4[8];
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            a4[b] = *reinterpret_cast<const f32x4 *>(ap + 4 * b);
+            b4[b] = *reinterpret_cast<const f32x4 *>(bp + (size_t) b * 256);
+        }
+#pragma unroll
+        for (int b = 0; b < 8; b++)
+#pragma unroll
+            for (int tt = 0; tt < 4; tt++) hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[b][tt], b4[b][tt], hacc, 0, 0, 0);
+        // C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+        for (int r = 0; r < 16; r++) hs4[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = hacc[r];
     }
     __syncthreads();
-    {
-        const f32x4 *hr = reinterpret_cast<const f32x4 *>(hb + row * ALD2);
-        f32x4 x[RUN / 4];
-#pragma unroll
-        for (int i = 0; i < RUN / 4; i++) x[i] = hr[CHUNK(i, part, PARTS)];
-        for (int o = 0; o < nout; o++) {
-            const f32x4 *wr = reinterpret_cast<const f32x4 *>(wl + o * 256);
-            float sum = 0.f;
-#pragma unroll
-            for (int i = 0; i < RUN / 4; i++) {
-                const f32x4 w = wr[CHUNK(i, part, PARTS)];
-                sum += (x[i][0] * w[0] + x[i][1] * w[1]) + (x[i][2] * w[2] + x[i][3] * w[3]);
-            }
-#pragma unroll
-            for (int m = 1; m < PARTS; m <<= 1) sum += __shfl_xor(sum, m);
-            if (part == 0) hs[row * 32 + o] = sum + N.bh[o];
-        }
+    for (int o = part; o < nout; o += PARTS)
+        hs[row * 32 + o] = ((hs4[row * 32 + o] + hs4[(32 + row) * 32 + o]) + (hs4[(64 + row) * 32 + o] + hs4[(96 + row) * 32 + o])) + N.bh[o];
+    __syncthreads();
+    PSTAMP(6)
+#ifdef EVM_PSTAMPS
+    if (net == 0 && mu_out && threadIdx.x == 0 && blockIdx.x < 128) {
+        unsigned long long *o = reinterpret_cast<unsigned long long *>(mu_out) + (size_t) blockIdx.x * 8;
+        for (int i = 0; i < 7; i++) o[i] = ps_t[i];
     }
+#endif
     if (net == 1) {
         if (part == 0 && gr < n) value[gr] = hs[row * 32];
         return;
     }
-    __syncthreads();
     for (int a = part; a < A; a += PARTS) {
         if (gr >= n) continue;
         const float mu = tanhf(hs[row * 32 + a]);
@@ -165,7 +188,9 @@ __global__ __launch_bounds__(PT) void k_policy_forward(PolicyDev p, int n, const
         const size_t o = (size_t) gr * A + a;
         action[o] = act;
         logp[o] = lp;
+#ifndef EVM_PSTAMPS
         if (mu_out) mu_out[o] = mu;
+#endif
         if (sigma_out) sigma_out[o] = sigma;
     }
 }
@@ -204,17 +229,24 @@ __global__ __launch_bounds__(256) void k_policy_pack(NetDev n, int S, int A, int
     o += 256;
     if (i < o + 256) { wr(n.be2)[i - o] = flat[i]; return; }
     o += 256;
+    // head weights: row major (wh) and as the B operand of the head GEMM (whp: [32 s4][32 cols][2][4], column = head row)
+    auto head = [&](size_t e, float v) {  // e = row * 256 + k
+        wr(n.wh)[e] = v;
+        const int row = (int) (e >> 8), k = (int) (e & 255);
+        const int st = k >> 1, h = k & 1, s4 = st >> 2, t = st & 3;
+        wr(n.whp)[(((size_t) s4 * 32 + row) * 2 + h) * 4 + t] = v;
+    };
     if (actor) {
         const size_t hw = (size_t) A * 256;
-        if (i < o + hw) { wr(n.wh)[i - o] = flat[i]; return; }             // mu.0.weight
+        if (i < o + hw) { head(i - o, flat[i]); return; }                  // mu.0.weight
         o += hw;
         if (i < o + A) { wr(n.bh)[i - o] = flat[i]; return; }              // mu.0.bias
         o += A;
-        if (i < o + hw) { wr(n.wh)[hw + (i - o)] = flat[i]; return; }      // sigma.0.weight
+        if (i < o + hw) { head(hw + (i - o), flat[i]); return; }           // sigma.0.weight
         o += hw;
         if (i < o + A) { wr(n.bh)[A + (i - o)] = flat[i]; return; }        // sigma.0.bias
     } else {
-        if (i < o + 256) { wr(n.wh)[i - o] = flat[i]; return; }
+        if (i < o + 256) { head(i - o, flat[i]); return; }
         o += 256;
         if (i < o + 1) { wr(n.bh)[0] = flat[i]; return; }
     }
@@ -226,7 +258,7 @@ hipError_t launch_policy_pack(const NetDev &n, int S, int A, bool actor, const f
 }
 
 size_t policy_lds_bytes() {
-    const size_t a = (size_t) TM * ALD1, b = (size_t) TM * ALD2 + 32 * 256 + TM * 32;
+    const size_t a = (size_t) TM * ALD1, b = (size_t) TM * ALD2 + 4 * 32 * 32 + TM * 32;
     return (a > b ? a : b) * sizeof(float);
 }
 
