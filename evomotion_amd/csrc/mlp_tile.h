@@ -107,16 +107,24 @@ __device__ __forceinline__ void stage_rows_ksplit(float *xs, const float *__rest
                 const int q = it * PT + (int) threadIdx.x;
                 v[it] = src[min(q, nq - 1)];
             }
+            // (row, column) of a flat element without a division per element: one division for the thread's first element,
+            // then a constant (row, column) stride per trip, with carry
+            const int e0 = 4 * (int) threadIdx.x;
+            int r = e0 / S, k = e0 - r * S;
+            const int dr = (4 * PT) / S, dk = 4 * PT - dr * S;
 #pragma unroll
             for (int it = 0; it < NIT; it++) {
                 const int q = it * PT + (int) threadIdx.x;
                 if (q < nq) {
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
-                        const int e = 4 * q + u, r = e / S, k = e - r * S;
-                        xs[r * ALD1 + (k & 1) * (K1 / 2) + (k >> 1)] = v[it][u];
+                        const bool wrap = k + u >= S;
+                        const int rr = r + (wrap ? 1 : 0), kk = k + u - (wrap ? S : 0);
+                        xs[rr * ALD1 + (kk & 1) * (K1 / 2) + (kk >> 1)] = v[it][u];
                     }
                 }
+                r += dr; k += dk;
+                if (k >= S) { k -= S; r++; }
             }
             for (int e = threadIdx.x; e < TM_ * (K1 - S); e += PT) {
                 const int r = e / (K1 - S), k = S + e % (K1 - S);

@@ -301,17 +301,17 @@ __global__ __launch_bounds__(64 * EVM_G_MAX_WAVES) void k_sweeps_g(EnvDev d, con
     const int flags_in = d.flags[c.env];
     const bool fin = autoreset && (flags_in & EVM_FLAG_DONE) != 0;  // a reset starts with this step (see LaneState)
     const bool any_pending = __any((flags_in & EVM_FLAG_PENDING) != 0 || fin);
-    // ---- joint-record image: global scratch [quad][64 lanes] -> LDS [quad][16 lanes], twelve quads in flight per lane ----
+    // ---- joint-record image: global scratch [quad][64 lanes] -> LDS [quad][16 lanes], by LDS-DMA (global_load_lds_dwordx4:
+    // no register round trip, so every request of the wave is in flight at once).  One instruction moves four consecutive
+    // quads: lane (g, e) fetches quad ib + g of its env, and the hardware writes lane l's 16 bytes at base + 16 l — which is
+    // exactly quad ib + g, env e of the image.  (The copy is a 25 MB burst over the whole chip: bandwidth, not latency.)
     {
         const f32x4 *grec = reinterpret_cast<const f32x4 *>(c.t.scratch + ((size_t) c_skel.sc_h << 6)) + c.lane;
-        const int step = EVM_G_SLOTS * nw;
-        int i = wave * EVM_G_SLOTS + G.g;
-        for (; i < nrq; i += 12 * step) {
-            f32x4 v[12];
-#pragma unroll
-            for (int u = 0; u < 12; u++) if (i + u * step < nrq) v[u] = grec[(size_t) (i + u * step) << 6];
-#pragma unroll
-            for (int u = 0; u < 12; u++) if (i + u * step < nrq) GQ(G, G.QR + i + u * step) = v[u];
+        for (int ib = wave * EVM_G_SLOTS; ib < nrq; ib += EVM_G_SLOTS * nw) {
+            const int i = ib + G.g;
+            if (i < nrq)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (grec + ((size_t) i << 6)),
+                                                 (__attribute__((address_space(3))) void *) (G.q + ((size_t) (G.QR + ib) << 4)), 16, 0, 0);
         }
     }
 #ifdef EVM_GSTAMPS
@@ -374,6 +374,7 @@ __global__ __launch_bounds__(64 * EVM_G_MAX_WAVES) void k_sweeps_g(EnvDev d, con
             if (__any(nn[m] > 0)) cmask |= 1u << m;
         }
     }
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the LDS-DMA requests of the record image have landed
     __syncthreads();
 
 #if defined(EVM_GSTAMPS) || defined(EVM_GSTAMPS2)
