@@ -52,8 +52,13 @@ struct EvmEnv {
 
 static const EvmEnv *g_skel_owner = nullptr;
 
+// The skeleton constants live in one __constant__ block per device.  An env that steps after ANOTHER env of this process
+// (alternating robot_walk / robot_jump, or two batches) re-uploads its block; the previous owner's kernels may still be in
+// flight on another stream, so the device is drained first (rare: one process per GPU owns one env in every benchmark and
+// in the rollout loops; one host thread per GPU is the ABI's threading rule).
 static int ensure_skeleton(EvmEnv *env, hipStream_t s) {
     if (g_skel_owner != env) {
+        if (g_skel_owner != nullptr) HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(evm::upload_skeleton(&env->skel, s));
         g_skel_owner = env;
     }

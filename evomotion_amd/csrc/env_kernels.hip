@@ -2165,15 +2165,22 @@ size_t step_lds_bytes(int nb, int nscan) {  // tiles + version counters + hull-s
     return (size_t) nb * 12 * 64 * sizeof(float) + (size_t) ((nb + 63) / 64) * 256 + (size_t) nscan * 2 * 64 * sizeof(float);
 }
 
+#define EVM_MAX_DEVICES 64
+static int current_device() {
+    int dev = 0;
+    (void) hipGetDevice(&dev);
+    return dev >= 0 && dev < EVM_MAX_DEVICES ? dev : 0;
+}
 template <int MODE>
 static hipError_t launch_mode(const EnvDev &d, size_t lds, const float *action, float *obs, float *reward, uint8_t *done,
                               uint8_t *valid, const uint8_t *mask, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[EVM_MAX_DEVICES] = {};  // the attribute is per device
+    const int dev = current_device();
+    if (!attr_set[dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_env_step<MODE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int) (160 * 1024));
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set[dev] = true;
     }
     hipLaunchKernelGGL((k_env_step<MODE>), dim3(d.n / 64), dim3(64 * EVM_NW), lds, s, d, action, obs, reward, done, valid, mask);
     return hipGetLastError();
@@ -2181,12 +2188,13 @@ static hipError_t launch_mode(const EnvDev &d, size_t lds, const float *action, 
 template <int MODE>
 static hipError_t launch_split(const EnvDev &d, size_t lds, const float *action, float *obs, float *reward, uint8_t *done,
                                uint8_t *valid, const uint8_t *mask, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[EVM_MAX_DEVICES] = {};
+    const int dev = current_device();
+    if (!attr_set[dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_split_sweeps),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int) (160 * 1024));
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set[dev] = true;
     }
     const int tiles = d.n / 64;
     // enough (tile, part) workgroups to cover the chip a few times over at small batches, one part at large ones
@@ -2200,12 +2208,12 @@ static hipError_t launch_split(const EnvDev &d, size_t lds, const float *action,
     hipLaunchKernelGGL((k_split_pre_b<MODE>), gp, bp, 0, s, d, action, mask);
     if (e0) (void) hipEventRecord(e0, s);
     if (d.gs) {
-        static bool attr_g = false;
-        if (!attr_g) {
+        static bool attr_g[EVM_MAX_DEVICES] = {};
+        if (!attr_g[dev]) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweeps_g),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int) (160 * 1024));
             if (e != hipSuccess) return e;
-            attr_g = true;
+            attr_g[dev] = true;
         }
         hipLaunchKernelGGL(k_sweeps_g, dim3(tiles * (64 / EVM_G_ENVS)), dim3(64 * d.g_waves), (size_t) d.g_lds, s, d, mask, (MODE & 4) ? 1 : 0);
     } else {

@@ -48,7 +48,9 @@ extern "C" {
 int evm_replay_create(int capacity_slots, int n_envs, int state_dim, int action_dim, int device, EvmReplay **out) {
     if (!out) return rfail(EVM_E_INVALID, "out is null");
     *out = nullptr;
-    if (capacity_slots < 1 || capacity_slots > 16384) return rfail(EVM_E_INVALID, "capacity_slots must be in [1, 16384]");
+    // k_replay_plan keeps (live slots + 1) prefix sums in dynamic LDS, + 36 bytes of static: stay inside the 64 KB a kernel gets
+    // without hipFuncAttributeMaxDynamicSharedMemorySize
+    if (capacity_slots < 1 || capacity_slots > 16000) return rfail(EVM_E_INVALID, "capacity_slots must be in [1, 16000]");
     if (n_envs < 1 || state_dim < 1 || action_dim < 1) return rfail(EVM_E_INVALID, "sizes must be positive");
     if (hipSetDevice(device) != hipSuccess) return rfail(EVM_E_HIP, "hipSetDevice failed");
     EvmReplay *rb = new EvmReplay();
