@@ -311,33 +311,44 @@ class VecPpoGaeAgent:
     def count_parameters(self):
         return count_parameters(self.actor, self.critic)
 
+    def _adam_states(self, module, opt):
+        out = []
+        for p in module.parameters():
+            st = opt.state.get(p)
+            out.append(None if not st or "exp_avg" not in st else (int(float(st["step"])), st["exp_avg"], st["exp_avg_sq"]))
+        return out
+
     def save(self, output_folder_path):
-        """PpoGaeAgent::save (ppo_gae.cpp:192-197): actor.th / critic.th in the reference's format; the optimiser
-        states go to `*_optimizer.pt` (torch.save) — the reference's optimiser archives are keyed by parameter
-        addresses of the saving process (checkpoint.py)."""
-        from .checkpoint import save_th
+        """PpoGaeAgent::save (ppo_gae.cpp:192-197): actor.th, actor_optimizer.th, critic.th, critic_optimizer.th in the
+        reference's formats (checkpoint.py) — the folder loads in the reference's PpoGaeAgent::load and the other way round."""
+        from .checkpoint import save_adam_th, save_th
         import os
         self.sync_modules()
         save_th(self.actor, os.path.join(output_folder_path, "actor.th"))
         save_th(self.critic, os.path.join(output_folder_path, "critic.th"))
-        torch.save(self.actor_opt.state_dict(), os.path.join(output_folder_path, "actor_optimizer.pt"))
-        torch.save(self.critic_opt.state_dict(), os.path.join(output_folder_path, "critic_optimizer.pt"))
+        save_adam_th(os.path.join(output_folder_path, "actor_optimizer.th"), self._adam_states(self.actor, self.actor_opt), self.learning_rate)
+        save_adam_th(os.path.join(output_folder_path, "critic_optimizer.th"), self._adam_states(self.critic, self.critic_opt), self.learning_rate)
 
     def load(self, input_folder_path):
-        """PpoGaeAgent::load (ppo_gae.cpp:199-204); optimiser states are restored when our `.pt` files are present."""
-        from .checkpoint import load_into
+        """PpoGaeAgent::load (ppo_gae.cpp:199-204): the four archives; like the reference's load_torch a missing file is an
+        error ("Could not find")."""
+        from .checkpoint import load_adam_th, load_into
         import os
         load_into(self.actor, os.path.join(input_folder_path, "actor.th"))
         load_into(self.critic, os.path.join(input_folder_path, "critic.th"))
-        import warnings
-        for opt, name in ((self.actor_opt, "actor_optimizer.pt"), (self.critic_opt, "critic_optimizer.pt")):
-            f = os.path.join(input_folder_path, name)
-            if os.path.isfile(f):
-                opt.load_state_dict(torch.load(f, map_location=self.device))
-            elif os.path.isfile(f[:-3] + ".th"):
-                # written by the reference (ppo_gae.cpp:194,196): keyed by parameter addresses of the saving process
-                warnings.warn("%s: the reference's optimiser archive is not loaded; Adam moments and step count restart from zero"
-                              % (f[:-3] + ".th"))
+        for mod, opt, name in ((self.actor, self.actor_opt, "actor_optimizer.th"), (self.critic, self.critic_opt, "critic_optimizer.th")):
+            states, options = load_adam_th(os.path.join(input_folder_path, name))
+            ps = list(mod.parameters())
+            if len(states) != len(ps):
+                raise RuntimeError("%s holds %d parameters, the module has %d" % (name, len(states), len(ps)))
+            opt.state.clear()
+            for p, st in zip(ps, states):
+                if st is not None:
+                    opt.state[p] = dict(step=torch.tensor(float(st[0])), exp_avg=st[1].to(self.device).reshape(p.shape).clone(),
+                                        exp_avg_sq=st[2].to(self.device).reshape(p.shape).clone())
+            self.learning_rate = options["lr"]   # AdamOptions travel with the archive (torch::optim::Adam::load)
+            for g in opt.param_groups:
+                g["lr"] = options["lr"]
         self.fused.load_modules(self.actor, self.critic)
         if self._trainer is not None:
             self._push_to_trainer()

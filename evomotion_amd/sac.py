@@ -274,19 +274,13 @@ class VecSacAgent:
                 self._graph.replay()
             self.train_steps += 1
 
-    _OPT_FILES = ("actor_optimizer.th", "critic_1_optimizer.th", "critic_2_optimizer.th", "entropy_optimizer.th")
-
     def _snapshot(self):
-        snap = dict(opt=self.optimizer_state(), train_steps=self.train_steps)
         from .ppo import ACTOR, PARAMS as PP
         from .qnet import PARAMS
-        snap["actor"] = self._actor_tr.vector(PP, ACTOR).clone()
-        snap["q"] = [self.twinq.vector(PARAMS, i).clone() for i in range(4)]
-        snap["log_alpha"] = self.entropy.log_alpha.detach().clone()
-        return snap
+        return dict(opt=self.optimizer_state(), train_steps=self.train_steps, actor=self._actor_tr.vector(PP, ACTOR).clone(),
+                    q=[self.twinq.vector(PARAMS, i).clone() for i in range(4)], log_alpha=self.entropy.log_alpha.detach().clone())
 
     def _restore(self, snap):
-        from .ppo import ACTOR, PARAMS as PP
         from .qnet import PARAMS
         self._actor_tr.set_flat(snap["actor"], self._critic_dummy, reset_optimizer=False)
         for i in range(4):
@@ -297,17 +291,23 @@ class VecSacAgent:
         self.train_steps = snap["train_steps"]
 
     def save(self, folder):
-        """SoftActorCriticAgent::save (soft_actor_critic.cpp:181-201): module archives in the reference's format.  The four
-        Adam states (actor, two critics, entropy parameter) go to `sac_optimizers.pt` (torch.save): the reference's
-        `*_optimizer.th` archives are keyed by parameter addresses of the saving process (torch::optim::serialize), see
-        checkpoint.py — a folder written here runs in the reference's `infer`, which loads modules only."""
+        """SoftActorCriticAgent::save (soft_actor_critic.cpp:181-201): the six module archives and the four
+        torch::optim::Adam archives (`actor_optimizer.th`, `critic_1_optimizer.th`, `critic_2_optimizer.th`,
+        `entropy_optimizer.th`) in the reference's formats (checkpoint.py): the folder loads in the reference's
+        SoftActorCriticAgent::load and the other way round."""
         import os
-        from .checkpoint import save_th
+        from .checkpoint import adam_states_from_flat, save_adam_th, save_th
         self.sync_modules()
         for m, f in ((self.actor, "actor.th"), (self.critic_1, "critic_1.th"), (self.target_critic_1, "target_critic_1.th"),
                      (self.critic_2, "critic_2.th"), (self.target_critic_2, "target_critic_2.th"), (self.entropy, "entropy.th")):
             save_th(m, os.path.join(folder, f))
-        torch.save(self.optimizer_state(), os.path.join(folder, "sac_optimizers.pt"))
+        st = self.optimizer_state()
+        for mod, key, f in ((self.actor, "actor", "actor_optimizer.th"), (self.critic_1, "critic_1", "critic_1_optimizer.th"),
+                            (self.critic_2, "critic_2", "critic_2_optimizer.th")):
+            save_adam_th(os.path.join(folder, f), adam_states_from_flat(mod, st[key]["step"], st[key]["m"], st[key]["v"]), self.learning_rate)
+        e = st["entropy"]
+        save_adam_th(os.path.join(folder, "entropy_optimizer.th"),
+                     [None if e["step"] == 0 else (e["step"], e["state"][0:1].clone(), e["state"][1:2].clone())], self.learning_rate)
 
     def optimizer_state(self):
         """Adam moments and step counts of the four optimisers, wherever they live (HIP trainers or torch.optim)"""
@@ -336,25 +336,26 @@ class VecSacAgent:
         self.train_steps = int(st.get("train_steps", self.train_steps))
 
     def load(self, folder):
-        """SoftActorCriticAgent::load (soft_actor_critic.cpp:203-223).  Optimiser state: restored from this package's
-        `sac_optimizers.pt` when present; a folder written by the REFERENCE carries `*_optimizer.th` archives that cannot be
-        consumed here (address-keyed) — that is said out loud, and the optimisers restart from zero moments."""
+        """SoftActorCriticAgent::load (soft_actor_critic.cpp:203-223): modules and the four Adam archives — written by this
+        package or by the reference; a missing file is an error like the reference's load_torch ("Could not find")."""
         import os
-        import warnings
-        from .checkpoint import load_into
+        from .checkpoint import adam_flat_from_states, load_adam_th, load_into
         for m, f in ((self.actor, "actor.th"), (self.critic_1, "critic_1.th"), (self.target_critic_1, "target_critic_1.th"),
                      (self.critic_2, "critic_2.th"), (self.target_critic_2, "target_critic_2.th"), (self.entropy, "entropy.th")):
             load_into(m, os.path.join(folder, f))
         self.fused.set_actor(self.actor)
         self._push_critics()
         self._push_actor()
-        self._ent_state.zero_()
-        self._ent_step.zero_()
-        own = os.path.join(folder, "sac_optimizers.pt")
-        if os.path.isfile(own):
-            self.load_optimizer_state(torch.load(own, map_location="cpu", weights_only=False))
-        else:
-            theirs = [f for f in self._OPT_FILES if os.path.isfile(os.path.join(folder, f))]
-            if theirs:
-                warnings.warn("%s: the reference's optimiser archives %s are keyed by parameter addresses and are not loaded; "
-                              "Adam moments and step counts restart from zero" % (folder, theirs))
+        st = dict(kind="hip")
+        for mod, key, f in ((self.actor, "actor", "actor_optimizer.th"), (self.critic_1, "critic_1", "critic_1_optimizer.th"),
+                            (self.critic_2, "critic_2", "critic_2_optimizer.th")):
+            states, options = load_adam_th(os.path.join(folder, f))
+            step, m, v = adam_flat_from_states(mod, states)
+            st[key] = dict(step=step, m=m, v=v)
+            self.learning_rate = options["lr"]
+        states, _ = load_adam_th(os.path.join(folder, "entropy_optimizer.th"))
+        e = states[0] if states else None
+        st["entropy"] = dict(step=0 if e is None else e[0],
+                             state=torch.zeros(2) if e is None else torch.cat([e[1].reshape(-1)[:1], e[2].reshape(-1)[:1]]).float())
+        st["train_steps"] = st["actor"]["step"]  # one actor step per train() call
+        self.load_optimizer_state(st)

@@ -80,6 +80,45 @@ int main(int argc, char **argv) {
         dump("mu", mu); dump("sigma", sigma);
         return 0;
     }
-    fprintf(stderr, "usage: ref_th save <folder> | ref_th load <folder> <file>\n");
+    if (argc >= 3 && !strcmp(argv[1], "saveopt")) {
+        // the reference's own optimiser archive: Adam over the pattern actor, two steps on a fixed loss, save_torch (ppo_gae.cpp:194)
+        auto actor = std::make_shared<ActorModule>(std::vector<int64_t>{S}, std::vector<int64_t>{A}, H);
+        fill_module(actor, 100);
+        auto opt = std::make_shared<torch::optim::Adam>(actor->parameters(), 1e-3);
+        auto X = torch::zeros({B, S});
+        { auto a = X.accessor<float, 2>(); for (int i = 0; i < B; i++) for (int j = 0; j < S; j++) a[i][j] = pat(7, (uint32_t) (i * S + j), 2.0f); }
+        for (int it = 0; it < 2; it++) {
+            auto [mu, sigma] = actor->forward(X);
+            auto loss = (mu * mu).sum() + sigma.sum();
+            opt->zero_grad(); loss.backward(); opt->step();
+        }
+        save_torch(argv[2], opt, "actor_optimizer.th");
+        save_torch(argv[2], actor, "actor_after.th");
+        return 0;
+    }
+    if (argc >= 4 && !strcmp(argv[1], "loadopt")) {
+        // load_torch (ppo_gae.cpp:201) of an optimiser archive into a fresh Adam; prints what arrived
+        auto actor = std::make_shared<ActorModule>(std::vector<int64_t>{S}, std::vector<int64_t>{A}, H);
+        auto opt = std::make_shared<torch::optim::Adam>(actor->parameters(), 5e-2);
+        load_torch(argv[2], opt, argv[3]);
+        auto &g = opt->param_groups()[0];
+        auto &o = static_cast<torch::optim::AdamOptions &>(g.options());
+        printf("scalar lr %.9g\nscalar beta1 %.9g\nscalar eps %.9g\n", o.lr(), std::get<0>(o.betas()), o.eps());
+        int idx = 0;
+        for (auto &p : g.params()) {
+            auto it = opt->state().find(p.unsafeGetTensorImpl());
+            if (it == opt->state().end()) { printf("scalar state_%d_missing 1\n", idx++); continue; }
+            auto &st = static_cast<torch::optim::AdamParamState &>(*it->second);
+            printf("scalar step_%d %lld\n", idx, (long long) st.step());
+            if (idx == 0 || idx == 9) {
+                char name[64];
+                snprintf(name, sizeof name, "exp_avg_%d_head", idx); dump(name, st.exp_avg().view({-1}).slice(0, 0, 8));
+                snprintf(name, sizeof name, "exp_avg_sq_%d_head", idx); dump(name, st.exp_avg_sq().view({-1}).slice(0, 0, 8));
+            }
+            idx++;
+        }
+        return 0;
+    }
+    fprintf(stderr, "usage: ref_th save <folder> | ref_th load <folder> <file> | ref_th saveopt <folder> | ref_th loadopt <folder> <file>\n");
     return 2;
 }

@@ -13,7 +13,8 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import agent_oracle as ao  # noqa: E402
 import golden_io  # noqa: E402
 from evomotion_amd.agent import ActorModule, CriticModule  # noqa: E402
-from evomotion_amd.checkpoint import load_into, load_th, save_th  # noqa: E402
+from evomotion_amd.checkpoint import (adam_flat_from_states, adam_states_from_flat, load_adam_th, load_into, load_th,  # noqa: E402
+                                      save_adam_th, save_th)
 
 REF_TH = os.path.join(ROOT, "oracle", "_ref", "ref_th")
 SHIPPED = "/root/reference/resources/robot_walk_crossq_save_34/actor.th"
@@ -93,3 +94,53 @@ def test_shipped_crossq_actor_loads_and_matches_the_reference_forward():
         mu, sigma = a(x)
     np.testing.assert_allclose(mu.numpy(), t["shipped_mu"], atol=2e-5)
     np.testing.assert_allclose(sigma.numpy(), t["shipped_sigma"], atol=2e-5, rtol=2e-5)
+
+
+# ---- torch::optim::Adam archives (`*_optimizer.th`, ppo_gae.cpp:194-203, soft_actor_critic.cpp:186-220) ------------------
+def _adam_states(module, step=3, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return [(step, torch.randn(p.shape, generator=g), torch.rand(p.shape, generator=g)) for p in module.parameters()]
+
+
+def test_adam_archive_python_round_trip(tmp_path):
+    a, _ = pattern_actor()
+    states = _adam_states(a)
+    states[4] = None  # a parameter that never received a gradient has no state entry
+    save_adam_th(str(tmp_path / "actor_optimizer.th"), states, lr=3e-4, betas=(0.5, 0.999), eps=1e-7, weight_decay=0.01)
+    got, opt = load_adam_th(str(tmp_path / "actor_optimizer.th"))
+    assert opt == dict(lr=3e-4, betas=(0.5, 0.999), eps=1e-7, weight_decay=0.01, amsgrad=False)
+    assert len(got) == len(states) and got[4] is None
+    for g_, w in zip(got, states):
+        if w is not None:
+            assert g_[0] == w[0] and torch.equal(g_[1], w[1]) and torch.equal(g_[2], w[2])
+    # flat (trainer) layout <-> per-parameter states
+    step, m, v = adam_flat_from_states(a, got)
+    assert step == 3 and m.numel() == sum(p.numel() for p in a.parameters())
+    back = adam_states_from_flat(a, step, m, v)
+    assert torch.equal(back[0][1], states[0][1]) and float(back[4][1].abs().max()) == 0.0
+    with pytest.raises(RuntimeError, match="Could not find"):
+        load_adam_th(str(tmp_path / "nope_optimizer.th"))
+    with pytest.raises(RuntimeError, match="parameters"):
+        adam_flat_from_states(CriticModule([371], 256), got)
+
+
+@pytest.mark.skipif(not os.path.isfile(REF_TH), reason="oracle/_ref not built (authoring container only)")
+def test_adam_archives_cross_the_boundary_in_both_directions(tmp_path):
+    """The compiled reference writes an Adam archive with its own save_torch (two steps on the pattern actor): we read it.
+    We write one: the reference's load_torch puts its options, step counts and moments into a fresh torch::optim::Adam."""
+    subprocess.run([REF_TH, "saveopt", str(tmp_path)], check=True)
+    states, opt = load_adam_th(str(tmp_path / "actor_optimizer.th"))
+    assert opt["lr"] == pytest.approx(1e-3) and opt["betas"] == (0.9, 0.999) and len(states) == 12
+    assert all(st is not None and st[0] == 2 for st in states)
+    a, _ = pattern_actor()
+    assert [tuple(st[1].shape) for st in states] == [tuple(p.shape) for p in a.parameters()]
+    # the moments are those of two Adam steps: exp_avg_sq >= 0, and non-trivial
+    assert all(float(st[2].min()) >= 0.0 for st in states) and float(states[0][1].abs().max()) > 0
+    save_adam_th(str(tmp_path / "ours_optimizer.th"), states, lr=3e-4)
+    out = subprocess.run([REF_TH, "loadopt", str(tmp_path), "ours_optimizer.th"], capture_output=True, text=True, check=True).stdout
+    (tmp_path / "o.txt").write_text(out)
+    got = golden_io.load(str(tmp_path / "o.txt"))
+    sc = {l.split()[1]: float(l.split()[2]) for l in out.split("\n") if l.startswith("scalar ")}
+    assert sc["lr"] == pytest.approx(3e-4) and sc["beta1"] == pytest.approx(0.9) and all(sc["step_%d" % i] == 2 for i in range(12))
+    np.testing.assert_array_equal(got["exp_avg_0_head"], states[0][1].reshape(-1)[:8].numpy())
+    np.testing.assert_array_equal(got["exp_avg_sq_9_head"], states[9][2].reshape(-1)[:8].numpy())

@@ -2,7 +2,7 @@
 ring).  No oracle of that size: size-independent properties (every drawn row is a stored row, its next state is the state one
 slot later for the same env, draws are distinct, the ring wrapped), then one SoftActorCriticAgent::train call on the device
 with a 4096-row batch drawn from it.  Plus the agent-level rules around the memory: no update before has_enough(batch), one
-effective train() per update on the captured-graph path, optimiser state through save() / load()."""
+effective train() per update on the captured-graph path, optimiser state through save() / load() in the reference's archive format."""
 import os
 
 import numpy as np
@@ -109,19 +109,20 @@ def test_graph_path_first_update_is_one_train_call_and_state_round_trips(tmp_pat
     # one Adam step moves every weight by at most lr: three steps would show up as up to 3 lr
     q0 = mk(False).twinq.vector(PARAMS, 0)
     assert float((graph.twinq.vector(PARAMS, 0) - q0).abs().max()) <= 1.001e-3
-    # save / load: weights and Adam state survive
+    # save / load: weights and all four Adam states survive, in the reference's own archive format
     graph.save(str(tmp_path))
-    assert os.path.isfile(tmp_path / "sac_optimizers.pt") and os.path.isfile(tmp_path / "critic_1.th")
+    for f in ("actor.th", "critic_1.th", "target_critic_2.th", "entropy.th", "actor_optimizer.th", "critic_1_optimizer.th",
+              "critic_2_optimizer.th", "entropy_optimizer.th"):
+        assert os.path.isfile(tmp_path / f), f
     other = mk(False)
     other.load(str(tmp_path))
     torch.cuda.synchronize()
     assert torch.equal(other.twinq.vector(PARAMS, 1), graph.twinq.vector(PARAMS, 1))
     assert torch.equal(other._actor_tr.vector(PP, ACTOR), graph._actor_tr.vector(PP, ACTOR))
     assert torch.equal(other._actor_tr.vector(EXP_AVG, ACTOR), graph._actor_tr.vector(EXP_AVG, ACTOR))
-    assert other.twinq.adam_step(1) == 1 and int(other._ent_step.item()) == 1
-    assert torch.equal(other._ent_state, graph._ent_state)
-    # a folder that only carries the reference's address-keyed optimiser archives: loaded modules, loud about the rest
-    os.remove(tmp_path / "sac_optimizers.pt")
-    open(tmp_path / "actor_optimizer.th", "wb").write(b"reference archive stand-in")
-    with pytest.warns(UserWarning, match="optimiser archives"):
+    assert other.twinq.adam_step(1) == 1 and int(other._ent_step.item()) == 1 and other._actor_tr.adam_step(ACTOR_DEV_STEP) == 1
+    assert torch.equal(other._ent_state, graph._ent_state) and other.train_steps == 1
+    # like the reference's load_torch, a missing archive is an error, not a silent restart of the optimiser
+    os.remove(tmp_path / "critic_2_optimizer.th")
+    with pytest.raises(RuntimeError, match="Could not find"):
         mk(False).load(str(tmp_path))
