@@ -1153,6 +1153,33 @@ DEV float mt_peek01(const Ctx &c, int k) {
     if (r >= 1.0f) r = 0.99999994f;
     return r;
 }
+// (float) sin((double) x), (float) cos((double) x) for |x| <= 1.2 (reset angles: <= pi / 3)
+DEV void sincos_small(float xf, float &s, float &c) {
+    const double x = (double) xf, z = x * x;
+    if (fabs(x) > 1.2) { s = (float) sin(x); c = (float) cos(x); return; }  // not a reset angle of the reference: library path
+    double ps = -1.0 / 51090942171709440000.0;                    // -1/21!
+    ps = fma(ps, z, 1.0 / 121645100408832000.0);                   //  1/19!
+    ps = fma(ps, z, -1.0 / 355687428096000.0);                     // -1/17!
+    ps = fma(ps, z, 1.0 / 1307674368000.0);                        //  1/15!
+    ps = fma(ps, z, -1.0 / 6227020800.0);                          // -1/13!
+    ps = fma(ps, z, 1.0 / 39916800.0);                             //  1/11!
+    ps = fma(ps, z, -1.0 / 362880.0);                              // -1/9!
+    ps = fma(ps, z, 1.0 / 5040.0);                                 //  1/7!
+    ps = fma(ps, z, -1.0 / 120.0);                                 // -1/5!
+    ps = fma(ps, z, 1.0 / 6.0);                                    //  1/3!
+    s = (float) fma(-ps * z, x, x);                                // x - x^3 (1/6 - ...)
+    double pc = 1.0 / 2432902008176640000.0;                       //  1/20!
+    pc = fma(pc, z, -1.0 / 6402373705728000.0);                    // -1/18!
+    pc = fma(pc, z, 1.0 / 20922789888000.0);                       //  1/16!
+    pc = fma(pc, z, -1.0 / 87178291200.0);                         // -1/14!
+    pc = fma(pc, z, 1.0 / 479001600.0);                            //  1/12!
+    pc = fma(pc, z, -1.0 / 3628800.0);                             // -1/10!
+    pc = fma(pc, z, 1.0 / 40320.0);                                //  1/8!
+    pc = fma(pc, z, -1.0 / 720.0);                                 // -1/6!
+    pc = fma(pc, z, 1.0 / 24.0);                                   //  1/4!
+    pc = fma(pc, z, -0.5);                                         // -1/2!
+    c = (float) fma(pc, z, 1.0);
+}
 // reset rotation from its three uniform draws -> glm::eulerAngleYXZ (robot_walk.cpp:80-86)
 DEV M33 repose_rotation(float u0, float u1, float u2) {
     const float angle_limit = c_skel.reset_angle_limit;
@@ -1161,9 +1188,14 @@ DEV M33 repose_rotation(float u0, float u1, float u2) {
     const float roll = xs_(xm(u1, angle_limit), half);
     const float pitch = xs_(xm(u2, angle_limit), half);
     // sin/cos through fp64 so that the fp32 results are the correctly rounded ones (what glibc returns for
-    // all but a handful of arguments); 6 evaluations per reset.
-    const float ch = (float) cos((double) yaw), sh = (float) sin((double) yaw), cp = (float) cos((double) pitch),
-                sp = (float) sin((double) pitch), cb = (float) cos((double) roll), sb = (float) sin((double) roll);
+    // all but a handful of arguments); 6 evaluations per reset.  The angles are at most pi / 3 in magnitude: no range
+    // reduction is needed and the Taylor series to x^21 / x^20 is exact to fp64 rounding (next term < 2e-22), 20 fmas
+    // instead of the ~2000 instructions of six library calls — which sat on the root body's item of the integration kernel and
+    // in the sweeps kernel's epilogue in nearly every step (some env of a wave finishes an episode almost every call).
+    float ch, sh, cp, sp, cb, sb;
+    sincos_small(yaw, sh, ch);
+    sincos_small(pitch, sp, cp);
+    sincos_small(roll, sb, cb);
     // glm::eulerAngleYXZ(yaw, pitch, roll), stored as rows, every operation individually rounded
     return m33(f3(xa(xm(ch, cb), xm(xm(sh, sp), sb)), xa(xm(-ch, sb), xm(xm(sh, sp), cb)), xm(sh, cp)),
                f3(xm(sb, cp), xm(cb, cp), -sp),
