@@ -45,7 +45,21 @@ def measured_traffic(n):
     return best
 
 
+def cpu_worker(seed, steps):
+    """child process of cpu_baseline()'s all-cores leg: one oracle env, prints `steps seconds`"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc
+    L = orc.load()
+    env = orc.OracleEnv(seed=seed, lib=L)
+    n_res = ctypes.c_int()
+    t = L.orc_bench_env_steps(env.h, steps, 11, ctypes.byref(n_res))
+    print(steps, t)
+
+
 def cpu_baseline(seconds=12.0):
+    """The scalar CPU restatement (oracle/) timed on this box's host cores: one env on one thread (the reference's loop is one
+    env, one thread driving Bullet), and — so that the comparison is not against a single core of a many-core host — one
+    independent env per core on all cores at once (plain child processes, bounded by a timeout)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orc
     L = orc.load()
@@ -55,11 +69,32 @@ def cpu_baseline(seconds=12.0):
     t = L.orc_bench_env_steps(env.h, 2000, 7, ctypes.byref(n_res))
     steps = max(2000, int(2000 * seconds / max(t, 1e-6)))
     t = L.orc_bench_env_steps(env.h, steps, 11, ctypes.byref(n_res))
-    return {
+    out = {
         "value": steps / t, "unit": "env-steps/s", "cores": 1, "kind": "port",
         "sample": f"{steps} do_step calls incl. {n_res.value} reset() (60 settle steps each), 1 env, 1 thread, "
                   f"{t:.1f} s of the scalar CPU restatement (oracle/); Bullet3 itself is not installed on this box",
     }
+    try:
+        import subprocess
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        if cores > 1:
+            per = max(2000, int(steps * 6.0 / max(t, 1e-6)))  # about 6 s per process at the single-core rate
+            procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(1234 + 17 * i), str(per)],
+                                      stdout=subprocess.PIPE, stderr=subprocess.DEVNULL) for i in range(cores)]
+            res = []
+            for p_ in procs:
+                try:
+                    o, _ = p_.communicate(timeout=120)
+                    a, b = o.decode().split()
+                    res.append((int(a), float(b)))
+                except Exception:
+                    p_.kill()
+            if len(res) == cores:
+                out["all_cores"] = {"value": sum(r[0] for r in res) / max(r[1] for r in res), "unit": "env-steps/s", "cores": cores,
+                                    "sample": f"{cores} independent envs, one process per core, {per} do_step calls each"}
+    except Exception as e:  # the single-core figure above stands on its own
+        out["all_cores"] = {"error": str(e)}
+    return out
 
 
 def launch_ranks(n_ranks, argv, worker=None, timeout=None):
@@ -120,6 +155,9 @@ def launch_ranks(n_ranks, argv, worker=None, timeout=None):
 
 
 def main():
+    if len(sys.argv) == 4 and sys.argv[1] == "--cpu-worker":  # child of cpu_baseline(): no torch, no GPU
+        cpu_worker(int(sys.argv[2]), int(sys.argv[3]))
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1024)
