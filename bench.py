@@ -45,6 +45,20 @@ def measured_traffic(n):
     return best
 
 
+def host_cores():
+    """cores this process may really use: the affinity mask, cut down by the cgroup CPU quota of a container (a GPU box hands
+    out 16 cores of a much larger host) and by 16"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 16))
+
+
 def cpu_worker(seed, steps):
     """child process of cpu_baseline()'s all-cores leg: one oracle env, prints `steps seconds`"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -76,15 +90,15 @@ def cpu_baseline(seconds=12.0):
     }
     try:
         import subprocess
-        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        cores = host_cores()
         if cores > 1:
             per = max(2000, int(steps * 6.0 / max(t, 1e-6)))  # about 6 s per process at the single-core rate
             procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(1234 + 17 * i), str(per)],
                                       stdout=subprocess.PIPE, stderr=subprocess.DEVNULL) for i in range(cores)]
-            res = []
+            res, deadline = [], time.time() + 60.0
             for p_ in procs:
                 try:
-                    o, _ = p_.communicate(timeout=120)
+                    o, _ = p_.communicate(timeout=max(deadline - time.time(), 0.1))
                     a, b = o.decode().split()
                     res.append((int(a), float(b)))
                 except Exception:
