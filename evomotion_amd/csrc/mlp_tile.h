@@ -91,6 +91,31 @@ __device__ __forceinline__ void dense_layer(const float *as, int ald, const floa
 }
 
 
+// The head GEMM [32 x 256] x [256 x 32] on the matrix pipe (as a row-wise dot product loop it was a quarter of the forward
+// kernel): K is split over the four waves, wave w leaves its partial 32 x 32 tile in hs4[w][row][col]; the caller
+// synchronises and sums the four.  hb: k-split activation tile (row stride ALD2); whp: [32 s4][32 cols][2][4].
+__device__ __forceinline__ void head_gemm(const float *hb, const float *__restrict__ whp, float *hs4, int wave, int lane) {
+    f32x16 hacc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) hacc[r] = 0.f;
+    const int aj = lane & 31, ah = lane >> 5;
+    const float *ap = hb + aj * ALD2 + ah * 128 + wave * 32;  // this wave's k range: 64 wave .. 64 wave + 63
+    const float *bp = whp + ((size_t) (8 * wave) * 32 + aj) * 8 + ah * 4;
+    f32x4 a4[8], b4[8];
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+        a4[b] = *reinterpret_cast<const f32x4 *>(ap + 4 * b);
+        b4[b] = *reinterpret_cast<const f32x4 *>(bp + (size_t) b * 256);
+    }
+#pragma unroll
+    for (int b = 0; b < 8; b++)
+#pragma unroll
+        for (int tt = 0; tt < 4; tt++) hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[b][tt], b4[b][tt], hacc, 0, 0, 0);
+    // C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int r = 0; r < 16; r++) hs4[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = hacc[r];
+}
+
 // stage a TM_ x S tile of a row-major [n][S] matrix, zero padded to K1 columns, k-split in LDS (row stride ALD1)
 template <int TM_>
 __device__ __forceinline__ void stage_rows_ksplit(float *xs, const float *__restrict__ obs, int row0, int n, int S) {

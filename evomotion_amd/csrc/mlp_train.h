@@ -10,7 +10,6 @@
 namespace evm {
 
 #define PRT 1  // 32-row MFMA tiles per wave in the training kernels (TM = 32 rows per workgroup)
-#define HEAD_PASS 12  // head outputs staged per pass in the forward: keeps its LDS at 49 KB = three workgroups per CU
 
 // ---------------------------------------------------------------------------------------------------------
 // tile helpers (k-split activation tile [TM][ALD2] <-> row-major [rows][256] in HBM)

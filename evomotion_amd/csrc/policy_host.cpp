@@ -32,7 +32,7 @@ int evm_policy_create(int state_dim, int action_dim, int hidden_size, int device
     const size_t per_net = (size_t) p->K1pad * 256 + 3 * 256 + 256 * 256 + 3 * 256;
     p->arena_floats = 2 * per_net + ((size_t) 2 * action_dim * 256 + 2 * action_dim) + (256 + 1) + 2 * 8192 + 4;
     if (hipMalloc((void **) &p->arena, p->arena_floats * 4) != hipSuccess) { delete p; return pfail(EVM_E_HIP, "hipMalloc failed"); }
-    hipMemset(p->arena, 0, p->arena_floats * 4);
+    if (hipMemset(p->arena, 0, p->arena_floats * 4) != hipSuccess) { hipFree(p->arena); delete p; return pfail(EVM_E_HIP, "hipMemset failed"); }
     float *b = p->arena;
     auto carve = [&](evm::NetDev &n, size_t head_w, size_t head_b) {
         n.w1t = b; b += (size_t) p->K1pad * 256;

@@ -120,9 +120,7 @@ __global__ __launch_bounds__(PT) void k_policy_forward(PolicyDev p, int n, const
     epilogue_mish_ln(acc, N.b2, N.g2, N.be2, hb, wave, lane);
     PSTAMP(5)
 
-    // heads: Linear(256, 1) for the critic, Linear(256, A) x 2 (mu, sigma) for the actor.  The head weights are
-    // staged into the (dead) observation tile in the activations' k-split order; thread (row, part) takes its RUN
-    // stored activations against every output and the 4 parts are summed with two shuffles.
+    // heads: Linear(256, 1) for the critic, Linear(256, A) x 2 (mu, sigma) for the actor
     const int t = threadIdx.x, row = t / PARTS, part = t % PARTS;
     const int gr = row0 + row;
     const int A = p.A;
@@ -132,27 +130,7 @@ __global__ __launch_bounds__(PT) void k_policy_forward(PolicyDev p, int n, const
     static_assert(TM == 32, "the head GEMM is one 32-row MFMA tile");
     float *hs4 = sm + TM * ALD2;     // [4 waves][32 rows][32 cols] partial sums
     float *hs = hs4 + 4 * 32 * 32;   // [TM][32] pre-activations
-    {
-        f32x16 hacc;
-#pragma unroll
-        for (int r = 0; r < 16; r++) hacc[r] = 0.f;
-        const int aj = lane & 31, ah = lane >> 5;
-        const float *ap = hb + aj * ALD2 + ah * 128 + wave * 32;                      // this wave's k range: 64 wave .. 64 wave + 63
-        const float *bp = N.whp + ((size_t) (8 * wave) * 32 + aj) * 8 + ah * 4;
-        f32x4 a4[8], b4[8];
-#pragma unroll
-        for (int b = 0; b < 8; b++) {
-            a4[b] = *reinterpret_cast<const f32x4 *>(ap + 4 * b);
-            b4[b] = *reinterpret_cast<const f32x4 *>(bp + (size_t) b * 256);
-        }
-#pragma unroll
-        for (int b = 0; b < 8; b++)
-#pragma unroll
-            for (int tt = 0; tt < 4; tt++) hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[b][tt], b4[b][tt], hacc, 0, 0, 0);
-        // C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-#pragma unroll
-        for (int r = 0; r < 16; r++) hs4[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = hacc[r];
-    }
+    head_gemm(hb, N.whp, hs4, wave, lane);
     __syncthreads();
     for (int o = part; o < nout; o += PARTS)
         hs[row * 32 + o] = ((hs4[row * 32 + o] + hs4[(32 + row) * 32 + o]) + (hs4[(64 + row) * 32 + o] + hs4[(96 + row) * 32 + o])) + N.bh[o];

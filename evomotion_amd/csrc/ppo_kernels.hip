@@ -44,40 +44,21 @@ __global__ __launch_bounds__(PT) void k_ppo_forward(PolicyDev p, PpoDev d, int n
     const int gr = row0 + row;
     const int A = p.A;
     const int nout = net == 1 ? 1 : 2 * A;
-    float *wl = sm + TM * ALD2;          // [HEAD_PASS][256] head weights, k-split
-    float *hs = wl + HEAD_PASS * 256;    // [TM][32] pre-activations
-    {
-        const f32x4 *hr = reinterpret_cast<const f32x4 *>(hb + row * ALD2);
-        f32x4 x[RUN / 4];
-#pragma unroll
-        for (int i = 0; i < RUN / 4; i++) x[i] = hr[CHUNK(i, part, PARTS)];
-        for (int o0 = 0; o0 < nout; o0 += HEAD_PASS) {
-            const int no = min(HEAD_PASS, nout - o0);
-            __syncthreads();  // the previous pass has been consumed (first pass: the activation tile is complete)
-            for (int e = threadIdx.x; e < no * 256; e += PT) {
-                const int c = e & 255;
-                wl[(e & ~255) + (c & 1) * 128 + (c >> 1)] = N.wh[o0 * 256 + e];
-            }
-            __syncthreads();
-            for (int o = 0; o < no; o++) {
-                const f32x4 *wr = reinterpret_cast<const f32x4 *>(wl + o * 256);
-                float sum = 0.f;
-#pragma unroll
-                for (int i = 0; i < RUN / 4; i++) {
-                    const f32x4 w = wr[CHUNK(i, part, PARTS)];
-                    sum += (x[i][0] * w[0] + x[i][1] * w[1]) + (x[i][2] * w[2] + x[i][3] * w[3]);
-                }
-#pragma unroll
-                for (int m = 1; m < PARTS; m <<= 1) sum += __shfl_xor(sum, m);
-                if (part == 0) hs[row * 32 + o0 + o] = sum + N.bh[o0 + o];
-            }
-        }
-    }
+    // head GEMM on the matrix pipe (mlp_tile.h): the four waves' partial tiles land behind the activation tile (inside the
+    // dead observation tile), their sum over the activation tile itself once every wave has read its operands
+    static_assert(TM == 32, "the head GEMM is one 32-row MFMA tile");
+    float *hs4 = sm + TM * ALD2;  // [4 waves][32 rows][32 cols]
+    float *hs = sm;               // [TM][32] pre-activations
+    __syncthreads();              // the activation tile is complete
+    head_gemm(hb, N.whp, hs4, wave, lane);
+    __syncthreads();
+    for (int o = part; o < nout; o += PARTS)
+        hs[row * 32 + o] = ((hs4[row * 32 + o] + hs4[(32 + row) * 32 + o]) + (hs4[(64 + row) * 32 + o] + hs4[(96 + row) * 32 + o])) + N.bh[o];
+    __syncthreads();
     if (net == 1) {
         if (part == 0 && gr < n) B.head[gr] = hs[row * 32];
         return;
     }
-    __syncthreads();
     for (int a = part; a < A; a += PARTS) {
         if (gr >= n) continue;
         B.head[(size_t) gr * 2 * A + a] = tanhf(hs[row * 32 + a]);
@@ -639,7 +620,7 @@ __global__ __launch_bounds__(256) void k_ppo_gae_finish(size_t total, const doub
 // ---------------------------------------------------------------------------------------------------------
 static size_t fwd_lds_bytes() {
     constexpr int TM = 32 * PRT;
-    const size_t a = (size_t) TM * ALD1, b = (size_t) TM * ALD2 + HEAD_PASS * 256 + TM * 32;
+    const size_t a = (size_t) TM * ALD1, b = (size_t) TM * ALD2 + 4 * 32 * 32;
     return (a > b ? a : b) * sizeof(float);
 }
 static size_t bwd_lds_bytes() {
