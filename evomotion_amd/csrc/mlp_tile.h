@@ -20,12 +20,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define CHUNK(i, part, PARTS_) ((i) * (PARTS_) + (part))
 
 // Mish(x) = x tanh(softplus(x)).  With n = e^x: tanh(log(1 + n)) = n (n + 2) / (n (n + 2) + 2), all terms positive
-// (no cancellation), one exp and one division instead of exp + log1p + tanh (which cost ~300 VALU instructions per
+// (no cancellation), one exp and one reciprocal instead of exp + log1p + tanh (which cost ~300 VALU instructions per
 // value and were 40 % of the kernel).  x > 20: the ratio is 1 to fp32 precision and e^x would overflow at 88.
+// The reciprocal is v_rcp_f32 (1 ulp; m + 2 is in [2, 2.4e17], no denormals): __fdividef expands to the full
+// div_scale / div_fmas / div_fixup sequence with this compiler, 10 instructions per value.
 __device__ __forceinline__ float mish_f(float x) {
     const float n = __expf(fminf(x, 20.f));
     const float m = n * (n + 2.f);
-    return x * __fdividef(m, m + 2.f);
+    return x * (m * __builtin_amdgcn_rcpf(m + 2.f));
 }
 __device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 __device__ __forceinline__ float theta_f(float x) { return 0.5f * (1.0f + erff(x / 1.41421356237309504880f)); }
@@ -90,6 +92,108 @@ __device__ __forceinline__ void dense_layer(const float *as, int ald, const floa
 #undef EVM_LOADQ
 }
 
+
+// Workgroup barrier for LDS hand-overs only: waits for this wave's LDS operations, NOT for its global stores.
+// __syncthreads() carries a workgroup fence = s_waitcnt vmcnt(0): with activations streaming to HBM from the epilogues every
+// barrier then stalls until the wave's stores are acknowledged (~20 k cycles per layer in the training forward).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Sum over the 32 lanes of each half wave, result in every lane: four DPP adds (quad swaps, half-row and row mirrors: no LDS,
+// no wait counters) and one ds_swizzle exchange between the two 16-lane rows of the half.
+__device__ __forceinline__ float half_wave_sum(float v) {
+#define EVM_DPP_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false));
+    EVM_DPP_ADD(0xB1)   // quad_perm [1,0,3,2]
+    EVM_DPP_ADD(0x4E)   // quad_perm [2,3,0,1]
+    EVM_DPP_ADD(0x141)  // row_half_mirror
+    EVM_DPP_ADD(0x140)  // row_mirror
+#undef EVM_DPP_ADD
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));  // lane ^ 16
+}
+
+// Bias + Mish + LayerNorm(256) of a 32-row tile straight from the MFMA accumulators of one dense layer (acc[j]: columns
+// wave * 64 + 32 j + (lane & 31), C layout: row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)).  Nothing is transposed for the
+// row statistics: each wave reduces its 64 columns inside the 32-lane halves (mean, then the squared deviations from that
+// mean), the four waves' (mean, M2) pairs meet in LDS and are combined as M2 = sum M2_w + 64 sum (mean_w - mean)^2, which is
+// exact and as well conditioned as the two-pass form; lane (lane & 31) of every wave combines row (lane & 31) — one division
+// and square root per lane — and hands (mean, rstd) to the lanes that hold the row through a wave-private LDS line.
+// The normalised activations go to the k-split tile hb for the next layer and, for training, to HBM together with the
+// pre-activations z and (mean, rstd); half a wave stores 32 consecutive columns of one row = 128 contiguous bytes.
+// One barrier inside, one at the end.  The first barrier also covers "every wave has finished reading the tile hb overlays":
+// callers need no barrier between the dense layer and this.  red: EVM_RED_FLOATS of LDS outside every tile
+// ([32 rows][4 waves][2] partials, then [4 waves][32 rows][2] results).
+// The row-wise form this replaces (accumulators -> tile -> (row, part) threads -> tile) cost three barriers and an LDS round
+// trip per layer: ~20 k cycles of latency per layer in the training forward (tools/fstamps.py).
+__device__ __forceinline__ void mish_ln_epilogue(f32x16 (&acc)[2], const float *__restrict__ bias, const float *__restrict__ gamma,
+                                                 const float *__restrict__ beta, float *hb, float *red, int wave, int lane,
+                                                 int row0, int n, float *__restrict__ zg, float *__restrict__ ag,
+                                                 float *__restrict__ st, int st_off, int st_stride) {
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    const int cl = lane & 31, hf = lane >> 5;
+    const int c0 = wave * 64 + cl, c1 = c0 + 32;
+    const float b0 = bias[c0], b1 = bias[c1];
+    float g0 = gamma[c0], g1 = gamma[c1], e0 = beta[c0], e1 = beta[c1];
+    // have the six parameters in registers before the first store is issued: vector memory operations complete in order, so
+    // a load scheduled behind the z stores (where the compiler sinks it, next to its use) waits for all of them
+    asm volatile("" : "+v"(g0), "+v"(g1), "+v"(e0), "+v"(e1));
+    float s[16], q[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hf;
+        const float z0 = acc[0][r] + b0, z1 = acc[1][r] + b1;
+        if (zg && row0 + row < n) {
+            zg[(size_t) (row0 + row) * 256 + c0] = z0;
+            zg[(size_t) (row0 + row) * 256 + c1] = z1;
+        }
+        acc[0][r] = mish_f(z0);
+        acc[1][r] = mish_f(z1);
+        s[r] = half_wave_sum(acc[0][r] + acc[1][r]) * (1.0f / 64.0f);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const float d0 = acc[0][r] - s[r], d1 = acc[1][r] - s[r];
+        q[r] = half_wave_sum(d0 * d0 + d1 * d1);
+    }
+    if (cl == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * hf;
+            *reinterpret_cast<f32x2_ *>(red + (row * 4 + wave) * 2) = f32x2_{s[r], q[r]};
+        }
+    }
+    lds_barrier();
+    float *mine = red + 256 + wave * 64;  // this wave's [32 rows][mean, rstd]
+    {
+        const f32x4 p0 = *reinterpret_cast<const f32x4 *>(red + cl * 8), p1 = *reinterpret_cast<const f32x4 *>(red + cl * 8 + 4);
+        const float mean = ((p0[0] + p0[2]) + (p1[0] + p1[2])) * 0.25f;
+        const float da = p0[0] - mean, db = p0[2] - mean, dc = p1[0] - mean, dd = p1[2] - mean;
+        const float m2 = ((p0[1] + p0[3]) + (p1[1] + p1[3])) + 64.0f * ((da * da + db * db) + (dc * dc + dd * dd));
+        const float rstd = 1.0f / sqrtf(m2 * (1.0f / 256.0f) + 1e-5f);
+        if (hf == 0) *reinterpret_cast<f32x2_ *>(mine + cl * 2) = f32x2_{mean, rstd};
+        if (st && wave == 0 && hf == 0 && row0 + cl < n) {
+            st[(size_t) (row0 + cl) * st_stride + st_off] = mean;
+            st[(size_t) (row0 + cl) * st_stride + st_off + 1] = rstd;
+        }
+    }
+    // (LDS operations of one wave complete in order: the reads below see this wave's line without a barrier)
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const f32x4 ma = *reinterpret_cast<const f32x4 *>(mine + (8 * g + 4 * hf) * 2), mb = *reinterpret_cast<const f32x4 *>(mine + (8 * g + 4 * hf) * 2 + 4);
+        const float mean[4] = {ma[0], ma[2], mb[0], mb[2]}, rstd[4] = {ma[1], ma[3], mb[1], mb[3]};
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int r = 4 * g + u, row = 8 * g + 4 * hf + u;
+            const float y0 = (acc[0][r] - mean[u]) * rstd[u] * g0 + e0, y1 = (acc[1][r] - mean[u]) * rstd[u] * g1 + e1;
+            hb[HIDX(row, c0)] = y0;
+            hb[HIDX(row, c1)] = y1;
+            if (ag && row0 + row < n) {
+                ag[(size_t) (row0 + row) * 256 + c0] = y0;
+                ag[(size_t) (row0 + row) * 256 + c1] = y1;
+            }
+        }
+    }
+    lds_barrier();
+}
+#define EVM_RED_FLOATS 512  // LDS floats of the statistics exchange of mish_ln_epilogue
 
 // The head GEMM [32 x 256] x [256 x 32] on the matrix pipe (as a row-wise dot product loop it was a quarter of the forward
 // kernel): K is split over the four waves, wave w leaves its partial 32 x 32 tile in hs4[w][row][col]; the caller

@@ -96,68 +96,15 @@ __device__ __forceinline__ void stage_padded_ksplit(float *xs, const float *__re
     }
 }
 
-// z = acc + bias -> HBM; Mish + LayerNorm per row -> tile and HBM; (mean, rstd) -> st[row * st_stride + st_off ..];
-// zg / ag / st may be NULL (a forward that keeps nothing)
+// forward epilogue of a layer with the activations kept: mish_ln_epilogue (mlp_tile.h) with z = acc + bias, the LayerNorm
+// output and (mean, rstd) -> st[row * st_stride + st_off ..] written to HBM; zg / ag / st may be NULL (a forward that keeps
+// nothing).  red: EVM_RED_FLOATS of LDS outside the tiles.
 template <int RT>
-__device__ __forceinline__ void train_epilogue(const f32x16 (&acc)[RT][2], const float *__restrict__ bias,
-                                               const float *__restrict__ gamma, const float *__restrict__ beta, float *hb,
+__device__ __forceinline__ void train_epilogue(f32x16 (&acc)[RT][2], const float *__restrict__ bias,
+                                               const float *__restrict__ gamma, const float *__restrict__ beta, float *hb, float *red,
                                                int wave, int lane, int row0, int n, float *zg, float *ag, float *st, int st_off, int st_stride) {
-    constexpr int TM = 32 * RT, PARTS = PT / TM, RUN = 256 / PARTS;
-    // z = acc + bias: to the tile for the row phase and straight to HBM from the accumulators (C layout: the 32 lanes of
-    // a half wave hold 32 consecutive columns of one row = 128 contiguous bytes)
-#pragma unroll
-    for (int i = 0; i < RT; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int c = wave * 64 + j * 32 + (lane & 31);
-            const float b = bias[c];
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const float z = acc[i][j][r] + b;
-                hb[HIDX(row, c)] = z;
-                if (zg && row0 + row < n) zg[(size_t) (row0 + row) * 256 + c] = z;
-            }
-        }
-    __syncthreads();
-    const int t = threadIdx.x, row = t / PARTS, part = t % PARTS;
-    f32x4 *hr = reinterpret_cast<f32x4 *>(hb + row * ALD2);
-    f32x4 x[RUN / 4];
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < RUN / 4; i++) {
-        x[i] = hr[CHUNK(i, part, PARTS)];
-#pragma unroll
-        for (int u = 0; u < 4; u++) x[i][u] = mish_f(x[i][u]);
-        s += (x[i][0] + x[i][1]) + (x[i][2] + x[i][3]);
-    }
-#pragma unroll
-    for (int m = 1; m < PARTS; m <<= 1) s += __shfl_xor(s, m);
-    const float mean = s / 256.f;
-    float v = 0.f;
-#pragma unroll
-    for (int i = 0; i < RUN / 4; i++)
-#pragma unroll
-        for (int u = 0; u < 4; u++) { const float d = x[i][u] - mean; v += d * d; }
-#pragma unroll
-    for (int m = 1; m < PARTS; m <<= 1) v += __shfl_xor(v, m);
-    const float rstd = 1.0f / sqrtf(v / 256.f + 1e-5f);
-    if (st && part == 0 && row0 + row < n) {
-        st[(size_t) (row0 + row) * st_stride + st_off] = mean;
-        st[(size_t) (row0 + row) * st_stride + st_off + 1] = rstd;
-    }
-#pragma unroll
-    for (int i = 0; i < RUN / 4; i++) {
-        f32x4 y;
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int c = QCOL(4 * CHUNK(i, part, PARTS) + u);
-            y[u] = (x[i][u] - mean) * rstd * gamma[c] + beta[c];
-        }
-        hr[CHUNK(i, part, PARTS)] = y;
-    }
-    __syncthreads();
-    if (ag) tile_store<TM>(hb, ag, row0, n);
+    static_assert(RT == 1, "one 32-row MFMA tile per wave");
+    mish_ln_epilogue(acc[0], bias, gamma, beta, hb, red, wave, lane, row0, n, zg, ag, st, st_off, st_stride);
 }
 
 

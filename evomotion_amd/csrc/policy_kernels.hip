@@ -25,56 +25,8 @@ namespace evm {
 #define TM (32 * RT)
 #define PARTS (PT / TM)   // threads sharing a row in the row-wise epilogues
 #define RUN (256 / PARTS) // stored activations per thread (a contiguous run of the k-split row)
-
-// bias + Mish into the activation tile, then LayerNorm(256) per row
-__device__ __forceinline__ void epilogue_mish_ln(f32x16 (&acc)[RT][2], const float *__restrict__ bias,
-                                                 const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                 float *hb, int wave, int lane) {
-    // C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-#pragma unroll
-    for (int i = 0; i < RT; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int c = wave * 64 + j * 32 + (lane & 31);
-            const float b = bias[c];
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                hb[HIDX(row, c)] = mish_f(acc[i][j][r] + b);
-            }
-        }
-    __syncthreads();
-    // LayerNorm: PARTS threads per row, each owning RUN / 4 interleaved 16-byte chunks of the k-split row (which columns a
-    // thread holds does not matter for the statistics); element q of the stored row is column QCOL(q)
-    const int t = threadIdx.x, row = t / PARTS, part = t % PARTS;
-    f32x4 *hr = reinterpret_cast<f32x4 *>(hb + row * ALD2);
-    f32x4 x[RUN / 4];
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < RUN / 4; i++) { x[i] = hr[CHUNK(i, part, PARTS)]; s += (x[i][0] + x[i][1]) + (x[i][2] + x[i][3]); }
-#pragma unroll
-    for (int m = 1; m < PARTS; m <<= 1) s += __shfl_xor(s, m);
-    const float mean = s / 256.f;
-    float v = 0.f;
-#pragma unroll
-    for (int i = 0; i < RUN / 4; i++)
-#pragma unroll
-        for (int u = 0; u < 4; u++) { const float d = x[i][u] - mean; v += d * d; }
-#pragma unroll
-    for (int m = 1; m < PARTS; m <<= 1) v += __shfl_xor(v, m);
-    const float rstd = 1.0f / sqrtf(v / 256.f + 1e-5f);
-#pragma unroll
-    for (int i = 0; i < RUN / 4; i++) {
-        f32x4 y;
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int c = QCOL(4 * CHUNK(i, part, PARTS) + u);
-            y[u] = (x[i][u] - mean) * rstd * gamma[c] + beta[c];
-        }
-        hr[CHUNK(i, part, PARTS)] = y;
-    }
-    __syncthreads();
-}
+// LDS floats of the two overlaid lives of the tile buffer: observations | activations + head partials + head pre-activations
+#define POLICY_TILE_FLOATS (TM * ALD1 > TM * ALD2 + 4 * 32 * 32 + TM * 32 ? TM * ALD1 : TM * ALD2 + 4 * 32 * 32 + TM * 32)
 
 __device__ __forceinline__ float rng_uniform(uint64_t seed, uint64_t counter, uint32_t row, uint32_t dim) {
     // counter-based (stateless) generator: splitmix64 finaliser over (seed, counter, row, dim) -> 24-bit uniform [0,1)
@@ -91,9 +43,11 @@ __global__ __launch_bounds__(PT) void k_policy_forward(PolicyDev p, int n, const
                                                        float *sigma_out) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     // one buffer, two lives: the observation tile [TM][ALD1] during layer 1, then the activation tile [TM][ALD2]
-    // followed by the staged head weights [32][256] and the head pre-activations [TM][32]
+    // followed by the head GEMM's partial tiles and the head pre-activations [TM][32]; behind both, the LayerNorm
+    // statistics exchange of mish_ln_epilogue
     float *xs = sm;
     float *hb = sm;
+    float *red = sm + POLICY_TILE_FLOATS;
     const int net = blockIdx.y;    // 0 actor, 1 critic
     const int row0 = blockIdx.x * TM;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -110,14 +64,12 @@ __global__ __launch_bounds__(PT) void k_policy_forward(PolicyDev p, int n, const
     PSTAMP(1)
     f32x16 acc[RT][2];
     dense_layer<K1, RT>(xs, ALD1, N.w1t, wave, lane, acc);
-    __syncthreads();  // every wave has finished reading the observation tile
     PSTAMP(2)
-    epilogue_mish_ln(acc, N.b1, N.g1, N.be1, hb, wave, lane);
+    mish_ln_epilogue(acc[0], N.b1, N.g1, N.be1, hb, red, wave, lane, row0, n, nullptr, nullptr, nullptr, 0, 0);
     PSTAMP(3)
     dense_layer<256, RT>(hb, ALD2, N.w2t, wave, lane, acc);
-    __syncthreads();  // every wave has finished reading the layer-1 activations
     PSTAMP(4)
-    epilogue_mish_ln(acc, N.b2, N.g2, N.be2, hb, wave, lane);
+    mish_ln_epilogue(acc[0], N.b2, N.g2, N.be2, hb, red, wave, lane, row0, n, nullptr, nullptr, nullptr, 0, 0);
     PSTAMP(5)
 
     // heads: Linear(256, 1) for the critic, Linear(256, A) x 2 (mu, sigma) for the actor
@@ -235,10 +187,7 @@ hipError_t launch_policy_pack(const NetDev &n, int S, int A, bool actor, const f
     return hipGetLastError();
 }
 
-size_t policy_lds_bytes() {
-    const size_t a = (size_t) TM * ALD1, b = (size_t) TM * ALD2 + 4 * 32 * 32 + TM * 32;
-    return (a > b ? a : b) * sizeof(float);
-}
+size_t policy_lds_bytes() { return (size_t) (POLICY_TILE_FLOATS + EVM_RED_FLOATS) * sizeof(float); }
 
 hipError_t launch_policy_forward(const PolicyDev &p, int n, const float *obs, const float *uniform, uint64_t seed,
                                  uint64_t counter, float *action, float *logp, float *value, float *mu, float *sigma,

@@ -19,6 +19,12 @@
 namespace evm {
 
 
+#ifdef EVM_FSTAMPS  // diagnostic build (tools/fstamps.py): s_memtime at the phase boundaries of every wave of k_ppo_forward
+__device__ unsigned long long g_fstamps[8192 * 4 * 8];
+#define FSTAMP { __builtin_amdgcn_sched_barrier(0); fs_t[fs_n++] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define FSTAMP
+#endif
 template <int RT>
 __global__ __launch_bounds__(PT) void k_ppo_forward(PolicyDev p, PpoDev d, int n, const float *__restrict__ states) {
     constexpr int TM = 32 * RT, PARTS = PT / TM, RUN = 256 / PARTS;
@@ -29,15 +35,24 @@ __global__ __launch_bounds__(PT) void k_ppo_forward(PolicyDev p, PpoDev d, int n
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const NetDev &N = net == 0 ? p.actor : p.critic;
     const PpoNet &B = net == 0 ? d.actor : d.critic;
+#ifdef EVM_FSTAMPS
+    unsigned long long fs_t[8];
+    int fs_n = 0;
+#endif
+    FSTAMP
     stage_padded_ksplit<TM>(xs, states, row0, n);  // the padded copy: [n][K1]
-    __syncthreads();
+    lds_barrier();
+    FSTAMP
     f32x16 acc[RT][2];
+    float *red = sm + TM * ALD1;  // behind both tiles
     dense_layer<K1, RT>(xs, ALD1, N.w1t, wave, lane, acc);
-    __syncthreads();
-    train_epilogue<RT>(acc, N.b1, N.g1, N.be1, hb, wave, lane, row0, n, B.z1, B.a1, B.st, 0, 4);
+    FSTAMP
+    train_epilogue<RT>(acc, N.b1, N.g1, N.be1, hb, red, wave, lane, row0, n, B.z1, B.a1, B.st, 0, 4);
+    FSTAMP
     dense_layer<256, RT>(hb, ALD2, N.w2t, wave, lane, acc);
-    __syncthreads();
-    train_epilogue<RT>(acc, N.b2, N.g2, N.be2, hb, wave, lane, row0, n, B.z2, B.a2, B.st, 2, 4);
+    FSTAMP
+    train_epilogue<RT>(acc, N.b2, N.g2, N.be2, hb, red, wave, lane, row0, n, B.z2, B.a2, B.st, 2, 4);
+    FSTAMP
 
     // heads, as in k_policy_forward
     const int t = threadIdx.x, row = t / PARTS, part = t % PARTS;
@@ -49,12 +64,19 @@ __global__ __launch_bounds__(PT) void k_ppo_forward(PolicyDev p, PpoDev d, int n
     static_assert(TM == 32, "the head GEMM is one 32-row MFMA tile");
     float *hs4 = sm + TM * ALD2;  // [4 waves][32 rows][32 cols]
     float *hs = sm;               // [TM][32] pre-activations
-    __syncthreads();              // the activation tile is complete
     head_gemm(hb, N.whp, hs4, wave, lane);
-    __syncthreads();
+    lds_barrier();
     for (int o = part; o < nout; o += PARTS)
         hs[row * 32 + o] = ((hs4[row * 32 + o] + hs4[(32 + row) * 32 + o]) + (hs4[(64 + row) * 32 + o] + hs4[(96 + row) * 32 + o])) + N.bh[o];
-    __syncthreads();
+    lds_barrier();
+    FSTAMP
+#ifdef EVM_FSTAMPS
+    if (lane == 0 && blockIdx.x < 4096) {
+        unsigned long long *o = g_fstamps + ((size_t) (blockIdx.y * 4096 + blockIdx.x) * 4 + wave) * 8;
+        for (int i = 0; i < 7; i++) o[i] = fs_t[i];
+        o[7] = __builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long) __builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);  // HW_ID, XCC_ID
+    }
+#endif
     if (net == 1) {
         if (part == 0 && gr < n) B.head[gr] = hs[row * 32];
         return;
@@ -620,7 +642,7 @@ __global__ __launch_bounds__(256) void k_ppo_gae_finish(size_t total, const doub
 // ---------------------------------------------------------------------------------------------------------
 static size_t fwd_lds_bytes() {
     constexpr int TM = 32 * PRT;
-    const size_t a = (size_t) TM * ALD1, b = (size_t) TM * ALD2 + 4 * 32 * 32;
+    const size_t a = (size_t) TM * ALD1 + EVM_RED_FLOATS, b = (size_t) TM * ALD2 + 4 * 32 * 32;
     return (a > b ? a : b) * sizeof(float);
 }
 static size_t bwd_lds_bytes() {
@@ -791,3 +813,9 @@ hipError_t launch_ppo_gae_finish(int T, int N, const double *stats, const float 
 }
 
 }  // namespace evm
+
+#ifdef EVM_FSTAMPS
+extern "C" int evm_debug_fstamps(unsigned long long *out) {
+    return (int) hipMemcpyFromSymbol(out, HIP_SYMBOL(evm::g_fstamps), sizeof(unsigned long long) * 8192 * 4 * 8);
+}
+#endif

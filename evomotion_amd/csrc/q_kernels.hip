@@ -69,15 +69,14 @@ __global__ __launch_bounds__(PT) void k_q_forward(QDev d, QSel sel, int n, int k
     stage_padded_ksplit<TM>(xs, d.xq, row0, n);
     __syncthreads();
     f32x16 acc[RT][2];
+    float *red = sm + TM * ALD1;  // behind both tiles
     dense_layer<K1, RT>(xs, ALD1, N.wt[0], wave, lane, acc);
-    __syncthreads();
-    train_epilogue<RT>(acc, N.theta + N.o_b[0], N.theta + N.o_g[0], N.theta + N.o_be[0], hb, wave, lane, row0, n, kp ? N.z[0] : nullptr,
+    train_epilogue<RT>(acc, N.theta + N.o_b[0], N.theta + N.o_g[0], N.theta + N.o_be[0], hb, red, wave, lane, row0, n, kp ? N.z[0] : nullptr,
                        kp ? N.a[0] : nullptr, kp ? N.st : nullptr, 0, 2 * Q_LAYERS);
 #pragma unroll
     for (int l = 1; l < Q_LAYERS; l++) {
         dense_layer<256, RT>(hb, ALD2, N.wt[l], wave, lane, acc);
-        __syncthreads();
-        train_epilogue<RT>(acc, N.theta + N.o_b[l], N.theta + N.o_g[l], N.theta + N.o_be[l], hb, wave, lane, row0, n,
+        train_epilogue<RT>(acc, N.theta + N.o_b[l], N.theta + N.o_g[l], N.theta + N.o_be[l], hb, red, wave, lane, row0, n,
                            kp ? N.z[l] : nullptr, kp ? N.a[l] : nullptr, kp ? N.st : nullptr, 2 * l, 2 * Q_LAYERS);
     }
     // head: one output; thread (row, part) takes its chunks against the weight row (read from the flat parameters: the
@@ -384,7 +383,7 @@ __global__ __launch_bounds__(1024) void k_sac_entropy(int n, const float *__rest
 // ---------------------------------------------------------------------------------------------------------
 static size_t q_fwd_lds() {
     constexpr int TM = 32 * PRT;
-    const size_t a = (size_t) TM * ALD1, b = (size_t) TM * ALD2;
+    const size_t a = (size_t) TM * ALD1 + EVM_RED_FLOATS, b = (size_t) TM * ALD2;
     return (a > b ? a : b) * sizeof(float);
 }
 static size_t q_bwd_lds() {
