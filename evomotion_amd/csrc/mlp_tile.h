@@ -58,12 +58,16 @@ __device__ __forceinline__ void dense_layer(const float *as, int ald, const floa
     const float *ap = as + aj * ald + ah * KH;
     const float *b0p = Wp + ((size_t) col * 2 + ah) * 4;
     const float *b1p = Wp + ((size_t) (col + 32) * 2 + ah) * 4;
-    // Software pipeline, 4-deep register ring: the operands of block s4 + 3 are requested before the 8 RT MFMAs of
-    // block s4 issue, i.e. ~1500 cycles ahead — more than an L2 hit.  (Left to itself the compiler issued each
-    // block's loads right before its own MFMAs and waited on them: the kernel ran at half speed.)
+    // Software pipeline, DEPTH-deep register ring: the operands of block s + DEPTH - 1 are requested before the 8 RT MFMAs of
+    // block s issue, i.e. (DEPTH - 1) x ~512 cycles ahead — more than an L2 hit under load.  (Left to itself the compiler
+    // issued each block's loads right before its own MFMAs and waited on them: the kernel ran at half speed.)
     constexpr int NB = K / 8;
-    static_assert(NB % 4 == 0, "K must be a multiple of 32");
-    f32x4 a[4][RT], b0[4], b1[4];
+#ifndef EVM_RING
+#define EVM_RING 4
+#endif
+    constexpr int DEPTH = EVM_RING;
+    static_assert(NB % DEPTH == 0, "K / 8 must be a multiple of the ring depth");
+    f32x4 a[DEPTH][RT], b0[DEPTH], b1[DEPTH];
 #define EVM_LOADQ(q, s)                                                                                   \
     {                                                                                                     \
         _Pragma("unroll") for (int i = 0; i < RT; i++) a[q][i] =                                        \
@@ -71,13 +75,14 @@ __device__ __forceinline__ void dense_layer(const float *as, int ald, const floa
         b0[q] = *reinterpret_cast<const f32x4 *>(b0p + (size_t) (s) * 2048);                              \
         b1[q] = *reinterpret_cast<const f32x4 *>(b1p + (size_t) (s) * 2048);                              \
     }
-    EVM_LOADQ(0, 0) EVM_LOADQ(1, 1) EVM_LOADQ(2, 2)
-    __builtin_amdgcn_sched_barrier(0);
-    for (int s4 = 0; s4 < NB; s4 += 4) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int sn = min(s4 + q + 3, NB - 1);  // the last three requests re-read the final block (harmless)
-            EVM_LOADQ((q + 3) & 3, sn)
+    for (int q = 0; q < DEPTH - 1; q++) EVM_LOADQ(q, q)
+    __builtin_amdgcn_sched_barrier(0);
+    for (int s4 = 0; s4 < NB; s4 += DEPTH) {
+#pragma unroll
+        for (int q = 0; q < DEPTH; q++) {
+            const int sn = min(s4 + q + DEPTH - 1, NB - 1);  // the last requests re-read the final block (harmless)
+            EVM_LOADQ((q + DEPTH - 1) % DEPTH, sn)
             __builtin_amdgcn_sched_barrier(0);  // keep the requests ahead of this block's MFMAs
 #pragma unroll
             for (int t = 0; t < 4; t++)
