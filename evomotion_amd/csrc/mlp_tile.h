@@ -103,6 +103,16 @@ __device__ __forceinline__ void dense_layer(const float *as, int ald, const floa
 // barrier then stalls until the wave's stores are acknowledged (~20 k cycles per layer in the training forward).
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Global accesses as (uniform base) + (32-bit byte offset): the form the compiler turns into `global_load/store v, v_off, s[base]`
+// (+ an immediate for small constant steps).  Indexing with size_t, or with an unsigned ELEMENT index (whose * 4 may wrap), makes a
+// 64-bit address pair per access instead: the 64 row addresses of an accumulator-layout tile then cost 128 registers.
+__device__ __forceinline__ float ldg_off(const float *base, unsigned byte_off) {
+    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+__device__ __forceinline__ void stg_off(float *base, unsigned byte_off, float v) {
+    *reinterpret_cast<float *>(reinterpret_cast<char *>(base) + byte_off) = v;
+}
+
 // Sum over the 32 lanes of each half wave, result in every lane: four DPP adds (quad swaps, half-row and row mirrors: no LDS,
 // no wait counters) and one ds_swizzle exchange between the two 16-lane rows of the half.
 __device__ __forceinline__ float half_wave_sum(float v) {
@@ -198,7 +208,7 @@ __device__ __forceinline__ void mish_ln_epilogue(f32x16 (&acc)[2], const float *
     }
     lds_barrier();
 }
-#define EVM_RED_FLOATS 512  // LDS floats of the statistics exchange of mish_ln_epilogue
+#define EVM_RED_FLOATS 512  // LDS floats of the row-statistics exchange: [32 rows][4 waves][2] partials + [4 waves][32 rows][2] results
 
 // The head GEMM [32 x 256] x [256 x 32] on the matrix pipe (as a row-wise dot product loop it was a quarter of the forward
 // kernel): K is split over the four waves, wave w leaves its partial 32 x 32 tile in hs4[w][row][col]; the caller

@@ -133,6 +133,99 @@ __device__ __forceinline__ void block_accumulate(float v, double *dst, float *sh
 }
 
 
+// LayerNorm + Mish backward of a 32-row tile in the MFMA accumulator layout (the counterpart of mish_ln_epilogue, mlp_tile.h):
+//   g[j][r]: in d loss / d a (LayerNorm output), out d loss / d z, for column wave * 64 + 32 j + (lane & 31) and row
+//   (r & 3) + 8 (r >> 2) + 4 (lane >> 5); in: the layer's pre-activations and LayerNorm statistics in the same layout (ln_bwd_load:
+//   half a wave reads 32 consecutive columns of a row).
+//   cs[k][j]: this lane's column sums over its 16 rows of  k = 0: g * xhat (dgamma), 1: g (dbeta), 2: dz (dbias);
+//   the caller adds the two halves of the wave.
+// The two row means of the LayerNorm backward are reduced like the forward statistics: DPP inside the 32-lane halves, the four
+// waves' partial sums through red (EVM_RED_FLOATS of LDS), one LDS-only barrier.
+// operands of ln_mish_backward_c, requested early (the caller puts a GEMM between this and their use): the layer's
+// pre-activations and LayerNorm statistics of the lane's 2 x 16 elements / 16 rows, in the accumulator layout
+struct LnBwdIn {
+    f32x16 z[2];
+    float mean[16], rstd[16];
+};
+template <bool FULL>  // FULL: the tile has all 32 rows (row0 + 32 <= n): no per-row guards
+__device__ __forceinline__ void ln_bwd_load(LnBwdIn &in, const float *__restrict__ zsrc, const float *__restrict__ st, int st_off, int st_stride,
+                                            int wave, int lane, int row0, int n) {
+    const int cl = lane & 31, hf = lane >> 5;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hf;
+        const bool ok = FULL || row0 + row < n;
+        const unsigned gr = (unsigned) (ok ? row0 + row : n - 1);  // byte offsets fit 32 bits: rows * 1 KiB < 4 GiB
+        const unsigned so = (gr * (unsigned) st_stride + (unsigned) st_off) * 4u, zo = (gr * 256u + (unsigned) (wave * 64 + cl)) * 4u;
+        const float m = ldg_off(st, so), rs = ldg_off(st, so + 4u), z0 = ldg_off(zsrc, zo), z1 = ldg_off(zsrc, zo + 128u);
+        in.mean[r] = ok ? m : 0.f;
+        in.rstd[r] = ok ? rs : 0.f;
+        in.z[0][r] = ok ? z0 : 0.f;
+        in.z[1][r] = ok ? z1 : 0.f;
+    }
+}
+__device__ __forceinline__ void ln_mish_backward_c(f32x16 (&g)[2], const LnBwdIn &in, const float *__restrict__ gamma, float *red, int wave,
+                                                   int lane, float (&cs)[3][2]) {
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    const int cl = lane & 31, hf = lane >> 5;
+    const int c0 = wave * 64 + cl, c1 = c0 + 32;
+    const float gam[2] = {gamma[c0], gamma[c1]};
+    f32x16 xh[2], mp[2];
+#pragma unroll
+    for (int k = 0; k < 3; k++) cs[k][0] = cs[k][1] = 0.f;
+    // Registers: g, xhat and Mish' (96) live across the barrier; the row sums go to LDS as soon as they are reduced.
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hf;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const float zz = in.z[j][r];
+            const float nn = __expf(fminf(zz, 20.f));
+            const float mm = nn * (nn + 2.f);
+            const float tt = mm * __builtin_amdgcn_rcpf(mm + 2.f);  // tanh(softplus(z))
+            float mpv = tt + zz * (1.f - tt * tt) * (nn * __builtin_amdgcn_rcpf(1.f + nn));  // Mish'(z) = tanh(sp) + z sigmoid(z) (1 - tanh(sp)^2)
+            float xhv = (zz * tt - in.mean[r]) * in.rstd[r];
+            // pin both here: their only other use is behind the barrier, and the compiler otherwise sinks the whole exp / rcp
+            // chain down there, keeping z, e^z and the statistics of all 32 elements alive instead (440 registers)
+            asm volatile("" : "+v"(mpv), "+v"(xhv));
+            mp[j][r] = mpv;
+            xh[j][r] = xhv;
+            cs[0][j] += g[j][r] * xh[j][r];
+            cs[1][j] += g[j][r];
+            const float gy = g[j][r] * gam[j];
+            g[j][r] = gy;
+            s1 += gy;
+            s2 += gy * xh[j][r];
+        }
+        s1 = half_wave_sum(s1);
+        s2 = half_wave_sum(s2);
+        if (cl == 0) *reinterpret_cast<f32x2_ *>(red + (row * 4 + wave) * 2) = f32x2_{s1, s2};
+    }
+    lds_barrier();
+    float *mine = red + 256 + wave * 64;  // this wave's [32 rows][mean of gy, mean of gy * xhat]
+    {
+        const f32x4 p0 = *reinterpret_cast<const f32x4 *>(red + cl * 8), p1 = *reinterpret_cast<const f32x4 *>(red + cl * 8 + 4);
+        const float m1 = ((p0[0] + p0[2]) + (p1[0] + p1[2])) * (1.f / 256.f), m2 = ((p0[1] + p0[3]) + (p1[1] + p1[3])) * (1.f / 256.f);
+        if (hf == 0) *reinterpret_cast<f32x2_ *>(mine + cl * 2) = f32x2_{m1, m2};
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const f32x4 ma = *reinterpret_cast<const f32x4 *>(mine + (8 * q + 4 * hf) * 2), mb = *reinterpret_cast<const f32x4 *>(mine + (8 * q + 4 * hf) * 2 + 4);
+        const float m1[4] = {ma[0], ma[2], mb[0], mb[2]}, m2[4] = {ma[1], ma[3], mb[1], mb[3]};
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int r = 4 * q + u;
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const float dz = in.rstd[r] * (g[j][r] - m1[u] - xh[j][r] * m2[u]) * mp[j][r];
+                g[j][r] = dz;
+                cs[2][j] += dz;
+            }
+        }
+    }
+}
+
 // thread (row, part): gradient w.r.t. the layer's pre-activation z from the gradient w.r.t. its LayerNorm output.
 //   g[i]: in d loss / d a (LayerNorm output) of the thread's run, out d loss / d z; Tz: the z tile, left holding
 //   da * xhat (the terms of dgamma).

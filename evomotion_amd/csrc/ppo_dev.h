@@ -13,6 +13,7 @@ struct PpoNet {
     float *theta, *grad, *m, *v;  // [n_params]
     size_t n_params;
     float *w2d;                   // Linear(256,256) weight packed for the dgrad GEMM: B[k = out j][col = in i]
+    float *whd;                   // head weights packed for their dgrad GEMM: B[k = head output o < 32][col = in i]
     float *z1, *a1, *z2, *a2;     // pre-Mish and post-LayerNorm activations of the two hidden layers
     float *st;                    // [rows][4]: LayerNorm mean, rstd of layer 1, of layer 2
     float *head;                  // actor: [rows][2A] = mu, sigma (after tanh / softplus); critic: [rows] values
@@ -40,7 +41,7 @@ constexpr int PPO_SK = 64;       // split-K chunks of the weight-gradient GEMMs
 constexpr int PPO_NORM_PARTS = 32;
 constexpr int PPO_COLSLOTS = 7;  // dgamma2, dbeta2, dbias2, dgamma1, dbeta1, dbias1, dbias_heads
 
-hipError_t launch_ppo_pack_w2d(const PpoNet &n, int S, hipStream_t s);
+hipError_t launch_ppo_pack_w2d(const PpoNet &n, int S, int A, bool actor, hipStream_t s);  // w2d and whd
 hipError_t launch_ppo_pad(const PpoDev &d, size_t rows, const float *states, hipStream_t s);
 hipError_t launch_ppo_forward(const PolicyDev &p, const PpoDev &d, size_t rows, const float *states, hipStream_t s, int nets = 2);
 hipError_t launch_actor_head_grad(const PpoDev &d, size_t rows, const float *dmu, const float *dsigma, hipStream_t s);

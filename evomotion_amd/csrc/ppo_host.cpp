@@ -56,6 +56,7 @@ int evm_ppo_create(EvmPolicy *policy, size_t max_rows, EvmPpo **out) {
         n.theta = (float *) alloc(np * 4); n.grad = (float *) alloc(np * 4);
         n.m = (float *) alloc(np * 4); n.v = (float *) alloc(np * 4);
         n.w2d = (float *) alloc(65536 * 4);
+        n.whd = (float *) alloc(8192 * 4);
         n.z1 = (float *) alloc(max_rows * 256 * 4); n.a1 = (float *) alloc(max_rows * 256 * 4);
         n.z2 = (float *) alloc(max_rows * 256 * 4); n.a2 = (float *) alloc(max_rows * 256 * 4);
         n.st = (float *) alloc(max_rows * 4 * 4);
@@ -108,8 +109,8 @@ int evm_ppo_set_params(EvmPpo *q, const float *d_actor, const float *d_critic, i
     }
     if (e == hipSuccess) e = evm::launch_policy_pack(q->policy->dev.actor, d.S, d.A, true, d.actor.theta, s);
     if (e == hipSuccess) e = evm::launch_policy_pack(q->policy->dev.critic, d.S, d.A, false, d.critic.theta, s);
-    if (e == hipSuccess) e = evm::launch_ppo_pack_w2d(d.actor, d.S, s);
-    if (e == hipSuccess) e = evm::launch_ppo_pack_w2d(d.critic, d.S, s);
+    if (e == hipSuccess) e = evm::launch_ppo_pack_w2d(d.actor, d.S, d.A, true, s);
+    if (e == hipSuccess) e = evm::launch_ppo_pack_w2d(d.critic, d.S, d.A, false, s);
     if (e != hipSuccess) return qfail(EVM_E_HIP, std::string("ppo set_params: ") + hipGetErrorString(e));
     q->have_params = true;
     return EVM_OK;

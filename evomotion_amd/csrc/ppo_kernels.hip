@@ -201,93 +201,87 @@ __global__ __launch_bounds__(256) void k_ppo_loss_critic(PpoDev d, int n, const 
 // ---------------------------------------------------------------------------------------------------------
 // backward through heads, LayerNorm, Mish and the second Linear for one 32-row tile
 // ---------------------------------------------------------------------------------------------------------
-template <int RT>
-__global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_ppo_backward(PolicyDev p, PpoDev d, int n) {
-    constexpr int TM = 32 * RT, PARTS = PT / TM, RUN = 256 / PARTS;
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    float *Tz = sm;             // z tile, then scratch for the column sums
-    float *Td = sm + TM * ALD2; // gradient tile (A operand of the dgrad GEMM); first life: head weights + dh tile
-    float *wl = Td, *dhs = Td + 32 * 256;
+// Everything stays in the MFMA accumulator layout (wave: 32 rows x 64 columns, half a wave = 32 consecutive columns of a row):
+//   d a2 = dh * W_heads           K = 32 GEMM on the matrix pipe (A: the dh tile, B: whd)
+//   d z2 = LayerNorm' Mish' (d a2) ln_mish_backward_c, z2 read from HBM in that layout; -> HBM and the k-split tile Td
+//   d a1 = d z2 * W2              K = 256 GEMM (B: w2d)
+//   d z1 = LayerNorm' Mish' (d a1) -> HBM
+// and the per-tile column sums (LayerNorm / bias gradients) are sums over a lane's 16 registers plus the other half of the
+// wave.  Three LDS-only barriers.  (The row-wise form this replaces moved every tile through LDS three times behind twelve
+// full barriers: 0.64 ms per launch at 131 072 rows, 36 % of what the matrix pipe alone needs.)
+#define BWD_DH_LD 36  // k-split dh tile: 2 x 16 + 4
+template <bool FULL>
+__device__ __forceinline__ void ppo_backward_tile(const PolicyDev &p, const PpoDev &d, int n, float *sm) {
+    constexpr int TM = 32, RT = 1;
+    float *Td = sm;                    // d z2, k-split: the A operand of the dgrad GEMM
+    float *dhs = sm + TM * ALD2;       // dh tile, k-split over the 32 head outputs
+    float *red = dhs + TM * BWD_DH_LD; // row-mean exchange of ln_mish_backward_c
     const int net = blockIdx.y;
     const int row0 = blockIdx.x * TM;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int t = threadIdx.x, row = t / PARTS, part = t % PARTS;
-    const int gr = row0 + row;
+    const int cl = lane & 31, hf = lane >> 5;
+    const int t = threadIdx.x;
     const NetDev &N = net == 0 ? p.actor : p.critic;
     const PpoNet &B = net == 0 ? d.actor : d.critic;
     const int nout = net == 1 ? 1 : 2 * p.A;
-    float colacc[PPO_COLSLOTS];
-#pragma unroll
-    for (int k = 0; k < PPO_COLSLOTS; k++) colacc[k] = 0.f;
+    float *cp = B.colpart + (size_t) blockIdx.x * PPO_COLSLOTS * 256;
 
-    for (int e = threadIdx.x; e < nout * 256; e += PT) {
-        const int c = e & 255;
-        wl[(e & ~255) + (c & 1) * 128 + (c >> 1)] = N.wh[e];
-    }
     for (int e = threadIdx.x; e < TM * 32; e += PT) {
         const int r = e >> 5, o = e & 31;
-        dhs[e] = (row0 + r < n && o < nout) ? B.dh[(size_t) (row0 + r) * 32 + o] : 0.f;
+        dhs[r * BWD_DH_LD + (o & 1) * 16 + (o >> 1)] = ((FULL || row0 + r < n) && o < nout) ? B.dh[(size_t) (row0 + r) * 32 + o] : 0.f;
     }
-    tile_load<TM>(Tz, B.z2, row0, n);
-    __syncthreads();
+    LnBwdIn in;
+    ln_bwd_load<FULL>(in, B.z2, B.st, 2, 4, wave, lane, row0, n);  // in flight across the head GEMM
+    lds_barrier();
     if (t < 32) {  // head bias gradient: column sums of the dh tile
         float s = 0.f;
-        for (int r = 0; r < TM; r++) s += dhs[r * 32 + t];
-        colacc[6] = s;
+        for (int r = 0; r < TM; r++) s += dhs[r * BWD_DH_LD + (t & 1) * 16 + (t >> 1)];
+        cp[6 * 256 + t] = s;
     }
-    float da[RUN];
-    {   // d a2 = dh * W_heads
-#pragma unroll
-        for (int i = 0; i < RUN; i++) da[i] = 0.f;
-        for (int o = 0; o < nout; o++) {
-            const float g = dhs[row * 32 + o];
-            const f32x4 *wr = reinterpret_cast<const f32x4 *>(wl + o * 256);
-#pragma unroll
-            for (int i = 0; i < RUN / 4; i++) {
-                const f32x4 w = wr[CHUNK(i, part, PARTS)];
-#pragma unroll
-                for (int u = 0; u < 4; u++) da[4 * i + u] += g * w[u];
-            }
-        }
-    }
-    const float mean2 = gr < n ? B.st[(size_t) gr * 4 + 2] : 0.f, rstd2 = gr < n ? B.st[(size_t) gr * 4 + 3] : 0.f;
-    __syncthreads();  // everyone is done with wl / dhs: Td may be overwritten
-#pragma unroll
-    for (int i = 0; i < RUN; i++) Td[row * ALD2 + 4 * CHUNK(i >> 2, part, PARTS) + (i & 3)] = da[i];
-    ln_mish_backward<RUN, PARTS>(da, Tz, row, part, mean2, rstd2, N.g2);  // da <- dz2
-    __syncthreads();
-    colacc[0] = tile_colsum<TM>(Tz);  // dgamma2 = sum da * xhat
-    colacc[1] = tile_colsum<TM>(Td);  // dbeta2 = sum da
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < RUN; i++) Td[row * ALD2 + 4 * CHUNK(i >> 2, part, PARTS) + (i & 3)] = da[i];
-    tile_load<TM>(Tz, B.z1, row0, n);  // Tz is free again: the layer-1 pre-activations
-    __syncthreads();
-    colacc[2] = tile_colsum<TM>(Td);  // dbias2 = sum dz2
-    tile_store<TM>(Td, B.dz2, row0, n);
-    // d a1 = dz2 * W2  (B operand: the dgrad packing of W2)
     f32x16 acc[RT][2];
-    dense_layer<256, RT>(Td, ALD2, B.w2d, wave, lane, acc);
-    __syncthreads();
-    acc_to_tile<RT>(acc, nullptr, Td, wave, lane);
-    __syncthreads();
+    dense_layer<32, RT>(dhs, BWD_DH_LD, B.whd, wave, lane, acc);  // d a2
+    float cs[3][2];
+    auto put_colsums = [&](int slot0) {
 #pragma unroll
-    for (int i = 0; i < RUN; i++) da[i] = Td[row * ALD2 + 4 * CHUNK(i >> 2, part, PARTS) + (i & 3)];
-    const float mean1 = gr < n ? B.st[(size_t) gr * 4] : 0.f, rstd1 = gr < n ? B.st[(size_t) gr * 4 + 1] : 0.f;
-    ln_mish_backward<RUN, PARTS>(da, Tz, row, part, mean1, rstd1, N.g1);  // da <- dz1
-    __syncthreads();
-    colacc[3] = tile_colsum<TM>(Tz);
-    colacc[4] = tile_colsum<TM>(Td);
-    __syncthreads();
+        for (int k = 0; k < 3; k++)
 #pragma unroll
-    for (int i = 0; i < RUN; i++) Td[row * ALD2 + 4 * CHUNK(i >> 2, part, PARTS) + (i & 3)] = da[i];
-    __syncthreads();
-    colacc[5] = tile_colsum<TM>(Td);
-    tile_store<TM>(Td, B.dz1, row0, n);
-    float *cp = B.colpart + (size_t) blockIdx.x * PPO_COLSLOTS * 256;
+            for (int j = 0; j < 2; j++) {
+                const float v = cs[k][j] + __shfl_xor(cs[k][j], 32);
+                if (hf == 0) cp[(slot0 + k) * 256 + wave * 64 + 32 * j + cl] = v;
+            }
+    };
+    // stores of a gradient tile in the accumulator layout, 32-bit offsets from the uniform base
+    auto put_rows = [&](float *dst, int r, float v0, float v1) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hf;
+        if (FULL || row0 + row < n) {
+            const unsigned o = ((unsigned) (row0 + row) * 256u + (unsigned) (wave * 64 + cl)) * 4u;
+            stg_off(dst, o, v0);
+            stg_off(dst, o + 128u, v1);
+        }
+    };
+    ln_mish_backward_c(acc[0], in, N.g2, red, wave, lane, cs);  // acc <- d z2
+    put_colsums(0);  // dgamma2, dbeta2, dbias2
+    ln_bwd_load<FULL>(in, B.z1, B.st, 0, 4, wave, lane, row0, n);  // in flight across the dgrad GEMM
 #pragma unroll
-    for (int k = 0; k < PPO_COLSLOTS - 1; k++) cp[k * 256 + QCOL(t)] = colacc[k];  // tile_colsum: thread t holds column QCOL(t)
-    cp[6 * 256 + t] = colacc[6];
+    for (int r = 0; r < 16; r++) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hf;
+        Td[HIDX(row, wave * 64 + cl)] = acc[0][0][r];
+        Td[HIDX(row, wave * 64 + 32 + cl)] = acc[0][1][r];
+        put_rows(B.dz2, r, acc[0][0][r], acc[0][1][r]);
+    }
+    lds_barrier();
+    dense_layer<256, RT>(Td, ALD2, B.w2d, wave, lane, acc);  // d a1 = d z2 * W2
+    ln_mish_backward_c(acc[0], in, N.g1, red, wave, lane, cs);  // acc <- d z1
+    put_colsums(3);  // dgamma1, dbeta1, dbias1
+#pragma unroll
+    for (int r = 0; r < 16; r++) put_rows(B.dz1, r, acc[0][0][r], acc[0][1][r]);
+}
+template <int RT>
+__global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_ppo_backward(PolicyDev p, PpoDev d, int n) {
+    static_assert(RT == 1, "one 32-row MFMA tile per wave");
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    if ((int) blockIdx.x * 32 + 32 <= n) ppo_backward_tile<true>(p, d, n, sm);
+    else ppo_backward_tile<false>(p, d, n, sm);  // the ragged last tile
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -556,7 +550,7 @@ hipError_t launch_actor_apply(const PolicyDev &p, const PpoDev &d, float lr, hip
     hipLaunchKernelGGL(k_actor_adam_dev, dim3((unsigned) ((d.actor.n_params + 255) / 256)), dim3(256), 0, s, d, lr);
     hipLaunchKernelGGL(k_actor_step_inc, dim3(1), dim3(64), 0, s, d);
     hipError_t e = launch_policy_pack(p.actor, p.S, p.A, true, d.actor.theta, s);
-    if (e == hipSuccess) e = launch_ppo_pack_w2d(d.actor, p.S, s);
+    if (e == hipSuccess) e = launch_ppo_pack_w2d(d.actor, p.S, p.A, true, s);
     return e;
 }
 
@@ -645,16 +639,26 @@ static size_t fwd_lds_bytes() {
     const size_t a = (size_t) TM * ALD1 + EVM_RED_FLOATS, b = (size_t) TM * ALD2 + 4 * 32 * 32;
     return (a > b ? a : b) * sizeof(float);
 }
-static size_t bwd_lds_bytes() {
-    constexpr int TM = 32 * PRT;
-    const size_t td = (size_t) TM * ALD2 > (size_t) 32 * 256 + TM * 32 ? (size_t) TM * ALD2 : (size_t) 32 * 256 + TM * 32;
-    return ((size_t) TM * ALD2 + td) * sizeof(float);
-}
+static size_t bwd_lds_bytes() { return ((size_t) 32 * ALD2 + 32 * BWD_DH_LD + EVM_RED_FLOATS) * sizeof(float); }
 size_t ppo_wpart_floats() { return (size_t) 128 * 256 * 256 > (size_t) 86 * 256 * 384 ? (size_t) 128 * 256 * 256 : (size_t) 86 * 256 * 384; }
 
-hipError_t launch_ppo_pack_w2d(const PpoNet &n, int S, hipStream_t s) {
+// head weights -> the B operand of the heads' dgrad GEMM: B[k = head output o][col = i], K padded to 32 with zero rows.
+// Actor: o < A is mu.0.weight row o, A <= o < 2A is sigma.0.weight row o - A (each followed by its bias in theta); critic: one row.
+__global__ __launch_bounds__(256) void k_ppo_pack_whd(const float *__restrict__ heads, int A, int actor, float *__restrict__ whd) {
+    const int e = blockIdx.x * 256 + threadIdx.x;  // e = o * 256 + i, o < 32
+    const int k = e >> 8, col = e & 255;
+    float v = 0.f;
+    if (actor) {
+        if (k < A) v = heads[(size_t) k * 256 + col];
+        else if (k < 2 * A) v = heads[(size_t) A * 256 + A + (size_t) (k - A) * 256 + col];
+    } else if (k == 0) v = heads[col];
+    const int st = k >> 1, h = k & 1, s4 = st >> 2, tt = st & 3;
+    whd[(((size_t) s4 * 256 + col) * 2 + h) * 4 + tt] = v;
+}
+hipError_t launch_ppo_pack_w2d(const PpoNet &n, int S, int A, bool actor, hipStream_t s) {
     const float *w2 = n.theta + (size_t) 256 * S + 3 * 256;
     hipLaunchKernelGGL(k_ppo_pack_w2d, dim3(256), dim3(256), 0, s, w2, n.w2d);
+    hipLaunchKernelGGL(k_ppo_pack_whd, dim3(32), dim3(256), 0, s, w2 + 65536 + 3 * 256, A, actor ? 1 : 0, n.whd);
     return hipGetLastError();
 }
 
@@ -789,8 +793,8 @@ hipError_t launch_ppo_apply(const PolicyDev &p, PpoDev &d, float lr, float clip_
                        bc2s(d.actor.step), bc1(d.critic.step), bc2s(d.critic.step));
     hipError_t e = launch_policy_pack(p.actor, p.S, p.A, true, d.actor.theta, s);
     if (e == hipSuccess) e = launch_policy_pack(p.critic, p.S, p.A, false, d.critic.theta, s);
-    if (e == hipSuccess) e = launch_ppo_pack_w2d(d.actor, p.S, s);
-    if (e == hipSuccess) e = launch_ppo_pack_w2d(d.critic, p.S, s);
+    if (e == hipSuccess) e = launch_ppo_pack_w2d(d.actor, p.S, p.A, true, s);
+    if (e == hipSuccess) e = launch_ppo_pack_w2d(d.critic, p.S, p.A, false, s);
     return e;
 }
 
