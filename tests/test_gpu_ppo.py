@@ -22,12 +22,12 @@ def gold():
     return golden_io.load()
 
 
-def _modules(seed=0, pattern=False):
+def _modules(seed=0, pattern=False, S=371, A=12):
     import torch
     from evomotion_amd import agent
     torch.manual_seed(seed)
-    actor = agent.ActorModule([371], [12], 256).cuda()
-    critic = agent.CriticModule([371], 256).cuda()
+    actor = agent.ActorModule([S], [A], 256).cuda()
+    critic = agent.CriticModule([S], 256).cuda()
     if pattern:
         for mod, shapes, base in ((actor, ao.ACTOR_SHAPES, 100), (critic, ao.CRITIC_SHAPES, 200)):
             p = ao.pattern_params(shapes, base)
@@ -59,10 +59,10 @@ def _rollout(T, N, seed=1, p_invalid=0.2, p_done=0.1):
     return states, actions, rewards, done, values, next_values, mask
 
 
-def _trainer(actor, critic, max_rows):
+def _trainer(actor, critic, max_rows, S=371, A=12):
     from evomotion_amd import FusedActorCritic
     from evomotion_amd.ppo import FusedPpoTrainer
-    f = FusedActorCritic(371, 12, 256, 0)
+    f = FusedActorCritic(S, A, 256, 0)
     tr = FusedPpoTrainer(f, max_rows)
     tr.set_modules(actor, critic)
     return f, tr
@@ -108,20 +108,22 @@ def _torch_grads(actor, critic, states, actions, logp_old, adv, returns, mask, n
     return flat(actor), flat(critic), float(a_loss), float(c_loss)
 
 
-@pytest.mark.parametrize("rows", [1000, 28, 4096])
-def test_gradients_match_autograd(rows):
+# (rows, state size, action size): the robot_walk sizes on full, ragged and single tiles; a generic skeleton's sizes (odd input
+# width, head GEMM with 10 of 32 columns, a ragged tile; 16 actions fill the 32 head columns)
+@pytest.mark.parametrize("rows,S,A", [(1000, 371, 12), (28, 371, 12), (4096, 371, 12), (77, 101, 5), (160, 64, 16)])
+def test_gradients_match_autograd(rows, S, A):
     import torch
     from evomotion_amd import agent
     from evomotion_amd.ppo import GRADS, ACTOR, CRITIC
-    actor, critic = _modules(seed=3)
-    f, tr = _trainer(actor, critic, rows)
+    actor, critic = _modules(seed=3, S=S, A=A)
+    f, tr = _trainer(actor, critic, rows, S=S, A=A)
     g = torch.Generator(device="cuda"); g.manual_seed(5)
-    states = (torch.rand(rows, 371, device="cuda", generator=g) * 2 - 1) * 1.5
+    states = (torch.rand(rows, S, device="cuda", generator=g) * 2 - 1) * 1.5
     with torch.no_grad():
         mu, sigma = actor(states)
-        actions = agent.truncated_normal_sample(mu, sigma, u=torch.rand(rows, 12, device="cuda", generator=g))
+        actions = agent.truncated_normal_sample(mu, sigma, u=torch.rand(rows, A, device="cuda", generator=g))
         # old log-probabilities around the current ones: ratios on both sides of the clip range
-        logp_old = agent.truncated_normal_log_pdf(actions, mu, sigma) + 0.3 * (torch.rand(rows, 12, device="cuda", generator=g) * 2 - 1)
+        logp_old = agent.truncated_normal_log_pdf(actions, mu, sigma) + 0.3 * (torch.rand(rows, A, device="cuda", generator=g) * 2 - 1)
     adv = torch.randn(rows, device="cuda", generator=g)
     returns = torch.randn(rows, device="cuda", generator=g)
     mask = (torch.rand(rows, device="cuda", generator=g) > 0.25).to(torch.uint8)
