@@ -111,6 +111,45 @@ def cpu_baseline(seconds=12.0):
     return out
 
 
+def pose_parity(device, n_oracles=8, steps=48):
+    """Second half of BASELINE.json's metric: per-step pose L2 of the HIP path against the CPU restatement (oracle/; Bullet3 is
+    not installed, so this is parity with the restatement, not with Bullet).  Teacher-forced: every step both sides start from
+    the restatement's state, take the same action, and the body poses [41][pos xyz, quat xyzw] are compared.  Part of the
+    cpu_baseline leg (rank 0, N = 1), outside every timed region."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc
+    from evomotion_amd import VecRobotWalk
+    L = orc.load()
+    env = VecRobotWalk(64, seed=4321, device=device)
+    env.reset()
+    oracles = [orc.OracleEnv(seed=4321 + i, lib=L) for i in range(n_oracles)]
+    for o in oracles:
+        o.reset()
+    rng = np.random.default_rng(7)
+    pos_l2, quat_l2 = [], []
+    for k in range(steps):
+        blob = env.get_state()
+        for i, o in enumerate(oracles):  # the restatement free-runs, the HIP path starts every step from its state
+            blob[i] = o.get_state()
+        env.set_state(blob)
+        act = rng.uniform(-1, 1, (64, env.action_dim)).astype(np.float32)
+        env.do_step(torch.from_numpy(act))
+        poses = env.body_poses().cpu().numpy()
+        for i, o in enumerate(oracles):
+            _, _, done = o.do_step(act[i])
+            d = poses[i] - o.poses()
+            pos_l2.append(float(np.sqrt((d[:, :3] ** 2).sum())))
+            quat_l2.append(float(np.sqrt((d[:, 3:] ** 2).sum())))
+            if done:
+                o.reset()
+    env.close()
+    return {"pose_l2_mean": float(np.mean(pos_l2)), "pose_l2_max": float(np.max(pos_l2)), "unit": "m (L2 over the 41 body positions, per env step)",
+            "quat_l2_max": float(np.max(quat_l2)), "env_steps": len(pos_l2),
+            "against": "CPU restatement (oracle/), one step from identical state (teacher-forced); Bullet3 absent: physics parity unpinned"}
+
+
 def launch_ranks(n_ranks, argv, worker=None, timeout=None):
     """`bench.py --gpus N` without a torchrun environment: start N fresh rank processes (RANK / LOCAL_RANK / WORLD_SIZE /
     MASTER_ADDR / MASTER_PORT set, as torch.distributed.run would) and relay rank 0's JSON line.  The parent never
@@ -424,6 +463,10 @@ def main():
                                           "note": "HIP events around evm_ppo_grads .. evm_ppo_apply; fp32-input MFMA, dense fp32 matrix peak"}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
+            try:
+                out["pose_parity"] = pose_parity(local_rank)
+            except Exception as e:  # reported, never fatal for the throughput line
+                out["pose_parity"] = {"error": repr(e)}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
