@@ -310,3 +310,125 @@ def check_motor_saturates_at_max_force(w, steps=30, mass=1000.0, sphere_mass=0.1
     assert abs(rel - pred) < 0.02 * pred, (rel, pred)
     assert abs((b[0, 7] + b[1, 7]) * mass + (b[2, 7] + b[3, 7]) * sphere_mass) < 1e-3 * mass * pred   # no net momentum
     return rel, pred
+
+
+# ---- second batch: welded pair, hinge limit, impact, static friction -----------------------------------------------------------
+def skel_welded_pair(write_skeleton, tmp_path):
+    """two unequal boxes joined by ONE fixed constraint whose frame sits between them"""
+    members = [dict(name="body", mass=2.0, scale=(0.2, 0.1, 0.15)),
+               dict(name="other", mass=0.5, t=(0.6, 0.0, 0.0), scale=(0.1, 0.1, 0.1))]
+    cons = [dict(type="fixed", name="f", parent="body", child="other", tp=(0.3, 0.0, 0.0), tc=(-0.3, 0.0, 0.0))]
+    return write_skeleton(tmp_path / "welded.skel", members, cons)
+
+
+def check_welded_pair_moves_as_one_body(w, steps=240):
+    """a fixed constraint transmits only internal forces: the pair's total linear momentum follows free fall exactly (Newton's
+    third law row by row), the relative pose of the two boxes stays what the constraint frames say, and the spin is shared"""
+    c = w.body_constants()
+    m = c[:2, 0].astype(np.float64)
+    v0 = np.array([0.4, 0.0, -0.2])
+    w0 = np.array([0.0, 1.5, 0.8])
+    pos = np.array([[0.0, 3000.0, 0.0], [0.6, 3000.0, 0.0]])
+    com = (m[:, None] * pos).sum(0) / m.sum()
+    lin = [v0 + np.cross(w0, p - com) for p in pos]          # rigid rotation about the common centre of mass
+    clean_state(w, pos, lin=lin, ang=[w0, w0])
+    p0 = (m[:, None] * np.array(lin)).sum(0)
+    w.step(steps)
+    b = bodies(w)
+    assert np.isfinite(b).all()
+    p1 = (m[:, None] * b[:2, 7:10]).sum(0)
+    assert abs(p1[0] - p0[0]) < 2e-5 * m.sum() and abs(p1[2] - p0[2]) < 2e-5 * m.sum()       # no external horizontal force
+    assert abs(p1[1] - (p0[1] - m.sum() * G * DT * steps)) < 2e-3 * m.sum() * G * DT * steps   # gravity only (fp32 accumulation)
+    # relative pose: child's frame origin seen from the parent
+    Rp = rot(b[0, 3:7])
+    rel = Rp.T @ (b[1, 0:3] - b[0, 0:3])
+    assert np.abs(rel - np.array([0.6, 0.0, 0.0])).max() < 2e-3, rel
+    Rrel = Rp.T @ rot(b[1, 3:7])
+    angle = 0.5 * math.sqrt((Rrel[2, 1] - Rrel[1, 2]) ** 2 + (Rrel[0, 2] - Rrel[2, 0]) ** 2 + (Rrel[1, 0] - Rrel[0, 1]) ** 2)  # sin(angle)
+    assert angle < 5e-3, angle
+    assert np.abs(b[0, 10:13] - b[1, 10:13]).max() < 2e-2                                      # one angular velocity
+    return float(np.abs(rel - np.array([0.6, 0.0, 0.0])).max()), angle
+
+
+def skel_limited_pendulum(write_skeleton, tmp_path, lim=0.3):
+    base_h = 1.0
+    base_y = FLOOR_TOP + 2 * MARGIN + base_h
+    members = [dict(name="body", mass=2000.0, scale=(1.0, base_h, 1.0)),
+               dict(name="bob", mass=0.5, t=(PEND_PIVOT_LOCAL[0], PEND_PIVOT_LOCAL[1] - PEND_L, 0.0), scale=(0.05, 0.05, 0.05))]
+    cons = [dict(type="hinge", name="h", parent="body", child="bob", pivot_p=PEND_PIVOT_LOCAL, pivot_c=(0.0, PEND_L, 0.0),
+                 axis_p=(0, 0, 1), axis_c=(0, 0, 1), lo=-lim, hi=lim)]
+    return write_skeleton(tmp_path / "pendulum_limited.skel", members, cons), base_y
+
+
+def check_hinge_limit_holds(w, base_y, lim=0.3):
+    """a pendulum thrown at its hinge limit: the swing angle never passes the limit by more than the velocity-level row's
+    one-step overshoot, and the bob stays on its circle"""
+    base = np.array([0.0, base_y, 0.0])
+    pivot = base + np.array(PEND_PIVOT_LOCAL)
+    bob = pivot + np.array([0.0, -PEND_L, 0.0])
+    omega = 3.0                                   # rad/s about z: would reach ~0.7 rad without the limit
+    clean_state(w, [base, bob], lin=[[0, 0, 0], [omega * PEND_L, 0.0, 0.0]], ang=[[0, 0, 0], [0.0, 0.0, omega]])
+    worst, reached = 0.0, False
+    for _ in range(240):
+        w.step()
+        b = bodies(w)
+        d = b[1, 0:3] - (b[0, 0:3] + rot(b[0, 3:7]) @ np.array(PEND_PIVOT_LOCAL))
+        ang = math.atan2(d[0], -d[1])
+        worst = max(worst, abs(ang))
+        reached = reached or abs(ang) > 0.9 * lim
+        assert abs(np.linalg.norm(d) - PEND_L) < 1e-2
+    assert reached                                 # it did run into the limit
+    assert worst < lim + omega * DT + 0.02, worst  # at most one step's travel (+ the limit's softness) beyond it
+    return worst
+
+
+def check_impact_does_not_bounce(w, half=0.2):
+    """restitution is zero on both sides: whatever the impact speed (3.1 and 6.3 m/s here), the only upward velocity a landing
+    box ever gets is the solver's position correction of a shallow penetration, erp x depth / dt with erp = 0.2 and depth below
+    the 0.04 m split-impulse threshold (deeper penetrations are pushed out without touching the velocity): under 0.48 m/s,
+    not proportional to the impact; and the box ends at its resting height"""
+    rest = FLOOR_TOP + 2 * MARGIN + half
+    bound = 0.2 * 0.04 / DT + 0.02
+    out = []
+    for drop in (0.5, 2.0):
+        clean_state(w, [[0.0, rest + drop, 0.0]])
+        low, up, hit = 1e9, 0.0, False
+        for k in range(200):
+            w.step()
+            b = bodies(w)
+            if int(manifold_counts(w)[0]) > 0:
+                hit = True
+            if hit:
+                up = max(up, b[0, 8])
+                low = min(low, b[0, 1])
+        assert hit
+        assert up < bound, (drop, up, bound)
+        assert low > rest - 0.12, (low, rest)          # one step of travel at the impact speed, at most
+        b = bodies(w)
+        assert abs(b[0, 1] - rest) < 8e-3 and np.abs(b[0, 7:10]).max() < 3e-2
+        out.append((math.sqrt(2 * G * drop), up, low - rest))
+    return out
+
+
+def check_static_friction_holds(w, half_y=0.1):
+    """inside the Coulomb cone the friction rows cancel a small sideways velocity completely in ONE step: a resting box
+    kicked with less than mu g dt stays where it is"""
+    mu = 0.25
+    rest = FLOOR_TOP + 2 * MARGIN + half_y
+    clean_state(w, [[0.0, rest, 0.0]])
+    w.step(120)
+    assert int(manifold_counts(w)[0]) == 4
+    s = w.state().copy()
+    f = fields(w)
+    b = s[f["bodies"]].reshape(w.nb, 13)
+    x0 = float(b[0, 0])
+    kick = 0.5 * mu * G * DT
+    b[0, 7] = kick
+    w.set_state(s)
+    w.step()
+    b1 = bodies(w)
+    assert abs(b1[0, 7]) < 0.05 * kick, (b1[0, 7], kick)
+    w.step(30)
+    b2 = bodies(w)
+    assert abs(b2[0, 0] - x0) < 2 * kick * DT + 1e-4 and abs(b2[0, 7]) < 0.05 * kick
+    return float(b1[0, 7]), kick

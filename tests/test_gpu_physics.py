@@ -48,3 +48,25 @@ def test_known_answer_slider_motor_saturates_at_64_newton(tmp_path):
     skel = pc.skel_two_masses(write_skeleton, tmp_path, mass=1000.0, force=64.0, name="motor_sat.skel")
     rel, pred = pc.check_motor_saturates_at_max_force(pc.HipWorld(skel))
     print("relative velocity %.5f m/s, predicted %.5f m/s" % (rel, pred))
+
+
+def test_known_answer_welded_pair_moves_as_one_body(tmp_path):
+    drift, angle = pc.check_welded_pair_moves_as_one_body(pc.HipWorld(pc.skel_welded_pair(write_skeleton, tmp_path)))
+    print("fixed constraint after 240 steps: relative position drift %.2e m, relative rotation %.2e rad" % (drift, angle))
+
+
+def test_known_answer_hinge_limit_holds(tmp_path):
+    skel, base_y = pc.skel_limited_pendulum(write_skeleton, tmp_path)
+    worst = pc.check_hinge_limit_holds(pc.HipWorld(skel), base_y)
+    print("largest swing angle %.4f rad against a 0.3 rad limit" % worst)
+
+
+def test_known_answer_impact_does_not_bounce(tmp_path):
+    res = pc.check_impact_does_not_bounce(pc.HipWorld(pc.skel_cube(write_skeleton, tmp_path)))
+    for v, up, low in res:
+        print("impact at %.2f m/s: largest upward velocity afterwards %.4f m/s, deepest point %.4f m below rest" % (v, up, -low))
+
+
+def test_known_answer_static_friction_holds(tmp_path):
+    left, kick = pc.check_static_friction_holds(pc.HipWorld(pc.skel_cube(write_skeleton, tmp_path, scale=(0.5, 0.1, 0.5))))
+    print("sideways velocity one step after a %.5f m/s kick: %.2e m/s" % (kick, left))

@@ -188,6 +188,28 @@ def test_known_answer_slider_motor_saturates_at_64_newton(orc_lib, tmp_path):
     print("relative velocity %.5f m/s, predicted %.5f m/s" % (rel, pred))
 
 
+def test_known_answer_welded_pair_moves_as_one_body(orc_lib, tmp_path):
+    drift, angle = pc.check_welded_pair_moves_as_one_body(_world(pc.skel_welded_pair(write_skeleton, tmp_path), orc_lib))
+    print("fixed constraint after 240 steps: relative position drift %.2e m, relative rotation %.2e rad" % (drift, angle))
+
+
+def test_known_answer_hinge_limit_holds(orc_lib, tmp_path):
+    skel, base_y = pc.skel_limited_pendulum(write_skeleton, tmp_path)
+    worst = pc.check_hinge_limit_holds(_world(skel, orc_lib), base_y)
+    print("largest swing angle %.4f rad against a 0.3 rad limit" % worst)
+
+
+def test_known_answer_impact_does_not_bounce(orc_lib, tmp_path):
+    res = pc.check_impact_does_not_bounce(_world(pc.skel_cube(write_skeleton, tmp_path), orc_lib))
+    for v, up, low in res:
+        print("impact at %.2f m/s: largest upward velocity afterwards %.4f m/s, deepest point %.4f m below rest" % (v, up, -low))
+
+
+def test_known_answer_static_friction_holds(orc_lib, tmp_path):
+    left, kick = pc.check_static_friction_holds(_world(pc.skel_cube(write_skeleton, tmp_path, scale=(0.5, 0.1, 0.5)), orc_lib))
+    print("sideways velocity one step after a %.5f m/s kick: %.2e m/s" % (kick, left))
+
+
 def test_self_collision_rate_diagnostic(orc_lib):
     """tools/self_collision_rate.py (oracle side): the measurement behind DESIGN.md's statement of the plane-contact deviation —
     how often non-adjacent member pairs come within Bullet's collision margins.  Here only that the diagnostic runs and is
