@@ -432,3 +432,50 @@ def check_static_friction_holds(w, half_y=0.1):
     b2 = bodies(w)
     assert abs(b2[0, 0] - x0) < 2 * kick * DT + 1e-4 and abs(b2[0, 7]) < 0.05 * kick
     return float(b1[0, 7]), kick
+
+
+def check_slider_limits(w, steps=40):
+    """the muscle's slider runs between 0 and twice the initial distance of its attach points (muscle.cpp:43-49): a
+    force-unlimited motor driven at +8 m/s ends at 2 m, driven back at -8 m/s ends at 0, and never passes either limit — the
+    motor's target speed is cut to what still fits before the stop (the approach is geometric, ratio 1 - erp = 0.8 per step)"""
+    _muscle_world(w)
+    seps = []
+    for _ in range(steps):
+        w.do_step([1.0])
+        b = bodies(w)
+        seps.append(b[3, 0] - b[2, 0])
+    hi = max(seps)
+    assert hi < 2.0 + 2e-3, hi
+    assert abs(seps[-1] - 2.0) < 5e-3, seps[-1]                   # held at the upper limit
+    near = [2.0 - x for x in seps if 0.005 < 2.0 - x < 0.2]
+    ratios = [b_ / a_ for a_, b_ in zip(near[:-1], near[1:])]
+    assert len(ratios) >= 5 and all(abs(r - 0.8) < 0.03 for r in ratios), ratios
+    for _ in range(steps):
+        w.do_step([-1.0])
+        b = bodies(w)
+        seps.append(b[3, 0] - b[2, 0])
+    lo = min(seps)
+    assert lo > -2e-3, lo
+    assert abs(seps[-1]) < 5e-3, seps[-1]                         # held at the lower limit
+    return hi, lo
+
+
+def check_hinge_removes_off_axis_rotation(w, base_y):
+    """a hinge leaves ONE relative rotation free: a bob kicked about an axis perpendicular to the hinge axis loses that spin to
+    the two angular rows at once (the 2000 kg base barely moves), and the two hinge axes stay parallel"""
+    base = np.array([0.0, base_y, 0.0])
+    pivot = base + np.array(PEND_PIVOT_LOCAL)
+    bob = pivot + np.array([0.0, -PEND_L, 0.0])
+    clean_state(w, [base, bob], ang=[[0, 0, 0], [2.0, 1.0, 0.0]])
+    w.step()
+    b = bodies(w)
+    rel = b[1, 10:13] - b[0, 10:13]
+    assert abs(rel[0]) < 2e-2 and abs(rel[1]) < 2e-2, rel      # gone after one step
+    worst = 0.0
+    for _ in range(120):
+        w.step()
+        b = bodies(w)
+        za, zb = rot(b[0, 3:7])[:, 2], rot(b[1, 3:7])[:, 2]
+        worst = max(worst, 1.0 - float(np.dot(za, zb)))
+    assert worst < 1e-4, worst
+    return float(np.abs(rel[:2]).max()), worst

@@ -70,3 +70,15 @@ def test_known_answer_impact_does_not_bounce(tmp_path):
 def test_known_answer_static_friction_holds(tmp_path):
     left, kick = pc.check_static_friction_holds(pc.HipWorld(pc.skel_cube(write_skeleton, tmp_path, scale=(0.5, 0.1, 0.5))))
     print("sideways velocity one step after a %.5f m/s kick: %.2e m/s" % (kick, left))
+
+
+def test_known_answer_slider_stops_at_its_limits(tmp_path):
+    skel = pc.skel_two_masses(write_skeleton, tmp_path, mass=0.25, force=1.0e6, name="motor_limits.skel")
+    hi, lo = pc.check_slider_limits(pc.HipWorld(skel))
+    print("slider length between %.4f and %.4f m (limits 0 and 2 m)" % (lo, hi))
+
+
+def test_known_answer_hinge_removes_off_axis_rotation(tmp_path):
+    skel, base_y = pc.skel_pendulum(write_skeleton, tmp_path)
+    left, tilt = pc.check_hinge_removes_off_axis_rotation(pc.HipWorld(skel), base_y)
+    print("off-axis relative spin after one step %.2e rad/s; hinge axes 1 - cos(angle) <= %.1e over 120 steps" % (left, tilt))

@@ -210,6 +210,18 @@ def test_known_answer_static_friction_holds(orc_lib, tmp_path):
     print("sideways velocity one step after a %.5f m/s kick: %.2e m/s" % (kick, left))
 
 
+def test_known_answer_slider_stops_at_its_limits(orc_lib, tmp_path):
+    skel = pc.skel_two_masses(write_skeleton, tmp_path, mass=0.25, force=1.0e6, name="motor_limits.skel")
+    hi, lo = pc.check_slider_limits(_world(skel, orc_lib))
+    print("slider length between %.4f and %.4f m (limits 0 and 2 m)" % (lo, hi))
+
+
+def test_known_answer_hinge_removes_off_axis_rotation(orc_lib, tmp_path):
+    skel, base_y = pc.skel_pendulum(write_skeleton, tmp_path)
+    left, tilt = pc.check_hinge_removes_off_axis_rotation(_world(skel, orc_lib), base_y)
+    print("off-axis relative spin after one step %.2e rad/s; hinge axes 1 - cos(angle) <= %.1e over 120 steps" % (left, tilt))
+
+
 def test_self_collision_rate_diagnostic(orc_lib):
     """tools/self_collision_rate.py (oracle side): the measurement behind DESIGN.md's statement of the plane-contact deviation —
     how often non-adjacent member pairs come within Bullet's collision margins.  Here only that the diagnostic runs and is
