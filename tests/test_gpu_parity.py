@@ -214,6 +214,34 @@ def test_full_batch_invariants(torch_mod):
     assert torch.equal(st2.state, st.state)
 
 
+def test_an_env_does_not_depend_on_its_batch(torch_mod):
+    """Shards are independent: env i of a 4096-env batch seeded s and env 0 of any other batch seeded s + i are the
+    same environment.  A 128-env batch whose seeds line up with envs 1000..1127 of the big one (a different tile, lane and
+    workgroup for every env, and a ragged last tile) must reproduce their rollout bit for bit, resets included — which is what
+    lets rank r of a multi-GPU run take seeds 1234 + r * 4096 and be a slice of one big batch."""
+    torch = torch_mod
+    big, small, off = make(4096), make(136, seed=1234 + 1000), 1000
+    sb, ss = big.reset(), small.reset()
+    assert torch.equal(sb.state[off:off + 136], ss.state)
+    big.stagger_episodes()
+    # the stagger is a function of the env index inside its batch: give the small batch the big one's budgets instead
+    blob_b, blob_s = big.get_state(), small.get_state()
+    blob_s[:, -2:] = blob_b[off:off + 136, -2:]
+    small.set_state(blob_s)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    resets = 0
+    for k in range(160):
+        a = torch.rand(4096, 12, device="cuda", generator=g) * 2 - 1
+        rb = big.step_autoreset(a)
+        ob, rwb, dnb, vb = rb.state[off:off + 136].clone(), rb.reward[off:off + 136].clone(), rb.done[off:off + 136].clone(), rb.valid[off:off + 136].clone()
+        rs = small.step_autoreset(a[off:off + 136].contiguous())
+        assert torch.equal(ob, rs.state) and torch.equal(rwb, rs.reward) and torch.equal(dnb, rs.done) and torch.equal(vb, rs.valid), k
+        resets += int(rs.done.sum())
+    assert resets > 0  # episodes ended and restarted inside the window
+    assert np.array_equal(big.get_state()[off:off + 136], small.get_state())
+
+
 def _tf_compare(env, orcs, nb, nm, nmus, steps, rng, act_dim):
     import torch
     worst = dict(pos=0.0, lin=0.0, ang=0.0, obs=0.0)
