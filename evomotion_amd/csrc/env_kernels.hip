@@ -2068,6 +2068,9 @@ __global__ __launch_bounds__(64 * EVM_SPLIT_WAVES) void k_split_post(EnvDev d, f
     F3 root_ms = f3(0.f, 0.f, 0.f);
     if (any_observe) root_ms = SC3(c_skel.sc_rootms);
     for (int b = vw; b < c_skel.nb; b += nvw) {
+#ifdef EVM_STAMPS5  // slots 8 / 9 / 10: longest attach-sphere item, member item, the root's item of k_split_post
+        const unsigned long long s5_p0 = __builtin_amdgcn_s_memtime();
+#endif
         const BodyState st = body_integrate(c, b);
         if (b < c_skel.nm && any_observe) {
             float v[19];
@@ -2103,6 +2106,9 @@ __global__ __launch_bounds__(64 * EVM_SPLIT_WAVES) void k_split_post(EnvDev d, f
                 if (fin_next) { SSC3(c_skel.sc_nexte, N.r0); SSC3(c_skel.sc_nexte + 3, N.r1); SSC3(c_skel.sc_nexte + 6, N.r2); }
             }
         }
+#ifdef EVM_STAMPS5
+        if (c.lane == 0) atomicMax(&c.d.stamps[(size_t) blockIdx.x * 16 + (b == c_skel.root ? 10 : b < c_skel.nm ? 9 : 8)], __builtin_amdgcn_s_memtime() - s5_p0);
+#endif
     }
     if (any_observe)
         for (int mi = vw; mi < c_skel.nmus; mi += nvw) {

@@ -1,4 +1,4 @@
-"""Diagnostic (-DEVM_STAMPS5 build): longest item of each kind in k_split_pre_b, cycles (max over the run, median over tiles).
+"""Diagnostic (-DEVM_STAMPS5 build): longest item of each kind in k_split_pre_b and k_split_post, cycles (max over the run, median over tiles).
     hipcc ... -DEVM_STAMPS5 -> build/libevm_stamps5.so; cp over evomotion_amd/libevomotion_hip.so; python tools/stamps5.py"""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,5 +16,5 @@ for k in range(150):
 st = (ctypes.c_ulonglong * (n // 64 * 16))()
 check(lib.evm_env_get_stamps(env._h, st))
 s = np.array(st, dtype=np.uint64).reshape(-1, 16).astype(np.float64)
-for q, name in enumerate(["hinge item", "fixed item", "slider item", "p2p item", "member item (cube)", "member item (foot)", "  manifold update", "  contact-row setup"]):
+for q, name in enumerate(["hinge item", "fixed item", "slider item", "p2p item", "member item (cube)", "member item (foot)", "  manifold update", "  contact-row setup", "post: attach sphere", "post: member", "post: root member"]):
     print("%-22s median of tiles' longest %8.0f   max %8.0f cycles" % (name, np.median(s[:, q]), s[:, q].max()))
