@@ -242,6 +242,64 @@ def test_an_env_does_not_depend_on_its_batch(torch_mod):
     assert np.array_equal(big.get_state()[off:off + 136], small.get_state())
 
 
+def test_teacher_forced_steps_in_the_trained_regime(torch_mod, orc_lib):
+    """The random-action tests exercise robots that flail and fall within ~60 steps.  A trained policy walks: long episodes,
+    feet in sustained sliding and rolling contact, muscles working against their limits.  Train PPO for 250 updates (4096
+    envs, a few seconds), then hold the HIP path to the oracle one step at a time from the states that policy visits, with
+    the policy's own actions: same fp32 tolerances as test_teacher_forced_steps."""
+    torch = torch_mod
+    from evomotion_amd import VecPpoGaeAgent
+    n, k_or = 4096, 12
+    env = make(n, seed=77)
+    env.reset(); env.stagger_episodes()
+    agent = VecPpoGaeAgent(5, [env.state_dim], [env.action_dim], hidden_size=256, device=0, horizon=32, epoch=8, learning_rate=3e-4)
+    lengths = []
+    for u in range(250):
+        b = agent.rollout(env)
+        agent.update()
+        if u >= 230:
+            m = b["valid_u8"] == 1
+            lengths.append(float(m.sum()) / max(float((b["done_u8"][m] != 0).sum()), 1.0))
+    assert np.mean(lengths) > 400, np.mean(lengths)         # it does walk: random actions give ~60-step episodes
+    orcs = oracles(k_or, lib=orc_lib)
+    blob0 = env.get_state()
+    for i, o in enumerate(orcs):
+        o.set_state(blob0[i])                                # the oracle continues from the HIP path's walking states
+    worst = dict(pos=0.0, quat=0.0, lin=0.0, ang=0.0, obs=0.0, rew=0.0, done=0, mf=0, contacts=0)
+    obs = env.obs.clone()
+    for k in range(150):
+        blob_k = env.get_state()
+        for i, o in enumerate(orcs):
+            blob_k[i] = o.get_state()
+        env.set_state(blob_k)
+        a, _, _ = agent.fused.forward(obs, seed=1000 + k)
+        st = env.do_step(a)
+        ah = a[:k_or].cpu().numpy()
+        outs = [o.do_step(ah[i]) for i, o in enumerate(orcs)]
+        d = blob.compare(np.stack([o.get_state() for o in orcs]), env.get_state()[:k_or], 41, 17, 12)
+        for key in ("pos", "quat", "lin", "ang"):
+            worst[key] = max(worst[key], d[key])
+        worst["mf"] = max(worst["mf"], d["mf_count"])
+        og = st.state[:k_or].cpu().numpy()
+        e = np.abs(og - np.stack([x[0] for x in outs]))
+        flips = e[:, SLIDER_IMPULSE_COLS] > 1e-3
+        e[:, SLIDER_IMPULSE_COLS] = np.where(flips, 0, e[:, SLIDER_IMPULSE_COLS])
+        worst["obs"] = max(worst["obs"], float(e.max()))
+        worst["rew"] = max(worst["rew"], float(np.abs(st.reward[:k_or].cpu().numpy() - np.array([x[1] for x in outs])).max()))
+        worst["done"] += int((st.done[:k_or].cpu().numpy().astype(bool) != np.array([x[2] for x in outs])).sum())
+        worst["contacts"] += int(sum(o.counters()["contacts"] for o in orcs))
+        for i, o in enumerate(orcs):
+            if outs[i][2]:
+                o.reset()
+        obs = st.state.clone()
+    print("trained-regime teacher-forced worst:", worst, "mean episode length %.0f" % np.mean(lengths))
+    assert worst["pos"] < 5e-6 and worst["quat"] < 5e-6
+    assert worst["lin"] < 5e-4 and worst["ang"] < 2e-3
+    assert worst["obs"] < 2e-3 and worst["rew"] < 1e-4
+    assert worst["done"] == 0 and worst["mf"] == 0
+    assert worst["contacts"] > 150 * k_or                     # more than one live contact point per env and step on average
+
+
 def _tf_compare(env, orcs, nb, nm, nmus, steps, rng, act_dim):
     import torch
     worst = dict(pos=0.0, lin=0.0, ang=0.0, obs=0.0)
