@@ -133,6 +133,20 @@ __device__ __forceinline__ void block_accumulate(float v, double *dst, float *sh
 }
 
 
+// one float per thread -> this workgroup's partial sum (double), summed later in a fixed order (block_partial_sum).  Thousands of
+// workgroups adding doubles to ONE address serialise in L2: the PPO actor loss kernel spent 60 of its 82 us there.
+__device__ __forceinline__ void block_partial(float v, double *part, float *sh) {
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < nw; i++) s += (double) sh[i];
+        part[blockIdx.x] = s;
+    }
+}
+
 // LayerNorm + Mish backward of a 32-row tile in the MFMA accumulator layout (the counterpart of mish_ln_epilogue, mlp_tile.h):
 //   g[j][r]: in d loss / d a (LayerNorm output), out d loss / d z, for column wave * 64 + 32 j + (lane & 31) and row
 //   (r & 3) + 8 (r >> 2) + 4 (lane >> 5); in: the layer's pre-activations and LayerNorm statistics in the same layout (ln_bwd_load:

@@ -32,6 +32,7 @@ struct PpoDev {
     PpoNet actor, critic;
     float *xpad;    // [max_rows][384] observations, zero padded (staged once per update)
     double *loss;   // [2] actor, critic loss sums of the last evm_ppo_grads call
+    double *loss_part;  // per-workgroup partial sums of the two loss kernels: actor blocks, then critic blocks
     double *gae;    // [3] n, mean, M2 of the raw advantages
     double *gae_part;  // [blocks of 256 envs][3] partial count, sum, M2
     int *step_dev;  // [1] device-side Adam step count of the actor (evm_ppo_actor_apply: SAC's captured update)

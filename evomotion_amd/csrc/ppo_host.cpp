@@ -72,6 +72,7 @@ int evm_ppo_create(EvmPolicy *policy, size_t max_rows, EvmPpo **out) {
     make(d.critic, nc, 1);
     d.xpad = (float *) alloc(max_rows * 384 * 4);
     d.loss = (double *) alloc(2 * sizeof(double));
+    d.loss_part = (double *) alloc(((max_rows * (size_t) d.A + 255) / 256 + (max_rows + 255) / 256) * sizeof(double));
     d.gae = (double *) alloc(3 * sizeof(double));
     d.gae_part = (double *) alloc(((max_rows + 255) / 256) * 3 * sizeof(double));
     d.step_dev = (int *) alloc(sizeof(int));

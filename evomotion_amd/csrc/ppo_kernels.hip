@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void k_ppo_loss_actor(PpoDev d, int n, const f
             dh[A + o] = g_sg;
         }
     }
-    block_accumulate(lsum, d.loss, sh);
+    block_partial(lsum, d.loss_part, sh);
 }
 
 // SAC's actor step: gradients w.r.t. (mu, sigma) supplied by the caller -> gradients at the head pre-activations
@@ -182,7 +182,7 @@ hipError_t launch_actor_head_out(const PpoDev &d, size_t rows, float *mu, float 
 
 // critic_loss_factor * mean((value - returns)^2) over the selected rows (ppo_gae.cpp:176-179)
 __global__ __launch_bounds__(256) void k_ppo_loss_critic(PpoDev d, int n, const float *__restrict__ returns,
-                                                         const uint8_t *__restrict__ mask, float inv_rows, float cf) {
+                                                         const uint8_t *__restrict__ mask, float inv_rows, float cf, int part_off) {
     __shared__ float sh[4];
     const size_t row = (size_t) blockIdx.x * 256 + threadIdx.x;
     float lsum = 0.f;
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void k_ppo_loss_critic(PpoDev d, int n, const 
         }
         d.critic.dh[row * 32] = dv;
     }
-    block_accumulate(lsum, d.loss + 1, sh);
+    block_partial(lsum, d.loss_part + part_off, sh);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -693,16 +693,34 @@ hipError_t launch_ppo_forward(const PolicyDev &p, const PpoDev &d, size_t rows, 
     return hipGetLastError();
 }
 
+// the two loss values: the workgroups' partial sums in index order (one workgroup; a strided pass, then a fixed tree)
+__global__ __launch_bounds__(256) void k_ppo_loss_sum(PpoDev d, int na, int nc) {
+    __shared__ double sh[256];
+    for (int which = 0; which < 2; which++) {
+        const double *p = d.loss_part + (which ? na : 0);
+        const int cnt = which ? nc : na;
+        double s = 0.0;
+        for (int i = threadIdx.x; i < cnt; i += 256) s += p[i];
+        sh[threadIdx.x] = s;
+        __syncthreads();
+        for (int m = 128; m >= 1; m >>= 1) {
+            if ((int) threadIdx.x < m) sh[threadIdx.x] += sh[threadIdx.x + m];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) d.loss[which] = sh[0];
+        __syncthreads();
+    }
+}
 hipError_t launch_ppo_loss(const PpoDev &d, size_t rows, const float *actions, const float *logp_old, const float *adv,
                            const float *returns, const uint8_t *mask, double inv_rows, float epsilon, float entropy_factor,
                            float critic_loss_factor, hipStream_t s) {
-    hipError_t e = hipMemsetAsync(d.loss, 0, 2 * sizeof(double), s);
-    if (e != hipSuccess) return e;
     const float inv_count = (float) (inv_rows / (double) d.A);
-    hipLaunchKernelGGL(k_ppo_loss_actor, dim3((unsigned) ((rows * d.A + 255) / 256)), dim3(256), 0, s, d, (int) rows, actions, logp_old,
-                       adv, mask, inv_count, epsilon, entropy_factor);
-    hipLaunchKernelGGL(k_ppo_loss_critic, dim3((unsigned) ((rows + 255) / 256)), dim3(256), 0, s, d, (int) rows, returns, mask,
-                       (float) inv_rows, critic_loss_factor);
+    const unsigned na = (unsigned) ((rows * d.A + 255) / 256), nc = (unsigned) ((rows + 255) / 256);
+    hipLaunchKernelGGL(k_ppo_loss_actor, dim3(na), dim3(256), 0, s, d, (int) rows, actions, logp_old, adv, mask, inv_count, epsilon,
+                       entropy_factor);
+    hipLaunchKernelGGL(k_ppo_loss_critic, dim3(nc), dim3(256), 0, s, d, (int) rows, returns, mask, (float) inv_rows, critic_loss_factor,
+                       (int) na);
+    hipLaunchKernelGGL(k_ppo_loss_sum, dim3(1), dim3(256), 0, s, d, (int) na, (int) nc);
     return hipGetLastError();
 }
 
