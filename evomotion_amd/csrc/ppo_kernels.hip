@@ -486,7 +486,15 @@ __global__ __launch_bounds__(256) void k_ppo_colfinish(const float *__restrict__
     if (e >= PPO_COLSLOTS * 256) return;
     const int slot = e >> 8, c = e & 255;
     float s = 0.f;
-    for (int k = 0; k < groups; k++) s += src[(size_t) k * PPO_COLSLOTS * 256 + e];
+    int k = 0;
+    for (; k + 8 <= groups; k += 8) {  // eight loads in flight, summed in index order (a handful of workgroups: pure latency otherwise)
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = src[(size_t) (k + u) * PPO_COLSLOTS * 256 + e];
+#pragma unroll
+        for (int u = 0; u < 8; u++) s += v[u];
+    }
+    for (; k < groups; k++) s += src[(size_t) k * PPO_COLSLOTS * 256 + e];
     if (slot < 6) { grad[cs.off[slot] + c] = s; return; }
     if (cs.actor) {
         if (c < cs.A) grad[cs.off[6] + c] = s;                                  // mu.0.bias
@@ -700,7 +708,15 @@ __global__ __launch_bounds__(256) void k_ppo_loss_sum(PpoDev d, int na, int nc) 
         const double *p = d.loss_part + (which ? na : 0);
         const int cnt = which ? nc : na;
         double s = 0.0;
-        for (int i = threadIdx.x; i < cnt; i += 256) s += p[i];
+        int i = threadIdx.x;
+        for (; i + 7 * 256 < cnt; i += 8 * 256) {  // eight loads in flight, added in index order
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = p[i + u * 256];
+#pragma unroll
+            for (int u = 0; u < 8; u++) s += v[u];
+        }
+        for (; i < cnt; i += 256) s += p[i];
         sh[threadIdx.x] = s;
         __syncthreads();
         for (int m = 128; m >= 1; m >>= 1) {

@@ -188,7 +188,15 @@ __global__ __launch_bounds__(256) void k_q_colfinish(const float *__restrict__ s
     if (e >= Q_COLSLOTS * 256) return;
     const int slot = e >> 8, c = e & 255;
     float s = 0.f;
-    for (int k = 0; k < groups; k++) s += src[(size_t) k * Q_COLSLOTS * 256 + e];
+    int k = 0;
+    for (; k + 8 <= groups; k += 8) {  // eight loads in flight, summed in index order (a handful of workgroups: pure latency otherwise)
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = src[(size_t) (k + u) * Q_COLSLOTS * 256 + e];
+#pragma unroll
+        for (int u = 0; u < 8; u++) s += v[u];
+    }
+    for (; k < groups; k++) s += src[(size_t) k * Q_COLSLOTS * 256 + e];
     if (slot < Q_COLSLOTS - 1) grad[cs.off[slot] + c] = s;
     else if (c == 0) grad[cs.off[slot]] = s;
 }
