@@ -22,6 +22,65 @@ struct PolicyDev {
     NetDev actor, critic;
 };
 
+#ifdef __HIPCC__
+// One flat parameter (index i of the network's named_parameters() vector, value v) -> every place the forward kernels read it
+// from: the k-split GEMM operands w1t / w2t, the bias / LayerNorm vectors, the head weights row major (wh) and as the head
+// GEMM's B operand (whp: [32 s4][32 cols][2][4], column = head row).  The same mapping as the host packer in policy_host.cpp.
+// Used by k_policy_pack and, fused behind the Adam step, by the trainers (one launch less per network and step).
+__device__ __forceinline__ void policy_pack_write(const NetDev &n, int S, int A, int actor, size_t i, float v) {
+    const size_t n_w1 = (size_t) 256 * S, n_w2 = 256 * 256;
+    size_t o = 0;
+    auto wr = [](const float *p) { return const_cast<float *>(p); };
+    if (i < n_w1) {  // head.0.weight [256][S]
+        const int col = (int) (i / S), k = (int) (i % S);
+        const int st = k >> 1, h = k & 1, s4 = st >> 2, t = st & 3;
+        wr(n.w1t)[(((size_t) s4 * 256 + col) * 2 + h) * 4 + t] = v;
+        return;
+    }
+    o = n_w1;
+    if (i < o + 256) { wr(n.b1)[i - o] = v; return; }
+    o += 256;
+    if (i < o + 256) { wr(n.g1)[i - o] = v; return; }
+    o += 256;
+    if (i < o + 256) { wr(n.be1)[i - o] = v; return; }
+    o += 256;
+    if (i < o + n_w2) {
+        const size_t j = i - o;
+        const int col = (int) (j / 256), k = (int) (j % 256);
+        const int st = k >> 1, h = k & 1, s4 = st >> 2, t = st & 3;
+        wr(n.w2t)[(((size_t) s4 * 256 + col) * 2 + h) * 4 + t] = v;
+        return;
+    }
+    o += n_w2;
+    if (i < o + 256) { wr(n.b2)[i - o] = v; return; }
+    o += 256;
+    if (i < o + 256) { wr(n.g2)[i - o] = v; return; }
+    o += 256;
+    if (i < o + 256) { wr(n.be2)[i - o] = v; return; }
+    o += 256;
+    auto head = [&](size_t e, float x) {  // e = row * 256 + k
+        wr(n.wh)[e] = x;
+        const int row = (int) (e >> 8), k = (int) (e & 255);
+        const int st = k >> 1, h = k & 1, s4 = st >> 2, t = st & 3;
+        wr(n.whp)[(((size_t) s4 * 32 + row) * 2 + h) * 4 + t] = x;
+    };
+    if (actor) {
+        const size_t hw = (size_t) A * 256;
+        if (i < o + hw) { head(i - o, v); return; }                  // mu.0.weight
+        o += hw;
+        if (i < o + A) { wr(n.bh)[i - o] = v; return; }              // mu.0.bias
+        o += A;
+        if (i < o + hw) { head(hw + (i - o), v); return; }           // sigma.0.weight
+        o += hw;
+        if (i < o + A) { wr(n.bh)[A + (i - o)] = v; return; }        // sigma.0.bias
+    } else {
+        if (i < o + 256) { head(i - o, v); return; }
+        o += 256;
+        if (i < o + 1) { wr(n.bh)[0] = v; return; }
+    }
+}
+#endif
+
 size_t policy_lds_bytes();
 // device-side repack of one network's flat parameters (named_parameters order) into the kernel's operand layout
 hipError_t launch_policy_pack(const NetDev &n, int S, int A, bool actor, const float *flat, hipStream_t s);

@@ -125,61 +125,11 @@ __global__ __launch_bounds__(PT) void k_policy_forward(PolicyDev p, int n, const
     }
 }
 
-// flat parameters of one network -> the operand layout of the forward kernel (same mapping as the host packer in
-// policy_host.cpp); one thread per source element
+// flat parameters of one network -> the operand layout of the forward kernel; one thread per source element
 __global__ __launch_bounds__(256) void k_policy_pack(NetDev n, int S, int A, int actor, const float *__restrict__ flat) {
     const size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x;
-    const size_t n_w1 = (size_t) 256 * S, n_w2 = 256 * 256;
-    size_t o = 0;
-    auto wr = [](const float *p) { return const_cast<float *>(p); };
-    if (i < n_w1) {  // head.0.weight [256][S]
-        const int col = (int) (i / S), k = (int) (i % S);
-        const int st = k >> 1, h = k & 1, s4 = st >> 2, t = st & 3;
-        wr(n.w1t)[(((size_t) s4 * 256 + col) * 2 + h) * 4 + t] = flat[i];
-        return;
-    }
-    o = n_w1;
-    if (i < o + 256) { wr(n.b1)[i - o] = flat[i]; return; }
-    o += 256;
-    if (i < o + 256) { wr(n.g1)[i - o] = flat[i]; return; }
-    o += 256;
-    if (i < o + 256) { wr(n.be1)[i - o] = flat[i]; return; }
-    o += 256;
-    if (i < o + n_w2) {
-        const size_t j = i - o;
-        const int col = (int) (j / 256), k = (int) (j % 256);
-        const int st = k >> 1, h = k & 1, s4 = st >> 2, t = st & 3;
-        wr(n.w2t)[(((size_t) s4 * 256 + col) * 2 + h) * 4 + t] = flat[i];
-        return;
-    }
-    o += n_w2;
-    if (i < o + 256) { wr(n.b2)[i - o] = flat[i]; return; }
-    o += 256;
-    if (i < o + 256) { wr(n.g2)[i - o] = flat[i]; return; }
-    o += 256;
-    if (i < o + 256) { wr(n.be2)[i - o] = flat[i]; return; }
-    o += 256;
-    // head weights: row major (wh) and as the B operand of the head GEMM (whp: [32 s4][32 cols][2][4], column = head row)
-    auto head = [&](size_t e, float v) {  // e = row * 256 + k
-        wr(n.wh)[e] = v;
-        const int row = (int) (e >> 8), k = (int) (e & 255);
-        const int st = k >> 1, h = k & 1, s4 = st >> 2, t = st & 3;
-        wr(n.whp)[(((size_t) s4 * 32 + row) * 2 + h) * 4 + t] = v;
-    };
-    if (actor) {
-        const size_t hw = (size_t) A * 256;
-        if (i < o + hw) { head(i - o, flat[i]); return; }                  // mu.0.weight
-        o += hw;
-        if (i < o + A) { wr(n.bh)[i - o] = flat[i]; return; }              // mu.0.bias
-        o += A;
-        if (i < o + hw) { head(hw + (i - o), flat[i]); return; }           // sigma.0.weight
-        o += hw;
-        if (i < o + A) { wr(n.bh)[A + (i - o)] = flat[i]; return; }        // sigma.0.bias
-    } else {
-        if (i < o + 256) { head(i - o, flat[i]); return; }
-        o += 256;
-        if (i < o + 1) { wr(n.bh)[0] = flat[i]; return; }
-    }
+    const size_t total = (size_t) 256 * S + 3 * 256 + 256 * 256 + 3 * 256 + (actor ? (size_t) 2 * A * 256 + 2 * A : 257);
+    if (i < total) policy_pack_write(n, S, A, actor, i, flat[i]);
 }
 hipError_t launch_policy_pack(const NetDev &n, int S, int A, bool actor, const float *flat, hipStream_t s) {
     const size_t total = (size_t) 256 * S + 3 * 256 + 256 * 256 + 3 * 256 + (actor ? (size_t) 2 * A * 256 + 2 * A : 257);

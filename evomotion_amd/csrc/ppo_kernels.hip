@@ -518,7 +518,35 @@ __global__ __launch_bounds__(256) void k_ppo_sqnorm(PpoDev d) {  // grid (PPO_NO
     const double tot = block_sum_double(s, sh);
     if (threadIdx.x == 0) B.normp[blockIdx.x] = tot;
 }
-__global__ __launch_bounds__(256) void k_ppo_adam(PpoDev d, float max_norm, float lr, float bc1_a, float bc2s_a, float bc1_c, float bc2s_c) {
+// One flat parameter -> the trainer's own dgrad operands: Linear(256,256) as B[k = out j][col = in i] (w2d) and the head weights as
+// B[k = head output o < 32][col = in i] (whd), both k-split as in mlp_tile.h.  (k_ppo_pack_w2d / _whd do the same from a whole vector.)
+__device__ __forceinline__ void ppo_dgrad_pack_write(const PpoNet &B, int S, int A, int actor, size_t i, float v) {
+    const size_t o_w2 = (size_t) 256 * S + 3 * 256, o_h = o_w2 + 65536 + 3 * 256;
+    if (i >= o_w2 && i < o_w2 + 65536) {
+        const int e = (int) (i - o_w2), k = e >> 8, col = e & 255;
+        const int st = k >> 1, h = k & 1, s4 = st >> 2, tt = st & 3;
+        B.w2d[(((size_t) s4 * 256 + col) * 2 + h) * 4 + tt] = v;
+        return;
+    }
+    if (i < o_h) return;
+    size_t e = i - o_h;
+    int k;
+    if (actor) {
+        const size_t hw = (size_t) A * 256;
+        if (e < hw) k = (int) (e >> 8);                                  // mu.0.weight row
+        else if (e >= hw + A && e < 2 * hw + A) { e -= hw + A; k = A + (int) (e >> 8); }  // sigma.0.weight row
+        else return;                                                     // a bias
+    } else {
+        if (e >= 256) return;
+        k = 0;
+    }
+    const int col = (int) (e & 255);
+    const int st = k >> 1, h = k & 1, s4 = st >> 2, tt = st & 3;
+    B.whd[(((size_t) s4 * 256 + col) * 2 + h) * 4 + tt] = v;
+}
+
+// clip + Adam + the repack of every new weight into the forward / dgrad operand layouts (policy_pack_write, ppo_dgrad_pack_write)
+__global__ __launch_bounds__(256) void k_ppo_adam(PolicyDev p, PpoDev d, float max_norm, float lr, float bc1_a, float bc2s_a, float bc1_c, float bc2s_c) {
     const PpoNet &B = blockIdx.y == 0 ? d.actor : d.critic;
     const size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
     const float bc1 = blockIdx.y == 0 ? bc1_a : bc1_c, bc2s = blockIdx.y == 0 ? bc2s_a : bc2s_c;
@@ -533,11 +561,15 @@ __global__ __launch_bounds__(256) void k_ppo_adam(PpoDev d, float max_norm, floa
     B.m[i] = m;
     B.v[i] = v;
     const float denom = sqrtf(v) / bc2s + 1e-8f;
-    B.theta[i] -= (lr / bc1) * (m / denom);
+    const float th = B.theta[i] - (lr / bc1) * (m / denom);
+    B.theta[i] = th;
+    const int actor = blockIdx.y == 0;
+    policy_pack_write(actor ? p.actor : p.critic, p.S, p.A, actor, i, th);
+    ppo_dgrad_pack_write(B, p.S, p.A, actor, i, th);
 }
 
 // the actor alone, no clipping, step count on the device (SAC's actor step inside a captured graph)
-__global__ __launch_bounds__(256) void k_actor_adam_dev(PpoDev d, float lr) {
+__global__ __launch_bounds__(256) void k_actor_adam_dev(PolicyDev p, PpoDev d, float lr) {
     const PpoNet &B = d.actor;
     const size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
     if (i >= B.n_params) return;
@@ -549,17 +581,18 @@ __global__ __launch_bounds__(256) void k_actor_adam_dev(PpoDev d, float lr) {
     const float v = B.v[i] * 0.999f + (g * g) * 0.001f;
     B.m[i] = m;
     B.v[i] = v;
-    B.theta[i] -= (lr / bc1) * (m / (sqrtf(v) / bc2s + 1e-8f));
+    const float th = B.theta[i] - (lr / bc1) * (m / (sqrtf(v) / bc2s + 1e-8f));
+    B.theta[i] = th;
+    policy_pack_write(p.actor, p.S, p.A, 1, i, th);
+    ppo_dgrad_pack_write(B, p.S, p.A, 1, i, th);
 }
 __global__ void k_actor_step_inc(PpoDev d) {
     if (threadIdx.x == 0) d.step_dev[0] += 1;
 }
 hipError_t launch_actor_apply(const PolicyDev &p, const PpoDev &d, float lr, hipStream_t s) {
-    hipLaunchKernelGGL(k_actor_adam_dev, dim3((unsigned) ((d.actor.n_params + 255) / 256)), dim3(256), 0, s, d, lr);
+    hipLaunchKernelGGL(k_actor_adam_dev, dim3((unsigned) ((d.actor.n_params + 255) / 256)), dim3(256), 0, s, p, d, lr);
     hipLaunchKernelGGL(k_actor_step_inc, dim3(1), dim3(64), 0, s, d);
-    hipError_t e = launch_policy_pack(p.actor, p.S, p.A, true, d.actor.theta, s);
-    if (e == hipSuccess) e = launch_ppo_pack_w2d(d.actor, p.S, p.A, true, s);
-    return e;
+    return hipGetLastError();
 }
 
 // Linear(256,256) weight -> the B operand of the dgrad GEMM: B[k = j][col = i] = W2[j][i], k-split as in mlp_tile.h
@@ -823,13 +856,10 @@ hipError_t launch_ppo_apply(const PolicyDev &p, PpoDev &d, float lr, float clip_
     auto bc2s = [](int t) { return (float) sqrt(1.0 - pow(0.999, (double) t)); };
     hipLaunchKernelGGL(k_ppo_sqnorm, dim3(PPO_NORM_PARTS, 2), dim3(256), 0, s, d);
     const size_t nmax = d.actor.n_params > d.critic.n_params ? d.actor.n_params : d.critic.n_params;
-    hipLaunchKernelGGL(k_ppo_adam, dim3((unsigned) ((nmax + 255) / 256), 2), dim3(256), 0, s, d, clip_grad_norm, lr, bc1(d.actor.step),
+    // the step and the repack of the new weights into every operand layout in one launch (policy_pack_write, ppo_dgrad_pack_write)
+    hipLaunchKernelGGL(k_ppo_adam, dim3((unsigned) ((nmax + 255) / 256), 2), dim3(256), 0, s, p, d, clip_grad_norm, lr, bc1(d.actor.step),
                        bc2s(d.actor.step), bc1(d.critic.step), bc2s(d.critic.step));
-    hipError_t e = launch_policy_pack(p.actor, p.S, p.A, true, d.actor.theta, s);
-    if (e == hipSuccess) e = launch_policy_pack(p.critic, p.S, p.A, false, d.critic.theta, s);
-    if (e == hipSuccess) e = launch_ppo_pack_w2d(d.actor, p.S, p.A, true, s);
-    if (e == hipSuccess) e = launch_ppo_pack_w2d(d.critic, p.S, p.A, false, s);
-    return e;
+    return hipGetLastError();
 }
 
 hipError_t launch_ppo_gae_scan(const PpoDev &d, int T, int N, const float *rewards, const uint8_t *done, const float *curr_values,
