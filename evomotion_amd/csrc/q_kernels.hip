@@ -43,6 +43,29 @@ __global__ __launch_bounds__(256) void k_q_pack(QNet n, int SA) {
     }
 }
 
+// One flat parameter (index i, value v) -> the operand layouts, for the kernels that change parameters in place (Adam, soft update):
+// the repack costs no launch of its own.
+__device__ __forceinline__ void q_pack_write(const QNet &n, int SA, size_t i, float v) {
+    auto put = [](float *dst, int k, int col, float x) {
+        const int st = k >> 1, h = k & 1, s4 = st >> 2, tt = st & 3;
+        dst[(((size_t) s4 * 256 + col) * 2 + h) * 4 + tt] = x;
+    };
+    if (i >= n.o_w[0] && i < n.o_w[0] + (size_t) 256 * SA) {
+        const size_t j = i - n.o_w[0];
+        put(n.wt[0], (int) (j % SA), (int) (j / SA), v);
+        return;
+    }
+#pragma unroll
+    for (int l = 1; l < Q_LAYERS; l++)
+        if (i >= n.o_w[l] && i < n.o_w[l] + 65536) {
+            const size_t j = i - n.o_w[l];
+            const int out = (int) (j >> 8), in = (int) (j & 255);
+            put(n.wt[l], in, out, v);
+            if (n.wd[l]) put(n.wd[l], out, in, v);
+            return;
+        }
+}
+
 // [state, action] rows, zero padded to K1 columns
 __global__ __launch_bounds__(256) void k_q_concat(const float *__restrict__ states, const float *__restrict__ actions, int S, int A,
                                                   size_t rows, float *__restrict__ dst) {
@@ -214,7 +237,9 @@ __global__ __launch_bounds__(256) void k_q_adam(QDev d, float lr) {
     const float v = N.v[i] * 0.999f + (g * g) * 0.001f;
     N.m[i] = m;
     N.v[i] = v;
-    N.theta[i] -= (lr / bc1) * (m / (sqrtf(v) / bc2s + 1e-8f));
+    const float th = N.theta[i] - (lr / bc1) * (m / (sqrtf(v) / bc2s + 1e-8f));
+    N.theta[i] = th;
+    q_pack_write(N, d.S + d.A, i, th);
 }
 __global__ void k_q_step_inc(QDev d) {
     if (threadIdx.x < 2) d.net[threadIdx.x].step[0] += 1;
@@ -229,6 +254,7 @@ __global__ __launch_bounds__(256) void k_q_soft(QDev d, float tau, float one_min
     const float a = tau * F.theta[i];
     const float b = one_minus_tau * T.theta[i];
     T.theta[i] = a + b;
+    q_pack_write(T, d.S + d.A, i, a + b);
 }
 #pragma clang fp contract(fast)
 
@@ -469,16 +495,12 @@ hipError_t launch_q_wgrads(const QDev &d, size_t rows, hipStream_t s) {
 hipError_t launch_q_adam(const QDev &d, float lr, hipStream_t s) {
     hipLaunchKernelGGL(k_q_adam, dim3((unsigned) ((d.net[0].n_params + 255) / 256), 2), dim3(256), 0, s, d, lr);
     hipLaunchKernelGGL(k_q_step_inc, dim3(1), dim3(64), 0, s, d);
-    hipError_t e = launch_q_pack(d, 0, s);
-    if (e == hipSuccess) e = launch_q_pack(d, 1, s);
-    return e;
+    return hipGetLastError();  // k_q_adam repacks what it changes
 }
 hipError_t launch_q_soft_update(const QDev &d, float tau, hipStream_t s) {
     const float omt = (float) (1.0 - (double) tau);
     hipLaunchKernelGGL(k_q_soft, dim3((unsigned) ((d.net[0].n_params + 255) / 256), 2), dim3(256), 0, s, d, tau, omt);
-    hipError_t e = launch_q_pack(d, 2, s);
-    if (e == hipSuccess) e = launch_q_pack(d, 3, s);
-    return e;
+    return hipGetLastError();  // k_q_soft repacks what it changes
 }
 
 hipError_t launch_sac_sample(int rows, int A, const float *mu, const float *sigma, const float *u, float *action, float *logp_sum, hipStream_t s) {
