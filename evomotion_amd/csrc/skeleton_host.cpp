@@ -132,7 +132,7 @@ struct RawSkeleton {
     std::vector<RawShape> shapes;
 };
 
-// (1) the decoded text fixture written by tools/decode_skeleton.py
+// (1) the decoded text fixture written by tests/diag/decode_skeleton.py
 int parse_fixture(const char *path, RawSkeleton &R, std::string &err) {
     std::ifstream f(path ? path : "");
     if (!f) { err = std::string("cannot open skeleton fixture: ") + (path ? path : "(null)"); return EVM_E_RUNTIME; }

@@ -18,7 +18,7 @@ import json, struct, sys, os
 import numpy as np
 
 REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
-OUT = sys.argv[2] if len(sys.argv) > 2 else os.path.join(os.path.dirname(__file__), "..", "evomotion_amd", "data", "robot_walk_spider.skel")
+OUT = sys.argv[2] if len(sys.argv) > 2 else os.path.join(os.path.dirname(__file__), "..", "..", "evomotion_amd", "data", "robot_walk_spider.skel")
 RES = os.path.join(REF, "evo_motion_model", "resources")
 
 
@@ -62,7 +62,7 @@ def load_hull(name):
 def main():
     j = json.load(open(os.path.join(RES, "skeleton", "new_format_spider.json")))
     out = []
-    out.append("# robot_walk skeleton fixture (decoded from the reference's data files by tools/decode_skeleton.py)")
+    out.append("# robot_walk skeleton fixture (decoded from the reference's data files by tests/diag/decode_skeleton.py)")
     out.append(f"skeleton {j['robot_name']} root {j['root_name']}")
     out.append(f"members {len(j['members'])}")
     for m in j["members"]:

@@ -1,6 +1,6 @@
 """End-to-end check on a GPU box: HIP env vs CPU oracle (teacher-forced and free-running)."""
 import sys, os, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import orc, blob

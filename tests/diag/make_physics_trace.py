@@ -1,13 +1,13 @@
 """Writes tests/golden/physics_trace.txt: a SELF-PIN of the CPU oracle (oracle/liborc.so) — 4 environments x 256 do_step
 calls with seeded uniform actions (resets included), every 4th call recorded.  It is not a reference output (Bullet3 cannot
 be built here): its purpose is that a refactor of the oracle cannot drift silently
-(tests/test_oracle_constants.py::test_oracle_matches_its_committed_trace).   python tools/make_physics_trace.py"""
+(tests/test_oracle_constants.py::test_oracle_matches_its_committed_trace).   python tests/diag/make_physics_trace.py"""
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import orc  # noqa: E402
 
@@ -37,7 +37,7 @@ if __name__ == "__main__":
     t = trace()
     out = os.path.join(ROOT, "tests", "golden", "physics_trace.txt")
     with open(out, "w") as f:
-        f.write("# SELF-PIN of oracle/liborc.so (tools/make_physics_trace.py), not a Bullet3 output: env, call, done, reward, root xyz, "
+        f.write("# SELF-PIN of oracle/liborc.so (tests/diag/make_physics_trace.py), not a Bullet3 output: env, call, done, reward, root xyz, "
                 "sum |member positions|, sum(root block of the observation), sum |observation|\n")
         for r in t:
             f.write("%d %d %d %s\n" % (r[0], r[1], r[2], " ".join("%.9g" % v for v in r[3:])))

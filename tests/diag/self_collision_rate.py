@@ -9,14 +9,14 @@ the product) rolls the CPU oracle with uniform random actions and counts, per en
       separating-axis search over the face normals of both (oriented) boxes and the 9 edge cross products on the hulls'
       vertex sets — exact for the cube members, and for the feet applied to their vertex hull (conservative: "no
       separating axis found among those" counts as touching)
-   python tools/self_collision_rate.py [--envs 8] [--steps 600]"""
+   python tests/diag/self_collision_rate.py [--envs 8] [--steps 600]"""
 import argparse
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import orc  # noqa: E402
 

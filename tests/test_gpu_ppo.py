@@ -170,7 +170,7 @@ def test_train_call_matches_reference_golden(gold):
     # The value head is ill-conditioned in this call by construction: returns = normalised advantages + V and V is the
     # critic's own output, so sum(value - returns) = -sum(adv) = 0 in exact arithmetic and the gradients of critic.6.bias
     # and critic.5.bias (LayerNorm beta) are pure rounding noise (~5e-8 here) that Adam turns into steps of up to lr each
-    # (tools/diag_ppo.py: every other gradient agrees with autograd to ~1e-6 relative).  Two epochs: 2 lr on the bias.
+    # (tests/diag/diag_ppo.py: every other gradient agrees with autograd to ~1e-6 relative).  Two epochs: 2 lr on the bias.
     np.testing.assert_allclose(value.cpu().numpy(), gold["ppo_after_value"].ravel(), atol=1e-3)
     tr.params_into(actor, critic)
     np.testing.assert_allclose(actor.head[0].weight[0].detach().cpu().numpy(), gold["ppo_after_actor_w0_row0"], atol=5e-6)
@@ -217,7 +217,7 @@ def test_epochs_in_lock_step_with_autograd_and_adam():
 def test_update_matches_torch_update():
     """the whole train() call (GAE + 3 epochs) against torch_ref.ppo_train with torch.optim.Adam, both free-running.  The
     clipped surrogate is discontinuous in the weights and the networks amplify weight noise through two LayerNorms
-    (tools/diag_ppo*.py), so after three epochs the outputs agree to ~1e-3, not to rounding."""
+    (tests/diag/diag_ppo*.py), so after three epochs the outputs agree to ~1e-3, not to rounding."""
     import torch
     from evomotion_amd import agent
     actor, critic = _modules(seed=7)

@@ -90,7 +90,7 @@ def test_state_roundtrip(orc_lib):
 
 
 def test_oracle_matches_its_committed_trace(orc_lib):
-    """tests/golden/physics_trace.txt is a SELF-PIN (written by tools/make_physics_trace.py from this same oracle): it does
+    """tests/golden/physics_trace.txt is a SELF-PIN (written by tests/diag/make_physics_trace.py from this same oracle): it does
     not add evidence about Bullet3, it makes a silent drift of the restatement impossible.  Tolerance: libm's sinf / atan2f /
     asinf may differ in the last place between glibc builds; contact-rich rollouts amplify that, so the early calls are
     compared tightly and the whole trace loosely."""

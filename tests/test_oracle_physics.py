@@ -223,12 +223,12 @@ def test_known_answer_hinge_removes_off_axis_rotation(orc_lib, tmp_path):
 
 
 def test_self_collision_rate_diagnostic(orc_lib):
-    """tools/self_collision_rate.py (oracle side): the measurement behind DESIGN.md's statement of the plane-contact deviation —
+    """tests/diag/self_collision_rate.py (oracle side): the measurement behind DESIGN.md's statement of the plane-contact deviation —
     how often non-adjacent member pairs come within Bullet's collision margins.  Here only that the diagnostic runs and is
     consistent; the rates of a long run are quoted in DESIGN.md §2."""
     import os
     import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "diag"))
     import self_collision_rate as sc
     names, hulls, adjacent = sc.load_members()
     assert len(names) == 17 and len(adjacent) == 16 and [len(h) for h in hulls].count(8) == 13   # 13 cubes, 4 feet
