@@ -97,7 +97,7 @@ def test_oracle_matches_its_committed_trace(orc_lib):
     import os
     import sys
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "diag"))
     import make_physics_trace as mpt
     ref = np.loadtxt(os.path.join(ROOT, "tests", "golden", "physics_trace.txt"))
     got = mpt.trace(lib=orc_lib)
