@@ -201,3 +201,48 @@ def test_generic_group_schedule(hip_lib, tmp_path):
     visits, _, _, _ = schedule(hip_lib, path)
     ent, w, lds, cyc = group_schedule(hip_lib, path, 1)
     check_groups(visits, ent, 1, 1)
+
+
+def _random_skeleton(rng, tmp_path, tag):
+    """a random tree of 2..14 members joined by hinges / fixed constraints, with 0..6 muscles between random member pairs
+    (several may share a member: the chain entries of the group schedule)"""
+    nm = int(rng.integers(2, 15))
+    members = [dict(name="body", mass=2.0, scale=(0.3, 0.2, 0.3))]
+    cons, mus = [], []
+    for k in range(1, nm):
+        parent = int(rng.integers(0, k))
+        members.append(dict(name=f"m{k}", mass=float(rng.uniform(0.1, 1.0)), t=(0.4 * k, 0.1 * parent, 0.0), scale=(0.15, 0.1, 0.1)))
+        pname = members[parent]["name"]
+        if rng.random() < 0.7:
+            ax = [(1, 0, 0), (0, 1, 0), (0, 0, 1)][int(rng.integers(0, 3))]
+            cons.append(dict(type="hinge", name=f"c{k}", parent=pname, child=f"m{k}", pivot_p=(0.2, 0, 0), pivot_c=(-0.2, 0, 0),
+                             axis_p=ax, axis_c=ax, lo=-1.0, hi=1.0))
+        else:
+            cons.append(dict(type="fixed", name=f"c{k}", parent=pname, child=f"m{k}", tp=(0.2, 0, 0), tc=(-0.2, 0, 0)))
+    for j in range(int(rng.integers(0, 7))):
+        a, b = rng.choice(nm, 2, replace=False)
+        mus.append(dict(name=f"mu{j}", a=members[int(a)]["name"], b=members[int(b)]["name"], pos_a=(0.05, 0.05, 0), pos_b=(0, 0.05, 0.05)))
+    return write_skeleton(tmp_path / f"rand{tag}.skel", members, cons, mus), nm, len(cons), len(mus)
+
+
+def test_random_skeletons_schedule_validly(hip_lib, tmp_path):
+    """40 random articulated trees: both schedules (level schedule of the tile kernel, lane-group entries of k_sweeps_g at 1, 2
+    and 4 waves) stay pure re-orderings of Bullet's visit list that never swap two visits sharing a body, or the loader says
+    why it cannot build one (a skeleton whose records do not fit the 160 KB of LDS falls back to the tile kernel)."""
+    rng = np.random.default_rng(2024)
+    built = 0
+    for tag in range(40):
+        path, nm, nc, nmu = _random_skeleton(rng, tmp_path, tag)
+        visits, sched, nlev, nw = schedule(hip_lib, path)
+        assert len(visits) == nc + 3 * nmu            # per muscle: the slider and its two p2p joints
+        check(visits, sched, nlev, nw, nm)
+        for gw in (1, 2, 4):
+            try:
+                ent, w, lds, cyc = group_schedule(hip_lib, path, gw)
+            except Exception as e:                    # refused with a reason (too many records / entries for the kernel's tables)
+                assert "group schedule" in str(e) or "LDS" in str(e) or "entries" in str(e), e
+                continue
+            assert lds <= 160 * 1024
+            check_groups(visits, ent, gw, nm)
+            built += 1
+    assert built >= 100, built
