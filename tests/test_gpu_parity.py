@@ -370,6 +370,48 @@ def test_generic_skeletons(torch_mod, orc_lib, tmp_path):
     assert w["pos"] < 5e-6 and w["lin"] < 1e-3 and w["ang"] < 5e-3 and w["obs"] < 5e-3, w
 
 
+def test_random_skeletons_match_the_oracle(torch_mod, orc_lib, tmp_path):
+    """Six random articulated trees (3..9 members, hinges about random axes and fixed joints with consistent frames, 1..4 muscles
+    between random members, several on one member now and then): loader constants bit-identical, and the HIP path — tile
+    schedule, lane-group entries, chain entries, whatever the topology produces — one step from the oracle's state at the
+    tolerances of the hand-written chain."""
+    from conftest import write_skeleton
+    rng = np.random.default_rng(31)
+    dirs = [(0.45, 0, 0), (0, 0, 0.45), (-0.45, 0, 0), (0, 0, -0.45), (0, 0.3, 0)]
+    for tag in range(6):
+        nm = int(rng.integers(3, 10))
+        members = [dict(name="body", mass=2.0, scale=(0.2, 0.12, 0.2))]
+        pos = [np.zeros(3)]
+        cons, mus = [], []
+        for k in range(1, nm):
+            parent = int(rng.integers(0, k))
+            d = np.array(dirs[int(rng.integers(0, len(dirs)))])
+            pos.append(pos[parent] + d)
+            members.append(dict(name=f"m{k}", mass=float(rng.uniform(0.2, 0.8)), t=tuple(pos[k]), scale=(0.12, 0.08, 0.12)))
+            if rng.random() < 0.7:
+                ax = [(1, 0, 0), (0, 1, 0), (0, 0, 1)][int(rng.integers(0, 3))]
+                cons.append(dict(type="hinge", name=f"c{k}", parent=members[parent]["name"], child=f"m{k}", pivot_p=tuple(d / 2),
+                                 pivot_c=tuple(-d / 2), axis_p=ax, axis_c=ax, lo=-1.0, hi=1.0))
+            else:
+                cons.append(dict(type="fixed", name=f"c{k}", parent=members[parent]["name"], child=f"m{k}", tp=tuple(d / 2), tc=tuple(-d / 2)))
+        nmus = int(rng.integers(1, 5))
+        for j in range(nmus):
+            a, b = rng.choice(nm, 2, replace=False)
+            mus.append(dict(name=f"mu{j}", a=members[int(a)]["name"], b=members[int(b)]["name"], pos_a=(0.03, 0.05, 0.0), pos_b=(0.0, 0.05, 0.03)))
+        path = write_skeleton(tmp_path / f"rand{tag}.skel", members, cons, mus)
+        n = 8
+        env = make(n, parameters=dict(skeleton_json_path=path))
+        orcs = [orc.OracleEnv(seed=500 + 10 * tag + i, skeleton=path, lib=orc_lib) for i in range(n)]
+        nb = nm + 2 * nmus
+        assert env.n_bodies == nb and env.action_dim == nmus and env.state_dim == 19 * nm + 4 * nmus
+        assert np.array_equal(env.body_constants()[:nm].view(np.uint32), orcs[0].body_constants()[:nm].view(np.uint32))
+        for o in orcs:
+            o.reset()
+        w = _tf_compare(env, orcs, nb, nm, nmus, 30, rng, nmus)
+        assert w["pos"] < 5e-6 and w["lin"] < 1e-3 and w["ang"] < 5e-3 and w["obs"] < 5e-3, (tag, nm, nmus, w)
+        env.close()
+
+
 def test_autoreset_episode_matches_oracle(torch_mod, orc_lib):
     """Rollout form vs the reference loop `while(!done) do_step; reset()`, call by call.  The oracle mirrors the
     in-band reset (reset_begin, then one settle step per call, compute_step after the 60th) and the GPU state is
