@@ -412,6 +412,31 @@ def test_random_skeletons_match_the_oracle(torch_mod, orc_lib, tmp_path):
         env.close()
 
 
+def test_large_skeletons(torch_mod, orc_lib, tmp_path):
+    """Size limits.  The host tables hold 24 members / 20 muscles / 64 bodies, but a tile of 64 environments must fit the CU's
+    160 KB of LDS (3 KB per body + hull-scan partials): the 64-body skeleton is refused at creation with a message, and an
+    18-member star with 13 muscles (44 bodies, 56 joint visits per sweep, all hinges on one root) is built, stepped and held
+    to the oracle like the small ones."""
+    import pytest
+    from conftest import write_skeleton
+    from evomotion_amd._lib import EvmError
+    import test_schedule as ts
+    with pytest.raises(EvmError) as e:
+        make(8, parameters=dict(skeleton_json_path=ts._star(write_skeleton, tmp_path, 24, 20, "max.skel")))
+    assert "LDS" in str(e.value)
+    path = ts._star(write_skeleton, tmp_path, 18, 13, "large.skel")
+    n = 8
+    env = make(n, parameters=dict(skeleton_json_path=path))
+    orcs = [orc.OracleEnv(seed=900 + i, skeleton=path, lib=orc_lib) for i in range(n)]
+    assert env.n_bodies == 44 and env.action_dim == 13 and env.state_dim == 19 * 18 + 52
+    assert np.array_equal(env.body_constants()[:18].view(np.uint32), orcs[0].body_constants()[:18].view(np.uint32))
+    for o in orcs:
+        o.reset()
+    rng = np.random.default_rng(9)
+    w = _tf_compare(env, orcs, 44, 18, 13, 25, rng, 13)
+    assert w["pos"] < 5e-6 and w["lin"] < 1e-3 and w["ang"] < 5e-3 and w["obs"] < 5e-3, w
+
+
 def test_autoreset_episode_matches_oracle(torch_mod, orc_lib):
     """Rollout form vs the reference loop `while(!done) do_step; reset()`, call by call.  The oracle mirrors the
     in-band reset (reset_begin, then one settle step per call, compute_step after the 60th) and the GPU state is

@@ -246,3 +246,32 @@ def test_random_skeletons_schedule_validly(hip_lib, tmp_path):
             check_groups(visits, ent, gw, nm)
             built += 1
     assert built >= 100, built
+
+
+def _star(write, tmp_path, nm, nmus, name):
+    """a root with nm - 1 members hinged to it in a ring and nmus muscles from the root to the first members"""
+    members = [dict(name="body", mass=3.0, scale=(0.3, 0.15, 0.3))]
+    cons, mus = [], []
+    for k in range(1, nm):
+        a = 2 * np.pi * k / nm
+        d = np.array([0.5 * np.cos(a), 0.0, 0.5 * np.sin(a)])
+        members.append(dict(name=f"m{k}", mass=0.3, t=tuple(d), scale=(0.08, 0.06, 0.08)))
+        cons.append(dict(type="hinge", name=f"c{k}", parent="body", child=f"m{k}", pivot_p=tuple(d / 2), pivot_c=tuple(-d / 2),
+                         axis_p=(0, 1, 0), axis_c=(0, 1, 0), lo=-0.5, hi=0.5))
+    for j in range(nmus):
+        mus.append(dict(name=f"mu{j}", a="body", b=f"m{1 + j % (nm - 1)}", pos_a=(0.02, 0.08, 0.0), pos_b=(0.0, 0.05, 0.0)))
+    return write(tmp_path / name, members, cons, mus)
+
+
+def test_capacity_limits_are_errors_not_crashes(hip_lib, tmp_path):
+    """skel_const.h compiles the tables for 24 members / 24 hinges / 20 muscles / 64 bodies: the largest skeleton that fits is
+    scheduled, one member or one muscle more is refused with a message"""
+    import pytest
+    path = _star(write_skeleton, tmp_path, 24, 20, "max.skel")        # 24 members + 40 attach spheres = 64 bodies
+    visits, sched, nlev, nw = schedule(hip_lib, path)
+    assert len(visits) == 23 + 60
+    check(visits, sched, nlev, nw, 24)
+    for nm, nmus, name in ((25, 4, "members.skel"), (12, 21, "muscles.skel")):
+        with pytest.raises(Exception) as e:
+            schedule(hip_lib, _star(write_skeleton, tmp_path, nm, nmus, name))
+        assert "capacity" in str(e.value) or "exceed" in str(e.value), e.value
