@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <random>
 #include <string>
+#include <vector>
 
 #include "orc_world.h"
 
@@ -45,7 +46,63 @@ void *orc_env_create_kind(const char *skel_path, int seed, float initial_remaini
     if (!w->init(s, seed, p, g_err)) { delete w; return nullptr; }
     return w;
 }
+// ... and with the collision mode: self_collision 1 = member-vs-member contacts as in the reference, 0 = floor only
+void *orc_env_create_ex(const char *skel_path, int seed, float initial_remaining_seconds, float max_episode_seconds,
+                        float target_velocity, float minimal_velocity, int reset_frames, int env_kind, int self_collision) {
+    SkeletonDef s;
+    if (!load_skeleton(skel_path, s, g_err)) return nullptr;
+    EnvParams p;
+    p.initial_remaining_seconds = initial_remaining_seconds;
+    p.max_episode_seconds = max_episode_seconds;
+    p.target_velocity = target_velocity;
+    p.minimal_velocity = minimal_velocity;
+    p.reset_frames = reset_frames;
+    p.env_kind = env_kind;
+    p.self_collision = self_collision;
+    World *w = new World();
+    if (!w->init(s, seed, p, g_err)) { delete w; return nullptr; }
+    return w;
+}
 void orc_env_destroy(void *h) { delete (World *) h; }
+int orc_env_num_pairs(void *h) { return ((World *) h)->npairs(); }
+void orc_env_get_pairs(void *h, int *out) {  // [npairs, 2] member indices, solver order
+    World *w = (World *) h;
+    for (int i = 0; i < w->npairs(); i++) { out[2 * i] = w->pairs[i].a; out[2 * i + 1] = w->pairs[i].b; }
+}
+// narrowphase diagnostics of the last physics step: [pair contact points, pairs tested (boxes overlap), GJK iterations,
+// penetration-solver calls, pairs with a cached point], out_f[0] = deepest pair contact distance (<= 0)
+void orc_env_get_pair_stats(void *h, int *out, float *out_f) {
+    World *w = (World *) h;
+    int live = 0;
+    for (const PairManifold &pm : w->pairs) live += pm.mf.n > 0;
+    out[0] = w->last_num_pair_contacts; out[1] = w->last_pair_tests; out[2] = w->last_pair_gjk_iters;
+    out[3] = w->last_pair_penetration_calls; out[4] = live;
+    if (out_f) out_f[0] = w->last_max_pair_penetration;
+}
+// one narrowphase query between two free convex hulls given as world-space transforms (tests of orc_narrow.cpp on its own):
+// pts [n, 3] unscaled, xf = basis rows (9) + origin (3); out = has, normalOnB (3), pointOnB (3), distance, iterations,
+// degenerate code, method, used_penetration
+void orc_gjk_query(const float *ptsA, int nA, const float *scaleA, const float *xfA, const float *ptsB, int nB,
+                   const float *scaleB, const float *xfB, float max_dist2, float *out) {
+    std::vector<V3> pa(nA), pb(nB);
+    for (int i = 0; i < nA; i++) pa[i] = V3(ptsA[3 * i], ptsA[3 * i + 1], ptsA[3 * i + 2]);
+    for (int i = 0; i < nB; i++) pb[i] = V3(ptsB[3 * i], ptsB[3 * i + 1], ptsB[3 * i + 2]);
+    auto mk = [](const std::vector<V3> &p, const float *sc, const float *xf) {
+        ConvexView v;
+        v.pts = p.data(); v.n = (int) p.size();
+        v.scale = V3(sc[0], sc[1], sc[2]);
+        v.xf.b = M3(xf[0], xf[1], xf[2], xf[3], xf[4], xf[5], xf[6], xf[7], xf[8]);
+        v.xf.o = V3(xf[9], xf[10], xf[11]);
+        v.margin = 0.04f;
+        return v;
+    };
+    const ClosestResult r = gjk_closest_points(mk(pa, scaleA, xfA), mk(pb, scaleB, xfB), max_dist2);
+    out[0] = r.has ? 1.f : 0.f;
+    out[1] = r.normalOnB.x; out[2] = r.normalOnB.y; out[3] = r.normalOnB.z;
+    out[4] = r.pointOnB.x; out[5] = r.pointOnB.y; out[6] = r.pointOnB.z;
+    out[7] = r.distance; out[8] = (float) r.iterations; out[9] = (float) r.degenerate; out[10] = (float) r.method;
+    out[11] = r.used_penetration ? 1.f : 0.f;
+}
 int orc_env_obs_dim(void *h) { return ((World *) h)->obs_dim(); }
 int orc_env_act_dim(void *h) { return ((World *) h)->act_dim(); }
 int orc_env_num_bodies(void *h) { return ((World *) h)->nb(); }

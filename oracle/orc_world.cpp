@@ -293,6 +293,27 @@ bool World::init(const SkeletonDef &s, int seed, const EnvParams &p, std::string
     }
 
     manifolds.assign(nmember(), Manifold());
+    // member pairs that may collide: all but constraint parent/child (setIgnoreCollisionCheck, constraint.cpp:65,147);
+    // CF_NO_CONTACT_RESPONSE bodies (attach spheres, muscle.cpp:57-60; ignore_collision members, member.cpp:31-33) get no rows
+    pairs.clear();
+    if (prm.self_collision) {
+        for (int i = 0; i < nmember(); i++)
+            for (int j = i + 1; j < nmember(); j++) {
+                if (!bodies[i].contact_response || !bodies[j].contact_response) continue;
+                bool adjacent = false;
+                for (const ConstraintDef &c : skel.constraints)
+                    if ((c.parent == i && c.child == j) || (c.parent == j && c.child == i)) adjacent = true;
+                if (adjacent) continue;
+                PairManifold pm;
+                pm.a = i; pm.b = j;
+                pm.break_thr = std::min(bodies[i].break_thr, bodies[j].break_thr);
+                float f = bodies[i].friction * bodies[j].friction;
+                if (f < -10.f) f = -10.f;
+                if (f > 10.f) f = 10.f;
+                pm.friction = f;
+                pairs.push_back(pm);
+            }
+    }
     root = skel.member_index(skel.root_name);
     state_members.clear();
     state_members.push_back(root);
@@ -410,6 +431,88 @@ void World::collide() {
                 mf.n--;
             }
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// collision: member vs member  ([UPSTREAM] btConvexConvexAlgorithm::processCollision + btManifoldResult)
+// ------------------------------------------------------------------------------------------------
+ConvexView World::convex_view(int member) const {
+    const Body &B = bodies[member];
+    const ShapeDef &sh = skel.shapes[B.shape];
+    ConvexView v;
+    v.pts = sh.pts.data();
+    v.n = (int) sh.pts.size();
+    v.scale = B.scale;
+    v.xf = B.xf;
+    v.margin = MARGIN;
+    return v;
+}
+
+void World::collide_pairs() {
+    last_pair_tests = 0; last_pair_gjk_iters = 0; last_pair_penetration_calls = 0;
+    last_max_pair_penetration = 0.f;
+    if (pairs.empty()) return;
+    // world AABBs as btCollisionWorld::updateAabbs leaves them.  The broadphase only culls: a pair whose boxes are apart
+    // cannot be within the breaking threshold, and a cached point is gone (refresh below) long before the boxes part, so
+    // the contacts do not depend on Bullet's pair-cache hysteresis, which is not restated.
+    std::vector<V3> amin(nmember()), amax(nmember());
+    for (int i = 0; i < nmember(); i++) world_aabb(convex_view(i), G_BREAK, amin[i], amax[i]);
+    for (PairManifold &pm : pairs) {
+        const Body &A = bodies[pm.a], &B = bodies[pm.b];
+        Manifold &mf = pm.mf;
+        const bool overlap = amin[pm.a].x <= amax[pm.b].x && amax[pm.a].x >= amin[pm.b].x && amin[pm.a].y <= amax[pm.b].y &&
+                             amax[pm.a].y >= amin[pm.b].y && amin[pm.a].z <= amax[pm.b].z && amax[pm.a].z >= amin[pm.b].z;
+        if (overlap) {
+            last_pair_tests++;
+            // btConvexConvexAlgorithm: m_maximumDistanceSquared = (marginA + marginB + breaking threshold)^2
+            float md = MARGIN + MARGIN + pm.break_thr;
+            const ClosestResult r = gjk_closest_points(convex_view(pm.a), convex_view(pm.b), md * md);
+            last_pair_gjk_iters += r.iterations;
+            if (r.used_penetration) last_pair_penetration_calls++;
+            if (r.has && !(r.distance > pm.break_thr)) {
+                // btManifoldResult::addContactPoint(normalOnBInWorld, pointInWorld, depth)
+                const V3 pointA = r.pointOnB + r.normalOnB * r.distance;
+                ManifoldPoint np{};
+                np.localA = A.xf.invXform(pointA);
+                np.localB = B.xf.invXform(r.pointOnB);
+                np.posA = pointA; np.posB = r.pointOnB; np.normalB = r.normalOnB; np.dist = r.distance;
+                np.applied = 0; np.applied_lat = 0;
+                int idx = get_cache_entry(mf, np.localA, pm.break_thr);
+                if (idx >= 0) {
+                    np.applied = mf.p[idx].applied; np.applied_lat = mf.p[idx].applied_lat;
+                    mf.p[idx] = np;
+                } else {
+                    int ins = mf.n;
+                    if (ins == 4) ins = sort_cached_points(mf, np); else mf.n++;
+                    if (ins < 0) ins = 0;
+                    mf.p[ins] = np;
+                }
+            }
+        }
+        // btPersistentManifold::refreshContactPoints(trA, trB): the stored normal stays, positions and distance follow the bodies
+        for (int i = mf.n - 1; i >= 0; i--) {
+            ManifoldPoint &mp = mf.p[i];
+            mp.posA = A.xf(mp.localA);
+            mp.posB = B.xf(mp.localB);
+            mp.dist = dot(mp.posA - mp.posB, mp.normalB);
+        }
+        for (int i = mf.n - 1; i >= 0; i--) {
+            ManifoldPoint &mp = mf.p[i];
+            bool remove = false;
+            if (!(mp.dist <= pm.break_thr)) remove = true;
+            else {
+                V3 projected = mp.posA - mp.normalB * mp.dist;
+                V3 diff = mp.posB - projected;
+                if (dot(diff, diff) > pm.break_thr * pm.break_thr) remove = true;
+            }
+            if (remove) {
+                int last = mf.n - 1;
+                if (i != last) mf.p[i] = mf.p[last];
+                mf.n--;
+            }
+        }
+        for (int i = 0; i < mf.n; i++) last_max_pair_penetration = std::fmin(last_max_pair_penetration, mf.p[i].dist);
     }
 }
 
@@ -775,52 +878,55 @@ void World::solve() {
     }
     last_num_joint_rows = (int) jrows.size();
 
-    // ---- convertContacts ----  (body0 = floor/static, body1 = member)
+    // ---- convertContacts ----  manifolds in the order: floor-vs-member by member index (body0 = floor/static, body1 =
+    // member), then member-vs-member pairs in lexicographic order (body0 = a, body1 = b).  Bullet's own manifold order
+    // (dispatcher array, island sort) cannot be known; what is Bullet's is kept: per manifold point a normal row and one
+    // friction row, all normal rows solved before all friction rows, both kinds in manifold order.
     std::vector<Row> crows, frows;
-    struct CRef { int member, slot; };
+    struct CRef { Manifold *mf; int slot; };
     std::vector<CRef> cref;
     const float invTimeStep = 1.f / DT;
-    for (int mi = 0; mi < nmember(); mi++) {
-        Body &B = bodies[mi];
-        if (!B.contact_response) continue;
-        Manifold &mf = manifolds[mi];
-        float combinedFriction = floor_friction * B.friction;
-        if (combinedFriction < -10.f) combinedFriction = -10.f;
-        if (combinedFriction > 10.f) combinedFriction = 10.f;
+    last_num_pair_contacts = 0;
+    auto convert_manifold = [&](int ia, int ib, Manifold &mf, float combinedFriction) {
+        Body *A = ia >= 0 ? &bodies[ia] : nullptr;
+        Body &B = bodies[ib];
+        const V3 originA = A ? A->xf.o : floor_xf.o;
         for (int j = 0; j < mf.n; j++) {
             ManifoldPoint &cp = mf.p[j];
             // contact processing threshold = BT_LARGE_FLOAT: every cached point is processed
             const V3 n = cp.normalB;
-            V3 rel_pos1 = cp.posA - floor_xf.o;
+            V3 rel_pos1 = cp.posA - originA;
             V3 rel_pos2 = cp.posB - B.xf.o;
-            V3 vel1(0, 0, 0);
+            // getVelocityInLocalPointNoDelta
+            V3 vel1 = A ? A->lin + A->extF + cross(A->ang + A->extT, rel_pos1) : V3(0, 0, 0);
             V3 vel2 = B.lin + B.extF + cross(B.ang + B.extT, rel_pos2);
             V3 vel = vel1 - vel2;
             float rel_vel = dot(n, vel);
-            (void) rel_pos1;
             Row r{};
-            r.a = -1; r.b = mi; r.owner = j;
+            r.a = ia; r.b = ib; r.owner = j;
             // setupContactConstraint
+            V3 torqueAxis0 = cross(rel_pos1, n);
             V3 torqueAxis1 = cross(rel_pos2, n);
-            r.angA = V3();
+            r.angA = A ? A->iinv_world * torqueAxis0 : V3();
             r.angB = B.iinv_world * (-torqueAxis1);
             {
-                V3 vec = cross(-r.angB, rel_pos2);
-                float denom0 = 0.f;
-                float denom1 = B.inv_mass + dot(n, vec);
+                float denom0 = 0.f, denom1 = 0.f;
+                if (A) { V3 vec = cross(r.angA, rel_pos1); denom0 = A->inv_mass + dot(n, vec); }
+                { V3 vec = cross(-r.angB, rel_pos2); denom1 = B.inv_mass + dot(n, vec); }
                 r.jd = SOR / (denom0 + denom1 + GLOBAL_CFM * invTimeStep);
             }
-            r.n1 = V3(); r.c1 = V3();
+            if (A) { r.n1 = n; r.c1 = torqueAxis0; } else { r.n1 = V3(); r.c1 = V3(); }
             r.n2 = -n; r.c2 = -torqueAxis1;
             float penetration = cp.dist + LINEAR_SLOP;
             r.friction = combinedFriction;
             float restitution = 0.f;  // combined restitution is 0
             // warm start
             r.applied = cp.applied * WARMSTART;
+            if (A) apply_impulse(*A, r.n1 * A->inv_mass, r.angA, r.applied);
             apply_impulse(B, -r.n2 * B.inv_mass, -r.angB, -r.applied);
             r.applied_push = 0.f;
             {
-                float vel1Dotn = 0.f;
+                float vel1Dotn = A ? dot(r.n1, A->lin + A->extF) + dot(r.c1, A->ang + A->extT) : 0.f;
                 float vel2Dotn = dot(r.n2, B.lin + B.extF) + dot(r.c2, B.ang + B.extT);
                 float rv = vel1Dotn + vel2Dotn;
                 float positionalError = 0.f;
@@ -836,7 +942,8 @@ void World::solve() {
             }
             int normal_index = (int) crows.size();
             crows.push_back(r);
-            cref.push_back({mi, j});
+            cref.push_back({&mf, j});
+            if (A) last_num_pair_contacts++;
             // friction direction (velocity dependent, one direction)
             cp.latdir = vel - n * rel_vel;
             float lat_rel_vel = length2(cp.latdir);
@@ -848,21 +955,27 @@ void World::solve() {
             }
             // setupFrictionConstraint
             Row fr{};
-            fr.a = -1; fr.b = mi; fr.owner = j; fr.fric_of = normal_index;
+            fr.a = ia; fr.b = ib; fr.owner = j; fr.fric_of = normal_index;
             fr.friction = combinedFriction;
-            fr.n1 = V3(); fr.c1 = V3(); fr.angA = V3();
+            if (A) {
+                fr.n1 = cp.latdir;
+                fr.c1 = cross(rel_pos1, fr.n1);
+                fr.angA = A->iinv_world * fr.c1;
+            } else { fr.n1 = V3(); fr.c1 = V3(); fr.angA = V3(); }
             fr.n2 = -cp.latdir;
             V3 ft = cross(rel_pos2, fr.n2);
             fr.c2 = ft;
             fr.angB = B.iinv_world * ft;
             {
+                float denom0 = 0.f;
+                if (A) { V3 vec = cross(fr.angA, rel_pos1); denom0 = A->inv_mass + dot(cp.latdir, vec); }
                 V3 vec = cross(-fr.angB, rel_pos2);
                 float denom1 = B.inv_mass + dot(cp.latdir, vec);
-                fr.jd = SOR / (0.f + denom1);
+                fr.jd = SOR / (denom0 + denom1);
             }
             {
-                float vel1Dotn = 0.f;
-                float vel2Dotn = dot(fr.n2, B.lin + B.extF) + dot(fr.c2, B.ang);  // no external torque impulse
+                float vel1Dotn = A ? dot(fr.n1, A->lin + A->extF) + dot(fr.c1, A->ang) : 0.f;  // no external torque impulse
+                float vel2Dotn = dot(fr.n2, B.lin + B.extF) + dot(fr.c2, B.ang);
                 float rv = vel1Dotn + vel2Dotn;
                 float velocityError = 0.f - rv;
                 fr.rhs = velocityError * fr.jd;
@@ -871,10 +984,20 @@ void World::solve() {
             }
             // setFrictionConstraintImpulse (warm start)
             fr.applied = cp.applied_lat * WARMSTART;
+            if (A) apply_impulse(*A, fr.n1 * A->inv_mass, fr.angA, fr.applied);
             apply_impulse(B, -fr.n2 * B.inv_mass, -fr.angB, -fr.applied);
             frows.push_back(fr);
         }
+    };
+    for (int mi = 0; mi < nmember(); mi++) {
+        Body &B = bodies[mi];
+        if (!B.contact_response) continue;
+        float combinedFriction = floor_friction * B.friction;
+        if (combinedFriction < -10.f) combinedFriction = -10.f;
+        if (combinedFriction > 10.f) combinedFriction = 10.f;
+        convert_manifold(-1, mi, manifolds[mi], combinedFriction);
     }
+    for (PairManifold &pm : pairs) convert_manifold(pm.a, pm.b, pm.mf, pm.friction);
     last_num_contacts = (int) crows.size();
 
     auto dl = [&](int i) -> V3 { return i >= 0 ? bodies[i].dlin : V3(); };
@@ -901,13 +1024,14 @@ void World::solve() {
             float deltaImpulse = 0.f;
             if (c.rhs_pen != 0.f) {
                 deltaImpulse = c.rhs_pen - c.applied_push * c.cfm;
-                float d1 = 0.f;
+                float d1 = c.a >= 0 ? dot(c.n1, bodies[c.a].push) + dot(c.c1, bodies[c.a].turn) : 0.f;
                 float d2 = dot(c.n2, bodies[c.b].push) + dot(c.c2, bodies[c.b].turn);
                 deltaImpulse -= d1 * c.jd;
                 deltaImpulse -= d2 * c.jd;
                 float sum = c.applied_push + deltaImpulse;
                 if (sum < c.lo) { deltaImpulse = c.lo - c.applied_push; c.applied_push = c.lo; }
                 else c.applied_push = sum;
+                if (c.a >= 0) apply_push(bodies[c.a], c.n1 * bodies[c.a].inv_mass, c.angA, deltaImpulse);
                 apply_push(bodies[c.b], c.n2 * bodies[c.b].inv_mass, c.angB, deltaImpulse);
             }
             float res = deltaImpulse * (1.f / c.jd);
@@ -936,7 +1060,7 @@ void World::solve() {
 
     // ---- finish ----
     for (size_t i = 0; i < crows.size(); i++) {
-        ManifoldPoint &cp = manifolds[cref[i].member].p[cref[i].slot];
+        ManifoldPoint &cp = cref[i].mf->p[cref[i].slot];
         cp.applied = crows[i].applied;
         cp.applied_lat = frows[i].applied;
     }
@@ -981,6 +1105,7 @@ void World::integrate() {
 
 void World::physics_step() {
     collide();
+    collide_pairs();
     solve();
     integrate();
 }
@@ -1053,6 +1178,7 @@ void World::reset_begin() {
         // runs on the previous transform's tensor.
     }
     for (Manifold &m : manifolds) m.n = 0;  // removeRigidBody/addRigidBody drops every persistent manifold
+    for (PairManifold &pm : pairs) pm.mf.n = 0;
     reset_pending = true;
     reset_E = model.b;
 }
@@ -1077,7 +1203,8 @@ void World::do_step(const float *action, float *obs, float *reward, int *done) {
 // canonical state blob (layout documented in include/evomotion.h, EVM_STATE_*)
 // ------------------------------------------------------------------------------------------------
 int World::state_size() const {
-    return 13 * nb() + 1 + 9 + 6 * nb() + 3 * nmember() + 6 * nmember() + 37 * nmember() + nmuscle() + 1 + 2;
+    // ... then, with self_collision, per member pair in lexicographic order: count, 4 x (localA3 localB3 normalOnB3 dist applied applied_lateral)
+    return 13 * nb() + 1 + 9 + 6 * nb() + 3 * nmember() + 6 * nmember() + 37 * nmember() + nmuscle() + 1 + 2 + 49 * npairs();
 }
 void World::get_state(float *o) const {
     int k = 0;
@@ -1114,6 +1241,18 @@ void World::get_state(float *o) const {
     o[k++] = (!sliders.empty() && sliders[0].powered) ? 1.f : 0.f;
     o[k++] = (float) curr_step;
     o[k++] = (float) remaining_steps;
+    for (const PairManifold &pm : pairs) {
+        o[k++] = (float) pm.mf.n;
+        for (int j = 0; j < 4; j++) {
+            if (j < pm.mf.n) {
+                const ManifoldPoint &p = pm.mf.p[j];
+                o[k++] = p.localA.x; o[k++] = p.localA.y; o[k++] = p.localA.z;
+                o[k++] = p.localB.x; o[k++] = p.localB.y; o[k++] = p.localB.z;
+                o[k++] = p.normalB.x; o[k++] = p.normalB.y; o[k++] = p.normalB.z;
+                o[k++] = p.dist; o[k++] = p.applied; o[k++] = p.applied_lat;
+            } else for (int t = 0; t < 12; t++) o[k++] = 0.f;
+        }
+    }
 }
 void World::set_state(const float *in) {
     int k = 0;
@@ -1162,6 +1301,16 @@ void World::set_state(const float *in) {
     for (Slider &s : sliders) s.powered = powered;
     curr_step = (int) in[k++];
     remaining_steps = (int) in[k++];
+    for (PairManifold &pm : pairs) {
+        pm.mf.n = (int) in[k++];
+        for (int j = 0; j < 4; j++) {
+            ManifoldPoint &p = pm.mf.p[j];
+            p.localA = V3(in[k], in[k + 1], in[k + 2]); k += 3;
+            p.localB = V3(in[k], in[k + 1], in[k + 2]); k += 3;
+            p.normalB = V3(in[k], in[k + 1], in[k + 2]); k += 3;
+            p.dist = in[k++]; p.applied = in[k++]; p.applied_lat = in[k++];
+        }
+    }
 }
 void World::get_poses(float *o) const {
     int k = 0;

@@ -18,14 +18,17 @@
 // only by (a) analytic invariants (tests/test_oracle_physics.py) and (b) the independently verifiable
 // constants of SURVEY.md App. D (RNG stream, step counters, dimensions).
 //
-// Deliberate deviation (stated in DESIGN.md): collision detection is hull-vs-floor-plane only
-// (deepest hull vertex per step fed into a Bullet-style 4-point persistent manifold); member-vs-member
-// self collision, which Bullet would also run (GJK/EPA), is not modelled.
+// Collision: member hull vs the floor plane (deepest hull vertex per step fed into a Bullet-style 4-point persistent
+// manifold; the reference's floor is a 2000 x 2 x 2000 box hull, so GJK against it reduces to that up to the choice of
+// the point on a flat face) and, with EnvParams::self_collision, every member-vs-member pair the reference lets collide
+// (all but constraint parent/child: constraint.cpp:65,147) through the GJK narrowphase of orc_narrow.h into one
+// persistent manifold per pair, solved as two-dynamic-body normal + friction rows.
 #pragma once
 #include <string>
 #include <vector>
 
 #include "orc_math.h"
+#include "orc_narrow.h"
 
 namespace orc {
 
@@ -77,6 +80,7 @@ struct EnvParams {
     float target_velocity = 0.5f;
     float minimal_velocity = 0.1f;
     int reset_frames = 30;
+    int self_collision = 0;  // 1: member-vs-member contacts (the reference's behaviour); 0: floor contacts only
     int env_kind = 0;  // 0 robot_walk (robot_walk.cpp), 1 robot_jump (robot_jump.cpp:66-110): reward max(vy,0)+vz, fail on
                        // remaining < 0, reset yaw/roll/pitch within pi/3, `reset_frames` settle steps in ONE loop
 };
@@ -91,6 +95,15 @@ struct ManifoldPoint {
 struct Manifold {
     int n = 0;
     ManifoldPoint p[4];
+};
+// One persistent manifold per member pair that may collide; body0 = a < b = body1 (btBroadphasePair orders its proxies by
+// unique id = insertion order = member order, skeleton.cpp:92-103).  Pairs are kept in lexicographic (a, b) order, which is
+// also the order of their rows in the solver: Bullet's own order (hashed pair cache, island sort) cannot be known.
+struct PairManifold {
+    int a, b;
+    float break_thr;   // min of the two shapes' relative breaking thresholds (btCollisionDispatcher::getNewManifold)
+    float friction;    // calculateCombinedFriction: product of the two, clamped to +-10
+    Manifold mf;
 };
 
 struct Body {
@@ -169,6 +182,7 @@ public:
     std::vector<P2P> p2ps;
     std::vector<WorldConstraint> order;  // skeleton.cpp:77-90
     std::vector<Manifold> manifolds;     // one per member (vs floor)
+    std::vector<PairManifold> pairs;     // member-vs-member, lexicographic; empty unless prm.self_collision
     int root = 0;
     std::vector<int> state_members;  // root first, then non-root members in array order (skeleton.cpp:140-160)
     std::vector<V3> last_lin, last_ang;
@@ -181,6 +195,9 @@ public:
     M3 reset_E;
     // diagnostics of the last step
     int last_num_contacts = 0, last_num_joint_rows = 0;
+    int last_num_pair_contacts = 0;      // of last_num_contacts: points of member-vs-member manifolds
+    int last_pair_tests = 0, last_pair_gjk_iters = 0, last_pair_penetration_calls = 0;  // narrowphase work of the last step
+    float last_max_pair_penetration = 0; // deepest pair contact distance (negative = penetrating) after the last collide()
     float last_residual = 0;
 
     bool init(const SkeletonDef &s, int seed, const EnvParams &p, std::string &err);
@@ -203,8 +220,12 @@ public:
     void set_state(const float *in);
     void get_poses(float *out) const;  // nb x (px py pz qx qy qz qw)
 
+    int npairs() const { return (int) pairs.size(); }
+    ConvexView convex_view(int member) const;
+
 private:
     void collide();
+    void collide_pairs();
     void solve();
     void integrate();
 };

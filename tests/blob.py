@@ -2,7 +2,8 @@
 import numpy as np
 
 
-def fields(nb, nm, nmus):
+def fields(nb, nm, nmus, npairs=0):
+    """npairs > 0: the env runs with member-vs-member contacts; its blob ends with one 49-float manifold per pair"""
     out, k = {}, 0
 
     def add(name, n):
@@ -20,6 +21,7 @@ def fields(nb, nm, nmus):
     add("target", nmus)
     add("powered", 1)
     add("counters", 2)
+    add("pairs", 49 * npairs)   # per pair: count, 4 x (localA3 localB3 normalOnB3 dist applied applied_lateral)
     out["_size"] = k
     return out
 

@@ -9,7 +9,11 @@ the product) rolls the CPU oracle with uniform random actions and counts, per en
       separating-axis search over the face normals of both (oriented) boxes and the 9 edge cross products on the hulls'
       vertex sets — exact for the cube members, and for the feet applied to their vertex hull (conservative: "no
       separating axis found among those" counts as touching)
-   python tests/diag/self_collision_rate.py [--envs 8] [--steps 600]"""
+With --self-collision 1 the oracle runs WITH member-vs-member contacts (EvmEnvParams::self_collision, the reference's
+behaviour) and the same geometric test, independent of the oracle's own GJK, reports what is left: pairs still closer than the
+margins are the contacts being held (expected), pairs whose un-margined cores overlap would be real inter-penetration.  The
+oracle's narrowphase statistics ride along (pairs tested, GJK iterations, calls of the penetration solver).
+   python tests/diag/self_collision_rate.py [--envs 8] [--steps 600] [--self-collision 0|1]"""
 import argparse
 import os
 import sys
@@ -69,28 +73,34 @@ def separated(va, vb, Ra, Rb, gap):
     return False
 
 
-def count(poses, hulls, adjacent):
+def count(poses, hulls, adjacent, core_gap=0.0):
     nm = len(hulls)
     world = [poses[m, :3] + hulls[m] @ rot(poses[m, 3:]).T for m in range(nm)]
     lo = np.array([w.min(0) - MARGIN for w in world])
     hi = np.array([w.max(0) + MARGIN for w in world])
-    aabb = touch = 0
+    aabb = touch = core = 0
     for a in range(nm):
         for b in range(a + 1, nm):
             if frozenset((a, b)) in adjacent:
                 continue
             if np.all(lo[a] <= hi[b]) and np.all(lo[b] <= hi[a]):
                 aabb += 1
-                if not separated(world[a], world[b], rot(poses[a, 3:]), rot(poses[b, 3:]), 2 * MARGIN):
+                Ra, Rb = rot(poses[a, 3:]), rot(poses[b, 3:])
+                if not separated(world[a], world[b], Ra, Rb, 2 * MARGIN):
                     touch += 1
-    return aabb, touch
+                    if not separated(world[a], world[b], Ra, Rb, core_gap):
+                        core += 1
+    return aabb, touch, core
 
 
-def run(n_envs=8, steps=600, seed=1234, lib=None):
+def run(n_envs=8, steps=600, seed=1234, lib=None, self_collision=0, core_gap=0.07):
+    """core_gap: a pair counts as inter-penetrating when no tested axis separates the un-margined hulls by more than this
+    (0.07 = the margins have given way by more than 1 cm)"""
     names, hulls, adjacent = load_members()
-    out = dict(env_steps=0, steps_with_aabb_pair=0, steps_with_touching_pair=0, aabb_pairs=0, touching_pairs=0)
+    out = dict(env_steps=0, steps_with_aabb_pair=0, steps_with_touching_pair=0, aabb_pairs=0, touching_pairs=0, core_pairs=0,
+               pair_contacts=0, live_pairs=0, pair_tests=0, gjk_iterations=0, penetration_calls=0, deepest=0.0, steps_with_pair_contact=0)
     for i in range(n_envs):
-        e = orc.OracleEnv(seed=seed + i, lib=lib)
+        e = orc.OracleEnv(seed=seed + i, lib=lib, self_collision=self_collision)
         e.reset()
         rng = np.random.default_rng(seed + 1000 + i)
         done = False
@@ -99,10 +109,17 @@ def run(n_envs=8, steps=600, seed=1234, lib=None):
                 e.reset()
                 done = False
             _, _, done = e.do_step(rng.uniform(-1, 1, 12).astype(np.float32))
-            a, t = count(e.poses()[:17].astype(np.float64), hulls, adjacent)
+            a, t, c = count(e.poses()[:17].astype(np.float64), hulls, adjacent, core_gap)
             out["env_steps"] += 1
             out["aabb_pairs"] += a
             out["touching_pairs"] += t
+            out["core_pairs"] += c
+            if self_collision:
+                st = e.pair_stats()
+                for k_ in ("pair_contacts", "live_pairs", "pair_tests", "gjk_iterations", "penetration_calls"):
+                    out[k_] += st[k_]
+                out["deepest"] = min(out["deepest"], st["deepest"])
+                out["steps_with_pair_contact"] += st["pair_contacts"] > 0
             out["steps_with_aabb_pair"] += a > 0
             out["steps_with_touching_pair"] += t > 0
     return out
@@ -112,11 +129,19 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--envs", type=int, default=8)
     ap.add_argument("--steps", type=int, default=600)
+    ap.add_argument("--self-collision", type=int, default=0)
     a = ap.parse_args()
-    r = run(a.envs, a.steps)
+    r = run(a.envs, a.steps, self_collision=a.self_collision)
     n = r["env_steps"]
     print("env-steps %d (uniform random actions, resets included)" % n)
     print("non-adjacent member pairs with overlapping margin-inflated AABBs: %.2f per env-step; env-steps with at least one: %.1f %%"
           % (r["aabb_pairs"] / n, 100.0 * r["steps_with_aabb_pair"] / n))
     print("non-adjacent member pairs closer than the two margins (would get a Bullet contact point): %.3f per env-step; "
           "env-steps with at least one: %.1f %%" % (r["touching_pairs"] / n, 100.0 * r["steps_with_touching_pair"] / n))
+    print("of those, pairs whose cores are within 0.07 m (margins given way by more than 1 cm): %.4f per env-step" % (r["core_pairs"] / n))
+    if a.self_collision:
+        print("oracle narrowphase: %.2f pairs tested per env-step (boxes overlap), %.2f GJK iterations per test, penetration solver "
+              "called in %d of %d tests; %.2f live pair manifolds and %.2f pair contact points per env-step, env-steps with a pair "
+              "contact %.1f %%; deepest pair contact distance %.4f m (margins are 0.08 m together)"
+              % (r["pair_tests"] / n, r["gjk_iterations"] / max(r["pair_tests"], 1), r["penetration_calls"], r["pair_tests"],
+                 r["live_pairs"] / n, r["pair_contacts"] / n, 100.0 * r["steps_with_pair_contact"] / n, r["deepest"]))

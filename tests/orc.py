@@ -28,6 +28,12 @@ def load():
     L.orc_env_create.argtypes = [ctypes.c_char_p, ctypes.c_int] + [ctypes.c_float] * 4 + [ctypes.c_int]
     L.orc_env_create_kind.restype = vp
     L.orc_env_create_kind.argtypes = [ctypes.c_char_p, ctypes.c_int] + [ctypes.c_float] * 4 + [ctypes.c_int, ctypes.c_int]
+    L.orc_env_create_ex.restype = vp
+    L.orc_env_create_ex.argtypes = [ctypes.c_char_p, ctypes.c_int] + [ctypes.c_float] * 4 + [ctypes.c_int] * 3
+    L.orc_env_num_pairs.argtypes = [vp]
+    L.orc_env_get_pairs.argtypes = [vp, ip]
+    L.orc_env_get_pair_stats.argtypes = [vp, ip, fp]
+    L.orc_gjk_query.argtypes = [fp, ctypes.c_int, fp, fp, fp, ctypes.c_int, fp, fp, ctypes.c_float, fp]
     L.orc_env_destroy.argtypes = [vp]
     for f in ["orc_env_obs_dim", "orc_env_act_dim", "orc_env_num_bodies", "orc_env_num_members", "orc_env_state_size"]:
         getattr(L, f).argtypes = [vp]
@@ -50,14 +56,36 @@ def load():
     return L
 
 
+# collision mode of the oracle envs the tests create unless they say otherwise: 1 = member-vs-member contacts (the
+# reference's behaviour), 0 = floor contacts only
+SELF_COLLISION_DEFAULT = 0
+
+
+def gjk_query(ptsA, scaleA, xfA, ptsB, scaleB, xfB, max_dist2=1e18, lib=None):
+    """One narrowphase query between two convex hulls (unscaled points, scaling, (basis rows, origin))."""
+    L = lib or load()
+    a = np.ascontiguousarray(ptsA, np.float32).reshape(-1, 3)
+    b = np.ascontiguousarray(ptsB, np.float32).reshape(-1, 3)
+    sa = np.ascontiguousarray(scaleA, np.float32)
+    sb = np.ascontiguousarray(scaleB, np.float32)
+    xa = np.ascontiguousarray(np.concatenate([np.asarray(xfA[0], np.float32).ravel(), np.asarray(xfA[1], np.float32)]))
+    xb = np.ascontiguousarray(np.concatenate([np.asarray(xfB[0], np.float32).ravel(), np.asarray(xfB[1], np.float32)]))
+    out = np.zeros(12, np.float32)
+    L.orc_gjk_query(a.ctypes.data_as(fp), len(a), sa.ctypes.data_as(fp), xa.ctypes.data_as(fp), b.ctypes.data_as(fp), len(b),
+                    sb.ctypes.data_as(fp), xb.ctypes.data_as(fp), ctypes.c_float(max_dist2), out.ctypes.data_as(fp))
+    return dict(has=bool(out[0]), normal=out[1:4].copy(), point_b=out[4:7].copy(), distance=float(out[7]), iterations=int(out[8]),
+                degenerate=int(out[9]), method=int(out[10]), used_penetration=bool(out[11]))
+
+
 class OracleEnv:
     """One scalar oracle environment (reference semantics: reset() / do_step(action))."""
 
     def __init__(self, seed=1234, skeleton=SKEL, initial_remaining_seconds=1.0, max_episode_seconds=30.0,
-                 target_velocity=0.5, minimal_velocity=0.1, reset_frames=30, lib=None, env_kind=0):
+                 target_velocity=0.5, minimal_velocity=0.1, reset_frames=30, lib=None, env_kind=0, self_collision=SELF_COLLISION_DEFAULT):
         self.L = lib or load()
-        self.h = self.L.orc_env_create_kind(skeleton.encode(), seed, initial_remaining_seconds, max_episode_seconds,
-                                            target_velocity, minimal_velocity, reset_frames, env_kind)
+        self.self_collision = int(self_collision)
+        self.h = self.L.orc_env_create_ex(skeleton.encode(), seed, initial_remaining_seconds, max_episode_seconds,
+                                          target_velocity, minimal_velocity, reset_frames, env_kind, self.self_collision)
         if not self.h:
             raise RuntimeError(self.L.orc_last_error().decode())
         self.obs_dim = self.L.orc_env_obs_dim(self.h)
@@ -127,6 +155,20 @@ class OracleEnv:
         p = np.zeros((self.nb, 7), np.float32)
         self.L.orc_env_get_poses(self.h, p.ctypes.data_as(fp))
         return p
+
+    def pairs(self):
+        n = self.L.orc_env_num_pairs(self.h)
+        p = np.zeros((n, 2), np.int32)
+        if n:
+            self.L.orc_env_get_pairs(self.h, p.ctypes.data_as(ip))
+        return p
+
+    def pair_stats(self):
+        c = np.zeros(5, np.int32)
+        f = np.zeros(1, np.float32)
+        self.L.orc_env_get_pair_stats(self.h, c.ctypes.data_as(ip), f.ctypes.data_as(fp))
+        return dict(pair_contacts=int(c[0]), pair_tests=int(c[1]), gjk_iterations=int(c[2]), penetration_calls=int(c[3]),
+                    live_pairs=int(c[4]), deepest=float(f[0]))
 
     def body_constants(self):
         p = np.zeros((self.nb, 19), np.float32)

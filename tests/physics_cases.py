@@ -19,11 +19,12 @@ MARGIN = 0.04
 class OracleWorld:
     name = "oracle"
 
-    def __init__(self, skeleton, seed=1, lib=None):
+    def __init__(self, skeleton, seed=1, lib=None, self_collision=0):
         import orc
-        self.e = orc.OracleEnv(seed=seed, skeleton=skeleton, lib=lib)
+        self.e = orc.OracleEnv(seed=seed, skeleton=skeleton, lib=lib, self_collision=self_collision)
         self.nb, self.nm = self.e.nb, self.e.nm
         self.nmus = self.e.act_dim
+        self.npairs = len(self.e.pairs())
         self.e.reset_begin()
 
     def state(self):
@@ -45,10 +46,11 @@ class OracleWorld:
 class HipWorld:
     name = "hip"
 
-    def __init__(self, skeleton, seed=1, lib=None):
+    def __init__(self, skeleton, seed=1, lib=None, self_collision=0):
         from evomotion_amd import VecRobotWalk
-        self.env = VecRobotWalk(1, seed=seed, device=0, parameters={"skeleton_json_path": skeleton})
+        self.env = VecRobotWalk(1, seed=seed, device=0, parameters={"skeleton_json_path": skeleton, "self_collision": self_collision})
         self.nb, self.nm, self.nmus = self.env.n_bodies, self.env.n_members, self.env.action_dim
+        self.npairs = self.env.n_pairs
         self.env.debug_reset_begin()
 
     def state(self):
@@ -71,7 +73,7 @@ class HipWorld:
 
 # ---- state helpers ----------------------------------------------------------------------------------------------------
 def fields(w):
-    return blobmod.fields(w.nb, w.nm, w.nmus)
+    return blobmod.fields(w.nb, w.nm, w.nmus, getattr(w, "npairs", 0))
 
 
 def clean_state(w, pos, quat=None, lin=None, ang=None):
@@ -92,6 +94,7 @@ def clean_state(w, pos, quat=None, lin=None, ang=None):
     m[:] = 0
     s[f["target"]] = 0
     s[f["powered"]] = 0
+    s[f["pairs"]] = 0
     w.set_state(s)
     return s
 
@@ -102,6 +105,11 @@ def bodies(w):
 
 def manifold_counts(w):
     return w.state()[fields(w)["manifold"]].reshape(w.nm, 37)[:, 0]
+
+
+def pair_manifolds(w):
+    """[npairs, 49]: count, then 4 x (localA3 localB3 normalOnB3 dist applied applied_lateral)"""
+    return w.state()[fields(w)["pairs"]].reshape(w.npairs, 49).astype(np.float64)
 
 
 def quat_z(theta):
@@ -479,3 +487,116 @@ def check_hinge_removes_off_axis_rotation(w, base_y):
         worst = max(worst, 1.0 - float(np.dot(za, zb)))
     assert worst < 1e-4, worst
     return float(np.abs(rel[:2]).max()), worst
+
+
+# ---- member-vs-member contacts (EvmEnvParams::self_collision; the reference lets every pair of members collide except
+# constraint parent / child: constraint.cpp:65,147) ----------------------------------------------------------------------
+def skel_two_free_boxes(write_skeleton, tmp_path, half_a=(0.5, 0.2, 0.5), half_b=(0.15, 0.15, 0.15), mass_a=4.0, mass_b=0.5,
+                        name="two_boxes.skel"):
+    """two members and no constraint between them: one collidable pair"""
+    members = [dict(name="body", mass=mass_a, scale=half_a), dict(name="other", mass=mass_b, t=(0.0, 1.0, 0.0), scale=half_b)]
+    return write_skeleton(tmp_path / name, members)
+
+
+def check_box_rests_on_box(w, half_a=(0.5, 0.2, 0.5), half_b=(0.15, 0.15, 0.15)):
+    """a small box set down on a big one that lies on the floor: both hulls carry the 0.04 margin, so the cores come to rest
+    0.08 apart (exactly like a box on the floor), the pair's persistent manifold fills to four points (one new point per step,
+    like every convex-convex pair of the reference), and nothing sinks or drifts"""
+    assert w.npairs == 1
+    ya = FLOOR_TOP + 2 * MARGIN + half_a[1]
+    yb = ya + half_a[1] + 2 * MARGIN + half_b[1]
+    clean_state(w, [[0.0, ya, 0.0], [0.1, yb + 0.03, -0.05]])
+    w.step(400)
+    b = bodies(w)
+    assert np.isfinite(b).all()
+    assert abs(b[0, 1] - ya) < 8e-3, (b[0, 1], ya)
+    gap = (b[1, 1] - half_b[1]) - (b[0, 1] + half_a[1])
+    assert abs(gap - 2 * MARGIN) < 8e-3, gap
+    assert np.abs(b[:2, 7:10]).max() < 3e-2 and np.abs(b[:2, 10:13]).max() < 8e-2
+    assert abs(b[1, 0] - 0.1) < 2e-2 and abs(b[1, 2] + 0.05) < 2e-2          # friction holds it where it was set down
+    pm = pair_manifolds(w)
+    assert int(pm[0, 0]) == 4, pm[0, 0]
+    pts = pm[0, 1:].reshape(4, 12)
+    assert np.all(pts[:, 7] < -0.999)                                         # normal on B (the upper box) points down, at A
+    assert np.all(pts[:, 10] >= 0) and pts[:, 10].sum() > 0                   # normal impulses push, never pull
+    # the four normal impulses of a step carry the upper box's weight
+    mb = float(w.body_constants()[1, 0])
+    assert abs(pts[:, 10].sum() - mb * G * DT) < 0.05 * mb * G * DT, (pts[:, 10].sum(), mb * G * DT)
+    return gap, pts[:, 10].sum()
+
+
+def check_free_boxes_collide_inelastically(w, half=0.15, mass_a=4.0, mass_b=0.5):
+    """two boxes meet head-on far above the floor: every contact row pushes the two bodies with equal and opposite impulses, so
+    the total momentum is the free-fall momentum to rounding; restitution is zero, so along the contact normal they separate no
+    faster than the solver's position correction; and the cores never get closer than the two margins allow (minus one step of
+    approach)"""
+    v = 1.5
+    pos = np.array([[0.0, 3000.0, 0.0], [1.2, 3000.0, 0.02]])
+    lin = np.array([[0.0, 0.0, 0.0], [-v, 0.0, 0.0]])
+    clean_state(w, pos, lin=lin)
+    m = np.array([mass_a, mass_b])
+    p0 = (m[:, None] * lin).sum(0)
+    touched, min_gap = False, 1e9
+    hx_a = float(w.body_constants()[0, 0]) and 0.5   # half extent of "body" along x (skel_two_free_boxes default)
+    for k in range(90):
+        w.step()
+        b = bodies(w)
+        gap = (b[1, 0] - half) - (b[0, 0] + hx_a)
+        min_gap = min(min_gap, gap)
+        touched = touched or int(pair_manifolds(w)[0, 0]) > 0
+        p = (m[:, None] * b[:2, 7:10]).sum(0)
+        assert abs(p[0] - p0[0]) < 2e-5 * m.sum() and abs(p[2] - p0[2]) < 2e-5 * m.sum(), (k, p, p0)
+    assert touched
+    assert min_gap > 2 * MARGIN - v * DT - 5e-3, min_gap                      # never deeper than one step of approach
+    b = bodies(w)
+    rel = b[1, 7] - b[0, 7]                                                    # separation speed along x afterwards
+    assert -1e-3 < rel < 0.2 * 0.04 / DT + 0.02, rel                           # no bounce beyond the erp correction
+    v_common = p0[0] / m.sum()
+    assert abs(b[0, 7] - v_common) < 0.12 and abs(b[1, 7] - v_common) < 0.6    # both near the common velocity
+    return min_gap, rel
+
+
+def skel_folding_arm(write_skeleton, tmp_path):
+    """body - upper - lower chained by two z hinges, laid out straight along +x: `lower` (the forearm, 1 m long) and `body` share
+    no constraint, so they may collide when the elbow folds the forearm back over the 0.8 m upper arm"""
+    members = [dict(name="body", mass=50.0, scale=(0.3, 0.3, 0.3)),
+               dict(name="upper", mass=0.5, t=(0.7, 0.0, 0.0), scale=(0.4, 0.05, 0.05)),
+               dict(name="lower", mass=0.5, t=(1.6, 0.0, 0.0), scale=(0.5, 0.05, 0.05))]
+    cons = [dict(type="hinge", name="h0", parent="body", child="upper", pivot_p=(0.3, 0.0, 0.0), pivot_c=(-0.4, 0.0, 0.0),
+                 axis_p=(0, 0, 1), axis_c=(0, 0, 1), lo=-0.1, hi=0.1),
+            dict(type="hinge", name="h1", parent="upper", child="lower", pivot_p=(0.4, 0.06, 0.0), pivot_c=(-0.5, 0.06, 0.0),
+                 axis_p=(0, 0, 1), axis_c=(0, 0, 1), lo=-3.1, hi=3.1)]
+    return write_skeleton(tmp_path / "folding_arm.skel", members, cons)
+
+
+def check_folded_arm_stops_at_the_body(w, omega=2.0):
+    """the forearm is swung about its elbow, up and over, back towards the body.  With member-vs-member contacts its tip
+    lands on the body's top face and stays outside it — cores 0.08 apart, less one step of approach; with floor contacts only
+    it sinks into the body until the elbow's own limit stops it"""
+    y0 = 3000.0
+    pos = np.array([[0.0, y0, 0.0], [0.7, y0, 0.0], [1.6, y0, 0.0]])
+    elbow = np.array([1.1, y0 + 0.06, 0.0])
+    lin = np.zeros((3, 3))
+    lin[2] = np.cross([0, 0, omega], pos[2] - elbow)
+    ang = np.zeros((3, 3))
+    ang[2] = [0, 0, omega]
+    clean_state(w, pos, lin=lin, ang=ang)
+    # sample the forearm's box densely (the closest feature is the body's top edge against the forearm's underside)
+    gx, gy, gz = np.meshgrid(np.linspace(-1, 1, 81), np.linspace(-1, 1, 5), np.linspace(-1, 1, 5), indexing="ij")
+    corners = np.stack([gx.ravel(), gy.ravel(), gz.ravel()], 1)
+    ha, hc = np.array([0.3, 0.3, 0.3]), np.array([0.5, 0.05, 0.05])
+    deepest, touched = 1e9, False
+    for k in range(170):
+        w.step()
+        b = bodies(w)
+        assert np.isfinite(b).all()
+        # signed distance of the forearm's sample points to the body's box (in the body's frame)
+        Ra, Rc = rot(b[0, 3:7]), rot(b[2, 3:7])
+        pc = (Rc @ (corners * hc).T).T + b[2, 0:3]
+        loc = (Ra.T @ (pc - b[0, 0:3]).T).T
+        q = np.abs(loc) - ha
+        sd = np.linalg.norm(np.maximum(q, 0), axis=1) + np.minimum(q.max(1), 0)
+        deepest = min(deepest, sd.min())
+        if w.npairs:
+            touched = touched or pair_manifolds(w)[:, 0].sum() > 0
+    return deepest, touched

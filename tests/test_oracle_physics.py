@@ -222,6 +222,28 @@ def test_known_answer_hinge_removes_off_axis_rotation(orc_lib, tmp_path):
     print("off-axis relative spin after one step %.2e rad/s; hinge axes 1 - cos(angle) <= %.1e over 120 steps" % (left, tilt))
 
 
+# ---- member-vs-member contacts: known answers (the same checks run on the HIP path in tests/test_gpu_physics.py) ----
+def test_known_answer_box_rests_on_box(orc_lib, tmp_path):
+    gap, imp = pc.check_box_rests_on_box(pc.OracleWorld(pc.skel_two_free_boxes(write_skeleton, tmp_path), lib=orc_lib, self_collision=1))
+    print("box on box: core gap %.4f m (2 margins = 0.08), normal impulse sum %.5f" % (gap, imp))
+
+
+def test_known_answer_free_boxes_collide_inelastically(orc_lib, tmp_path):
+    sk = pc.skel_two_free_boxes(write_skeleton, tmp_path, half_b=(0.15, 0.15, 0.15))
+    min_gap, rel = pc.check_free_boxes_collide_inelastically(pc.OracleWorld(sk, lib=orc_lib, self_collision=1))
+    print("head-on boxes: smallest core gap %.4f m, separation speed afterwards %.4f m/s" % (min_gap, rel))
+
+
+def test_known_answer_folded_arm_stops_at_the_body(orc_lib, tmp_path):
+    sk = pc.skel_folding_arm(write_skeleton, tmp_path)
+    deep1, touched = pc.check_folded_arm_stops_at_the_body(pc.OracleWorld(sk, lib=orc_lib, self_collision=1))
+    deep0, _ = pc.check_folded_arm_stops_at_the_body(pc.OracleWorld(sk, lib=orc_lib, self_collision=0))
+    print("forearm vs body: closest core distance %.4f m with member contacts, %.4f m without" % (deep1, deep0))
+    assert touched
+    assert deep1 > 2 * pc.MARGIN - 2.0 * 1.0 * pc.DT - 0.01, deep1     # stops at the margins, less one step of the tip's approach
+    assert deep0 < -0.02, deep0                                         # plane-only: it passes through the body
+
+
 def test_self_collision_rate_diagnostic(orc_lib):
     """tests/diag/self_collision_rate.py (oracle side): the measurement behind DESIGN.md's statement of the plane-contact deviation —
     how often non-adjacent member pairs come within Bullet's collision margins.  Here only that the diagnostic runs and is
