@@ -20,6 +20,7 @@ class EvmEnvParams(ctypes.Structure):
         ("minimal_velocity", ctypes.c_float),
         ("reset_frames", ctypes.c_int),
         ("env_kind", ctypes.c_int),
+        ("self_collision", ctypes.c_int),
     ]
 
 
@@ -44,6 +45,7 @@ def _load():
     lib.evm_env_destroy.restype = None
     lib.evm_env_spaces.argtypes = [vp, ip, ip]
     lib.evm_env_counts.argtypes = [vp, ip, ip, ip, ip]
+    lib.evm_env_pairs.argtypes = [vp, ip, ip]
     lib.evm_env_reset.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.evm_env_step.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.evm_env_step_autoreset.argtypes = [vp, vp, vp, vp, vp, vp, vp]
@@ -59,6 +61,7 @@ def _load():
     lib.evm_skeleton_digest.argtypes = [cp, ctypes.POINTER(ctypes.c_ulonglong)]
     lib.evm_skeleton_schedule.argtypes = [cp, ip, ip, ip, ctypes.c_int]
     lib.evm_skeleton_group_schedule.argtypes = [cp, ctypes.c_int, ip, ip, ctypes.c_int]
+    lib.evm_skeleton_group_schedule_ex.argtypes = [cp, ctypes.c_int, ctypes.c_int, ip, ip, ctypes.c_int]
     lib.evm_env_get_residual.argtypes = [vp, fp, ctypes.c_int, vp]
     lib.evm_env_get_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_longlong)]
     lib.evm_env_clear_stats.argtypes = [vp]

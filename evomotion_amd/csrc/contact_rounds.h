@@ -1,0 +1,228 @@
+// Member-vs-member mode (EvmSkelC::self_collision) of the lane-group sweeps kernel: the contact rows of a sweep — floor
+// manifolds and member pairs alike — run AFTER the sweep's joint rows as rounds of body-disjoint manifolds, chosen per
+// environment at run time.  Included by sweep_groups.h (same translation unit: GCtx, g_load_body, ...).
+//
+// Order kept: Bullet solves, per iteration, all joint rows, then all contact normal rows, then all friction rows, both in
+// manifold order (btSequentialImpulseConstraintSolver::solveSingleIteration).  The manifold order here is: floor-vs-member
+// by member index, then the pairs in table order (Bullet's own order — dispatcher array, island sort — cannot be known).
+// Two manifolds that share no body commute exactly, so a greedy levelling of that list (a manifold goes to the first round
+// after the last round of either of its bodies) reproduces the sequential order bit for bit whatever the round sizes.
+//
+// Execution: every (wave, lane group) pair is a SLOT; slot s of environment e owns the s-th active manifold of that env
+// for the whole step (16 slots; a robot has been seen with 14 live manifolds in 5 000 random env-steps, an env with more
+// leaves the surplus out for that step and raises the sticky residual flag).  The owner keeps the manifold's record (4 points x 5 quads)
+// and its accumulated impulses in registers across the ten sweeps; bodies are read from and written to the workgroup's LDS
+// image with per-lane body indices ([quad][16 lanes]: the bank depends on the env column only, so any mix of bodies is
+// conflict-free).  A round is closed by a workgroup barrier.
+#pragma once
+
+namespace evm {
+
+struct CBank {
+    int id;       // manifold id: member m (floor) or nm + pair; -1 = none
+    int a, b;     // body0 (-1: the static floor) and body1
+    int round;
+    f32x4 q[20];  // the contact record: per point quads 0..4 (skel_const.h, EVM_CR_STRIDE); the accumulated impulses of the
+                  // sweeps live in its applied_n / applied_f fields
+};
+#define K_APN(K, j) ((K).q[5 * (j) + 2][3])
+#define K_APF(K, j) ((K).q[5 * (j) + 4][1])
+DEV void g_lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+// body b (per-lane index) as a row operand; b < 0: the static floor (zero inverse mass and inertia, never stored)
+DEV BodyD g_body_any(const GCtx &G, int b, const float *imt) {
+    const int bb = b < 0 ? 0 : b;
+    BodyD k = g_load_body(G, bb, imt[bb]);
+    if (b < 0) { k.dl = f3(0, 0, 0); k.da = f3(0, 0, 0); k.I.xx = k.I.xy = k.I.xz = k.I.yy = k.I.yz = k.I.zz = 0.f; k.im = 0.f; }
+    return k;
+}
+// one two-body row along `dir` (contact normal or friction direction): resolveSingleConstraintRowGeneric / LowerLimit
+DEV float g_row2(F3 dir, F3 relA, F3 relB, BodyD &A, BodyD &B, float jd, float rhs, float lo, float hi, float &ap) {
+    const F3 c1 = cross(relA, dir), c2 = -cross(relB, dir);
+    const float d1 = dot(dir, A.dl) + dot(c1, A.da);
+    const float d2 = -dot(dir, B.dl) + dot(c2, B.da);
+    float dI = rhs;
+    dI -= d1 * jd;
+    dI -= d2 * jd;
+    const float sum = ap + dI;
+    if (sum < lo) { dI = lo - ap; ap = lo; }
+    else if (sum > hi) { dI = hi - ap; ap = hi; }
+    else ap = sum;
+    A.dl = A.dl + dir * (A.im * dI);
+    A.da = A.da + mul(A.I, c1) * dI;
+    B.dl = B.dl - dir * (B.im * dI);
+    B.da = B.da + mul(B.I, c2) * dI;
+    return dI;
+}
+// PHASE 0: warm start (convertContact applies the cached impulses x 0.85, per point normal then friction)
+//       1: normal rows   2: friction rows (limits +-mu x the point's normal impulse of this sweep)
+template <int PHASE>
+DEV float g_contact_bank(const GCtx &G, CBank &K, bool on, const float *imt) {
+    float res = 0.f;
+    if (!__any(on)) return res;
+    BodyD A, B;
+    if (on) { A = g_body_any(G, K.a, imt); B = g_body_any(G, K.b, imt); }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const bool live = on && K.q[5 * j][3] != 0.f;  // jd_n = 1 / denominator > 0 for a live point
+        if (!__any(live)) continue;
+        if (live) {
+            const F3 relA = f3(K.q[5 * j][0], K.q[5 * j][1], K.q[5 * j][2]);
+            const F3 relB = f3(K.q[5 * j + 1][0], K.q[5 * j + 1][1], K.q[5 * j + 1][2]);
+            const F3 nrm = f3(K.q[5 * j + 2][0], K.q[5 * j + 2][1], K.q[5 * j + 2][2]);
+            const F3 lat = f3(K.q[5 * j + 3][0], K.q[5 * j + 3][1], K.q[5 * j + 3][2]);
+            if (PHASE == 0) {
+                // internalApplyImpulse(n1 * imA, angA, ap) on body0, (-n2 * imB, -angB, -ap) on body1 for the normal row, then
+                // the same with the friction direction
+                const float an = K_APN(K, j), af = K_APF(K, j);
+                const F3 c1 = cross(relA, nrm), c2 = cross(relB, nrm);
+                A.dl = A.dl + (nrm * A.im) * an; A.da = A.da + mul(A.I, c1) * an;
+                B.dl = B.dl + (nrm * B.im) * (-an); B.da = B.da + mul(B.I, c2) * (-an);
+                const F3 f1 = cross(relA, lat), f2 = cross(relB, lat);
+                A.dl = A.dl + (lat * A.im) * af; A.da = A.da + mul(A.I, f1) * af;
+                B.dl = B.dl + (lat * B.im) * (-af); B.da = B.da + mul(B.I, f2) * (-af);
+            } else if (PHASE == 1) {
+                float ap = K_APN(K, j);
+                res = fmaxf(res, fabsf(g_row2(nrm, relA, relB, A, B, K.q[5 * j][3], K.q[5 * j + 1][3], 0.f, 1e10f, ap)));
+                K_APN(K, j) = ap;
+            } else {
+                if (K_APN(K, j) > 0.f) {
+                    const float lim = K.q[4][3] * K_APN(K, j);  // mu x the point's normal impulse
+                    float ap = K_APF(K, j);
+                    res = fmaxf(res, fabsf(g_row2(lat, relA, relB, A, B, K.q[5 * j + 3][3], K.q[5 * j + 4][0], -lim, lim, ap)));
+                    K_APF(K, j) = ap;
+                }
+            }
+        }
+    }
+    if (on) {
+        if (K.a >= 0) g_store_body(G, K.a, A);
+        g_store_body(G, K.b, B);
+    }
+    return res;
+}
+// split-impulse recovery of one manifold (resolveSplitPenetrationImpulse): push / turn velocities of the two bodies live in
+// the tile's scratch (sc_pt, per-lane body index); rare (a point deeper than the 0.04 threshold), so no LDS is spent on it
+DEV void g_split_bank(const GCtx &G, const Ctx &c, const CBank &K, bool on, float (&push_ap)[4], const float *imt) {
+    bool pen = false;
+#pragma unroll
+    for (int j = 0; j < 4; j++) pen = pen || (on && K.q[5 * j + 4][2] != 0.f);
+    if (!__any(pen)) return;
+    if (!pen) return;
+    const int ba = K.a < 0 ? 0 : K.a;
+    float *pa = c.t.scratch + ((size_t) (c_skel.sc_pt + 6 * ba) << 6) + c.lane;
+    float *pb = c.t.scratch + ((size_t) (c_skel.sc_pt + 6 * K.b) << 6) + c.lane;
+    BodyD A = g_body_any(G, K.a, imt), B = g_body_any(G, K.b, imt);  // inertia + inverse mass; dl = push, da = turn below
+    A.dl = K.a < 0 ? f3(0, 0, 0) : f3(pa[0], pa[64], pa[128]);
+    A.da = K.a < 0 ? f3(0, 0, 0) : f3(pa[192], pa[256], pa[320]);
+    B.dl = f3(pb[0], pb[64], pb[128]);
+    B.da = f3(pb[192], pb[256], pb[320]);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const float rp = K.q[5 * j + 4][2];
+        if (rp != 0.f) {
+            const F3 relA = f3(K.q[5 * j][0], K.q[5 * j][1], K.q[5 * j][2]);
+            const F3 relB = f3(K.q[5 * j + 1][0], K.q[5 * j + 1][1], K.q[5 * j + 1][2]);
+            const F3 nrm = f3(K.q[5 * j + 2][0], K.q[5 * j + 2][1], K.q[5 * j + 2][2]);
+            g_row2(nrm, relA, relB, A, B, K.q[5 * j][3], rp, 0.f, EVM_INF, push_ap[j]);
+        }
+    }
+    if (K.a >= 0) { pa[0] = A.dl.x; pa[64] = A.dl.y; pa[128] = A.dl.z; pa[192] = A.da.x; pa[256] = A.da.y; pa[320] = A.da.z; }
+    pb[0] = B.dl.x; pb[64] = B.dl.y; pb[128] = B.dl.z; pb[192] = B.da.x; pb[256] = B.da.y; pb[320] = B.da.z;
+}
+// program word: id (9 bits) | (body0 + 1) << 9 (6 bits, 0 = floor) | body1 << 15 (6 bits) | round << 21 (4 bits); ~0 = none
+DEV unsigned g_prog_word(int id, int a, int b, int round) {
+    return (unsigned) id | ((unsigned) (a + 1) << 9) | ((unsigned) b << 15) | ((unsigned) round << 21);
+}
+DEV void g_bank_load(const Ctx &c, unsigned w, CBank &K) {
+    if (w == 0xffffffffu) { K.id = -1; K.a = -1; K.b = 0; K.round = -1; }
+    else { K.id = (int) (w & 511u); K.a = (int) ((w >> 9) & 63u) - 1; K.b = (int) ((w >> 15) & 63u); K.round = (int) ((w >> 21) & 15u); }
+#pragma unroll
+    for (int q = 0; q < 20; q++) K.q[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (K.id >= 0) {
+        const f32x4 *p = reinterpret_cast<const f32x4 *>(c.t.crec + ((size_t) (K.id * EVM_CR_STRIDE) << 6)) + c.lane;
+#pragma unroll
+        for (int q = 0; q < 20; q++) K.q[q] = p[q << 6];
+    }
+}
+// the accumulated impulses back into the persistent manifold the bank's manifold came from (warm start of the next step)
+DEV void g_bank_writeback(const Ctx &c, const CBank &K) {
+    if (K.id < 0) return;
+    const int nm = c_skel.nm;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (K.q[5 * j][3] == 0.f) continue;
+        if (K.id < nm) {
+            c.t.mfp[(((K.id * 4 + j) * 9 + 7) << 6) + c.lane] = K_APN(K, j);
+            c.t.mfp[(((K.id * 4 + j) * 9 + 8) << 6) + c.lane] = K_APF(K, j);
+        } else {
+            const int p = K.id - nm;
+            c.t.pmp[(((p * 4 + j) * 12 + 10) << 6) + c.lane] = K_APN(K, j);
+            c.t.pmp[(((p * 4 + j) * 12 + 11) << 6) + c.lane] = K_APF(K, j);
+        }
+    }
+}
+
+// Builds the contact program of the workgroup's 16 envs (one wave; lanes of group 0, one env each): walks the manifold ids in
+// solver order, gives the k-th active one of an env to slot k and levels it into rounds.
+//   prog [16 slots][16 envs] words (pre-filled with ~0), meta[0] = rounds used (max over envs), meta[2] = 1 if some env has a
+//   point for the split-impulse recovery
+// nn: this env's floor manifold counts; returns false for an env whose manifolds did not all fit (overflow: > 16 active
+// manifolds or > 15 rounds)
+DEV bool g_build_program(const Ctx &c, const GCtx &G, int nw, const int (&nn)[EVM_MAX_MEMBERS], unsigned *prog, int *meta) {
+    const int nm = c_skel.nm, np = c_skel.npair, nwords = (np + 31) >> 5;
+    unsigned pw[(EVM_MAX_PAIRS + 31) / 32];
+#pragma unroll
+    for (int k = 0; k < (EVM_MAX_PAIRS + 31) / 32; k++) pw[k] = k < nwords ? c.t.pact[(k << 6) + c.lane] : 0u;
+    const unsigned flags = c.t.pact[(nwords << 6) + c.lane];
+    unsigned nf[3] = {0u, 0u, 0u};  // next free round per member, 4 bits each
+    int ord = 0, rmax = 0;
+    bool ok = true;
+    auto place = [&](int id, int a, int b) {
+        auto getnf = [&](int m) { const unsigned w = m < 8 ? nf[0] : (m < 16 ? nf[1] : nf[2]); return (int) ((w >> ((m & 7) * 4)) & 15u); };
+        auto setnf = [&](int m, int v) {
+            const unsigned sh = (unsigned) (m & 7) * 4u, msk = ~(15u << sh), val = (unsigned) v << sh;
+            if (m < 8) nf[0] = (nf[0] & msk) | val; else if (m < 16) nf[1] = (nf[1] & msk) | val; else nf[2] = (nf[2] & msk) | val;
+        };
+        const int r = max(a >= 0 ? getnf(a) : 0, getnf(b));
+        if (r > 14 || ord >= 16) { ok = false; return; }
+        const int slot = (ord % nw) * 4 + ord / nw;
+        prog[(slot << 4) + G.e] = g_prog_word(id, a, b, r);
+        if (a >= 0) setnf(a, r + 1);
+        setnf(b, r + 1);
+        rmax = max(rmax, r + 1);
+        ord++;
+    };
+    for (int m = 0; m < nm; m++) {
+        const bool act = nn[m] > 0;
+        if (!__any(act)) continue;
+        if (act) place(m, -1, m);
+    }
+#pragma unroll
+    for (int k = 0; k < (EVM_MAX_PAIRS + 31) / 32; k++) {
+        if (k >= nwords) break;
+        unsigned long long any = 0;  // pairs of this word active in some lane (wave-uniform walk over their union)
+        {
+            unsigned u = pw[k];
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) u |= __shfl_xor(u, o);
+            any = u;
+        }
+        while (any) {
+            const int bit = __builtin_ctzll(any);
+            any &= any - 1;
+            const int p = 32 * k + bit;
+            const bool act = (pw[k] >> bit) & 1u;
+            if (act) place(nm + p, (int) c_skel.pair[p].a, (int) c_skel.pair[p].b);
+        }
+    }
+    // workgroup-wide facts
+    if (rmax > 0) atomicMax(&meta[0], rmax);
+    if (flags & 1u) atomicMax(&meta[2], 1);
+    return ok;
+}
+
+}  // namespace evm

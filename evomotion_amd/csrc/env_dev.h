@@ -19,6 +19,10 @@ struct EnvDev {
     float *hist;                    // [nm*6][n]  last_lin, last_ang (proprioception_state.cpp:33-34)
     int *mfn;                       // [nm][n]    persistent manifold point counts
     float *mfp;                     // [nm*4*9][n] localA3 localB3 dist applied applied_lateral
+    int *pmn;                       // [npair][n]  member-vs-member persistent manifold point counts (null unless self_collision)
+    float *pmp;                     // [npair*48][n] their points (EVM_PM_STRIDE)
+    unsigned *pact;                 // [ceil(npair/32)][n] bit p: pair p holds a point after this step's collision detection
+    float *crec;                    // [(nm+npair)*80][n] two-body contact records of the step (EVM_CR_STRIDE), by manifold id
     float *target;                  // [nmus][n]  slider target velocity
     int *flags, *curr_step, *remaining, *settle_left;  // [n]
     float *E;                       // [9][n]     reset rotation (rows)

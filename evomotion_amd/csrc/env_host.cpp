@@ -76,6 +76,7 @@ void evm_env_default_params(EvmEnvParams *p) {
     p->minimal_velocity = 0.1f;
     p->reset_frames = 30;
     p->env_kind = 0;
+    p->self_collision = 1;
 }
 
 int evm_env_default_params_for(const char *env_name, EvmEnvParams *p) {
@@ -130,6 +131,14 @@ int evm_env_create(const char *skeleton_path, int n_envs, int device, uint64_t s
         {(void **) &env->d.mt, 624}, {(void **) &env->d.mt_idx, 1}, {(void **) &env->d.scratch, (size_t) S.sc_total},
         {(void **) &env->d.diag, 2}, {(void **) &env->d.stat, 2}, {(void **) &env->d.stamps, 1}, {(void **) &env->d.resid, 1},
         {(void **) &env->d.gtile, evm::step_lds_bytes(S.nb, S.nscan) / 4 / 64}};  // stamps: 16 u64 per tile = 128 B <= 256 B
+    if (S.self_collision) {
+        // member-vs-member contacts: persistent pair manifolds, the activity words (+ one flag word) and the two-body contact
+        // records of a step, one per manifold id (floor manifolds first)
+        segs.push_back({(void **) &env->d.pmn, (size_t) (S.npair > 0 ? S.npair : 1)});
+        segs.push_back({(void **) &env->d.pmp, (size_t) EVM_PM_STRIDE * (S.npair > 0 ? S.npair : 1)});
+        segs.push_back({(void **) &env->d.pact, (size_t) ((S.npair + 31) / 32 + 1)});
+        segs.push_back({(void **) &env->d.crec, (size_t) EVM_CR_STRIDE * (S.nm + S.npair)});
+    }
     size_t total = 0;
     for (auto &s : segs) total += s.count * n * 4;
     he = hipMalloc(&env->arena, total);
@@ -162,6 +171,10 @@ int evm_env_create(const char *skeleton_path, int n_envs, int device, uint64_t s
             }
             delete G;
         }
+    }
+    if (S.self_collision && !env->gsched) {
+        evm_env_destroy(env);
+        return fail(EVM_E_UNSUPPORTED, "self_collision = 1 needs the lane-group sweeps kernel, which this skeleton (or EVM_SWEEPS=tile) rules out");
     }
     g_skel_owner = nullptr;
     rc = ensure_skeleton(env, 0);
@@ -267,6 +280,13 @@ int evm_env_get_body_poses(const EvmEnv *env, float *d_pose, void *stream) {
     return EVM_OK;
 }
 
+int evm_env_pairs(const EvmEnv *env, int *n_pairs, int *h_pairs) {
+    if (!env) return fail(EVM_E_INVALID, "env is null");
+    if (n_pairs) *n_pairs = env->skel.npair;
+    for (int p = 0; p < env->skel.npair && h_pairs; p++) { h_pairs[2 * p] = env->skel.pair[p].a; h_pairs[2 * p + 1] = env->skel.pair[p].b; }
+    return EVM_OK;
+}
+
 int evm_env_debug_reset_begin(EvmEnv *env, const uint8_t *d_mask) {
     if (!env) return fail(EVM_E_INVALID, "env is null");
     int rc = ensure_skeleton(env, 0);
@@ -291,6 +311,7 @@ static void body_constants(const EvmSkelC &S, float *out);
 int evm_skeleton_probe(const char *skeleton_path, int *counts /* nb nm nh nf nmus obs act root */, float *out) {
     EvmEnvParams prm;
     evm_env_default_params(&prm);
+    prm.self_collision = 0;  // (the tables these report do not depend on the collision mode)
     EvmSkelC *S = new EvmSkelC();
     std::string err;
     int rc = evm::load_skeleton_constants(skeleton_path, prm, *S, err);
@@ -311,6 +332,7 @@ int evm_skeleton_digest(const char *skeleton_path, unsigned long long *h_out) {
     if (!h_out) return fail(EVM_E_INVALID, "h_out is null");
     EvmEnvParams prm;
     evm_env_default_params(&prm);
+    prm.self_collision = 0;  // (the tables these report do not depend on the collision mode)
     EvmSkelC *S = new EvmSkelC();
     std::string err;
     int rc = evm::load_skeleton_constants(skeleton_path, prm, *S, err);
@@ -329,6 +351,7 @@ int evm_skeleton_digest(const char *skeleton_path, unsigned long long *h_out) {
 int evm_skeleton_schedule(const char *skeleton_path, int *dims, int *visits, int *sched, int cap) {
     EvmEnvParams prm;
     evm_env_default_params(&prm);
+    prm.self_collision = 0;  // (the tables these report do not depend on the collision mode)
     EvmSkelC *S = new EvmSkelC();
     std::string err;
     int rc = evm::load_skeleton_constants(skeleton_path, prm, *S, err);
@@ -346,8 +369,12 @@ int evm_skeleton_schedule(const char *skeleton_path, int *dims, int *visits, int
 }
 
 int evm_skeleton_group_schedule(const char *skeleton_path, int n_waves, int *dims, int *entries, int cap) {
+    return evm_skeleton_group_schedule_ex(skeleton_path, n_waves, 0, dims, entries, cap);
+}
+int evm_skeleton_group_schedule_ex(const char *skeleton_path, int n_waves, int self_collision, int *dims, int *entries, int cap) {
     EvmEnvParams prm;
     evm_env_default_params(&prm);
+    prm.self_collision = self_collision;
     EvmSkelC *S = new EvmSkelC();
     EvmGSchedC *G = new EvmGSchedC();
     std::string err;
@@ -402,13 +429,13 @@ int evm_env_get_diagnostics(const EvmEnv *env, float *d_out, void *stream) {
 int evm_env_state_size(const EvmEnv *env) {
     if (!env) return fail(EVM_E_INVALID, "env is null");
     const EvmSkelC &S = env->skel;
-    return 13 * S.nb + 1 + 9 + 6 * S.nb + 3 * S.nm + 6 * S.nm + 37 * S.nm + S.nmus + 1 + 2;
+    return 13 * S.nb + 1 + 9 + 6 * S.nb + 3 * S.nm + 6 * S.nm + 37 * S.nm + S.nmus + 1 + 2 + 49 * S.npair;
 }
 
 namespace {
 struct HostMirror {
-    std::vector<float> pos, quat, lin, ang, hist, mfp, target, E, iinv, scratch_ms;
-    std::vector<int> mfn, flags, curr, rem;
+    std::vector<float> pos, quat, lin, ang, hist, mfp, target, E, iinv, scratch_ms, pmp;
+    std::vector<int> mfn, flags, curr, rem, pmn;
 };
 }
 
@@ -436,6 +463,7 @@ int evm_env_get_state(EvmEnv *env, float *h_state) {
                         (size_t) S.sc_total * 256, (size_t) 3 * S.nm * 256, n / 64, hipMemcpyDeviceToHost));
     HIP_TRY(dli(env->d.mfn, S.nm, m.mfn)); HIP_TRY(dli(env->d.flags, 1, m.flags));
     HIP_TRY(dli(env->d.curr_step, 1, m.curr)); HIP_TRY(dli(env->d.remaining, 1, m.rem));
+    if (S.npair > 0) { HIP_TRY(dl(env->d.pmp, (size_t) EVM_PM_STRIDE * S.npair, m.pmp)); HIP_TRY(dli(env->d.pmn, S.npair, m.pmn)); }
     const int ss = evm_env_state_size(env);
     for (int e = 0; e < env->d.n_real; e++) {
         float *o = h_state + (size_t) e * ss;
@@ -459,6 +487,12 @@ int evm_env_get_state(EvmEnv *env, float *h_state) {
             for (int j = 0; j < 4; j++)
                 for (int f = 0; f < 9; f++) o[k++] = j < cnt ? m.mfp[tix(36 * S.nm, (mm * 4 + j) * 9 + f, e)] : 0.f;
         }
+        for (int p = 0; p < S.npair; p++) {
+            const int cnt = m.pmn[tix(S.npair, p, e)];
+            o[k++] = (float) cnt;
+            for (int j = 0; j < 4; j++)
+                for (int f = 0; f < 12; f++) o[k++] = j < cnt ? m.pmp[tix((size_t) EVM_PM_STRIDE * S.npair, (p * 4 + j) * 12 + f, e)] : 0.f;
+        }
         for (int a = 0; a < S.nmus; a++) o[k++] = m.target[tix((S.nmus > 0 ? S.nmus : 1), a, e)];
         o[k++] = (m.flags[e] & EVM_FLAG_POWERED) ? 1.f : 0.f;
         o[k++] = (float) m.curr[e];
@@ -478,6 +512,7 @@ int evm_env_set_state(EvmEnv *env, const float *h_state) {
     m.target.assign((S.nmus > 0 ? S.nmus : 1) * n, 0.f); m.E.assign(9 * n, 0.f); m.iinv.assign(6 * S.nb * n, 0.f);
     m.scratch_ms.assign(3 * S.nm * n, 0.f);
     m.mfn.assign(S.nm * n, 0); m.flags.assign(n, 0); m.curr.assign(n, 0); m.rem.assign(n, 0);
+    m.pmp.assign((size_t) EVM_PM_STRIDE * S.npair * n, 0.f); m.pmn.assign((size_t) S.npair * n, 0);
     // keep the rollout flag and whatever the padded lanes hold
     HIP_TRY(hipMemcpy(m.flags.data(), env->d.flags, n * 4, hipMemcpyDeviceToHost));
     const int ss = evm_env_state_size(env);
@@ -500,6 +535,11 @@ int evm_env_set_state(EvmEnv *env, const float *h_state) {
             for (int j = 0; j < 4; j++)
                 for (int f = 0; f < 9; f++) m.mfp[tix(36 * S.nm, (mm * 4 + j) * 9 + f, e)] = in[k++];
         }
+        for (int p = 0; p < S.npair; p++) {
+            m.pmn[tix(S.npair, p, e)] = (int) in[k++];
+            for (int j = 0; j < 4; j++)
+                for (int f = 0; f < 12; f++) m.pmp[tix((size_t) EVM_PM_STRIDE * S.npair, (p * 4 + j) * 12 + f, e)] = in[k++];
+        }
         for (int a = 0; a < S.nmus; a++) m.target[tix((S.nmus > 0 ? S.nmus : 1), a, e)] = in[k++];
         const bool powered = in[k++] != 0.f;
         m.curr[e] = (int) in[k++];
@@ -518,6 +558,7 @@ int evm_env_set_state(EvmEnv *env, const float *h_state) {
                         (size_t) 3 * S.nm * 256, (size_t) 3 * S.nm * 256, n / 64, hipMemcpyHostToDevice));
     HIP_TRY(uli(env->d.mfn, m.mfn)); HIP_TRY(uli(env->d.flags, m.flags));
     HIP_TRY(uli(env->d.curr_step, m.curr)); HIP_TRY(uli(env->d.remaining, m.rem));
+    if (S.npair > 0) { HIP_TRY(ul(env->d.pmp, m.pmp)); HIP_TRY(uli(env->d.pmn, m.pmn)); }
     return EVM_OK;
 }
 

@@ -49,6 +49,14 @@ struct Ctx {
 // HBM layout: every array is [tile][slot][64 lanes].  Inside a kernel the tile base is wave-uniform (SGPR pair),
 // the lane offset is one VGPR shared by every access, and the slot offset is an immediate or one scalar add:
 // no per-access 64-bit address arithmetic.
+// the member-vs-member arrays of a tile (null pointers stay null: floor-contacts-only mode)
+DEV void ctx_pair_arrays(Ctx &c, const EnvDev &d, size_t tile) {
+    const int np = c_skel.npair, nwords = ((np + 31) >> 5) + 1;
+    c.t.pmn = d.pmn ? d.pmn + tile * np : nullptr;
+    c.t.pmp = d.pmp ? d.pmp + tile * (EVM_PM_STRIDE * np) : nullptr;
+    c.t.pact = d.pact ? d.pact + tile * nwords : nullptr;
+    c.t.crec = d.crec ? d.crec + tile * (EVM_CR_STRIDE * (c_skel.nm + np)) : nullptr;
+}
 DEV Ctx make_ctx(const EnvDev &d, float *lds) {
     Ctx c;
     c.d = d;
@@ -65,6 +73,7 @@ DEV Ctx make_ctx(const EnvDev &d, float *lds) {
     c.t.target = d.target + tile * nmus; c.t.E = d.E + tile * 9; c.t.iinv_stale = d.iinv_stale + tile * (6 * nb);
     c.t.mt = d.mt + tile * 624; c.t.scratch = d.scratch + tile * c_skel.sc_total;
     c.t.diag = d.diag + tile * 2; c.t.stat = d.stat + tile * 2;
+    ctx_pair_arrays(c, d, tile);
     return c;
 }
 
@@ -1227,8 +1236,10 @@ DEV void repose_body(const Ctx &c, int b, const M33 &E, bool was_pending) {
 }
 // per-env bookkeeping of a reset: manifolds dropped, rotation kept for the first step, counters
 DEV void repose_finish(const Ctx &c, const M33 &E, int flags, bool drop_manifolds = true) {
-    if (drop_manifolds)
+    if (drop_manifolds) {
         for (int m = 0; m < c_skel.nm; m++) GS(mfn, m) = 0;
+        for (int p = 0; p < c_skel.npair; p++) c.t.pmn[(p << 6) + c.lane] = 0;
+    }
     GS(E, 0) = E.r0.x; GS(E, 1) = E.r0.y; GS(E, 2) = E.r0.z;
     GS(E, 3) = E.r1.x; GS(E, 4) = E.r1.y; GS(E, 5) = E.r1.z;
     GS(E, 6) = E.r2.x; GS(E, 7) = E.r2.y; GS(E, 8) = E.r2.z;
@@ -1817,6 +1828,10 @@ __global__ __launch_bounds__(64 * EVM_NW) void k_env_step(EnvDev d, const float 
     if (lead) d.flags[c.env] = flags;
 }
 
+}  // namespace evm
+#include "pairs_dev.h"
+namespace evm {
+
 // =================================================================================================================
 // Split pipeline.  At the mandated 4096 envs/GPU the monolithic kernel occupies 64 of the 256 CUs, and 40 % of its time
 // goes to phases that are embarrassingly parallel over bodies / constraints / members.  Here those phases run as
@@ -1876,6 +1891,10 @@ __global__ __launch_bounds__(64 * EVM_SPLIT_WAVES) void k_split_pre_a(EnvDev d, 
     EVM_SPLIT_GUARD()
     const LaneState L = lane_state<MODE>(c);
     const int vw = blockIdx.y * EVM_SPLIT_WAVES + c.wave, nvw = gridDim.y * EVM_SPLIT_WAVES;
+    if (c_skel.self_collision && vw == nvw - 1) {  // the pair kernel ORs its live pairs in, the setup kernels the split-impulse flag
+        const int nwords = ((c_skel.npair + 31) >> 5) + 1;
+        for (int k = 0; k < nwords; k++) c.t.pact[(k << 6) + c.lane] = 0u;
+    }
     // one item list (bodies, then scan slices) dealt round robin, so that no wave gets the head of both
     for (int j = vw; j < c_skel.nb + c_skel.nscan; j += nvw) {
         if (j < c_skel.nb) {
@@ -1943,6 +1962,13 @@ __global__ __launch_bounds__(64 * EVM_SPLIT_WAVES) __attribute__((amdgpu_waves_p
             if (c.lane == 0) atomicMax(&c.d.stamps[(size_t) blockIdx.x * 16 + 6], s5_b - s5_a);
 #endif
             const bool touching = __any(n > 0);
+            if (c_skel.self_collision) {
+                // member-vs-member mode: the rows go to the two-body record the sweeps kernel's contact rounds read; warm
+                // start and split-impulse recovery happen there, in manifold order across floor and pair contacts
+                if (touching) floor_record(c, m, n, pts);
+                SSC3(c_skel.sc_pt + 6 * m, f3(0.f, 0.f, 0.f)); SSC3(c_skel.sc_pt + 6 * m + 3, f3(0.f, 0.f, 0.f));
+                continue;
+            }
             if (touching) contact_setup(c, m, n, pts);
 #ifdef EVM_STAMPS5
             if (c.lane == 0) atomicMax(&c.d.stamps[(size_t) blockIdx.x * 16 + 7], __builtin_amdgcn_s_memtime() - s5_b);
@@ -1967,6 +1993,18 @@ __global__ __launch_bounds__(64 * EVM_SPLIT_WAVES) __attribute__((amdgpu_waves_p
 #ifdef EVM_STAMPS5
     if (s5_kind >= 0 && c.lane == 0) atomicMax(&c.d.stamps[(size_t) blockIdx.x * 16 + s5_kind], __builtin_amdgcn_s_memtime() - s5_t0);
 #endif
+}
+
+// member-vs-member mode: one (pair, tile) item per wavefront (pairs_dev.h); runs after k_split_pre_a (world bases, inertia,
+// external impulses), independent of k_split_pre_b
+template <int MODE>
+__global__ __launch_bounds__(64 * EVM_SPLIT_WAVES) void k_split_pairs(EnvDev d, const uint8_t *__restrict__ mask) {
+    Ctx c = make_ctx(d, tile_stage(d));
+    EVM_SPLIT_GUARD()
+    const LaneState L = lane_state<MODE>(c);
+    const int vw = blockIdx.y * EVM_SPLIT_WAVES + c.wave, nvw = gridDim.y * EVM_SPLIT_WAVES;
+    // feet first: their 451-vertex support scans make those items two orders of magnitude longer than a box pair's
+    for (int j = vw; j < c_skel.npair; j += nvw) pair_item(c, c_skel.pair_order[j], L.fin);
 }
 
 __global__ __launch_bounds__(64 * EVM_NW) void k_split_sweeps(EnvDev d, const uint8_t *__restrict__ mask, int autoreset) {
@@ -2165,6 +2203,10 @@ __global__ __launch_bounds__(64) void k_env_init(EnvDev d, uint64_t seed) {
         GS(target, mi) = 0.f;
         for (int k = 0; k < 4; k++) SC(c_skel.sc_mobs + 4 * mi + k) = 0.f;
     }
+    for (int p = 0; p < c_skel.npair; p++) {
+        c.t.pmn[(p << 6) + c.lane] = 0;
+        for (int k = 0; k < EVM_PM_STRIDE; k++) c.t.pmp[((p * EVM_PM_STRIDE + k) << 6) + c.lane] = 0.f;
+    }
     for (int k = 0; k < 9; k++) GS(E, k) = (k % 4 == 0) ? 1.f : 0.f;
     d.flags[e] = EVM_FLAG_PENDING;
     d.curr_step[e] = 0;
@@ -2244,6 +2286,7 @@ static hipError_t launch_split(const EnvDev &d, size_t lds, const float *action,
     const dim3 gp(tiles, parts), bp(64 * EVM_SPLIT_WAVES);
     hipLaunchKernelGGL((k_split_pre_a<MODE>), gp, bp, 0, s, d, mask);
     hipLaunchKernelGGL((k_split_pre_b<MODE>), gp, bp, 0, s, d, action, mask);
+    if (d.pmn) hipLaunchKernelGGL((k_split_pairs<MODE>), gp, bp, 0, s, d, mask);
     if (e0) (void) hipEventRecord(e0, s);
     if (d.gs) {
         static bool attr_g[EVM_MAX_DEVICES] = {};
@@ -2267,6 +2310,7 @@ hipError_t launch_step(const EnvDev &d, size_t lds_bytes, int split, int mode, c
     // split pipeline wins (0.179 vs 0.227 ms at 64 tiles); with every CU holding a tile it only adds launches and staging
     // traffic (0.472 vs 0.419 ms at 256 tiles).
     if (split < 0) split = d.n / 64 <= 128 ? 1 : 0;
+    if (d.pmn) split = 1;  // member-vs-member contacts live in the split pipeline with the lane-group sweeps kernel only
     if (split) {
         // the sweeps kernel keeps only the body tiles and the version counters in LDS (no scan minima)
         const size_t lds = lds_bytes;  // same layout as the staging copy

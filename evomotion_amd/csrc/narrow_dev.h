@@ -1,0 +1,458 @@
+// Convex-convex narrowphase for the member-vs-member pairs (included by env_kernels.hip; one environment per lane, the pair
+// — hence both hulls — is wave-uniform).
+//
+// What it replaces: Bullet3's btConvexConvexAlgorithm::processCollision -> btGjkPairDetector::getClosestPointsNonVirtual
+// with btVoronoiSimplexSolver, one query per overlapping pair and step (the reference's dispatcher / broadphase:
+// evo_motion_model/src/environment.cpp:20-31; which pairs: evo_motion_model/src/robot/constraint.cpp:65,147; the shapes:
+// btConvexHullShape of the OBJ vertices with local scaling, evo_motion_model/src/item.cpp:17-41), and for overlapping
+// un-margined cores Bullet's btMinkowskiPenetrationDepthSolver (42 fixed directions + a second GJK on the displaced
+// shape) — the data-parallel one of Bullet's two penetration solvers; the reference's configuration selects EPA
+// (DESIGN.md §2c states the deviation and how rarely the branch runs).
+//
+// GJK's exits hang on rounding (is the new support point already in the simplex, did the distance still shrink), and a
+// different exit is a different contact point.  So everything in this header is compiled WITHOUT fma contraction and in
+// one fixed operation order: identical transforms give identical contact points on every kernel build.
+//
+// SIMT shape: the simplex (<= 4 vertices x (w, p, q)) lives in registers, slot selection by compare-and-select; hull
+// vertices are wave-uniform scalar loads, two vertices per packed instruction; lanes iterate until every lane of the
+// wave has left the loop.
+#pragma once
+
+namespace evm {
+#pragma clang fp contract(off)
+namespace gj {
+
+#define GJ_REL_ERROR2 1.0e-6f
+#define GJ_PEN_TOLERANCE 0.001f
+#define GJ_MAX_ITER 1000
+#define GJ_EQUAL_VERTEX 0.0001f
+#define GJ_LARGE 1e18f
+
+DEV F3 add(F3 a, F3 b) { return f3(a.x + b.x, a.y + b.y, a.z + b.z); }
+DEV F3 sub(F3 a, F3 b) { return f3(a.x - b.x, a.y - b.y, a.z - b.z); }
+DEV F3 neg(F3 a) { return f3(-a.x, -a.y, -a.z); }
+DEV F3 scl(F3 a, float s) { return f3(a.x * s, a.y * s, a.z * s); }
+DEV float dot(F3 a, F3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+DEV F3 cross(F3 a, F3 b) { return f3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+DEV float len2(F3 a) { return gj::dot(a, a); }
+DEV F3 sel3(bool c, F3 a, F3 b) { return f3(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z); }
+// btVector3 * btMatrix3x3 (row vector times matrix = R^T v)
+DEV F3 vmul(F3 v, const M33 &m) {
+    return f3(m.r0.x * v.x + m.r1.x * v.y + m.r2.x * v.z, m.r0.y * v.x + m.r1.y * v.y + m.r2.y * v.z,
+              m.r0.z * v.x + m.r1.z * v.y + m.r2.z * v.z);
+}
+// btTransform::operator()(x)
+DEV F3 xform(const M33 &R, F3 o, F3 x) { return gj::add(f3(gj::dot(R.r0, x), gj::dot(R.r1, x), gj::dot(R.r2, x)), o); }
+
+// btConvexHullShape::localGetSupportingVertexWithoutMargin: first maximum of dot(dir, scaled vertex) over the hull in table
+// order (EvmSkelC::hull pair layout: vertex g = 2 P + s at hull[6 P + s], hull[6 P + 2 + s], hull[6 P + 4 + s])
+DEV F3 support(int hull_off, int hull_n, F3 dir) {
+    const P2 dx = p2(dir.x, dir.x), dy = p2(dir.y, dir.y), dz = p2(dir.z, dir.z);
+    const float *hp = c_skel.hull + 3 * hull_off;
+    const int np = (hull_n + 1) >> 1;
+    P2 best = p2(-GJ_LARGE, -GJ_LARGE);
+    int be = 0, bo = 0;
+#define GJ_PAIR(H, Q, PI)                                                                            \
+    {                                                                                                \
+        const P2 x = p2(H[6 * (Q)], H[6 * (Q) + 1]), y = p2(H[6 * (Q) + 2], H[6 * (Q) + 3]),         \
+                 z = p2(H[6 * (Q) + 4], H[6 * (Q) + 5]);                                             \
+        const P2 d = (dx * x + dy * y) + dz * z;                                                     \
+        const bool ce = d.x > best.x, co = d.y > best.y;                                             \
+        best = p2(ce ? d.x : best.x, co ? d.y : best.y);                                             \
+        be = ce ? (PI) : be;                                                                         \
+        bo = co ? (PI) : bo;                                                                         \
+    }
+    int p = 0;
+    for (; p + 4 <= np; p += 4) {
+        float h[24];
+#pragma unroll
+        for (int k = 0; k < 24; k++) h[k] = hp[6 * p + k];
+#pragma unroll
+        for (int q = 0; q < 4; q++) GJ_PAIR(h, q, p + q)
+    }
+    for (; p < np; p++) {
+        float h[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) h[k] = hp[6 * p + k];
+        GJ_PAIR(h, 0, p)
+    }
+#undef GJ_PAIR
+    // even and odd vertices kept separate running maxima: the first maximum overall is the larger one, the lower index on a
+    // tie (an odd hull repeats its last vertex at an odd position: it never wins a tie)
+    int bi = 2 * be;
+    if (best.y > best.x || (best.y == best.x && 2 * bo + 1 < bi)) bi = 2 * bo + 1;
+    const int g = hull_off + bi, hb = 6 * (g >> 1) + (g & 1);
+    return f3(c_skel.hull[hb], c_skel.hull[hb + 2], c_skel.hull[hb + 4]);
+}
+
+struct Shape {  // one member's hull and world transform (the basis may be non-orthonormal in the step that follows reset())
+    int hull_off, hull_n;
+    M33 R;
+    F3 o;
+};
+// w = support_A(-axis) - support_B(axis) in world space, with the two support points
+DEV void minkowski(const Shape &A, F3 oA, const Shape &B, F3 oB, F3 axis, F3 &pW, F3 &qW) {
+    const F3 sA = gj::vmul(gj::neg(axis), A.R), sB = gj::vmul(axis, B.R);
+    pW = gj::xform(A.R, oA, gj::support(A.hull_off, A.hull_n, sA));
+    qW = gj::xform(B.R, oB, gj::support(B.hull_off, B.hull_n, sB));
+}
+
+// ---- btVoronoiSimplexSolver on registers -------------------------------------------------------------------------------
+struct Bary {  // btSubSimplexClosestResult
+    F3 closest;
+    bool uA, uB, uC, uD, degenerate;
+    float b0, b1, b2, b3;
+};
+DEV bool bary_valid(const Bary &r) { return r.b0 >= 0.f && r.b1 >= 0.f && r.b2 >= 0.f && r.b3 >= 0.f; }
+DEV void bary_reset(Bary &r) { r.degenerate = false; r.b0 = r.b1 = r.b2 = r.b3 = 0.f; r.uA = r.uB = r.uC = r.uD = false; }
+
+DEV void closest_triangle(F3 p, F3 a, F3 b, F3 c, Bary &r) {
+    r.uA = r.uB = r.uC = r.uD = false;
+    const F3 ab = gj::sub(b, a), ac = gj::sub(c, a), ap = gj::sub(p, a);
+    const float d1 = gj::dot(ab, ap), d2 = gj::dot(ac, ap);
+    if (d1 <= 0.f && d2 <= 0.f) { r.closest = a; r.uA = true; r.b0 = 1; r.b1 = 0; r.b2 = 0; r.b3 = 0; return; }
+    const F3 bp = gj::sub(p, b);
+    const float d3 = gj::dot(ab, bp), d4 = gj::dot(ac, bp);
+    if (d3 >= 0.f && d4 <= d3) { r.closest = b; r.uB = true; r.b0 = 0; r.b1 = 1; r.b2 = 0; r.b3 = 0; return; }
+    const float vc = d1 * d4 - d3 * d2;
+    if (vc <= 0.f && d1 >= 0.f && d3 <= 0.f) {
+        const float v = d1 / (d1 - d3);
+        r.closest = gj::add(a, gj::scl(ab, v)); r.uA = true; r.uB = true; r.b0 = 1 - v; r.b1 = v; r.b2 = 0; r.b3 = 0;
+        return;
+    }
+    const F3 cp = gj::sub(p, c);
+    const float d5 = gj::dot(ab, cp), d6 = gj::dot(ac, cp);
+    if (d6 >= 0.f && d5 <= d6) { r.closest = c; r.uC = true; r.b0 = 0; r.b1 = 0; r.b2 = 1; r.b3 = 0; return; }
+    const float vb = d5 * d2 - d1 * d6;
+    if (vb <= 0.f && d2 >= 0.f && d6 <= 0.f) {
+        const float w = d2 / (d2 - d6);
+        r.closest = gj::add(a, gj::scl(ac, w)); r.uA = true; r.uC = true; r.b0 = 1 - w; r.b1 = 0; r.b2 = w; r.b3 = 0;
+        return;
+    }
+    const float va = d3 * d6 - d5 * d4;
+    if (va <= 0.f && (d4 - d3) >= 0.f && (d5 - d6) >= 0.f) {
+        const float w = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+        r.closest = gj::add(b, gj::scl(gj::sub(c, b), w)); r.uB = true; r.uC = true; r.b0 = 0; r.b1 = 1 - w; r.b2 = w; r.b3 = 0;
+        return;
+    }
+    const float denom = 1.0f / (va + vb + vc);
+    const float v = vb * denom, w = vc * denom;
+    r.closest = gj::add(gj::add(a, gj::scl(ab, v)), gj::scl(ac, w));
+    r.uA = true; r.uB = true; r.uC = true;
+    r.b0 = 1 - v - w; r.b1 = v; r.b2 = w; r.b3 = 0;
+}
+// -1 degenerate, 0 inside, 1 outside
+DEV int outside_of_plane(F3 p, F3 a, F3 b, F3 c, F3 d) {
+    const F3 normal = gj::cross(gj::sub(b, a), gj::sub(c, a));
+    const float signp = gj::dot(gj::sub(p, a), normal);
+    const float signd = gj::dot(gj::sub(d, a), normal);
+    if (signd * signd < (1e-4f * 1e-4f)) return -1;
+    return signp * signd < 0.f ? 1 : 0;
+}
+DEV bool closest_tetrahedron(F3 p, F3 a, F3 b, F3 c, F3 d, Bary &f) {
+    Bary t;
+    f.closest = p;
+    f.uA = f.uB = f.uC = f.uD = true;
+    const int oABC = outside_of_plane(p, a, b, c, d), oACD = outside_of_plane(p, a, c, d, b);
+    const int oADB = outside_of_plane(p, a, d, b, c), oBDC = outside_of_plane(p, b, d, c, a);
+    if (oABC < 0 || oACD < 0 || oADB < 0 || oBDC < 0) { f.degenerate = true; return false; }
+    if (!oABC && !oACD && !oADB && !oBDC) return false;
+    float best = EVM_INF;
+    if (oABC) {
+        closest_triangle(p, a, b, c, t);
+        const F3 q = t.closest;
+        const float sq = gj::dot(gj::sub(q, p), gj::sub(q, p));
+        if (sq < best) { best = sq; f.closest = q; f.uA = t.uA; f.uB = t.uB; f.uC = t.uC; f.uD = false; f.b0 = t.b0; f.b1 = t.b1; f.b2 = t.b2; f.b3 = 0; }
+    }
+    if (oACD) {
+        closest_triangle(p, a, c, d, t);
+        const F3 q = t.closest;
+        const float sq = gj::dot(gj::sub(q, p), gj::sub(q, p));
+        if (sq < best) { best = sq; f.closest = q; f.uA = t.uA; f.uB = false; f.uC = t.uB; f.uD = t.uC; f.b0 = t.b0; f.b1 = 0; f.b2 = t.b1; f.b3 = t.b2; }
+    }
+    if (oADB) {
+        closest_triangle(p, a, d, b, t);
+        const F3 q = t.closest;
+        const float sq = gj::dot(gj::sub(q, p), gj::sub(q, p));
+        if (sq < best) { best = sq; f.closest = q; f.uA = t.uA; f.uB = t.uC; f.uC = false; f.uD = t.uB; f.b0 = t.b0; f.b1 = t.b2; f.b2 = 0; f.b3 = t.b1; }
+    }
+    if (oBDC) {
+        closest_triangle(p, b, d, c, t);
+        const F3 q = t.closest;
+        const float sq = gj::dot(gj::sub(q, p), gj::sub(q, p));
+        if (sq < best) { best = sq; f.closest = q; f.uA = false; f.uB = t.uA; f.uC = t.uC; f.uD = t.uB; f.b0 = 0; f.b1 = t.b0; f.b2 = t.b2; f.b3 = t.b1; }
+    }
+    return true;
+}
+
+struct Simplex {
+    int n;
+    F3 W[4], P[4], Q[4];
+    F3 cP1, cP2, cV, lastW;
+    bool cachedValid;
+};
+DEV void sx_reset(Simplex &s) {
+    s.n = 0; s.cachedValid = false;
+    s.lastW = f3(GJ_LARGE, GJ_LARGE, GJ_LARGE);
+#pragma unroll
+    for (int i = 0; i < 4; i++) { s.W[i] = f3(0, 0, 0); s.P[i] = f3(0, 0, 0); s.Q[i] = f3(0, 0, 0); }
+    s.cP1 = s.cP2 = s.cV = f3(0, 0, 0);
+}
+DEV void sx_add(Simplex &s, F3 w, F3 p, F3 q) {
+    s.lastW = w;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { const bool h = s.n == i; s.W[i] = sel3(h, w, s.W[i]); s.P[i] = sel3(h, p, s.P[i]); s.Q[i] = sel3(h, q, s.Q[i]); }
+    s.n++;
+}
+// removeVertex(i): the last vertex takes slot i
+DEV void sx_remove(Simplex &s, int i) {
+    s.n--;
+    const int l = s.n;
+    const F3 lw = sel3(l == 0, s.W[0], sel3(l == 1, s.W[1], sel3(l == 2, s.W[2], s.W[3])));
+    const F3 lp = sel3(l == 0, s.P[0], sel3(l == 1, s.P[1], sel3(l == 2, s.P[2], s.P[3])));
+    const F3 lq = sel3(l == 0, s.Q[0], sel3(l == 1, s.Q[1], sel3(l == 2, s.Q[2], s.Q[3])));
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const bool h = i == k; s.W[k] = sel3(h, lw, s.W[k]); s.P[k] = sel3(h, lp, s.P[k]); s.Q[k] = sel3(h, lq, s.Q[k]); }
+}
+DEV void sx_reduce(Simplex &s, const Bary &u) {
+    if (s.n >= 4 && !u.uD) sx_remove(s, 3);
+    if (s.n >= 3 && !u.uC) sx_remove(s, 2);
+    if (s.n >= 2 && !u.uB) sx_remove(s, 1);
+    if (s.n >= 1 && !u.uA) sx_remove(s, 0);
+}
+DEV bool sx_in_simplex(const Simplex &s, F3 w) {
+    bool found = false;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const F3 d = gj::sub(s.W[i], w);
+        if (i < s.n && !found && gj::dot(d, d) <= GJ_EQUAL_VERTEX) found = true;
+    }
+    if (w.x == s.lastW.x && w.y == s.lastW.y && w.z == s.lastW.z) return true;
+    return found;
+}
+// updateClosestVectorAndPoints (called right after every addVertex, so the cached values are never stale)
+DEV bool sx_closest(Simplex &s, F3 &v) {
+    Bary bc;
+    bary_reset(bc);
+    const F3 zero = f3(0.f, 0.f, 0.f);
+    if (s.n == 1) {
+        s.cP1 = s.P[0]; s.cP2 = s.Q[0]; s.cV = gj::sub(s.cP1, s.cP2);
+        bc.b0 = 1;
+        s.cachedValid = bary_valid(bc);
+    } else if (s.n == 2) {
+        const F3 from = s.W[0], to = s.W[1];
+        F3 diff = gj::sub(zero, from);
+        const F3 vv = gj::sub(to, from);
+        float t = gj::dot(vv, diff);
+        if (t > 0.f) {
+            const float dotVV = gj::dot(vv, vv);
+            if (t < dotVV) { t /= dotVV; diff = gj::sub(diff, gj::scl(vv, t)); bc.uA = true; bc.uB = true; }
+            else { t = 1; diff = gj::sub(diff, vv); bc.uB = true; }
+        } else { t = 0; bc.uA = true; }
+        bc.b0 = 1 - t; bc.b1 = t;
+        s.cP1 = gj::add(s.P[0], gj::scl(gj::sub(s.P[1], s.P[0]), t));
+        s.cP2 = gj::add(s.Q[0], gj::scl(gj::sub(s.Q[1], s.Q[0]), t));
+        s.cV = gj::sub(s.cP1, s.cP2);
+        sx_reduce(s, bc);
+        s.cachedValid = bary_valid(bc);
+    } else if (s.n == 3) {
+        closest_triangle(zero, s.W[0], s.W[1], s.W[2], bc);
+        s.cP1 = gj::add(gj::add(gj::scl(s.P[0], bc.b0), gj::scl(s.P[1], bc.b1)), gj::scl(s.P[2], bc.b2));
+        s.cP2 = gj::add(gj::add(gj::scl(s.Q[0], bc.b0), gj::scl(s.Q[1], bc.b1)), gj::scl(s.Q[2], bc.b2));
+        s.cV = gj::sub(s.cP1, s.cP2);
+        sx_reduce(s, bc);
+        s.cachedValid = bary_valid(bc);
+    } else if (s.n == 4) {
+        const bool sep = closest_tetrahedron(zero, s.W[0], s.W[1], s.W[2], s.W[3], bc);
+        if (sep) {
+            s.cP1 = gj::add(gj::add(gj::add(gj::scl(s.P[0], bc.b0), gj::scl(s.P[1], bc.b1)), gj::scl(s.P[2], bc.b2)), gj::scl(s.P[3], bc.b3));
+            s.cP2 = gj::add(gj::add(gj::add(gj::scl(s.Q[0], bc.b0), gj::scl(s.Q[1], bc.b1)), gj::scl(s.Q[2], bc.b2)), gj::scl(s.Q[3], bc.b3));
+            s.cV = gj::sub(s.cP1, s.cP2);
+            sx_reduce(s, bc);
+            s.cachedValid = bary_valid(bc);
+        } else if (bc.degenerate) s.cachedValid = false;
+        else { s.cachedValid = true; s.cV = zero; }
+    } else s.cachedValid = false;
+    v = s.cV;
+    return s.cachedValid;
+}
+
+struct Result {
+    bool has;        // a point for btManifoldResult::addContactPoint
+    F3 normalOnB, pointOnB;
+    float distance;
+    int iterations;
+    bool used_pen;
+};
+
+// One btGjkPairDetector::getClosestPointsNonVirtual run for the lanes in `active`.  oA / oB: the two origins already shifted by
+// positionOffset.  Without the penetration branch (that is the caller's, between two runs).  Outputs per lane.
+struct RunOut {
+    bool isValid;
+    float distance, squaredDistance;
+    F3 normalInB, pointOnA, pointOnB, axis;
+    int degenerate, iters;
+};
+DEV RunOut gjk_run(const Shape &A, F3 oA, const Shape &B, F3 oB, float max_dist2, bool active, float marginA, float marginB) {
+    RunOut o;
+    o.isValid = false; o.distance = 0.f; o.squaredDistance = GJ_LARGE; o.degenerate = 0; o.iters = 0;
+    o.normalInB = f3(0, 0, 0); o.pointOnA = f3(0, 0, 0); o.pointOnB = f3(0, 0, 0);
+    F3 axis = f3(0.f, 1.f, 0.f);
+    bool checkSimplex = false, running = active;
+    float squaredDistance = GJ_LARGE;
+    const float margin = marginA + marginB;
+    Simplex sx;
+    sx_reset(sx);
+    int cur_iter = 0, degenerate = 0;
+    while (__any(running)) {
+        F3 pW, qW;
+        minkowski(A, oA, B, oB, axis, pW, qW);  // (lanes that have left keep their last axis: harmless, results unused)
+        if (running) {
+            const F3 w = gj::sub(pW, qW);
+            const float delta = gj::dot(axis, w);
+            const float f0 = squaredDistance - delta, f1 = squaredDistance * GJ_REL_ERROR2;
+            if (delta > 0.f && delta * delta > squaredDistance * max_dist2) { degenerate = 10; checkSimplex = true; running = false; }
+            else if (sx_in_simplex(sx, w)) { degenerate = 1; checkSimplex = true; running = false; }
+            else if (f0 <= f1) { degenerate = f0 <= 0.f ? 2 : 11; checkSimplex = true; running = false; }
+            else {
+                sx_add(sx, w, pW, qW);
+                F3 newAxis;
+                if (!sx_closest(sx, newAxis)) { degenerate = 3; checkSimplex = true; running = false; }
+                else if (gj::len2(newAxis) < GJ_REL_ERROR2) { axis = newAxis; degenerate = 6; checkSimplex = true; running = false; }
+                else {
+                    const float prev = squaredDistance;
+                    squaredDistance = gj::len2(newAxis);
+                    if (prev - squaredDistance <= EVM_EPS * prev) { checkSimplex = true; degenerate = 12; running = false; }
+                    else {
+                        axis = newAxis;
+                        if (cur_iter++ > GJ_MAX_ITER) running = false;
+                        else if (sx.n == 4) { degenerate = 13; running = false; }
+                    }
+                }
+            }
+        }
+    }
+    if (checkSimplex) {
+        F3 pointOnA = sx.cP1, pointOnB = sx.cP2;  // compute_points: the cached pair of the last closest()
+        F3 normalInB = axis;
+        const float lenSqr = gj::len2(axis);
+        if (lenSqr < GJ_REL_ERROR2) degenerate = 5;
+        if (lenSqr > EVM_EPS * EVM_EPS) {
+            const float rlen = 1.0f / sqrtf(lenSqr);
+            normalInB = gj::scl(normalInB, rlen);
+            const float s = sqrtf(squaredDistance);
+            pointOnA = gj::sub(pointOnA, gj::scl(axis, marginA / s));
+            pointOnB = gj::add(pointOnB, gj::scl(axis, marginB / s));
+            o.distance = (1.0f / rlen) - margin;
+            o.isValid = true;
+            o.normalInB = normalInB;
+            o.pointOnA = pointOnA; o.pointOnB = pointOnB;
+        }
+    }
+    o.axis = axis;
+    o.degenerate = degenerate;
+    o.squaredDistance = squaredDistance;
+    o.iters = cur_iter;
+    return o;
+}
+
+// btMinkowskiPenetrationDepthSolver::getPenetrationDirections (NUM_UNITSPHERE_POINTS = 42)
+__device__ const float kPenDirs[42][3] = {
+    {0.000000f, -0.000000f, -1.000000f}, {0.723608f, -0.525725f, -0.447219f}, {-0.276388f, -0.850649f, -0.447219f},
+    {-0.894426f, -0.000000f, -0.447216f}, {-0.276388f, 0.850649f, -0.447220f}, {0.723608f, 0.525725f, -0.447219f},
+    {0.276388f, -0.850649f, 0.447220f}, {-0.723608f, -0.525725f, 0.447219f}, {-0.723608f, 0.525725f, 0.447219f},
+    {0.276388f, 0.850649f, 0.447219f}, {0.894426f, 0.000000f, 0.447216f}, {-0.000000f, 0.000000f, 1.000000f},
+    {0.425323f, -0.309011f, -0.850654f}, {-0.162456f, -0.499995f, -0.850654f}, {0.262869f, -0.809012f, -0.525738f},
+    {0.425323f, 0.309011f, -0.850654f}, {0.850648f, -0.000000f, -0.525736f}, {-0.525730f, -0.000000f, -0.850652f},
+    {-0.688190f, -0.499997f, -0.525736f}, {-0.162456f, 0.499995f, -0.850654f}, {-0.688190f, 0.499997f, -0.525736f},
+    {0.262869f, 0.809012f, -0.525738f}, {0.951058f, 0.309013f, 0.000000f}, {0.951058f, -0.309013f, 0.000000f},
+    {0.587786f, -0.809017f, 0.000000f}, {0.000000f, -1.000000f, 0.000000f}, {-0.587786f, -0.809017f, 0.000000f},
+    {-0.951058f, -0.309013f, -0.000000f}, {-0.951058f, 0.309013f, -0.000000f}, {-0.587786f, 0.809017f, -0.000000f},
+    {-0.000000f, 1.000000f, -0.000000f}, {0.587786f, 0.809017f, -0.000000f}, {0.688190f, -0.499997f, 0.525736f},
+    {-0.262869f, -0.809012f, 0.525738f}, {-0.850648f, 0.000000f, 0.525736f}, {-0.262869f, 0.809012f, 0.525738f},
+    {0.688190f, 0.499997f, 0.525736f}, {0.525730f, 0.000000f, 0.850652f}, {0.162456f, -0.499995f, 0.850654f},
+    {-0.425323f, -0.309011f, 0.850654f}, {-0.425323f, 0.309011f, 0.850654f}, {0.162456f, 0.499995f, 0.850654f}};
+
+// btGjkPairDetector::getClosestPoints for the lanes in `active` (the others return has = false)
+DEV Result closest_points(const Shape &A, const Shape &B, float max_dist2, bool active) {
+    const float marginA = MARGIN_F, marginB = MARGIN_F, margin = marginA + marginB;
+    Result out;
+    out.has = false; out.normalOnB = f3(0, 0, 0); out.pointOnB = f3(0, 0, 0); out.distance = 0.f; out.iterations = 0; out.used_pen = false;
+    const F3 positionOffset = gj::scl(gj::add(A.o, B.o), 0.5f);
+    const F3 oA = gj::sub(A.o, positionOffset), oB = gj::sub(B.o, positionOffset);
+    const RunOut r = gjk_run(A, oA, B, oB, max_dist2, active, marginA, marginB);
+    bool isValid = r.isValid;
+    float distance = r.distance;
+    F3 normalInB = r.normalInB, pointOnB = r.pointOnB;
+    const F3 orgNormalInB = r.isValid ? r.normalInB : f3(0.f, 0.f, 0.f);
+    out.iterations = r.iters;
+    const bool catchDegenerate = r.degenerate != 0 && (distance + margin) < GJ_PEN_TOLERANCE;
+    const bool need_pen = active && (!isValid || catchDegenerate);
+    if (__any(need_pen)) {
+        // btMinkowskiPenetrationDepthSolver::calcPenDepth
+        float minProj = GJ_LARGE;
+        F3 minNorm = f3(0.f, 0.f, 0.f);
+        for (int i = 0; i < 42; i++) {
+            const F3 norm = f3(kPenDirs[i][0], kPenDirs[i][1], kPenDirs[i][2]);
+            F3 pW, qW;
+            minkowski(A, oA, B, oB, norm, pW, qW);
+            const float delta = gj::dot(norm, gj::sub(qW, pW));
+            if (delta < minProj) { minProj = delta; minNorm = norm; }
+        }
+        const bool overlap = !(minProj < 0.f);
+        minProj += 0.5f + (marginA + marginB);  // extraSeparation + margins
+        const F3 offset = gj::scl(minNorm, minProj);
+        // the nested detector (no penetration solver of its own) re-centres the displaced pair like every detector run; its
+        // own final normal check can only flip the normal, which calcPenDepth does not read
+        const F3 oAd = gj::add(oA, offset);
+        const F3 po2 = gj::scl(gj::add(oAd, oB), 0.5f);
+        RunOut n2 = gjk_run(A, gj::sub(oAd, po2), B, gj::sub(oB, po2), GJ_LARGE, need_pen && overlap, marginA, marginB);
+        n2.pointOnB = gj::add(n2.pointOnB, po2);
+        const bool nested_has = n2.isValid;
+        if (need_pen) {
+            out.used_pen = true;
+            if (overlap && nested_has) {
+                const float corrected = minProj - n2.distance;
+                const F3 pb = n2.pointOnB;                        // in the offset-free local frame (B was not displaced)
+                const F3 pa = gj::sub(pb, gj::scl(minNorm, corrected));
+                F3 tmpN = gj::sub(pb, pa);
+                float lenSqr = gj::len2(tmpN);
+                if (lenSqr <= EVM_EPS * EVM_EPS) { tmpN = minNorm; lenSqr = gj::len2(minNorm); }
+                if (lenSqr > EVM_EPS * EVM_EPS) {
+                    tmpN = gj::scl(tmpN, 1.0f / sqrtf(lenSqr));
+                    const F3 dd = gj::sub(pa, pb);
+                    const float distance2 = -sqrtf(gj::len2(dd));
+                    if (!isValid || distance2 < distance) { distance = distance2; pointOnB = pb; normalInB = tmpN; isValid = true; }
+                }
+            }
+            // (calcPenDepth returning false leaves m_cachedSeparatingAxis zero: nothing more to take from it)
+        }
+    }
+    if (active && isValid && (distance < 0.f || distance * distance < max_dist2)) out.has = true;
+    if (__any(out.has)) {
+        // the normal check at the end of getClosestPointsNonVirtual
+        F3 pW, qW;
+        minkowski(A, oA, B, oB, normalInB, pW, qW);
+        const float d0 = gj::dot(normalInB, gj::sub(pW, qW)) - margin;
+        const F3 nn = gj::neg(normalInB);
+        minkowski(A, oA, B, oB, nn, pW, qW);
+        const float d1 = gj::dot(nn, gj::sub(pW, qW)) - margin;
+        float d2 = d0;  // orgNormalInB == normalInB unless the penetration branch replaced it
+        if (__any(out.has && out.used_pen)) {
+            minkowski(A, oA, B, oB, orgNormalInB, pW, qW);
+            d2 = gj::dot(orgNormalInB, gj::sub(pW, qW)) - margin;
+        }
+        if (d1 > d0) normalInB = nn;
+        if (gj::len2(orgNormalInB) != 0.f) {
+            if (d2 > d0 && d2 > d1 && d2 > distance) { normalInB = orgNormalInB; distance = d2; }
+        }
+    }
+    out.normalOnB = normalInB;
+    out.pointOnB = gj::add(pointOnB, positionOffset);
+    out.distance = distance;
+    return out;
+}
+
+}  // namespace gj
+#pragma clang fp contract(fast)
+}  // namespace evm

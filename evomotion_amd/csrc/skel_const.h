@@ -10,6 +10,7 @@
 #define EVM_MAX_FIXED 8
 #define EVM_MAX_MUSCLES 20
 #define EVM_MAX_HULL_PTS 1024
+#define EVM_MAX_PAIRS (EVM_MAX_MEMBERS * (EVM_MAX_MEMBERS - 1) / 2)
 
 // per-constraint scratch strides (floats per env)
 // Constraint records in the scratch tile.  A record starts on a multiple of 4 slots and is stored in QUADS: fields
@@ -22,6 +23,13 @@
 #define EVM_P_STRIDE 16   // p2p   : a1_3 a2_3 | jd3 6 | rhs3 9 | applied3 12 | pad
 #define EVM_C_STRIDE 10   // contact point: rel3 lat3 | jd_n rhs_n jd_f rhs_f
 #define EVM_CM_STRIDE 48  // contact record of a member: 4 points x EVM_C_STRIDE, then 4 x (applied normal, applied lateral)
+// Two-body contact record (member-vs-member mode, EvmSkelC::self_collision): one per manifold id (floor-vs-member m -> id m,
+// pair p -> id nm + p), 4 points x 5 quads; read-only during the sweeps (the accumulated impulses live in LDS there):
+//   quad 0: relA.xyz, jd_n   quad 1: relB.xyz, rhs_n   quad 2: normalOnB.xyz, applied_n (warm-started)
+//   quad 3: lat.xyz, jd_f    quad 4: rhs_f, applied_f (warm-started), rhs_penetration (split impulse), mu
+#define EVM_CR_POINT 20
+#define EVM_CR_STRIDE 80
+#define EVM_PM_STRIDE 48  // persistent pair manifold: 4 points x (localA3 localB3 normalOnB3 dist applied applied_lateral)
 
 struct EvmBodyC {
     float inv_mass;
@@ -39,6 +47,14 @@ struct EvmMemberC {
     float break_thr;       // relative contact breaking threshold
     float mu;              // combined friction with the floor
     int contact_response;
+    float aabb_c[3], aabb_h[3];  // local box of btPolyhedralConvexAabbCachingShape::getAabb: centre and half extents (the
+                                 // margin added twice, like Bullet) + gContactBreakingThreshold: the broadphase cull of the pairs
+};
+// A member pair that may collide (all but constraint parent / child: constraint.cpp:65,147), a < b; solver order = table order
+struct EvmPairC {
+    uint16_t a, b;
+    float thr;   // min of the two relative breaking thresholds (btCollisionDispatcher::getNewManifold)
+    float mu;    // product of the two frictions, clamped to +-10 (btManifoldResult::calculateCombinedFriction)
 };
 struct EvmHingeC {
     int a, b;
@@ -120,6 +136,8 @@ struct EvmSkelC {
     float min_vel, target_vel;
     int max_steps, init_remaining, reset_frames;
     int env_kind;          // 0 robot_walk, 1 robot_jump (EvmEnvParams::env_kind)
+    int self_collision;    // member-vs-member contacts (EvmEnvParams::self_collision)
+    int npair;             // collidable member pairs (0 unless self_collision)
     int settle_steps;      // physics steps inside reset(): 2 * reset_frames (robot_walk.cpp:98-103) or reset_frames (robot_jump.cpp:104)
     float reset_angle_limit;  // pi * 2 / 3 (robot_walk.cpp:80) or pi / 3 (robot_jump.cpp:89)
     // scratch layout (offsets in floats-per-env)
@@ -154,6 +172,8 @@ struct EvmSkelC {
     // hull vertices in PAIRS: vertex g = 2 P + s has x, y, z at hull[6 P + s], hull[6 P + 2 + s], hull[6 P + 4 + s]
     // (two vertices per packed multiply/add in the scan); a hull with an odd count repeats its last vertex
     float hull[EVM_MAX_HULL_PTS * 3];
+    EvmPairC pair[EVM_MAX_PAIRS];
+    uint16_t pair_order[EVM_MAX_PAIRS];  // the pairs by decreasing narrowphase cost (hull sizes): the pair kernel's item order
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -191,6 +211,8 @@ struct EvmGSchedC {
     int nrq;                            // quads of the joint-record image per env: (sc_c - sc_h) / 4
     int lds_bytes;                      // dynamic LDS of the kernel for this skeleton
     float est_cycles;                   // host estimate of the ten sweeps (information only)
+    int with_contacts;                  // 1: the schedule carries the members' contact entries (floor contacts only); 0: joint
+                                        // entries only, the contact rows run as barrier-separated rounds (member-vs-member mode)
     EvmGEntryC entry[EVM_G_MAX_ENTRIES];
     EvmGSlotC slot[EVM_G_MAX_ENTRIES][EVM_G_SLOTS];
 };

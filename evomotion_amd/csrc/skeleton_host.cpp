@@ -89,7 +89,7 @@ void quat_rotate(const float q[4], const float v[3], float out[3]) {
 // Box-like inertia of the margin-inflated local AABB + the relative contact breaking threshold
 // (btPolyhedralConvexShape::calculateLocalInertia, btCollisionShape::getContactBreakingThreshold).
 void shape_properties(const std::vector<float> &pts, const float scale[3], float mass, float inv_inertia[3],
-                      float &break_thr) {
+                      float &break_thr, float *aabb_c = nullptr, float *aabb_h = nullptr) {
     float hi[3] = {-1e18f, -1e18f, -1e18f}, lo[3] = {1e18f, 1e18f, 1e18f};
     for (size_t i = 0; i + 2 < pts.size(); i += 3)
         for (int a = 0; a < 3; a++) {
@@ -105,6 +105,10 @@ void shape_properties(const std::vector<float> &pts, const float scale[3], float
         float centre = 0.5f * (lmax + lmin);
         amin[a] = centre - half;
         amax[a] = centre + half;
+        // btTransformAabb(localMin, localMax, margin, trans) works on exactly these; btCollisionWorld::updateSingleAabb
+        // fattens the world box by gContactBreakingThreshold, which commutes with the transform when added to the extents
+        if (aabb_c) aabb_c[a] = centre;
+        if (aabb_h) aabb_h[a] = half;
     }
     float l[3];
     for (int a = 0; a < 3; a++) l[a] = 2.f * ((amax[a] - amin[a]) * 0.5f + kMargin);
@@ -478,6 +482,7 @@ int load_skeleton_constants(const char *path, const EvmEnvParams &prm, EvmSkelC 
     S.init_remaining = (int) (prm.initial_remaining_seconds / kDt);
     S.reset_frames = prm.reset_frames;
     S.env_kind = prm.env_kind;
+    S.self_collision = prm.self_collision ? 1 : 0;
     S.settle_steps = prm.env_kind == 1 ? prm.reset_frames : 2 * prm.reset_frames;
     S.reset_angle_limit = prm.env_kind == 1 ? (float) 3.14159265358979323846 / 3.f : (float) 3.14159265358979323846 * 2.f / 3.f;
 
@@ -552,7 +557,8 @@ int load_skeleton_constants(const char *path, const EvmEnvParams &prm, EvmSkelC 
         EvmBodyC &b = S.body[i];
         b.inv_mass = b.mass == 0.f ? 0.f : 1.0f / b.mass;
         float thr;
-        shape_properties(shapes[body_shape[i]].pts, body_scale[i], b.mass, b.inv_inertia, thr);
+        if (i < nm) shape_properties(shapes[body_shape[i]].pts, body_scale[i], b.mass, b.inv_inertia, thr, S.member[i].aabb_c, S.member[i].aabb_h);
+        else shape_properties(shapes[body_shape[i]].pts, body_scale[i], b.mass, b.inv_inertia, thr);
         if (i < nm) S.member[i].break_thr = thr;
         // applyGravity: m_gravity = g * (1 / invMass); solver: externalForceImpulse = (F * invMass) * dt
         float gy = b.inv_mass != 0.f ? -9.8f * (1.0f / b.inv_mass) : 0.f;
@@ -638,6 +644,32 @@ int load_skeleton_constants(const char *path, const EvmEnvParams &prm, EvmSkelC 
         const float miA = S.body[m.sa].inv_mass, miB = S.body[m.sb].inv_mass, miS = miA + miB;
         m.factA = miS > 0.f ? miB / miS : 0.5f;
         m.factB = 1.0f - m.factA;
+    }
+
+    // ---- member pairs that may collide: all but constraint parent / child (setIgnoreCollisionCheck, constraint.cpp:65,147);
+    // members without contact response (member.cpp:31-33) get no rows.  Lexicographic (a < b): body0 = a, body1 = b, and
+    // this is the order of their rows in the solver ----
+    S.npair = 0;
+    if (S.self_collision) {
+        for (int i = 0; i < nm; i++)
+            for (int j = i + 1; j < nm; j++) {
+                if (!S.member[i].contact_response || !S.member[j].contact_response) continue;
+                bool adjacent = false;
+                for (int hq = 0; hq < nh; hq++) adjacent = adjacent || (S.hinge[hq].a == i && S.hinge[hq].b == j) || (S.hinge[hq].a == j && S.hinge[hq].b == i);
+                for (int fq = 0; fq < nf; fq++) adjacent = adjacent || (S.fixed[fq].a == i && S.fixed[fq].b == j) || (S.fixed[fq].a == j && S.fixed[fq].b == i);
+                if (adjacent) continue;
+                EvmPairC &P = S.pair[S.npair++];
+                P.a = (uint16_t) i; P.b = (uint16_t) j;
+                P.thr = std::min(S.member[i].break_thr, S.member[j].break_thr);
+                const float f = S.body[i].friction * S.body[j].friction;
+                P.mu = f < -10.f ? -10.f : (f > 10.f ? 10.f : f);
+            }
+        std::vector<int> ord(S.npair);
+        for (int k = 0; k < S.npair; k++) ord[k] = k;
+        std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) {
+            return S.member[S.pair[x].a].hull_n + S.member[S.pair[x].b].hull_n > S.member[S.pair[y].a].hull_n + S.member[S.pair[y].b].hull_n;
+        });
+        for (int k = 0; k < S.npair; k++) S.pair_order[k] = (uint16_t) ord[k];
     }
 
     // ---- scratch layout ----
@@ -926,6 +958,9 @@ int load_skeleton_constants(const char *path, const EvmEnvParams &prm, EvmSkelC 
 // back-to-back sweeps and improved by moving entries between waves.
 // ---------------------------------------------------------------------------------------------------------------------
 int build_group_schedule(const EvmSkelC &S, int nwaves, EvmGSchedC &G, std::string &err) {
+    // member-vs-member mode: the schedule holds the joint entries only; contact rows (floor and pairs) run after the joint
+    // rows of each sweep as rounds of body-disjoint manifolds chosen per env at run time (sweep_groups.h)
+    const bool with_contacts = !S.self_collision;
     memset(&G, 0, sizeof(G));
     if (nwaves < 1 || nwaves > EVM_G_MAX_WAVES) { err = "group schedule: bad wave count"; return EVM_E_INVALID; }
     struct V { int type, a, b, rec; float imA, imB, aux; int needA, needB; };
@@ -936,7 +971,7 @@ int build_group_schedule(const EvmSkelC &S, int nwaves, EvmGSchedC &G, std::stri
         if (v.type == 2) aux = (S.body[v.a].isotropic && S.body[v.b].isotropic) ? 1.f : 0.f;
         vs.push_back({v.type, v.a, v.b, (v.slot - S.sc_h) / 4, v.imA, v.imB, aux, 0, 0});
     }
-    for (int m = 0; m < S.nm; m++)
+    for (int m = 0; m < S.nm && with_contacts; m++)
         if (S.member[m].contact_response)
             vs.push_back({4, m, m, S.sc_c + EVM_CM_STRIDE * m, S.body[m].inv_mass, S.body[m].inv_mass, S.member[m].mu, 0, 0});
     const int nv = (int) vs.size();
@@ -1206,7 +1241,14 @@ int build_group_schedule(const EvmSkelC &S, int nwaves, EvmGSchedC &G, std::stri
     // LDS image: per env (3 quads per body + the joint records), then the slot table (2 quads per slot) and the entry
     // headers (1 quad each), the version counters and the per-env residuals
     const size_t quads = (size_t) (3 * S.nb + G.nrq) * EVM_G_ENVS + (size_t) ne * (2 * EVM_G_SLOTS + 1);
-    const size_t bytes = quads * 16 + (size_t) ((S.nb + 3) / 4 * 4) * 4 + EVM_G_ENVS * 4;
+    size_t bytes = quads * 16 + (size_t) ((S.nb + 3) / 4 * 4) * 4 + EVM_G_ENVS * 4;
+    G.with_contacts = with_contacts ? 1 : 0;
+    if (!with_contacts) {
+        // behind the image: the contact program (16 slots x 16 envs words), four workgroup-wide words and the bodies'
+        // inverse masses
+        bytes = (bytes + 15) & ~(size_t) 15;
+        bytes += (size_t) 16 * EVM_G_ENVS * 4 + 16 + (size_t) ((S.nb + 3) & ~3) * 4;
+    }
     G.lds_bytes = (int) bytes;
     if (bytes > 160 * 1024) { err = "skeleton records exceed the LDS image of the lane-group sweeps"; return EVM_E_UNSUPPORTED; }
     return EVM_OK;

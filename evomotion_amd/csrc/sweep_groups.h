@@ -48,8 +48,9 @@ DEV void g_wait2(GCtx &G, const Ctx &c, int a, int expA, int b, int expB) {
         const int vb = __hip_atomic_load(&G.ver[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (va >= expA && vb >= expB) break;
         if (++spins > EVM_SPIN_HOT) __builtin_amdgcn_s_sleep(1);
-        // a schedule bug must not hang the GPU: give up, poison the diagnostic slot and stop waiting for the rest of the launch
-        if (spins > (1 << 16)) { c.t.diag[c.lane] = -1.f; G.multi = false; break; }
+        // a schedule bug must not hang the GPU: give up and stop waiting for the rest of the launch; the batch residual is
+        // poisoned with +inf (sticky: evm_env_get_residual returns it until cleared; the tests and the soak assert on it)
+        if (spins > (1 << 20)) { atomicMax(c.d.resid, 0x7f800000); G.multi = false; break; }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     GWAIT_T1
@@ -229,6 +230,10 @@ DEV float g_contact(const GCtx &G, const Ctx &c, const Blk42 &k, int rec, int m,
     return res;
 }
 
+}  // namespace evm
+#include "contact_rounds.h"
+namespace evm {
+
 DEV Ctx make_ctx_at(const EnvDev &d, float *lds, int tile64, int lane64, int wave) {
     Ctx c;
     c.d = d;
@@ -245,6 +250,7 @@ DEV Ctx make_ctx_at(const EnvDev &d, float *lds, int tile64, int lane64, int wav
     c.t.target = d.target + tile * nmus; c.t.E = d.E + tile * 9; c.t.iinv_stale = d.iinv_stale + tile * (6 * nb);
     c.t.mt = d.mt + tile * 624; c.t.scratch = d.scratch + tile * c_skel.sc_total;
     c.t.diag = d.diag + tile * 2; c.t.stat = d.stat + tile * 2;
+    ctx_pair_arrays(c, d, tile);
     return c;
 }
 
@@ -282,6 +288,14 @@ __global__ __launch_bounds__(64 * EVM_G_MAX_WAVES) void k_sweeps_g(EnvDev d, con
         const f32x4 *hs = reinterpret_cast<const f32x4 *>(&gs->entry[0]);
         for (int i = threadIdx.x; i < total; i += blockDim.x) hdr[i] = hs[i];
         for (int i = threadIdx.x; i < ((nb + 3) & ~3) + EVM_G_ENVS; i += blockDim.x) ver_base[i] = 0;
+        if (gs->with_contacts == 0) {  // member-vs-member mode: empty contact program, workgroup-wide words, inverse masses
+            unsigned *prog0 = reinterpret_cast<unsigned *>(resmax + EVM_G_ENVS);
+            for (int i = threadIdx.x; i < 16 * EVM_G_ENVS; i += blockDim.x) prog0[i] = 0xffffffffu;
+            int *meta0 = reinterpret_cast<int *>(prog0 + 16 * EVM_G_ENVS);
+            if (threadIdx.x < 4) meta0[threadIdx.x] = 0;
+            float *imt0 = reinterpret_cast<float *>(meta0 + 4);
+            for (int i = threadIdx.x; i < nb; i += blockDim.x) imt0[i] = c_skel.body[i].inv_mass;
+        }
     }
 #if defined(EVM_GSTAMPS) || defined(EVM_GSTAMPS2)  // diagnostic builds (tools/gstamps.py)
     const unsigned long long gs_t0 = __builtin_amdgcn_s_memtime();
@@ -376,6 +390,41 @@ __global__ __launch_bounds__(64 * EVM_G_MAX_WAVES) void k_sweeps_g(EnvDev d, con
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the LDS-DMA requests of the record image have landed
     __syncthreads();
+
+    // ---- member-vs-member mode: contact program, the owners' records into registers, split-impulse recovery, warm start ----
+    const bool scm = gs->with_contacts == 0;  // (wave-uniform)
+    CBank K0;
+    K0.id = -1; K0.round = -1;
+    int nrounds = 0;
+    unsigned *prog = reinterpret_cast<unsigned *>(resmax + EVM_G_ENVS);  // [16 slots][16 envs]
+    int *meta = reinterpret_cast<int *>(prog + 16 * EVM_G_ENVS);          // rounds, -, split impulse needed, -
+    float *imt = reinterpret_cast<float *>(meta + 4);                     // inverse mass per body
+    if (scm) {  // (program, words and inverse masses were initialised by every thread before any lane left)
+        if (wave == 0) {
+            int nn[EVM_MAX_MEMBERS];
+#pragma unroll
+            for (int m = 0; m < EVM_MAX_MEMBERS; m++) nn[m] = m < nm ? GS(mfn, m) : 0;
+            if (!g_build_program(c, G, nw, nn, prog, meta)) atomicMax(d.resid, 0x7f800000);  // sticky: a manifold was left out
+        }
+        g_lds_barrier();
+        nrounds = __builtin_amdgcn_readfirstlane(meta[0]);
+        const int slot = wave * EVM_G_SLOTS + G.g;
+        g_bank_load(c, prog[(slot << 4) + G.e], K0);
+        if (__builtin_amdgcn_readfirstlane(meta[2]) != 0) {
+            // solveGroupCacheFriendlySplitImpulseIterations: the same rounds on the push / turn velocities (sc_pt, zeroed by the
+            // setup kernel); ten iterations like the oracle (further ones would add exactly nothing once an iteration changes nothing)
+            float pa0[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int it = 0; it < NUM_ITER; it++)
+                for (int r = 0; r < nrounds; r++) {
+                    g_split_bank(G, c, K0, K0.round == r, pa0, imt);
+                    g_lds_barrier();
+                }
+        }
+        for (int r = 0; r < nrounds; r++) {
+            g_contact_bank<0>(G, K0, K0.round == r, imt);
+            g_lds_barrier();
+        }
+    }
 
 #if defined(EVM_GSTAMPS) || defined(EVM_GSTAMPS2)
     const unsigned long long gs_t1 = __builtin_amdgcn_s_memtime();
@@ -479,6 +528,18 @@ __global__ __launch_bounds__(64 * EVM_G_MAX_WAVES) void k_sweeps_g(EnvDev d, con
             }
             j0 += run;
         }
+        if (scm) {
+            // contact rows of this sweep: all normal rows, then all friction rows, each as rounds of body-disjoint manifolds
+            g_lds_barrier();
+            for (int r = 0; r < nrounds; r++) {
+                rs = fmaxf(rs, g_contact_bank<1>(G, K0, K0.round == r, imt));
+                g_lds_barrier();
+            }
+            for (int r = 0; r < nrounds; r++) {
+                rs = fmaxf(rs, g_contact_bank<2>(G, K0, K0.round == r, imt));
+                g_lds_barrier();
+            }
+        }
         if (it == NUM_ITER - 1) res = rs;
     }
     atomicMax(&resmax[G.e], __float_as_int(res));
@@ -495,6 +556,9 @@ __global__ __launch_bounds__(64 * EVM_G_MAX_WAVES) void k_sweeps_g(EnvDev d, con
             gt[(b * 6 + 0) << 6] = q0[0]; gt[(b * 6 + 1) << 6] = q0[1]; gt[(b * 6 + 2) << 6] = q0[2];
             gt[(b * 6 + 3) << 6] = q0[3]; gt[(b * 6 + 4) << 6] = q1[0]; gt[(b * 6 + 5) << 6] = q1[1];
         }
+    }
+    if (scm) {
+        g_bank_writeback(c, K0);
     }
     // ---- contact impulses back into the manifolds (by the lane group that ran the member's contact rows) ----
     for (int j = 0; j < count; j++) {

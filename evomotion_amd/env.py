@@ -17,8 +17,14 @@ from ._lib import EvmEnvParams, check, lib
 Step = namedtuple("Step", ["state", "reward", "done"])
 RolloutStep = namedtuple("RolloutStep", ["state", "reward", "done", "valid"])
 
-# RobotWalkFactory parameter names and defaults (evo_motion_model/src/env/env_factory.cpp:74-83)
+# Collision mode when the parameters do not say: 1 = member-vs-member contacts as in the reference (every pair of members except
+# constraint parent / child, constraint.cpp:65,147), 0 = floor contacts only (the north-star's plane-contact configuration)
+SELF_COLLISION_DEFAULT = 1
+
+# RobotWalkFactory parameter names and defaults (evo_motion_model/src/env/env_factory.cpp:74-83); "self_collision" is this
+# path's own switch
 _PARAM_DEFAULTS = {
+    "self_collision": SELF_COLLISION_DEFAULT,
     "skeleton_json_path": _lib.DEFAULT_SKELETON,
     "initial_remaining_seconds": 1.0,
     "max_episode_seconds": 30.0,
@@ -34,6 +40,7 @@ def _ptr(t):
 
 # RobotJumpFactory parameter names and defaults (env_factory.cpp:91-100)
 _JUMP_DEFAULTS = {
+    "self_collision": SELF_COLLISION_DEFAULT,
     "skeleton_json_path": _lib.DEFAULT_SKELETON,
     "minimal_velocity": 0.1,
     "target_velocity": 0.5,
@@ -57,10 +64,17 @@ class VecRobotWalk:
     ENV_KIND = 0
 
     def _parameters(self, parameters):
+        # keys the factory does not know are ignored, as EnvironmentFactory::generic_get_value does (env_factory.cpp:22-28), so
+        # one parameter map can serve several environments; parameters={"strict": 1, ...} turns them into ValueError
         prm = dict(_PARAM_DEFAULTS)
+        strict = bool(int((parameters or {}).get("strict", 0)))
         for k, v in (parameters or {}).items():
+            if k == "strict":
+                continue
             if k not in prm:
-                raise ValueError(k)
+                if strict:
+                    raise ValueError(k)
+                continue
             prm[k] = type(_PARAM_DEFAULTS[k])(v)
         return prm
 
@@ -71,7 +85,7 @@ class VecRobotWalk:
         self.device = torch.device("cuda", device)
         self.n_envs = int(n_envs)
         p = EvmEnvParams(prm["initial_remaining_seconds"], prm["max_episode_seconds"], prm["target_velocity"],
-                         prm["minimal_velocity"], prm["reset_frames"], self.ENV_KIND)
+                         prm["minimal_velocity"], prm["reset_frames"], self.ENV_KIND, int(prm.get("self_collision", SELF_COLLISION_DEFAULT)))
         self._h = ctypes.c_void_p()
         # int(initial_remaining_seconds / dt) in fp32 (robot_walk.cpp:30, SURVEY App. D: 59 for the default 1 s)
         self._remaining0 = int(np.float32(prm["initial_remaining_seconds"]) / (np.float32(1.0) / np.float32(60.0)))
@@ -84,6 +98,9 @@ class VecRobotWalk:
         c = [ctypes.c_int() for _ in range(4)]
         check(lib.evm_env_counts(self._h, *[ctypes.byref(x) for x in c]))
         _, self.n_bodies, self.n_members, self.n_muscles = [x.value for x in c]
+        npairs = ctypes.c_int()
+        check(lib.evm_env_pairs(self._h, ctypes.byref(npairs), None))
+        self.n_pairs = npairs.value
         self.obs = torch.zeros(self.n_envs, self.state_dim, device=self.device)
         self.reward = torch.zeros(self.n_envs, device=self.device)
         self.done = torch.zeros(self.n_envs, dtype=torch.uint8, device=self.device)
@@ -228,11 +245,16 @@ class VecRobotJump(VecRobotWalk):
 
     def _parameters(self, parameters):
         prm = dict(_JUMP_DEFAULTS)
+        strict = bool(int((parameters or {}).get("strict", 0)))
         for k, v in (parameters or {}).items():
+            if k == "strict":
+                continue
             if k not in prm:
-                raise ValueError(k)
+                if strict:
+                    raise ValueError(k)
+                continue
             prm[k] = type(_JUMP_DEFAULTS[k])(v)
         dt = np.float32(1.0) / np.float32(60.0)
-        return dict(skeleton_json_path=prm["skeleton_json_path"], initial_remaining_seconds=prm["initial_seconds"],
+        return dict(skeleton_json_path=prm["skeleton_json_path"], self_collision=prm["self_collision"], initial_remaining_seconds=prm["initial_seconds"],
                     max_episode_seconds=prm["max_seconds"], target_velocity=prm["target_velocity"],
                     minimal_velocity=prm["minimal_velocity"], reset_frames=int(np.float32(prm["reset_seconds"]) / dt))

@@ -18,7 +18,9 @@ int main(int argc, char **argv) {
         EXPECT(threw);  // unknown environment name
         threw = false;
         try { get_environment_factory("robot_walk", {{"no_such_parameter", "1"}}); } catch (const std::invalid_argument &) { threw = true; }
-        EXPECT(threw);  // unknown parameter key
+        EXPECT(!threw);  // unknown parameter keys are ignored, like EnvironmentFactory::generic_get_value (env_factory.cpp:22-28)
+        try { get_environment_factory("robot_walk", {{"no_such_parameter", "1"}, {"strict", "1"}}); } catch (const std::invalid_argument &) { threw = true; }
+        EXPECT(threw);   // ... unless the adapter's own `strict` switch is on
         auto factory = get_environment_factory("robot_walk", {{"skeleton_json_path", argv[1]}, {"max_episode_seconds", "2"}});
         auto env = factory->get_env(/*num_threads=*/8, /*seed=*/1234);
         EXPECT(env->get_state_space() == std::vector<int64_t>{371} && env->get_action_space() == std::vector<int64_t>{12});

@@ -4,7 +4,8 @@
 //                         environment.h:56-72): reset() / do_step(action) -> step{state, reward, done}, get_state_space(),
 //                         get_action_space(); built by RobotWalkHipFactory::get_env(num_threads, seed) which
 //                         get_environment_factory(name, parameters) returns (environment.h:80,96-97; parameter names and
-//                         defaults of env_factory.cpp:74-83,91-100; unknown names / keys -> std::invalid_argument, :118).
+//                         defaults of env_factory.cpp:74-83,91-100; an unknown NAME -> std::invalid_argument, :118; unknown parameter
+//                         KEYS are ignored, like EnvironmentFactory::generic_get_value, :22-28).
 //   VecRobotWalkHip       N environments behind the same calls plus the train loop's body as one call
 //                         (src/train.cpp:61-66: while(!done) do_step; done(); reset()) = step_autoreset().
 //
@@ -46,18 +47,20 @@ public:
         : n(n_envs), stream_(stream) {
         hip_check(hipSetDevice(device), "hipSetDevice");
         check(evm_env_create(skeleton_json_path.c_str(), n_envs, device, (uint64_t) seed, &params, &env));
-        check(evm_env_spaces(env, &state_dim, &action_dim));
-        hip_check(hipMalloc(&d_obs, sizeof(float) * (size_t) n * state_dim), "hipMalloc");
-        hip_check(hipMalloc(&d_reward, sizeof(float) * n), "hipMalloc");
-        hip_check(hipMalloc(&d_done, n), "hipMalloc");
-        hip_check(hipMalloc(&d_valid, n), "hipMalloc");
+        try {
+            check(evm_env_spaces(env, &state_dim, &action_dim));
+            hip_check(hipMalloc(&d_obs, sizeof(float) * (size_t) n * state_dim), "hipMalloc");
+            hip_check(hipMalloc(&d_reward, sizeof(float) * n), "hipMalloc");
+            hip_check(hipMalloc(&d_done, n), "hipMalloc");
+            hip_check(hipMalloc(&d_valid, n), "hipMalloc");
+        } catch (...) {  // a constructor that throws runs no destructor: release what was taken
+            release();
+            throw;
+        }
     }
     VecRobotWalkHip(const VecRobotWalkHip &) = delete;
     VecRobotWalkHip &operator=(const VecRobotWalkHip &) = delete;
-    ~VecRobotWalkHip() {
-        if (env) evm_env_destroy(env);
-        (void) hipFree(d_obs); (void) hipFree(d_reward); (void) hipFree(d_done); (void) hipFree(d_valid);
-    }
+    ~VecRobotWalkHip() { release(); }
     // Environment::reset (environment.cpp:45-48) for every env
     void reset() { check(evm_env_reset(env, nullptr, d_obs, d_reward, d_done, stream_)); }
     // Environment::do_step (environment.cpp:33-39) for every env; d_action [n, action_dim] on the device
@@ -77,6 +80,12 @@ public:
     int state_dim = 0, action_dim = 0;
 
 private:
+    void release() {
+        if (env) evm_env_destroy(env);
+        env = nullptr;
+        (void) hipFree(d_obs); (void) hipFree(d_reward); (void) hipFree(d_done); (void) hipFree(d_valid);
+        d_obs = d_reward = nullptr; d_done = d_valid = nullptr;
+    }
     EvmEnv *env = nullptr;
     hipStream_t stream_;
     float *d_obs = nullptr, *d_reward = nullptr;
@@ -110,7 +119,10 @@ public:
     RobotWalkHipFactory(const std::string &env_name, std::map<std::string, std::string> parameters) {
         check(evm_env_default_params_for(env_name.c_str(), &prm));  // unknown env name -> std::invalid_argument
         const bool jump = prm.env_kind == 1;
-        // typed parameters with defaults (env_factory.cpp:22-28,74-83,91-100); an unknown key throws like the reference
+        // typed parameters with defaults (env_factory.cpp:74-83,91-100).  Keys the factory does not know are ignored, as
+        // EnvironmentFactory::generic_get_value does (:22-28: it only ever looks up the keys it wants), so one parameter map
+        // can be shared between environments; `strict` (this adapter's own switch) turns them into std::invalid_argument.
+        const bool strict = parameters.count("strict") && parameters["strict"] != "0";
         for (const auto &kv : parameters) {
             const std::string &k = kv.first;
             if (k == "skeleton_json_path") skeleton = kv.second;
@@ -120,15 +132,22 @@ public:
             else if (k == "minimal_velocity") prm.minimal_velocity = std::stof(kv.second);
             else if (!jump && k == "reset_frames") prm.reset_frames = std::stoi(kv.second);
             else if (jump && k == "reset_seconds") prm.reset_frames = (int) (std::stof(kv.second) / (1.f / 60.f));
-            else throw std::invalid_argument(k);
+            else if (k == "self_collision") prm.self_collision = std::stoi(kv.second);  // this path's own switch (evomotion.h)
+            else if (k == "strict") continue;
+            else if (strict) throw std::invalid_argument(k);
         }
     }
     std::shared_ptr<RobotWalkHip> get_env(int /*num_threads*/, int seed) {
-        if (skeleton.empty()) throw std::runtime_error("skeleton_json_path is not set");
         return std::make_shared<RobotWalkHip>(seed, skeleton, prm);
     }
     EvmEnvParams prm;
-    std::string skeleton;
+    // the reference's default is RESOURCES_PATH/resources/skeleton/new_format_spider.json (env_factory.cpp:79-80,95-96); its
+    // decoded copy ships with this package (EVM_DEFAULT_SKELETON: set by the build to evomotion_amd/data/robot_walk_spider.skel)
+#ifdef EVM_DEFAULT_SKELETON
+    std::string skeleton = EVM_DEFAULT_SKELETON;
+#else
+    std::string skeleton = "evomotion_amd/data/robot_walk_spider.skel";
+#endif
 };
 inline std::shared_ptr<RobotWalkHipFactory> get_environment_factory(const std::string &env_name, std::map<std::string, std::string> parameters) {
     return std::make_shared<RobotWalkHipFactory>(env_name, std::move(parameters));

@@ -41,6 +41,9 @@ typedef struct EvmEnvParams {
     int env_kind;                    /* 0 = robot_walk, 1 = robot_jump (evo_motion_model/src/env/robot_jump.cpp:66-110:
                                         reward max(vy, 0) + vz, fail on remaining < 0, reset angles within pi/3, and
                                         reset_frames = int(reset_seconds / dt) = 10 settle steps in one loop) */
+    int self_collision;              /* 1 (default) = member-vs-member contacts as in the reference: every pair of members may
+                                        collide except constraint parent / child (evo_motion_model/src/robot/constraint.cpp:65,147;
+                                        dispatcher / broadphase evo_motion_model/src/environment.cpp:20-31); 0 = floor contacts only */
 } EvmEnvParams;
 
 const char *evm_last_error(void);
@@ -63,6 +66,10 @@ void evm_env_destroy(EvmEnv *env);
 /* Environment::get_state_space / get_action_space (environment.h:66-67): 371 and 12 for robot_walk. */
 int evm_env_spaces(const EvmEnv *env, int *state_dim, int *action_dim);
 int evm_env_counts(const EvmEnv *env, int *n_envs, int *n_bodies, int *n_members, int *n_muscles);
+/* Member pairs that may collide (EvmEnvParams::self_collision): every pair of members except constraint parent / child
+ * (constraint.cpp:65,147), lexicographic — also the order of their contact rows in the solver.  h_pairs (optional)
+ * [n_pairs, 2] member indices.  n_pairs = 0 with self_collision = 0. */
+int evm_env_pairs(const EvmEnv *env, int *n_pairs, int *h_pairs);
 
 /*
  * Environment::reset() (evo_motion_model/src/environment.cpp:45-48 -> RobotWalk::reset_engine,
@@ -102,6 +109,7 @@ int evm_env_get_body_poses(const EvmEnv *env, float *d_pose, void *stream);
  *   nm x motion_state_origin[3]
  *   nm x (last_lin[3], last_ang[3])          (proprioception history, member array order)
  *   nm x (count, 4 x (localA[3], localB[3], dist, applied, applied_lateral))
+ *   with self_collision: n_pairs x (count, 4 x (localA[3], localB[3], normalOnB[3], dist, applied, applied_lateral))
  *   nmuscle x target_velocity, powered, curr_step, remaining_steps
  */
 int evm_env_state_size(const EvmEnv *env);
@@ -129,6 +137,9 @@ int evm_skeleton_schedule(const char *skeleton_path, int *dims, int *visits, int
  * entries [n, 2 + 5 * 4] = wave | global order << 8, type (0 hinge, 1 fixed, 2 slider, 3 p2p, 4 contact rows), then per slot
  * record (-1 = empty), body a, body b, need (versions a | b << 16), visits per sweep (a | b << 16). */
 int evm_skeleton_group_schedule(const char *skeleton_path, int n_waves, int *dims, int *entries, int cap);
+/* the same for a collision mode: with self_collision = 1 the schedule holds the joint entries only (the contact rows of
+ * floor and member-pair manifolds run as rounds chosen per env at run time: csrc/contact_rounds.h) */
+int evm_skeleton_group_schedule_ex(const char *skeleton_path, int n_waves, int self_collision, int *dims, int *entries, int cap);
 /* Loader cross-check: per body 19 floats [mass, inv_mass, invI xyz, friction, break_thr, M0 rows(9), t0(3)] */
 int evm_env_get_body_constants(const EvmEnv *env, float *h_out);
 /* Per-env diagnostics of the last physics step: [max |delta impulse| of the last PGS iteration, contacts] */

@@ -1203,7 +1203,7 @@ void World::do_step(const float *action, float *obs, float *reward, int *done) {
 // canonical state blob (layout documented in include/evomotion.h, EVM_STATE_*)
 // ------------------------------------------------------------------------------------------------
 int World::state_size() const {
-    // ... then, with self_collision, per member pair in lexicographic order: count, 4 x (localA3 localB3 normalOnB3 dist applied applied_lateral)
+    // (49 per member pair, right after the floor manifolds: count, 4 x (localA3 localB3 normalOnB3 dist applied applied_lateral))
     return 13 * nb() + 1 + 9 + 6 * nb() + 3 * nmember() + 6 * nmember() + 37 * nmember() + nmuscle() + 1 + 2 + 49 * npairs();
 }
 void World::get_state(float *o) const {
@@ -1237,10 +1237,6 @@ void World::get_state(float *o) const {
             } else for (int t = 0; t < 9; t++) o[k++] = 0.f;
         }
     }
-    for (const Slider &s : sliders) o[k++] = s.target_vel;
-    o[k++] = (!sliders.empty() && sliders[0].powered) ? 1.f : 0.f;
-    o[k++] = (float) curr_step;
-    o[k++] = (float) remaining_steps;
     for (const PairManifold &pm : pairs) {
         o[k++] = (float) pm.mf.n;
         for (int j = 0; j < 4; j++) {
@@ -1253,6 +1249,10 @@ void World::get_state(float *o) const {
             } else for (int t = 0; t < 12; t++) o[k++] = 0.f;
         }
     }
+    for (const Slider &s : sliders) o[k++] = s.target_vel;
+    o[k++] = (!sliders.empty() && sliders[0].powered) ? 1.f : 0.f;
+    o[k++] = (float) curr_step;
+    o[k++] = (float) remaining_steps;
 }
 void World::set_state(const float *in) {
     int k = 0;
@@ -1296,11 +1296,6 @@ void World::set_state(const float *in) {
             p.normalB = V3(0.f, -1.f, 0.f);
         }
     }
-    for (Slider &s : sliders) s.target_vel = in[k++];
-    bool powered = in[k++] != 0.f;
-    for (Slider &s : sliders) s.powered = powered;
-    curr_step = (int) in[k++];
-    remaining_steps = (int) in[k++];
     for (PairManifold &pm : pairs) {
         pm.mf.n = (int) in[k++];
         for (int j = 0; j < 4; j++) {
@@ -1311,6 +1306,11 @@ void World::set_state(const float *in) {
             p.dist = in[k++]; p.applied = in[k++]; p.applied_lat = in[k++];
         }
     }
+    for (Slider &s : sliders) s.target_vel = in[k++];
+    bool powered = in[k++] != 0.f;
+    for (Slider &s : sliders) s.powered = powered;
+    curr_step = (int) in[k++];
+    remaining_steps = (int) in[k++];
 }
 void World::get_poses(float *o) const {
     int k = 0;

@@ -1,4 +1,5 @@
-"""Writes tests/golden/physics_trace.txt: a SELF-PIN of the CPU oracle (oracle/liborc.so) — 4 environments x 256 do_step
+"""Writes tests/golden/physics_trace.txt (floor contacts only) and tests/golden/physics_trace_selfcol.txt (member-vs-member
+contacts, the reference's behaviour): a SELF-PIN of the CPU oracle (oracle/liborc.so) — 4 environments x 256 do_step
 calls with seeded uniform actions (resets included), every 4th call recorded.  It is not a reference output (Bullet3 cannot
 be built here): its purpose is that a refactor of the oracle cannot drift silently
 (tests/test_oracle_constants.py::test_oracle_matches_its_committed_trace).   python tests/diag/make_physics_trace.py"""
@@ -14,10 +15,10 @@ import orc  # noqa: E402
 N_ENV, N_STEP, EVERY = 4, 256, 4
 
 
-def trace(lib=None):
+def trace(lib=None, self_collision=0):
     rows = []
     for i in range(N_ENV):
-        e = orc.OracleEnv(seed=1234 + i, lib=lib)
+        e = orc.OracleEnv(seed=1234 + i, lib=lib, self_collision=self_collision)
         obs, rew, done = e.reset()
         rng = np.random.default_rng(100 + i)
         for k in range(N_STEP):
@@ -34,8 +35,9 @@ def trace(lib=None):
 
 
 if __name__ == "__main__":
-    t = trace()
-    out = os.path.join(ROOT, "tests", "golden", "physics_trace.txt")
+  for mode, name in ((0, "physics_trace.txt"), (1, "physics_trace_selfcol.txt")):
+    t = trace(self_collision=mode)
+    out = os.path.join(ROOT, "tests", "golden", name)
     with open(out, "w") as f:
         f.write("# SELF-PIN of oracle/liborc.so (tests/diag/make_physics_trace.py), not a Bullet3 output: env, call, done, reward, root xyz, "
                 "sum |member positions|, sum(root block of the observation), sum |observation|\n")

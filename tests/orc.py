@@ -58,7 +58,7 @@ def load():
 
 # collision mode of the oracle envs the tests create unless they say otherwise: 1 = member-vs-member contacts (the
 # reference's behaviour), 0 = floor contacts only
-SELF_COLLISION_DEFAULT = 0
+SELF_COLLISION_DEFAULT = 1
 
 
 def gjk_query(ptsA, scaleA, xfA, ptsB, scaleB, xfB, max_dist2=1e18, lib=None):

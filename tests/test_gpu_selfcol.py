@@ -1,0 +1,137 @@
+"""Member-vs-member contacts (EvmEnvParams::self_collision = 1, the reference's behaviour: every pair of members may collide
+except constraint parent / child, evo_motion_model/src/robot/constraint.cpp:65,147) — the HIP path through the C ABI against
+the CPU oracle, teacher-forced (both sides start every step from the oracle's state, so the numbers are single-step errors),
+and the known answers of tests/physics_cases.py on the HIP backend."""
+import numpy as np
+import pytest
+
+import blob
+import orc
+import physics_cases as pc
+from conftest import write_skeleton
+
+pytestmark = pytest.mark.gpu
+
+SLIDER_IMPULSE_COLS = np.arange(324, 371, 4)
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch
+
+
+def make(n, seed=1234, **kw):
+    from evomotion_amd import VecRobotWalk
+    prm = dict(kw.pop("parameters", {}))
+    prm["self_collision"] = 1
+    return VecRobotWalk(n, seed=seed, parameters=prm, **kw)
+
+
+def test_pair_table_matches_the_oracle(torch_mod, orc_lib):
+    import ctypes
+    from evomotion_amd._lib import check, lib
+    env = make(2)
+    o = orc.OracleEnv(lib=orc_lib, self_collision=1)
+    assert env.n_pairs == len(o.pairs()) == 120            # 17 * 16 / 2 - 16 constraint pairs
+    got = np.zeros((env.n_pairs, 2), np.int32)
+    n = ctypes.c_int()
+    check(lib.evm_env_pairs(env._h, ctypes.byref(n), got.ctypes.data_as(ctypes.POINTER(ctypes.c_int))))
+    assert np.array_equal(got, o.pairs())
+    assert env.state_size() == o.state_size()
+
+
+def test_teacher_forced_steps_with_member_contacts(torch_mod, orc_lib):
+    torch = torch_mod
+    n, steps = 32, 150
+    env = make(n)
+    orcs = [orc.OracleEnv(seed=1234 + i, lib=orc_lib, self_collision=1) for i in range(n)]
+    npairs = env.n_pairs
+    for o in orcs:
+        o.reset()
+    rng = np.random.default_rng(0)
+    worst = dict(pos=0.0, quat=0.0, lin=0.0, ang=0.0, obs=0.0, slider_imp_flips=0, rew=0.0, done=0, mf=0, pm_mismatch=0, pm_live=0,
+                 pm_geom=0.0, pm_impulse=0.0)
+    pair_points = 0
+    for k in range(steps):
+        so = np.stack([o.get_state() for o in orcs])
+        env.set_state(so)
+        a = rng.uniform(-1, 1, (n, 12)).astype(np.float32)
+        st = env.do_step(torch.from_numpy(a))
+        og, rg, dg = st.state.cpu().numpy(), st.reward.cpu().numpy(), st.done.cpu().numpy()
+        outs = [o.do_step(a[i]) for i, o in enumerate(orcs)]
+        pair_points += sum(o.pair_stats()["pair_contacts"] for o in orcs)
+        oo = np.stack([x[0] for x in outs])
+        d = blob.compare(np.stack([o.get_state() for o in orcs]), env.get_state(), 41, 17, 12, npairs)
+        for key in ("pos", "quat", "lin", "ang", "pm_geom", "pm_impulse"):
+            worst[key] = max(worst[key], d[key])
+        worst["mf"] = max(worst["mf"], d["mf_count"])
+        worst["pm_mismatch"] += d["pm_count_mismatches"]
+        worst["pm_live"] += d["pm_live"]
+        e = np.abs(og - oo)
+        flips = e[:, SLIDER_IMPULSE_COLS] > 1e-3
+        worst["slider_imp_flips"] += int(flips.sum())
+        e[:, SLIDER_IMPULSE_COLS] = np.where(flips, 0, e[:, SLIDER_IMPULSE_COLS])
+        worst["obs"] = max(worst["obs"], float(e.max()))
+        worst["rew"] = max(worst["rew"], float(np.abs(rg - np.array([x[1] for x in outs])).max()))
+        worst["done"] += int((dg.astype(bool) != np.array([x[2] for x in outs])).sum())
+        for i, o in enumerate(orcs):
+            if outs[i][2]:
+                o.reset()
+    print("teacher-forced with member-vs-member contacts, worst:", worst, "pair contact points per env-step: %.2f" % (pair_points / (n * steps)))
+    assert pair_points > 0.5 * n * steps            # the regime is exercised: member pairs really touch
+    # the same fp32 tolerances as the floor-only test, for ONE 1/60 s step from identical state
+    assert worst["pos"] < 5e-6 and worst["quat"] < 5e-6
+    assert worst["lin"] < 5e-4 and worst["ang"] < 2e-3
+    assert worst["obs"] < 2e-3 and worst["rew"] < 1e-4
+    assert worst["done"] == 0 and worst["mf"] == 0
+    # the narrowphase is compiled without contraction on both sides: the same transforms give the same contact point
+    assert worst["pm_mismatch"] == 0, worst
+    assert worst["pm_geom"] < 5e-6 and worst["pm_impulse"] < 2e-4, worst
+    assert env.residual(clear=True) < 1e30           # no version wait timed out, no manifold was left out
+
+
+def test_reset_and_rollout_with_member_contacts(torch_mod, orc_lib):
+    """free-running: reset() (60 settle steps) and a short rollout stay close to the oracle; in-band autoreset keeps going"""
+    torch = torch_mod
+    n = 16
+    env = make(n)
+    orcs = [orc.OracleEnv(seed=1234 + i, lib=orc_lib, self_collision=1) for i in range(n)]
+    st = env.reset()
+    for o in orcs:
+        o.reset()
+    assert np.isfinite(st.state.cpu().numpy()).all()
+    errs = [np.abs(env.body_poses().cpu().numpy()[i, :17, :3] - orcs[i].poses()[:17, :3]).max() for i in range(n)]
+    print("member position error after reset(): max %.3g median %.3g" % (max(errs), np.median(errs)))
+    assert np.median(errs) < 2e-2 and max(errs) < 0.3
+    rng = np.random.default_rng(5)
+    for k in range(300):
+        a = torch.from_numpy(rng.uniform(-1, 1, (n, 12)).astype(np.float32))
+        r = env.step_autoreset(a)
+    assert np.isfinite(r.state.cpu().numpy()).all()
+    p = env.body_poses().cpu().numpy()
+    assert np.isfinite(p).all() and np.abs(p[..., :3]).max() < 50.0
+    assert env.residual(clear=True) < 1e30
+
+
+# ---- known answers on the HIP backend (the same functions run on the oracle in tests/test_oracle_physics.py) ----
+def test_known_answer_box_rests_on_box(tmp_path):
+    gap, imp = pc.check_box_rests_on_box(pc.HipWorld(pc.skel_two_free_boxes(write_skeleton, tmp_path), self_collision=1))
+    print("box on box: core gap %.4f m (2 margins = 0.08), normal impulse sum %.5f" % (gap, imp))
+
+
+def test_known_answer_free_boxes_collide_inelastically(tmp_path):
+    sk = pc.skel_two_free_boxes(write_skeleton, tmp_path)
+    min_gap, rel = pc.check_free_boxes_collide_inelastically(pc.HipWorld(sk, self_collision=1))
+    print("head-on boxes: smallest core gap %.4f m, separation speed afterwards %.4f m/s" % (min_gap, rel))
+
+
+def test_known_answer_folded_arm_stops_at_the_body(tmp_path):
+    sk = pc.skel_folding_arm(write_skeleton, tmp_path)
+    deep1, touched = pc.check_folded_arm_stops_at_the_body(pc.HipWorld(sk, self_collision=1))
+    deep0, _ = pc.check_folded_arm_stops_at_the_body(pc.HipWorld(sk, self_collision=0))
+    print("forearm vs body: closest core distance %.4f m with member contacts, %.4f m without" % (deep1, deep0))
+    assert touched
+    assert deep1 > 2 * pc.MARGIN - 2.0 * 1.0 * pc.DT - 0.01, deep1
+    assert deep0 < -0.02, deep0

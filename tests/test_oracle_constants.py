@@ -99,10 +99,11 @@ def test_oracle_matches_its_committed_trace(orc_lib):
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(ROOT, "tests", "diag"))
     import make_physics_trace as mpt
-    ref = np.loadtxt(os.path.join(ROOT, "tests", "golden", "physics_trace.txt"))
-    got = mpt.trace(lib=orc_lib)
-    assert got.shape == ref.shape == (mpt.N_ENV * mpt.N_STEP // mpt.EVERY, 10)
-    assert np.array_equal(got[:, :3], ref[:, :3])                      # env, call, done: the episode structure is exact
-    early = ref[:, 1] < 32
-    np.testing.assert_allclose(got[early, 3:], ref[early, 3:], rtol=2e-5, atol=2e-5)
-    np.testing.assert_allclose(got[:, 3:], ref[:, 3:], rtol=5e-2, atol=5e-2)
+    for mode, name in ((0, "physics_trace.txt"), (1, "physics_trace_selfcol.txt")):   # floor only / member-vs-member contacts
+        ref = np.loadtxt(os.path.join(ROOT, "tests", "golden", name))
+        got = mpt.trace(lib=orc_lib, self_collision=mode)
+        assert got.shape == ref.shape == (mpt.N_ENV * mpt.N_STEP // mpt.EVERY, 10)
+        assert np.array_equal(got[:, :3], ref[:, :3])                      # env, call, done: the episode structure is exact
+        early = ref[:, 1] < 32
+        np.testing.assert_allclose(got[early, 3:], ref[early, 3:], rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(got[:, 3:], ref[:, 3:], rtol=5e-2, atol=5e-2)

@@ -51,7 +51,7 @@ def test_motion_state_lags_one_step(orc_lib, tmp_path):
     for _ in range(5):
         e.physics_step()
         s = e.get_state()
-        f = blob.fields(1, 1, 0)
+        f = blob.fields(1, 1, 0, len(e.pairs()))
         ms = s[f["ms"]]
         pos = blob.body_view(s[None], 1)["pos"][0, 0]
         if prev is not None:
