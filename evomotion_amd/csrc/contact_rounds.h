@@ -9,9 +9,11 @@
 // after the last round of either of its bodies) reproduces the sequential order bit for bit whatever the round sizes.
 //
 // Execution: every (wave, lane group) pair is a SLOT; slot s of environment e owns the s-th active manifold of that env
-// for the whole step (16 slots; a robot has been seen with 14 live manifolds in 5 000 random env-steps, an env with more
-// leaves the surplus out for that step and raises the sticky residual flag).  The owner keeps the manifold's record (4 points x 5 quads)
-// and its accumulated impulses in registers across the ten sweeps; bodies are read from and written to the workgroup's LDS
+// for the whole step and keeps the manifold's record (4 points x 5 quads) and its accumulated impulses in registers across
+// the ten sweeps (16 slots; the spider has been seen with 14 live manifolds in 5 000 random env-steps).  The 17th..32nd live
+// manifold of an env go to a second bank that the same slots serve from global memory (g_slow_visit: record re-read at every
+// visit, impulses kept in the record) — correct, slow, and rare; beyond that the manifold is left out and counted in
+// EnvDev::errs.  Both banks: bodies are read from and written to the workgroup's LDS
 // image with per-lane body indices ([quad][16 lanes]: the bank depends on the env column only, so any mix of bodies is
 // conflict-free).  A round is closed by a workgroup barrier.
 #pragma once
@@ -133,13 +135,13 @@ DEV void g_split_bank(const GCtx &G, const Ctx &c, const CBank &K, bool on, floa
     if (K.a >= 0) { pa[0] = A.dl.x; pa[64] = A.dl.y; pa[128] = A.dl.z; pa[192] = A.da.x; pa[256] = A.da.y; pa[320] = A.da.z; }
     pb[0] = B.dl.x; pb[64] = B.dl.y; pb[128] = B.dl.z; pb[192] = B.da.x; pb[256] = B.da.y; pb[320] = B.da.z;
 }
-// program word: id (9 bits) | (body0 + 1) << 9 (6 bits, 0 = floor) | body1 << 15 (6 bits) | round << 21 (4 bits); ~0 = none
+// program word: id (9 bits) | (body0 + 1) << 9 (6 bits, 0 = floor) | body1 << 15 (6 bits) | round << 21 (5 bits); ~0 = none
 DEV unsigned g_prog_word(int id, int a, int b, int round) {
     return (unsigned) id | ((unsigned) (a + 1) << 9) | ((unsigned) b << 15) | ((unsigned) round << 21);
 }
 DEV void g_bank_load(const Ctx &c, unsigned w, CBank &K) {
     if (w == 0xffffffffu) { K.id = -1; K.a = -1; K.b = 0; K.round = -1; }
-    else { K.id = (int) (w & 511u); K.a = (int) ((w >> 9) & 63u) - 1; K.b = (int) ((w >> 15) & 63u); K.round = (int) ((w >> 21) & 15u); }
+    else { K.id = (int) (w & 511u); K.a = (int) ((w >> 9) & 63u) - 1; K.b = (int) ((w >> 15) & 63u); K.round = (int) ((w >> 21) & 31u); }
 #pragma unroll
     for (int q = 0; q < 20; q++) K.q[q] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (K.id >= 0) {
@@ -166,31 +168,72 @@ DEV void g_bank_writeback(const Ctx &c, const CBank &K) {
     }
 }
 
+// The overflow bank: one visit of the manifold in program word w (round r, phase 0 warm start / 1 normal rows / 2 friction rows /
+// 3 split-impulse recovery) straight from its record in global memory; the accumulated impulses are written back into the
+// record's applied fields (the spare quad holds the split-impulse accumulators).  Not inlined: the fast path's register
+// allocation must not pay for this one.
+__device__ __attribute__((noinline)) float g_slow_visit(int phase, unsigned w, int r, f32x4 *ldsq, int e, const float *imt, float *crec_lane,
+                                                         float *scratch_lane, int sc_pt) {
+    if (w == 0xffffffffu || (int) ((w >> 21) & 31u) != r) return 0.f;
+    GCtx G;
+    G.q = ldsq; G.e = e; G.g = 0; G.QR = 0; G.ver = nullptr; G.multi = false;
+    CBank K;
+    K.id = (int) (w & 511u); K.a = (int) ((w >> 9) & 63u) - 1; K.b = (int) ((w >> 15) & 63u); K.round = r;
+    f32x4 *rec = reinterpret_cast<f32x4 *>(crec_lane + ((size_t) (K.id * EVM_CR_STRIDE) << 6));
+#pragma unroll
+    for (int q = 0; q < 20; q++) K.q[q] = rec[q << 6];
+    float res = 0.f;
+    if (phase == 0) res = g_contact_bank<0>(G, K, true, imt);
+    else if (phase == 1) res = g_contact_bank<1>(G, K, true, imt);
+    else if (phase == 2) res = g_contact_bank<2>(G, K, true, imt);
+    else {
+        f32x4 pq = rec[20 << 6];
+        float pa[4] = {pq[0], pq[1], pq[2], pq[3]};
+        Ctx c;
+        c.lane = 0;
+        c.t.scratch = scratch_lane;
+        (void) sc_pt;
+        g_split_bank(G, c, K, true, pa, imt);
+        pq[0] = pa[0]; pq[1] = pa[1]; pq[2] = pa[2]; pq[3] = pa[3];
+        rec[20 << 6] = pq;
+    }
+    if (phase == 1 || phase == 2) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) { rec[(5 * j + 2) << 6] = K.q[5 * j + 2]; rec[(5 * j + 4) << 6] = K.q[5 * j + 4]; }
+    }
+    return res;
+}
+
 // Builds the contact program of the workgroup's 16 envs (one wave; lanes of group 0, one env each): walks the manifold ids in
-// solver order, gives the k-th active one of an env to slot k and levels it into rounds.
-//   prog [16 slots][16 envs] words (pre-filled with ~0), meta[0] = rounds used (max over envs), meta[2] = 1 if some env has a
-//   point for the split-impulse recovery
-// nn: this env's floor manifold counts; returns false for an env whose manifolds did not all fit (overflow: > 16 active
-// manifolds or > 15 rounds)
-DEV bool g_build_program(const Ctx &c, const GCtx &G, int nw, const int (&nn)[EVM_MAX_MEMBERS], unsigned *prog, int *meta) {
+// solver order, gives the k-th active one of an env to slot k % 16 of bank k / 16 and levels it into rounds.
+//   prog [2 banks][16 slots][16 envs] words (pre-filled with ~0), meta[0] = rounds used (max over envs), meta[1] = 1 if some
+//   env uses the second bank, meta[2] = 1 if some env has a point for the split-impulse recovery
+// nn: this env's floor manifold counts; returns the number of manifolds that did not fit (> 32 live manifolds or > 31 rounds)
+DEV int g_build_program(const Ctx &c, const GCtx &G, int nw, const int (&nn)[EVM_MAX_MEMBERS], unsigned *prog, int *meta) {
     const int nm = c_skel.nm, np = c_skel.npair, nwords = (np + 31) >> 5;
     unsigned pw[(EVM_MAX_PAIRS + 31) / 32];
 #pragma unroll
     for (int k = 0; k < (EVM_MAX_PAIRS + 31) / 32; k++) pw[k] = k < nwords ? c.t.pact[(k << 6) + c.lane] : 0u;
     const unsigned flags = c.t.pact[(nwords << 6) + c.lane];
-    unsigned nf[3] = {0u, 0u, 0u};  // next free round per member, 4 bits each
+    unsigned nf[4] = {0u, 0u, 0u, 0u};  // next free round per member: 5 bits each, 6 members per word
     int ord = 0, rmax = 0;
-    bool ok = true;
+    int left_out = 0;
     auto place = [&](int id, int a, int b) {
-        auto getnf = [&](int m) { const unsigned w = m < 8 ? nf[0] : (m < 16 ? nf[1] : nf[2]); return (int) ((w >> ((m & 7) * 4)) & 15u); };
+        auto getnf = [&](int m) {
+            const int wi = m / 6;
+            const unsigned w = wi == 0 ? nf[0] : (wi == 1 ? nf[1] : (wi == 2 ? nf[2] : nf[3]));
+            return (int) ((w >> ((m - 6 * wi) * 5)) & 31u);
+        };
         auto setnf = [&](int m, int v) {
-            const unsigned sh = (unsigned) (m & 7) * 4u, msk = ~(15u << sh), val = (unsigned) v << sh;
-            if (m < 8) nf[0] = (nf[0] & msk) | val; else if (m < 16) nf[1] = (nf[1] & msk) | val; else nf[2] = (nf[2] & msk) | val;
+            const int wi = m / 6;
+            const unsigned sh = (unsigned) (m - 6 * wi) * 5u, msk = ~(31u << sh), val = (unsigned) v << sh;
+            if (wi == 0) nf[0] = (nf[0] & msk) | val; else if (wi == 1) nf[1] = (nf[1] & msk) | val;
+            else if (wi == 2) nf[2] = (nf[2] & msk) | val; else nf[3] = (nf[3] & msk) | val;
         };
         const int r = max(a >= 0 ? getnf(a) : 0, getnf(b));
-        if (r > 14 || ord >= 16) { ok = false; return; }
-        const int slot = (ord % nw) * 4 + ord / nw;
-        prog[(slot << 4) + G.e] = g_prog_word(id, a, b, r);
+        if (r > 30 || ord >= 32) { left_out++; return; }
+        const int k = ord & 15, slot = (k % nw) * 4 + k / nw;
+        prog[(((ord >> 4) * 16 + slot) << 4) + G.e] = g_prog_word(id, a, b, r);
         if (a >= 0) setnf(a, r + 1);
         setnf(b, r + 1);
         rmax = max(rmax, r + 1);
@@ -221,8 +264,9 @@ DEV bool g_build_program(const Ctx &c, const GCtx &G, int nw, const int (&nn)[EV
     }
     // workgroup-wide facts
     if (rmax > 0) atomicMax(&meta[0], rmax);
+    if (ord > 16) atomicMax(&meta[1], 1);
     if (flags & 1u) atomicMax(&meta[2], 1);
-    return ok;
+    return left_out;
 }
 
 }  // namespace evm

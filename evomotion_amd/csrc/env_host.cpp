@@ -129,7 +129,7 @@ int evm_env_create(const char *skeleton_path, int n_envs, int device, uint64_t s
         {(void **) &env->d.flags, 1}, {(void **) &env->d.curr_step, 1}, {(void **) &env->d.remaining, 1},
         {(void **) &env->d.settle_left, 1}, {(void **) &env->d.E, 9}, {(void **) &env->d.iinv_stale, 6u * S.nb},
         {(void **) &env->d.mt, 624}, {(void **) &env->d.mt_idx, 1}, {(void **) &env->d.scratch, (size_t) S.sc_total},
-        {(void **) &env->d.diag, 2}, {(void **) &env->d.stat, 2}, {(void **) &env->d.stamps, 1}, {(void **) &env->d.resid, 1},
+        {(void **) &env->d.diag, 2}, {(void **) &env->d.stat, 2}, {(void **) &env->d.stamps, 1}, {(void **) &env->d.resid, 1}, {(void **) &env->d.errs, 1},
         {(void **) &env->d.gtile, evm::step_lds_bytes(S.nb, S.nscan) / 4 / 64}};  // stamps: 16 u64 per tile = 128 B <= 256 B
     if (S.self_collision) {
         // member-vs-member contacts: persistent pair manifolds, the activity words (+ one flag word) and the two-body contact
@@ -570,6 +570,15 @@ int evm_env_get_residual(EvmEnv *env, float *h_max, int clear, void *stream) {
     if (clear) HIP_TRY(hipMemsetAsync(env->d.resid, 0, sizeof(int), s));
     HIP_TRY(hipStreamSynchronize(s));
     if (h_max) memcpy(h_max, &bits, sizeof(float));
+    return EVM_OK;
+}
+
+int evm_env_get_errors(EvmEnv *env, int *h_out, int clear, void *stream) {
+    if (!env || !h_out) return fail(EVM_E_INVALID, "null argument");
+    hipStream_t s = (hipStream_t) stream;
+    HIP_TRY(hipMemcpyAsync(h_out, env->d.errs, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+    if (clear) HIP_TRY(hipMemsetAsync(env->d.errs, 0, 2 * sizeof(int), s));
+    HIP_TRY(hipStreamSynchronize(s));
     return EVM_OK;
 }
 

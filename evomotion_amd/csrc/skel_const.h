@@ -27,8 +27,9 @@
 // pair p -> id nm + p), 4 points x 5 quads; read-only during the sweeps (the accumulated impulses live in LDS there):
 //   quad 0: relA.xyz, jd_n   quad 1: relB.xyz, rhs_n   quad 2: normalOnB.xyz, applied_n (warm-started)
 //   quad 3: lat.xyz, jd_f    quad 4: rhs_f, applied_f (warm-started), rhs_penetration (split impulse), mu
+// and one spare quad (20) that only the overflow path of the sweeps kernel uses (its split-impulse accumulators)
 #define EVM_CR_POINT 20
-#define EVM_CR_STRIDE 80
+#define EVM_CR_STRIDE 84
 #define EVM_PM_STRIDE 48  // persistent pair manifold: 4 points x (localA3 localB3 normalOnB3 dist applied applied_lateral)
 
 struct EvmBodyC {

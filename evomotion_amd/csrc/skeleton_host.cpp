@@ -1244,10 +1244,10 @@ int build_group_schedule(const EvmSkelC &S, int nwaves, EvmGSchedC &G, std::stri
     size_t bytes = quads * 16 + (size_t) ((S.nb + 3) / 4 * 4) * 4 + EVM_G_ENVS * 4;
     G.with_contacts = with_contacts ? 1 : 0;
     if (!with_contacts) {
-        // behind the image: the contact program (16 slots x 16 envs words), four workgroup-wide words and the bodies'
-        // inverse masses
+        // behind the image: the contact program (2 banks x 16 slots x 16 envs words), four workgroup-wide words and the
+        // bodies' inverse masses
         bytes = (bytes + 15) & ~(size_t) 15;
-        bytes += (size_t) 16 * EVM_G_ENVS * 4 + 16 + (size_t) ((S.nb + 3) & ~3) * 4;
+        bytes += (size_t) 2 * 16 * EVM_G_ENVS * 4 + 16 + (size_t) ((S.nb + 3) & ~3) * 4;
     }
     G.lds_bytes = (int) bytes;
     if (bytes > 160 * 1024) { err = "skeleton records exceed the LDS image of the lane-group sweeps"; return EVM_E_UNSUPPORTED; }

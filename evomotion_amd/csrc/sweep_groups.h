@@ -50,7 +50,7 @@ DEV void g_wait2(GCtx &G, const Ctx &c, int a, int expA, int b, int expB) {
         if (++spins > EVM_SPIN_HOT) __builtin_amdgcn_s_sleep(1);
         // a schedule bug must not hang the GPU: give up and stop waiting for the rest of the launch; the batch residual is
         // poisoned with +inf (sticky: evm_env_get_residual returns it until cleared; the tests and the soak assert on it)
-        if (spins > (1 << 20)) { atomicMax(c.d.resid, 0x7f800000); G.multi = false; break; }
+        if (spins > (1 << 20)) { atomicMax(c.d.resid, 0x7f800000); atomicAdd(&c.d.errs[0], 1); G.multi = false; break; }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     GWAIT_T1
@@ -290,8 +290,8 @@ __global__ __launch_bounds__(64 * EVM_G_MAX_WAVES) void k_sweeps_g(EnvDev d, con
         for (int i = threadIdx.x; i < ((nb + 3) & ~3) + EVM_G_ENVS; i += blockDim.x) ver_base[i] = 0;
         if (gs->with_contacts == 0) {  // member-vs-member mode: empty contact program, workgroup-wide words, inverse masses
             unsigned *prog0 = reinterpret_cast<unsigned *>(resmax + EVM_G_ENVS);
-            for (int i = threadIdx.x; i < 16 * EVM_G_ENVS; i += blockDim.x) prog0[i] = 0xffffffffu;
-            int *meta0 = reinterpret_cast<int *>(prog0 + 16 * EVM_G_ENVS);
+            for (int i = threadIdx.x; i < 2 * 16 * EVM_G_ENVS; i += blockDim.x) prog0[i] = 0xffffffffu;
+            int *meta0 = reinterpret_cast<int *>(prog0 + 2 * 16 * EVM_G_ENVS);
             if (threadIdx.x < 4) meta0[threadIdx.x] = 0;
             float *imt0 = reinterpret_cast<float *>(meta0 + 4);
             for (int i = threadIdx.x; i < nb; i += blockDim.x) imt0[i] = c_skel.body[i].inv_mass;
@@ -396,20 +396,32 @@ __global__ __launch_bounds__(64 * EVM_G_MAX_WAVES) void k_sweeps_g(EnvDev d, con
     CBank K0;
     K0.id = -1; K0.round = -1;
     int nrounds = 0;
-    unsigned *prog = reinterpret_cast<unsigned *>(resmax + EVM_G_ENVS);  // [16 slots][16 envs]
-    int *meta = reinterpret_cast<int *>(prog + 16 * EVM_G_ENVS);          // rounds, -, split impulse needed, -
+    unsigned *prog = reinterpret_cast<unsigned *>(resmax + EVM_G_ENVS);  // [2 banks][16 slots][16 envs]
+    int *meta = reinterpret_cast<int *>(prog + 2 * 16 * EVM_G_ENVS);      // rounds, second bank in use, split impulse needed, -
     float *imt = reinterpret_cast<float *>(meta + 4);                     // inverse mass per body
+    unsigned w1 = 0xffffffffu;  // this slot's manifold of the overflow bank (served from global memory)
+    bool use_b1 = false;
+    float *const crec_lane = c.t.crec ? c.t.crec + 4 * c.lane : nullptr, *const scratch_lane = c.t.scratch + c.lane;
+    auto slow = [&](int phase, int r) -> float { return g_slow_visit(phase, w1, r, G.q, G.e, imt, crec_lane, scratch_lane, c_skel.sc_pt); };
     if (scm) {  // (program, words and inverse masses were initialised by every thread before any lane left)
         if (wave == 0) {
             int nn[EVM_MAX_MEMBERS];
 #pragma unroll
             for (int m = 0; m < EVM_MAX_MEMBERS; m++) nn[m] = m < nm ? GS(mfn, m) : 0;
-            if (!g_build_program(c, G, nw, nn, prog, meta)) atomicMax(d.resid, 0x7f800000);  // sticky: a manifold was left out
+            const int left_out = g_build_program(c, G, nw, nn, prog, meta);
+            if (left_out > 0 && G.g == 0) { atomicMax(d.resid, 0x7f800000); atomicAdd(&d.errs[1], left_out); }  // sticky
         }
         g_lds_barrier();
         nrounds = __builtin_amdgcn_readfirstlane(meta[0]);
+        use_b1 = __builtin_amdgcn_readfirstlane(meta[1]) != 0;
         const int slot = wave * EVM_G_SLOTS + G.g;
         g_bank_load(c, prog[(slot << 4) + G.e], K0);
+        if (use_b1) {
+            w1 = prog[((16 + slot) << 4) + G.e];
+            if (w1 != 0xffffffffu) {  // its split-impulse accumulators start at zero
+                reinterpret_cast<f32x4 *>(crec_lane + ((size_t) ((int) (w1 & 511u) * EVM_CR_STRIDE + 80) << 6))[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
         if (__builtin_amdgcn_readfirstlane(meta[2]) != 0) {
             // solveGroupCacheFriendlySplitImpulseIterations: the same rounds on the push / turn velocities (sc_pt, zeroed by the
             // setup kernel); ten iterations like the oracle (further ones would add exactly nothing once an iteration changes nothing)
@@ -417,11 +429,13 @@ __global__ __launch_bounds__(64 * EVM_G_MAX_WAVES) void k_sweeps_g(EnvDev d, con
             for (int it = 0; it < NUM_ITER; it++)
                 for (int r = 0; r < nrounds; r++) {
                     g_split_bank(G, c, K0, K0.round == r, pa0, imt);
+                    if (use_b1) slow(3, r);
                     g_lds_barrier();
                 }
         }
         for (int r = 0; r < nrounds; r++) {
             g_contact_bank<0>(G, K0, K0.round == r, imt);
+            if (use_b1) slow(0, r);
             g_lds_barrier();
         }
     }
@@ -533,10 +547,12 @@ __global__ __launch_bounds__(64 * EVM_G_MAX_WAVES) void k_sweeps_g(EnvDev d, con
             g_lds_barrier();
             for (int r = 0; r < nrounds; r++) {
                 rs = fmaxf(rs, g_contact_bank<1>(G, K0, K0.round == r, imt));
+                if (use_b1) rs = fmaxf(rs, slow(1, r));
                 g_lds_barrier();
             }
             for (int r = 0; r < nrounds; r++) {
                 rs = fmaxf(rs, g_contact_bank<2>(G, K0, K0.round == r, imt));
+                if (use_b1) rs = fmaxf(rs, slow(2, r));
                 g_lds_barrier();
             }
         }
@@ -559,6 +575,11 @@ __global__ __launch_bounds__(64 * EVM_G_MAX_WAVES) void k_sweeps_g(EnvDev d, con
     }
     if (scm) {
         g_bank_writeback(c, K0);
+        if (use_b1 && w1 != 0xffffffffu) {
+            CBank K1;
+            g_bank_load(c, w1, K1);
+            g_bank_writeback(c, K1);
+        }
     }
     // ---- contact impulses back into the manifolds (by the lane group that ran the member's contact rows) ----
     for (int j = 0; j < count; j++) {

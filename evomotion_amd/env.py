@@ -215,6 +215,12 @@ class VecRobotWalk:
         check(lib.evm_env_get_residual(self._h, ctypes.byref(out), 1 if clear else 0, self._stream()))
         return out.value
 
+    def errors(self, clear=True):
+        """(schedule waits that timed out, contact manifolds left out of a step) since the last clear: both must stay 0"""
+        out = (ctypes.c_int * 2)()
+        check(lib.evm_env_get_errors(self._h, out, 1 if clear else 0, self._stream()))
+        return int(out[0]), int(out[1])
+
     def stats(self):
         out = (ctypes.c_longlong * 2)()
         check(lib.evm_env_get_stats(self._h, out))

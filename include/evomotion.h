@@ -149,6 +149,11 @@ int evm_env_get_diagnostics(const EvmEnv *env, float *d_out /* [n_envs, 2] */, v
  * in the wave, one atomic max per workgroup): the largest |delta impulse| any constraint row applied in its LAST sweep, maximum
  * over all envs and all physics steps since the last clear.  Synchronises `stream`. */
 int evm_env_get_residual(EvmEnv *env, float *h_max_delta_impulse, int clear, void *stream);
+/* Things that must not happen, counted on the device since the last clear (either one also poisons the residual above with
+ * +inf): h_out[0] = waits of the sweeps kernel's dataflow schedule that timed out (a schedule bug: the physics of that step is
+ * wrong), h_out[1] = contact manifolds left out of a step because an env held more than 32 live manifolds or needed more
+ * than 31 contact rounds (member-vs-member mode).  Synchronises `stream`. */
+int evm_env_get_errors(EvmEnv *env, int *h_out /* [2] */, int clear, void *stream);
 /* Rollout counters since the last clear, summed over envs: h_out[0] = do_step transitions emitted by
  * evm_env_step_autoreset (the reset()'s own step and settle calls are not counted), h_out[1] = resets started. */
 int evm_env_get_stats(EvmEnv *env, long long *h_out /* [2] */);
