@@ -59,26 +59,47 @@ def host_cores():
     return max(1, min(n, 16))
 
 
-def cpu_worker(seed, steps):
+def cpu_worker(seed, steps, self_collision=1):
     """child process of cpu_baseline()'s all-cores leg: one oracle env, prints `steps seconds`"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orc
     L = orc.load()
-    env = orc.OracleEnv(seed=seed, lib=L)
+    env = orc.OracleEnv(seed=seed, lib=L, self_collision=self_collision)
     n_res = ctypes.c_int()
     t = L.orc_bench_env_steps(env.h, steps, 11, ctypes.byref(n_res))
     print(steps, t)
 
 
-def cpu_baseline(seconds=12.0):
+def bullet_probe():
+    """Is Bullet3 (the library the reference's step lives in, evo_motion_model/CMakeLists.txt:14) on THIS box?  Looks for the
+    header and the library the reference links; nothing is built or downloaded.  Returns a short finding."""
+    import glob
+    hdr = [p for p in ("/usr/include/bullet/btBulletDynamicsCommon.h", "/usr/local/include/bullet/btBulletDynamicsCommon.h",
+                       "/usr/include/btBulletDynamicsCommon.h") if os.path.exists(p)]
+    libs = []
+    for d in ("/usr/lib", "/usr/lib64", "/usr/lib/x86_64-linux-gnu", "/usr/local/lib"):
+        libs += glob.glob(os.path.join(d, "libBulletDynamics*"))
+    try:
+        import importlib.util
+        pyb = importlib.util.find_spec("pybullet") is not None
+    except Exception:
+        pyb = False
+    harness = os.path.join(ROOT, "oracle", "_ref", "bullet_harness")
+    return {"header": hdr[0] if hdr else None, "library": libs[0] if libs else None, "pybullet": pyb,
+            "harness_built": os.path.exists(harness)}
+
+
+def cpu_baseline(seconds=12.0, self_collision=1):
     """The scalar CPU restatement (oracle/) timed on this box's host cores: one env on one thread (the reference's loop is one
     env, one thread driving Bullet), and — so that the comparison is not against a single core of a many-core host — one
     independent env per core on all cores at once (plain child processes, bounded by a timeout)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orc
     L = orc.load()
-    env = orc.OracleEnv(seed=1234, lib=L)
+    env = orc.OracleEnv(seed=1234, lib=L, self_collision=self_collision)
     n_res = ctypes.c_int()
+    probe = bullet_probe()
+    found = probe["header"] and probe["library"]
     # calibrate, then one bounded sample
     t = L.orc_bench_env_steps(env.h, 2000, 7, ctypes.byref(n_res))
     steps = max(2000, int(2000 * seconds / max(t, 1e-6)))
@@ -86,14 +107,17 @@ def cpu_baseline(seconds=12.0):
     out = {
         "value": steps / t, "unit": "env-steps/s", "cores": 1, "kind": "port",
         "sample": f"{steps} do_step calls incl. {n_res.value} reset() (60 settle steps each), 1 env, 1 thread, "
-                  f"{t:.1f} s of the scalar CPU restatement (oracle/); Bullet3 itself is not installed on this box",
+                  f"{t:.1f} s of the scalar CPU restatement (oracle/, {'member-vs-member' if self_collision else 'floor-only'} contacts); "
+                  + ("Bullet3 found on this box (%s) but the harness oracle/bullet_harness.cpp was not built: timed the restatement" % probe["library"]
+                     if found else "Bullet3 probed for on this box and not found (no btBulletDynamicsCommon.h / libBulletDynamics, no pybullet)"),
+        "bullet_probe": probe,
     }
     try:
         import subprocess
         cores = host_cores()
         if cores > 1:
             per = max(2000, int(steps * 6.0 / max(t, 1e-6)))  # about 6 s per process at the single-core rate
-            procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(1234 + 17 * i), str(per)],
+            procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(1234 + 17 * i), str(per), str(self_collision)],
                                       stdout=subprocess.PIPE, stderr=subprocess.DEVNULL) for i in range(cores)]
             res, deadline = [], time.time() + 60.0
             for p_ in procs:
@@ -111,7 +135,7 @@ def cpu_baseline(seconds=12.0):
     return out
 
 
-def pose_parity(device, n_oracles=8, steps=48):
+def pose_parity(device, n_oracles=8, steps=48, self_collision=1):
     """Second half of BASELINE.json's metric: per-step pose L2 of the HIP path against the CPU restatement (oracle/; Bullet3 is
     not installed, so this is parity with the restatement, not with Bullet).  Teacher-forced: every step both sides start from
     the restatement's state, take the same action, and the body poses [41][pos xyz, quat xyzw] are compared.  Part of the
@@ -122,9 +146,9 @@ def pose_parity(device, n_oracles=8, steps=48):
     import orc
     from evomotion_amd import VecRobotWalk
     L = orc.load()
-    env = VecRobotWalk(64, seed=4321, device=device)
+    env = VecRobotWalk(64, seed=4321, device=device, parameters={"self_collision": self_collision})
     env.reset()
-    oracles = [orc.OracleEnv(seed=4321 + i, lib=L) for i in range(n_oracles)]
+    oracles = [orc.OracleEnv(seed=4321 + i, lib=L, self_collision=self_collision) for i in range(n_oracles)]
     for o in oracles:
         o.reset()
     rng = np.random.default_rng(7)
@@ -208,8 +232,8 @@ def launch_ranks(n_ranks, argv, worker=None, timeout=None):
 
 
 def main():
-    if len(sys.argv) == 4 and sys.argv[1] == "--cpu-worker":  # child of cpu_baseline(): no torch, no GPU
-        cpu_worker(int(sys.argv[2]), int(sys.argv[3]))
+    if len(sys.argv) in (4, 5) and sys.argv[1] == "--cpu-worker":  # child of cpu_baseline(): no torch, no GPU
+        cpu_worker(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]) if len(sys.argv) == 5 else 1)
         return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -217,6 +241,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=256)
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--self-collision", type=int, choices=[0, 1], default=1,
+                    help="1 (default) = member-vs-member contacts as in the reference (every pair of members except constraint "
+                         "parent / child collides); 0 = floor contacts only (the north-star's plane-contact configuration)")
     ap.add_argument("--mode", choices=["dynamics", "ppo", "sac"], default="dynamics",
                     help="dynamics = BASELINE configs[1] (random actions, headline); ppo = configs[2]/[3]: fused MFMA "
                          "actor-critic forward inside the rollout, PPO update every --horizon steps; sac = configs[4]: fused "
@@ -264,7 +291,7 @@ def main():
         rccl_ranks = int(ones.item())
 
     n = args.envs
-    env = VecRobotWalk(n, seed=1234 + rank * n, device=local_rank)
+    env = VecRobotWalk(n, seed=1234 + rank * n, device=local_rank, parameters={"self_collision": args.self_collision})
     st0 = env.reset()
     # RandomAgent (debug_agents.cpp:28-30) fills an action bank resident in HBM, cycled by the rollout loop: config 2 times
     # the dynamics, not the generator
@@ -322,9 +349,13 @@ def main():
     if sac is not None:
         sac.fused.timing_begin()
         sac.replay.timing_begin()
+    ev_begin, ev_end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev_begin.record()  # on the stream every kernel of the timed region is launched on (torch's current stream)
     run(args.steps, args.warmup)
+    ev_end.record()
     ms_kernel, n_launch, ms_sweeps = env.timing_end_detail()
+    region_ms = ev_begin.elapsed_time(ev_end)  # (timing_end_detail synchronised the stream)
     ms_policy, n_policy = agent.fused.timing_end() if agent is not None else (sac.fused.timing_end() if sac is not None else (0.0, 0))
     rp = sac.replay.timing_end() if sac is not None else None
     barrier()
@@ -363,7 +394,10 @@ def main():
         elapsed = float(tmax[0].item())
     env_steps, resets = float(tt[1].item()), float(tt[2].item())
     if rank == 0:
-        launch_ms = ms_kernel / max(n_launch, 1)
+        # ONE denominator for `value` and `roofline.achieved`: the timed region, by HIP events on the launch stream around all of
+        # its K steps (agrees with the wall clock between the barriers to the launch latency of the first kernel)
+        sampled_ms = ms_kernel / max(n_launch, 1)   # mean of the individually bracketed steps (every 4th)
+        launch_ms = region_ms / max(args.steps if agent is None and sac is None else n_launch, 1) if agent is None and sac is None else sampled_ms
         phys_per_launch = n  # every lane runs one stepSimulation per launch
         achieved = ALG_BYTES_PER_ENV_STEP * phys_per_launch / (launch_ms * 1e-3) / 1e9
         out = {
@@ -385,12 +419,14 @@ def main():
                               "SAC update (batch %d) every %d steps on the device (twin Q, targets, actor and entropy steps, fp32 MFMA), "
                               "one HIP graph" % (args.sac_batch, args.train_every))) if sac is not None else
                             ("robot_walk, %d envs/GPU on %d MI355X, HIP dynamics only, uniform random actions, "
-                             "rollout form with in-band reset (configs[1])" % (n, world)) if agent is None else
+                             "rollout form with in-band reset, %s (configs[1])" % (n, world, "member-vs-member contacts as in the reference "
+                              "(self_collision=1)" if args.self_collision else "floor contacts only (self_collision=0)")) if agent is None else
                             ("robot_walk, %d envs/GPU on %d MI355X, PPO hidden_size=256, fused MFMA actor-critic forward "
                              "in the rollout, horizon %d, %s (configs[2])" % (n, world, args.horizon,
                               "rollout only" if args.no_update else
                               "HIP PPO update (fp32 MFMA forward / backward / weight gradients, epoch 8) every horizon")),
                 "envs_per_gpu": n,
+                "self_collision": args.self_collision,
                 "physics_steps_per_s": world * n * args.steps / elapsed,
                 "do_step_fraction": env_steps / (world * n * args.steps),
                 "resets_started": resets,
@@ -399,8 +435,8 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n)[0], "traffic_source": measured_traffic(n)[1],
-                "kernel": ("k_sweeps_g (dominant: the Gauss-Seidel sweeps) + k_split_pre_a / pre_b / post: one step" if ms_sweeps > 0 else "k_env_step<7>"),
-                "launch_ms": launch_ms, "dominant_kernel_ms": (ms_sweeps / max(n_launch, 1)) if ms_sweeps > 0 else launch_ms,
+                "kernel": ("k_sweeps_g (dominant: the Gauss-Seidel sweeps) + k_split_pre_a / pre_b / %spost: one step" % ("pairs / " if args.self_collision else "") if ms_sweeps > 0 else "k_env_step<7>"),
+                "launch_ms": launch_ms, "sampled_step_ms": sampled_ms, "dominant_kernel_ms": (ms_sweeps / max(n_launch, 1)) if ms_sweeps > 0 else launch_ms,
                 "note": "algorithmic 8300 B per env physics step x %d envs per step; a step is a pipeline of four kernels up to "
                         "8192 envs (launch_ms = all of them, HIP events on the launch stream; dominant_kernel_ms = the Gauss-Seidel "
                         "sweeps kernel alone), one monolithic kernel above; fp32-VALU/latency bound (about 50 FLOP per algorithmic "
@@ -462,9 +498,9 @@ def main():
                                           "kernel": "k_ppo_forward + k_ppo_loss_* + k_ppo_backward + k_ppo_wgrad (x6) + reductions + k_ppo_adam: one epoch",
                                           "note": "HIP events around evm_ppo_grads .. evm_ppo_apply; fp32-input MFMA, dense fp32 matrix peak"}
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(self_collision=args.self_collision)
             try:
-                out["pose_parity"] = pose_parity(local_rank)
+                out["pose_parity"] = pose_parity(local_rank, self_collision=args.self_collision)
             except Exception as e:  # reported, never fatal for the throughput line
                 out["pose_parity"] = {"error": repr(e)}
         print(json.dumps(out))

@@ -46,6 +46,7 @@ def _load():
     lib.evm_env_spaces.argtypes = [vp, ip, ip]
     lib.evm_env_counts.argtypes = [vp, ip, ip, ip, ip]
     lib.evm_env_pairs.argtypes = [vp, ip, ip]
+    lib.evm_env_debug_pair_counts.argtypes = [vp, ip]
     lib.evm_env_reset.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.evm_env_step.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.evm_env_step_autoreset.argtypes = [vp, vp, vp, vp, vp, vp, vp]

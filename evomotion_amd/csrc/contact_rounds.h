@@ -41,7 +41,28 @@ DEV BodyD g_body_any(const GCtx &G, int b, const float *imt) {
     if (b < 0) { k.dl = f3(0, 0, 0); k.da = f3(0, 0, 0); k.I.xx = k.I.xy = k.I.xz = k.I.yy = k.I.yz = k.I.zz = 0.f; k.im = 0.f; }
     return k;
 }
-// one two-body row along `dir` (contact normal or friction direction): resolveSingleConstraintRowGeneric / LowerLimit
+// both bodies of a manifold as an (A, B) pair for the packed row arithmetic of the joint rows (row_iter<LIN = true, BOUNDED>:
+// one packed instruction serves both sides); a < 0: the A half is the static floor = all zeros
+DEV BodyPD g_pair_any(const GCtx &G, int a, int b, const float *imt) {
+    const int aa = a < 0 ? b : a;
+    BodyPD Q = g_load_pair(G, aa, b, imt[aa], imt[b]);
+    if (a < 0) {
+        Q.dl.x.x = 0.f; Q.dl.y.x = 0.f; Q.dl.z.x = 0.f; Q.da.x.x = 0.f; Q.da.y.x = 0.f; Q.da.z.x = 0.f;
+        Q.I.xx.x = 0.f; Q.I.xy.x = 0.f; Q.I.xz.x = 0.f; Q.I.yy.x = 0.f; Q.I.yz.x = 0.f; Q.I.zz.x = 0.f;
+        Q.im.x = 0.f;
+    }
+    return Q;
+}
+DEV void g_store_pair_any(const GCtx &G, int a, int b, const BodyPD &Q) {
+    f32x4 x;
+    if (a >= 0) {
+        x[0] = Q.dl.x.x; x[1] = Q.dl.y.x; x[2] = Q.dl.z.x; x[3] = Q.da.x.x; GQ(G, 3 * a) = x;
+        x[0] = Q.da.y.x; x[1] = Q.da.z.x; x[2] = Q.I.xx.x; x[3] = Q.I.xy.x; GQ(G, 3 * a + 1) = x;
+    }
+    x[0] = Q.dl.x.y; x[1] = Q.dl.y.y; x[2] = Q.dl.z.y; x[3] = Q.da.x.y; GQ(G, 3 * b) = x;
+    x[0] = Q.da.y.y; x[1] = Q.da.z.y; x[2] = Q.I.xx.y; x[3] = Q.I.xy.y; GQ(G, 3 * b + 1) = x;
+}
+// one two-body row along `dir` (contact normal or friction direction) on scalar bodies: the split-impulse recovery's form
 DEV float g_row2(F3 dir, F3 relA, F3 relB, BodyD &A, BodyD &B, float jd, float rhs, float lo, float hi, float &ap) {
     const F3 c1 = cross(relA, dir), c2 = -cross(relB, dir);
     const float d1 = dot(dir, A.dl) + dot(c1, A.da);
@@ -61,67 +82,70 @@ DEV float g_row2(F3 dir, F3 relA, F3 relB, BodyD &A, BodyD &B, float jd, float r
 }
 // PHASE 0: warm start (convertContact applies the cached impulses x 0.85, per point normal then friction)
 //       1: normal rows   2: friction rows (limits +-mu x the point's normal impulse of this sweep)
+// A contact row is a two-body LINEAR row (n, relA x n, -(relB x n)) like a joint's: the packed (A, B) row of the joint rows
+// does it in half the instructions of two scalar sides.
 template <int PHASE>
 DEV float g_contact_bank(const GCtx &G, CBank &K, bool on, const float *imt) {
     float res = 0.f;
     if (!__any(on)) return res;
-    BodyD A, B;
-    if (on) { A = g_body_any(G, K.a, imt); B = g_body_any(G, K.b, imt); }
+    BodyPD Q;
+    if (on) Q = g_pair_any(G, K.a, K.b, imt);
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const bool live = on && K.q[5 * j][3] != 0.f;  // jd_n = 1 / denominator > 0 for a live point
         if (!__any(live)) continue;
         if (live) {
-            const F3 relA = f3(K.q[5 * j][0], K.q[5 * j][1], K.q[5 * j][2]);
-            const F3 relB = f3(K.q[5 * j + 1][0], K.q[5 * j + 1][1], K.q[5 * j + 1][2]);
+            const F3P rel = f3p(p2(K.q[5 * j][0], -K.q[5 * j + 1][0]), p2(K.q[5 * j][1], -K.q[5 * j + 1][1]), p2(K.q[5 * j][2], -K.q[5 * j + 1][2]));  // (relA, -relB)
             const F3 nrm = f3(K.q[5 * j + 2][0], K.q[5 * j + 2][1], K.q[5 * j + 2][2]);
             const F3 lat = f3(K.q[5 * j + 3][0], K.q[5 * j + 3][1], K.q[5 * j + 3][2]);
             if (PHASE == 0) {
                 // internalApplyImpulse(n1 * imA, angA, ap) on body0, (-n2 * imB, -angB, -ap) on body1 for the normal row, then
-                // the same with the friction direction
+                // the same with the friction direction: delta = (n * im, I (rel x n)) * (ap, -ap)  [im = (imA, -imB), rel = (relA, -relB)]
                 const float an = K_APN(K, j), af = K_APF(K, j);
-                const F3 c1 = cross(relA, nrm), c2 = cross(relB, nrm);
-                A.dl = A.dl + (nrm * A.im) * an; A.da = A.da + mul(A.I, c1) * an;
-                B.dl = B.dl + (nrm * B.im) * (-an); B.da = B.da + mul(B.I, c2) * (-an);
-                const F3 f1 = cross(relA, lat), f2 = cross(relB, lat);
-                A.dl = A.dl + (lat * A.im) * af; A.da = A.da + mul(A.I, f1) * af;
-                B.dl = B.dl + (lat * B.im) * (-af); B.da = B.da + mul(B.I, f2) * (-af);
+                {
+                    const F3P A = f3p(p2(nrm.x, nrm.x), p2(nrm.y, nrm.y), p2(nrm.z, nrm.z));
+                    const F3P cc = cross(rel, A);
+                    Q.dl = Q.dl + A * (Q.im * an);
+                    Q.da = Q.da + mul(Q.I, cc) * an;
+                }
+                {
+                    const F3P A = f3p(p2(lat.x, lat.x), p2(lat.y, lat.y), p2(lat.z, lat.z));
+                    const F3P cc = cross(rel, A);
+                    Q.dl = Q.dl + A * (Q.im * af);
+                    Q.da = Q.da + mul(Q.I, cc) * af;
+                }
             } else if (PHASE == 1) {
                 float ap = K_APN(K, j);
-                res = fmaxf(res, fabsf(g_row2(nrm, relA, relB, A, B, K.q[5 * j][3], K.q[5 * j + 1][3], 0.f, 1e10f, ap)));
+                res = fmaxf(res, fabsf(row_iter<true, true>(nrm, rel, Q, K.q[5 * j][3], K.q[5 * j + 1][3], 0.f, 1e10f, ap)));
                 K_APN(K, j) = ap;
             } else {
                 if (K_APN(K, j) > 0.f) {
                     const float lim = K.q[4][3] * K_APN(K, j);  // mu x the point's normal impulse
                     float ap = K_APF(K, j);
-                    res = fmaxf(res, fabsf(g_row2(lat, relA, relB, A, B, K.q[5 * j + 3][3], K.q[5 * j + 4][0], -lim, lim, ap)));
+                    res = fmaxf(res, fabsf(row_iter<true, true>(lat, rel, Q, K.q[5 * j + 3][3], K.q[5 * j + 4][0], -lim, lim, ap)));
                     K_APF(K, j) = ap;
                 }
             }
         }
     }
-    if (on) {
-        if (K.a >= 0) g_store_body(G, K.a, A);
-        g_store_body(G, K.b, B);
-    }
+    if (on) g_store_pair_any(G, K.a, K.b, Q);
     return res;
 }
-// split-impulse recovery of one manifold (resolveSplitPenetrationImpulse): push / turn velocities of the two bodies live in
-// the tile's scratch (sc_pt, per-lane body index); rare (a point deeper than the 0.04 threshold), so no LDS is spent on it
-DEV void g_split_bank(const GCtx &G, const Ctx &c, const CBank &K, bool on, float (&push_ap)[4], const float *imt) {
+// split-impulse recovery of one manifold (resolveSplitPenetrationImpulse): the push / turn velocities of the members live in
+// LDS for the phase, ptl[(6 m + k) * 16 + env] (k = 0..2 push, 3..5 turn), per-lane member index
+DEV void g_split_bank(const GCtx &G, const CBank &K, bool on, float (&push_ap)[4], const float *imt, float *ptl) {
     bool pen = false;
 #pragma unroll
     for (int j = 0; j < 4; j++) pen = pen || (on && K.q[5 * j + 4][2] != 0.f);
     if (!__any(pen)) return;
     if (!pen) return;
     const int ba = K.a < 0 ? 0 : K.a;
-    float *pa = c.t.scratch + ((size_t) (c_skel.sc_pt + 6 * ba) << 6) + c.lane;
-    float *pb = c.t.scratch + ((size_t) (c_skel.sc_pt + 6 * K.b) << 6) + c.lane;
+    float *pa = ptl + ((6 * ba) << 4) + G.e, *pb = ptl + ((6 * K.b) << 4) + G.e;
     BodyD A = g_body_any(G, K.a, imt), B = g_body_any(G, K.b, imt);  // inertia + inverse mass; dl = push, da = turn below
-    A.dl = K.a < 0 ? f3(0, 0, 0) : f3(pa[0], pa[64], pa[128]);
-    A.da = K.a < 0 ? f3(0, 0, 0) : f3(pa[192], pa[256], pa[320]);
-    B.dl = f3(pb[0], pb[64], pb[128]);
-    B.da = f3(pb[192], pb[256], pb[320]);
+    A.dl = K.a < 0 ? f3(0, 0, 0) : f3(pa[0], pa[16], pa[32]);
+    A.da = K.a < 0 ? f3(0, 0, 0) : f3(pa[48], pa[64], pa[80]);
+    B.dl = f3(pb[0], pb[16], pb[32]);
+    B.da = f3(pb[48], pb[64], pb[80]);
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const float rp = K.q[5 * j + 4][2];
@@ -132,8 +156,8 @@ DEV void g_split_bank(const GCtx &G, const Ctx &c, const CBank &K, bool on, floa
             g_row2(nrm, relA, relB, A, B, K.q[5 * j][3], rp, 0.f, EVM_INF, push_ap[j]);
         }
     }
-    if (K.a >= 0) { pa[0] = A.dl.x; pa[64] = A.dl.y; pa[128] = A.dl.z; pa[192] = A.da.x; pa[256] = A.da.y; pa[320] = A.da.z; }
-    pb[0] = B.dl.x; pb[64] = B.dl.y; pb[128] = B.dl.z; pb[192] = B.da.x; pb[256] = B.da.y; pb[320] = B.da.z;
+    if (K.a >= 0) { pa[0] = A.dl.x; pa[16] = A.dl.y; pa[32] = A.dl.z; pa[48] = A.da.x; pa[64] = A.da.y; pa[80] = A.da.z; }
+    pb[0] = B.dl.x; pb[16] = B.dl.y; pb[32] = B.dl.z; pb[48] = B.da.x; pb[64] = B.da.y; pb[80] = B.da.z;
 }
 // program word: id (9 bits) | (body0 + 1) << 9 (6 bits, 0 = floor) | body1 << 15 (6 bits) | round << 21 (5 bits); ~0 = none
 DEV unsigned g_prog_word(int id, int a, int b, int round) {
@@ -173,7 +197,7 @@ DEV void g_bank_writeback(const Ctx &c, const CBank &K) {
 // record's applied fields (the spare quad holds the split-impulse accumulators).  Not inlined: the fast path's register
 // allocation must not pay for this one.
 __device__ __attribute__((noinline)) float g_slow_visit(int phase, unsigned w, int r, f32x4 *ldsq, int e, const float *imt, float *crec_lane,
-                                                         float *scratch_lane, int sc_pt) {
+                                                         float *ptl) {
     if (w == 0xffffffffu || (int) ((w >> 21) & 31u) != r) return 0.f;
     GCtx G;
     G.q = ldsq; G.e = e; G.g = 0; G.QR = 0; G.ver = nullptr; G.multi = false;
@@ -189,11 +213,7 @@ __device__ __attribute__((noinline)) float g_slow_visit(int phase, unsigned w, i
     else {
         f32x4 pq = rec[20 << 6];
         float pa[4] = {pq[0], pq[1], pq[2], pq[3]};
-        Ctx c;
-        c.lane = 0;
-        c.t.scratch = scratch_lane;
-        (void) sc_pt;
-        g_split_bank(G, c, K, true, pa, imt);
+        g_split_bank(G, K, true, pa, imt, ptl);
         pq[0] = pa[0]; pq[1] = pa[1]; pq[2] = pa[2]; pq[3] = pa[3];
         rec[20 << 6] = pq;
     }

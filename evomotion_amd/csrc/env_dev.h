@@ -22,7 +22,11 @@ struct EnvDev {
     int *pmn;                       // [npair][n]  member-vs-member persistent manifold point counts (null unless self_collision)
     float *pmp;                     // [npair*48][n] their points (EVM_PM_STRIDE)
     unsigned *pact;                 // [ceil(npair/32)][n] bit p: pair p holds a point after this step's collision detection
-    float *crec;                    // [(nm+npair)*80][n] two-body contact records of the step (EVM_CR_STRIDE), by manifold id
+    float *crec;                    // [(nm+npair)*84][n] two-body contact records of the step (EVM_CR_STRIDE), by manifold id
+    int *plist;                     // [npair][n] per pair: the envs whose boxes overlap or that hold a cached point (this step)
+    int *blist;                     // [n * npair] (pair << 20 | env) entries of the pairs with a big hull, one flat list
+    int *pcount;                    // [npair + 1] the lists' lengths, [npair] = the flat list's (zeroed by the first setup kernel)
+    int npair_host;                 // EvmSkelC::npair, for the launch geometry
     float *target;                  // [nmus][n]  slider target velocity
     int *flags, *curr_step, *remaining, *settle_left;  // [n]
     float *E;                       // [9][n]     reset rotation (rows)

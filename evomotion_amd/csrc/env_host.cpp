@@ -121,6 +121,7 @@ int evm_env_create(const char *skeleton_path, int n_envs, int device, uint64_t s
     env->d.n = (int) n;
     env->d.tile_floats = (int) (evm::step_lds_bytes(S.nb, S.nscan) / 4);
     env->d.n_real = n_envs;
+    env->d.npair_host = S.npair;
     struct Seg { void **p; size_t count; };
     std::vector<Seg> segs = {
         {(void **) &env->d.pos, 3u * S.nb}, {(void **) &env->d.quat, 4u * S.nb}, {(void **) &env->d.lin, 3u * S.nb},
@@ -138,6 +139,9 @@ int evm_env_create(const char *skeleton_path, int n_envs, int device, uint64_t s
         segs.push_back({(void **) &env->d.pmp, (size_t) EVM_PM_STRIDE * (S.npair > 0 ? S.npair : 1)});
         segs.push_back({(void **) &env->d.pact, (size_t) ((S.npair + 31) / 32 + 1)});
         segs.push_back({(void **) &env->d.crec, (size_t) EVM_CR_STRIDE * (S.nm + S.npair)});
+        segs.push_back({(void **) &env->d.plist, (size_t) (S.npair > 0 ? S.npair : 1)});
+        segs.push_back({(void **) &env->d.blist, (size_t) (S.npair > 0 ? S.npair : 1)});
+        segs.push_back({(void **) &env->d.pcount, (size_t) (EVM_MAX_PAIRS + 1 + 63) / 64});  // >= EVM_MAX_PAIRS + 1 ints whatever the batch (n >= 64)
     }
     size_t total = 0;
     for (auto &s : segs) total += s.count * n * 4;
@@ -284,6 +288,14 @@ int evm_env_pairs(const EvmEnv *env, int *n_pairs, int *h_pairs) {
     if (!env) return fail(EVM_E_INVALID, "env is null");
     if (n_pairs) *n_pairs = env->skel.npair;
     for (int p = 0; p < env->skel.npair && h_pairs; p++) { h_pairs[2 * p] = env->skel.pair[p].a; h_pairs[2 * p + 1] = env->skel.pair[p].b; }
+    return EVM_OK;
+}
+
+// diagnostic: the narrowphase work-list sizes of the last step, one per pair (table order)
+int evm_env_debug_pair_counts(EvmEnv *env, int *h_out) {
+    if (!env || !h_out) return fail(EVM_E_INVALID, "null argument");
+    HIP_TRY(hipDeviceSynchronize());
+    if (env->skel.npair > 0) HIP_TRY(hipMemcpy(h_out, env->d.pcount, (env->skel.npair + 1) * sizeof(int), hipMemcpyDeviceToHost));
     return EVM_OK;
 }
 

@@ -77,6 +77,28 @@ DEV Ctx make_ctx(const EnvDev &d, float *lds) {
     return c;
 }
 
+// the same view for an ARBITRARY env per lane (the pair kernel's compacted work lists): the tile bases become per-lane
+// pointers, everything built on GS / SC / LII keeps working
+DEV Ctx make_ctx_env(const EnvDev &d, int env) {
+    Ctx c;
+    c.d = d;
+    c.t = d;
+    c.lane = env & 63;
+    c.wave = 0;
+    c.env = env;
+    const size_t tile = (size_t) (env >> 6) * 64;
+    c.lds = d.gtile + (size_t) (env >> 6) * d.tile_floats;
+    const int nb = c_skel.nb, nm = c_skel.nm, nmus = c_skel.nmus > 0 ? c_skel.nmus : 1;
+    c.t.pos = d.pos + tile * (3 * nb); c.t.quat = d.quat + tile * (4 * nb);
+    c.t.lin = d.lin + tile * (3 * nb); c.t.ang = d.ang + tile * (3 * nb);
+    c.t.hist = d.hist + tile * (6 * nm); c.t.mfn = d.mfn + tile * nm; c.t.mfp = d.mfp + tile * (36 * nm);
+    c.t.target = d.target + tile * nmus; c.t.E = d.E + tile * 9; c.t.iinv_stale = d.iinv_stale + tile * (6 * nb);
+    c.t.mt = d.mt + tile * 624; c.t.scratch = d.scratch + tile * c_skel.sc_total;
+    c.t.diag = d.diag + tile * 2; c.t.stat = d.stat + tile * 2;
+    ctx_pair_arrays(c, d, tile);
+    return c;
+}
+
 #define GS(arr, k) (c.t.arr[((k) << 6) + c.lane])
 #define SC(k) (c.t.scratch[((k) << 6) + c.lane])
 // field f of the quad-packed record that starts at slot `base` (a multiple of 4), see skel_const.h
@@ -1894,6 +1916,11 @@ __global__ __launch_bounds__(64 * EVM_SPLIT_WAVES) void k_split_pre_a(EnvDev d, 
     if (c_skel.self_collision && vw == nvw - 1) {  // the pair kernel ORs its live pairs in, the setup kernels the split-impulse flag
         const int nwords = ((c_skel.npair + 31) >> 5) + 1;
         for (int k = 0; k < nwords; k++) c.t.pact[(k << 6) + c.lane] = 0u;
+        if (blockIdx.x == 0) {  // this step's narrowphase work lists start empty (dealt to the LIVE lanes: a ragged tile has fewer than 64)
+            const unsigned long long live = __ballot(true);
+            const int nlive = (int) __popcll(live), mine = (int) __popcll(live & ((1ull << c.lane) - 1ull));
+            for (int k = mine; k <= c_skel.npair; k += nlive) d.pcount[k] = 0;
+        }
     }
     // one item list (bodies, then scan slices) dealt round robin, so that no wave gets the head of both
     for (int j = vw; j < c_skel.nb + c_skel.nscan; j += nvw) {
@@ -1936,8 +1963,14 @@ __global__ __launch_bounds__(64 * EVM_SPLIT_WAVES) __attribute__((amdgpu_waves_p
     int s5_kind = -1;
     unsigned long long s5_t0 = 0;
 #endif
-    // one item list: members first (manifold + contact rows, the longest items), then the joint visits
-    for (int j = vw; j < c_skel.nm + c_skel.nvisit; j += nvw) {
+    // one item list: members first (manifold + contact rows, the longest items), then the joint visits, then (member-vs-member
+    // mode) the broadphase of the member pairs: the envs whose boxes overlap, or that hold a cached point, go to the pair's
+    // work list for the narrowphase kernel
+    for (int j = vw; j < c_skel.nm + c_skel.nvisit + c_skel.npair; j += nvw) {
+        if (j >= c_skel.nm + c_skel.nvisit) {
+            pair_broadphase(c, j - c_skel.nm - c_skel.nvisit, L.fin);
+            continue;
+        }
 #ifdef EVM_STAMPS5  // diagnostic: longest item of each kind, per tile (cycles); tools/stamps5.py
         {
             const unsigned long long now = __builtin_amdgcn_s_memtime();
@@ -1995,16 +2028,48 @@ __global__ __launch_bounds__(64 * EVM_SPLIT_WAVES) __attribute__((amdgpu_waves_p
 #endif
 }
 
-// member-vs-member mode: one (pair, tile) item per wavefront (pairs_dev.h); runs after k_split_pre_a (world bases, inertia,
-// external impulses), independent of k_split_pre_b
+// Member-vs-member mode, narrowphase (pairs_dev.h).  The envs that need a pair are compacted over the whole batch by the
+// broadphase items of k_split_pre_b, so a wavefront is full of real work whatever fraction of the envs has that pair close.
+//   blocks [0, EVM_BIG_BLOCKS)   the pairs with a big hull (the 451-vertex feet): one query per QUARTER wavefront, the 16 lanes
+//                                of a row sharing the hull scans (narrow_dev.h, support_group; the hull sits in LDS); the
+//                                blocks walk the flat (pair, env) list
+//   the rest, (tile, pair)       the other pairs: one env per lane, the pair wave-uniform, 64 entries of the pair's own list per
+//                                block, pairs in decreasing cost order
+// One launch for both, so that the few long big-hull wavefronts and the many short ones share the chip.
+#define EVM_BIG_BLOCKS 2048
 template <int MODE>
-__global__ __launch_bounds__(64 * EVM_SPLIT_WAVES) void k_split_pairs(EnvDev d, const uint8_t *__restrict__ mask) {
-    Ctx c = make_ctx(d, tile_stage(d));
-    EVM_SPLIT_GUARD()
-    const LaneState L = lane_state<MODE>(c);
-    const int vw = blockIdx.y * EVM_SPLIT_WAVES + c.wave, nvw = gridDim.y * EVM_SPLIT_WAVES;
-    // feet first: their 451-vertex support scans make those items two orders of magnitude longer than a box pair's
-    for (int j = vw; j < c_skel.npair; j += nvw) pair_item(c, c_skel.pair_order[j], L.fin);
+__global__ __launch_bounds__(64) void k_split_pairs(EnvDev d, const uint8_t *__restrict__ mask, int tiles) {
+    (void) mask;  // (masked-out envs never enter a list)
+    if ((int) blockIdx.x < EVM_BIG_BLOCKS) {
+        const int cnt = d.pcount[c_skel.npair];
+        if ((int) blockIdx.x * 4 >= cnt) return;
+        const int hoff = c_skel.big_hull_off, hn = c_skel.big_hull_n;
+        for (int k = threadIdx.x; k < 3 * hn; k += 64) {  // [vertex][xyz] from the pair-packed table
+            const int v = k / 3, a = k - 3 * v, g = hoff + v;
+            gj::g_lds_hull[k] = c_skel.hull[6 * (g >> 1) + 2 * a + (g & 1)];
+        }
+        __syncthreads();
+        for (int i0 = blockIdx.x * 4; i0 < cnt; i0 += EVM_BIG_BLOCKS * 4) {
+            const int i = i0 + (int) (threadIdx.x >> 4);
+            if (i < cnt) {  // (a row without an entry sits the iteration out; rows are independent of each other)
+                const int e = d.blist[i], p = e >> 20, env = e & 0xfffff;
+                const Ctx c = make_ctx_env(d, env);
+                const bool fin = (MODE & 4) && (d.flags[env] & EVM_FLAG_DONE) != 0;
+                pair_item<true>(c, p, fin, hoff);
+            }
+        }
+        return;
+    }
+    const int bx = (int) blockIdx.x - EVM_BIG_BLOCKS;
+    const int p = c_skel.pair_order[bx / tiles];
+    const int cnt = d.pcount[p], base = (bx % tiles) * 64;
+    if (base >= cnt) return;
+    const int i = base + (int) threadIdx.x;
+    if (i >= cnt) return;
+    const int env = d.plist[(size_t) p * d.n + i];
+    const Ctx c = make_ctx_env(d, env);
+    const bool fin = (MODE & 4) && (d.flags[env] & EVM_FLAG_DONE) != 0;
+    pair_item<false>(c, p, fin);
 }
 
 __global__ __launch_bounds__(64 * EVM_NW) void k_split_sweeps(EnvDev d, const uint8_t *__restrict__ mask, int autoreset) {
@@ -2286,7 +2351,7 @@ static hipError_t launch_split(const EnvDev &d, size_t lds, const float *action,
     const dim3 gp(tiles, parts), bp(64 * EVM_SPLIT_WAVES);
     hipLaunchKernelGGL((k_split_pre_a<MODE>), gp, bp, 0, s, d, mask);
     hipLaunchKernelGGL((k_split_pre_b<MODE>), gp, bp, 0, s, d, action, mask);
-    if (d.pmn) hipLaunchKernelGGL((k_split_pairs<MODE>), gp, bp, 0, s, d, mask);
+    if (d.pmn) hipLaunchKernelGGL((k_split_pairs<MODE>), dim3(EVM_BIG_BLOCKS + tiles * d.npair_host), dim3(64), 0, s, d, mask, tiles);
     if (e0) (void) hipEventRecord(e0, s);
     if (d.gs) {
         static bool attr_g[EVM_MAX_DEVICES] = {};

@@ -85,16 +85,73 @@ DEV F3 support(int hull_off, int hull_n, F3 dir) {
     return f3(c_skel.hull[hb], c_skel.hull[hb + 2], c_skel.hull[hb + 4]);
 }
 
+// The same support vertex found by the 16 lanes of a DPP row together (GROUP mode of the narrowphase: one query per
+// quarter wavefront — for the 451-vertex feet, where one lane per query would walk the whole hull alone): lane k of the row
+// takes vertices k, k + 16, ..., then a four-step butterfly inside the row (quad permutes, half-row and row mirrors) leaves
+// the first maximum (larger value, lower index on a tie) in every lane.  dir, hull_off and hull_n are equal across the row.
+DEV int dpp_i(int v, const int ctrl) {
+    switch (ctrl) {
+        case 0: return __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+        case 1: return __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+        case 2: return __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false);  // row_half_mirror
+        default: return __builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false); // row_mirror
+    }
+}
+// The block may hold ONE big hull in LDS (g_lds_hull, [vertex][xyz], filled by the kernel from hull table offset
+// g_lds_hull_off): a row's 16 lanes then read 192 contiguous bytes per step instead of gathering from the constant table.
+__device__ __shared__ float g_lds_hull[3 * EVM_MAX_HULL_PTS / 2];
+DEV F3 support_group(int hull_off, int hull_n, F3 dir, int lds_hull_off) {
+    const int sub = (int) (threadIdx.x & 15);
+    float best = -GJ_LARGE;
+    int bi = 0x7fffffff;
+    if (hull_off == lds_hull_off) {
+        for (int v0 = 0; __any(v0 < hull_n); v0 += 64) {  // four vertices per lane and trip: the LDS reads of a trip are in flight together
+            float x[4], y[4], z[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int v = v0 + 16 * k + sub, vv = v < hull_n ? v : 0;
+                x[k] = g_lds_hull[3 * vv]; y[k] = g_lds_hull[3 * vv + 1]; z[k] = g_lds_hull[3 * vv + 2];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int v = v0 + 16 * k + sub;
+                const float d = (dir.x * x[k] + dir.y * y[k]) + dir.z * z[k];
+                if (v < hull_n && d > best) { best = d; bi = v; }
+            }
+        }
+    } else {
+        for (int v = sub; __any(v < hull_n); v += 16) {
+            if (v < hull_n) {
+                const int g = hull_off + v, hb = 6 * (g >> 1) + (g & 1);
+                const float d = (dir.x * c_skel.hull[hb] + dir.y * c_skel.hull[hb + 2]) + dir.z * c_skel.hull[hb + 4];
+                if (d > best) { best = d; bi = v; }
+            }
+        }
+    }
+#pragma unroll
+    for (int st = 0; st < 4; st++) {
+        const float ob = __int_as_float(dpp_i(__float_as_int(best), st));
+        const int oi = dpp_i(bi, st);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (hull_off == lds_hull_off) return f3(g_lds_hull[3 * bi], g_lds_hull[3 * bi + 1], g_lds_hull[3 * bi + 2]);
+    const int g = hull_off + bi, hb = 6 * (g >> 1) + (g & 1);
+    return f3(c_skel.hull[hb], c_skel.hull[hb + 2], c_skel.hull[hb + 4]);
+}
+
 struct Shape {  // one member's hull and world transform (the basis may be non-orthonormal in the step that follows reset())
     int hull_off, hull_n;
+    int lds_hull_off;  // GROUP mode: hull table offset of the hull the block holds in LDS (-1: none)
     M33 R;
     F3 o;
 };
-// w = support_A(-axis) - support_B(axis) in world space, with the two support points
+// w = support_A(-axis) - support_B(axis) in world space, with the two support points.  GROUP: the 16 lanes of a row work
+// on one query (identical state in all of them) and share the support scans.
+template <bool GROUP>
 DEV void minkowski(const Shape &A, F3 oA, const Shape &B, F3 oB, F3 axis, F3 &pW, F3 &qW) {
     const F3 sA = gj::vmul(gj::neg(axis), A.R), sB = gj::vmul(axis, B.R);
-    pW = gj::xform(A.R, oA, gj::support(A.hull_off, A.hull_n, sA));
-    qW = gj::xform(B.R, oB, gj::support(B.hull_off, B.hull_n, sB));
+    pW = gj::xform(A.R, oA, GROUP ? gj::support_group(A.hull_off, A.hull_n, sA, A.lds_hull_off) : gj::support(A.hull_off, A.hull_n, sA));
+    qW = gj::xform(B.R, oB, GROUP ? gj::support_group(B.hull_off, B.hull_n, sB, A.lds_hull_off) : gj::support(B.hull_off, B.hull_n, sB));
 }
 
 // ---- btVoronoiSimplexSolver on registers -------------------------------------------------------------------------------
@@ -293,6 +350,7 @@ struct RunOut {
     F3 normalInB, pointOnA, pointOnB, axis;
     int degenerate, iters;
 };
+template <bool GROUP>
 DEV RunOut gjk_run(const Shape &A, F3 oA, const Shape &B, F3 oB, float max_dist2, bool active, float marginA, float marginB) {
     RunOut o;
     o.isValid = false; o.distance = 0.f; o.squaredDistance = GJ_LARGE; o.degenerate = 0; o.iters = 0;
@@ -306,7 +364,7 @@ DEV RunOut gjk_run(const Shape &A, F3 oA, const Shape &B, F3 oB, float max_dist2
     int cur_iter = 0, degenerate = 0;
     while (__any(running)) {
         F3 pW, qW;
-        minkowski(A, oA, B, oB, axis, pW, qW);  // (lanes that have left keep their last axis: harmless, results unused)
+        minkowski<GROUP>(A, oA, B, oB, axis, pW, qW);  // (lanes that have left keep their last axis: harmless, results unused)
         if (running) {
             const F3 w = gj::sub(pW, qW);
             const float delta = gj::dot(axis, w);
@@ -374,13 +432,14 @@ __device__ const float kPenDirs[42][3] = {
     {-0.425323f, -0.309011f, 0.850654f}, {-0.425323f, 0.309011f, 0.850654f}, {0.162456f, 0.499995f, 0.850654f}};
 
 // btGjkPairDetector::getClosestPoints for the lanes in `active` (the others return has = false)
+template <bool GROUP>
 DEV Result closest_points(const Shape &A, const Shape &B, float max_dist2, bool active) {
     const float marginA = MARGIN_F, marginB = MARGIN_F, margin = marginA + marginB;
     Result out;
     out.has = false; out.normalOnB = f3(0, 0, 0); out.pointOnB = f3(0, 0, 0); out.distance = 0.f; out.iterations = 0; out.used_pen = false;
     const F3 positionOffset = gj::scl(gj::add(A.o, B.o), 0.5f);
     const F3 oA = gj::sub(A.o, positionOffset), oB = gj::sub(B.o, positionOffset);
-    const RunOut r = gjk_run(A, oA, B, oB, max_dist2, active, marginA, marginB);
+    const RunOut r = gjk_run<GROUP>(A, oA, B, oB, max_dist2, active, marginA, marginB);
     bool isValid = r.isValid;
     float distance = r.distance;
     F3 normalInB = r.normalInB, pointOnB = r.pointOnB;
@@ -395,7 +454,7 @@ DEV Result closest_points(const Shape &A, const Shape &B, float max_dist2, bool 
         for (int i = 0; i < 42; i++) {
             const F3 norm = f3(kPenDirs[i][0], kPenDirs[i][1], kPenDirs[i][2]);
             F3 pW, qW;
-            minkowski(A, oA, B, oB, norm, pW, qW);
+            minkowski<GROUP>(A, oA, B, oB, norm, pW, qW);
             const float delta = gj::dot(norm, gj::sub(qW, pW));
             if (delta < minProj) { minProj = delta; minNorm = norm; }
         }
@@ -406,7 +465,7 @@ DEV Result closest_points(const Shape &A, const Shape &B, float max_dist2, bool 
         // own final normal check can only flip the normal, which calcPenDepth does not read
         const F3 oAd = gj::add(oA, offset);
         const F3 po2 = gj::scl(gj::add(oAd, oB), 0.5f);
-        RunOut n2 = gjk_run(A, gj::sub(oAd, po2), B, gj::sub(oB, po2), GJ_LARGE, need_pen && overlap, marginA, marginB);
+        RunOut n2 = gjk_run<GROUP>(A, gj::sub(oAd, po2), B, gj::sub(oB, po2), GJ_LARGE, need_pen && overlap, marginA, marginB);
         n2.pointOnB = gj::add(n2.pointOnB, po2);
         const bool nested_has = n2.isValid;
         if (need_pen) {
@@ -429,22 +488,25 @@ DEV Result closest_points(const Shape &A, const Shape &B, float max_dist2, bool 
         }
     }
     if (active && isValid && (distance < 0.f || distance * distance < max_dist2)) out.has = true;
-    if (__any(out.has)) {
-        // the normal check at the end of getClosestPointsNonVirtual
+    if (__any(out.has && out.used_pen)) {
+        // The normal check at the end of getClosestPointsNonVirtual: the candidate normal n, its opposite and the plain GJK
+        // normal are compared by the separation they give along themselves (d0, d1, d2).  After a plain GJK result n IS the
+        // GJK normal (d2 = d0 exactly) and d0 + d1 = -(width of A + width of B along n) - 2 margins - ... < 0 with d0 >= -margin >
+        // d1: the check cannot change anything, so it only runs for lanes that went through the penetration branch (the
+        // oracle evaluates it for every query and gets the same answer).
         F3 pW, qW;
-        minkowski(A, oA, B, oB, normalInB, pW, qW);
+        minkowski<GROUP>(A, oA, B, oB, normalInB, pW, qW);
         const float d0 = gj::dot(normalInB, gj::sub(pW, qW)) - margin;
         const F3 nn = gj::neg(normalInB);
-        minkowski(A, oA, B, oB, nn, pW, qW);
+        minkowski<GROUP>(A, oA, B, oB, nn, pW, qW);
         const float d1 = gj::dot(nn, gj::sub(pW, qW)) - margin;
-        float d2 = d0;  // orgNormalInB == normalInB unless the penetration branch replaced it
-        if (__any(out.has && out.used_pen)) {
-            minkowski(A, oA, B, oB, orgNormalInB, pW, qW);
-            d2 = gj::dot(orgNormalInB, gj::sub(pW, qW)) - margin;
-        }
-        if (d1 > d0) normalInB = nn;
-        if (gj::len2(orgNormalInB) != 0.f) {
-            if (d2 > d0 && d2 > d1 && d2 > distance) { normalInB = orgNormalInB; distance = d2; }
+        minkowski<GROUP>(A, oA, B, oB, orgNormalInB, pW, qW);
+        const float d2 = gj::dot(orgNormalInB, gj::sub(pW, qW)) - margin;
+        if (out.has && out.used_pen) {
+            if (d1 > d0) normalInB = nn;
+            if (gj::len2(orgNormalInB) != 0.f) {
+                if (d2 > d0 && d2 > d1 && d2 > distance) { normalInB = orgNormalInB; distance = d2; }
+            }
         }
     }
     out.normalOnB = normalInB;

@@ -51,7 +51,7 @@ DEV void store_mp2(const Ctx &c, int p, int slot, const MPoint2 &m) {
 // friction direction, setupFrictionConstraint) into its contact record.  A = body0 (absent for the static floor), B = body1;
 // posA / posB / nrm / dist / ap / apl: the manifold's points as refreshContactPoints left them.
 DEV void contact_record(const Ctx &c, int id, int n, bool hasA, const BodyK &A, const BodyK &B, const F3 (&posA)[4], const F3 (&posB)[4],
-                        const F3 (&nrm)[4], const float (&dist)[4], const float (&ap)[4], const float (&apl)[4], float mu) {
+                        const F3 (&nrm)[4], const float (&dist)[4], const float (&ap)[4], const float (&apl)[4], float mu, bool lead = true) {
     const float invdt = 1.f / DT_F;
     bool deep = false;  // some point waits for the split-impulse recovery
 #pragma unroll
@@ -109,7 +109,7 @@ DEV void contact_record(const Ctx &c, int id, int n, bool hasA, const BodyK &A, 
         p[0] = q0; p[64] = q1; p[128] = q2; p[192] = q3; p[256] = q4;
     }
     // the flag word behind the pairs' activity words: bit 0 = this env has a point deeper than the split-impulse threshold
-    if (deep) atomicOr(&c.t.pact[((((c_skel.npair + 31) >> 5)) << 6) + c.lane], 1u);
+    if (deep && lead) atomicOr(&c.t.pact[((((c_skel.npair + 31) >> 5)) << 6) + c.lane], 1u);
 }
 
 // floor manifold of member m in the two-body record format (normal on B = (0, -1, 0), body0 = the static floor)
@@ -137,15 +137,73 @@ DEV void member_box(const EvmMemberC &MB, const M33 &R, F3 o, F3 &ctr, F3 &ext) 
              fabsf(R.r2.x) * h.x + fabsf(R.r2.y) * h.y + fabsf(R.r2.z) * h.z + 0.02f);
 }
 
-// one (pair, tile) item: broadphase cull, narrowphase, manifold maintenance, rows.  drop: lanes whose env starts a reset
-// with this step (their cached points are discarded: removeRigidBody / addRigidBody)
-DEV void pair_item(const Ctx &c, int p, bool drop) {
+// Broadphase of pair p for the 64 envs of a tile (an item of k_split_pre_b): an env whose two boxes overlap, or that still
+// holds a cached point, is appended to the pair's work list (one atomic per wavefront).  drop: lanes whose env starts a
+// reset with this step (their cached points are discarded: removeRigidBody / addRigidBody).
+DEV void pair_broadphase(const Ctx &c, int p, bool drop) {
+    const EvmPairC &PC = c_skel.pair[p];
+    const int a = PC.a, b = PC.b;
+    int n = PMN(p);
+    if (drop && n > 0) { PMN(p) = 0; n = 0; }
+    const M33 Ra = m33(SC3(c_skel.sc_r + 9 * a), SC3(c_skel.sc_r + 9 * a + 3), SC3(c_skel.sc_r + 9 * a + 6));
+    const M33 Rb = m33(SC3(c_skel.sc_r + 9 * b), SC3(c_skel.sc_r + 9 * b + 3), SC3(c_skel.sc_r + 9 * b + 6));
+    F3 ca, ea, cb, eb;
+    member_box(c_skel.member[a], Ra, G3(pos, 3 * a), ca, ea);
+    member_box(c_skel.member[b], Rb, G3(pos, 3 * b), cb, eb);
+    bool near = fabsf(ca.x - cb.x) <= ea.x + eb.x && fabsf(ca.y - cb.y) <= ea.y + eb.y && fabsf(ca.z - cb.z) <= ea.z + eb.z;
+    if (__any(near && n == 0)) {
+        // Second cull, for pairs without a cached point: the un-margined hulls lie inside their oriented local boxes, so if a
+        // face normal of either box separates the boxes by more than the two margins + the breaking threshold, GJK could only
+        // report a distance beyond the manifold's reach: same result, no query.  (Four out of five box overlaps end here.)
+        // Not applied in the step that follows reset(): that step's bases are not orthonormal.
+        const EvmMemberC &MA = c_skel.member[a], &MB = c_skel.member[b];
+        const F3 ha = f3(MA.aabb_h[0] - 2.f * MARGIN_F, MA.aabb_h[1] - 2.f * MARGIN_F, MA.aabb_h[2] - 2.f * MARGIN_F);  // core half extents
+        const F3 hb = f3(MB.aabb_h[0] - 2.f * MARGIN_F, MB.aabb_h[1] - 2.f * MARGIN_F, MB.aabb_h[2] - 2.f * MARGIN_F);
+        const F3 t = cb - ca;                                   // (the fattened boxes share their centres with the core boxes)
+        const F3 a0 = col0(Ra), a1 = col1(Ra), a2 = col2(Ra), b0 = col0(Rb), b1 = col1(Rb), b2 = col2(Rb);
+        const float reach = MARGIN_F + MARGIN_F + PC.thr + 1e-4f;
+        float gap = -EVM_INF;
+        // axes of A: radius of A = ha_i, radius of B = sum_j hb_j |a_i . b_j|
+        gap = fmaxf(gap, fabsf(dot(t, a0)) - ha.x - (hb.x * fabsf(dot(a0, b0)) + hb.y * fabsf(dot(a0, b1)) + hb.z * fabsf(dot(a0, b2))));
+        gap = fmaxf(gap, fabsf(dot(t, a1)) - ha.y - (hb.x * fabsf(dot(a1, b0)) + hb.y * fabsf(dot(a1, b1)) + hb.z * fabsf(dot(a1, b2))));
+        gap = fmaxf(gap, fabsf(dot(t, a2)) - ha.z - (hb.x * fabsf(dot(a2, b0)) + hb.y * fabsf(dot(a2, b1)) + hb.z * fabsf(dot(a2, b2))));
+        gap = fmaxf(gap, fabsf(dot(t, b0)) - hb.x - (ha.x * fabsf(dot(b0, a0)) + ha.y * fabsf(dot(b0, a1)) + ha.z * fabsf(dot(b0, a2))));
+        gap = fmaxf(gap, fabsf(dot(t, b1)) - hb.y - (ha.x * fabsf(dot(b1, a0)) + ha.y * fabsf(dot(b1, a1)) + ha.z * fabsf(dot(b1, a2))));
+        gap = fmaxf(gap, fabsf(dot(t, b2)) - hb.z - (ha.x * fabsf(dot(b2, a0)) + ha.y * fabsf(dot(b2, a1)) + ha.z * fabsf(dot(b2, a2))));
+        const bool pending = (c.d.flags[c.env] & EVM_FLAG_PENDING) != 0 || drop;
+        if (n == 0 && !pending && gap > reach) near = false;
+    }
+    const bool need = n > 0 || near;
+    const unsigned long long m = __ballot(need);
+    if (m == 0ull) return;
+    const int lane = c.lane & 63, leader = (int) __builtin_ctzll(m);
+    // a pair with a big hull (the feet) goes to ONE flat list of (pair, env) entries that the quarter-wave narrowphase kernel
+    // walks; the others to the pair's own list (one env per lane, the pair wave-uniform)
+    const bool big = c_skel.member[a].hull_n > EVM_BIG_HULL || c_skel.member[b].hull_n > EVM_BIG_HULL;
+    const int slot = big ? c_skel.npair : p;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(&c.d.pcount[slot], (int) __popcll(m));
+    base = __shfl(base, leader);
+    const int at = base + (int) __popcll(m & ((1ull << lane) - 1ull));
+    if (need) {
+        if (big) c.d.blist[at] = (p << 20) | c.env;
+        else c.d.plist[(size_t) p * c.d.n + at] = c.env;
+    }
+}
+
+// one pair for one env per lane (any envs: the narrowphase kernel's compacted work list): narrowphase, manifold
+// maintenance, rows.  drop: as above.  GROUP: the 16 lanes of a row carry the SAME (pair, env) and share the hull scans
+// (every lane computes and stores the same values; lane 0 of the row does the atomics); p may then differ between rows.
+template <bool GROUP>
+DEV void pair_item(const Ctx &c, int p, bool drop, int lds_hull_off = -1) {
+    const bool lead = !GROUP || (threadIdx.x & 15) == 0;
     const EvmPairC &PC = c_skel.pair[p];
     const int a = PC.a, b = PC.b;
     const EvmMemberC &MA = c_skel.member[a], &MB = c_skel.member[b];
     int n = drop ? 0 : PMN(p);
     gj::Shape SA, SB;
     SA.hull_off = MA.hull_off; SA.hull_n = MA.hull_n; SB.hull_off = MB.hull_off; SB.hull_n = MB.hull_n;
+    SA.lds_hull_off = SB.lds_hull_off = lds_hull_off;
     SA.o = G3(pos, 3 * a); SB.o = G3(pos, 3 * b);
     SA.R = m33(SC3(c_skel.sc_r + 9 * a), SC3(c_skel.sc_r + 9 * a + 3), SC3(c_skel.sc_r + 9 * a + 6));
     SB.R = m33(SC3(c_skel.sc_r + 9 * b), SC3(c_skel.sc_r + 9 * b + 3), SC3(c_skel.sc_r + 9 * b + 6));
@@ -161,7 +219,7 @@ DEV void pair_item(const Ctx &c, int p, bool drop) {
     MPoint2 p0 = load_mp2(c, p, 0), p1 = load_mp2(c, p, 1), p2 = load_mp2(c, p, 2), p3 = load_mp2(c, p, 3);
     if (__any(overlap)) {
         const float md = MARGIN_F + MARGIN_F + thr;
-        const gj::Result r = gj::closest_points(SA, SB, md * md, overlap);
+        const gj::Result r = gj::closest_points<GROUP>(SA, SB, md * md, overlap);
         const bool add = r.has && !(r.distance > thr);
         if (add) {
             // btManifoldResult::addContactPoint(normalOnBInWorld, pointInWorld, depth)
@@ -244,11 +302,11 @@ DEV void pair_item(const Ctx &c, int p, bool drop) {
     store_mp2(c, p, 0, p0); store_mp2(c, p, 1, p1); store_mp2(c, p, 2, p2); store_mp2(c, p, 3, p3);
     PMN(p) = n;
     if (!__any(n > 0)) return;
-    if (n > 0) atomicOr(&c.t.pact[((p >> 5) << 6) + c.lane], 1u << (p & 31));
+    if (n > 0 && lead) atomicOr(&c.t.pact[((p >> 5) << 6) + c.lane], 1u << (p & 31));
     const BodyK A = load_bodyk(c, a), B = load_bodyk(c, b);
     F3 nrm[4] = {p0.nb, p1.nb, p2.nb, p3.nb};
     float dist[4] = {p0.dist, p1.dist, p2.dist, p3.dist}, ap[4] = {p0.ap, p1.ap, p2.ap, p3.ap}, apl[4] = {p0.apl, p1.apl, p2.apl, p3.apl};
-    contact_record(c, c_skel.nm + p, n, true, A, B, wA, wB, nrm, dist, ap, apl, PC.mu);
+    contact_record(c, c_skel.nm + p, n, true, A, B, wA, wB, nrm, dist, ap, apl, PC.mu, lead);
 }
 
 }  // namespace evm

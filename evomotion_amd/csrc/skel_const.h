@@ -30,6 +30,7 @@
 // and one spare quad (20) that only the overflow path of the sweeps kernel uses (its split-impulse accumulators)
 #define EVM_CR_POINT 20
 #define EVM_CR_STRIDE 84
+#define EVM_BIG_HULL 64    // hulls above this many vertices get the quarter-wave narrowphase (one query per 16 lanes)
 #define EVM_PM_STRIDE 48  // persistent pair manifold: 4 points x (localA3 localB3 normalOnB3 dist applied applied_lateral)
 
 struct EvmBodyC {
@@ -139,6 +140,8 @@ struct EvmSkelC {
     int env_kind;          // 0 robot_walk, 1 robot_jump (EvmEnvParams::env_kind)
     int self_collision;    // member-vs-member contacts (EvmEnvParams::self_collision)
     int npair;             // collidable member pairs (0 unless self_collision)
+    int big_hull_off, big_hull_n;  // the largest hull above EVM_BIG_HULL vertices (hull table offset, vertex count; -1: none):
+                                   // the narrowphase kernel's blocks keep it in LDS
     int settle_steps;      // physics steps inside reset(): 2 * reset_frames (robot_walk.cpp:98-103) or reset_frames (robot_jump.cpp:104)
     float reset_angle_limit;  // pi * 2 / 3 (robot_walk.cpp:80) or pi / 3 (robot_jump.cpp:89)
     // scratch layout (offsets in floats-per-env)

@@ -650,6 +650,9 @@ int load_skeleton_constants(const char *path, const EvmEnvParams &prm, EvmSkelC 
     // members without contact response (member.cpp:31-33) get no rows.  Lexicographic (a < b): body0 = a, body1 = b, and
     // this is the order of their rows in the solver ----
     S.npair = 0;
+    S.big_hull_off = -1; S.big_hull_n = 0;
+    for (int i = 0; i < nm; i++)
+        if (S.member[i].hull_n > EVM_BIG_HULL && S.member[i].hull_n > S.big_hull_n) { S.big_hull_off = S.member[i].hull_off; S.big_hull_n = S.member[i].hull_n; }
     if (S.self_collision) {
         for (int i = 0; i < nm; i++)
             for (int j = i + 1; j < nm; j++) {
@@ -1244,10 +1247,10 @@ int build_group_schedule(const EvmSkelC &S, int nwaves, EvmGSchedC &G, std::stri
     size_t bytes = quads * 16 + (size_t) ((S.nb + 3) / 4 * 4) * 4 + EVM_G_ENVS * 4;
     G.with_contacts = with_contacts ? 1 : 0;
     if (!with_contacts) {
-        // behind the image: the contact program (2 banks x 16 slots x 16 envs words), four workgroup-wide words and the
-        // bodies' inverse masses
+        // behind the image: the contact program (2 banks x 16 slots x 16 envs words), four workgroup-wide words, the bodies'
+        // inverse masses and the members' push / turn velocities of the split-impulse phase
         bytes = (bytes + 15) & ~(size_t) 15;
-        bytes += (size_t) 2 * 16 * EVM_G_ENVS * 4 + 16 + (size_t) ((S.nb + 3) & ~3) * 4;
+        bytes += (size_t) 2 * 16 * EVM_G_ENVS * 4 + 16 + (size_t) ((S.nb + 3) & ~3) * 4 + (size_t) 6 * S.nm * EVM_G_ENVS * 4;
     }
     G.lds_bytes = (int) bytes;
     if (bytes > 160 * 1024) { err = "skeleton records exceed the LDS image of the lane-group sweeps"; return EVM_E_UNSUPPORTED; }

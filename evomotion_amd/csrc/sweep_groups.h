@@ -401,8 +401,12 @@ __global__ __launch_bounds__(64 * EVM_G_MAX_WAVES) void k_sweeps_g(EnvDev d, con
     float *imt = reinterpret_cast<float *>(meta + 4);                     // inverse mass per body
     unsigned w1 = 0xffffffffu;  // this slot's manifold of the overflow bank (served from global memory)
     bool use_b1 = false;
-    float *const crec_lane = c.t.crec ? c.t.crec + 4 * c.lane : nullptr, *const scratch_lane = c.t.scratch + c.lane;
-    auto slow = [&](int phase, int r) -> float { return g_slow_visit(phase, w1, r, G.q, G.e, imt, crec_lane, scratch_lane, c_skel.sc_pt); };
+    float *const crec_lane = c.t.crec ? c.t.crec + 4 * c.lane : nullptr;
+    float *ptl = imt + ((nb + 3) & ~3);  // [6 nm][16 envs] push / turn velocities of the members during the split-impulse phase
+    auto slow = [&](int phase, int r) -> float { return g_slow_visit(phase, w1, r, G.q, G.e, imt, crec_lane, ptl); };
+#ifdef EVM_GSTAMPS
+    unsigned long long gs_c0 = __builtin_amdgcn_s_memtime(), gs_c1 = gs_c0, gs_c2 = gs_c0, gs_c3 = gs_c0;
+#endif
     if (scm) {  // (program, words and inverse masses were initialised by every thread before any lane left)
         if (wave == 0) {
             int nn[EVM_MAX_MEMBERS];
@@ -422,22 +426,35 @@ __global__ __launch_bounds__(64 * EVM_G_MAX_WAVES) void k_sweeps_g(EnvDev d, con
                 reinterpret_cast<f32x4 *>(crec_lane + ((size_t) ((int) (w1 & 511u) * EVM_CR_STRIDE + 80) << 6))[0] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
+#ifdef EVM_GSTAMPS
+        gs_c1 = __builtin_amdgcn_s_memtime();
+#endif
         if (__builtin_amdgcn_readfirstlane(meta[2]) != 0) {
             // solveGroupCacheFriendlySplitImpulseIterations: the same rounds on the push / turn velocities (sc_pt, zeroed by the
             // setup kernel); ten iterations like the oracle (further ones would add exactly nothing once an iteration changes nothing)
             float pa0[4] = {0.f, 0.f, 0.f, 0.f};
+            const int slot16 = wave * EVM_G_SLOTS + G.g, nslots = nw * EVM_G_SLOTS;
+            for (int k = slot16; k < 6 * nm; k += nslots) ptl[(k << 4) + G.e] = 0.f;
+            g_lds_barrier();
             for (int it = 0; it < NUM_ITER; it++)
                 for (int r = 0; r < nrounds; r++) {
-                    g_split_bank(G, c, K0, K0.round == r, pa0, imt);
+                    g_split_bank(G, K0, K0.round == r, pa0, imt, ptl);
                     if (use_b1) slow(3, r);
                     g_lds_barrier();
                 }
+            for (int k = slot16; k < 6 * nm; k += nslots) SC(c_skel.sc_pt + k) = ptl[(k << 4) + G.e];  // for the integration kernel
         }
+#ifdef EVM_GSTAMPS
+        gs_c2 = __builtin_amdgcn_s_memtime();
+#endif
         for (int r = 0; r < nrounds; r++) {
             g_contact_bank<0>(G, K0, K0.round == r, imt);
             if (use_b1) slow(0, r);
             g_lds_barrier();
         }
+#ifdef EVM_GSTAMPS
+        gs_c3 = __builtin_amdgcn_s_memtime();
+#endif
     }
 
 #if defined(EVM_GSTAMPS) || defined(EVM_GSTAMPS2)
@@ -544,6 +561,9 @@ __global__ __launch_bounds__(64 * EVM_G_MAX_WAVES) void k_sweeps_g(EnvDev d, con
         }
         if (scm) {
             // contact rows of this sweep: all normal rows, then all friction rows, each as rounds of body-disjoint manifolds
+#ifdef EVM_GSTAMPS
+            const unsigned long long gs_e0 = __builtin_amdgcn_s_memtime();
+#endif
             g_lds_barrier();
             for (int r = 0; r < nrounds; r++) {
                 rs = fmaxf(rs, g_contact_bank<1>(G, K0, K0.round == r, imt));
@@ -555,6 +575,9 @@ __global__ __launch_bounds__(64 * EVM_G_MAX_WAVES) void k_sweeps_g(EnvDev d, con
                 if (use_b1) rs = fmaxf(rs, slow(2, r));
                 g_lds_barrier();
             }
+#ifdef EVM_GSTAMPS
+            gs_type[4] += __builtin_amdgcn_s_memtime() - gs_e0; gs_n[4] += 2 * nrounds;
+#endif
         }
         if (it == NUM_ITER - 1) res = rs;
     }
@@ -643,6 +666,7 @@ __global__ __launch_bounds__(64 * EVM_G_MAX_WAVES) void k_sweeps_g(EnvDev d, con
         for (int q = 0; q < 5; q++) { st[2 * q] = gs_type[q]; st[2 * q + 1] = gs_n[q]; }
         st[10] = gs_t1 - gs_t0; st[11] = gs_t2 - gs_t1; st[12] = __builtin_amdgcn_s_memtime() - gs_t2;
         st[13] = gs_ta - gs_t0; st[14] = gs_tb - gs_ta; st[15] = gs_tc - gs_tb;
+        if (scm) { st[13] = gs_c1 - gs_c0; st[14] = gs_c2 - gs_c1; st[15] = gs_c3 - gs_c2; }  // program + records, split impulse, warm start
     }
 #endif
 }

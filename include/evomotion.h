@@ -115,6 +115,8 @@ int evm_env_get_body_poses(const EvmEnv *env, float *d_pose, void *stream);
 int evm_env_state_size(const EvmEnv *env);
 int evm_env_get_state(EvmEnv *env, float *h_state /* [n_envs, state_size] */);
 int evm_env_set_state(EvmEnv *env, const float *h_state);
+/* Diagnostic (synchronous): per member pair, how many envs the last step's broadphase handed to the narrowphase. */
+int evm_env_debug_pair_counts(EvmEnv *env, int *h_out /* [n_pairs + 1]: per small-hull pair; last = all big-hull pairs together */);
 /* Low-level pieces of reset()/do_step() for step-by-step parity tests (synchronous). */
 int evm_env_debug_reset_begin(EvmEnv *env, const uint8_t *d_mask);
 int evm_env_debug_physics_steps(EvmEnv *env, int n_steps, const uint8_t *d_mask);

@@ -28,5 +28,9 @@ if "--waves" in sys.argv:  # -DEVM_GSTAMPS2 build: per wave
     sys.exit(0)
 for q, name in enumerate(["hinge", "fixed", "slider", "p2p", "contact"]):
     print("%-8s %7.0f cycles/entry  %6.1f entries per step (wave 0)  %8.0f cycles per step" % (name, acc[2 * q] / max(acc[2 * q + 1], 1), acc[2 * q + 1], acc[2 * q]))
-print("prologue %.0f (table %.0f, records %.0f, bodies %.0f, manifold counts + barrier %.0f)  sweeps %.0f  epilogue %.0f cycles (wave 0)"
-      % (acc[10], acc[13], acc[14], acc[15], acc[10] - acc[13] - acc[14] - acc[15], acc[11], acc[12]))
+if env.n_pairs:   # member-vs-member mode: slots 13..15 hold the contact set-up phases, the "contact" line is the contact rounds of a sweep
+    print("prologue %.0f (of it: contact program + owners' records %.0f, split-impulse recovery %.0f, warm start %.0f)  sweeps %.0f  epilogue %.0f cycles (wave 0); contact line = cycles per round-phase"
+          % (acc[10], acc[13], acc[14], acc[15], acc[11], acc[12]))
+else:
+    print("prologue %.0f (table %.0f, records %.0f, bodies %.0f, manifold counts + barrier %.0f)  sweeps %.0f  epilogue %.0f cycles (wave 0)"
+          % (acc[10], acc[13], acc[14], acc[15], acc[10] - acc[13] - acc[14] - acc[15], acc[11], acc[12]))
