@@ -56,11 +56,11 @@ DEV BodyPD g_pair_any(const GCtx &G, int a, int b, const float *imt) {
 DEV void g_store_pair_any(const GCtx &G, int a, int b, const BodyPD &Q) {
     f32x4 x;
     if (a >= 0) {
-        x[0] = Q.dl.x.x; x[1] = Q.dl.y.x; x[2] = Q.dl.z.x; x[3] = Q.da.x.x; GQ(G, 3 * a) = x;
-        x[0] = Q.da.y.x; x[1] = Q.da.z.x; x[2] = Q.I.xx.x; x[3] = Q.I.xy.x; GQ(G, 3 * a + 1) = x;
+        x[0] = Q.dl.x.x; x[1] = Q.dl.y.x; x[2] = Q.dl.z.x; x[3] = Q.da.x.x; GB(G, 3 * a) = x;
+        x[0] = Q.da.y.x; x[1] = Q.da.z.x; x[2] = Q.I.xx.x; x[3] = Q.I.xy.x; GB(G, 3 * a + 1) = x;
     }
-    x[0] = Q.dl.x.y; x[1] = Q.dl.y.y; x[2] = Q.dl.z.y; x[3] = Q.da.x.y; GQ(G, 3 * b) = x;
-    x[0] = Q.da.y.y; x[1] = Q.da.z.y; x[2] = Q.I.xx.y; x[3] = Q.I.xy.y; GQ(G, 3 * b + 1) = x;
+    x[0] = Q.dl.x.y; x[1] = Q.dl.y.y; x[2] = Q.dl.z.y; x[3] = Q.da.x.y; GB(G, 3 * b) = x;
+    x[0] = Q.da.y.y; x[1] = Q.da.z.y; x[2] = Q.I.xx.y; x[3] = Q.I.xy.y; GB(G, 3 * b + 1) = x;
 }
 // one two-body row along `dir` (contact normal or friction direction) on scalar bodies: the split-impulse recovery's form
 DEV float g_row2(F3 dir, F3 relA, F3 relB, BodyD &A, BodyD &B, float jd, float rhs, float lo, float hi, float &ap) {
@@ -200,7 +200,7 @@ __device__ __attribute__((noinline)) float g_slow_visit(int phase, unsigned w, i
                                                          float *ptl) {
     if (w == 0xffffffffu || (int) ((w >> 21) & 31u) != r) return 0.f;
     GCtx G;
-    G.q = ldsq; G.e = e; G.g = 0; G.QR = 0; G.ver = nullptr; G.multi = false;
+    G.qb = ldsq; G.q = ldsq; G.e = e; G.g = 0; G.QR = 0; G.ver = nullptr; G.multi = false;
     CBank K;
     K.id = (int) (w & 511u); K.a = (int) ((w >> 9) & 63u) - 1; K.b = (int) ((w >> 15) & 63u); K.round = r;
     f32x4 *rec = reinterpret_cast<f32x4 *>(crec_lane + ((size_t) (K.id * EVM_CR_STRIDE) << 6));
@@ -229,12 +229,12 @@ __device__ __attribute__((noinline)) float g_slow_visit(int phase, unsigned w, i
 //   prog [2 banks][16 slots][16 envs] words (pre-filled with ~0), meta[0] = rounds used (max over envs), meta[1] = 1 if some
 //   env uses the second bank, meta[2] = 1 if some env has a point for the split-impulse recovery
 // nn: this env's floor manifold counts; returns the number of manifolds that did not fit (> 32 live manifolds or > 31 rounds)
-DEV int g_build_program(const Ctx &c, const GCtx &G, int nw, const int (&nn)[EVM_MAX_MEMBERS], unsigned *prog, int *meta) {
+#define EVM_PACT_WORDS ((EVM_MAX_PAIRS + 31) / 32)
+// (the caller reads the env's activity words pw, the flag word and the floor manifold counts nn early, so that their latency
+// hides behind the record image's copy)
+DEV int g_build_program(const GCtx &G, int nslots, const int (&nn)[EVM_MAX_MEMBERS], const unsigned (&pw)[EVM_PACT_WORDS], unsigned flags,
+                        unsigned *prog, int *meta) {
     const int nm = c_skel.nm, np = c_skel.npair, nwords = (np + 31) >> 5;
-    unsigned pw[(EVM_MAX_PAIRS + 31) / 32];
-#pragma unroll
-    for (int k = 0; k < (EVM_MAX_PAIRS + 31) / 32; k++) pw[k] = k < nwords ? c.t.pact[(k << 6) + c.lane] : 0u;
-    const unsigned flags = c.t.pact[(nwords << 6) + c.lane];
     unsigned nf[4] = {0u, 0u, 0u, 0u};  // next free round per member: 5 bits each, 6 members per word
     int ord = 0, rmax = 0;
     int left_out = 0;
@@ -251,16 +251,17 @@ DEV int g_build_program(const Ctx &c, const GCtx &G, int nw, const int (&nn)[EVM
             else if (wi == 2) nf[2] = (nf[2] & msk) | val; else nf[3] = (nf[3] & msk) | val;
         };
         const int r = max(a >= 0 ? getnf(a) : 0, getnf(b));
-        if (r > 30 || ord >= 32) { left_out++; return; }
-        const int k = ord & 15, slot = (k % nw) * 4 + k / nw;
-        prog[(((ord >> 4) * 16 + slot) << 4) + G.e] = g_prog_word(id, a, b, r);
+        if (r > 30 || ord >= 2 * nslots) { left_out++; return; }
+        const int bank = ord >= nslots ? 1 : 0, slot = ord - bank * nslots;
+        prog[((bank * 16 + slot) << 4) + G.e] = g_prog_word(id, a, b, r);
         if (a >= 0) setnf(a, r + 1);
         setnf(b, r + 1);
         rmax = max(rmax, r + 1);
         ord++;
     };
-    for (int m = 0; m < nm; m++) {
-        const bool act = nn[m] > 0;
+#pragma unroll
+    for (int m = 0; m < EVM_MAX_MEMBERS; m++) {  // (unrolled: nn stays in registers)
+        const bool act = m < nm && nn[m] > 0;
         if (!__any(act)) continue;
         if (act) place(m, -1, m);
     }
@@ -284,7 +285,7 @@ DEV int g_build_program(const Ctx &c, const GCtx &G, int nw, const int (&nn)[EVM
     }
     // workgroup-wide facts
     if (rmax > 0) atomicMax(&meta[0], rmax);
-    if (ord > 16) atomicMax(&meta[1], 1);
+    if (ord > nslots) atomicMax(&meta[1], 1);
     if (flags & 1u) atomicMax(&meta[2], 1);
     return left_out;
 }

@@ -2037,8 +2037,11 @@ __global__ __launch_bounds__(64 * EVM_SPLIT_WAVES) __attribute__((amdgpu_waves_p
 //                                block, pairs in decreasing cost order
 // One launch for both, so that the few long big-hull wavefronts and the many short ones share the chip.
 #define EVM_BIG_BLOCKS 2048
+#ifndef EVM_PAIRS_WAVES
+#define EVM_PAIRS_WAVES 2   // wavefronts per SIMD the narrowphase kernel is compiled for (128 arch VGPRs + AGPR spill space at 2)
+#endif
 template <int MODE>
-__global__ __launch_bounds__(64) void k_split_pairs(EnvDev d, const uint8_t *__restrict__ mask, int tiles) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EVM_PAIRS_WAVES, EVM_PAIRS_WAVES))) void k_split_pairs(EnvDev d, const uint8_t *__restrict__ mask, int tiles) {
     (void) mask;  // (masked-out envs never enter a list)
     if ((int) blockIdx.x < EVM_BIG_BLOCKS) {
         const int cnt = d.pcount[c_skel.npair];

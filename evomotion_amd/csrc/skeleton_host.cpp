@@ -1243,14 +1243,15 @@ int build_group_schedule(const EvmSkelC &S, int nwaves, EvmGSchedC &G, std::stri
     }
     // LDS image: per env (3 quads per body + the joint records), then the slot table (2 quads per slot) and the entry
     // headers (1 quad each), the version counters and the per-env residuals
-    const size_t quads = (size_t) (3 * S.nb + G.nrq) * EVM_G_ENVS + (size_t) ne * (2 * EVM_G_SLOTS + 1);
+    const size_t quads = (size_t) (3 * S.nb + G.nrq) * EVM_G_ENVS + (size_t) 3 * S.nb /* one pad quad per body row */ + (size_t) ne * (2 * EVM_G_SLOTS + 1);
     size_t bytes = quads * 16 + (size_t) ((S.nb + 3) / 4 * 4) * 4 + EVM_G_ENVS * 4;
     G.with_contacts = with_contacts ? 1 : 0;
     if (!with_contacts) {
-        // behind the image: the contact program (2 banks x 16 slots x 16 envs words), four workgroup-wide words, the bodies'
+        // behind the image: the contact program (2 banks x 16 slots x 16 envs words), four words per wave, the bodies'
         // inverse masses and the members' push / turn velocities of the split-impulse phase
         bytes = (bytes + 15) & ~(size_t) 15;
-        bytes += (size_t) 2 * 16 * EVM_G_ENVS * 4 + 16 + (size_t) ((S.nb + 3) & ~3) * 4 + (size_t) 6 * S.nm * EVM_G_ENVS * 4;
+        bytes += (size_t) 2 * 16 * EVM_G_ENVS * 4 + 64 + (size_t) ((S.nb + 3) & ~3) * 4 + (size_t) 6 * S.nm * EVM_G_ENVS * 4;
+        if (nwaves == 3) { err = "member-vs-member contacts: the lane-group sweeps kernel takes 1, 2 or 4 waves per workgroup"; return EVM_E_UNSUPPORTED; }
     }
     G.lds_bytes = (int) bytes;
     if (bytes > 160 * 1024) { err = "skeleton records exceed the LDS image of the lane-group sweeps"; return EVM_E_UNSUPPORTED; }

@@ -20,7 +20,10 @@
 namespace evm {
 
 struct GCtx {
-    f32x4 *q;    // LDS image: quad qi of this lane's env = q[(qi << 4) + e]
+    f32x4 *q;    // LDS image, joint records: quad row qi of this lane's env = q[(qi << 4) + e]
+    f32x4 *qb;   // LDS image, bodies (3 quad rows per body): row qi = qb[qi * 17 + e].  The one-quad pad per row shifts the banks
+                 // by four words per row: the joint rows (16 lanes = 16 envs, one row) and the contact rounds (16 lanes = a few envs,
+                 // different bodies) are both conflict-free on ds_read_b128
     int e, g;    // env within the quarter tile, lane group
     int QR;      // first quad of the joint-record image
     int *ver;    // per-body version counters
@@ -30,6 +33,7 @@ struct GCtx {
 #endif
 };
 #define GQ(G, qi) ((G).q[((qi) << 4) + (G).e])
+#define GB(G, qi) ((G).qb[(qi) * 17 + (G).e])
 
 #ifdef EVM_GSTAMPS2
 __device__ unsigned long long g_wait_cycles_dummy;
@@ -62,8 +66,8 @@ DEV void g_publish(const GCtx &G, int a, int va, int b, int vb) {
 }
 
 DEV BodyPD g_load_pair(const GCtx &G, int a, int b, float imA, float imB) {
-    const f32x4 a0 = GQ(G, 3 * a), a1 = GQ(G, 3 * a + 1), a2 = GQ(G, 3 * a + 2);
-    const f32x4 b0 = GQ(G, 3 * b), b1 = GQ(G, 3 * b + 1), b2 = GQ(G, 3 * b + 2);
+    const f32x4 a0 = GB(G, 3 * a), a1 = GB(G, 3 * a + 1), a2 = GB(G, 3 * a + 2);
+    const f32x4 b0 = GB(G, 3 * b), b1 = GB(G, 3 * b + 1), b2 = GB(G, 3 * b + 2);
     BodyPD k;
     k.dl = f3p(p2(a0[0], b0[0]), p2(a0[1], b0[1]), p2(a0[2], b0[2]));
     k.da = f3p(p2(a0[3], b0[3]), p2(a1[0], b1[0]), p2(a1[1], b1[1]));
@@ -74,13 +78,13 @@ DEV BodyPD g_load_pair(const GCtx &G, int a, int b, float imA, float imB) {
 }
 DEV void g_store_pair(const GCtx &G, int a, int b, const BodyPD &Q) {
     f32x4 x;
-    x[0] = Q.dl.x.x; x[1] = Q.dl.y.x; x[2] = Q.dl.z.x; x[3] = Q.da.x.x; GQ(G, 3 * a) = x;
-    x[0] = Q.da.y.x; x[1] = Q.da.z.x; x[2] = Q.I.xx.x; x[3] = Q.I.xy.x; GQ(G, 3 * a + 1) = x;
-    x[0] = Q.dl.x.y; x[1] = Q.dl.y.y; x[2] = Q.dl.z.y; x[3] = Q.da.x.y; GQ(G, 3 * b) = x;
-    x[0] = Q.da.y.y; x[1] = Q.da.z.y; x[2] = Q.I.xx.y; x[3] = Q.I.xy.y; GQ(G, 3 * b + 1) = x;
+    x[0] = Q.dl.x.x; x[1] = Q.dl.y.x; x[2] = Q.dl.z.x; x[3] = Q.da.x.x; GB(G, 3 * a) = x;
+    x[0] = Q.da.y.x; x[1] = Q.da.z.x; x[2] = Q.I.xx.x; x[3] = Q.I.xy.x; GB(G, 3 * a + 1) = x;
+    x[0] = Q.dl.x.y; x[1] = Q.dl.y.y; x[2] = Q.dl.z.y; x[3] = Q.da.x.y; GB(G, 3 * b) = x;
+    x[0] = Q.da.y.y; x[1] = Q.da.z.y; x[2] = Q.I.xx.y; x[3] = Q.I.xy.y; GB(G, 3 * b + 1) = x;
 }
 DEV BodyD g_load_body(const GCtx &G, int b, float im) {
-    const f32x4 b0 = GQ(G, 3 * b), b1 = GQ(G, 3 * b + 1), b2 = GQ(G, 3 * b + 2);
+    const f32x4 b0 = GB(G, 3 * b), b1 = GB(G, 3 * b + 1), b2 = GB(G, 3 * b + 2);
     BodyD k;
     k.dl = f3(b0[0], b0[1], b0[2]);
     k.da = f3(b0[3], b1[0], b1[1]);
@@ -90,8 +94,8 @@ DEV BodyD g_load_body(const GCtx &G, int b, float im) {
 }
 DEV void g_store_body(const GCtx &G, int b, const BodyD &k) {
     f32x4 x;
-    x[0] = k.dl.x; x[1] = k.dl.y; x[2] = k.dl.z; x[3] = k.da.x; GQ(G, 3 * b) = x;
-    x[0] = k.da.y; x[1] = k.da.z; x[2] = k.I.xx; x[3] = k.I.xy; GQ(G, 3 * b + 1) = x;
+    x[0] = k.dl.x; x[1] = k.dl.y; x[2] = k.dl.z; x[3] = k.da.x; GB(G, 3 * b) = x;
+    x[0] = k.da.y; x[1] = k.da.z; x[2] = k.I.xx; x[3] = k.I.xy; GB(G, 3 * b + 1) = x;
 }
 
 DEV void g_store_applied6(const GCtx &G, int quad, const float (&ap)[6], float t2, float t3) {
@@ -146,13 +150,13 @@ DEV float g_p2p(const GCtx &G, int rec, int a, int b, float imA, float imB) {
 #pragma unroll
     for (int i = 0; i < 4; i++) kk.q[i] = p[i << 4];
     BodyD A = g_load_body(G, a, imA);
-    const f32x4 s0 = GQ(G, 3 * b);
+    const f32x4 s0 = GB(G, 3 * b);
     F3 dlS = f3(s0[0], s0[1], s0[2]);
     float ap0, ap1, ap2;
     const float res = p2p_rows(kk, A, dlS, imB, ap0, ap1, ap2);
     g_store_body(G, a, A);
     f32x4 x;
-    x[0] = dlS.x; x[1] = dlS.y; x[2] = dlS.z; x[3] = s0[3]; GQ(G, 3 * b) = x;
+    x[0] = dlS.x; x[1] = dlS.y; x[2] = dlS.z; x[3] = s0[3]; GB(G, 3 * b) = x;
     x[0] = ap0; x[1] = ap1; x[2] = ap2; x[3] = 0.f; GQ(G, G.QR + rec + 3) = x;
     return res;
 }
@@ -181,12 +185,12 @@ DEV float g_hinge_chain(const GCtx &G, int rec, int a, int b, float imA, float i
     }
     if (rec >= 0) {
         f32x4 x;  // the second body and the impulses of this group's visit; the shared body once (group 0 holds the final values too)
-        x[0] = Q.dl.x.y; x[1] = Q.dl.y.y; x[2] = Q.dl.z.y; x[3] = Q.da.x.y; GQ(G, 3 * b) = x;
-        x[0] = Q.da.y.y; x[1] = Q.da.z.y; x[2] = Q.I.xx.y; x[3] = Q.I.xy.y; GQ(G, 3 * b + 1) = x;
+        x[0] = Q.dl.x.y; x[1] = Q.dl.y.y; x[2] = Q.dl.z.y; x[3] = Q.da.x.y; GB(G, 3 * b) = x;
+        x[0] = Q.da.y.y; x[1] = Q.da.z.y; x[2] = Q.I.xx.y; x[3] = Q.I.xy.y; GB(G, 3 * b + 1) = x;
         g_store_applied6(G, G.QR + rec + 7, ap, KV(k, 34), KV(k, 35));
         if (G.g == 0) {
-            x[0] = Q.dl.x.x; x[1] = Q.dl.y.x; x[2] = Q.dl.z.x; x[3] = Q.da.x.x; GQ(G, 3 * a) = x;
-            x[0] = Q.da.y.x; x[1] = Q.da.z.x; x[2] = Q.I.xx.x; x[3] = Q.I.xy.x; GQ(G, 3 * a + 1) = x;
+            x[0] = Q.dl.x.x; x[1] = Q.dl.y.x; x[2] = Q.dl.z.x; x[3] = Q.da.x.x; GB(G, 3 * a) = x;
+            x[0] = Q.da.y.x; x[1] = Q.da.z.x; x[2] = Q.I.xx.x; x[3] = Q.I.xy.x; GB(G, 3 * a + 1) = x;
         }
     }
     return res;
@@ -201,7 +205,7 @@ DEV float g_p2p_chain(const GCtx &G, int rec, int a, int b, float imA, float imB
 #pragma unroll
         for (int i = 0; i < 4; i++) kk.q[i] = p[i << 4];
         A = g_load_body(G, a, imA);
-        s0 = GQ(G, 3 * b);
+        s0 = GB(G, 3 * b);
     }
     F3 dlS = f3(s0[0], s0[1], s0[2]);
     float ap0 = 0.f, ap1 = 0.f, ap2 = 0.f;
@@ -214,7 +218,7 @@ DEV float g_p2p_chain(const GCtx &G, int rec, int a, int b, float imA, float imB
     }
     if (rec >= 0) {
         f32x4 x;
-        x[0] = dlS.x; x[1] = dlS.y; x[2] = dlS.z; x[3] = s0[3]; GQ(G, 3 * b) = x;
+        x[0] = dlS.x; x[1] = dlS.y; x[2] = dlS.z; x[3] = s0[3]; GB(G, 3 * b) = x;
         x[0] = ap0; x[1] = ap1; x[2] = ap2; x[3] = 0.f; GQ(G, G.QR + rec + 3) = x;
         if (G.g == 0) g_store_body(G, a, A);
     }
@@ -266,7 +270,8 @@ __global__ __launch_bounds__(64 * EVM_G_MAX_WAVES) void k_sweeps_g(EnvDev d, con
     if ((tiles & 7) == 0) { const int x = blockIdx.x & 7, y = blockIdx.x >> 3; tile64 = x + 8 * (y >> 2); sub = y & 3; }
     else { tile64 = blockIdx.x >> 2; sub = blockIdx.x & 3; }
     GCtx G;
-    G.q = reinterpret_cast<f32x4 *>(lds_dyn);
+    G.qb = reinterpret_cast<f32x4 *>(lds_dyn);
+    G.q = G.qb + 3 * c_skel.nb;  // record row r (r >= QR = 3 nb) at qb[3 nb * 17 + (r - QR) * 16 + e] = q[(r << 4) + e]
     G.e = lane & (EVM_G_ENVS - 1);
     G.g = lane >> 4;
     G.multi = nw > 1;  // (cleared by a wait that times out)
@@ -292,8 +297,8 @@ __global__ __launch_bounds__(64 * EVM_G_MAX_WAVES) void k_sweeps_g(EnvDev d, con
             unsigned *prog0 = reinterpret_cast<unsigned *>(resmax + EVM_G_ENVS);
             for (int i = threadIdx.x; i < 2 * 16 * EVM_G_ENVS; i += blockDim.x) prog0[i] = 0xffffffffu;
             int *meta0 = reinterpret_cast<int *>(prog0 + 2 * 16 * EVM_G_ENVS);
-            if (threadIdx.x < 4) meta0[threadIdx.x] = 0;
-            float *imt0 = reinterpret_cast<float *>(meta0 + 4);
+            if (threadIdx.x < 16) meta0[threadIdx.x] = 0;
+            float *imt0 = reinterpret_cast<float *>(meta0 + 16);
             for (int i = threadIdx.x; i < nb; i += blockDim.x) imt0[i] = c_skel.body[i].inv_mass;
         }
     }
@@ -305,16 +310,48 @@ __global__ __launch_bounds__(64 * EVM_G_MAX_WAVES) void k_sweeps_g(EnvDev d, con
     unsigned gs_n[5] = {0, 0, 0, 0, 0};
 #endif
     Ctx c = make_ctx_at(d, nullptr, tile64, sub * EVM_G_ENVS + G.e, wave);
-    // lanes outside the batch / the mask drop out; every wave of the workgroup owns the same 16 envs, so either every wave
-    // keeps a live lane (and meets the others at the barriers) or the whole workgroup leaves here
-    if (c.env >= d.n_real) return;
-    if (mask && !mask[c.env]) return;
+    // Lanes outside the batch / the mask.  Floor-contacts mode: they drop out; every wave of the workgroup owns the same 16
+    // envs, so either every wave keeps a live lane (and meets the others at the barriers) or the whole workgroup leaves here.
+    // Member-vs-member mode regroups the lanes by env for the contact phases (below), so there every lane stays: a dead
+    // lane computes on whatever its (allocated, initialised) env slot holds and writes nothing but LDS columns of dead envs;
+    // all global stores are guarded by `live` / `clive`.
+    const bool scm = gs->with_contacts == 0;  // (wave-uniform)
+    const bool live = c.env < d.n_real && (!mask || mask[c.env]);
+    if (!__any(live)) return;   // (the same decision in every wave of the workgroup)
+    if (!scm && !live) return;
 #ifdef EVM_GSTAMPS
     const unsigned long long gs_ta = __builtin_amdgcn_s_memtime();
 #endif
     const int flags_in = d.flags[c.env];
-    const bool fin = autoreset && (flags_in & EVM_FLAG_DONE) != 0;  // a reset starts with this step (see LaneState)
-    const bool any_pending = __any((flags_in & EVM_FLAG_PENDING) != 0 || fin);
+    const bool fin = live && autoreset && (flags_in & EVM_FLAG_DONE) != 0;  // a reset starts with this step (see LaneState)
+    const bool any_pending = __any(live && ((flags_in & EVM_FLAG_PENDING) != 0 || fin));
+    // (member-vs-member mode) the contact phases' lane -> (env, slot) map and the env's manifold bookkeeping, requested now so
+    // that the loads fly while the record image is copied
+    CBank K0;
+    K0.id = -1; K0.round = -1;
+    int nrounds = 0;
+    unsigned *prog = reinterpret_cast<unsigned *>(resmax + EVM_G_ENVS);  // [2 banks][16 slots][16 envs]
+    int *meta = reinterpret_cast<int *>(prog + 2 * 16 * EVM_G_ENVS);      // per wave: rounds, second bank in use, split impulse needed, -
+    float *imt = reinterpret_cast<float *>(meta + 16);                    // inverse mass per body
+    unsigned w1 = 0xffffffffu;  // this slot's manifold of the overflow bank (served from global memory)
+    bool use_b1 = false;
+    const int epw = EVM_G_ENVS / nw, nslots = 64 / epw;
+    const int ce = wave * epw + lane % epw, cs = lane / epw;
+    GCtx GC = G;
+    GC.e = ce;
+    const Ctx cc = make_ctx_at(d, nullptr, tile64, sub * EVM_G_ENVS + ce, wave);
+    const bool clive = cc.env < d.n_real && (!mask || mask[cc.env]);
+    int nn_c[EVM_MAX_MEMBERS];
+    unsigned pw_c[EVM_PACT_WORDS];
+    unsigned pflags_c = 0u;
+    if (scm) {
+        const int nwords_c = (c_skel.npair + 31) >> 5;
+#pragma unroll
+        for (int m = 0; m < EVM_MAX_MEMBERS; m++) nn_c[m] = m < nm ? cc.t.mfn[(m << 6) + cc.lane] : 0;
+#pragma unroll
+        for (int k = 0; k < EVM_PACT_WORDS; k++) pw_c[k] = k < nwords_c ? cc.t.pact[(k << 6) + cc.lane] : 0u;
+        pflags_c = cc.t.pact[(nwords_c << 6) + cc.lane];
+    }
     // ---- joint-record image: global scratch [quad][64 lanes] -> LDS [quad][16 lanes], by LDS-DMA (global_load_lds_dwordx4:
     // no register round trip, so every request of the wave is in flight at once).  One instruction moves four consecutive
     // quads: lane (g, e) fetches quad ib + g of its env, and the hardware writes lane l's 16 bytes at base + 16 l — which is
@@ -357,9 +394,9 @@ __global__ __launch_bounds__(64 * EVM_G_MAX_WAVES) void k_sweeps_g(EnvDev d, con
         };
         auto body_put = [&](int b, const float (&v)[12]) {
             f32x4 x;
-            x[0] = v[0]; x[1] = v[1]; x[2] = v[2]; x[3] = v[3]; GQ(G, 3 * b) = x;
-            x[0] = v[4]; x[1] = v[5]; x[2] = v[6]; x[3] = v[7]; GQ(G, 3 * b + 1) = x;
-            x[0] = v[8]; x[1] = v[9]; x[2] = v[10]; x[3] = v[11]; GQ(G, 3 * b + 2) = x;
+            x[0] = v[0]; x[1] = v[1]; x[2] = v[2]; x[3] = v[3]; GB(G, 3 * b) = x;
+            x[0] = v[4]; x[1] = v[5]; x[2] = v[6]; x[3] = v[7]; GB(G, 3 * b + 1) = x;
+            x[0] = v[8]; x[1] = v[9]; x[2] = v[10]; x[3] = v[11]; GB(G, 3 * b + 2) = x;
         };
         int b = wave * EVM_G_SLOTS + G.g;
         for (; b + 2 * step < nb; b += 3 * step) {  // three bodies' reads in flight per lane
@@ -392,36 +429,31 @@ __global__ __launch_bounds__(64 * EVM_G_MAX_WAVES) void k_sweeps_g(EnvDev d, con
     __syncthreads();
 
     // ---- member-vs-member mode: contact program, the owners' records into registers, split-impulse recovery, warm start ----
-    const bool scm = gs->with_contacts == 0;  // (wave-uniform)
-    CBank K0;
-    K0.id = -1; K0.round = -1;
-    int nrounds = 0;
-    unsigned *prog = reinterpret_cast<unsigned *>(resmax + EVM_G_ENVS);  // [2 banks][16 slots][16 envs]
-    int *meta = reinterpret_cast<int *>(prog + 2 * 16 * EVM_G_ENVS);      // rounds, second bank in use, split impulse needed, -
-    float *imt = reinterpret_cast<float *>(meta + 4);                     // inverse mass per body
-    unsigned w1 = 0xffffffffu;  // this slot's manifold of the overflow bank (served from global memory)
-    bool use_b1 = false;
-    float *const crec_lane = c.t.crec ? c.t.crec + 4 * c.lane : nullptr;
+    // For the contact phases the lanes of a wave regroup: wave w serves the envs [w epw, (w + 1) epw) of the workgroup (epw =
+    // 16 / waves), lane -> (env ce = w epw + lane % epw, slot cs = lane / epw).  All slots of an env sit in ONE wave, so the
+    // rounds of the contact rows need no workgroup barrier between them — only the switches between joint rows and contact
+    // rows do.  (LDS image: a row's 16 lanes now hit epw env columns, a 64 / (4 epw)... -way bank conflict on the b128 reads
+    // of the bodies; cheaper than a barrier per round.)
+    float *const crec_lane = cc.t.crec ? cc.t.crec + 4 * cc.lane : nullptr;
     float *ptl = imt + ((nb + 3) & ~3);  // [6 nm][16 envs] push / turn velocities of the members during the split-impulse phase
-    auto slow = [&](int phase, int r) -> float { return g_slow_visit(phase, w1, r, G.q, G.e, imt, crec_lane, ptl); };
+    auto slow = [&](int phase, int r) -> float { return g_slow_visit(phase, w1, r, G.qb, ce, imt, crec_lane, ptl); };
 #ifdef EVM_GSTAMPS
     unsigned long long gs_c0 = __builtin_amdgcn_s_memtime(), gs_c1 = gs_c0, gs_c2 = gs_c0, gs_c3 = gs_c0;
 #endif
-    if (scm) {  // (program, words and inverse masses were initialised by every thread before any lane left)
-        if (wave == 0) {
-            int nn[EVM_MAX_MEMBERS];
-#pragma unroll
-            for (int m = 0; m < EVM_MAX_MEMBERS; m++) nn[m] = m < nm ? GS(mfn, m) : 0;
-            const int left_out = g_build_program(c, G, nw, nn, prog, meta);
-            if (left_out > 0 && G.g == 0) { atomicMax(d.resid, 0x7f800000); atomicAdd(&d.errs[1], left_out); }  // sticky
+    if (scm) {  // (program, words and inverse masses were initialised by every thread before the barrier above)
+        {
+            // every lane of the wave walks the ids of its env (the slots of an env redundantly: same values, same stores)
+            const int left_out = g_build_program(GC, nslots, nn_c, pw_c, pflags_c, prog, meta + 4 * wave);
+            if (left_out > 0 && cs == 0 && clive) { atomicMax(d.resid, 0x7f800000); atomicAdd(&d.errs[1], left_out); }  // sticky
         }
-        g_lds_barrier();
-        nrounds = __builtin_amdgcn_readfirstlane(meta[0]);
-        use_b1 = __builtin_amdgcn_readfirstlane(meta[1]) != 0;
-        const int slot = wave * EVM_G_SLOTS + G.g;
-        g_bank_load(c, prog[(slot << 4) + G.e], K0);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        nrounds = __builtin_amdgcn_readfirstlane(meta[4 * wave]);
+        use_b1 = __builtin_amdgcn_readfirstlane(meta[4 * wave + 1]) != 0;
+        g_bank_load(cc, prog[(cs << 4) + ce], K0);
         if (use_b1) {
-            w1 = prog[((16 + slot) << 4) + G.e];
+            w1 = prog[((16 + cs) << 4) + ce];
             if (w1 != 0xffffffffu) {  // its split-impulse accumulators start at zero
                 reinterpret_cast<f32x4 *>(crec_lane + ((size_t) ((int) (w1 & 511u) * EVM_CR_STRIDE + 80) << 6))[0] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
@@ -429,32 +461,30 @@ __global__ __launch_bounds__(64 * EVM_G_MAX_WAVES) void k_sweeps_g(EnvDev d, con
 #ifdef EVM_GSTAMPS
         gs_c1 = __builtin_amdgcn_s_memtime();
 #endif
-        if (__builtin_amdgcn_readfirstlane(meta[2]) != 0) {
-            // solveGroupCacheFriendlySplitImpulseIterations: the same rounds on the push / turn velocities (sc_pt, zeroed by the
-            // setup kernel); ten iterations like the oracle (further ones would add exactly nothing once an iteration changes nothing)
+        if (__builtin_amdgcn_readfirstlane(meta[4 * wave + 2]) != 0) {
+            // solveGroupCacheFriendlySplitImpulseIterations: the same rounds on the push / turn velocities; ten iterations like
+            // the oracle (further ones would add exactly nothing once an iteration changes nothing)
             float pa0[4] = {0.f, 0.f, 0.f, 0.f};
-            const int slot16 = wave * EVM_G_SLOTS + G.g, nslots = nw * EVM_G_SLOTS;
-            for (int k = slot16; k < 6 * nm; k += nslots) ptl[(k << 4) + G.e] = 0.f;
-            g_lds_barrier();
+            for (int k = cs; k < 6 * nm; k += nslots) ptl[(k << 4) + ce] = 0.f;
             for (int it = 0; it < NUM_ITER; it++)
                 for (int r = 0; r < nrounds; r++) {
-                    g_split_bank(G, K0, K0.round == r, pa0, imt, ptl);
+                    g_split_bank(GC, K0, K0.round == r, pa0, imt, ptl);
                     if (use_b1) slow(3, r);
-                    g_lds_barrier();
                 }
-            for (int k = slot16; k < 6 * nm; k += nslots) SC(c_skel.sc_pt + k) = ptl[(k << 4) + G.e];  // for the integration kernel
+            if (clive)
+                for (int k = cs; k < 6 * nm; k += nslots) cc.t.scratch[((size_t) (c_skel.sc_pt + k) << 6) + cc.lane] = ptl[(k << 4) + ce];  // for the integration kernel
         }
 #ifdef EVM_GSTAMPS
         gs_c2 = __builtin_amdgcn_s_memtime();
 #endif
         for (int r = 0; r < nrounds; r++) {
-            g_contact_bank<0>(G, K0, K0.round == r, imt);
+            g_contact_bank<0>(GC, K0, K0.round == r, imt);
             if (use_b1) slow(0, r);
-            g_lds_barrier();
         }
 #ifdef EVM_GSTAMPS
         gs_c3 = __builtin_amdgcn_s_memtime();
 #endif
+        g_lds_barrier();  // the warm-started deltas of every env are in place before any wave's joint rows read them
     }
 
 #if defined(EVM_GSTAMPS) || defined(EVM_GSTAMPS2)
@@ -490,8 +520,9 @@ __global__ __launch_bounds__(64 * EVM_G_MAX_WAVES) void k_sweeps_g(EnvDev d, con
         }
         return r;
     };
+    float res_c = 0.f;  // contact rows of the last sweep: belongs to env ce (member-vs-member mode)
     for (int it = 0; it < NUM_ITER; it++) {
-        float rs = 0.f;
+        float rs = 0.f, rc = 0.f;
         int j0 = 0;
         while (j0 < count) {  // runs of joint entries and runs of contact entries, as the wave's list has them
             GDesc cur;
@@ -560,28 +591,36 @@ __global__ __launch_bounds__(64 * EVM_G_MAX_WAVES) void k_sweeps_g(EnvDev d, con
             j0 += run;
         }
         if (scm) {
-            // contact rows of this sweep: all normal rows, then all friction rows, each as rounds of body-disjoint manifolds
+            // contact rows of this sweep: all normal rows, then all friction rows, each as rounds of body-disjoint manifolds;
+            // a wave's rounds touch the LDS columns of its own envs only
 #ifdef EVM_GSTAMPS
             const unsigned long long gs_e0 = __builtin_amdgcn_s_memtime();
 #endif
-            g_lds_barrier();
+            g_lds_barrier();   // every joint row of this sweep is done
+#ifdef EVM_GSTAMPS
+            const unsigned long long gs_e1 = __builtin_amdgcn_s_memtime();
+#endif
             for (int r = 0; r < nrounds; r++) {
-                rs = fmaxf(rs, g_contact_bank<1>(G, K0, K0.round == r, imt));
-                if (use_b1) rs = fmaxf(rs, slow(1, r));
-                g_lds_barrier();
+                rc = fmaxf(rc, g_contact_bank<1>(GC, K0, K0.round == r, imt));
+                if (use_b1) rc = fmaxf(rc, slow(1, r));
             }
             for (int r = 0; r < nrounds; r++) {
-                rs = fmaxf(rs, g_contact_bank<2>(G, K0, K0.round == r, imt));
-                if (use_b1) rs = fmaxf(rs, slow(2, r));
-                g_lds_barrier();
+                rc = fmaxf(rc, g_contact_bank<2>(GC, K0, K0.round == r, imt));
+                if (use_b1) rc = fmaxf(rc, slow(2, r));
             }
+#ifdef EVM_GSTAMPS
+            if (gs_n[2] == 0) { gs_type[2] += __builtin_amdgcn_s_memtime() - gs_e1; }  // (slider slot of a wave without sliders: the rounds alone, no barrier)
+#endif
+            g_lds_barrier();   // ... and every contact row, before the next sweep's joint rows
+            if (it == NUM_ITER - 1) res_c = rc;
 #ifdef EVM_GSTAMPS
             gs_type[4] += __builtin_amdgcn_s_memtime() - gs_e0; gs_n[4] += 2 * nrounds;
 #endif
         }
         if (it == NUM_ITER - 1) res = rs;
     }
-    atomicMax(&resmax[G.e], __float_as_int(res));
+    if (live) atomicMax(&resmax[G.e], __float_as_int(res));
+    if (scm && clive) atomicMax(&resmax[ce], __float_as_int(res_c));
 #if defined(EVM_GSTAMPS) || defined(EVM_GSTAMPS2)
     const unsigned long long gs_t2 = __builtin_amdgcn_s_memtime();
 #endif
@@ -590,18 +629,18 @@ __global__ __launch_bounds__(64 * EVM_G_MAX_WAVES) void k_sweeps_g(EnvDev d, con
     // ---- final deltas -> staging copy (the integration kernel reads them) ----
     {
         float *gt = d.gtile + (size_t) tile64 * d.tile_floats + c.lane;
-        for (int b = wave * EVM_G_SLOTS + G.g; b < nb; b += EVM_G_SLOTS * nw) {
-            const f32x4 q0 = GQ(G, 3 * b), q1 = GQ(G, 3 * b + 1);
+        for (int b = wave * EVM_G_SLOTS + G.g; b < nb && live; b += EVM_G_SLOTS * nw) {
+            const f32x4 q0 = GB(G, 3 * b), q1 = GB(G, 3 * b + 1);
             gt[(b * 6 + 0) << 6] = q0[0]; gt[(b * 6 + 1) << 6] = q0[1]; gt[(b * 6 + 2) << 6] = q0[2];
             gt[(b * 6 + 3) << 6] = q0[3]; gt[(b * 6 + 4) << 6] = q1[0]; gt[(b * 6 + 5) << 6] = q1[1];
         }
     }
-    if (scm) {
-        g_bank_writeback(c, K0);
+    if (scm && clive) {
+        g_bank_writeback(cc, K0);
         if (use_b1 && w1 != 0xffffffffu) {
             CBank K1;
-            g_bank_load(c, w1, K1);
-            g_bank_writeback(c, K1);
+            g_bank_load(cc, w1, K1);
+            g_bank_writeback(cc, K1);
         }
     }
     // ---- contact impulses back into the manifolds (by the lane group that ran the member's contact rows) ----
@@ -612,7 +651,7 @@ __global__ __launch_bounds__(64 * EVM_G_MAX_WAVES) void k_sweeps_g(EnvDev d, con
         if (rec >= 0 && ((cmask >> m) & 1u)) contact_writeback(c, m, GS(mfn, m));
     }
     // ---- muscle readbacks: getAppliedImpulse() = impulse of the last row written back ----
-    for (int mi = wave * EVM_G_SLOTS + G.g; mi < c_skel.nmus; mi += EVM_G_SLOTS * nw) {
+    for (int mi = wave * EVM_G_SLOTS + G.g; mi < c_skel.nmus && live; mi += EVM_G_SLOTS * nw) {
         const int rs = G.QR + (c_skel.sc_s + EVM_S_STRIDE * mi - c_skel.sc_h) / 4;
         const f32x4 s6 = GQ(G, rs + 6), s9 = GQ(G, rs + 9), s10 = GQ(G, rs + 10);  // fields 24..27, 36..39, 40..43
         const float jd4 = s6[1], jd5 = s6[2], a3 = s9[3], a4 = s10[0], a5 = s10[1];
@@ -621,7 +660,7 @@ __global__ __launch_bounds__(64 * EVM_G_MAX_WAVES) void k_sweeps_g(EnvDev d, con
         SC(c_skel.sc_mobs + 4 * mi + 2) = GQ(G, rp + 3)[2];       // field 14 of p2p_a
         SC(c_skel.sc_mobs + 4 * mi + 3) = GQ(G, rp + 4 + 3)[2];   // field 14 of p2p_b
     }
-    if (wave == 0 && G.g == 0) {
+    if (wave == 0 && G.g == 0 && live) {
         {   // batch-level residual: max over the 16 envs in the wave, one atomic per workgroup
             if (lane == (int) __builtin_ctzll(__ballot(true))) {  // (envs that left the kernel keep a zero in resmax)
                 int r = 0;
@@ -644,7 +683,7 @@ __global__ __launch_bounds__(64 * EVM_G_MAX_WAVES) void k_sweeps_g(EnvDev d, con
         // the root's motion-state origin after this step, for every member's observation block
         const int b = c_skel.root;
         F3 o = G3(pos, 3 * b);
-        const f32x4 r0 = GQ(G, 3 * b);
+        const f32x4 r0 = GB(G, 3 * b);
         const F3 dl = f3(r0[0], r0[1], r0[2]);
         F3 lin = G3(lin, 3 * b) + dl;
         const F3 push = SC3(c_skel.sc_pt + 6 * b), turn = SC3(c_skel.sc_pt + 6 * b + 3);
