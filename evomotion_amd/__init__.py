@@ -5,7 +5,7 @@ Environment / Agent interfaces in env.py / agent.py.  The CPU oracle under /orac
 and is never imported from here."""
 from ._lib import DEFAULT_SKELETON, EvmError, LIB_PATH  # noqa: F401
 from .env import RolloutStep, Step, VecRobotJump, VecRobotWalk, get_environment  # noqa: F401
-from .agent import (ActorModule, CriticModule, FusedActorCritic, RandomAgent, VecPpoGaeAgent,  # noqa: F401,E402
+from .agent import (ActorModule, CriticModule, FusedActorCritic, PpoGaeAgent, RandomAgent, TrajectoryReplayBuffer, VecPpoGaeAgent,  # noqa: F401,E402
                     truncated_normal_log_pdf, truncated_normal_entropy, truncated_normal_sample)
 from .checkpoint import load_into, load_th, save_th  # noqa: F401,E402
 from .replay import ReplayRing  # noqa: F401,E402

@@ -391,3 +391,157 @@ class VecPpoGaeAgent:
                        self.learning_rate, hp["clip_grad_norm"])
         self._modules_stale = True
         return out
+
+
+# ---- the reference's Agent surface for PPO: act / done / check_train over whole episodes ------------------------------------
+class TrajectoryReplayBuffer:
+    """TrajectoryReplayBuffer (evo_motion_networks/src/replay_buffer.cpp:73-138,176-189): a FIFO of whole trajectories.
+
+      new_trajectory()   push an empty trajectory, evict from the front beyond `size` trajectories            (:105-110)
+      add / update_last  append a step to / rewrite (reward, done, next_value) of the newest trajectory's last step (:112-123,176-186)
+      enough_trajectory  at least batch_size trajectories of more than one step                               (:139-146)
+      sample             the trajectories of more than one step, ALL BUT THE LAST of them shuffled, the first batch_size
+                         taken — fewer when there are not that many                                             (:80-98)
+
+    A step is a dict(state, action, reward, done, log_prob, curr_value, next_value) of device tensors / Python scalars
+    (ppo_episode_step, replay_buffer.h:22-30).  The reference shuffles with its own std::mt19937(seed) + std::shuffle, whose
+    stream is libstdc++'s business; here `shuffle(index_list)` is a hook (default: a numpy Generator seeded with `seed`) —
+    the golden test plugs in the orders the reference's generator produced."""
+
+    def __init__(self, size, seed):
+        self.size, self.memory = int(size), []
+        self._rng = np.random.default_rng(seed)
+        self.shuffle = lambda index: [index[i] for i in self._rng.permutation(len(index))]
+
+    def empty(self):
+        return not self.memory
+
+    def trajectory_empty(self):
+        return self.empty() or not self.memory[-1]
+
+    def new_trajectory(self):
+        self.memory.append([])
+        while len(self.memory) > self.size:
+            self.memory.pop(0)
+        return self.memory[-1]
+
+    def add(self, step, trajectory=None):
+        (self.memory[-1] if trajectory is None else trajectory).append(step)
+
+    def update_last(self, reward, done, next_value, trajectory=None):
+        st = (self.memory[-1] if trajectory is None else trajectory)[-1]
+        st["reward"], st["done"], st["next_value"] = reward, done, next_value
+
+    def _filtered(self):
+        return [t for t in self.memory if len(t) > 1]
+
+    def enough_trajectory(self, batch_size):
+        return len(self._filtered()) >= batch_size
+
+    def sample(self, batch_size):
+        filtered = self._filtered()
+        index = self.shuffle(list(range(len(filtered) - 1)))
+        return [filtered[i] for i in index[:batch_size]]
+
+
+class PpoGaeAgent(VecPpoGaeAgent):
+    """PpoGaeAgent with the reference's Agent surface (evo_motion_networks/include/evo_motion_networks/agent.h:16-35,
+    src/agents/ppo_gae.cpp:29-115): act(state, reward) -> action, done(state, reward), whole episodes in a
+    TrajectoryReplayBuffer, a train() call every `train_every` finished EPISODES on `batch_size` trajectories padded to the
+    longest one (done = 1 in the padding, the shifted mask of ppo_gae.cpp:127-132).  The forward pass is the fused HIP kernel,
+    train() the HIP trainer behind evm_ppo_* (time-major [T][B] with the same mask) — this class is the bookkeeping around
+    them.  With n_envs > 1 every environment fills its own open trajectory of the ONE buffer (act / done take a batch and
+    an env index); n_envs = 1 is the reference call for call.  The fixed-horizon VecPpoGaeAgent.rollout()/update() stays
+    the fast path for thousands of environments.
+
+    `reward` of act() is the reward of the PREVIOUS transition (ppo_gae.cpp:38); done() gets the terminal state before the
+    environment is reset (src/train.cpp:64-65)."""
+
+    def __init__(self, seed, state_space, action_space, hidden_size=256, gamma=0.99, lam=0.95, epsilon=0.2, entropy_factor=0.01,
+                 critic_loss_factor=0.5, epoch=8, batch_size=32, train_every=8, replay_buffer_size=1024, learning_rate=1e-3,
+                 clip_grad_norm=0.5, device=0, n_envs=1):
+        super().__init__(seed, state_space, action_space, hidden_size, gamma, lam, epsilon, entropy_factor, critic_loss_factor, epoch,
+                         learning_rate, clip_grad_norm, device, horizon=1)
+        self.batch_size, self.train_every, self.n_envs = int(batch_size), int(train_every), int(n_envs)
+        self.replay_buffer = TrajectoryReplayBuffer(replay_buffer_size, seed)
+        self.curr_train_step = self.global_curr_step = 0
+        self.curr_episode_step = [0] * self.n_envs
+        self._open = [None] * self.n_envs      # the open trajectory of every env (a list inside replay_buffer.memory)
+        self._act_calls = 0
+        self.S, self.A = int(state_space[0]), int(action_space[0])
+        self.episode_steps = []
+
+    # -- Agent interface ---------------------------------------------------------------------------------------------------
+    def _forward(self, states, uniform=None):
+        obs = states.to(device=self.device, dtype=torch.float32).reshape(-1, self.S).contiguous()
+        if uniform is not None:
+            uniform = uniform.to(device=self.device, dtype=torch.float32).reshape(-1, self.A).contiguous()
+        self._act_calls += 1
+        return obs, self.fused.forward(obs, uniform=uniform, seed=(self.noise_seed + 7919 * self._act_calls) & 0x7FFFFFFF)
+
+    def act(self, state, reward, uniform=None):
+        """state [S] (one env, like the reference) or [n_envs, S]; reward a float or [n_envs].  uniform: the U[0,1) draws
+        of truncated_normal_sample (the reference's at::rand), else the kernel's counter-based generator."""
+        single = state.dim() == 1
+        obs, (action, logp, value) = self._forward(state, uniform)
+        rewards = [float(reward)] if single else [float(r) for r in torch.as_tensor(reward).reshape(-1).tolist()]
+        assert obs.shape[0] == self.n_envs == len(rewards)
+        for e in range(self.n_envs):
+            if self._open[e] is None:           # `if (replay_buffer.empty()) new_trajectory()` + the one done() opens
+                self._open[e] = self.replay_buffer.new_trajectory()
+            traj = self._open[e]
+            if traj:
+                self.replay_buffer.update_last(rewards[e], False, value[e].clone(), traj)
+            self.replay_buffer.add(dict(state=obs[e].clone(), action=action[e].clone(), reward=0.0, done=False, log_prob=logp[e].clone(),
+                                        curr_value=value[e].clone(), next_value=value[e].clone()), traj)
+            self.curr_episode_step[e] += 1
+        return action[0].clone() if single else action.clone()
+
+    def done(self, state, reward, env=0):
+        """the episode of environment `env` has ended in `state` (its terminal observation) with `reward`"""
+        obs, (_, _, value) = self._forward(state.reshape(1, -1), None)
+        traj = self._open[env]
+        self.replay_buffer.update_last(float(reward), True, value[0].clone(), traj)
+        self.check_train()
+        self._open[env] = self.replay_buffer.new_trajectory() if self.n_envs == 1 else None   # (n_envs > 1: opened by its next act())
+        self.global_curr_step += 1
+        self.episode_steps.append(self.curr_episode_step[env])
+        self.curr_episode_step[env] = 0
+
+    def check_train(self):
+        if not (self.global_curr_step % self.train_every == self.train_every - 1 and self.replay_buffer.enough_trajectory(self.batch_size)):
+            return None
+        episodes = self.replay_buffer.sample(self.batch_size)
+        B, T = len(episodes), max(len(t) for t in episodes)
+        z = lambda *s, **k: torch.zeros(*s, device=self.device, **k)
+        # time-major [T][B]; padding: zeros, done = 1 (ppo_gae.cpp:93-103)
+        states, actions, logp = z(T, B, self.S), z(T, B, self.A), z(T, B, self.A)
+        rewards, values, next_values = z(T, B), z(T, B), z(T, B)
+        done = torch.ones(T, B, device=self.device, dtype=torch.uint8)
+        for b, traj in enumerate(episodes):
+            L = len(traj)
+            states[:L, b] = torch.stack([s["state"] for s in traj])
+            actions[:L, b] = torch.stack([s["action"] for s in traj])
+            logp[:L, b] = torch.stack([s["log_prob"] for s in traj])
+            values[:L, b] = torch.stack([s["curr_value"].reshape(()) for s in traj])
+            next_values[:L, b] = torch.stack([s["next_value"].reshape(()) for s in traj])
+            rewards[:L, b] = torch.tensor([s["reward"] for s in traj], device=self.device)
+            done[:L, b] = torch.tensor([1 if s["done"] else 0 for s in traj], device=self.device, dtype=torch.uint8)
+        # mask[t] = 1 at t = 0, else 1 - done[t - 1] (ppo_gae.cpp:127-132)
+        mask = torch.cat([torch.ones(1, B, device=self.device, dtype=torch.uint8), 1 - done[:-1]], 0).contiguous()
+        tr = self._get_trainer(T * B)
+        hp = self.hp
+        out = tr.train(states, actions, rewards, done, logp, values, next_values, mask, hp["gamma"], hp["lam"], hp["epsilon"],
+                       hp["entropy_factor"], hp["critic_loss_factor"], hp["epoch"], self.learning_rate, hp["clip_grad_norm"])
+        self._modules_stale = True
+        self.curr_train_step += 1
+        return out
+
+    def get_metrics(self):
+        return {"steps": self.episode_steps[-64:]}
+
+    def to(self, device):
+        return self
+
+    def set_eval(self, eval_mode):
+        pass

@@ -154,3 +154,96 @@ def gae(rewards, done, curr_values, next_values, gamma, lam):
     sel = adv[mask]
     adv = ((adv - sel.mean(dtype=np.float32)) / (sel.std(ddof=1, dtype=np.float32) + F(1e-8))).astype(np.float32)
     return mask, adv, (adv + cv).astype(np.float32)
+
+
+# ---- PpoGaeAgent::act / done / check_train and TrajectoryReplayBuffer: the bookkeeping, restated ------------------------------
+class TrajectoryBufferOracle:
+    """AbstractTrajectoryBuffer / TrajectoryReplayBuffer (evo_motion_networks/src/replay_buffer.cpp:73-138,176-189):
+    `memory` is a list of trajectories (lists of step dicts); the newest is the one being filled."""
+
+    def __init__(self, size):
+        self.size, self.memory = size, []
+
+    def new_trajectory(self):                 # :105-110
+        self.memory.append([])
+        while len(self.memory) > self.size:
+            del self.memory[0]
+
+    def add(self, step):                      # :112-115
+        self.memory[-1].append(step)
+
+    def update_last(self, reward, done, next_value):   # :117-123 + update_last_step :176-186
+        last = dict(self.memory[-1][-1])
+        last.update(reward=reward, done=done, next_value=next_value)
+        self.memory[-1][-1] = last
+
+    def empty(self):
+        return len(self.memory) == 0
+
+    def trajectory_empty(self):
+        return self.empty() or len(self.memory[-1]) == 0
+
+    def filtered_positions(self):             # copy_if(trajectory.size() > 1)
+        return [i for i, t in enumerate(self.memory) if len(t) > 1]
+
+    def enough_trajectory(self, batch_size):  # :139-146
+        return len(self.filtered_positions()) >= batch_size
+
+    def sample(self, batch_size, shuffled_index):
+        """:80-98 — shuffled_index: what std::shuffle(rand_gen) made of iota(filtered.size() - 1) (the reference's generator
+        is libstdc++'s; the test supplies the recorded result)"""
+        filtered = self.filtered_positions()
+        assert sorted(shuffled_index) == list(range(len(filtered) - 1))
+        return [self.memory[filtered[i]] for i in shuffled_index[:batch_size]]
+
+
+class PpoLoopOracle:
+    """PpoGaeAgent::act / done / check_train (evo_motion_networks/src/agents/ppo_gae.cpp:29-115) around two callbacks:
+    forward(state, u) -> (action, log_prob, value) and train(batch dict of padded [B, T, ...] arrays)."""
+
+    def __init__(self, forward, train, batch_size, train_every, replay_buffer_size):
+        self.forward, self.train = forward, train
+        self.batch_size, self.train_every = batch_size, train_every
+        self.buffer = TrajectoryBufferOracle(replay_buffer_size)
+        self.global_curr_step = self.curr_train_step = self.curr_episode_step = 0
+
+    def act(self, state, reward, u):
+        action, log_prob, value = self.forward(state, u)
+        if self.buffer.empty():
+            self.buffer.new_trajectory()
+        if not self.buffer.trajectory_empty():
+            self.buffer.update_last(reward, False, value)
+        self.buffer.add(dict(state=state, action=action, reward=0.0, done=False, log_prob=log_prob, curr_value=value, next_value=value))
+        self.curr_episode_step += 1
+        return action
+
+    def done(self, state, reward, shuffled_index=None):
+        _, _, value = self.forward(state, None)
+        self.buffer.update_last(reward, True, value)
+        trained = self.check_train(shuffled_index)
+        self.buffer.new_trajectory()
+        self.global_curr_step += 1
+        self.curr_episode_step = 0
+        return trained
+
+    def will_train(self):
+        return self.global_curr_step % self.train_every == self.train_every - 1 and self.buffer.enough_trajectory(self.batch_size)
+
+    def check_train(self, shuffled_index):
+        if not self.will_train():
+            return False
+        episodes = self.buffer.sample(self.batch_size, shuffled_index)
+        T = max(len(t) for t in episodes)
+
+        def stack(key, width, pad_value=0.0):
+            out = np.full((len(episodes), T, width), pad_value, np.float32)
+            for b, traj in enumerate(episodes):
+                for t, st in enumerate(traj):
+                    out[b, t] = np.asarray(st[key], np.float32).reshape(-1) if key != "done" else (1.0 if st["done"] else 0.0)
+            return out
+        S, A = len(episodes[0][0]["state"]), len(episodes[0][0]["action"])
+        batch = dict(states=stack("state", S), actions=stack("action", A), rewards=stack("reward", 1), done=stack("done", 1, 1.0),
+                     log_prob=stack("log_prob", A), curr_values=stack("curr_value", 1), next_values=stack("next_value", 1))
+        self.train(batch)
+        self.curr_train_step += 1
+        return True

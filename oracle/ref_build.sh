@@ -29,4 +29,8 @@ if [ -f "$HERE/ref_sac.cpp" ]; then
   g++ $FLAGS "$HERE/ref_sac.cpp" -L"$OUT" -levo_motion_networks -L"$T/lib" -ltorch_cpu -lc10 \
       -Wl,-rpath,"$OUT" -Wl,-rpath,"$T/lib" -o "$OUT/ref_sac"
 fi
+if [ -f "$HERE/ref_loop.cpp" ]; then
+  g++ $FLAGS "$HERE/ref_loop.cpp" -L"$OUT" -levo_motion_networks -L"$T/lib" -ltorch_cpu -lc10 \
+      -Wl,-rpath,"$OUT" -Wl,-rpath,"$T/lib" -o "$OUT/ref_loop"
+fi
 echo "reference build ok: $OUT"
