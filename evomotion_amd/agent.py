@@ -286,10 +286,15 @@ class VecPpoGaeAgent:
         tr.set_modules(self.actor, self.critic, reset_optimizer=True)
         for net, mod, opt in ((0, self.actor, self.actor_opt), (1, self.critic, self.critic_opt)):
             ps = list(mod.parameters())
-            if all(p in opt.state and "exp_avg" in opt.state[p] for p in ps):
-                tr.load_vector(EXP_AVG, net, torch.cat([opt.state[p]["exp_avg"].reshape(-1) for p in ps]))
-                tr.load_vector(EXP_AVG_SQ, net, torch.cat([opt.state[p]["exp_avg_sq"].reshape(-1) for p in ps]))
-                tr.adam_step(net, int(float(opt.state[ps[0]]["step"])))
+            have = [p in opt.state and "exp_avg" in opt.state[p] for p in ps]
+            if any(have):
+                # per parameter: an archive (the reference's, or one written before a parameter took its first step) may hold
+                # state for some parameters only — those without get zero moments; the trainer has one step count per network,
+                # the largest of the archive's (torch keeps one per parameter, all equal after ordinary training)
+                zero = lambda p: torch.zeros(p.numel(), device=p.device)
+                tr.load_vector(EXP_AVG, net, torch.cat([opt.state[p]["exp_avg"].reshape(-1) if h else zero(p) for p, h in zip(ps, have)]))
+                tr.load_vector(EXP_AVG_SQ, net, torch.cat([opt.state[p]["exp_avg_sq"].reshape(-1) if h else zero(p) for p, h in zip(ps, have)]))
+                tr.adam_step(net, max(int(float(opt.state[p]["step"])) for p, h in zip(ps, have) if h))
 
     def sync_modules(self):
         """the trainer's weights and Adam state -> the torch modules / optimisers (save(), evaluation in torch)"""
@@ -338,6 +343,11 @@ class VecPpoGaeAgent:
         load_into(self.critic, os.path.join(input_folder_path, "critic.th"))
         for mod, opt, name in ((self.actor, self.actor_opt, "actor_optimizer.th"), (self.critic, self.critic_opt, "critic_optimizer.th")):
             states, options = load_adam_th(os.path.join(input_folder_path, name))
+            # the trainer's Adam is torch's default one (betas 0.9 / 0.999, eps 1e-8, no weight decay, no amsgrad — what the
+            # reference constructs, ppo_gae.cpp:22-25); an archive that says otherwise cannot be continued faithfully
+            if (tuple(round(b, 6) for b in options["betas"]) != (0.9, 0.999) or abs(options["eps"] - 1e-8) > 1e-12
+                    or options["weight_decay"] != 0.0 or options["amsgrad"]):
+                raise RuntimeError("%s: Adam options %r differ from the trainer's fixed defaults" % (name, options))
             ps = list(mod.parameters())
             if len(states) != len(ps):
                 raise RuntimeError("%s holds %d parameters, the module has %d" % (name, len(states), len(ps)))

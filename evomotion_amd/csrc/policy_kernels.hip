@@ -137,12 +137,20 @@ hipError_t launch_policy_pack(const NetDev &n, int S, int A, bool actor, const f
     return hipGetLastError();
 }
 
+// hipFuncSetAttribute is per DEVICE: a process that creates policies / trainers on a second device must set it there too
+static bool &evm_attr_done_for_current_device() {
+    static bool done[64] = {};
+    int dev = 0;
+    (void) hipGetDevice(&dev);
+    return done[dev >= 0 && dev < 64 ? dev : 0];
+}
+
 size_t policy_lds_bytes() { return (size_t) (POLICY_TILE_FLOATS + EVM_RED_FLOATS) * sizeof(float); }
 
 hipError_t launch_policy_forward(const PolicyDev &p, int n, const float *obs, const float *uniform, uint64_t seed,
                                  uint64_t counter, float *action, float *logp, float *value, float *mu, float *sigma,
                                  hipStream_t s) {
-    static bool attr = false;
+    bool &attr = evm_attr_done_for_current_device();
     if (!attr) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_policy_forward),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int) policy_lds_bytes());

@@ -716,8 +716,16 @@ hipError_t launch_ppo_pad(const PpoDev &d, size_t rows, const float *states, hip
     return hipGetLastError();
 }
 
+// hipFuncSetAttribute is per DEVICE: a process that creates policies / trainers on a second device must set it there too
+static bool &evm_attr_done_for_current_device() {
+    static bool done[64] = {};
+    int dev = 0;
+    (void) hipGetDevice(&dev);
+    return done[dev >= 0 && dev < 64 ? dev : 0];
+}
+
 hipError_t launch_ppo_forward(const PolicyDev &p, const PpoDev &d, size_t rows, const float *states, hipStream_t s, int nets) {
-    static bool attr = false;
+    bool &attr = evm_attr_done_for_current_device();
     if (!attr) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ppo_forward<PRT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int) fwd_lds_bytes());

@@ -426,8 +426,16 @@ static size_t q_bwd_lds() {
 }
 size_t q_wpart_floats() { return ppo_wpart_floats(); }
 
+// hipFuncSetAttribute is per DEVICE: a process that creates policies / trainers on a second device must set it there too
+static bool &evm_attr_done_for_current_device() {
+    static bool done[64] = {};
+    int dev = 0;
+    (void) hipGetDevice(&dev);
+    return done[dev >= 0 && dev < 64 ? dev : 0];
+}
+
 static hipError_t q_attrs() {
-    static bool done = false;
+    bool &done = evm_attr_done_for_current_device();
     if (done) return hipSuccess;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_q_forward<PRT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) q_fwd_lds());
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_q_backward<PRT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) q_bwd_lds());

@@ -202,15 +202,14 @@ class VecSacAgent:
             self._actor_tr.load_vector(PGRADS, ACTOR, all_reduce_mean(self._actor_tr.vector(PGRADS, ACTOR)))
         self._actor_tr.actor_apply(self.learning_rate)
         # entropy parameter (:155-164) and the loss values
-        if dist_on:  # the parameter's gradient is a mean over the global batch: autograd + the gradient hook
-            alpha = log_alpha.exp()
-            loss_actor = torch.mean(alpha * ab["logp"] - ab["qmin"])
-            loss_entropy = -torch.mean(self.entropy.log_alpha * (ab["logp"] + self.target_entropy))
-            self.entropy_opt.zero_grad()
-            loss_entropy.backward()
-            self.entropy.log_alpha.grad.copy_(all_reduce_mean(self.entropy.log_alpha.grad))
-            self.entropy_opt.step()
-            ab["losses"].copy_(torch.stack([loss_actor.detach(), loss_entropy.detach()]))
+        if dist_on:
+            # The entropy parameter's loss and gradient are means over the GLOBAL batch, and both are linear in the batch means of
+            # logp and qmin: all-reduce those two numbers and run the same device step on a one-row "batch" holding them.  One
+            # owner of the parameter's Adam state (the device one) in single-process and data-parallel runs alike, so
+            # optimizer_state() / save() / load() carry it either way.
+            m = all_reduce_mean(torch.stack([ab["logp"].mean(), ab["qmin"].mean()]))
+            sac_entropy_step(m[0:1].contiguous(), m[1:2].contiguous(), self.target_entropy, self.learning_rate, log_alpha, self._ent_state,
+                             self._ent_step, ab["losses"])
         else:
             sac_entropy_step(ab["logp"], ab["qmin"], self.target_entropy, self.learning_rate, log_alpha, self._ent_state, self._ent_step,
                              ab["losses"])
@@ -310,7 +309,8 @@ class VecSacAgent:
                      [None if e["step"] == 0 else (e["step"], e["state"][0:1].clone(), e["state"][1:2].clone())], self.learning_rate)
 
     def optimizer_state(self):
-        """Adam moments and step counts of the four optimisers, wherever they live (HIP trainers or torch.optim)"""
+        """Adam moments and step counts of the four optimisers (all four live in the HIP trainers, in single-process and
+        data-parallel runs alike)"""
         from .ppo import ACTOR, ACTOR_DEV_STEP, EXP_AVG, EXP_AVG_SQ
         tr, tq = self._actor_tr, self.twinq
         out = dict(kind="hip", train_steps=self.train_steps,
@@ -352,6 +352,8 @@ class VecSacAgent:
             states, options = load_adam_th(os.path.join(folder, f))
             step, m, v = adam_flat_from_states(mod, states)
             st[key] = dict(step=step, m=m, v=v)
+            if options["lr"] != self.learning_rate:
+                self._graph = None   # a captured update has the old learning rate baked into its kernel arguments
             self.learning_rate = options["lr"]
         states, _ = load_adam_th(os.path.join(folder, "entropy_optimizer.th"))
         e = states[0] if states else None

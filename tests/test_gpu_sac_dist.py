@@ -38,6 +38,21 @@ def _run(lo, hi):
     for _ in range(2):
         ag._train_once_hip(u_next=u_next[lo:hi].contiguous(), u_curr=u_curr[lo:hi].contiguous())
     vecs = [ag.twinq.vector(PARAMS, i) for i in range(4)] + [ag._actor_tr.vector(PP, ACTOR), ag.entropy.log_alpha.detach().reshape(-1)]
+    # the entropy parameter's Adam state has ONE owner (the device step) in single-process and data-parallel runs: two
+    # updates = two steps, non-zero moments, and a save() / load() round trip carries them (they used to be lost)
+    import tempfile
+    st = ag.optimizer_state()
+    assert st["entropy"]["step"] == 2 and float(st["entropy"]["state"].abs().min()) > 0.0, st["entropy"]
+    with tempfile.TemporaryDirectory() as d:
+        ag.save(d)
+        ag2 = VecSacAgent(32, [371], [12], batch_size=n, epoch=1, replay_buffer_size=4, train_every=2, n_envs=64, use_graph=False)
+        ag2.load(d)
+        st2 = ag2.optimizer_state()
+        assert st2["entropy"]["step"] == 2 and torch.allclose(st2["entropy"]["state"], st["entropy"]["state"], rtol=0, atol=0)
+        for dst, src in zip(ag2._batch, full):
+            dst.copy_(src[lo:hi])
+        ag2._train_once_hip(u_next=u_next[lo:hi].contiguous(), u_curr=u_curr[lo:hi].contiguous())
+        assert ag2.optimizer_state()["entropy"]["step"] == 3
     return torch.cat(vecs).cpu().numpy()
 
 
