@@ -92,6 +92,8 @@ def _load():
     lib.evm_ppo_set_params.argtypes = [vp, vp, vp, ctypes.c_int, vp]
     lib.evm_ppo_copy.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]
     lib.evm_ppo_adam_step.argtypes = [vp, ctypes.c_int, ctypes.c_int, ip]
+    lib.evm_ppo_grad_buffer.argtypes = [vp, vp, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]
+    lib.evm_ppo_gae_merge.argtypes = [vp, vp, ctypes.c_int, vp, vp]
     lib.evm_ppo_gae.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp, ctypes.c_float, ctypes.c_float, vp, vp, vp]
     lib.evm_ppo_gae_normalize.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp]
     lib.evm_ppo_grads.argtypes = [vp, ctypes.c_size_t, vp, vp, vp, vp, vp, vp, ctypes.c_double, ctypes.c_float, ctypes.c_float,

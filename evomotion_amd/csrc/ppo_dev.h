@@ -54,6 +54,7 @@ hipError_t launch_ppo_backward(const PolicyDev &p, const PpoDev &d, size_t rows,
 hipError_t launch_ppo_wgrads(const PpoDev &d, size_t rows, const float *states, hipStream_t s, int nets = 2);
 hipError_t launch_actor_apply(const PolicyDev &p, const PpoDev &d, float lr, hipStream_t s);
 hipError_t launch_ppo_apply(const PolicyDev &p, PpoDev &d, float lr, float clip_grad_norm, hipStream_t s);
+hipError_t launch_ppo_gae_merge(const PpoDev &d, const double *all, int world, hipStream_t s);
 hipError_t launch_ppo_gae_scan(const PpoDev &d, int T, int N, const float *rewards, const uint8_t *done, const float *curr_values,
                                const float *next_values, const uint8_t *mask, float gamma, float lam, float *adv, hipStream_t s);
 hipError_t launch_ppo_gae_finish(int T, int N, const double *stats, const float *curr_values, const uint8_t *mask, float *adv,

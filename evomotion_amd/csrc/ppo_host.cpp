@@ -20,6 +20,7 @@ struct EvmPpo {
     float ms_acc;
     int n_timed;
     size_t staged_rows;  // rows of the observation copy made by the last evm_ppo_grads
+    float *own_grads;    // the trainer's own contiguous [actor | critic] gradient vector (unless the caller supplied one)
 };
 
 static int qfail(int code, const std::string &m) { evm::set_last_error(m); return code; }
@@ -51,9 +52,12 @@ int evm_ppo_create(EvmPolicy *policy, size_t max_rows, EvmPpo **out) {
     size_t na, nc;
     evm_policy_param_counts(policy, &na, &nc);
     const size_t tiles = (max_rows + 31) / 32;
+    // both networks' gradients in ONE vector, actor first: a data-parallel caller reduces it with one collective
+    const size_t goff = (na + 63) / 64 * 64;  // the critic's part starts on a 256-byte boundary
+    q->own_grads = (float *) alloc((goff + nc) * 4);
     auto make = [&](evm::PpoNet &n, size_t np, size_t head_floats) {
         n.n_params = np; n.step = 0;
-        n.theta = (float *) alloc(np * 4); n.grad = (float *) alloc(np * 4);
+        n.theta = (float *) alloc(np * 4); n.grad = &n == &d.actor ? q->own_grads : (q->own_grads ? q->own_grads + goff : nullptr);
         n.m = (float *) alloc(np * 4); n.v = (float *) alloc(np * 4);
         n.w2d = (float *) alloc(65536 * 4);
         n.whd = (float *) alloc(8192 * 4);
@@ -130,6 +134,34 @@ int evm_ppo_copy(EvmPpo *q, int what, int net, int to_trainer, float *d_buf, voi
     return EVM_OK;
 }
 
+// The gradients of both networks as one contiguous DEVICE vector [actor | pad to 64 floats | critic]:
+// after evm_ppo_grads a data-parallel caller all-reduces it in place on the launch stream (one collective per epoch, no copy,
+// no host synchronisation) and calls evm_ppo_apply.  d_buf != NULL makes the trainer use the caller's buffer from now on.
+int evm_ppo_grad_buffer(EvmPpo *q, float *d_buf, float **d_grads, size_t *n_floats, size_t *critic_offset) {
+    if (!q) return qfail(EVM_E_INVALID, "trainer is null");
+    evm::PpoDev &d = q->dev;
+    const size_t goff = (d.actor.n_params + 63) / 64 * 64;
+    if (d_buf) {
+        if ((uintptr_t) d_buf % 256) return qfail(EVM_E_INVALID, "the gradient buffer must be 256-byte aligned");
+        d.actor.grad = d_buf; d.critic.grad = d_buf + goff;
+    }
+    if (d_grads) *d_grads = d.actor.grad;
+    if (n_floats) *n_floats = goff + d.critic.n_params;
+    if (critic_offset) *critic_offset = goff;
+    return EVM_OK;
+}
+
+// (count, mean, M2) of every rank's advantages -> the trainer's statistics, merged on the device in rank order; d_all_stats
+// [world][3] is what an all-gather of the d_stats of evm_ppo_gae delivers.  Afterwards evm_ppo_gae_normalize(d_stats = NULL)
+// and evm_ppo_grads(n_selected_global < 0) use the merged numbers: no host read anywhere in the update.
+int evm_ppo_gae_merge(EvmPpo *q, const double *d_all_stats, int world, double *d_stats, void *stream) {
+    if (!q || !d_all_stats || world < 1) return qfail(EVM_E_INVALID, "bad argument");
+    hipError_t e = evm::launch_ppo_gae_merge(q->dev, d_all_stats, world, (hipStream_t) stream);
+    if (e == hipSuccess && d_stats) e = hipMemcpyAsync(d_stats, q->dev.gae, 3 * sizeof(double), hipMemcpyDeviceToDevice, (hipStream_t) stream);
+    if (e != hipSuccess) return qfail(EVM_E_HIP, std::string("ppo gae merge: ") + hipGetErrorString(e));
+    return EVM_OK;
+}
+
 int evm_ppo_adam_step(EvmPpo *q, int net, int set_step, int *step) {
     if (!q || (net != 0 && net != 1 && net != 2)) return qfail(EVM_E_INVALID, "bad argument");
     if (net == 2) {  // the actor's device-side counter (evm_ppo_actor_apply: SAC's captured update)
@@ -176,7 +208,8 @@ int evm_ppo_grads(EvmPpo *q, size_t rows, const float *d_states, const float *d_
     if (!q || !d_states || !d_actions || !d_logp_old || !d_adv || !d_returns || !d_mask) return qfail(EVM_E_INVALID, "null argument");
     if (!q->have_params) return qfail(EVM_E_INVALID, "evm_ppo_set_params has not been called");
     if (rows < 1 || rows > q->dev.max_rows) return qfail(EVM_E_INVALID, "rows exceeds the trainer's capacity");
-    if (!(n_selected_global >= 1.0)) return qfail(EVM_E_INVALID, "no selected transition");
+    // n_selected_global < 0: the count is the trainer's own statistic on the device (evm_ppo_gae [+ evm_ppo_gae_merge])
+    if (!(n_selected_global >= 1.0) && !(n_selected_global < 0.0)) return qfail(EVM_E_INVALID, "no selected transition");
     hipStream_t s = (hipStream_t) stream;
     if (q->timing) (void) hipEventRecord(q->ev0, s);
     const evm::PolicyDev &p = q->policy->dev;
@@ -186,7 +219,7 @@ int evm_ppo_grads(EvmPpo *q, size_t rows, const float *d_states, const float *d_
         q->staged_rows = rows;
     }
     if (e == hipSuccess) e = evm::launch_ppo_forward(p, q->dev, rows, d_states, s);
-    if (e == hipSuccess) e = evm::launch_ppo_loss(q->dev, rows, d_actions, d_logp_old, d_adv, d_returns, d_mask, 1.0 / n_selected_global,
+    if (e == hipSuccess) e = evm::launch_ppo_loss(q->dev, rows, d_actions, d_logp_old, d_adv, d_returns, d_mask, n_selected_global < 0.0 ? -1.0 : 1.0 / n_selected_global,
                                                   epsilon, entropy_factor, critic_loss_factor, s);
     if (e == hipSuccess) e = evm::launch_ppo_backward(p, q->dev, rows, s);
     if (e == hipSuccess) e = evm::launch_ppo_wgrads(q->dev, rows, d_states, s);

@@ -97,6 +97,8 @@ __global__ __launch_bounds__(PT) void k_ppo_forward(PolicyDev p, PpoDev d, int n
 __global__ __launch_bounds__(256) void k_ppo_loss_actor(PpoDev d, int n, const float *__restrict__ actions,
                                                         const float *__restrict__ logp_old, const float *__restrict__ adv,
                                                         const uint8_t *__restrict__ mask, float inv_count, float eps, float ef) {
+    // inv_count < 0: the global count lives on the device (evm_ppo_gae, merged over the ranks); nothing selected -> zero gradients
+    if (inv_count < 0.f) inv_count = d.gae[0] >= 1.0 ? (float) ((1.0 / d.gae[0]) / (double) d.A) : 0.f;
     __shared__ float sh[4];
     const int A = d.A;
     const size_t e = (size_t) blockIdx.x * 256 + threadIdx.x;
@@ -183,6 +185,7 @@ hipError_t launch_actor_head_out(const PpoDev &d, size_t rows, float *mu, float 
 // critic_loss_factor * mean((value - returns)^2) over the selected rows (ppo_gae.cpp:176-179)
 __global__ __launch_bounds__(256) void k_ppo_loss_critic(PpoDev d, int n, const float *__restrict__ returns,
                                                          const uint8_t *__restrict__ mask, float inv_rows, float cf, int part_off) {
+    if (inv_rows < 0.f) inv_rows = d.gae[0] >= 1.0 ? (float) (1.0 / d.gae[0]) : 0.f;
     __shared__ float sh[4];
     const size_t row = (size_t) blockIdx.x * 256 + threadIdx.x;
     float lsum = 0.f;
@@ -771,7 +774,7 @@ __global__ __launch_bounds__(256) void k_ppo_loss_sum(PpoDev d, int na, int nc) 
 hipError_t launch_ppo_loss(const PpoDev &d, size_t rows, const float *actions, const float *logp_old, const float *adv,
                            const float *returns, const uint8_t *mask, double inv_rows, float epsilon, float entropy_factor,
                            float critic_loss_factor, hipStream_t s) {
-    const float inv_count = (float) (inv_rows / (double) d.A);
+    const float inv_count = inv_rows < 0.0 ? -1.f : (float) (inv_rows / (double) d.A);
     const unsigned na = (unsigned) ((rows * d.A + 255) / 256), nc = (unsigned) ((rows + 255) / 256);
     hipLaunchKernelGGL(k_ppo_loss_actor, dim3(na), dim3(256), 0, s, d, (int) rows, actions, logp_old, adv, mask, inv_count, epsilon,
                        entropy_factor);
@@ -870,6 +873,26 @@ hipError_t launch_ppo_apply(const PolicyDev &p, PpoDev &d, float lr, float clip_
     return hipGetLastError();
 }
 
+// (count, mean, M2) triples of `world` ranks -> the trainer's own statistics, Chan's pairwise merge in rank order (the same
+// order on every rank, so the replicas normalise with identical numbers); one thread
+__global__ __launch_bounds__(64) void k_ppo_gae_merge(const double *__restrict__ all, int world, double *__restrict__ stats) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double n = all[0], mean = all[1], m2 = all[2];
+    for (int r = 1; r < world; r++) {
+        const double nb = all[3 * r], mb = all[3 * r + 1], m2b = all[3 * r + 2];
+        const double tot = n + nb;
+        if (tot == 0.0) continue;
+        const double dlt = mb - mean;
+        mean = mean + dlt * nb / tot;
+        m2 = m2 + m2b + dlt * dlt * n * nb / tot;
+        n = tot;
+    }
+    stats[0] = n; stats[1] = mean; stats[2] = m2;
+}
+hipError_t launch_ppo_gae_merge(const PpoDev &d, const double *all, int world, hipStream_t s) {
+    hipLaunchKernelGGL(k_ppo_gae_merge, dim3(1), dim3(64), 0, s, all, world, d.gae);
+    return hipGetLastError();
+}
 hipError_t launch_ppo_gae_scan(const PpoDev &d, int T, int N, const float *rewards, const uint8_t *done, const float *curr_values,
                                const float *next_values, const uint8_t *mask, float gamma, float lam, float *adv, hipStream_t s) {
     const float gl = (float) ((double) gamma * (double) lam);

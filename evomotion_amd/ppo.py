@@ -26,6 +26,7 @@ def _via_host():
 
 
 def _all_reduce_sum(t):
+    """in place.  RCCL: enqueued on the current stream behind the kernels that produced t, nothing waits on the host"""
     if _via_host():
         h = t.cpu()
         torch.distributed.all_reduce(h)
@@ -34,12 +35,25 @@ def _all_reduce_sum(t):
         torch.distributed.all_reduce(t)
 
 
-def _all_gather(t):
-    w = torch.distributed.get_world_size()
-    src = t.cpu() if _via_host() else t
-    out = [torch.zeros_like(src) for _ in range(w)]
-    torch.distributed.all_gather(out, src)
-    return [o.to(t.device) for o in out]
+def _all_gather_into(out, t):
+    """out [world, ...] <- every rank's t, rank order"""
+    if _via_host():
+        h = torch.empty(out.numel(), dtype=out.dtype)
+        torch.distributed.all_gather_into_tensor(h, t.reshape(-1).cpu())
+        out.copy_(h.view(out.shape))
+    else:
+        torch.distributed.all_gather_into_tensor(out.view(-1), t.reshape(-1))
+
+
+class DeviceCount:
+    """The number of selected transitions over all ranks.  It stays on the device (evm_ppo_grads reads it there); float() is a
+    host read for tests and logs."""
+
+    def __init__(self, stats):
+        self._stats = stats
+
+    def __float__(self):
+        return float(self._stats[0])
 
 
 class FusedPpoTrainer:
@@ -56,6 +70,20 @@ class FusedPpoTrainer:
         check(lib.evm_policy_param_counts(fused._h, ctypes.byref(na), ctypes.byref(nc)))
         self.n_params = (na.value, nc.value)
         self._stats = torch.zeros(3, device=self.device, dtype=torch.float64)
+        self._all_stats = None
+        # actor and critic gradients are one vector: the data-parallel exchange is ONE in-place all-reduce per epoch
+        gp, gn, go = ctypes.c_void_p(), ctypes.c_size_t(), ctypes.c_size_t()
+        check(lib.evm_ppo_grad_buffer(self._h, None, ctypes.byref(gp), ctypes.byref(gn), ctypes.byref(go)))
+        self.grad_floats, self.critic_grad_offset = gn.value, go.value
+        self._grads = None
+
+    def grad_buffer(self):
+        """[grad_floats] device vector, actor gradients at 0, critic gradients at critic_grad_offset; owned by this object and
+        handed to the trainer (evm_ppo_grad_buffer) the first time it is asked for"""
+        if self._grads is None:
+            self._grads = torch.zeros(self.grad_floats, device=self.device)
+            check(lib.evm_ppo_grad_buffer(self._h, _ptr(self._grads), None, None, None))
+        return self._grads
 
     def close(self):
         if self._h:
@@ -116,25 +144,15 @@ class FusedPpoTrainer:
         s = self._stream()
         check(lib.evm_ppo_gae(self._h, T, N, _ptr(rewards), _ptr(done_u8), _ptr(values), _ptr(next_values), _ptr(mask_u8),
                               gamma, lam, _ptr(adv), _ptr(self._stats), s))
-        n_glob = None
         if _dist_ready():
-            allt = _all_gather(self._stats)
-            n, mean, m2 = allt[0]
-            for t in allt[1:]:  # Chan's merge, same order on every rank
-                nb, mb, m2b = t
-                tot = n + nb
-                if float(tot) == 0:
-                    continue
-                dlt = mb - mean
-                mean = mean + dlt * nb / tot
-                m2 = m2 + m2b + dlt * dlt * n * nb / tot
-                n = tot
-            self._stats.copy_(torch.stack([n, mean, m2]))
-            n_glob = float(n)
-        check(lib.evm_ppo_gae_normalize(self._h, T, N, _ptr(self._stats), _ptr(values), _ptr(adv), _ptr(ret), s))
-        if n_glob is None:
-            n_glob = float(self._stats[0])
-        return adv, ret, n_glob
+            # every rank's (count, mean, M2) -> Chan's merge in rank order ON THE DEVICE: the update never reads the host
+            w = torch.distributed.get_world_size()
+            if self._all_stats is None or self._all_stats.shape[0] != w:
+                self._all_stats = torch.zeros(w, 3, device=self.device, dtype=torch.float64)
+            _all_gather_into(self._all_stats, self._stats)
+            check(lib.evm_ppo_gae_merge(self._h, _ptr(self._all_stats), w, _ptr(self._stats), s))
+        check(lib.evm_ppo_gae_normalize(self._h, T, N, None, _ptr(values), _ptr(adv), _ptr(ret), s))
+        return adv, ret, DeviceCount(self._stats)
 
     def epoch(self, states, actions, logp_old, adv, returns, mask_u8, n_selected_global, epsilon, entropy_factor,
               critic_loss_factor, learning_rate, clip_grad_norm, states_unchanged=False):
@@ -145,14 +163,17 @@ class FusedPpoTrainer:
         for t in (states, actions, logp_old, adv, returns, mask_u8):
             assert t.is_cuda and t.is_contiguous()
         s = self._stream()
+        dist = _dist_ready()
+        g = self.grad_buffer() if dist else None
+        # a DeviceCount (what gae() returns) stays on the device: the loss kernels read 1 / count there
+        n_sel = -1.0 if isinstance(n_selected_global, DeviceCount) else float(n_selected_global)
         check(lib.evm_ppo_grads(self._h, rows, _ptr(states), _ptr(actions), _ptr(logp_old), _ptr(adv), _ptr(returns), _ptr(mask_u8),
-                                float(n_selected_global), epsilon, entropy_factor, critic_loss_factor, 1 if states_unchanged else 0, s))
-        if _dist_ready():
-            for net in (ACTOR, CRITIC):
-                g = self.vector(GRADS, net)
-                _all_reduce_sum(g)  # the losses are normalised by the global count: SUM is the global gradient
-                check(lib.evm_ppo_copy(self._h, GRADS, net, 1, _ptr(g), s))
-                torch.cuda.current_stream(self.device).synchronize()
+                                n_sel, epsilon, entropy_factor, critic_loss_factor, 1 if states_unchanged else 0, s))
+        if dist:
+            # the losses are normalised by the global count, so the SUM over ranks is the global gradient.  One collective over
+            # [actor | critic], in place in the buffer the gradient kernels wrote and the optimiser kernel reads, ordered by the
+            # stream: no copy, no synchronize()
+            _all_reduce_sum(g)
         check(lib.evm_ppo_apply(self._h, learning_rate, clip_grad_norm, s))
 
     # ---- SAC's actor step on the same kernels ----------------------------------------------------------------------
@@ -185,8 +206,8 @@ class FusedPpoTrainer:
         """time-major rollout: states [T, N, S], actions / logp_old [T, N, A], the rest [T, N]"""
         T, N = rewards.shape
         adv, ret, n_glob = self.gae(rewards, done_u8, values, next_values, mask_u8, gamma, lam)
-        if n_glob < 1:
-            return float("nan"), float("nan")
+        # nothing selected on any rank: the device-side count makes every gradient zero (and the losses zero); callers train on
+        # batches that hold transitions (check_train, ppo_gae.cpp:63-66), so this is not read back here
         S, A = states.shape[-1], actions.shape[-1]
         st, ac, lp = states.reshape(T * N, S), actions.reshape(T * N, A), logp_old.reshape(T * N, A)
         for ep in range(epoch):

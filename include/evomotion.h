@@ -244,6 +244,17 @@ int evm_ppo_set_params(EvmPpo *q, const float *d_actor, const float *d_critic, i
  * the trainer's vector to d_buf, 1 copies d_buf into the trainer (gradients after an all-reduce, moments of a loaded
  * checkpoint; parameters go through evm_ppo_set_params). */
 int evm_ppo_copy(EvmPpo *q, int what, int net, int to_trainer, float *d_buf, void *stream);
+/* The gradients of both networks as ONE contiguous DEVICE vector of *n_floats floats: the actor's at 0, the critic's at
+ * *critic_offset (the actor's count rounded up to 64 floats; the gap is never written).  After
+ * evm_ppo_grads a data-parallel caller all-reduces it in place on the launch stream — one collective per epoch, no copy, no host
+ * synchronisation — then calls evm_ppo_apply.  d_buf != NULL: the trainer uses that caller-owned buffer from now on (it must
+ * outlive the trainer, be 256-byte aligned and *n_floats long; zero it once); d_grads / n_floats / critic_offset are optional outputs. */
+int evm_ppo_grad_buffer(EvmPpo *q, float *d_buf, float **d_grads, size_t *n_floats, size_t *critic_offset);
+/* (count, mean, M2) of every rank's selected advantages -> the trainer's statistics, Chan's merge on the device in rank order;
+ * d_all_stats [world][3] = an all-gather of the d_stats of evm_ppo_gae (d_all_stats and d_stats must not overlap).  Afterwards evm_ppo_gae_normalize(d_stats = NULL) and
+ * evm_ppo_grads(n_selected_global < 0) use the merged numbers: the whole update runs without a host read
+ * (the global statistic of ppo_gae.cpp:148-149 over all GPUs). */
+int evm_ppo_gae_merge(EvmPpo *q, const double *d_all_stats, int world, double *d_stats /* optional copy of the result */, void *stream);
 /* Adam step count of a network: set when set_step >= 0, returned in *step.  net 2 = the actor's device-side counter that
  * evm_ppo_actor_apply advances (SAC's update inside a captured graph). */
 int evm_ppo_adam_step(EvmPpo *q, int net, int set_step, int *step);
@@ -259,7 +270,8 @@ int evm_ppo_gae_normalize(EvmPpo *q, int horizon, int n_envs, const double *d_st
                           float *d_returns, void *stream);
 /* Forward, losses and backward of both networks over `rows` transitions: gradients land in the trainer (evm_ppo_copy).
  * n_selected_global = number of rows with d_mask == 1 over ALL ranks (the losses are means over them, so summing the
- * ranks' gradients gives the global gradient).  d_states [rows, S], d_actions / d_logp_old [rows, A], d_adv /
+ * ranks' gradients gives the global gradient); negative: use the count of the trainer's own statistics on the device
+ * (evm_ppo_gae, merged over the ranks by evm_ppo_gae_merge).  d_states [rows, S], d_actions / d_logp_old [rows, A], d_adv /
  * d_returns [rows], d_mask [rows].  states_unchanged != 0: d_states holds what it held in the previous call (the later
  * epochs of one train call) and the trainer's 16-byte aligned copy of it is reused. */
 int evm_ppo_grads(EvmPpo *q, size_t rows, const float *d_states, const float *d_actions, const float *d_logp_old, const float *d_adv,

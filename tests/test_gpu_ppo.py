@@ -80,7 +80,7 @@ def test_gae_matches_torch():
     mb = tb(mask) == 1
     dn = torch.where(mb, tb(done).float(), torch.ones((), device="cuda"))
     m2, a2, r2 = torch_ref.gae_advantages(tb(rewards), dn, tb(values), tb(next_values), 0.99, 0.95, mask=mb)
-    assert n_glob == float(mb.sum())
+    assert float(n_glob) == float(mb.sum())
     sel = mb.squeeze(-1).transpose(0, 1)
     np.testing.assert_allclose(adv[sel].cpu().numpy(), a2.squeeze(-1).transpose(0, 1)[sel].cpu().numpy(), atol=2e-5)
     np.testing.assert_allclose(ret[sel].cpu().numpy(), r2.squeeze(-1).transpose(0, 1)[sel].cpu().numpy(), atol=2e-5)
@@ -194,6 +194,7 @@ def test_epochs_in_lock_step_with_autograd_and_adam():
         mu, sigma = actor(states.reshape(rows, 371))
         logp = agent.truncated_normal_log_pdf(actions.reshape(rows, 12), mu, sigma) + 0.2 * (torch.rand(rows, 12, device="cuda") * 2 - 1)
     adv, ret, ng = tr.gae(rewards, done, values, next_values, mask, 0.99, 0.95)
+    ng = float(ng)
     st, ac = states.reshape(rows, 371), actions.reshape(rows, 12)
     oa = torch.optim.Adam(actor.parameters(), lr=1e-3)
     oc = torch.optim.Adam(critic.parameters(), lr=1e-3)

@@ -8,6 +8,7 @@ TAG=${1:-r1}; MODE=${2:-dynamics}
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out
 EXTRA=""; [ "$MODE" = ppo ] && EXTRA="--mode ppo --no-update"
 [ -n "${ENVS:-}" ] && EXTRA="$EXTRA --envs $ENVS"   # default: 4096 envs (BASELINE configs[1])
+[ -n "${BENCH_EXTRA:-}" ] && EXTRA="$EXTRA $BENCH_EXTRA"   # e.g. BENCH_EXTRA="--self-collision 0"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_stats -o run -- python3 $R/bench.py --steps 256 --warmup 64 --no-cpu-baseline $EXTRA > $O/prof_${TAG}_stats.log 2>&1 || exit 1
 i=0
