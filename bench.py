@@ -28,17 +28,17 @@ POLICY_FLOP_PER_ROW = 654848.0  # actor 333 312 + critic 321 5
 PREROLL_CALLS = 192             # untimed, after stagger_episodes(): every env is past its first (staggered) episode
 
 
-def measured_traffic(n):
+def measured_traffic(n, self_collision=0):
     """HBM-side bytes per step of the dynamics pipeline, from the newest committed PMC profile of this exact workload
-    (profiles/r*_traffic.json; rocprofv3 cannot run inside the timed bench); None when the batch size differs from the
-    profiled one.  Returns (bytes, file name)."""
+    (profiles/r*_traffic.json; rocprofv3 cannot run inside the timed bench); None when the batch size or the collision mode
+    differs from the profiled one.  Returns (bytes, file name)."""
     import glob
     best = (None, None)
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json"))):
         try:
             with open(path) as f:
                 t = json.load(f)
-            if t["envs_per_launch"] == n:
+            if t["envs_per_launch"] == n and int(t.get("self_collision", 0)) == int(self_collision):
                 best = (t["traffic_bytes_per_launch"], os.path.basename(path))
         except (OSError, KeyError, ValueError):
             pass
@@ -434,7 +434,7 @@ def main():
             "rccl_ranks": rccl_ranks,
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n)[0], "traffic_source": measured_traffic(n)[1],
+                "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n, args.self_collision)[0], "traffic_source": measured_traffic(n, args.self_collision)[1],
                 "kernel": ("k_sweeps_g (dominant: the Gauss-Seidel sweeps) + k_split_pre_a / pre_b / %spost: one step" % ("pairs / " if args.self_collision else "") if ms_sweeps > 0 else "k_env_step<7>"),
                 "launch_ms": launch_ms, "sampled_step_ms": sampled_ms, "dominant_kernel_ms": (ms_sweeps / max(n_launch, 1)) if ms_sweeps > 0 else launch_ms,
                 "note": "algorithmic 8300 B per env physics step x %d envs per step; a step is a pipeline of four kernels up to "

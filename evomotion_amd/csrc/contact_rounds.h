@@ -24,11 +24,13 @@ struct CBank {
     int id;       // manifold id: member m (floor) or nm + pair; -1 = none
     int a, b;     // body0 (-1: the static floor) and body1
     int round;
-    f32x4 q[20];  // the contact record: per point quads 0..4 (skel_const.h, EVM_CR_STRIDE); the accumulated impulses of the
-                  // sweeps live in its applied_n / applied_f fields
+    int lv;       // bit j: point j is live (jd_n != 0)
+    f32x4 q[20];  // the contact record: per point quads 0..4 (skel_const.h, EVM_CR_STRIDE)
+    float apn[4], apf[4];  // the accumulated impulses of the sweeps (the record's applied_n / applied_f fields at load time): on
+                           // their own, so that a row rewrites one register, not its quad
 };
-#define K_APN(K, j) ((K).q[5 * (j) + 2][3])
-#define K_APF(K, j) ((K).q[5 * (j) + 4][1])
+#define K_APN(K, j) ((K).apn[j])
+#define K_APF(K, j) ((K).apf[j])
 DEV void g_lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_barrier();
@@ -114,18 +116,60 @@ DEV float g_contact_bank(const GCtx &G, CBank &K, bool on, const float *imt) {
                     Q.dl = Q.dl + A * (Q.im * af);
                     Q.da = Q.da + mul(Q.I, cc) * af;
                 }
-            } else if (PHASE == 1) {
-                float ap = K_APN(K, j);
-                res = fmaxf(res, fabsf(row_iter<true, true>(nrm, rel, Q, K.q[5 * j][3], K.q[5 * j + 1][3], 0.f, 1e10f, ap)));
-                K_APN(K, j) = ap;
-            } else {
-                if (K_APN(K, j) > 0.f) {
-                    const float lim = K.q[4][3] * K_APN(K, j);  // mu x the point's normal impulse
-                    float ap = K_APF(K, j);
-                    res = fmaxf(res, fabsf(row_iter<true, true>(lat, rel, Q, K.q[5 * j + 3][3], K.q[5 * j + 4][0], -lim, lim, ap)));
-                    K_APF(K, j) = ap;
-                }
             }
+        }
+    }
+    if (on) g_store_pair_any(G, K.a, K.b, Q);
+    return res;
+}
+// One bounded two-body linear row on the packed (A, B) pair, branch-free: the arithmetic of row_iter<true, true> op for op; a lane
+// with act == false runs it as an exact no-op (zero impulse, accumulated impulse kept), so a round needs no per-lane branches.
+DEV float g_crow(F3 ax, const F3P &rel, BodyPD &Q, float jd, float rhs, float lo, float hi, float ap, bool act, float &ap_out) {
+    const F3P A = f3p(p2(ax.x, ax.x), p2(ax.y, ax.y), p2(ax.z, ax.z));
+    const F3P cc = cross(rel, A);
+    const P2 t = dot(A, Q.dl), u = dot(cc, Q.da);
+    const P2 d = p2(t.x, -t.y) + u;
+    float dI = rhs;
+    dI -= d.x * jd;
+    dI -= d.y * jd;
+    const float sum = ap + dI;
+    const bool cl = sum < lo, ch = !cl && sum > hi;
+    const float nap = cl ? lo : (ch ? hi : sum);
+    dI = (cl || ch) ? nap - ap : dI;
+    dI = act ? dI : 0.f;
+    ap_out = act ? nap : ap;
+    const F3P ang = mul(Q.I, cc);
+    Q.dl = Q.dl + A * (Q.im * dI);
+    Q.da = Q.da + ang * dI;
+    return dI;
+}
+// PHASE 1: normal rows   2: friction rows (limits +-mu x the point's normal impulse of this sweep) of the manifolds whose round
+// it is (`on`); the other lanes ride along with zero bodies and act == false
+template <int PHASE>
+DEV float g_contact_rows(const GCtx &G, CBank &K, bool on, const float *imt) {
+    float res = 0.f;
+    if (!__any(on)) return res;
+    BodyPD Q;
+    Q.dl = f3p(p2(0.f, 0.f), p2(0.f, 0.f), p2(0.f, 0.f)); Q.da = Q.dl;
+    Q.I.xx = Q.I.xy = Q.I.xz = Q.I.yy = Q.I.yz = Q.I.zz = p2(0.f, 0.f); Q.im = p2(0.f, 0.f);
+    if (on) Q = g_pair_any(G, K.a, K.b, imt);
+    const float mu = K.q[4][3];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const bool live = on && ((K.lv >> j) & 1);
+        if (!__any(live)) continue;
+        const F3P rel = f3p(p2(K.q[5 * j][0], -K.q[5 * j + 1][0]), p2(K.q[5 * j][1], -K.q[5 * j + 1][1]), p2(K.q[5 * j][2], -K.q[5 * j + 1][2]));  // (relA, -relB)
+        if (PHASE == 1) {
+            const F3 nrm = f3(K.q[5 * j + 2][0], K.q[5 * j + 2][1], K.q[5 * j + 2][2]);
+            float ap;
+            res = fmaxf(res, fabsf(g_crow(nrm, rel, Q, K.q[5 * j][3], K.q[5 * j + 1][3], 0.f, 1e10f, K_APN(K, j), live, ap)));
+            K_APN(K, j) = ap;
+        } else {
+            const F3 lat = f3(K.q[5 * j + 3][0], K.q[5 * j + 3][1], K.q[5 * j + 3][2]);
+            const float apn = K_APN(K, j), lim = mu * apn;  // a point without normal impulse has no friction row this sweep
+            float ap;
+            res = fmaxf(res, fabsf(g_crow(lat, rel, Q, K.q[5 * j + 3][3], K.q[5 * j + 4][0], -lim, lim, K_APF(K, j), live && apn > 0.f, ap)));
+            K_APF(K, j) = ap;
         }
     }
     if (on) g_store_pair_any(G, K.a, K.b, Q);
@@ -163,6 +207,15 @@ DEV void g_split_bank(const GCtx &G, const CBank &K, bool on, float (&push_ap)[4
 DEV unsigned g_prog_word(int id, int a, int b, int round) {
     return (unsigned) id | ((unsigned) (a + 1) << 9) | ((unsigned) b << 15) | ((unsigned) round << 21);
 }
+DEV void g_bank_live(CBank &K) {
+    K.lv = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        K.lv |= K.q[5 * j][3] != 0.f ? 1 << j : 0;  // jd_n = 1 / denominator > 0 for a live point
+        K.apn[j] = K.q[5 * j + 2][3];
+        K.apf[j] = K.q[5 * j + 4][1];
+    }
+}
 DEV void g_bank_load(const Ctx &c, unsigned w, CBank &K) {
     if (w == 0xffffffffu) { K.id = -1; K.a = -1; K.b = 0; K.round = -1; }
     else { K.id = (int) (w & 511u); K.a = (int) ((w >> 9) & 63u) - 1; K.b = (int) ((w >> 15) & 63u); K.round = (int) ((w >> 21) & 31u); }
@@ -173,6 +226,7 @@ DEV void g_bank_load(const Ctx &c, unsigned w, CBank &K) {
 #pragma unroll
         for (int q = 0; q < 20; q++) K.q[q] = p[q << 6];
     }
+    g_bank_live(K);
 }
 // the accumulated impulses back into the persistent manifold the bank's manifold came from (warm start of the next step)
 DEV void g_bank_writeback(const Ctx &c, const CBank &K) {
@@ -206,10 +260,11 @@ __device__ __attribute__((noinline)) float g_slow_visit(int phase, unsigned w, i
     f32x4 *rec = reinterpret_cast<f32x4 *>(crec_lane + ((size_t) (K.id * EVM_CR_STRIDE) << 6));
 #pragma unroll
     for (int q = 0; q < 20; q++) K.q[q] = rec[q << 6];
+    g_bank_live(K);
     float res = 0.f;
     if (phase == 0) res = g_contact_bank<0>(G, K, true, imt);
-    else if (phase == 1) res = g_contact_bank<1>(G, K, true, imt);
-    else if (phase == 2) res = g_contact_bank<2>(G, K, true, imt);
+    else if (phase == 1) res = g_contact_rows<1>(G, K, true, imt);
+    else if (phase == 2) res = g_contact_rows<2>(G, K, true, imt);
     else {
         f32x4 pq = rec[20 << 6];
         float pa[4] = {pq[0], pq[1], pq[2], pq[3]};
@@ -219,7 +274,10 @@ __device__ __attribute__((noinline)) float g_slow_visit(int phase, unsigned w, i
     }
     if (phase == 1 || phase == 2) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) { rec[(5 * j + 2) << 6] = K.q[5 * j + 2]; rec[(5 * j + 4) << 6] = K.q[5 * j + 4]; }
+        for (int j = 0; j < 4; j++) {
+            K.q[5 * j + 2][3] = K.apn[j]; K.q[5 * j + 4][1] = K.apf[j];
+            rec[(5 * j + 2) << 6] = K.q[5 * j + 2]; rec[(5 * j + 4) << 6] = K.q[5 * j + 4];
+        }
     }
     return res;
 }

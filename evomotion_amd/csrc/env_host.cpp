@@ -607,6 +607,10 @@ int evm_env_get_stamps(EvmEnv *env, unsigned long long *h_out /* [n_tiles, 16] *
     if (!env || !h_out) return fail(EVM_E_INVALID, "null argument");
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(h_out, env->d.stamps, (size_t) (env->d.n / 64) * 16 * 8, hipMemcpyDeviceToHost));
+#ifdef EVM_KSTAMPS  // the narrowphase kernel accumulates with atomics: every read starts a new interval
+    const unsigned long long reset[8] = {0, 0, 0, 0, 0, 0, ~0ull, 0};
+    HIP_TRY(hipMemcpy(env->d.stamps, reset, sizeof(reset), hipMemcpyHostToDevice));
+#endif
     return EVM_OK;
 }
 int evm_env_clear_stats(EvmEnv *env) {

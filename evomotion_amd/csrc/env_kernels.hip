@@ -250,10 +250,11 @@ DEV float row_iter(F3 ax, F3 relA, F3 relB, BodyD &A, BodyD &B, float jd, float 
     dI -= d1 * jd;
     dI -= d2 * jd;
     const float sum = applied + dI;
-    if (BOUNDED) {
-        if (sum < lo) { dI = lo - applied; applied = lo; }
-        else if (sum > hi) { dI = hi - applied; applied = hi; }
-        else applied = sum;
+    if (BOUNDED) {  // (selects, not branches: sum < lo -> lo, else sum > hi -> hi, else sum)
+        const bool cl = sum < lo, ch = !cl && sum > hi;
+        const float nap = cl ? lo : (ch ? hi : sum);
+        dI = (cl || ch) ? nap - applied : dI;
+        applied = nap;
     } else applied = sum;
     if (LIN) {
         A.dl = A.dl + ax * (A.im * dI);
@@ -314,10 +315,11 @@ DEV float row_iter(F3 ax, const F3P &relS, BodyPD &Q, float jd, float rhs, float
     dI -= d.x * jd;
     dI -= d.y * jd;
     const float sum = applied + dI;
-    if (BOUNDED) {
-        if (sum < lo) { dI = lo - applied; applied = lo; }
-        else if (sum > hi) { dI = hi - applied; applied = hi; }
-        else applied = sum;
+    if (BOUNDED) {  // (selects, not branches: sum < lo -> lo, else sum > hi -> hi, else sum)
+        const bool cl = sum < lo, ch = !cl && sum > hi;
+        const float nap = cl ? lo : (ch ? hi : sum);
+        dI = (cl || ch) ? nap - applied : dI;
+        applied = nap;
     } else applied = sum;
     if (LIN) {
         const F3P ang = ISO ? cc * Q.I.xx : mul(Q.I, cc);
@@ -2043,9 +2045,25 @@ __global__ __launch_bounds__(64 * EVM_SPLIT_WAVES) __attribute__((amdgpu_waves_p
 template <int MODE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EVM_PAIRS_WAVES, EVM_PAIRS_WAVES))) void k_split_pairs(EnvDev d, const uint8_t *__restrict__ mask, int tiles) {
     (void) mask;  // (masked-out envs never enter a list)
+#ifdef EVM_KSTAMPS  // diagnostic build (tools/kstamps.py): working wavefronts of the narrowphase kernel, cycles and extent
+    struct KStamp {
+        unsigned long long *st, t0, r0; int kind;
+        __device__ void begin(unsigned long long *s, int k) { st = s; kind = k; t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+        __device__ ~KStamp() {
+            if (!st || threadIdx.x != 0) return;
+            const unsigned long long dt = __builtin_amdgcn_s_memtime() - t0, r1 = __builtin_amdgcn_s_memrealtime();
+            atomicAdd(&st[3 * kind], dt); atomicAdd(&st[3 * kind + 1], 1ull); atomicMax(&st[3 * kind + 2], dt);
+            atomicMin(&st[6], r0); atomicMax(&st[7], r1);
+        }
+    } ks;
+    ks.st = nullptr;
+#endif
     if ((int) blockIdx.x < EVM_BIG_BLOCKS) {
         const int cnt = d.pcount[c_skel.npair];
         if ((int) blockIdx.x * 4 >= cnt) return;
+#ifdef EVM_KSTAMPS
+        ks.begin(d.stamps, 0);
+#endif
         const int hoff = c_skel.big_hull_off, hn = c_skel.big_hull_n;
         for (int k = threadIdx.x; k < 3 * hn; k += 64) {  // [vertex][xyz] from the pair-packed table
             const int v = k / 3, a = k - 3 * v, g = hoff + v;
@@ -2069,6 +2087,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EVM_PAIRS_WA
     if (base >= cnt) return;
     const int i = base + (int) threadIdx.x;
     if (i >= cnt) return;
+#ifdef EVM_KSTAMPS
+    ks.begin(d.stamps, 1);
+#endif
     const int env = d.plist[(size_t) p * d.n + i];
     const Ctx c = make_ctx_env(d, env);
     const bool fin = (MODE & 4) && (d.flags[env] & EVM_FLAG_DONE) != 0;

@@ -601,11 +601,11 @@ __global__ __launch_bounds__(64 * EVM_G_MAX_WAVES) void k_sweeps_g(EnvDev d, con
             const unsigned long long gs_e1 = __builtin_amdgcn_s_memtime();
 #endif
             for (int r = 0; r < nrounds; r++) {
-                rc = fmaxf(rc, g_contact_bank<1>(GC, K0, K0.round == r, imt));
+                rc = fmaxf(rc, g_contact_rows<1>(GC, K0, K0.round == r, imt));
                 if (use_b1) rc = fmaxf(rc, slow(1, r));
             }
             for (int r = 0; r < nrounds; r++) {
-                rc = fmaxf(rc, g_contact_bank<2>(GC, K0, K0.round == r, imt));
+                rc = fmaxf(rc, g_contact_rows<2>(GC, K0, K0.round == r, imt));
                 if (use_b1) rc = fmaxf(rc, slow(2, r));
             }
 #ifdef EVM_GSTAMPS

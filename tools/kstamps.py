@@ -1,0 +1,29 @@
+"""Diagnostic (-DEVM_KSTAMPS build of the library): the working wavefronts of the narrowphase kernel k_split_pairs — how many, how
+long each runs (s_memtime cycles: mean and longest), and the extent of the kernel from the first working wave's start to the last
+one's end (s_memrealtime, 100 MHz).  Build + run on the GPU box:
+    make -C evomotion_amd/csrc kstamps && cp build/libevm_kstamps.so evomotion_amd/libevomotion_hip.so && python tools/kstamps.py"""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from evomotion_amd import VecRobotWalk
+from evomotion_amd._lib import lib, check
+n = 4096
+env = VecRobotWalk(n, seed=1234)
+env.reset()
+env.stagger_episodes()
+g = torch.Generator(device="cuda"); g.manual_seed(0)
+K = 40
+rows = []
+for k in range(K + 200):
+    if k == 199:
+        check(lib.evm_env_get_stamps(env._h, (ctypes.c_ulonglong * (n // 64 * 16))()))  # (a read resets the accumulators)
+    env.step_autoreset(torch.rand(n, 12, device="cuda", generator=g) * 2 - 1)
+    if k >= 200:
+        st = (ctypes.c_ulonglong * (n // 64 * 16))()
+        check(lib.evm_env_get_stamps(env._h, st))
+        rows.append(np.array(st, dtype=np.uint64)[:8].astype(np.float64))
+r = np.array(rows)
+for kind, name in ((0, "big-hull waves (4 queries of 16 lanes)"), (1, "small-hull waves (one env per lane)")):
+    print("%-40s %7.1f per step, mean %8.0f cycles, longest %8.0f cycles" % (name, r[:, 3 * kind + 1].mean(), (r[:, 3 * kind] / np.maximum(r[:, 3 * kind + 1], 1)).mean(), r[:, 3 * kind + 2].mean()))
+print("extent first start -> last end: %.1f us" % ((r[:, 7] - r[:, 6]).mean() / 100.0))
