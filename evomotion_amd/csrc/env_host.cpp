@@ -50,17 +50,22 @@ struct EvmEnv {
     void *gsched;  // device copy of the lane-group sweep schedule (EvmGSchedC), or null
 };
 
-static const EvmEnv *g_skel_owner = nullptr;
+#ifndef EVM_MAX_DEVICES
+#define EVM_MAX_DEVICES 64
+#endif
+static const EvmEnv *g_skel_owner[EVM_MAX_DEVICES] = {};
 
-// The skeleton constants live in one __constant__ block per device.  An env that steps after ANOTHER env of this process
-// (alternating robot_walk / robot_jump, or two batches) re-uploads its block; the previous owner's kernels may still be in
-// flight on another stream, so the device is drained first (rare: one process per GPU owns one env in every benchmark and
-// in the rollout loops; one host thread per GPU is the ABI's threading rule).
+// The skeleton constants live in one __constant__ block PER DEVICE (a __constant__ symbol has one instance on every device of
+// the process), so ownership is tracked per device: envs on different GPUs of one process never evict each other.  An env that
+// steps after ANOTHER env on the same device (alternating robot_walk / robot_jump, or two batches) re-uploads its block; the
+// previous owner's kernels may still be in flight on another stream, so that device is drained first (rare: one process per
+// GPU owns one env in every benchmark and in the rollout loops; one host thread per GPU is the ABI's threading rule).
 static int ensure_skeleton(EvmEnv *env, hipStream_t s) {
-    if (g_skel_owner != env) {
-        if (g_skel_owner != nullptr) HIP_TRY(hipDeviceSynchronize());
+    const EvmEnv *&owner = g_skel_owner[env->device];
+    if (owner != env) {
+        if (owner != nullptr) HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(evm::upload_skeleton(&env->skel, s));
-        g_skel_owner = env;
+        owner = env;
     }
     return EVM_OK;
 }
@@ -114,6 +119,7 @@ int evm_env_create(const char *skeleton_path, int n_envs, int device, uint64_t s
     if (rc != EVM_OK) { delete env; return fail(rc, err); }
     const EvmSkelC &S = env->skel;
     if (evm::step_lds_bytes(S.nb, S.nscan) > 160 * 1024) { delete env; return fail(EVM_E_UNSUPPORTED, "skeleton has too many bodies for the LDS tile"); }
+    if (device < 0 || device >= EVM_MAX_DEVICES) { delete env; return fail(EVM_E_INVALID, "device index out of range"); }
     hipError_t he = hipSetDevice(device);
     if (he != hipSuccess) { delete env; return fail(EVM_E_HIP, std::string("hipSetDevice: ") + hipGetErrorString(he)); }
 
@@ -180,7 +186,9 @@ int evm_env_create(const char *skeleton_path, int n_envs, int device, uint64_t s
         evm_env_destroy(env);
         return fail(EVM_E_UNSUPPORTED, "self_collision = 1 needs the lane-group sweeps kernel, which this skeleton (or EVM_SWEEPS=tile) rules out");
     }
-    g_skel_owner = nullptr;
+    // a new env always uploads (its address may be a destroyed owner's); the device's previous owner may have kernels in flight
+    if (g_skel_owner[device] != nullptr) (void) hipDeviceSynchronize();
+    g_skel_owner[device] = nullptr;
     rc = ensure_skeleton(env, 0);
     if (rc != EVM_OK) { evm_env_destroy(env); return rc; }
     he = evm::launch_init(env->d, seed, 0);
@@ -192,7 +200,7 @@ int evm_env_create(const char *skeleton_path, int n_envs, int device, uint64_t s
 
 void evm_env_destroy(EvmEnv *env) {
     if (!env) return;
-    if (g_skel_owner == env) g_skel_owner = nullptr;
+    if (env->device >= 0 && env->device < EVM_MAX_DEVICES && g_skel_owner[env->device] == env) g_skel_owner[env->device] = nullptr;
     if (env->arena) hipFree(env->arena);
     if (env->gsched) hipFree(env->gsched);
     (void) hipEventDestroy(env->ev0);
