@@ -51,9 +51,12 @@ hipError_t upload_skeleton(const EvmSkelC *h, hipStream_t s);
 size_t step_lds_bytes(int nb, int nscan);
 // split = 1: pre / sweeps / post kernels (the throughput phases spread over the whole chip); 0: one monolithic kernel
 // ev_sweeps0/1 (optional): recorded around the sweeps kernel of the split pipeline
+// side (optional, member-vs-member mode): the env's own side stream + fork / join events — the narrowphase kernel runs on it
+// beside k_split_pre_b
+struct StepSide { hipStream_t stream; hipEvent_t fork, join; };
 hipError_t launch_step(const EnvDev &d, size_t lds_bytes, int split, int mode, const float *action, float *obs, float *reward,
                        uint8_t *done, uint8_t *valid, const uint8_t *mask, hipStream_t s, hipEvent_t ev_sweeps0 = nullptr,
-                       hipEvent_t ev_sweeps1 = nullptr);
+                       hipEvent_t ev_sweeps1 = nullptr, const StepSide *side = nullptr);
 hipError_t launch_repose(const EnvDev &d, const uint8_t *mask, hipStream_t s);
 hipError_t launch_init(const EnvDev &d, uint64_t seed, hipStream_t s);
 hipError_t launch_poses(const EnvDev &d, float *out, hipStream_t s);

@@ -48,6 +48,7 @@ struct EvmEnv {
     int split;  // -1: by batch size (default), 1: split pipeline, 0: monolithic step kernel (EVM_MONOLITHIC=0/1 forces: A/B runs)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_sweeps;  // timed launches: around the sweeps kernel of the split pipeline
     void *gsched;  // device copy of the lane-group sweep schedule (EvmGSchedC), or null
+    evm::StepSide side;  // member-vs-member mode: side stream + events of the narrowphase (null stream: not in use; EVM_PAIRS_OVERLAP=0)
 };
 
 #ifndef EVM_MAX_DEVICES
@@ -110,6 +111,7 @@ int evm_env_create(const char *skeleton_path, int n_envs, int device, uint64_t s
     env->prm = prm;
     env->device = device;
     env->arena = nullptr;
+    env->side.stream = nullptr; env->side.fork = env->side.join = nullptr;
     env->timing = false;
     env->timed_launches = 0;
     env->ev_used = 0;
@@ -186,6 +188,17 @@ int evm_env_create(const char *skeleton_path, int n_envs, int device, uint64_t s
         evm_env_destroy(env);
         return fail(EVM_E_UNSUPPORTED, "self_collision = 1 needs the lane-group sweeps kernel, which this skeleton (or EVM_SWEEPS=tile) rules out");
     }
+    {
+        const char *ov = getenv("EVM_PAIRS_OVERLAP");
+        // opt-in (EVM_PAIRS_OVERLAP=1): measured on MI355X at 4096 envs the fork / join through two events costs more than the
+        // 27 us of k_split_pre_b it hides (step 0.4153 ms with, 0.4052 ms without)
+        if (S.self_collision && ov && ov[0] == '1') {
+            he = hipStreamCreateWithFlags(&env->side.stream, hipStreamNonBlocking);
+            if (he == hipSuccess) he = hipEventCreateWithFlags(&env->side.fork, hipEventDisableTiming);
+            if (he == hipSuccess) he = hipEventCreateWithFlags(&env->side.join, hipEventDisableTiming);
+            if (he != hipSuccess) { evm_env_destroy(env); return fail(EVM_E_HIP, std::string("side stream: ") + hipGetErrorString(he)); }
+        }
+    }
     // a new env always uploads (its address may be a destroyed owner's); the device's previous owner may have kernels in flight
     if (g_skel_owner[device] != nullptr) (void) hipDeviceSynchronize();
     g_skel_owner[device] = nullptr;
@@ -201,6 +214,9 @@ int evm_env_create(const char *skeleton_path, int n_envs, int device, uint64_t s
 void evm_env_destroy(EvmEnv *env) {
     if (!env) return;
     if (env->device >= 0 && env->device < EVM_MAX_DEVICES && g_skel_owner[env->device] == env) g_skel_owner[env->device] = nullptr;
+    if (env->side.stream) { (void) hipStreamSynchronize(env->side.stream); (void) hipStreamDestroy(env->side.stream); }
+    if (env->side.fork) (void) hipEventDestroy(env->side.fork);
+    if (env->side.join) (void) hipEventDestroy(env->side.join);
     if (env->arena) hipFree(env->arena);
     if (env->gsched) hipFree(env->gsched);
     (void) hipEventDestroy(env->ev0);
@@ -248,7 +264,8 @@ static int step_launch(EvmEnv *env, int mode, const float *a, float *obs, float 
     HIP_TRY(evm::launch_step(env->d, evm::step_lds_bytes(env->skel.nb, env->skel.nscan), env->split, mode, a, obs, rew, done, valid, mask, s,
                              // every 8th step also brackets its sweeps kernel
                              (sample && env->ev_used % 2 == 0) ? env->ev_sweeps[env->ev_used].first : nullptr,
-                             (sample && env->ev_used % 2 == 0) ? env->ev_sweeps[env->ev_used].second : nullptr));
+                             (sample && env->ev_used % 2 == 0) ? env->ev_sweeps[env->ev_used].second : nullptr,
+                             env->side.stream ? &env->side : nullptr));
     if (sample) {
         HIP_TRY(hipEventRecord(env->ev_pairs[env->ev_used].second, s));
         env->ev_used++;
@@ -616,7 +633,7 @@ int evm_env_get_stamps(EvmEnv *env, unsigned long long *h_out /* [n_tiles, 16] *
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(h_out, env->d.stamps, (size_t) (env->d.n / 64) * 16 * 8, hipMemcpyDeviceToHost));
 #ifdef EVM_KSTAMPS  // the narrowphase kernel accumulates with atomics: every read starts a new interval
-    const unsigned long long reset[8] = {0, 0, 0, 0, 0, 0, ~0ull, 0};
+    const unsigned long long reset[24] = {0, 0, 0, 0, 0, 0, ~0ull, 0};
     HIP_TRY(hipMemcpy(env->d.stamps, reset, sizeof(reset), hipMemcpyHostToDevice));
 #endif
     return EVM_OK;

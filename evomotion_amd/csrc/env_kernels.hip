@@ -1955,7 +1955,7 @@ __global__ __launch_bounds__(64 * EVM_SPLIT_WAVES) void k_split_pre_a(EnvDev d, 
 #endif
 template <int MODE>
 __global__ __launch_bounds__(64 * EVM_SPLIT_WAVES) __attribute__((amdgpu_waves_per_eu(EVM_PRE_B_WAVES, EVM_PRE_B_WAVES))) void k_split_pre_b(EnvDev d, const float *__restrict__ action,
-                                                                        const uint8_t *__restrict__ mask) {
+                                                                        const uint8_t *__restrict__ mask, int broad) {
     Ctx c = make_ctx(d, tile_stage(d));
     EVM_SPLIT_GUARD()
     const LaneState L = lane_state<MODE>(c);
@@ -1968,7 +1968,8 @@ __global__ __launch_bounds__(64 * EVM_SPLIT_WAVES) __attribute__((amdgpu_waves_p
     // one item list: members first (manifold + contact rows, the longest items), then the joint visits, then (member-vs-member
     // mode) the broadphase of the member pairs: the envs whose boxes overlap, or that hold a cached point, go to the pair's
     // work list for the narrowphase kernel
-    for (int j = vw; j < c_skel.nm + c_skel.nvisit + c_skel.npair; j += nvw) {
+    // (broad == 0: k_split_broad has done the broadphase already, so that the narrowphase runs beside this kernel)
+    for (int j = vw; j < c_skel.nm + c_skel.nvisit + (broad ? c_skel.npair : 0); j += nvw) {
         if (j >= c_skel.nm + c_skel.nvisit) {
             pair_broadphase(c, j - c_skel.nm - c_skel.nvisit, L.fin);
             continue;
@@ -2030,6 +2031,16 @@ __global__ __launch_bounds__(64 * EVM_SPLIT_WAVES) __attribute__((amdgpu_waves_p
 #endif
 }
 
+// Member-vs-member mode with the narrowphase on a side stream: the broadphase items alone (they need k_split_pre_a's poses only)
+template <int MODE>
+__global__ __launch_bounds__(64 * EVM_SPLIT_WAVES) void k_split_broad(EnvDev d, const uint8_t *__restrict__ mask) {
+    Ctx c = make_ctx(d, tile_stage(d));
+    EVM_SPLIT_GUARD()
+    const LaneState L = lane_state<MODE>(c);
+    const int vw = blockIdx.y * EVM_SPLIT_WAVES + c.wave, nvw = gridDim.y * EVM_SPLIT_WAVES;
+    for (int j = vw; j < c_skel.npair; j += nvw) pair_broadphase(c, j, L.fin);
+}
+
 // Member-vs-member mode, narrowphase (pairs_dev.h).  The envs that need a pair are compacted over the whole batch by the
 // broadphase items of k_split_pre_b, so a wavefront is full of real work whatever fraction of the envs has that pair close.
 //   blocks [0, EVM_BIG_BLOCKS)   the pairs with a big hull (the 451-vertex feet): one query per QUARTER wavefront, the 16 lanes
@@ -2070,6 +2081,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EVM_PAIRS_WA
             gj::g_lds_hull[k] = c_skel.hull[6 * (g >> 1) + 2 * a + (g & 1)];
         }
         __syncthreads();
+#ifdef EVM_KSTAMPS
+        if (threadIdx.x == 0) atomicAdd(&d.stamps[16], __builtin_amdgcn_s_memtime() - ks.t0);  // hull staging
+#endif
         for (int i0 = blockIdx.x * 4; i0 < cnt; i0 += EVM_BIG_BLOCKS * 4) {
             const int i = i0 + (int) (threadIdx.x >> 4);
             if (i < cnt) {  // (a row without an entry sits the iteration out; rows are independent of each other)
@@ -2322,6 +2336,36 @@ __global__ __launch_bounds__(64) void k_env_poses(EnvDev d, float *out) {
 
 }  // namespace evm
 #include "sweep_groups.h"
+#ifdef EVM_ISA_PROBE
+namespace evm {
+// Diagnostic (tools/chain_isa.py): the row arithmetic of ONE hinge visit and of one link of the root's hinge chain as kernels of
+// their own, so that their ISA can be read in isolation (instruction count and longest dependent path per hinge).
+__global__ __launch_bounds__(64) void k_probe_hinge_rows(const f32x4 *__restrict__ rec, const float *__restrict__ body, float *__restrict__ out) {
+    Blk42 k;
+#pragma unroll
+    for (int i = 0; i < EVM_H_STRIDE / 4; i++) k.q[i] = rec[(i << 6) + threadIdx.x];
+    BodyPD Q;
+    const float *b = body + threadIdx.x;
+    Q.dl = f3p(p2(b[0], b[64]), p2(b[128], b[192]), p2(b[256], b[320]));
+    Q.da = f3p(p2(b[384], b[448]), p2(b[512], b[576]), p2(b[640], b[704]));
+    Q.I.xx = p2(b[768], b[832]); Q.I.xy = p2(b[896], b[960]); Q.I.xz = p2(b[1024], b[1088]);
+    Q.I.yy = p2(b[1152], b[1216]); Q.I.yz = p2(b[1280], b[1344]); Q.I.zz = p2(b[1408], b[1472]);
+    Q.im = p2(b[1536], b[1600]);
+    float ap[6];
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("; PROBE_BEGIN hinge_rows" ::: "memory");
+    const float res = hinge_rows(k, Q, ap);
+    asm volatile("; PROBE_END hinge_rows" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    float *o = out + threadIdx.x;
+    o[0] = Q.dl.x.x; o[64] = Q.dl.y.x; o[128] = Q.dl.z.x; o[192] = Q.da.x.x; o[256] = Q.da.y.x; o[320] = Q.da.z.x;
+    o[384] = Q.dl.x.y; o[448] = Q.dl.y.y; o[512] = Q.dl.z.y; o[576] = Q.da.x.y; o[640] = Q.da.y.y; o[704] = Q.da.z.y;
+#pragma unroll
+    for (int r = 0; r < 6; r++) o[768 + 64 * r] = ap[r];
+    o[1152] = res;
+}
+}  // namespace evm
+#endif
 namespace evm {
 
 // ---------------------------------------------------------------------------------------------
@@ -2356,7 +2400,7 @@ static hipError_t launch_mode(const EnvDev &d, size_t lds, const float *action, 
 }
 template <int MODE>
 static hipError_t launch_split(const EnvDev &d, size_t lds, const float *action, float *obs, float *reward, uint8_t *done,
-                               uint8_t *valid, const uint8_t *mask, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+                               uint8_t *valid, const uint8_t *mask, hipStream_t s, hipEvent_t e0, hipEvent_t e1, const StepSide *side) {
     static bool attr_set[EVM_MAX_DEVICES] = {};
     const int dev = current_device();
     if (!attr_set[dev]) {
@@ -2374,8 +2418,24 @@ static hipError_t launch_split(const EnvDev &d, size_t lds, const float *action,
     if (parts > 32) parts = 32;
     const dim3 gp(tiles, parts), bp(64 * EVM_SPLIT_WAVES);
     hipLaunchKernelGGL((k_split_pre_a<MODE>), gp, bp, 0, s, d, mask);
-    hipLaunchKernelGGL((k_split_pre_b<MODE>), gp, bp, 0, s, d, action, mask);
-    if (d.pmn) hipLaunchKernelGGL((k_split_pairs<MODE>), dim3(EVM_BIG_BLOCKS + tiles * d.npair_host), dim3(64), 0, s, d, mask, tiles);
+    if (d.pmn && side) {
+        // The narrowphase is a few long, latency-bound wavefronts (GJK chains) that leave most of the chip idle, and the joint /
+        // floor records of k_split_pre_b do not depend on it: broadphase first, then the narrowphase on the side stream BESIDE
+        // k_split_pre_b, joined before the sweeps.
+        hipLaunchKernelGGL((k_split_broad<MODE>), gp, bp, 0, s, d, mask);
+        hipError_t e = hipEventRecord(side->fork, s);
+        if (e == hipSuccess) e = hipStreamWaitEvent(side->stream, side->fork, 0);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_split_pairs<MODE>), dim3(EVM_BIG_BLOCKS + tiles * d.npair_host), dim3(64), 0, side->stream, d, mask, tiles);
+        e = hipEventRecord(side->join, side->stream);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_split_pre_b<MODE>), gp, bp, 0, s, d, action, mask, 0);
+        e = hipStreamWaitEvent(s, side->join, 0);
+        if (e != hipSuccess) return e;
+    } else {
+        hipLaunchKernelGGL((k_split_pre_b<MODE>), gp, bp, 0, s, d, action, mask, 1);
+        if (d.pmn) hipLaunchKernelGGL((k_split_pairs<MODE>), dim3(EVM_BIG_BLOCKS + tiles * d.npair_host), dim3(64), 0, s, d, mask, tiles);
+    }
     if (e0) (void) hipEventRecord(e0, s);
     if (d.gs) {
         static bool attr_g[EVM_MAX_DEVICES] = {};
@@ -2394,7 +2454,7 @@ static hipError_t launch_split(const EnvDev &d, size_t lds, const float *action,
     return hipGetLastError();
 }
 hipError_t launch_step(const EnvDev &d, size_t lds_bytes, int split, int mode, const float *action, float *obs, float *reward,
-                       uint8_t *done, uint8_t *valid, const uint8_t *mask, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+                       uint8_t *done, uint8_t *valid, const uint8_t *mask, hipStream_t s, hipEvent_t e0, hipEvent_t e1, const StepSide *side) {
     // split < 0: choose by batch.  Up to 128 tiles (8192 envs) the monolithic kernel leaves most of the chip idle and the
     // split pipeline wins (0.179 vs 0.227 ms at 64 tiles); with every CU holding a tile it only adds launches and staging
     // traffic (0.472 vs 0.419 ms at 256 tiles).
@@ -2404,10 +2464,10 @@ hipError_t launch_step(const EnvDev &d, size_t lds_bytes, int split, int mode, c
         // the sweeps kernel keeps only the body tiles and the version counters in LDS (no scan minima)
         const size_t lds = lds_bytes;  // same layout as the staging copy
         switch (mode) {
-            case 0: return launch_split<0>(d, lds, action, obs, reward, done, valid, mask, s, e0, e1);
-            case 2: return launch_split<2>(d, lds, action, obs, reward, done, valid, mask, s, e0, e1);
-            case 3: return launch_split<3>(d, lds, action, obs, reward, done, valid, mask, s, e0, e1);
-            case 7: return launch_split<7>(d, lds, action, obs, reward, done, valid, mask, s, e0, e1);
+            case 0: return launch_split<0>(d, lds, action, obs, reward, done, valid, mask, s, e0, e1, side);
+            case 2: return launch_split<2>(d, lds, action, obs, reward, done, valid, mask, s, e0, e1, side);
+            case 3: return launch_split<3>(d, lds, action, obs, reward, done, valid, mask, s, e0, e1, side);
+            case 7: return launch_split<7>(d, lds, action, obs, reward, done, valid, mask, s, e0, e1, side);
             default: return hipErrorInvalidValue;
         }
     }

@@ -197,6 +197,18 @@ DEV void pair_broadphase(const Ctx &c, int p, bool drop) {
 template <bool GROUP>
 DEV void pair_item(const Ctx &c, int p, bool drop, int lds_hull_off = -1) {
     const bool lead = !GROUP || (threadIdx.x & 15) == 0;
+#ifdef EVM_KSTAMPS  // (tools/kstamps.py) cycles of a working wavefront by phase; a mark waits for the outstanding memory traffic first
+    unsigned long long ks_prev = __builtin_amdgcn_s_memtime();
+#define KS_MARK(k)                                                                                        \
+    {                                                                                                     \
+        __builtin_amdgcn_s_waitcnt(0);                                                                    \
+        const unsigned long long ks_now = __builtin_amdgcn_s_memtime();                                   \
+        if (threadIdx.x == 0) atomicAdd(&c.d.stamps[8 + (GROUP ? 0 : 4) + (k)], ks_now - ks_prev);       \
+        ks_prev = ks_now;                                                                                 \
+    }
+#else
+#define KS_MARK(k)
+#endif
     const EvmPairC &PC = c_skel.pair[p];
     const int a = PC.a, b = PC.b;
     const EvmMemberC &MA = c_skel.member[a], &MB = c_skel.member[b];
@@ -217,9 +229,11 @@ DEV void pair_item(const Ctx &c, int p, bool drop, int lds_hull_off = -1) {
     }
     const float thr = PC.thr;
     MPoint2 p0 = load_mp2(c, p, 0), p1 = load_mp2(c, p, 1), p2 = load_mp2(c, p, 2), p3 = load_mp2(c, p, 3);
+    KS_MARK(0)
     if (__any(overlap)) {
         const float md = MARGIN_F + MARGIN_F + thr;
         const gj::Result r = gj::closest_points<GROUP>(SA, SB, md * md, overlap);
+        KS_MARK(1)
         const bool add = r.has && !(r.distance > thr);
         if (add) {
             // btManifoldResult::addContactPoint(normalOnBInWorld, pointInWorld, depth)
@@ -301,12 +315,15 @@ DEV void pair_item(const Ctx &c, int p, bool drop, int lds_hull_off = -1) {
 #undef REMOVE2
     store_mp2(c, p, 0, p0); store_mp2(c, p, 1, p1); store_mp2(c, p, 2, p2); store_mp2(c, p, 3, p3);
     PMN(p) = n;
+    KS_MARK(2)
     if (!__any(n > 0)) return;
     if (n > 0 && lead) atomicOr(&c.t.pact[((p >> 5) << 6) + c.lane], 1u << (p & 31));
     const BodyK A = load_bodyk(c, a), B = load_bodyk(c, b);
     F3 nrm[4] = {p0.nb, p1.nb, p2.nb, p3.nb};
     float dist[4] = {p0.dist, p1.dist, p2.dist, p3.dist}, ap[4] = {p0.ap, p1.ap, p2.ap, p3.ap}, apl[4] = {p0.apl, p1.apl, p2.apl, p3.apl};
     contact_record(c, c_skel.nm + p, n, true, A, B, wA, wB, nrm, dist, ap, apl, PC.mu, lead);
+    KS_MARK(3)
 }
+#undef KS_MARK
 
 }  // namespace evm

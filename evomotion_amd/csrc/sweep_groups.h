@@ -31,6 +31,9 @@ struct GCtx {
 #ifdef EVM_GSTAMPS2
     unsigned long long wait_cycles;
 #endif
+#ifdef EVM_GSTAMPS3
+    unsigned long long *st3;  // d.stamps: [0] loads, [1] rows, [2] hand-over, [3] stores (cycle sums over all hinge chain entries), [4] entries, [5] phases
+#endif
 };
 #define GQ(G, qi) ((G).q[((qi) << 4) + (G).e])
 #define GB(G, qi) ((G).qb[(qi) * 17 + (G).e])
@@ -169,6 +172,11 @@ DEV float g_bcast(float v, int src_lane) { return __shfl(v, src_lane); }
 DEV float g_hinge_chain(const GCtx &G, int rec, int a, int b, float imA, float imB, int nact) {
     Blk42 k;
     BodyPD Q;
+#ifdef EVM_GSTAMPS3  // (tools/gstamps3.py) where the cycles of a chain entry go; every stamp waits for the outstanding LDS traffic first
+#define GS3_STAMP(var) __builtin_amdgcn_s_waitcnt(0xC07F); const unsigned long long var = __builtin_amdgcn_s_memtime();
+    GS3_STAMP(s3_a)
+    unsigned long long s3_rows = 0, s3_hand = 0;
+#endif
     if (rec >= 0) {
         const f32x4 *p = &GQ(G, G.QR + rec);
 #pragma unroll
@@ -177,12 +185,28 @@ DEV float g_hinge_chain(const GCtx &G, int rec, int a, int b, float imA, float i
     }
     float ap[6];
     float res = 0.f;
+#ifdef EVM_GSTAMPS3
+    GS3_STAMP(s3_b)
+#endif
     for (int ph = 0; ph < nact; ph++) {
+#ifdef EVM_GSTAMPS3
+        GS3_STAMP(s3_p0)
+#endif
         if (G.g == ph) res = hinge_rows(k, Q, ap);
+#ifdef EVM_GSTAMPS3
+        GS3_STAMP(s3_p1)
+#endif
         const int src = (ph << 4) + G.e;  // the shared body's deltas after this phase, to every group
         Q.dl.x.x = g_bcast(Q.dl.x.x, src); Q.dl.y.x = g_bcast(Q.dl.y.x, src); Q.dl.z.x = g_bcast(Q.dl.z.x, src);
         Q.da.x.x = g_bcast(Q.da.x.x, src); Q.da.y.x = g_bcast(Q.da.y.x, src); Q.da.z.x = g_bcast(Q.da.z.x, src);
+#ifdef EVM_GSTAMPS3
+        GS3_STAMP(s3_p2)
+        s3_rows += s3_p1 - s3_p0; s3_hand += s3_p2 - s3_p1;
+#endif
     }
+#ifdef EVM_GSTAMPS3
+    GS3_STAMP(s3_c)
+#endif
     if (rec >= 0) {
         f32x4 x;  // the second body and the impulses of this group's visit; the shared body once (group 0 holds the final values too)
         x[0] = Q.dl.x.y; x[1] = Q.dl.y.y; x[2] = Q.dl.z.y; x[3] = Q.da.x.y; GB(G, 3 * b) = x;
@@ -193,6 +217,13 @@ DEV float g_hinge_chain(const GCtx &G, int rec, int a, int b, float imA, float i
             x[0] = Q.da.y.x; x[1] = Q.da.z.x; x[2] = Q.I.xx.x; x[3] = Q.I.xy.x; GB(G, 3 * a + 1) = x;
         }
     }
+#ifdef EVM_GSTAMPS3
+    GS3_STAMP(s3_d)
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&G.st3[0], s3_b - s3_a); atomicAdd(&G.st3[1], s3_rows); atomicAdd(&G.st3[2], s3_hand); atomicAdd(&G.st3[3], s3_d - s3_c);
+        atomicAdd(&G.st3[4], 1ull); atomicAdd(&G.st3[5], (unsigned long long) nact);
+    }
+#endif
     return res;
 }
 // a = the shared member, b = this group's attach sphere
@@ -277,6 +308,9 @@ __global__ __launch_bounds__(64 * EVM_G_MAX_WAVES) void k_sweeps_g(EnvDev d, con
     G.multi = nw > 1;  // (cleared by a wait that times out)
 #ifdef EVM_GSTAMPS2
     G.wait_cycles = 0;
+#endif
+#ifdef EVM_GSTAMPS3
+    G.st3 = d.stamps;
 #endif
     const int nb = c_skel.nb, nm = c_skel.nm;
     const int nrq = gs->nrq, total = gs->total;

@@ -22,8 +22,13 @@ for k in range(K + 200):
     if k >= 200:
         st = (ctypes.c_ulonglong * (n // 64 * 16))()
         check(lib.evm_env_get_stamps(env._h, st))
-        rows.append(np.array(st, dtype=np.uint64)[:8].astype(np.float64))
+        rows.append(np.array(st, dtype=np.uint64)[:24].astype(np.float64))
 r = np.array(rows)
 for kind, name in ((0, "big-hull waves (4 queries of 16 lanes)"), (1, "small-hull waves (one env per lane)")):
     print("%-40s %7.1f per step, mean %8.0f cycles, longest %8.0f cycles" % (name, r[:, 3 * kind + 1].mean(), (r[:, 3 * kind] / np.maximum(r[:, 3 * kind + 1], 1)).mean(), r[:, 3 * kind + 2].mean()))
 print("extent first start -> last end: %.1f us" % ((r[:, 7] - r[:, 6]).mean() / 100.0))
+for kind, name in ((0, "big-hull"), (1, "small-hull")):
+    w = np.maximum(r[:, 3 * kind + 1], 1)
+    ph = [(r[:, 8 + 4 * kind + k] / w).mean() for k in range(4)]
+    print("%-10s per working wave: set-up + manifold loads %.0f, closest points (GJK) %.0f, refresh + manifold stores %.0f, contact record %.0f cycles%s"
+          % (name, ph[0], ph[1], ph[2], ph[3], (", hull staging into LDS %.0f" % (r[:, 16] / w).mean()) if kind == 0 else ""))
