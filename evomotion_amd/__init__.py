@@ -9,4 +9,4 @@ from .agent import (ActorModule, CriticModule, FusedActorCritic, PpoGaeAgent, Ra
                     truncated_normal_log_pdf, truncated_normal_entropy, truncated_normal_sample)
 from .checkpoint import load_into, load_th, save_th  # noqa: F401,E402
 from .replay import ReplayRing  # noqa: F401,E402
-from .sac import EntropyParameter, QNetworkModule, VecSacAgent  # noqa: F401,E402
+from .sac import EntropyParameter, QNetworkModule, ReplayBuffer, SoftActorCriticAgent, VecSacAgent  # noqa: F401,E402

@@ -13,6 +13,8 @@ the tests pin to the reference's golden call (tests/golden/sac_golden.txt) lives
 """
 import math
 
+import numpy as np
+
 import torch
 from torch import nn
 
@@ -361,3 +363,119 @@ class VecSacAgent:
                              state=torch.zeros(2) if e is None else torch.cat([e[1].reshape(-1)[:1], e[2].reshape(-1)[:1]]).float())
         st["train_steps"] = st["actor"]["step"]  # one actor step per train() call
         self.load_optimizer_state(st)
+
+
+# ---- the reference's Agent surface for SAC: act / done / check_train over a flat replay buffer of transitions ------------------
+class ReplayBuffer:
+    """ReplayBuffer (evo_motion_networks/src/replay_buffer.cpp:16-52,146-153): a FIFO of at most `size` transitions
+    dict(state, action, reward, done, next_state).  The newest one is still open — add() stores it with reward 0, done false and
+    next_state = state; update_last() fills those in — and sample() never returns it: the indices of all the others are shuffled
+    and the first batch_size taken.  The reference shuffles with its own std::mt19937(seed) + std::shuffle, whose stream is
+    libstdc++'s business; here `shuffle(index_list)` is a hook (default: a numpy Generator seeded with `seed`) — the golden test
+    plugs in the orders the reference's generator produced."""
+
+    def __init__(self, size, seed):
+        self.size, self.memory = int(size), []
+        self._rng = np.random.default_rng(seed)
+        self.shuffle = lambda index: [index[i] for i in self._rng.permutation(len(index))]
+
+    def empty(self):
+        return not self.memory
+
+    def add(self, item):
+        self.memory.append(item)
+        while len(self.memory) > self.size:
+            self.memory.pop(0)
+
+    def update_last(self, reward, next_state, done):
+        last = self.memory[-1]
+        last["reward"], last["next_state"], last["done"] = reward, next_state, done
+
+    def has_enough(self, batch_size):
+        return len(self.memory) - 1 >= batch_size
+
+    def sample(self, batch_size):
+        index = self.shuffle(list(range(len(self.memory) - 1)))
+        return [self.memory[i] for i in index[:batch_size]]
+
+
+class SoftActorCriticAgent(VecSacAgent):
+    """SoftActorCriticAgent with the reference's Agent surface (evo_motion_networks/include/evo_motion_networks/agent.h:16-35,
+    src/agents/soft_actor_critic.cpp:47-91,172-180) for ONE environment, call for call: act(state, reward) -> action with the
+    previous transition's reward, done(state, reward), a ReplayBuffer of transitions, `epoch` train() calls on `batch_size` sampled
+    transitions whenever global_curr_step % train_every == train_every - 1 and the buffer holds a batch.  The actor forward is the
+    fused HIP kernel, train() the HIP update of VecSacAgent (evm_q_* / evm_ppo_actor_* / evm_sac_*) — this class is the bookkeeping
+    around them.  VecSacAgent.step()/update() with the device-resident ring stays the fast path for thousands of environments.
+
+    Kept from the reference on purpose: act() rewrites the newest transition whenever the buffer is not empty, ALSO right after
+    done() — the first act() of an episode turns the terminal transition back into (reset's reward, first state of the new episode,
+    done = false).  The reference's SAC therefore never trains on a done flag (tests/golden/sac_loop_golden.txt shows it)."""
+
+    def __init__(self, seed, state_space, action_space, actor_hidden_size=256, critic_hidden_size=256, batch_size=256, epoch=1,
+                 learning_rate=1e-3, gamma=0.99, tau=0.005, replay_buffer_size=4096, train_every=32, device=0):
+        super().__init__(seed, state_space, action_space, actor_hidden_size=actor_hidden_size, critic_hidden_size=critic_hidden_size,
+                         batch_size=batch_size, epoch=epoch, learning_rate=learning_rate, gamma=gamma, tau=tau, replay_buffer_size=2,
+                         train_every=train_every, device=device, n_envs=1, use_graph=False)
+        self.replay_buffer = ReplayBuffer(replay_buffer_size, seed)
+        self.S, self.A = int(state_space[0]), int(action_space[0])
+        self.curr_episode_step = self.curr_train_step = self.global_curr_step = 0
+        self._act_calls = 0
+        self.episode_steps, self.episode_rewards = [], []
+
+    def _obs(self, state):
+        return state.to(device=self.device, dtype=torch.float32).reshape(1, self.S).contiguous()
+
+    def act(self, state, reward, uniform=None, train_uniforms=None):
+        """state [S]; reward: the PREVIOUS transition's (soft_actor_critic.cpp:53).  uniform [A]: the U[0,1) draws of
+        truncated_normal_sample (the reference's at::rand), else the kernel's counter-based generator; train_uniforms: per epoch of
+        the train() calls this act() may trigger, (u_next, u_curr) [batch_size, A] (tests)."""
+        obs = self._obs(state)
+        if uniform is not None:
+            uniform = uniform.to(device=self.device, dtype=torch.float32).reshape(1, self.A).contiguous()
+        self._act_calls += 1
+        action, _, _ = self.fused.forward(obs, uniform=uniform, seed=(self.noise_seed + 7919 * self._act_calls) & 0x7FFFFFFF, actor_only=True)
+        action = action[0].clone()
+        if not self.replay_buffer.empty():
+            self.replay_buffer.update_last(float(reward), obs[0], False)
+        self.replay_buffer.add(dict(state=obs[0], action=action, reward=0.0, done=False, next_state=obs[0]))
+        self.check_train(train_uniforms)
+        self.curr_episode_step += 1
+        self.global_curr_step += 1
+        return action
+
+    def check_train(self, train_uniforms=None):
+        if not (self.global_curr_step % self.train_every == self.train_every - 1 and self.replay_buffer.has_enough(self.batch_size)):
+            return 0
+        s, a, r, d, n = self._batch
+        for e in range(self.epoch):
+            items = self.replay_buffer.sample(self.batch_size)
+            s.copy_(torch.stack([i["state"] for i in items]))
+            a.copy_(torch.stack([i["action"] for i in items]))
+            n.copy_(torch.stack([i["next_state"] for i in items]))
+            r.copy_(torch.tensor([i["reward"] for i in items], dtype=torch.float32))
+            d.copy_(torch.tensor([1.0 if i["done"] else 0.0 for i in items], dtype=torch.float32))
+            u = train_uniforms[e] if train_uniforms is not None else (None, None)
+            dev = lambda t: None if t is None else t.to(device=self.device, dtype=torch.float32).contiguous()
+            self.last_losses = self._train_once_hip(u_next=dev(u[0]), u_curr=dev(u[1]))
+            self.train_steps += 1
+            self.curr_train_step += 1
+        return self.epoch
+
+    def done(self, state, reward):
+        """the episode has ended in `state` (its terminal observation) with `reward` (soft_actor_critic.cpp:172-180)"""
+        self.replay_buffer.update_last(float(reward), self._obs(state)[0], True)
+        self.episode_rewards.append(float(reward))
+        self.episode_steps.append(self.curr_episode_step)
+        self.curr_episode_step = 0
+
+    def get_metrics(self):
+        out = {"steps": self.episode_steps[-64:], "rewards": self.episode_rewards[-64:]}
+        if self.last_losses is not None:
+            out.update({k: float(v) for k, v in self.last_losses.items()})
+        return out
+
+    def to(self, device):
+        return self
+
+    def set_eval(self, eval_mode):
+        pass

@@ -247,3 +247,80 @@ class PpoLoopOracle:
         self.train(batch)
         self.curr_train_step += 1
         return True
+
+
+# ---- SoftActorCriticAgent::act / done / check_train and the flat ReplayBuffer: the bookkeeping, restated ------------------------
+class ReplayBufferOracle:
+    """AbstractReplayBuffer / ReplayBuffer (evo_motion_networks/src/replay_buffer.cpp:16-52,146-153): a FIFO of transitions
+    dict(state, action, reward, done, next_state); the newest one is still open (its reward / done / next_state arrive with the
+    next act() or with done()) and is never sampled."""
+
+    def __init__(self, size):
+        self.size, self.memory = size, []
+
+    def empty(self):
+        return not self.memory
+
+    def add(self, item):                       # :29-33
+        self.memory.append(item)
+        while len(self.memory) > self.size:
+            del self.memory[0]
+
+    def update_last(self, reward, next_state, done):   # :36-40 + update_last_item :146-153
+        last = dict(self.memory[-1])
+        last.update(reward=reward, next_state=next_state, done=done)
+        self.memory[-1] = last
+
+    def has_enough(self, batch_size):          # :48-51
+        return len(self.memory) - 1 >= batch_size
+
+    def sample(self, batch_size, shuffled_index):
+        """:16-27 — shuffled_index: what std::shuffle(rand_gen) made of iota(memory.size() - 1)"""
+        assert sorted(shuffled_index) == list(range(len(self.memory) - 1))
+        return [self.memory[i] for i in shuffled_index[:batch_size]]
+
+
+class SacLoopOracle:
+    """SoftActorCriticAgent::act / done / check_train (evo_motion_networks/src/agents/soft_actor_critic.cpp:47-91,172-180) around two
+    callbacks: forward(state, u) -> action and train(batch dict of [B, ...] arrays, u_next, u_curr).
+
+    As in the reference, act() ALWAYS rewrites the newest transition when the buffer is not empty — also right after done(): the
+    first act() of an episode overwrites the terminal transition's (reward, next_state, done = true) with (the reset's reward, the
+    new episode's first state, done = false).  A done flag therefore only ever sits on the newest element, which sample() never
+    returns: the reference's SAC never trains on done = 1 (pinned by the buffer dumps of tests/golden/sac_loop_golden.txt)."""
+
+    def __init__(self, forward, train, batch_size, epoch, train_every, replay_buffer_size):
+        self.forward, self.train = forward, train
+        self.batch_size, self.epoch, self.train_every = batch_size, epoch, train_every
+        self.buffer = ReplayBufferOracle(replay_buffer_size)
+        self.global_curr_step = self.curr_train_step = self.curr_episode_step = 0
+
+    def act(self, state, reward, u, shuffles=(), train_u=()):
+        """shuffles / train_u: per epoch of the train call this act() may trigger, the recorded shuffle and (u_next, u_curr)"""
+        action = self.forward(state, u)
+        if not self.buffer.empty():
+            self.buffer.update_last(reward, state, False)
+        self.buffer.add(dict(state=state, action=action, reward=0.0, done=False, next_state=state))
+        trained = self.check_train(shuffles, train_u)
+        self.curr_episode_step += 1
+        self.global_curr_step += 1
+        return action, trained
+
+    def will_train(self):
+        return self.global_curr_step % self.train_every == self.train_every - 1 and self.buffer.has_enough(self.batch_size)
+
+    def check_train(self, shuffles, train_u):
+        if not self.will_train():
+            return 0
+        for e in range(self.epoch):
+            items = self.buffer.sample(self.batch_size, shuffles[e])
+            batch = dict(states=np.stack([i["state"] for i in items]).astype(np.float32), actions=np.stack([i["action"] for i in items]).astype(np.float32),
+                         rewards=np.array([[i["reward"]] for i in items], np.float32), done=np.array([[1.0 if i["done"] else 0.0] for i in items], np.float32),
+                         next_states=np.stack([i["next_state"] for i in items]).astype(np.float32))
+            self.train(batch, train_u[e][0], train_u[e][1])
+            self.curr_train_step += 1
+        return self.epoch
+
+    def done(self, state, reward):
+        self.buffer.update_last(reward, state, True)
+        self.curr_episode_step = 0

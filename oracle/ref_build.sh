@@ -33,4 +33,8 @@ if [ -f "$HERE/ref_loop.cpp" ]; then
   g++ $FLAGS "$HERE/ref_loop.cpp" -L"$OUT" -levo_motion_networks -L"$T/lib" -ltorch_cpu -lc10 \
       -Wl,-rpath,"$OUT" -Wl,-rpath,"$T/lib" -o "$OUT/ref_loop"
 fi
+if [ -f "$HERE/ref_sac_loop.cpp" ]; then
+  g++ $FLAGS "$HERE/ref_sac_loop.cpp" -L"$OUT" -levo_motion_networks -L"$T/lib" -ltorch_cpu -lc10 \
+      -Wl,-rpath,"$OUT" -Wl,-rpath,"$T/lib" -o "$OUT/ref_sac_loop"
+fi
 echo "reference build ok: $OUT"
