@@ -633,7 +633,7 @@ int evm_env_get_stamps(EvmEnv *env, unsigned long long *h_out /* [n_tiles, 16] *
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(h_out, env->d.stamps, (size_t) (env->d.n / 64) * 16 * 8, hipMemcpyDeviceToHost));
 #ifdef EVM_KSTAMPS  // the narrowphase kernel accumulates with atomics: every read starts a new interval
-    const unsigned long long reset[24] = {0, 0, 0, 0, 0, 0, ~0ull, 0};
+    const unsigned long long reset[32] = {0, 0, 0, 0, 0, 0, ~0ull, 0};
     HIP_TRY(hipMemcpy(env->d.stamps, reset, sizeof(reset), hipMemcpyHostToDevice));
 #endif
     return EVM_OK;

@@ -2075,10 +2075,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EVM_PAIRS_WA
 #ifdef EVM_KSTAMPS
         ks.begin(d.stamps, 0);
 #endif
-        const int hoff = c_skel.big_hull_off, hn = c_skel.big_hull_n;
-        for (int k = threadIdx.x; k < 3 * hn; k += 64) {  // [vertex][xyz] from the pair-packed table
-            const int v = k / 3, a = k - 3 * v, g = hoff + v;
-            gj::g_lds_hull[k] = c_skel.hull[6 * (g >> 1) + 2 * a + (g & 1)];
+        // the hull table into LDS as [vertex][xyz]: all of it when it fits (the boxes' supports then stay off the memory system
+        // too: a GJK iteration of a foot-vs-box query has no global access left), else the big hull alone
+        const bool all = c_skel.hull_pts <= EVM_LDS_HULL_PTS;
+        const int h0 = all ? 0 : c_skel.big_hull_off, hn = all ? c_skel.hull_pts : c_skel.big_hull_n;
+        const int hoff = all ? -2 : c_skel.big_hull_off;
+        for (int v = threadIdx.x; v < hn; v += 64) {  // from the pair-packed table
+            const int g = h0 + v, hb = 6 * (g >> 1) + (g & 1);
+            gj::g_lds_hull[v] = gj::gj_f4{c_skel.hull[hb], c_skel.hull[hb + 2], c_skel.hull[hb + 4], 0.f};
         }
         __syncthreads();
 #ifdef EVM_KSTAMPS

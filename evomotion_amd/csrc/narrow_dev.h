@@ -99,25 +99,33 @@ DEV int dpp_i(int v, const int ctrl) {
 }
 // The block may hold ONE big hull in LDS (g_lds_hull, [vertex][xyz], filled by the kernel from hull table offset
 // g_lds_hull_off): a row's 16 lanes then read 192 contiguous bytes per step instead of gathering from the constant table.
-__device__ __shared__ float g_lds_hull[3 * EVM_MAX_HULL_PTS / 2];
+typedef float gj_f4 __attribute__((ext_vector_type(4)));
+#define EVM_LDS_HULL_PTS (EVM_MAX_HULL_PTS / 2)
+__device__ __shared__ gj_f4 g_lds_hull[EVM_LDS_HULL_PTS];   // [vertex] = (x, y, z, -): one ds_read_b128 per vertex
 DEV F3 support_group(int hull_off, int hull_n, F3 dir, int lds_hull_off) {
     const int sub = (int) (threadIdx.x & 15);
     float best = -GJ_LARGE;
     int bi = 0x7fffffff;
-    if (hull_off == lds_hull_off) {
-        for (int v0 = 0; __any(v0 < hull_n); v0 += 64) {  // four vertices per lane and trip: the LDS reads of a trip are in flight together
-            float x[4], y[4], z[4];
+    // lds_hull_off == -2: the block holds the WHOLE hull table in LDS (every hull of the skeleton), else the one hull at that offset
+    const bool in_lds = lds_hull_off == -2 || hull_off == lds_hull_off;
+    const gj_f4 *lh = g_lds_hull + (lds_hull_off == -2 ? hull_off : 0);
+    if (in_lds) {
+        // four vertices per lane and trip, the next trip's reads in flight while this one's dot products run
+        gj_f4 cur[4];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int v = v0 + 16 * k + sub, vv = v < hull_n ? v : 0;
-                x[k] = g_lds_hull[3 * vv]; y[k] = g_lds_hull[3 * vv + 1]; z[k] = g_lds_hull[3 * vv + 2];
-            }
+        for (int k = 0; k < 4; k++) { const int v = 16 * k + sub; cur[k] = lh[v < hull_n ? v : 0]; }
+        for (int v0 = 0; __any(v0 < hull_n); v0 += 64) {
+            gj_f4 nxt[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) { const int v = v0 + 64 + 16 * k + sub; nxt[k] = lh[v < hull_n ? v : 0]; }
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const int v = v0 + 16 * k + sub;
-                const float d = (dir.x * x[k] + dir.y * y[k]) + dir.z * z[k];
+                const float d = (dir.x * cur[k][0] + dir.y * cur[k][1]) + dir.z * cur[k][2];
                 if (v < hull_n && d > best) { best = d; bi = v; }
             }
+#pragma unroll
+            for (int k = 0; k < 4; k++) cur[k] = nxt[k];
         }
     } else {
         for (int v = sub; __any(v < hull_n); v += 16) {
@@ -134,7 +142,7 @@ DEV F3 support_group(int hull_off, int hull_n, F3 dir, int lds_hull_off) {
         const int oi = dpp_i(bi, st);
         if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
     }
-    if (hull_off == lds_hull_off) return f3(g_lds_hull[3 * bi], g_lds_hull[3 * bi + 1], g_lds_hull[3 * bi + 2]);
+    if (in_lds) { const gj_f4 w = lh[bi]; return f3(w[0], w[1], w[2]); }
     const int g = hull_off + bi, hb = 6 * (g >> 1) + (g & 1);
     return f3(c_skel.hull[hb], c_skel.hull[hb + 2], c_skel.hull[hb + 4]);
 }
@@ -144,6 +152,9 @@ struct Shape {  // one member's hull and world transform (the basis may be non-o
     int lds_hull_off;  // GROUP mode: hull table offset of the hull the block holds in LDS (-1: none)
     M33 R;
     F3 o;
+#ifdef EVM_KSTAMPS
+    unsigned long long *ks;  // d.stamps: [17] queries that took the penetration branch, [18] wavefronts with such a query, [19] GJK iterations of the slowest lane summed over waves
+#endif
 };
 // w = support_A(-axis) - support_B(axis) in world space, with the two support points.  GROUP: the 16 lanes of a row work
 // on one query (identical state in all of them) and share the support scans.
@@ -206,6 +217,8 @@ DEV int outside_of_plane(F3 p, F3 a, F3 b, F3 c, F3 d) {
     if (signd * signd < (1e-4f * 1e-4f)) return -1;
     return signp * signd < 0.f ? 1 : 0;
 }
+DEV int dpp_i(int v, const int ctrl);
+template <bool GROUP>
 DEV bool closest_tetrahedron(F3 p, F3 a, F3 b, F3 c, F3 d, Bary &f) {
     Bary t;
     f.closest = p;
@@ -215,6 +228,46 @@ DEV bool closest_tetrahedron(F3 p, F3 a, F3 b, F3 c, F3 d, Bary &f) {
     if (oABC < 0 || oACD < 0 || oADB < 0 || oBDC < 0) { f.degenerate = true; return false; }
     if (!oABC && !oACD && !oADB && !oBDC) return false;
     float best = EVM_INF;
+    if (GROUP) {
+        // One query per 16-lane row, identical state in its lanes: lane k of every quad takes face k (ABC, ACD, ADB, BDC), then a
+        // two-step exchange inside the quad leaves the sequential loop's winner (smallest squared distance, the FIRST face on a
+        // tie: `sq < best` is strict) in all of them — one closest_triangle instead of up to four.
+        const int fi = (int) (threadIdx.x & 3);
+        const F3 x = sel3(fi == 3, b, a);
+        const F3 y = sel3(fi == 0, b, sel3(fi == 1, c, d));
+        const F3 z = sel3(fi == 0, c, sel3(fi == 1, d, sel3(fi == 2, b, c)));
+        const bool mine = (fi == 0 ? oABC : (fi == 1 ? oACD : (fi == 2 ? oADB : oBDC))) != 0;
+        closest_triangle(p, x, y, z, t);
+        const F3 q = t.closest;
+        float sq = mine ? gj::dot(gj::sub(q, p), gj::sub(q, p)) : EVM_INF;
+        // the face's result in tetrahedron terms (the four blocks of the sequential form)
+        const bool uA = fi != 3 && t.uA, uB = fi == 0 ? t.uB : (fi == 2 ? t.uC : (fi == 3 ? t.uA : false));
+        const bool uC = fi == 0 ? t.uC : (fi == 1 ? t.uB : (fi == 3 ? t.uC : false)), uD = fi == 1 ? t.uC : (fi == 0 ? false : t.uB);
+        float w0 = fi == 3 ? 0.f : t.b0;
+        float w1 = fi == 0 ? t.b1 : (fi == 2 ? t.b2 : (fi == 3 ? t.b0 : 0.f));
+        float w2 = fi == 0 ? t.b2 : (fi == 1 ? t.b1 : (fi == 3 ? t.b2 : 0.f));
+        float w3 = fi == 1 ? t.b2 : (fi == 0 ? 0.f : t.b1);
+        int fl = (uA ? 1 : 0) | (uB ? 2 : 0) | (uC ? 4 : 0) | (uD ? 8 : 0), face = fi;
+        F3 cl = q;
+#pragma unroll
+        for (int st = 0; st < 2; st++) {
+            const float osq = __int_as_float(dpp_i(__float_as_int(sq), st));
+            const int oface = dpp_i(face, st), ofl = dpp_i(fl, st);
+            const float ox = __int_as_float(dpp_i(__float_as_int(cl.x), st)), oy = __int_as_float(dpp_i(__float_as_int(cl.y), st));
+            const float oz = __int_as_float(dpp_i(__float_as_int(cl.z), st));
+            const float o0 = __int_as_float(dpp_i(__float_as_int(w0), st)), o1 = __int_as_float(dpp_i(__float_as_int(w1), st));
+            const float o2 = __int_as_float(dpp_i(__float_as_int(w2), st)), o3 = __int_as_float(dpp_i(__float_as_int(w3), st));
+            const bool take = osq < sq || (osq == sq && oface < face);
+            sq = take ? osq : sq; face = take ? oface : face; fl = take ? ofl : fl;
+            cl = sel3(take, f3(ox, oy, oz), cl);
+            w0 = take ? o0 : w0; w1 = take ? o1 : w1; w2 = take ? o2 : w2; w3 = take ? o3 : w3;
+        }
+        if (sq < best) {
+            f.closest = cl; f.uA = (fl & 1) != 0; f.uB = (fl & 2) != 0; f.uC = (fl & 4) != 0; f.uD = (fl & 8) != 0;
+            f.b0 = w0; f.b1 = w1; f.b2 = w2; f.b3 = w3;
+        }
+        return true;
+    }
     if (oABC) {
         closest_triangle(p, a, b, c, t);
         const F3 q = t.closest;
@@ -288,6 +341,7 @@ DEV bool sx_in_simplex(const Simplex &s, F3 w) {
     return found;
 }
 // updateClosestVectorAndPoints (called right after every addVertex, so the cached values are never stale)
+template <bool GROUP>
 DEV bool sx_closest(Simplex &s, F3 &v) {
     Bary bc;
     bary_reset(bc);
@@ -320,7 +374,7 @@ DEV bool sx_closest(Simplex &s, F3 &v) {
         sx_reduce(s, bc);
         s.cachedValid = bary_valid(bc);
     } else if (s.n == 4) {
-        const bool sep = closest_tetrahedron(zero, s.W[0], s.W[1], s.W[2], s.W[3], bc);
+        const bool sep = closest_tetrahedron<GROUP>(zero, s.W[0], s.W[1], s.W[2], s.W[3], bc);
         if (sep) {
             s.cP1 = gj::add(gj::add(gj::add(gj::scl(s.P[0], bc.b0), gj::scl(s.P[1], bc.b1)), gj::scl(s.P[2], bc.b2)), gj::scl(s.P[3], bc.b3));
             s.cP2 = gj::add(gj::add(gj::add(gj::scl(s.Q[0], bc.b0), gj::scl(s.Q[1], bc.b1)), gj::scl(s.Q[2], bc.b2)), gj::scl(s.Q[3], bc.b3));
@@ -362,9 +416,20 @@ DEV RunOut gjk_run(const Shape &A, F3 oA, const Shape &B, F3 oB, float max_dist2
     Simplex sx;
     sx_reset(sx);
     int cur_iter = 0, degenerate = 0;
+#ifdef EVM_KSTAMPS
+    unsigned long long ks_sup = 0, ks_rest = 0, ks_trips = 0;
+#endif
     while (__any(running)) {
         F3 pW, qW;
+#ifdef EVM_KSTAMPS
+        __builtin_amdgcn_s_waitcnt(0);
+        const unsigned long long ks_a = __builtin_amdgcn_s_memtime();
+#endif
         minkowski<GROUP>(A, oA, B, oB, axis, pW, qW);  // (lanes that have left keep their last axis: harmless, results unused)
+#ifdef EVM_KSTAMPS
+        __builtin_amdgcn_s_waitcnt(0);
+        const unsigned long long ks_b = __builtin_amdgcn_s_memtime();
+#endif
         if (running) {
             const F3 w = gj::sub(pW, qW);
             const float delta = gj::dot(axis, w);
@@ -375,7 +440,7 @@ DEV RunOut gjk_run(const Shape &A, F3 oA, const Shape &B, F3 oB, float max_dist2
             else {
                 sx_add(sx, w, pW, qW);
                 F3 newAxis;
-                if (!sx_closest(sx, newAxis)) { degenerate = 3; checkSimplex = true; running = false; }
+                if (!sx_closest<GROUP>(sx, newAxis)) { degenerate = 3; checkSimplex = true; running = false; }
                 else if (gj::len2(newAxis) < GJ_REL_ERROR2) { axis = newAxis; degenerate = 6; checkSimplex = true; running = false; }
                 else {
                     const float prev = squaredDistance;
@@ -389,7 +454,17 @@ DEV RunOut gjk_run(const Shape &A, F3 oA, const Shape &B, F3 oB, float max_dist2
                 }
             }
         }
+#ifdef EVM_KSTAMPS
+        __builtin_amdgcn_s_waitcnt(0);
+        {
+            const unsigned long long ks_c = __builtin_amdgcn_s_memtime();
+            ks_sup += ks_b - ks_a; ks_rest += ks_c - ks_b; ks_trips++;
+        }
+#endif
     }
+#ifdef EVM_KSTAMPS
+    if (threadIdx.x == 0) { atomicAdd(&A.ks[20 + (GROUP ? 0 : 4)], ks_sup); atomicAdd(&A.ks[21 + (GROUP ? 0 : 4)], ks_rest); atomicAdd(&A.ks[22 + (GROUP ? 0 : 4)], ks_trips); }
+#endif
     if (checkSimplex) {
         F3 pointOnA = sx.cP1, pointOnB = sx.cP2;  // compute_points: the cached pair of the last closest()
         F3 normalInB = axis;
@@ -447,16 +522,74 @@ DEV Result closest_points(const Shape &A, const Shape &B, float max_dist2, bool 
     out.iterations = r.iters;
     const bool catchDegenerate = r.degenerate != 0 && (distance + margin) < GJ_PEN_TOLERANCE;
     const bool need_pen = active && (!isValid || catchDegenerate);
+#ifdef EVM_KSTAMPS
+    {
+        const unsigned long long m = __ballot(need_pen);
+        int it = r.iters;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) it = max(it, __shfl_xor(it, o));
+        if (threadIdx.x == 0) {
+            if (m) { atomicAdd(&A.ks[17], (unsigned long long) __popcll(m) / (GROUP ? 16 : 1)); atomicAdd(&A.ks[18], 1ull); }
+            atomicAdd(&A.ks[19], (unsigned long long) it);
+        }
+    }
+#endif
     if (__any(need_pen)) {
         // btMinkowskiPenetrationDepthSolver::calcPenDepth
         float minProj = GJ_LARGE;
         F3 minNorm = f3(0.f, 0.f, 0.f);
-        for (int i = 0; i < 42; i++) {
-            const F3 norm = f3(kPenDirs[i][0], kPenDirs[i][1], kPenDirs[i][2]);
-            F3 pW, qW;
-            minkowski<GROUP>(A, oA, B, oB, norm, pW, qW);
-            const float delta = gj::dot(norm, gj::sub(qW, pW));
-            if (delta < minProj) { minProj = delta; minNorm = norm; }
+        if (GROUP) {
+            for (int i = 0; i < 42; i++) {
+                const F3 norm = f3(kPenDirs[i][0], kPenDirs[i][1], kPenDirs[i][2]);
+                F3 pW, qW;
+                minkowski<GROUP>(A, oA, B, oB, norm, pW, qW);
+                const float delta = gj::dot(norm, gj::sub(qW, pW));
+                if (delta < minProj) { minProj = delta; minNorm = norm; }
+            }
+        } else {
+            // One query per lane, and the branch is rare (a few queries per 18 000): the 42 directions of ONE such query go to 42
+            // lanes of the wavefront — its transforms broadcast, the hulls are wave-uniform anyway — and a shuffle reduction returns
+            // the sequential loop's answer (smallest projection, the FIRST direction on a tie: `delta < minProj` is strict).
+            // (a ragged wavefront has fewer than 64 lanes: its lanes take several directions each, in increasing order)
+            const int lane = (int) (threadIdx.x & 63);
+            const unsigned long long act = __ballot(true);
+            const int nact = (int) __popcll(act), rank = (int) __popcll(act & ((1ull << lane) - 1ull));
+            unsigned long long todo = __ballot(need_pen);
+            while (todo) {
+                const int src = (int) __builtin_ctzll(todo);
+                todo &= todo - 1;
+                auto bc = [&](float x) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), src)); };
+                auto bc3 = [&](F3 x) { return f3(bc(x.x), bc(x.y), bc(x.z)); };
+                Shape As = A, Bs = B;
+                As.R = m33(bc3(A.R.r0), bc3(A.R.r1), bc3(A.R.r2)); Bs.R = m33(bc3(B.R.r0), bc3(B.R.r1), bc3(B.R.r2));
+                const F3 oAs = bc3(oA), oBs = bc3(oB);
+                float dl = GJ_LARGE;
+                int ix = 64;
+                for (int k = 0; k * nact < 42; k++) {
+                    const int i = rank + k * nact, ii = i < 42 ? i : 0;
+                    const F3 norm = f3(kPenDirs[ii][0], kPenDirs[ii][1], kPenDirs[ii][2]);
+                    F3 pW, qW;
+                    minkowski<false>(As, oAs, Bs, oBs, norm, pW, qW);
+                    const float delta = gj::dot(norm, gj::sub(qW, pW));
+                    if (i < 42 && delta < dl) { dl = delta; ix = i; }
+                }
+                // the lanes' results meet in wave-uniform registers (lane by lane: a butterfly would need every relay lane alive)
+                float bd = GJ_LARGE;
+                int bx = 64;
+                {
+                    unsigned long long rest = act;
+                    for (int k = 0; k < 42 && rest; k++) {
+                        const int l = (int) __builtin_ctzll(rest);
+                        rest &= rest - 1;
+                        const float od = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dl), l));
+                        const int oi = __builtin_amdgcn_readlane(ix, l);
+                        if (od < bd || (od == bd && oi < bx)) { bd = od; bx = oi; }
+                    }
+                }
+                dl = bd; ix = bx;
+                const int jx = ix < 42 ? ix : 0;
+                if (lane == src && dl < minProj) { minProj = dl; minNorm = f3(kPenDirs[jx][0], kPenDirs[jx][1], kPenDirs[jx][2]); }
+            }
         }
         const bool overlap = !(minProj < 0.f);
         minProj += 0.5f + (marginA + marginB);  // extraSeparation + margins

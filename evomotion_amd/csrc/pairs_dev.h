@@ -216,6 +216,9 @@ DEV void pair_item(const Ctx &c, int p, bool drop, int lds_hull_off = -1) {
     gj::Shape SA, SB;
     SA.hull_off = MA.hull_off; SA.hull_n = MA.hull_n; SB.hull_off = MB.hull_off; SB.hull_n = MB.hull_n;
     SA.lds_hull_off = SB.lds_hull_off = lds_hull_off;
+#ifdef EVM_KSTAMPS
+    SA.ks = SB.ks = c.d.stamps;
+#endif
     SA.o = G3(pos, 3 * a); SB.o = G3(pos, 3 * b);
     SA.R = m33(SC3(c_skel.sc_r + 9 * a), SC3(c_skel.sc_r + 9 * a + 3), SC3(c_skel.sc_r + 9 * a + 6));
     SB.R = m33(SC3(c_skel.sc_r + 9 * b), SC3(c_skel.sc_r + 9 * b + 3), SC3(c_skel.sc_r + 9 * b + 6));

@@ -140,6 +140,7 @@ struct EvmSkelC {
     int env_kind;          // 0 robot_walk, 1 robot_jump (EvmEnvParams::env_kind)
     int self_collision;    // member-vs-member contacts (EvmEnvParams::self_collision)
     int npair;             // collidable member pairs (0 unless self_collision)
+    int hull_pts;                  // vertices in use in hull[] (all hulls, pair-padded)
     int big_hull_off, big_hull_n;  // the largest hull above EVM_BIG_HULL vertices (hull table offset, vertex count; -1: none):
                                    // the narrowphase kernel's blocks keep it in LDS
     int settle_steps;      // physics steps inside reset(): 2 * reset_frames (robot_walk.cpp:98-103) or reset_frames (robot_jump.cpp:104)

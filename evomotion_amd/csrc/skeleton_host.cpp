@@ -650,9 +650,14 @@ int load_skeleton_constants(const char *path, const EvmEnvParams &prm, EvmSkelC 
     // members without contact response (member.cpp:31-33) get no rows.  Lexicographic (a < b): body0 = a, body1 = b, and
     // this is the order of their rows in the solver ----
     S.npair = 0;
+    S.hull_pts = hull_used;
     S.big_hull_off = -1; S.big_hull_n = 0;
     for (int i = 0; i < nm; i++)
         if (S.member[i].hull_n > EVM_BIG_HULL && S.member[i].hull_n > S.big_hull_n) { S.big_hull_off = S.member[i].hull_off; S.big_hull_n = S.member[i].hull_n; }
+    if (S.self_collision && S.big_hull_n > EVM_MAX_HULL_PTS / 2) {
+        err = "member-vs-member contacts: a hull has more vertices than the narrowphase kernel's LDS table holds";
+        return EVM_E_UNSUPPORTED;
+    }
     if (S.self_collision) {
         for (int i = 0; i < nm; i++)
             for (int j = i + 1; j < nm; j++) {

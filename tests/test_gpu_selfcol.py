@@ -135,3 +135,54 @@ def test_known_answer_folded_arm_stops_at_the_body(tmp_path):
     assert touched
     assert deep1 > 2 * pc.MARGIN - 2.0 * 1.0 * pc.DT - 0.01, deep1
     assert deep0 < -0.02, deep0
+
+
+def test_deep_interpenetration_takes_the_penetration_branch(tmp_path, orc_lib):
+    """Cores that interpenetrate (GJK ends degenerate with the cores touching: btGjkPairDetector's catchDegeneracies / the invalid
+    result) go through the penetration-depth solver — 42 sphere directions + a nested GJK run on the displaced pair.
+    Random rollouts reach it a few times per 18 000 queries, so it gets a scene of its own: 70 pairs of boxes (more than one
+    wavefront's worth: a full wave and a ragged one) set inside each other at random offsets and rotations, one physics step from
+    identical state on the oracle and on the HIP path — in one-query-per-lane form the kernel deals the 42 directions of such a
+    query to the lanes of its wavefront."""
+    from evomotion_amd import VecRobotWalk
+    sk = pc.skel_two_free_boxes(write_skeleton, tmp_path, half_b=(0.3, 0.25, 0.2))
+    n = 70
+    env = VecRobotWalk(n, seed=1, device=0, parameters={"skeleton_json_path": sk, "self_collision": 1})
+    env.debug_reset_begin()
+    ow = pc.OracleWorld(sk, lib=orc_lib, self_collision=1)
+    assert env.n_pairs == ow.npairs == 1
+    tmpl = pc.clean_state(ow, [[0.0, 3000.0, 0.0], [0.0, 3000.0, 0.0]])
+    f = pc.fields(ow)
+    rng = np.random.default_rng(5)
+    S = np.repeat(tmpl[None], n, 0).copy()
+    for i in range(n):
+        b = S[i, f["bodies"]].reshape(ow.nb, 13)
+        depth = rng.uniform(0.0, 1.0)
+        d = rng.normal(size=3); d /= np.linalg.norm(d)
+        b[1, 0:3] = b[0, 0:3] + (d * np.array([0.8, 0.45, 0.7]) * depth * (1.0 if i % 7 else 0.0)).astype(np.float32)  # every 7th: centres coincide
+        q = rng.normal(size=4); q /= np.linalg.norm(q)
+        b[1, 3:7] = q.astype(np.float32)
+        S[i, f["ms"]] = b[: ow.nm, 0:3].ravel()
+    env.set_state(S)
+    env.debug_physics_steps(1)
+    got = env.get_state()
+    pen_calls = 0
+    worst = dict(pos=0.0, lin=0.0, ang=0.0, geom=0.0, imp=0.0)
+    for i in range(n):
+        ow.set_state(S[i])
+        ow.step(1)
+        pen_calls += ow.e.pair_stats()["penetration_calls"]
+        want = ow.state()
+        pg, pw = got[i, f["pairs"]].reshape(1, 49), want[f["pairs"]].reshape(1, 49)
+        assert pg[0, 0] == pw[0, 0], (i, pg[0, 0], pw[0, 0])
+        if pw[0, 0] > 0:
+            worst["geom"] = max(worst["geom"], float(np.abs(pg[0, 1:11] - pw[0, 1:11]).max()))   # local points, normal, distance
+            worst["imp"] = max(worst["imp"], float(np.abs(pg[0, 11:13] - pw[0, 11:13]).max()))
+        bg, bw = got[i, f["bodies"]].reshape(ow.nb, 13), want[f["bodies"]].reshape(ow.nb, 13)
+        worst["pos"] = max(worst["pos"], float(np.abs(bg[:, 0:3] - bw[:, 0:3]).max()))
+        worst["lin"] = max(worst["lin"], float(np.abs(bg[:, 7:10] - bw[:, 7:10]).max()))
+        worst["ang"] = max(worst["ang"], float(np.abs(bg[:, 10:13] - bw[:, 10:13]).max()))
+    print("penetration-branch queries: %d of %d; worst" % (pen_calls, n), worst)
+    assert pen_calls >= n // 2, pen_calls
+    assert worst["geom"] < 2e-6 and worst["pos"] < 1e-4 and worst["lin"] < 2e-3 and worst["ang"] < 2e-2 and worst["imp"] < 2e-3, worst
+    assert env.errors() == (0, 0)

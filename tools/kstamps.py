@@ -22,7 +22,7 @@ for k in range(K + 200):
     if k >= 200:
         st = (ctypes.c_ulonglong * (n // 64 * 16))()
         check(lib.evm_env_get_stamps(env._h, st))
-        rows.append(np.array(st, dtype=np.uint64)[:24].astype(np.float64))
+        rows.append(np.array(st, dtype=np.uint64)[:32].astype(np.float64))
 r = np.array(rows)
 for kind, name in ((0, "big-hull waves (4 queries of 16 lanes)"), (1, "small-hull waves (one env per lane)")):
     print("%-40s %7.1f per step, mean %8.0f cycles, longest %8.0f cycles" % (name, r[:, 3 * kind + 1].mean(), (r[:, 3 * kind] / np.maximum(r[:, 3 * kind + 1], 1)).mean(), r[:, 3 * kind + 2].mean()))
@@ -32,3 +32,10 @@ for kind, name in ((0, "big-hull"), (1, "small-hull")):
     ph = [(r[:, 8 + 4 * kind + k] / w).mean() for k in range(4)]
     print("%-10s per working wave: set-up + manifold loads %.0f, closest points (GJK) %.0f, refresh + manifold stores %.0f, contact record %.0f cycles%s"
           % (name, ph[0], ph[1], ph[2], ph[3], (", hull staging into LDS %.0f" % (r[:, 16] / w).mean()) if kind == 0 else ""))
+w = r[:, 1] + r[:, 4]
+print("queries that took the penetration branch: %.2f per step in %.2f wavefronts; GJK iterations of a wave's slowest lane: %.1f on average"
+      % (r[:, 17].mean(), r[:, 18].mean(), (r[:, 19] / np.maximum(w, 1)).mean()))
+for kind, name in ((0, "big-hull"), (1, "small-hull")):
+    it = np.maximum(r[:, 22 + 4 * kind], 1)
+    print("%-10s GJK loop trips %.1f per step (%.1f per working wave): supports (Minkowski difference) %.0f, rest of the iteration (simplex, exits) %.0f cycles per trip"
+          % (name, it.mean(), (it / np.maximum(r[:, 3 * kind + 1], 1)).mean(), (r[:, 20 + 4 * kind] / it).mean(), (r[:, 21 + 4 * kind] / it).mean()))
