@@ -113,6 +113,7 @@ def test_reset_and_rollout_with_member_contacts(torch_mod, orc_lib):
     p = env.body_poses().cpu().numpy()
     assert np.isfinite(p).all() and np.abs(p[..., :3]).max() < 50.0
     assert env.residual(clear=True) < 1e30
+    assert env.errors() == (0, 0)   # no version wait timed out, no manifold left out of a step
 
 
 # ---- known answers on the HIP backend (the same functions run on the oracle in tests/test_oracle_physics.py) ----

@@ -21,7 +21,10 @@ for k in range(n_dyn):
         assert p[..., :3].abs().max() < 50.0 and ((p[..., 3:].norm(dim=-1) - 1).abs().max() < 1e-4), k
         worst_res = max(worst_res, float(env.residual()))
 episodes = env.stats()
-print("dynamics: %d calls x %d envs in %.1f s, stats %s, worst batch residual %.3g" % (n_dyn, n, time.time() - t0, episodes, worst_res))
+errs = env.errors()   # (version waits that timed out, manifolds left out of a step): both must stay zero
+print("dynamics: %d calls x %d envs in %.1f s, stats %s, worst batch residual %.3g, error counters %s, member pairs %d"
+      % (n_dyn, n, time.time() - t0, episodes, worst_res, errs, env.n_pairs))
+assert errs[0] == 0, errs
 agent = VecPpoGaeAgent(7, [env.state_dim], [env.action_dim], hidden_size=256, device=0, horizon=32, epoch=8, learning_rate=3e-4)
 t0 = time.time(); updates = 0
 for k in range(n_ppo // 32):
