@@ -112,6 +112,20 @@ def cpu_baseline(seconds=12.0, self_collision=1):
                      if found else "Bullet3 probed for on this box and not found (no btBulletDynamicsCommon.h / libBulletDynamics, no pybullet)"),
         "bullet_probe": probe,
     }
+    if probe["harness_built"]:
+        # the reference's own physics library under our harness (oracle/bullet_harness.cpp, built by oracle/Makefile where Bullet3
+        # exists): one env, one thread, a bounded sample — then THIS is the baseline and the restatement's figure rides along
+        try:
+            import subprocess
+            skel = os.path.join(ROOT, "evomotion_amd", "data", "robot_walk_spider.skel")
+            o = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "bullet_harness"), skel, "--bench", str(seconds), "--self-collision", str(self_collision)],
+                               capture_output=True, timeout=4 * seconds + 60)
+            r = json.loads(o.stdout.decode().strip().splitlines()[-1])
+            out["port"] = {"value": out["value"], "sample": out["sample"]}
+            out.update(value=r["bullet_env_steps_per_s"], kind="reference",
+                       sample="%.1f s of do_step calls (resets included) on Bullet3 itself through oracle/bullet_harness.cpp, 1 env, 1 thread" % r["seconds"])
+        except Exception as e:
+            out["bullet_harness_error"] = str(e)
     try:
         import subprocess
         cores = host_cores()

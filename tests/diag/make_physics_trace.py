@@ -15,7 +15,16 @@ import orc  # noqa: E402
 N_ENV, N_STEP, EVERY = 4, 256, 4
 
 
-def trace(lib=None, self_collision=0):
+def hash_action(env, call, k):
+    """oracle/bullet_harness.cpp::hash_action — an action stream both programs can produce"""
+    h = ((env * 1000003 + call) * 2654435761 + k * 40503 + 12345) & 0xFFFFFFFF
+    h ^= h >> 13
+    h = (h * 0x5bd1e995) & 0xFFFFFFFF
+    h ^= h >> 15
+    return np.float32(np.float32(h & 0xFFFFFF) / np.float32(16777216.0)) * np.float32(2.0) - np.float32(1.0)
+
+
+def trace(lib=None, self_collision=0, hash_actions=False):
     rows = []
     for i in range(N_ENV):
         e = orc.OracleEnv(seed=1234 + i, lib=lib, self_collision=self_collision)
@@ -23,6 +32,8 @@ def trace(lib=None, self_collision=0):
         rng = np.random.default_rng(100 + i)
         for k in range(N_STEP):
             a = rng.uniform(-1, 1, 12).astype(np.float32)
+            if hash_actions:
+                a = np.array([hash_action(i, k, j) for j in range(12)], np.float32)
             if done:
                 obs, rew, done = e.reset()
             else:
@@ -35,6 +46,13 @@ def trace(lib=None, self_collision=0):
 
 
 if __name__ == "__main__":
+  if "--hash-actions" in sys.argv:
+    # the restatement's side of a comparison with `oracle/_ref/bullet_harness <fixture>` on a machine that has Bullet3: stdout, same format
+    mode = 0 if "--self-collision=0" in sys.argv else 1
+    print("# oracle/liborc.so, hash actions, self_collision=%d: env, call, done, reward, root xyz, sum |member positions|, sum(root block of the observation), sum |observation|" % mode)
+    for r in trace(self_collision=mode, hash_actions=True):
+        print("%d %d %d %s" % (r[0], r[1], r[2], " ".join("%.9g" % v for v in r[3:])))
+    sys.exit(0)
   for mode, name in ((0, "physics_trace.txt"), (1, "physics_trace_selfcol.txt")):
     t = trace(self_collision=mode)
     out = os.path.join(ROOT, "tests", "golden", name)
