@@ -293,54 +293,63 @@ __device__ __attribute__((noinline)) float g_slow_visit(int phase, unsigned w, i
 DEV int g_build_program(const GCtx &G, int nslots, const int (&nn)[EVM_MAX_MEMBERS], const unsigned (&pw)[EVM_PACT_WORDS], unsigned flags,
                         unsigned *prog, int *meta) {
     const int nm = c_skel.nm, np = c_skel.npair, nwords = (np + 31) >> 5;
-    unsigned nf[4] = {0u, 0u, 0u, 0u};  // next free round per member: 5 bits each, 6 members per word
-    int ord = 0, rmax = 0;
-    int left_out = 0;
-    auto place = [&](int id, int a, int b) {
-        auto getnf = [&](int m) {
-            const int wi = m / 6;
-            const unsigned w = wi == 0 ? nf[0] : (wi == 1 ? nf[1] : (wi == 2 ? nf[2] : nf[3]));
-            return (int) ((w >> ((m - 6 * wi) * 5)) & 31u);
-        };
-        auto setnf = [&](int m, int v) {
-            const int wi = m / 6;
-            const unsigned sh = (unsigned) (m - 6 * wi) * 5u, msk = ~(31u << sh), val = (unsigned) v << sh;
-            if (wi == 0) nf[0] = (nf[0] & msk) | val; else if (wi == 1) nf[1] = (nf[1] & msk) | val;
-            else if (wi == 2) nf[2] = (nf[2] & msk) | val; else nf[3] = (nf[3] & msk) | val;
-        };
-        const int r = max(a >= 0 ? getnf(a) : 0, getnf(b));
-        if (r > 30 || ord >= 2 * nslots) { left_out++; return; }
-        const int bank = ord >= nslots ? 1 : 0, slot = ord - bank * nslots;
-        prog[((bank * 16 + slot) << 4) + G.e] = g_prog_word(id, a, b, r);
-        if (a >= 0) setnf(a, r + 1);
-        setnf(b, r + 1);
-        rmax = max(rmax, r + 1);
-        ord++;
-    };
+    // Everything below lives in registers on purpose: plain scalars and macros, no lambdas, no arrays indexed at run time.  (A
+    // first form with reference-capturing lambdas and a four-word array kept its counters in scratch memory — 44 scratch loads,
+    // each waited for: 26 k of the kernel's 440 k ticks.)
+    static_assert(EVM_MAX_MEMBERS <= 24, "next-free-round table: 5 bits x 12 members per 64-bit word");
+    unsigned long long nf0 = 0ull, nf1 = 0ull;  // next free round per member, 5 bits each: members 0..11 in nf0, 12..23 in nf1
+    int ord = 0, rmax = 0, left_out = 0;
+#define G_NF_GET(m) ((int) ((((m) < 12 ? nf0 : nf1) >> (5 * ((m) < 12 ? (m) : (m) - 12))) & 31ull))
+#define G_NF_SET(m, v)                                                                                  \
+    {                                                                                                   \
+        const int sh_ = 5 * ((m) < 12 ? (m) : (m) - 12);                                                \
+        const unsigned long long msk_ = ~(31ull << sh_), val_ = (unsigned long long) (v) << sh_;         \
+        if ((m) < 12) nf0 = (nf0 & msk_) | val_; else nf1 = (nf1 & msk_) | val_;                         \
+    }
+#define G_PLACE(ID, A, B)                                                                               \
+    {                                                                                                   \
+        const int a_ = (A), b_ = (B);                                                                   \
+        const int ra_ = a_ >= 0 ? G_NF_GET(a_ >= 0 ? a_ : 0) : 0, rb_ = G_NF_GET(b_);                   \
+        const int r_ = max(ra_, rb_);                                                                   \
+        if (r_ > 30 || ord >= 2 * nslots) left_out++;                                                   \
+        else {                                                                                          \
+            const int bank_ = ord >= nslots ? 1 : 0, slot_ = ord - bank_ * nslots;                      \
+            prog[((bank_ * 16 + slot_) << 4) + G.e] = g_prog_word((ID), a_, b_, r_);                    \
+            if (a_ >= 0) G_NF_SET(a_ >= 0 ? a_ : 0, r_ + 1)                                             \
+            G_NF_SET(b_, r_ + 1)                                                                        \
+            rmax = max(rmax, r_ + 1);                                                                   \
+            ord++;                                                                                      \
+        }                                                                                               \
+    }
 #pragma unroll
-    for (int m = 0; m < EVM_MAX_MEMBERS; m++) {  // (unrolled: nn stays in registers)
+    for (int m = 0; m < EVM_MAX_MEMBERS; m++) {  // (unrolled: nn stays in registers, m is a constant)
         const bool act = m < nm && nn[m] > 0;
         if (!__any(act)) continue;
-        if (act) place(m, -1, m);
+        if (act) G_PLACE(m, -1, m)
     }
 #pragma unroll
-    for (int k = 0; k < (EVM_MAX_PAIRS + 31) / 32; k++) {
-        if (k >= nwords) break;
-        unsigned long long any = 0;  // pairs of this word active in some lane (wave-uniform walk over their union)
-        {
-            unsigned u = pw[k];
+    for (int k = 0; k < EVM_PACT_WORDS; k++) {   // (unrolled to the end: pw[k] is a register; words past the table are skipped)
+        if (k < nwords) {
+            unsigned long long any = 0;  // pairs of this word active in some lane (wave-uniform walk over their union)
+            {
+                unsigned u = pw[k];
 #pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) u |= __shfl_xor(u, o);
-            any = u;
-        }
-        while (any) {
-            const int bit = __builtin_ctzll(any);
-            any &= any - 1;
-            const int p = 32 * k + bit;
-            const bool act = (pw[k] >> bit) & 1u;
-            if (act) place(nm + p, (int) c_skel.pair[p].a, (int) c_skel.pair[p].b);
+                for (int o = 32; o >= 1; o >>= 1) u |= __shfl_xor(u, o);
+                any = u;
+            }
+            while (any) {
+                const int bit = __builtin_ctzll(any);
+                any &= any - 1;
+                const int p = 32 * k + bit;
+                const bool act = (pw[k] >> bit) & 1u;
+                const int pa = (int) c_skel.pair[p].a, pb = (int) c_skel.pair[p].b;
+                if (act) G_PLACE(nm + p, pa, pb)
+            }
         }
     }
+#undef G_PLACE
+#undef G_NF_SET
+#undef G_NF_GET
     // workgroup-wide facts
     if (rmax > 0) atomicMax(&meta[0], rmax);
     if (ord > nslots) atomicMax(&meta[1], 1);

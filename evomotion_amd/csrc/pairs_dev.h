@@ -231,12 +231,19 @@ DEV void pair_item(const Ctx &c, int p, bool drop, int lds_hull_off = -1) {
         return;
     }
     const float thr = PC.thr;
-    MPoint2 p0 = load_mp2(c, p, 0), p1 = load_mp2(c, p, 1), p2 = load_mp2(c, p, 2), p3 = load_mp2(c, p, 3);
     KS_MARK(0)
-    if (__any(overlap)) {
+    // The closest-point query first, the cached points after it: the query is one long dependent chain at the register limit of
+    // two waves per SIMD, and 48 registers of manifold points held across it were spilled inside its loop.
+    gj::Result r;
+    r.has = false; r.distance = 0.f; r.normalOnB = f3(0.f, 0.f, 0.f); r.pointOnB = f3(0.f, 0.f, 0.f); r.iterations = 0; r.used_pen = false;
+    const bool any_overlap = __any(overlap);
+    if (any_overlap) {
         const float md = MARGIN_F + MARGIN_F + thr;
-        const gj::Result r = gj::closest_points<GROUP>(SA, SB, md * md, overlap);
-        KS_MARK(1)
+        r = gj::closest_points<GROUP>(SA, SB, md * md, overlap);
+    }
+    KS_MARK(1)
+    MPoint2 p0 = load_mp2(c, p, 0), p1 = load_mp2(c, p, 1), p2 = load_mp2(c, p, 2), p3 = load_mp2(c, p, 3);
+    if (any_overlap) {
         const bool add = r.has && !(r.distance > thr);
         if (add) {
             // btManifoldResult::addContactPoint(normalOnBInWorld, pointInWorld, depth)

@@ -472,7 +472,7 @@ __global__ __launch_bounds__(64 * EVM_G_MAX_WAVES) void k_sweeps_g(EnvDev d, con
     float *ptl = imt + ((nb + 3) & ~3);  // [6 nm][16 envs] push / turn velocities of the members during the split-impulse phase
     auto slow = [&](int phase, int r) -> float { return g_slow_visit(phase, w1, r, G.qb, ce, imt, crec_lane, ptl); };
 #ifdef EVM_GSTAMPS
-    unsigned long long gs_c0 = __builtin_amdgcn_s_memtime(), gs_c1 = gs_c0, gs_c2 = gs_c0, gs_c3 = gs_c0;
+    unsigned long long gs_c0 = __builtin_amdgcn_s_memtime(), gs_c1 = gs_c0, gs_c2 = gs_c0, gs_c3 = gs_c0, gs_cb = gs_c0;
 #endif
     if (scm) {  // (program, words and inverse masses were initialised by every thread before the barrier above)
         {
@@ -483,6 +483,10 @@ __global__ __launch_bounds__(64 * EVM_G_MAX_WAVES) void k_sweeps_g(EnvDev d, con
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#ifdef EVM_GSTAMPS
+        __builtin_amdgcn_s_waitcnt(0);
+        gs_cb = __builtin_amdgcn_s_memtime();
+#endif
         nrounds = __builtin_amdgcn_readfirstlane(meta[4 * wave]);
         use_b1 = __builtin_amdgcn_readfirstlane(meta[4 * wave + 1]) != 0;
         g_bank_load(cc, prog[(cs << 4) + ce], K0);
@@ -493,6 +497,7 @@ __global__ __launch_bounds__(64 * EVM_G_MAX_WAVES) void k_sweeps_g(EnvDev d, con
             }
         }
 #ifdef EVM_GSTAMPS
+        __builtin_amdgcn_s_waitcnt(0);   // (the owners' records have landed)
         gs_c1 = __builtin_amdgcn_s_memtime();
 #endif
         if (__builtin_amdgcn_readfirstlane(meta[4 * wave + 2]) != 0) {
@@ -739,7 +744,7 @@ __global__ __launch_bounds__(64 * EVM_G_MAX_WAVES) void k_sweeps_g(EnvDev d, con
         for (int q = 0; q < 5; q++) { st[2 * q] = gs_type[q]; st[2 * q + 1] = gs_n[q]; }
         st[10] = gs_t1 - gs_t0; st[11] = gs_t2 - gs_t1; st[12] = __builtin_amdgcn_s_memtime() - gs_t2;
         st[13] = gs_ta - gs_t0; st[14] = gs_tb - gs_ta; st[15] = gs_tc - gs_tb;
-        if (scm) { st[13] = gs_c1 - gs_c0; st[14] = gs_c2 - gs_c1; st[15] = gs_c3 - gs_c2; }  // program + records, split impulse, warm start
+        if (scm) { st[13] = gs_cb - gs_c0; st[14] = gs_c1 - gs_cb; st[15] = gs_c3 - gs_c1; st[5] = gs_c0 - gs_t0; }  // program, owners' records, split impulse + warm start; [5] (no plain slider entries in this mode): before the contact set-up
     }
 #endif
 }

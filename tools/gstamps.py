@@ -27,10 +27,13 @@ if "--waves" in sys.argv:  # -DEVM_GSTAMPS2 build: per wave
         print("wave %d: sweeps phase %.0f cycles, waiting for versions %.0f (%.0f %%), %d entries, prologue %.0f" % (w, acc[4 * w], acc[4 * w + 1], 100 * acc[4 * w + 1] / max(acc[4 * w], 1), acc[4 * w + 2], acc[4 * w + 3]))
     sys.exit(0)
 for q, name in enumerate(["hinge", "fixed", "slider", "p2p", "contact"]):
+    if q == 2 and env.n_pairs:
+        print("contact rounds alone (no barriers) %8.0f cycles per step" % acc[4])
+        continue
     print("%-8s %7.0f cycles/entry  %6.1f entries per step (wave 0)  %8.0f cycles per step" % (name, acc[2 * q] / max(acc[2 * q + 1], 1), acc[2 * q + 1], acc[2 * q]))
 if env.n_pairs:   # member-vs-member mode: slots 13..15 hold the contact set-up phases, the "contact" line is the contact rounds of a sweep
-    print("prologue %.0f (of it: contact program + owners' records %.0f, split-impulse recovery %.0f, warm start %.0f)  sweeps %.0f  epilogue %.0f cycles (wave 0); contact line = cycles per round-phase"
-          % (acc[10], acc[13], acc[14], acc[15], acc[11], acc[12]))
+    print("prologue %.0f (of it: record image + bodies + barrier %.0f, contact program %.0f, owners' records %.0f, split-impulse recovery + warm start %.0f)  sweeps %.0f  epilogue %.0f cycles (wave 0); contact line = cycles per round-phase"
+          % (acc[10], acc[5], acc[13], acc[14], acc[15], acc[11], acc[12]))
 else:
     print("prologue %.0f (table %.0f, records %.0f, bodies %.0f, manifold counts + barrier %.0f)  sweeps %.0f  epilogue %.0f cycles (wave 0)"
           % (acc[10], acc[13], acc[14], acc[15], acc[10] - acc[13] - acc[14] - acc[15], acc[11], acc[12]))
