@@ -147,6 +147,21 @@ DEV F3 support_group(int hull_off, int hull_n, F3 dir, int lds_hull_off) {
     return f3(c_skel.hull[hb], c_skel.hull[hb + 2], c_skel.hull[hb + 4]);
 }
 
+// Support vertex of a hull held in LDS for a direction of the lane's own (all lanes read the same vertex at a time: a broadcast
+// read); first maximum in table order like support() — used by the penetration branch of the grouped form
+DEV F3 support_lane_lds(int hull_off, int hull_n, F3 dir) {
+    const gj_f4 *lh = g_lds_hull + hull_off;
+    float best = -GJ_LARGE;
+    int bi = 0;
+    for (int v = 0; v < hull_n; v++) {
+        const gj_f4 w = lh[v];
+        const float d = (dir.x * w[0] + dir.y * w[1]) + dir.z * w[2];
+        if (d > best) { best = d; bi = v; }
+    }
+    const gj_f4 w = lh[bi];
+    return f3(w[0], w[1], w[2]);
+}
+
 struct Shape {  // one member's hull and world transform (the basis may be non-orthonormal in the step that follows reset())
     int hull_off, hull_n;
     int lds_hull_off;  // GROUP mode: hull table offset of the hull the block holds in LDS (-1: none)
@@ -538,7 +553,7 @@ DEV Result closest_points(const Shape &A, const Shape &B, float max_dist2, bool 
         // btMinkowskiPenetrationDepthSolver::calcPenDepth
         float minProj = GJ_LARGE;
         F3 minNorm = f3(0.f, 0.f, 0.f);
-        if (GROUP) {
+        if (GROUP && A.lds_hull_off != -2) {   // (the block holds one hull only: the sequential form, row by row)
             for (int i = 0; i < 42; i++) {
                 const F3 norm = f3(kPenDirs[i][0], kPenDirs[i][1], kPenDirs[i][2]);
                 F3 pW, qW;
@@ -547,9 +562,11 @@ DEV Result closest_points(const Shape &A, const Shape &B, float max_dist2, bool 
                 if (delta < minProj) { minProj = delta; minNorm = norm; }
             }
         } else {
-            // One query per lane, and the branch is rare (a few queries per 18 000): the 42 directions of ONE such query go to 42
-            // lanes of the wavefront — its transforms broadcast, the hulls are wave-uniform anyway — and a shuffle reduction returns
-            // the sequential loop's answer (smallest projection, the FIRST direction on a tie: `delta < minProj` is strict).
+            // The branch is rare (a few queries per 18 000) and, run as a loop, the longest thing a wavefront can do (42 x two
+            // hull scans: a grouped wave took 300 k ticks for it, three times a whole query).  So the 42 directions of ONE such
+            // query go to 42 lanes of the wavefront — its transforms broadcast; the hulls are wave-uniform in the one-query-per-
+            // lane form and sit in LDS in the grouped form — and a lane-by-lane reduction returns the sequential loop's answer
+            // (smallest projection, the FIRST direction on a tie: `delta < minProj` is strict).
             // (a ragged wavefront has fewer than 64 lanes: its lanes take several directions each, in increasing order)
             const int lane = (int) (threadIdx.x & 63);
             const unsigned long long act = __ballot(true);
@@ -557,10 +574,12 @@ DEV Result closest_points(const Shape &A, const Shape &B, float max_dist2, bool 
             unsigned long long todo = __ballot(need_pen);
             while (todo) {
                 const int src = (int) __builtin_ctzll(todo);
-                todo &= todo - 1;
+                todo &= GROUP ? ~(0xFFFFull << (src & ~15)) : todo - 1;   // (grouped: the 16 lanes of a row are one query)
                 auto bc = [&](float x) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), src)); };
                 auto bc3 = [&](F3 x) { return f3(bc(x.x), bc(x.y), bc(x.z)); };
                 Shape As = A, Bs = B;
+                As.hull_off = __builtin_amdgcn_readlane(A.hull_off, src); As.hull_n = __builtin_amdgcn_readlane(A.hull_n, src);   // (grouped: rows hold different pairs)
+                Bs.hull_off = __builtin_amdgcn_readlane(B.hull_off, src); Bs.hull_n = __builtin_amdgcn_readlane(B.hull_n, src);
                 As.R = m33(bc3(A.R.r0), bc3(A.R.r1), bc3(A.R.r2)); Bs.R = m33(bc3(B.R.r0), bc3(B.R.r1), bc3(B.R.r2));
                 const F3 oAs = bc3(oA), oBs = bc3(oB);
                 float dl = GJ_LARGE;
@@ -569,7 +588,11 @@ DEV Result closest_points(const Shape &A, const Shape &B, float max_dist2, bool 
                     const int i = rank + k * nact, ii = i < 42 ? i : 0;
                     const F3 norm = f3(kPenDirs[ii][0], kPenDirs[ii][1], kPenDirs[ii][2]);
                     F3 pW, qW;
-                    minkowski<false>(As, oAs, Bs, oBs, norm, pW, qW);
+                    if (GROUP) {  // (lane-private direction, hulls from LDS: the row's lanes work apart here)
+                        const F3 sA = gj::vmul(gj::neg(norm), As.R), sB = gj::vmul(norm, Bs.R);
+                        pW = gj::xform(As.R, oAs, gj::support_lane_lds(As.hull_off, As.hull_n, sA));
+                        qW = gj::xform(Bs.R, oBs, gj::support_lane_lds(Bs.hull_off, Bs.hull_n, sB));
+                    } else minkowski<false>(As, oAs, Bs, oBs, norm, pW, qW);
                     const float delta = gj::dot(norm, gj::sub(qW, pW));
                     if (i < 42 && delta < dl) { dl = delta; ix = i; }
                 }
@@ -588,7 +611,8 @@ DEV Result closest_points(const Shape &A, const Shape &B, float max_dist2, bool 
                 }
                 dl = bd; ix = bx;
                 const int jx = ix < 42 ? ix : 0;
-                if (lane == src && dl < minProj) { minProj = dl; minNorm = f3(kPenDirs[jx][0], kPenDirs[jx][1], kPenDirs[jx][2]); }
+                const bool mine = GROUP ? (lane >> 4) == (src >> 4) : lane == src;
+                if (mine && dl < minProj) { minProj = dl; minNorm = f3(kPenDirs[jx][0], kPenDirs[jx][1], kPenDirs[jx][2]); }
             }
         }
         const bool overlap = !(minProj < 0.f);

@@ -138,15 +138,18 @@ def test_known_answer_folded_arm_stops_at_the_body(tmp_path):
     assert deep0 < -0.02, deep0
 
 
-def test_deep_interpenetration_takes_the_penetration_branch(tmp_path, orc_lib):
+@pytest.mark.parametrize("shape_b", ["cube", "feet"])
+def test_deep_interpenetration_takes_the_penetration_branch(tmp_path, orc_lib, shape_b):
     """Cores that interpenetrate (GJK ends degenerate with the cores touching: btGjkPairDetector's catchDegeneracies / the invalid
     result) go through the penetration-depth solver — 42 sphere directions + a nested GJK run on the displaced pair.
     Random rollouts reach it a few times per 18 000 queries, so it gets a scene of its own: 70 pairs of boxes (more than one
     wavefront's worth: a full wave and a ragged one) set inside each other at random offsets and rotations, one physics step from
     identical state on the oracle and on the HIP path — in one-query-per-lane form the kernel deals the 42 directions of such a
-    query to the lanes of its wavefront."""
+    query to the lanes of its wavefront.  shape_b = "feet": the 451-vertex hull, i.e. the grouped form of the narrowphase (one
+    query per 16-lane row, hulls in LDS), where the directions go to the lanes of all four rows."""
     from evomotion_amd import VecRobotWalk
-    sk = pc.skel_two_free_boxes(write_skeleton, tmp_path, half_b=(0.3, 0.25, 0.2))
+    sk = write_skeleton(tmp_path / "two_bodies.skel", [dict(name="body", mass=4.0, scale=(0.5, 0.2, 0.5)),
+                                                       dict(name="other", mass=0.5, t=(0.0, 1.0, 0.0), scale=(0.3, 0.25, 0.2), shape=shape_b)])
     n = 70
     env = VecRobotWalk(n, seed=1, device=0, parameters={"skeleton_json_path": sk, "self_collision": 1})
     env.debug_reset_begin()
