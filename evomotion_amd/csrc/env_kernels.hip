@@ -1953,13 +1953,11 @@ __global__ __launch_bounds__(64 * EVM_SPLIT_WAVES) void k_split_pre_a(EnvDev d, 
 #ifndef EVM_PRE_B_WAVES
 #define EVM_PRE_B_WAVES 3
 #endif
+// The items of k_split_pre_b for the virtual wave vw of nvw (a function of its own: the narrowphase kernel's record blocks run
+// the same items, k_split_pairs_rec below)
 template <int MODE>
-__global__ __launch_bounds__(64 * EVM_SPLIT_WAVES) __attribute__((amdgpu_waves_per_eu(EVM_PRE_B_WAVES, EVM_PRE_B_WAVES))) void k_split_pre_b(EnvDev d, const float *__restrict__ action,
-                                                                        const uint8_t *__restrict__ mask, int broad) {
-    Ctx c = make_ctx(d, tile_stage(d));
-    EVM_SPLIT_GUARD()
-    const LaneState L = lane_state<MODE>(c);
-    const int vw = blockIdx.y * EVM_SPLIT_WAVES + c.wave, nvw = gridDim.y * EVM_SPLIT_WAVES;
+DEV void pre_b_items(const Ctx &c, const LaneState &L, int vw, int nvw, const float *__restrict__ action, int broad, int tile_ix) {
+    (void) tile_ix;
     const bool powered = (L.flags & EVM_FLAG_POWERED) != 0 || ((MODE & 1) && !L.settling);
 #ifdef EVM_STAMPS5
     int s5_kind = -1;
@@ -1977,7 +1975,7 @@ __global__ __launch_bounds__(64 * EVM_SPLIT_WAVES) __attribute__((amdgpu_waves_p
 #ifdef EVM_STAMPS5  // diagnostic: longest item of each kind, per tile (cycles); tools/stamps5.py
         {
             const unsigned long long now = __builtin_amdgcn_s_memtime();
-            if (s5_kind >= 0 && c.lane == 0) atomicMax(&c.d.stamps[(size_t) blockIdx.x * 16 + s5_kind], now - s5_t0);
+            if (s5_kind >= 0 && c.lane == 0) atomicMax(&c.d.stamps[(size_t) tile_ix * 16 + s5_kind], now - s5_t0);
             s5_kind = j < c_skel.nm ? (c_skel.member[j].hull_n > 64 ? 5 : 4) : c_skel.visit[j - c_skel.nm].type;
             s5_t0 = now;
         }
@@ -1995,7 +1993,7 @@ __global__ __launch_bounds__(64 * EVM_SPLIT_WAVES) __attribute__((amdgpu_waves_p
             else if (__any(L.fin)) { if (L.fin) GS(mfn, m) = 0; }
 #ifdef EVM_STAMPS5  // slots 6 / 7: longest manifold update, longest contact-row setup of a member
             const unsigned long long s5_b = __builtin_amdgcn_s_memtime();
-            if (c.lane == 0) atomicMax(&c.d.stamps[(size_t) blockIdx.x * 16 + 6], s5_b - s5_a);
+            if (c.lane == 0) atomicMax(&c.d.stamps[(size_t) tile_ix * 16 + 6], s5_b - s5_a);
 #endif
             const bool touching = __any(n > 0);
             if (c_skel.self_collision) {
@@ -2007,7 +2005,7 @@ __global__ __launch_bounds__(64 * EVM_SPLIT_WAVES) __attribute__((amdgpu_waves_p
             }
             if (touching) contact_setup(c, m, n, pts);
 #ifdef EVM_STAMPS5
-            if (c.lane == 0) atomicMax(&c.d.stamps[(size_t) blockIdx.x * 16 + 7], __builtin_amdgcn_s_memtime() - s5_b);
+            if (c.lane == 0) atomicMax(&c.d.stamps[(size_t) tile_ix * 16 + 7], __builtin_amdgcn_s_memtime() - s5_b);
 #endif
             if (!touching) { SSC3(c_skel.sc_pt + 6 * m, f3(0.f, 0.f, 0.f)); SSC3(c_skel.sc_pt + 6 * m + 3, f3(0.f, 0.f, 0.f)); }
             continue;
@@ -2027,8 +2025,18 @@ __global__ __launch_bounds__(64 * EVM_SPLIT_WAVES) __attribute__((amdgpu_waves_p
         }
     }
 #ifdef EVM_STAMPS5
-    if (s5_kind >= 0 && c.lane == 0) atomicMax(&c.d.stamps[(size_t) blockIdx.x * 16 + s5_kind], __builtin_amdgcn_s_memtime() - s5_t0);
+    if (s5_kind >= 0 && c.lane == 0) atomicMax(&c.d.stamps[(size_t) tile_ix * 16 + s5_kind], __builtin_amdgcn_s_memtime() - s5_t0);
 #endif
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64 * EVM_SPLIT_WAVES) __attribute__((amdgpu_waves_per_eu(EVM_PRE_B_WAVES, EVM_PRE_B_WAVES))) void k_split_pre_b(EnvDev d, const float *__restrict__ action,
+                                                                        const uint8_t *__restrict__ mask, int broad) {
+    Ctx c = make_ctx(d, tile_stage(d));
+    EVM_SPLIT_GUARD()
+    const LaneState L = lane_state<MODE>(c);
+    const int vw = blockIdx.y * EVM_SPLIT_WAVES + c.wave, nvw = gridDim.y * EVM_SPLIT_WAVES;
+    pre_b_items<MODE>(c, L, vw, nvw, action, broad, (int) blockIdx.x);
 }
 
 // Member-vs-member mode with the narrowphase on a side stream: the broadphase items alone (they need k_split_pre_a's poses only)
@@ -2054,8 +2062,7 @@ __global__ __launch_bounds__(64 * EVM_SPLIT_WAVES) void k_split_broad(EnvDev d, 
 #define EVM_PAIRS_WAVES 2   // wavefronts per SIMD the narrowphase kernel is compiled for (128 arch VGPRs + AGPR spill space at 2)
 #endif
 template <int MODE>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EVM_PAIRS_WAVES, EVM_PAIRS_WAVES))) void k_split_pairs(EnvDev d, const uint8_t *__restrict__ mask, int tiles) {
-    (void) mask;  // (masked-out envs never enter a list)
+DEV void narrow_block(const EnvDev &d, int blk, int tiles) {
 #ifdef EVM_KSTAMPS  // diagnostic build (tools/kstamps.py): working wavefronts of the narrowphase kernel, cycles and extent
     struct KStamp {
         unsigned long long *st, t0, r0; int kind;
@@ -2069,9 +2076,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EVM_PAIRS_WA
     } ks;
     ks.st = nullptr;
 #endif
-    if ((int) blockIdx.x < EVM_BIG_BLOCKS) {
+    if (blk < EVM_BIG_BLOCKS) {
         const int cnt = d.pcount[c_skel.npair];
-        if ((int) blockIdx.x * 4 >= cnt) return;
+        if (blk * 4 >= cnt) return;
 #ifdef EVM_KSTAMPS
         ks.begin(d.stamps, 0);
 #endif
@@ -2088,7 +2095,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EVM_PAIRS_WA
 #ifdef EVM_KSTAMPS
         if (threadIdx.x == 0) atomicAdd(&d.stamps[16], __builtin_amdgcn_s_memtime() - ks.t0);  // hull staging
 #endif
-        for (int i0 = blockIdx.x * 4; i0 < cnt; i0 += EVM_BIG_BLOCKS * 4) {
+        for (int i0 = blk * 4; i0 < cnt; i0 += EVM_BIG_BLOCKS * 4) {
             const int i = i0 + (int) (threadIdx.x >> 4);
             if (i < cnt) {  // (a row without an entry sits the iteration out; rows are independent of each other)
                 const int e = d.blist[i], p = e >> 20, env = e & 0xfffff;
@@ -2099,7 +2106,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EVM_PAIRS_WA
         }
         return;
     }
-    const int bx = (int) blockIdx.x - EVM_BIG_BLOCKS;
+    const int bx = blk - EVM_BIG_BLOCKS;
     const int p = c_skel.pair_order[bx / tiles];
     const int cnt = d.pcount[p], base = (bx % tiles) * 64;
     if (base >= cnt) return;
@@ -2112,6 +2119,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EVM_PAIRS_WA
     const Ctx c = make_ctx_env(d, env);
     const bool fin = (MODE & 4) && (d.flags[env] & EVM_FLAG_DONE) != 0;
     pair_item<false>(c, p, fin);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EVM_PAIRS_WAVES, EVM_PAIRS_WAVES))) void k_split_pairs(EnvDev d, const uint8_t *__restrict__ mask, int tiles) {
+    (void) mask;  // (masked-out envs never enter a list)
+    narrow_block<MODE>(d, (int) blockIdx.x, tiles);
 }
 
 __global__ __launch_bounds__(64 * EVM_NW) void k_split_sweeps(EnvDev d, const uint8_t *__restrict__ mask, int autoreset) {
@@ -2340,6 +2353,24 @@ __global__ __launch_bounds__(64) void k_env_poses(EnvDev d, float *out) {
 
 }  // namespace evm
 #include "sweep_groups.h"
+namespace evm {
+// Narrowphase + the setup kernel's records in ONE launch (member-vs-member mode, the default pipeline): the narrowphase is a few
+// hundred latency-bound wavefronts that leave most of the chip idle for 80 us, and the joint / floor records of k_split_pre_b
+// depend on nothing it produces.  Blocks [0, narrow) are narrow_block's, the rest are k_split_pre_b's virtual waves (one 64-lane
+// block each, the long narrowphase blocks first in dispatch order).  The broadphase items run before, in k_split_broad.
+template <int MODE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EVM_PAIRS_WAVES, EVM_PAIRS_WAVES))) void k_split_pairs_rec(EnvDev d, const float *__restrict__ action,
+                                                                        const uint8_t *__restrict__ mask, int tiles, int nvw) {
+    const int narrow = EVM_BIG_BLOCKS + tiles * d.npair_host;
+    if ((int) blockIdx.x < narrow) { narrow_block<MODE>(d, (int) blockIdx.x, tiles); return; }
+    const int rb = (int) blockIdx.x - narrow, tile = rb / nvw, vw = rb - tile * nvw;
+    const Ctx c = make_ctx_at(d, d.gtile + (size_t) tile * d.tile_floats, tile, (int) threadIdx.x, 0);
+    if (c.env >= d.n_real) return;
+    if (mask && !mask[c.env]) return;
+    const LaneState L = lane_state<MODE>(c);
+    pre_b_items<MODE>(c, L, vw, nvw, action, 0, tile);
+}
+}  // namespace evm
 #ifdef EVM_ISA_PROBE
 namespace evm {
 // Diagnostic (tools/chain_isa.py): the row arithmetic of ONE hinge visit and of one link of the root's hinge chain as kernels of
@@ -2422,10 +2453,11 @@ static hipError_t launch_split(const EnvDev &d, size_t lds, const float *action,
     if (parts > 32) parts = 32;
     const dim3 gp(tiles, parts), bp(64 * EVM_SPLIT_WAVES);
     hipLaunchKernelGGL((k_split_pre_a<MODE>), gp, bp, 0, s, d, mask);
+    static int merge = -1;   // EVM_PAIRS_MERGE=0: the narrowphase and the records as two launches (A/B)
+    if (merge < 0) { const char *e = getenv("EVM_PAIRS_MERGE"); merge = (e && e[0] == '0') ? 0 : 1; }
     if (d.pmn && side) {
-        // The narrowphase is a few long, latency-bound wavefronts (GJK chains) that leave most of the chip idle, and the joint /
-        // floor records of k_split_pre_b do not depend on it: broadphase first, then the narrowphase on the side stream BESIDE
-        // k_split_pre_b, joined before the sweeps.
+        // (opt-in, EVM_PAIRS_OVERLAP=1) the narrowphase on a side stream BESIDE k_split_pre_b: measured slower than one stream —
+        // the two events cost more than they hide; the merged launch below does the same without them
         hipLaunchKernelGGL((k_split_broad<MODE>), gp, bp, 0, s, d, mask);
         hipError_t e = hipEventRecord(side->fork, s);
         if (e == hipSuccess) e = hipStreamWaitEvent(side->stream, side->fork, 0);
@@ -2436,6 +2468,10 @@ static hipError_t launch_split(const EnvDev &d, size_t lds, const float *action,
         hipLaunchKernelGGL((k_split_pre_b<MODE>), gp, bp, 0, s, d, action, mask, 0);
         e = hipStreamWaitEvent(s, side->join, 0);
         if (e != hipSuccess) return e;
+    } else if (d.pmn && merge) {
+        const int nvw = parts * EVM_SPLIT_WAVES;
+        hipLaunchKernelGGL((k_split_broad<MODE>), gp, bp, 0, s, d, mask);
+        hipLaunchKernelGGL((k_split_pairs_rec<MODE>), dim3(EVM_BIG_BLOCKS + tiles * d.npair_host + tiles * nvw), dim3(64), 0, s, d, action, mask, tiles, nvw);
     } else {
         hipLaunchKernelGGL((k_split_pre_b<MODE>), gp, bp, 0, s, d, action, mask, 1);
         if (d.pmn) hipLaunchKernelGGL((k_split_pairs<MODE>), dim3(EVM_BIG_BLOCKS + tiles * d.npair_host), dim3(64), 0, s, d, mask, tiles);

@@ -1161,10 +1161,11 @@ int build_group_schedule(const EvmSkelC &S, int nwaves, EvmGSchedC &G, std::stri
     if (ne > EVM_G_MAX_ENTRIES) { err = "group schedule overflow"; return EVM_E_UNSUPPORTED; }
     // ---- score: the ten back-to-back sweeps with fixed per-wave lists; improve by moving entries between waves ----
     const float balance_w = getenv("EVM_G_BALANCE") ? (float) atof(getenv("EVM_G_BALANCE")) : 0.f;  // (A/B knob)
+    const bool barrier_model = !(getenv("EVM_G_BARRIER_MODEL") && getenv("EVM_G_BARRIER_MODEL")[0] == '0');  // (A/B knob)
     auto simulate = [&](const std::vector<int> &asg) -> float {
         std::vector<float> wave_t(nwaves, 0.f), ready(S.nb, 0.f);
         std::vector<int> lastw(S.nb, -1);
-        for (int sweep = 0; sweep < 10; sweep++)
+        for (int sweep = 0; sweep < 10; sweep++) {
             for (int e = 0; e < ne; e++) {
                 const int w = asg[e];
                 float st = wave_t[w];
@@ -1177,6 +1178,16 @@ int build_group_schedule(const EvmSkelC &S, int nwaves, EvmGSchedC &G, std::stri
                 wave_t[w] = fn;
                 for (int i : ents[e].vis) { ready[vs[i].a] = ready[vs[i].b] = fn; lastw[vs[i].a] = lastw[vs[i].b] = w; }
             }
+            // member-vs-member mode: the contact rounds sit between two workgroup barriers after every sweep's joint rows, so the
+            // sweeps do not flow into each other — every sweep starts from a common time and what counts is ONE sweep's makespan
+            if (!with_contacts && barrier_model) {
+                float mx = 0.f;
+                for (float t : wave_t) mx = std::max(mx, t);
+                std::fill(wave_t.begin(), wave_t.end(), mx);
+                std::fill(ready.begin(), ready.end(), mx);
+                std::fill(lastw.begin(), lastw.end(), -1);
+            }
+        }
         float m = 0.f;
         for (float t : wave_t) m = std::max(m, t);
         // tie-break towards balanced waves: the cost model is approximate, and the busiest wave is the one that cannot absorb
