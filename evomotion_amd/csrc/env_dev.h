@@ -25,7 +25,9 @@ struct EnvDev {
     float *crec;                    // [(nm+npair)*84][n] two-body contact records of the step (EVM_CR_STRIDE), by manifold id
     int *plist;                     // [npair][n] per pair: the envs whose boxes overlap or that hold a cached point (this step)
     int *blist;                     // [n * npair] (pair << 20 | env) entries of the pairs with a big hull, one flat list
-    int *pcount;                    // [npair + 1] the lists' lengths, [npair] = the flat list's (zeroed by the first setup kernel)
+    int *pcount;                    // [2][EVM_MAX_PAIRS + 1] the lists' lengths, [npair] = the flat list's; two copies: a step appends to
+                                    // copy pc_cur and zeroes the other one for the next step (the host flips pc_cur per launch)
+    int pc_cur;
     int npair_host;                 // EvmSkelC::npair, for the launch geometry
     float *target;                  // [nmus][n]  slider target velocity
     int *flags, *curr_step, *remaining, *settle_left;  // [n]
@@ -51,12 +53,9 @@ hipError_t upload_skeleton(const EvmSkelC *h, hipStream_t s);
 size_t step_lds_bytes(int nb, int nscan);
 // split = 1: pre / sweeps / post kernels (the throughput phases spread over the whole chip); 0: one monolithic kernel
 // ev_sweeps0/1 (optional): recorded around the sweeps kernel of the split pipeline
-// side (optional, member-vs-member mode): the env's own side stream + fork / join events — the narrowphase kernel runs on it
-// beside k_split_pre_b
-struct StepSide { hipStream_t stream; hipEvent_t fork, join; };
 hipError_t launch_step(const EnvDev &d, size_t lds_bytes, int split, int mode, const float *action, float *obs, float *reward,
                        uint8_t *done, uint8_t *valid, const uint8_t *mask, hipStream_t s, hipEvent_t ev_sweeps0 = nullptr,
-                       hipEvent_t ev_sweeps1 = nullptr, const StepSide *side = nullptr);
+                       hipEvent_t ev_sweeps1 = nullptr);
 hipError_t launch_repose(const EnvDev &d, const uint8_t *mask, hipStream_t s);
 hipError_t launch_init(const EnvDev &d, uint64_t seed, hipStream_t s);
 hipError_t launch_poses(const EnvDev &d, float *out, hipStream_t s);

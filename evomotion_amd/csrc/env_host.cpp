@@ -48,7 +48,6 @@ struct EvmEnv {
     int split;  // -1: by batch size (default), 1: split pipeline, 0: monolithic step kernel (EVM_MONOLITHIC=0/1 forces: A/B runs)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_sweeps;  // timed launches: around the sweeps kernel of the split pipeline
     void *gsched;  // device copy of the lane-group sweep schedule (EvmGSchedC), or null
-    evm::StepSide side;  // member-vs-member mode: side stream + events of the narrowphase (null stream: not in use; EVM_PAIRS_OVERLAP=0)
 };
 
 #ifndef EVM_MAX_DEVICES
@@ -111,7 +110,6 @@ int evm_env_create(const char *skeleton_path, int n_envs, int device, uint64_t s
     env->prm = prm;
     env->device = device;
     env->arena = nullptr;
-    env->side.stream = nullptr; env->side.fork = env->side.join = nullptr;
     env->timing = false;
     env->timed_launches = 0;
     env->ev_used = 0;
@@ -149,7 +147,7 @@ int evm_env_create(const char *skeleton_path, int n_envs, int device, uint64_t s
         segs.push_back({(void **) &env->d.crec, (size_t) EVM_CR_STRIDE * (S.nm + S.npair)});
         segs.push_back({(void **) &env->d.plist, (size_t) (S.npair > 0 ? S.npair : 1)});
         segs.push_back({(void **) &env->d.blist, (size_t) (S.npair > 0 ? S.npair : 1)});
-        segs.push_back({(void **) &env->d.pcount, (size_t) (EVM_MAX_PAIRS + 1 + 63) / 64});  // >= EVM_MAX_PAIRS + 1 ints whatever the batch (n >= 64)
+        segs.push_back({(void **) &env->d.pcount, (size_t) (2 * (EVM_MAX_PAIRS + 1) + 63) / 64});  // >= 2 x (EVM_MAX_PAIRS + 1) ints whatever the batch (n >= 64)
     }
     size_t total = 0;
     for (auto &s : segs) total += s.count * n * 4;
@@ -188,17 +186,6 @@ int evm_env_create(const char *skeleton_path, int n_envs, int device, uint64_t s
         evm_env_destroy(env);
         return fail(EVM_E_UNSUPPORTED, "self_collision = 1 needs the lane-group sweeps kernel, which this skeleton (or EVM_SWEEPS=tile) rules out");
     }
-    {
-        const char *ov = getenv("EVM_PAIRS_OVERLAP");
-        // opt-in (EVM_PAIRS_OVERLAP=1): measured on MI355X at 4096 envs the fork / join through two events costs more than the
-        // 27 us of k_split_pre_b it hides (step 0.4153 ms with, 0.4052 ms without)
-        if (S.self_collision && ov && ov[0] == '1') {
-            he = hipStreamCreateWithFlags(&env->side.stream, hipStreamNonBlocking);
-            if (he == hipSuccess) he = hipEventCreateWithFlags(&env->side.fork, hipEventDisableTiming);
-            if (he == hipSuccess) he = hipEventCreateWithFlags(&env->side.join, hipEventDisableTiming);
-            if (he != hipSuccess) { evm_env_destroy(env); return fail(EVM_E_HIP, std::string("side stream: ") + hipGetErrorString(he)); }
-        }
-    }
     // a new env always uploads (its address may be a destroyed owner's); the device's previous owner may have kernels in flight
     if (g_skel_owner[device] != nullptr) (void) hipDeviceSynchronize();
     g_skel_owner[device] = nullptr;
@@ -214,9 +201,6 @@ int evm_env_create(const char *skeleton_path, int n_envs, int device, uint64_t s
 void evm_env_destroy(EvmEnv *env) {
     if (!env) return;
     if (env->device >= 0 && env->device < EVM_MAX_DEVICES && g_skel_owner[env->device] == env) g_skel_owner[env->device] = nullptr;
-    if (env->side.stream) { (void) hipStreamSynchronize(env->side.stream); (void) hipStreamDestroy(env->side.stream); }
-    if (env->side.fork) (void) hipEventDestroy(env->side.fork);
-    if (env->side.join) (void) hipEventDestroy(env->side.join);
     if (env->arena) hipFree(env->arena);
     if (env->gsched) hipFree(env->gsched);
     (void) hipEventDestroy(env->ev0);
@@ -261,11 +245,11 @@ static int step_launch(EvmEnv *env, int mode, const float *a, float *obs, float 
         }
         HIP_TRY(hipEventRecord(env->ev_pairs[env->ev_used].first, s));
     }
+    env->d.pc_cur ^= 1;  // this step's copy of the narrowphase list counters (zeroed by the previous step's first kernel)
     HIP_TRY(evm::launch_step(env->d, evm::step_lds_bytes(env->skel.nb, env->skel.nscan), env->split, mode, a, obs, rew, done, valid, mask, s,
                              // every 8th step also brackets its sweeps kernel
                              (sample && env->ev_used % 2 == 0) ? env->ev_sweeps[env->ev_used].first : nullptr,
-                             (sample && env->ev_used % 2 == 0) ? env->ev_sweeps[env->ev_used].second : nullptr,
-                             env->side.stream ? &env->side : nullptr));
+                             (sample && env->ev_used % 2 == 0) ? env->ev_sweeps[env->ev_used].second : nullptr));
     if (sample) {
         HIP_TRY(hipEventRecord(env->ev_pairs[env->ev_used].second, s));
         env->ev_used++;
@@ -320,7 +304,7 @@ int evm_env_pairs(const EvmEnv *env, int *n_pairs, int *h_pairs) {
 int evm_env_debug_pair_counts(EvmEnv *env, int *h_out) {
     if (!env || !h_out) return fail(EVM_E_INVALID, "null argument");
     HIP_TRY(hipDeviceSynchronize());
-    if (env->skel.npair > 0) HIP_TRY(hipMemcpy(h_out, env->d.pcount, (env->skel.npair + 1) * sizeof(int), hipMemcpyDeviceToHost));
+    if (env->skel.npair > 0) HIP_TRY(hipMemcpy(h_out, env->d.pcount + env->d.pc_cur * (EVM_MAX_PAIRS + 1), (env->skel.npair + 1) * sizeof(int), hipMemcpyDeviceToHost));  // the last step's copy
     return EVM_OK;
 }
 

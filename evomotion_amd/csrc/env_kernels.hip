@@ -1912,23 +1912,56 @@ DEV LaneState lane_state(const Ctx &c) {
 template <int MODE>
 __global__ __launch_bounds__(64 * EVM_SPLIT_WAVES) void k_split_pre_a(EnvDev d, const uint8_t *__restrict__ mask) {
     Ctx c = make_ctx(d, tile_stage(d));
+    // The NEXT step's narrowphase work lists start empty (this step's were zeroed by the previous step: the broadphase items below
+    // append to them).  Before the guard: one wavefront of the grid does it whatever the mask leaves of its tile.
+    if (c_skel.self_collision && blockIdx.x == 0 && blockIdx.y == gridDim.y - 1 && c.wave == EVM_SPLIT_WAVES - 1) {
+        int *nxt = pc_next(d);
+        for (int k = c.lane; k <= c_skel.npair; k += 64) nxt[k] = 0;
+    }
     EVM_SPLIT_GUARD()
     const LaneState L = lane_state<MODE>(c);
     const int vw = blockIdx.y * EVM_SPLIT_WAVES + c.wave, nvw = gridDim.y * EVM_SPLIT_WAVES;
     if (c_skel.self_collision && vw == nvw - 1) {  // the pair kernel ORs its live pairs in, the setup kernels the split-impulse flag
         const int nwords = ((c_skel.npair + 31) >> 5) + 1;
         for (int k = 0; k < nwords; k++) c.t.pact[(k << 6) + c.lane] = 0u;
-        if (blockIdx.x == 0) {  // this step's narrowphase work lists start empty (dealt to the LIVE lanes: a ragged tile has fewer than 64)
-            const unsigned long long live = __ballot(true);
-            const int nlive = (int) __popcll(live), mine = (int) __popcll(live & ((1ull << c.lane) - 1ull));
-            for (int k = mine; k <= c_skel.npair; k += nlive) d.pcount[k] = 0;
-        }
     }
-    // one item list (bodies, then scan slices) dealt round robin, so that no wave gets the head of both
-    for (int j = vw; j < c_skel.nb + c_skel.nscan; j += nvw) {
+    // one item list (bodies, then scan slices, then — member-vs-member mode — the broadphase of the member pairs) dealt round
+    // robin, so that no wave gets the head of two kinds
+    const int nbroad = c_skel.self_collision ? c_skel.npair : 0;
+    for (int j = vw; j < c_skel.nb + c_skel.nscan + nbroad; j += nvw) {
         if (j < c_skel.nb) {
             if (__any(L.fin)) { if (L.fin) repose_body(c, j, L.E, L.was_pending); }  // RigidBodyItem::reset of a starting reset
             body_prepare(c, j, L.pending, L.any_pending, L.E);
+            continue;
+        }
+        if (j >= c_skel.nb + c_skel.nscan) {
+            // broadphase of one member pair: the envs whose boxes overlap, or that hold a cached point, go to the pair's work
+            // list for the narrowphase.  The members' transforms are derived here, as body_prepare / repose_body derive them
+            // (those run in other waves of this kernel): basis from the quaternion, or E * M0 in the step that follows a reset;
+            // origin from the state, or the re-posed one when the reset starts with this step.
+            const int p = j - c_skel.nb - c_skel.nscan;
+            M33 Rm[2];
+            F3 om[2];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; s2++) {
+                const int m = s2 == 0 ? (int) c_skel.pair[p].a : (int) c_skel.pair[p].b;
+                M33 R = mat_from_quat(q4(GS(quat, 4 * m), GS(quat, 4 * m + 1), GS(quat, 4 * m + 2), GS(quat, 4 * m + 3)));
+                if (L.any_pending) {
+                    const M33 Rp = glm_mul_basis(L.E, load_m33(c_skel.body[m].m0));
+                    if (L.pending) R = Rp;
+                }
+                F3 o = G3(pos, 3 * m);
+                if (__any(L.fin)) {  // (repose_body's arithmetic)
+                    const F3 e0 = col0(L.E), e1 = col1(L.E), e2 = col2(L.E);
+                    const F3 t0 = load_f3(c_skel.body[m].t0), rp = load_f3(c_skel.root_pos);
+                    const F3 orp = f3(xa(xa(xa(xm(e0.x, t0.x), xm(e1.x, t0.y)), xm(e2.x, t0.z)), rp.x),
+                                      xa(xa(xa(xm(e0.y, t0.x), xm(e1.y, t0.y)), xm(e2.y, t0.z)), rp.y),
+                                      xa(xa(xa(xm(e0.z, t0.x), xm(e1.z, t0.y)), xm(e2.z, t0.z)), rp.z));
+                    if (L.fin) o = orp;
+                }
+                Rm[s2] = R; om[s2] = o;
+            }
+            pair_broadphase(c, p, L.fin, Rm[0], om[0], Rm[1], om[1]);
             continue;
         }
         const int i = j - c_skel.nb;
@@ -1963,15 +1996,9 @@ DEV void pre_b_items(const Ctx &c, const LaneState &L, int vw, int nvw, const fl
     int s5_kind = -1;
     unsigned long long s5_t0 = 0;
 #endif
-    // one item list: members first (manifold + contact rows, the longest items), then the joint visits, then (member-vs-member
-    // mode) the broadphase of the member pairs: the envs whose boxes overlap, or that hold a cached point, go to the pair's
-    // work list for the narrowphase kernel
-    // (broad == 0: k_split_broad has done the broadphase already, so that the narrowphase runs beside this kernel)
-    for (int j = vw; j < c_skel.nm + c_skel.nvisit + (broad ? c_skel.npair : 0); j += nvw) {
-        if (j >= c_skel.nm + c_skel.nvisit) {
-            pair_broadphase(c, j - c_skel.nm - c_skel.nvisit, L.fin);
-            continue;
-        }
+    // one item list: members first (manifold + contact rows, the longest items), then the joint visits
+    (void) broad;
+    for (int j = vw; j < c_skel.nm + c_skel.nvisit; j += nvw) {
 #ifdef EVM_STAMPS5  // diagnostic: longest item of each kind, per tile (cycles); tools/stamps5.py
         {
             const unsigned long long now = __builtin_amdgcn_s_memtime();
@@ -2039,18 +2066,8 @@ __global__ __launch_bounds__(64 * EVM_SPLIT_WAVES) __attribute__((amdgpu_waves_p
     pre_b_items<MODE>(c, L, vw, nvw, action, broad, (int) blockIdx.x);
 }
 
-// Member-vs-member mode with the narrowphase on a side stream: the broadphase items alone (they need k_split_pre_a's poses only)
-template <int MODE>
-__global__ __launch_bounds__(64 * EVM_SPLIT_WAVES) void k_split_broad(EnvDev d, const uint8_t *__restrict__ mask) {
-    Ctx c = make_ctx(d, tile_stage(d));
-    EVM_SPLIT_GUARD()
-    const LaneState L = lane_state<MODE>(c);
-    const int vw = blockIdx.y * EVM_SPLIT_WAVES + c.wave, nvw = gridDim.y * EVM_SPLIT_WAVES;
-    for (int j = vw; j < c_skel.npair; j += nvw) pair_broadphase(c, j, L.fin);
-}
-
 // Member-vs-member mode, narrowphase (pairs_dev.h).  The envs that need a pair are compacted over the whole batch by the
-// broadphase items of k_split_pre_b, so a wavefront is full of real work whatever fraction of the envs has that pair close.
+// broadphase items of k_split_pre_a, so a wavefront is full of real work whatever fraction of the envs has that pair close.
 //   blocks [0, EVM_BIG_BLOCKS)   the pairs with a big hull (the 451-vertex feet): one query per QUARTER wavefront, the 16 lanes
 //                                of a row sharing the hull scans (narrow_dev.h, support_group; the hull sits in LDS); the
 //                                blocks walk the flat (pair, env) list
@@ -2077,7 +2094,7 @@ DEV void narrow_block(const EnvDev &d, int blk, int tiles) {
     ks.st = nullptr;
 #endif
     if (blk < EVM_BIG_BLOCKS) {
-        const int cnt = d.pcount[c_skel.npair];
+        const int cnt = pc_cur(d)[c_skel.npair];
         if (blk * 4 >= cnt) return;
 #ifdef EVM_KSTAMPS
         ks.begin(d.stamps, 0);
@@ -2108,7 +2125,7 @@ DEV void narrow_block(const EnvDev &d, int blk, int tiles) {
     }
     const int bx = blk - EVM_BIG_BLOCKS;
     const int p = c_skel.pair_order[bx / tiles];
-    const int cnt = d.pcount[p], base = (bx % tiles) * 64;
+    const int cnt = pc_cur(d)[p], base = (bx % tiles) * 64;
     if (base >= cnt) return;
     const int i = base + (int) threadIdx.x;
     if (i >= cnt) return;
@@ -2357,7 +2374,7 @@ namespace evm {
 // Narrowphase + the setup kernel's records in ONE launch (member-vs-member mode, the default pipeline): the narrowphase is a few
 // hundred latency-bound wavefronts that leave most of the chip idle for 80 us, and the joint / floor records of k_split_pre_b
 // depend on nothing it produces.  Blocks [0, narrow) are narrow_block's, the rest are k_split_pre_b's virtual waves (one 64-lane
-// block each, the long narrowphase blocks first in dispatch order).  The broadphase items run before, in k_split_broad.
+// block each, the long narrowphase blocks first in dispatch order).  The broadphase items run before, in k_split_pre_a.
 template <int MODE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EVM_PAIRS_WAVES, EVM_PAIRS_WAVES))) void k_split_pairs_rec(EnvDev d, const float *__restrict__ action,
                                                                         const uint8_t *__restrict__ mask, int tiles, int nvw) {
@@ -2435,7 +2452,7 @@ static hipError_t launch_mode(const EnvDev &d, size_t lds, const float *action, 
 }
 template <int MODE>
 static hipError_t launch_split(const EnvDev &d, size_t lds, const float *action, float *obs, float *reward, uint8_t *done,
-                               uint8_t *valid, const uint8_t *mask, hipStream_t s, hipEvent_t e0, hipEvent_t e1, const StepSide *side) {
+                               uint8_t *valid, const uint8_t *mask, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
     static bool attr_set[EVM_MAX_DEVICES] = {};
     const int dev = current_device();
     if (!attr_set[dev]) {
@@ -2455,25 +2472,11 @@ static hipError_t launch_split(const EnvDev &d, size_t lds, const float *action,
     hipLaunchKernelGGL((k_split_pre_a<MODE>), gp, bp, 0, s, d, mask);
     static int merge = -1;   // EVM_PAIRS_MERGE=0: the narrowphase and the records as two launches (A/B)
     if (merge < 0) { const char *e = getenv("EVM_PAIRS_MERGE"); merge = (e && e[0] == '0') ? 0 : 1; }
-    if (d.pmn && side) {
-        // (opt-in, EVM_PAIRS_OVERLAP=1) the narrowphase on a side stream BESIDE k_split_pre_b: measured slower than one stream —
-        // the two events cost more than they hide; the merged launch below does the same without them
-        hipLaunchKernelGGL((k_split_broad<MODE>), gp, bp, 0, s, d, mask);
-        hipError_t e = hipEventRecord(side->fork, s);
-        if (e == hipSuccess) e = hipStreamWaitEvent(side->stream, side->fork, 0);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_split_pairs<MODE>), dim3(EVM_BIG_BLOCKS + tiles * d.npair_host), dim3(64), 0, side->stream, d, mask, tiles);
-        e = hipEventRecord(side->join, side->stream);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_split_pre_b<MODE>), gp, bp, 0, s, d, action, mask, 0);
-        e = hipStreamWaitEvent(s, side->join, 0);
-        if (e != hipSuccess) return e;
-    } else if (d.pmn && merge) {
+    if (d.pmn && merge) {
         const int nvw = parts * EVM_SPLIT_WAVES;
-        hipLaunchKernelGGL((k_split_broad<MODE>), gp, bp, 0, s, d, mask);
         hipLaunchKernelGGL((k_split_pairs_rec<MODE>), dim3(EVM_BIG_BLOCKS + tiles * d.npair_host + tiles * nvw), dim3(64), 0, s, d, action, mask, tiles, nvw);
     } else {
-        hipLaunchKernelGGL((k_split_pre_b<MODE>), gp, bp, 0, s, d, action, mask, 1);
+        hipLaunchKernelGGL((k_split_pre_b<MODE>), gp, bp, 0, s, d, action, mask, 0);
         if (d.pmn) hipLaunchKernelGGL((k_split_pairs<MODE>), dim3(EVM_BIG_BLOCKS + tiles * d.npair_host), dim3(64), 0, s, d, mask, tiles);
     }
     if (e0) (void) hipEventRecord(e0, s);
@@ -2494,7 +2497,7 @@ static hipError_t launch_split(const EnvDev &d, size_t lds, const float *action,
     return hipGetLastError();
 }
 hipError_t launch_step(const EnvDev &d, size_t lds_bytes, int split, int mode, const float *action, float *obs, float *reward,
-                       uint8_t *done, uint8_t *valid, const uint8_t *mask, hipStream_t s, hipEvent_t e0, hipEvent_t e1, const StepSide *side) {
+                       uint8_t *done, uint8_t *valid, const uint8_t *mask, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
     // split < 0: choose by batch.  Up to 128 tiles (8192 envs) the monolithic kernel leaves most of the chip idle and the
     // split pipeline wins (0.179 vs 0.227 ms at 64 tiles); with every CU holding a tile it only adds launches and staging
     // traffic (0.472 vs 0.419 ms at 256 tiles).
@@ -2504,10 +2507,10 @@ hipError_t launch_step(const EnvDev &d, size_t lds_bytes, int split, int mode, c
         // the sweeps kernel keeps only the body tiles and the version counters in LDS (no scan minima)
         const size_t lds = lds_bytes;  // same layout as the staging copy
         switch (mode) {
-            case 0: return launch_split<0>(d, lds, action, obs, reward, done, valid, mask, s, e0, e1, side);
-            case 2: return launch_split<2>(d, lds, action, obs, reward, done, valid, mask, s, e0, e1, side);
-            case 3: return launch_split<3>(d, lds, action, obs, reward, done, valid, mask, s, e0, e1, side);
-            case 7: return launch_split<7>(d, lds, action, obs, reward, done, valid, mask, s, e0, e1, side);
+            case 0: return launch_split<0>(d, lds, action, obs, reward, done, valid, mask, s, e0, e1);
+            case 2: return launch_split<2>(d, lds, action, obs, reward, done, valid, mask, s, e0, e1);
+            case 3: return launch_split<3>(d, lds, action, obs, reward, done, valid, mask, s, e0, e1);
+            case 7: return launch_split<7>(d, lds, action, obs, reward, done, valid, mask, s, e0, e1);
             default: return hipErrorInvalidValue;
         }
     }

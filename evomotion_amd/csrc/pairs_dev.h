@@ -137,19 +137,23 @@ DEV void member_box(const EvmMemberC &MB, const M33 &R, F3 o, F3 &ctr, F3 &ext) 
              fabsf(R.r2.x) * h.x + fabsf(R.r2.y) * h.y + fabsf(R.r2.z) * h.z + 0.02f);
 }
 
-// Broadphase of pair p for the 64 envs of a tile (an item of k_split_pre_b): an env whose two boxes overlap, or that still
+// Broadphase of pair p for the 64 envs of a tile (an item of k_split_pre_a): an env whose two boxes overlap, or that still
 // holds a cached point, is appended to the pair's work list (one atomic per wavefront).  drop: lanes whose env starts a
 // reset with this step (their cached points are discarded: removeRigidBody / addRigidBody).
-DEV void pair_broadphase(const Ctx &c, int p, bool drop) {
+// the step's work-list counters (EnvDev::pcount: the copy this step appends to)
+DEV int *pc_cur(const EnvDev &d) { return d.pcount + d.pc_cur * (EVM_MAX_PAIRS + 1); }
+DEV int *pc_next(const EnvDev &d) { return d.pcount + (d.pc_cur ^ 1) * (EVM_MAX_PAIRS + 1); }
+
+// Ra, oa / Rb, ob: the two members' world transforms of this step (k_split_pre_a derives them itself: the bodies are being
+// prepared by other waves of the same kernel)
+DEV void pair_broadphase(const Ctx &c, int p, bool drop, const M33 &Ra, F3 oa, const M33 &Rb, F3 ob) {
     const EvmPairC &PC = c_skel.pair[p];
     const int a = PC.a, b = PC.b;
     int n = PMN(p);
     if (drop && n > 0) { PMN(p) = 0; n = 0; }
-    const M33 Ra = m33(SC3(c_skel.sc_r + 9 * a), SC3(c_skel.sc_r + 9 * a + 3), SC3(c_skel.sc_r + 9 * a + 6));
-    const M33 Rb = m33(SC3(c_skel.sc_r + 9 * b), SC3(c_skel.sc_r + 9 * b + 3), SC3(c_skel.sc_r + 9 * b + 6));
     F3 ca, ea, cb, eb;
-    member_box(c_skel.member[a], Ra, G3(pos, 3 * a), ca, ea);
-    member_box(c_skel.member[b], Rb, G3(pos, 3 * b), cb, eb);
+    member_box(c_skel.member[a], Ra, oa, ca, ea);
+    member_box(c_skel.member[b], Rb, ob, cb, eb);
     bool near = fabsf(ca.x - cb.x) <= ea.x + eb.x && fabsf(ca.y - cb.y) <= ea.y + eb.y && fabsf(ca.z - cb.z) <= ea.z + eb.z;
     if (__any(near && n == 0)) {
         // Second cull, for pairs without a cached point: the un-margined hulls lie inside their oriented local boxes, so if a
@@ -182,7 +186,7 @@ DEV void pair_broadphase(const Ctx &c, int p, bool drop) {
     const bool big = c_skel.member[a].hull_n > EVM_BIG_HULL || c_skel.member[b].hull_n > EVM_BIG_HULL;
     const int slot = big ? c_skel.npair : p;
     int base = 0;
-    if (lane == leader) base = atomicAdd(&c.d.pcount[slot], (int) __popcll(m));
+    if (lane == leader) base = atomicAdd(&pc_cur(c.d)[slot], (int) __popcll(m));
     base = __shfl(base, leader);
     const int at = base + (int) __popcll(m & ((1ull << lane) - 1ull));
     if (need) {
