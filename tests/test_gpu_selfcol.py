@@ -190,3 +190,26 @@ def test_deep_interpenetration_takes_the_penetration_branch(tmp_path, orc_lib, s
     assert pen_calls >= n // 2, pen_calls
     assert worst["geom"] < 2e-6 and worst["pos"] < 1e-4 and worst["lin"] < 2e-3 and worst["ang"] < 2e-2 and worst["imp"] < 2e-3, worst
     assert env.errors() == (0, 0)
+
+
+def test_masked_reset_leaves_the_other_envs_untouched(torch_mod):
+    """evm_env_reset with a mask steps only the selected envs through reset().  The narrowphase works on lists compacted over the
+    whole batch, whose counters are zeroed by one wavefront of the first setup kernel: when the mask excluded that wavefront's
+    whole tile, the lists of the previous step survived and the narrowphase ran again on envs that were not part of the call.
+    (Counters are now double-buffered and zeroed before the mask guard.)  Here the mask leaves out tile 0 entirely: every env of
+    it must come through bit for bit — bodies, manifolds, pair manifolds, counters."""
+    torch = torch_mod
+    n = 128
+    env = make(n)
+    env.reset()
+    rng = np.random.default_rng(11)
+    for k in range(45):   # into the contact-rich part of the episodes
+        env.step_autoreset(torch.from_numpy(rng.uniform(-1, 1, (n, 12)).astype(np.float32)))
+    before = env.get_state()
+    mask = torch.zeros(n, dtype=torch.uint8)
+    mask[64:] = 1
+    env.reset(mask=mask)
+    after = env.get_state()
+    assert np.array_equal(before[:64], after[:64]), int((before[:64] != after[:64]).sum())
+    assert not np.array_equal(before[64:], after[64:])
+    assert np.isfinite(after).all() and env.errors() == (0, 0)
