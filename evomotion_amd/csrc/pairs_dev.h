@@ -296,29 +296,34 @@ DEV void pair_item(const Ctx &c, int p, bool drop, int lds_hull_off = -1) {
     }
     // refreshContactPoints(trA, trB): world points and distance follow the bodies, the stored normal stays; then removal from
     // the last slot down (swap-with-last)
-    F3 wA[4], wB[4];
+    // (named scalars, selected with sel3: as arrays the compiler turned `last == 0 ? wA[0] : ...` into indexed loads from
+    // scratch memory, a dependent round trip per removal)
+    F3 wA0, wA1, wA2, wA3, wB0, wB1, wB2, wB3;
 #define REFRESH2(I, P)                                    \
     {                                                     \
-        wA[I] = mul(SA.R, P.la) + SA.o;                   \
-        wB[I] = mul(SB.R, P.lb) + SB.o;                   \
-        P.dist = dot(wA[I] - wB[I], P.nb);                \
+        wA##I = mul(SA.R, P.la) + SA.o;                   \
+        wB##I = mul(SB.R, P.lb) + SB.o;                   \
+        P.dist = dot(wA##I - wB##I, P.nb);                \
     }
     REFRESH2(3, p3) REFRESH2(2, p2) REFRESH2(1, p1) REFRESH2(0, p0)
 #undef REFRESH2
+    auto pick = [](int k, F3 x0, F3 x1, F3 x2, F3 x3) {
+        return f3(k == 0 ? x0.x : (k == 1 ? x1.x : (k == 2 ? x2.x : x3.x)), k == 0 ? x0.y : (k == 1 ? x1.y : (k == 2 ? x2.y : x3.y)),
+                  k == 0 ? x0.z : (k == 1 ? x1.z : (k == 2 ? x2.z : x3.z)));
+    };
 #define REMOVE2(I, P)                                                                              \
     if (I < n) {                                                                                   \
         bool rm = !(P.dist <= thr);                                                                \
         if (!rm) {                                                                                 \
-            const F3 projected = wA[I] - P.nb * P.dist;                                            \
-            const F3 diff = wB[I] - projected;                                                     \
+            const F3 projected = wA##I - P.nb * P.dist;                                            \
+            const F3 diff = wB##I - projected;                                                     \
             rm = dot(diff, diff) > thr * thr;                                                      \
         }                                                                                          \
         if (rm) {                                                                                  \
             const int last = n - 1;                                                                \
             const MPoint2 lp = sel(last == 0, p0, sel(last == 1, p1, sel(last == 2, p2, p3)));     \
-            const F3 la_ = last == 0 ? wA[0] : (last == 1 ? wA[1] : (last == 2 ? wA[2] : wA[3])); \
-            const F3 lb_ = last == 0 ? wB[0] : (last == 1 ? wB[1] : (last == 2 ? wB[2] : wB[3])); \
-            P = lp; wA[I] = la_; wB[I] = lb_;                                                      \
+            const F3 la_ = pick(last, wA0, wA1, wA2, wA3), lb_ = pick(last, wB0, wB1, wB2, wB3);   \
+            P = lp; wA##I = la_; wB##I = lb_;                                                      \
             n--;                                                                                   \
         }                                                                                          \
     }
@@ -327,6 +332,7 @@ DEV void pair_item(const Ctx &c, int p, bool drop, int lds_hull_off = -1) {
     REMOVE2(1, p1)
     REMOVE2(0, p0)
 #undef REMOVE2
+    const F3 wA[4] = {wA0, wA1, wA2, wA3}, wB[4] = {wB0, wB1, wB2, wB3};
     store_mp2(c, p, 0, p0); store_mp2(c, p, 1, p1); store_mp2(c, p, 2, p2); store_mp2(c, p, 3, p3);
     PMN(p) = n;
     KS_MARK(2)
