@@ -560,6 +560,9 @@ __global__ __launch_bounds__(64 * EVM_G_MAX_WAVES) void k_sweeps_g(EnvDev d, con
         return r;
     };
     float res_c = 0.f;  // contact rows of the last sweep: belongs to env ce (member-vs-member mode)
+#ifdef EVM_GSTAMPS3
+    unsigned long long s3_prev_end = __builtin_amdgcn_s_memtime();
+#endif
     for (int it = 0; it < NUM_ITER; it++) {
         float rs = 0.f, rc = 0.f;
         int j0 = 0;
@@ -578,6 +581,9 @@ __global__ __launch_bounds__(64 * EVM_G_MAX_WAVES) void k_sweeps_g(EnvDev d, con
                     const int rec = __float_as_int(cur.d0[0]), a = __float_as_int(cur.d0[1]), b = __float_as_int(cur.d0[2]);
                     if (ty >= 5) {
                         // chain entry (5: hinges, 6: p2p): every lane takes part in the hand-over, filled slot or not
+#ifdef EVM_GSTAMPS3
+                        __builtin_amdgcn_s_waitcnt(0xC07F); const unsigned long long s3_e0 = __builtin_amdgcn_s_memtime();
+#endif
                         const int nact = __builtin_amdgcn_readfirstlane(__float_as_int(cur.h[2]));
                         const float imA = cur.d0[3], imB = cur.d1[0];
                         const int need = __float_as_int(cur.d1[1]), ps = __float_as_int(cur.d1[2]);
@@ -585,8 +591,23 @@ __global__ __launch_bounds__(64 * EVM_G_MAX_WAVES) void k_sweeps_g(EnvDev d, con
                         // (its own count) = expA - g and the last one publishes expA - g + nact
                         const int expA0 = it * (ps & 0xffff) + (need & 0xffff) - G.g, expB = it * (ps >> 16) + (need >> 16);
                         if (rec >= 0) g_wait2(G, c, a, expA0, b, expB);
+#ifdef EVM_GSTAMPS3
+                        __builtin_amdgcn_s_waitcnt(0xC07F); const unsigned long long s3_e1 = __builtin_amdgcn_s_memtime();
+#endif
                         const float r = ty == 5 ? g_hinge_chain(G, rec, a, b, imA, imB, nact) : g_p2p_chain(G, rec, a, b, imA, imB, nact);
+#ifdef EVM_GSTAMPS3
+                        __builtin_amdgcn_s_waitcnt(0xC07F); const unsigned long long s3_e2 = __builtin_amdgcn_s_memtime();
+#endif
                         if (rec >= 0) { g_publish(G, a, expA0 + nact, b, expB + 1); rs = fmaxf(rs, r); }
+#ifdef EVM_GSTAMPS3
+                        __builtin_amdgcn_s_waitcnt(0xC07F);
+                        if (ty == 5 && (threadIdx.x & 63) == 0) {
+                            const unsigned long long s3_e3 = __builtin_amdgcn_s_memtime();
+                            atomicAdd(&G.st3[8], s3_e1 - s3_e0); atomicAdd(&G.st3[9], s3_e2 - s3_e1); atomicAdd(&G.st3[10], s3_e3 - s3_e2);
+                            atomicAdd(&G.st3[11], s3_e0 - s3_prev_end); 
+                        }
+                        s3_prev_end = __builtin_amdgcn_s_memtime();
+#endif
                     } else if (rec >= 0) {
                         const float imA = cur.d0[3], imB = cur.d1[0];
                         const int need = __float_as_int(cur.d1[1]), ps = __float_as_int(cur.d1[2]);

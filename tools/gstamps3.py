@@ -19,8 +19,10 @@ for k in range(200):
     env.step_autoreset(torch.rand(n, 12, device="cuda", generator=g) * 2 - 1)
 st = (ctypes.c_ulonglong * (n // 64 * 16))()
 check(lib.evm_env_get_stamps(env._h, st))
-a = np.array(st, dtype=np.uint64)[:6].astype(np.float64)
+a = np.array(st, dtype=np.uint64)[:12].astype(np.float64)
 e, ph = a[4], a[5]
 print("self_collision=%d: hinge chain entries %.0f, phases per entry %.2f" % (sc, e, ph / e))
 print("per entry: loads %.0f  rows %.0f (%.0f per phase = one hinge visit)  hand-over %.0f (%.0f per phase)  stores %.0f  sum %.0f cycles"
       % (a[0] / e, a[1] / e, a[1] / ph, a[2] / e, a[2] / ph, a[3] / e, a[:4].sum() / e))
+print("around it, per hinge chain entry: decode + wait for versions %.0f, the chain function %.0f, publish %.0f; from the end of the previous chain entry of the wave to this one's start %.0f (p2p chain entries are stamped too: they set the 'previous end')"
+      % (a[8] / e, a[9] / e, a[10] / e, a[11] / e))
