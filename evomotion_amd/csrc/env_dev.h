@@ -28,6 +28,8 @@ struct EnvDev {
     int *pcount;                    // [2][EVM_MAX_PAIRS + 1] the lists' lengths, [npair] = the flat list's; two copies: a step appends to
                                     // copy pc_cur and zeroes the other one for the next step (the host flips pc_cur per launch)
     int pc_cur;
+    int gtile_only;                 // the 64-env tile (3 KB per body) does not fit the CU's LDS: the tile sweeps kernel works on the
+                                    // global staging copy instead (slower), and there is no monolithic kernel
     int npair_host;                 // EvmSkelC::npair, for the launch geometry
     float *target;                  // [nmus][n]  slider target velocity
     int *flags, *curr_step, *remaining, *settle_left;  // [n]

@@ -118,7 +118,9 @@ int evm_env_create(const char *skeleton_path, int n_envs, int device, uint64_t s
     int rc = evm::load_skeleton_constants(skeleton_path, prm, env->skel, err);
     if (rc != EVM_OK) { delete env; return fail(rc, err); }
     const EvmSkelC &S = env->skel;
-    if (evm::step_lds_bytes(S.nb, S.nscan) > 160 * 1024) { delete env; return fail(EVM_E_UNSUPPORTED, "skeleton has too many bodies for the LDS tile"); }
+    // a 64-env tile is 3 KB per body: beyond the CU's 160 KB of LDS the sweeps work on the tile's global staging copy (slower);
+    // the member-vs-member mode needs the lane-group kernel's LDS image and stays refused for such a skeleton (below)
+    const bool gtile_only = evm::step_lds_bytes(S.nb, S.nscan) > 160 * 1024;
     if (device < 0 || device >= EVM_MAX_DEVICES) { delete env; return fail(EVM_E_INVALID, "device index out of range"); }
     hipError_t he = hipSetDevice(device);
     if (he != hipSuccess) { delete env; return fail(EVM_E_HIP, std::string("hipSetDevice: ") + hipGetErrorString(he)); }
@@ -128,6 +130,7 @@ int evm_env_create(const char *skeleton_path, int n_envs, int device, uint64_t s
     env->d.tile_floats = (int) (evm::step_lds_bytes(S.nb, S.nscan) / 4);
     env->d.n_real = n_envs;
     env->d.npair_host = S.npair;
+    env->d.gtile_only = gtile_only ? 1 : 0;
     struct Seg { void **p; size_t count; };
     std::vector<Seg> segs = {
         {(void **) &env->d.pos, 3u * S.nb}, {(void **) &env->d.quat, 4u * S.nb}, {(void **) &env->d.lin, 3u * S.nb},
@@ -184,7 +187,8 @@ int evm_env_create(const char *skeleton_path, int n_envs, int device, uint64_t s
     }
     if (S.self_collision && !env->gsched) {
         evm_env_destroy(env);
-        return fail(EVM_E_UNSUPPORTED, "self_collision = 1 needs the lane-group sweeps kernel, which this skeleton (or EVM_SWEEPS=tile) rules out");
+        return fail(EVM_E_UNSUPPORTED, "self_collision = 1 needs the lane-group sweeps kernel, whose LDS image this skeleton exceeds (or EVM_SWEEPS=tile rules out); "
+                                       "self_collision = 0 runs it on the global-memory tile");
     }
     // a new env always uploads (its address may be a destroyed owner's); the device's previous owner may have kernels in flight
     if (g_skel_owner[device] != nullptr) (void) hipDeviceSynchronize();

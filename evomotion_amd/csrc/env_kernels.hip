@@ -2144,9 +2144,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EVM_PAIRS_WA
     narrow_block<MODE>(d, (int) blockIdx.x, tiles);
 }
 
+// GT: the tile does not fit the LDS (more than ~53 bodies): the kernel works in place on the tile's global staging copy — the
+// same layout, so the copy-in below degenerates to the attach spheres' zero fill and the copy-out to a self-copy; the waves
+// still meet through the version counters (workgroup scope: one CU, one L1).  Slower, but a skeleton is not refused for its size.
+template <bool GT>
 __global__ __launch_bounds__(64 * EVM_NW) void k_split_sweeps(EnvDev d, const uint8_t *__restrict__ mask, int autoreset) {
     extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
-    Ctx c = make_ctx(d, lds_dyn);
+    Ctx c = make_ctx(d, GT ? tile_stage(d) : lds_dyn);
     EVM_SPLIT_GUARD()
     const int flags_in = d.flags[c.env];
     const bool fin = autoreset && (flags_in & EVM_FLAG_DONE) != 0;  // a reset starts with this step (see LaneState)
@@ -2456,7 +2460,7 @@ static hipError_t launch_split(const EnvDev &d, size_t lds, const float *action,
     static bool attr_set[EVM_MAX_DEVICES] = {};
     const int dev = current_device();
     if (!attr_set[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_split_sweeps),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_split_sweeps<false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int) (160 * 1024));
         if (e != hipSuccess) return e;
         attr_set[dev] = true;
@@ -2490,7 +2494,8 @@ static hipError_t launch_split(const EnvDev &d, size_t lds, const float *action,
         }
         hipLaunchKernelGGL(k_sweeps_g, dim3(tiles * (64 / EVM_G_ENVS)), dim3(64 * d.g_waves), (size_t) d.g_lds, s, d, mask, (MODE & 4) ? 1 : 0);
     } else {
-        hipLaunchKernelGGL(k_split_sweeps, dim3(tiles), dim3(64 * EVM_NW), lds, s, d, mask, (MODE & 4) ? 1 : 0);
+        if (d.gtile_only) hipLaunchKernelGGL(k_split_sweeps<true>, dim3(tiles), dim3(64 * EVM_NW), 0, s, d, mask, (MODE & 4) ? 1 : 0);
+        else hipLaunchKernelGGL(k_split_sweeps<false>, dim3(tiles), dim3(64 * EVM_NW), lds, s, d, mask, (MODE & 4) ? 1 : 0);
     }
     if (e1) (void) hipEventRecord(e1, s);
     hipLaunchKernelGGL((k_split_post<MODE>), gp, bp, 0, s, d, obs, reward, done, valid, mask);
@@ -2503,6 +2508,7 @@ hipError_t launch_step(const EnvDev &d, size_t lds_bytes, int split, int mode, c
     // traffic (0.472 vs 0.419 ms at 256 tiles).
     if (split < 0) split = d.n / 64 <= 128 ? 1 : 0;
     if (d.pmn) split = 1;  // member-vs-member contacts live in the split pipeline with the lane-group sweeps kernel only
+    if (d.gtile_only) split = 1;  // a tile beyond the LDS: the pipeline's tile kernel on the global staging copy
     if (split) {
         // the sweeps kernel keeps only the body tiles and the version counters in LDS (no scan minima)
         const size_t lds = lds_bytes;  // same layout as the staging copy

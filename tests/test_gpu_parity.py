@@ -413,17 +413,27 @@ def test_random_skeletons_match_the_oracle(torch_mod, orc_lib, tmp_path):
 
 
 def test_large_skeletons(torch_mod, orc_lib, tmp_path):
-    """Size limits.  The host tables hold 24 members / 20 muscles / 64 bodies, but a tile of 64 environments must fit the CU's
-    160 KB of LDS (3 KB per body + hull-scan partials): the 64-body skeleton is refused at creation with a message, and an
+    """Size limits.  The host tables hold 24 members / 20 muscles / 64 bodies.  A tile of 64 environments is 3 KB per body, so the
+    64-body skeleton does not fit the CU's 160 KB of LDS: in plane-contact mode its sweeps run on the global staging copy of the tile
+    (k_split_sweeps<true>) and are held to the oracle; member-vs-member mode is refused for it with a message.  An
     18-member star with 13 muscles (44 bodies, 56 joint visits per sweep, all hinges on one root) is built, stepped and held
     to the oracle like the small ones."""
     import pytest
     from conftest import write_skeleton
     from evomotion_amd._lib import EvmError
     import test_schedule as ts
-    with pytest.raises(EvmError) as e:
-        make(8, parameters=dict(skeleton_json_path=ts._star(write_skeleton, tmp_path, 24, 20, "max.skel")))
-    assert "LDS" in str(e.value)
+    big = ts._star(write_skeleton, tmp_path, 24, 20, "max.skel")
+    with pytest.raises(EvmError) as e:   # member-vs-member mode (the default) needs the lane-group kernel's LDS image
+        make(8, parameters=dict(skeleton_json_path=big))
+    assert "LDS" in str(e.value) and "self_collision = 0" in str(e.value)
+    # plane-contact mode: the tile sweeps kernel runs on the tile's global staging copy instead of LDS — slower, not refused
+    envb = make(8, parameters=dict(skeleton_json_path=big, self_collision=0))
+    assert envb.n_bodies == 64
+    orcb = [orc.OracleEnv(seed=700 + i, skeleton=big, lib=orc_lib, self_collision=0) for i in range(8)]
+    for o in orcb:
+        o.reset()
+    wb = _tf_compare(envb, orcb, 64, 24, 20, 12, np.random.default_rng(4), 20)
+    assert wb["pos"] < 5e-6 and wb["lin"] < 1e-3 and wb["ang"] < 5e-3 and wb["obs"] < 5e-3, wb
     path = ts._star(write_skeleton, tmp_path, 18, 13, "large.skel")
     n = 8
     env = make(n, parameters=dict(skeleton_json_path=path))
