@@ -43,8 +43,10 @@ def test_pair_table_matches_the_oracle(torch_mod, orc_lib):
 
 
 def test_teacher_forced_steps_with_member_contacts(torch_mod, orc_lib):
+    import os
     torch = torch_mod
-    n, steps = 32, 150
+    # (EVM_TF_ENVS / EVM_TF_STEPS: a longer run of the same comparison, e.g. 64 x 600 for profiles/r3_parity_long.txt)
+    n, steps = int(os.environ.get("EVM_TF_ENVS", 32)), int(os.environ.get("EVM_TF_STEPS", 150))
     env = make(n)
     orcs = [orc.OracleEnv(seed=1234 + i, lib=orc_lib, self_collision=1) for i in range(n)]
     npairs = env.n_pairs
