@@ -375,6 +375,10 @@ __global__ __launch_bounds__(64 * EVM_G_MAX_WAVES) void k_sweeps_g(EnvDev d, con
     GC.e = ce;
     const Ctx cc = make_ctx_at(d, nullptr, tile64, sub * EVM_G_ENVS + ce, wave);
     const bool clive = cc.env < d.n_real && (!mask || mask[cc.env]);
+    // (the same three for the env this lane's MANIFOLD belongs to: its own env, or — a guest slot — another env of the wave)
+    Ctx ck = cc;
+    int ce_k = ce;
+    bool clive_k = clive;
     int nn_c[EVM_MAX_MEMBERS];
     unsigned pw_c[EVM_PACT_WORDS];
     unsigned pflags_c = 0u;
@@ -489,7 +493,58 @@ __global__ __launch_bounds__(64 * EVM_G_MAX_WAVES) void k_sweeps_g(EnvDev d, con
 #endif
         nrounds = __builtin_amdgcn_readfirstlane(meta[4 * wave]);
         use_b1 = __builtin_amdgcn_readfirstlane(meta[4 * wave + 1]) != 0;
-        g_bank_load(cc, prog[(cs << 4) + ce], K0);
+        if (use_b1) {
+            // An env with more than 16 live manifolds (one or two of 4096 in most steps): its 17th.. manifold moves into a FREE
+            // slot of another env of this wavefront (a typical env uses 7 of its 16) as a guest — the lane then works on the
+            // guest's env column — instead of the overflow bank, whose every visit re-reads its record from global memory and
+            // made that one wavefront, hence the whole launch, wait.  One lane rewrites the wave's program words; the overflow
+            // bank stays for what finds no free slot.
+            if (lane == 0) {
+                int left = 0;
+                for (int ea = 0; ea < epw; ea++)
+                    for (int sa = 0; sa < nslots; sa++) {
+                        const unsigned w = prog[((16 + sa) << 4) + wave * epw + ea];
+                        if (w == 0xffffffffu) break;  // (an env's overflow words are contiguous from slot 0)
+                        bool placed = false;
+                        for (int eb = 0; eb < epw && !placed; eb++)
+                            for (int sb = 0; sb < nslots && !placed; sb++)
+                                if (prog[(sb << 4) + wave * epw + eb] == 0xffffffffu) {
+                                    prog[(sb << 4) + wave * epw + eb] = w | (1u << 26) | ((unsigned) ea << 27);
+                                    prog[((16 + sa) << 4) + wave * epw + ea] = 0xffffffffu;
+                                    placed = true;
+                                }
+                        if (!placed) left++;
+                    }
+                // (a hole left in an env's overflow words would hide the ones behind it: keep them packed from slot 0)
+                if (left > 0)
+                    for (int ea = 0; ea < epw; ea++) {
+                        int o = 0;
+                        for (int sa = 0; sa < nslots; sa++) {
+                            const unsigned w = prog[((16 + sa) << 4) + wave * epw + ea];
+                            if (w == 0xffffffffu) continue;
+                            prog[((16 + sa) << 4) + wave * epw + ea] = 0xffffffffu;
+                            prog[((16 + o) << 4) + wave * epw + ea] = w;
+                            o++;
+                        }
+                    }
+                meta[4 * wave + 1] = left > 0 ? 1 : 0;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            use_b1 = __builtin_amdgcn_readfirstlane(meta[4 * wave + 1]) != 0;
+        }
+        {
+            // this lane's manifold and the env it belongs to (its own env, or the guest's)
+            const unsigned w0 = prog[(cs << 4) + ce];
+            const bool guest = w0 != 0xffffffffu && ((w0 >> 26) & 1u) != 0;
+            ce_k = guest ? wave * epw + (int) ((w0 >> 27) & 15u) : ce;
+            GC.e = ce_k;
+            ck.lane = sub * EVM_G_ENVS + ce_k;
+            ck.env = tile64 * 64 + ck.lane;
+            clive_k = ck.env < d.n_real && (!mask || mask[ck.env]);
+            g_bank_load(ck, w0 == 0xffffffffu ? w0 : (w0 & 0x03ffffffu), K0);
+        }
         if (use_b1) {
             w1 = prog[((16 + cs) << 4) + ce];
             if (w1 != 0xffffffffu) {  // its split-impulse accumulators start at zero
@@ -680,7 +735,7 @@ __global__ __launch_bounds__(64 * EVM_G_MAX_WAVES) void k_sweeps_g(EnvDev d, con
         if (it == NUM_ITER - 1) res = rs;
     }
     if (live) atomicMax(&resmax[G.e], __float_as_int(res));
-    if (scm && clive) atomicMax(&resmax[ce], __float_as_int(res_c));
+    if (scm && clive_k) atomicMax(&resmax[ce_k], __float_as_int(res_c));
 #if defined(EVM_GSTAMPS) || defined(EVM_GSTAMPS2)
     const unsigned long long gs_t2 = __builtin_amdgcn_s_memtime();
 #endif
@@ -695,8 +750,8 @@ __global__ __launch_bounds__(64 * EVM_G_MAX_WAVES) void k_sweeps_g(EnvDev d, con
             gt[(b * 6 + 3) << 6] = q0[3]; gt[(b * 6 + 4) << 6] = q1[0]; gt[(b * 6 + 5) << 6] = q1[1];
         }
     }
+    if (scm && clive_k) g_bank_writeback(ck, K0);
     if (scm && clive) {
-        g_bank_writeback(cc, K0);
         if (use_b1 && w1 != 0xffffffffu) {
             CBank K1;
             g_bank_load(cc, w1, K1);
