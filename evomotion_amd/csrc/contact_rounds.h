@@ -290,7 +290,7 @@ __device__ __attribute__((noinline)) float g_slow_visit(int phase, unsigned w, i
 #define EVM_PACT_WORDS ((EVM_MAX_PAIRS + 31) / 32)
 // (the caller reads the env's activity words pw, the flag word and the floor manifold counts nn early, so that their latency
 // hides behind the record image's copy)
-DEV int g_build_program(const GCtx &G, int nslots, const int (&nn)[EVM_MAX_MEMBERS], const unsigned (&pw)[EVM_PACT_WORDS], unsigned flags,
+DEV int g_build_program(const GCtx &G, int nslots, int epw, const int (&nn)[EVM_MAX_MEMBERS], const unsigned (&pw)[EVM_PACT_WORDS], unsigned flags,
                         unsigned *prog, int *meta) {
     const int nm = c_skel.nm, np = c_skel.npair, nwords = (np + 31) >> 5;
     // Everything below lives in registers on purpose: plain scalars and macros, no lambdas, no arrays indexed at run time.  (A
@@ -327,22 +327,33 @@ DEV int g_build_program(const GCtx &G, int nslots, const int (&nn)[EVM_MAX_MEMBE
         if (!__any(act)) continue;
         if (act) G_PLACE(m, -1, m)
     }
+    // The pair table's (body0, body1) as a register table across the lanes (lane l: pairs l, 64 + l, ...; read with v_readlane):
+    // the walk below visits the union of the wave's active pairs one after the other, and a scalar load of the constant table
+    // per pair was a dependent memory round trip each time.
+    const int lane64 = (int) (threadIdx.x & 63);
+    static_assert(EVM_MAX_PAIRS <= 64 * 5, "pair table as five registers per lane");
+    int ptab[5];
+#pragma unroll
+    for (int q = 0; q < 5; q++) {
+        const int p = 64 * q + lane64;
+        ptab[q] = p < np ? ((int) c_skel.pair[p].a | ((int) c_skel.pair[p].b << 16)) : 0;
+    }
 #pragma unroll
     for (int k = 0; k < EVM_PACT_WORDS; k++) {   // (unrolled to the end: pw[k] is a register; words past the table are skipped)
         if (k < nwords) {
-            unsigned long long any = 0;  // pairs of this word active in some lane (wave-uniform walk over their union)
-            {
-                unsigned u = pw[k];
-#pragma unroll
-                for (int o = 32; o >= 1; o >>= 1) u |= __shfl_xor(u, o);
-                any = u;
-            }
+            // pairs of this word active in some env of the wave (wave-uniform walk over their union): the wave's envs sit in its
+            // first epw lanes (lane -> env lane % epw), so the union is an OR over those lanes
+            unsigned u = 0u;
+            for (int e = 0; e < epw; e++) u |= (unsigned) __builtin_amdgcn_readlane((int) pw[k], e);
+            unsigned long long any = u;
             while (any) {
                 const int bit = __builtin_ctzll(any);
                 any &= any - 1;
                 const int p = 32 * k + bit;
                 const bool act = (pw[k] >> bit) & 1u;
-                const int pa = (int) c_skel.pair[p].a, pb = (int) c_skel.pair[p].b;
+                const int q = p >> 6, pl = p & 63;
+                const int ab = __builtin_amdgcn_readlane(q == 0 ? ptab[0] : (q == 1 ? ptab[1] : (q == 2 ? ptab[2] : (q == 3 ? ptab[3] : ptab[4]))), pl);
+                const int pa = ab & 0xffff, pb = ab >> 16;
                 if (act) G_PLACE(nm + p, pa, pb)
             }
         }

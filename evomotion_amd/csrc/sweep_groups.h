@@ -481,7 +481,7 @@ __global__ __launch_bounds__(64 * EVM_G_MAX_WAVES) void k_sweeps_g(EnvDev d, con
     if (scm) {  // (program, words and inverse masses were initialised by every thread before the barrier above)
         {
             // every lane of the wave walks the ids of its env (the slots of an env redundantly: same values, same stores)
-            const int left_out = g_build_program(GC, nslots, nn_c, pw_c, pflags_c, prog, meta + 4 * wave);
+            const int left_out = g_build_program(GC, nslots, epw, nn_c, pw_c, pflags_c, prog, meta + 4 * wave);
             if (left_out > 0 && cs == 0 && clive) { atomicMax(d.resid, 0x7f800000); atomicAdd(&d.errs[1], left_out); }  // sticky
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
