@@ -329,21 +329,31 @@ DEV void sx_add(Simplex &s, F3 w, F3 p, F3 q) {
     for (int i = 0; i < 4; i++) { const bool h = s.n == i; s.W[i] = sel3(h, w, s.W[i]); s.P[i] = sel3(h, p, s.P[i]); s.Q[i] = sel3(h, q, s.Q[i]); }
     s.n++;
 }
-// removeVertex(i): the last vertex takes slot i
-DEV void sx_remove(Simplex &s, int i) {
-    s.n--;
-    const int l = s.n;
-    const F3 lw = sel3(l == 0, s.W[0], sel3(l == 1, s.W[1], sel3(l == 2, s.W[2], s.W[3])));
-    const F3 lp = sel3(l == 0, s.P[0], sel3(l == 1, s.P[1], sel3(l == 2, s.P[2], s.P[3])));
-    const F3 lq = sel3(l == 0, s.Q[0], sel3(l == 1, s.Q[1], sel3(l == 2, s.Q[2], s.Q[3])));
-#pragma unroll
-    for (int k = 0; k < 4; k++) { const bool h = i == k; s.W[k] = sel3(h, lw, s.W[k]); s.P[k] = sel3(h, lp, s.P[k]); s.Q[k] = sel3(h, lq, s.Q[k]); }
-}
+// reduceVertices: removeVertex(3), (2), (1), (0) for the unused ones, in that order, each moving the LAST vertex into the freed
+// slot.  The four conditional removals are simulated on slot indices (four 2-bit fields) and the vertices gathered once:
+// as four select cascades over the 36 simplex registers each, they were a sixth of a GJK iteration.
 DEV void sx_reduce(Simplex &s, const Bary &u) {
-    if (s.n >= 4 && !u.uD) sx_remove(s, 3);
-    if (s.n >= 3 && !u.uC) sx_remove(s, 2);
-    if (s.n >= 2 && !u.uB) sx_remove(s, 1);
-    if (s.n >= 1 && !u.uA) sx_remove(s, 0);
+    int n = s.n;
+    unsigned idx = 0xE4u;  // slot k holds original vertex (idx >> 2k) & 3: identity 3,2,1,0
+    auto rem = [&](int i) {
+        n--;
+        const unsigned last = (idx >> (2 * n)) & 3u;
+        idx = (idx & ~(3u << (2 * i))) | (last << (2 * i));
+    };
+    if (n >= 4 && !u.uD) rem(3);
+    if (n >= 3 && !u.uC) rem(2);
+    if (n >= 2 && !u.uB) rem(1);
+    if (n >= 1 && !u.uA) rem(0);
+    s.n = n;
+    const F3 W0 = s.W[0], W1 = s.W[1], W2 = s.W[2], W3 = s.W[3], P0 = s.P[0], P1 = s.P[1], P2 = s.P[2], P3 = s.P[3];
+    const F3 Q0 = s.Q[0], Q1 = s.Q[1], Q2 = s.Q[2], Q3 = s.Q[3];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int j = (int) ((idx >> (2 * k)) & 3u);
+        s.W[k] = sel3(j == 0, W0, sel3(j == 1, W1, sel3(j == 2, W2, W3)));
+        s.P[k] = sel3(j == 0, P0, sel3(j == 1, P1, sel3(j == 2, P2, P3)));
+        s.Q[k] = sel3(j == 0, Q0, sel3(j == 1, Q1, sel3(j == 2, Q2, Q3)));
+    }
 }
 DEV bool sx_in_simplex(const Simplex &s, F3 w) {
     bool found = false;
