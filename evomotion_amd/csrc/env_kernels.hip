@@ -2227,6 +2227,66 @@ __global__ __launch_bounds__(64 * EVM_NW) void k_split_sweeps(EnvDev d, const ui
     }
 }
 
+// The integration / observation items of k_split_post for processor vw of nvw, one env per lane whatever the lanes' envs are
+// (row-wise stores): the lane-group sweeps kernel runs them itself at its end (k_sweeps_g, fused form), on the 16 envs and 16
+// (wave, lane group) processors of its workgroup — a launch of its own cost 15 us per step for 3 us of work.  `mode` as
+// k_split_post's MODE (bit 0 motors powered, bit 1 observe, bit 2 rollout form).
+struct PostArgs {
+    float *obs, *reward;
+    uint8_t *done, *valid;
+    int mode;   // < 0: not fused (k_split_post follows)
+};
+DEV void post_items(const Ctx &c, const EnvDev &d, const PostArgs &pa, int vw, int nvw) {
+    const int MODE = pa.mode;
+    LaneState L;  // from the snapshot taken by the sweeps kernel: the live values are rewritten below by the root's processor
+    L.flags = __float_as_int(SC(c_skel.sc_snap));
+    L.settle0 = (MODE & 4) ? __float_as_int(SC(c_skel.sc_snap + 1)) : 0;
+    L.settling = L.settle0 > 0;
+    bool do_observe = (MODE & 2) != 0;
+    if ((MODE & 4) && L.settling) do_observe = L.settle0 == 1;
+    const bool any_observe = __any(do_observe);
+    F3 root_ms = f3(0.f, 0.f, 0.f);
+    if (any_observe) root_ms = SC3(c_skel.sc_rootms);
+    for (int b = vw; b < c_skel.nb; b += nvw) {
+        const BodyState st = body_integrate(c, b);
+        if (b < c_skel.nm && any_observe) {
+            float v[19];
+            if (do_observe) {
+                member_values(c, b, root_ms, v, &st);
+                float *o = pa.obs + (size_t) c.env * c_skel.obs_dim + 19 * c_skel.state_index[b];
+#pragma unroll
+                for (int k = 0; k < 19; k++) o[k] = v[k];
+            }
+        }
+        if (b == c_skel.root) {
+            // one writer per env: reward / termination / counters / rollout bookkeeping
+            int flags = L.flags & ~EVM_FLAG_PENDING;
+            if ((MODE & 1) && !L.settling) {
+                flags |= EVM_FLAG_POWERED;
+                if (MODE & 4) GS(stat, 0) += 1;
+            }
+            if (MODE & 4) {
+                if (L.settling) d.settle_left[c.env] = L.settle0 - 1;
+                pa.valid[c.env] = do_observe ? (L.settling ? 2 : 1) : 0;  // 1 = do_step transition, 2 = reset()'s own step
+            }
+            bool fin_next = false;
+            if (do_observe) {
+                observe_tail(c, pa.reward, pa.done);
+                if ((MODE & 4) && pa.done[c.env]) { flags |= EVM_FLAG_DONE; fin_next = true; }
+            }
+            d.flags[c.env] = flags;
+            if ((MODE & 4) && __any(fin_next)) {
+                // the next call starts this env's reset: draw its rotation ahead (read-only) for that call's setup kernels
+                const M33 N = repose_rotation(mt_peek01(c, 0), mt_peek01(c, 1), mt_peek01(c, 2));
+                if (fin_next) { SSC3(c_skel.sc_nexte, N.r0); SSC3(c_skel.sc_nexte + 3, N.r1); SSC3(c_skel.sc_nexte + 6, N.r2); }
+            }
+        }
+    }
+    if (any_observe)
+        for (int mi = vw; mi < c_skel.nmus; mi += nvw)
+            if (do_observe) observe_muscle(c, mi, pa.obs);
+}
+
 template <int MODE>
 __global__ __launch_bounds__(64 * EVM_SPLIT_WAVES) void k_split_post(EnvDev d, float *obs, float *reward, uint8_t *done,
                                                                        uint8_t *valid, const uint8_t *__restrict__ mask) {
@@ -2484,6 +2544,7 @@ static hipError_t launch_split(const EnvDev &d, size_t lds, const float *action,
         if (d.pmn) hipLaunchKernelGGL((k_split_pairs<MODE>), dim3(EVM_BIG_BLOCKS + tiles * d.npair_host), dim3(64), 0, s, d, mask, tiles);
     }
     if (e0) (void) hipEventRecord(e0, s);
+    bool fused_post = false;
     if (d.gs) {
         static bool attr_g[EVM_MAX_DEVICES] = {};
         if (!attr_g[dev]) {
@@ -2492,13 +2553,18 @@ static hipError_t launch_split(const EnvDev &d, size_t lds, const float *action,
             if (e != hipSuccess) return e;
             attr_g[dev] = true;
         }
-        hipLaunchKernelGGL(k_sweeps_g, dim3(tiles * (64 / EVM_G_ENVS)), dim3(64 * d.g_waves), (size_t) d.g_lds, s, d, mask, (MODE & 4) ? 1 : 0);
+        static int fuse = -1;   // EVM_FUSE_POST=0: integration / observation as a launch of its own (A/B)
+        if (fuse < 0) { const char *e = getenv("EVM_FUSE_POST"); fuse = (e && e[0] == '0') ? 0 : 1; }
+        fused_post = fuse != 0;
+        PostArgs pa;
+        pa.obs = obs; pa.reward = reward; pa.done = done; pa.valid = valid; pa.mode = fused_post ? MODE : -1;
+        hipLaunchKernelGGL(k_sweeps_g, dim3(tiles * (64 / EVM_G_ENVS)), dim3(64 * d.g_waves), (size_t) d.g_lds, s, d, mask, (MODE & 4) ? 1 : 0, pa);
     } else {
         if (d.gtile_only) hipLaunchKernelGGL(k_split_sweeps<true>, dim3(tiles), dim3(64 * EVM_NW), 0, s, d, mask, (MODE & 4) ? 1 : 0);
         else hipLaunchKernelGGL(k_split_sweeps<false>, dim3(tiles), dim3(64 * EVM_NW), lds, s, d, mask, (MODE & 4) ? 1 : 0);
     }
     if (e1) (void) hipEventRecord(e1, s);
-    hipLaunchKernelGGL((k_split_post<MODE>), gp, bp, 0, s, d, obs, reward, done, valid, mask);
+    if (!fused_post) hipLaunchKernelGGL((k_split_post<MODE>), gp, bp, 0, s, d, obs, reward, done, valid, mask);
     return hipGetLastError();
 }
 hipError_t launch_step(const EnvDev &d, size_t lds_bytes, int split, int mode, const float *action, float *obs, float *reward,

@@ -289,7 +289,7 @@ DEV Ctx make_ctx_at(const EnvDev &d, float *lds, int tile64, int lane64, int wav
     return c;
 }
 
-__global__ __launch_bounds__(64 * EVM_G_MAX_WAVES) void k_sweeps_g(EnvDev d, const uint8_t *__restrict__ mask, int autoreset) {
+__global__ __launch_bounds__(64 * EVM_G_MAX_WAVES) void k_sweeps_g(EnvDev d, const uint8_t *__restrict__ mask, int autoreset, PostArgs pa) {
     extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
     const EvmGSchedC *__restrict__ gs = d.gs;
     const int lane = threadIdx.x & 63;
@@ -807,6 +807,17 @@ __global__ __launch_bounds__(64 * EVM_G_MAX_WAVES) void k_sweeps_g(EnvDev d, con
         lin = lin + f3(0.f, c_skel.body[b].ext_force_y, 0.f);
         const F3 o2 = integ_pos(o, lin, DT_F);
         SSC3(c_skel.sc_rootms, integ_pos(o2, lin, 0.f - DT_F));
+    }
+    // ---- fused form: the integration / observation items of k_split_post for this workgroup's 16 envs, by its 16 (wave, lane
+    // group) processors.  Everything they read was written above by this workgroup (deltas in the staging copy, snapshot, root
+    // motion state, muscle read-backs) or by earlier kernels: one barrier (with its workgroup-scope fences) in between.
+    if (pa.mode >= 0) {
+        __syncthreads();
+        if (live) {
+            Ctx cp = c;
+            cp.lds = d.gtile + (size_t) tile64 * d.tile_floats;
+            post_items(cp, d, pa, wave * EVM_G_SLOTS + G.g, EVM_G_SLOTS * nw);
+        }
     }
 #ifdef EVM_GSTAMPS2  // per wave: cycles in the sweeps phase, cycles of it spent waiting for versions, entries run (tools/gstamps.py --waves)
     if (sub == 0 && lane == (int) __builtin_ctzll(__ballot(true)) && wave < 4) {
