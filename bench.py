@@ -449,9 +449,9 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n, args.self_collision)[0], "traffic_source": measured_traffic(n, args.self_collision)[1],
-                "kernel": ("k_sweeps_g (dominant: the Gauss-Seidel sweeps) + k_split_pre_a / pre_b / %spost: one step" % ("pairs / " if args.self_collision else "") if ms_sweeps > 0 else "k_env_step<7>"),
+                "kernel": ("k_sweeps_g (dominant: the Gauss-Seidel sweeps) + k_split_pre_a / %s: one step" % ("pairs_rec" if args.self_collision else "pre_b") if ms_sweeps > 0 else "k_env_step<7>"),
                 "launch_ms": launch_ms, "sampled_step_ms": sampled_ms, "dominant_kernel_ms": (ms_sweeps / max(n_launch, 1)) if ms_sweeps > 0 else launch_ms,
-                "note": "algorithmic 8300 B per env physics step x %d envs per step; a step is a pipeline of four kernels (five with member-vs-member contacts: + the narrowphase) up to "
+                "note": "algorithmic 8300 B per env physics step x %d envs per step; a step is a pipeline of three kernels (setup, records [+ narrowphase with member-vs-member contacts], sweeps + integration) up to "
                         "8192 envs (launch_ms = all of them, HIP events on the launch stream; dominant_kernel_ms = the Gauss-Seidel "
                         "sweeps kernel alone), one monolithic kernel above; fp32-VALU/latency bound (about 50 FLOP per algorithmic "
                         "byte); traffic = memory-side bytes per step from the committed rocprofv3 PMC passes "
