@@ -8,5 +8,6 @@ from .env import RolloutStep, Step, VecRobotJump, VecRobotWalk, get_environment 
 from .agent import (ActorModule, CriticModule, FusedActorCritic, PpoGaeAgent, RandomAgent, TrajectoryReplayBuffer, VecPpoGaeAgent,  # noqa: F401,E402
                     truncated_normal_log_pdf, truncated_normal_entropy, truncated_normal_sample)
 from .checkpoint import load_into, load_th, save_th  # noqa: F401,E402
+from .metrics import LossMeter  # noqa: F401,E402
 from .replay import ReplayRing  # noqa: F401,E402
 from .sac import EntropyParameter, QNetworkModule, ReplayBuffer, SoftActorCriticAgent, VecSacAgent  # noqa: F401,E402

@@ -479,7 +479,10 @@ class PpoGaeAgent(VecPpoGaeAgent):
         self._open = [None] * self.n_envs      # the open trajectory of every env (a list inside replay_buffer.memory)
         self._act_calls = 0
         self.S, self.A = int(state_space[0]), int(action_space[0])
-        self.episode_steps = []
+        from .metrics import LossMeter
+        # ppo_gae.cpp:23-24: the three meters of get_metrics(), windows of 64
+        self.actor_loss_meter, self.critic_loss_meter = LossMeter("actor_loss", 64), LossMeter("critic_loss", 64)
+        self.episode_steps_meter = LossMeter("steps", 64)
 
     # -- Agent interface ---------------------------------------------------------------------------------------------------
     def _forward(self, states, uniform=None):
@@ -515,7 +518,7 @@ class PpoGaeAgent(VecPpoGaeAgent):
         self.check_train()
         self._open[env] = self.replay_buffer.new_trajectory() if self.n_envs == 1 else None   # (n_envs > 1: opened by its next act())
         self.global_curr_step += 1
-        self.episode_steps.append(self.curr_episode_step[env])
+        self.episode_steps_meter.add(float(self.curr_episode_step[env]))
         self.curr_episode_step[env] = 0
 
     def check_train(self):
@@ -542,13 +545,20 @@ class PpoGaeAgent(VecPpoGaeAgent):
         tr = self._get_trainer(T * B)
         hp = self.hp
         out = tr.train(states, actions, rewards, done, logp, values, next_values, mask, hp["gamma"], hp["lam"], hp["epsilon"],
-                       hp["entropy_factor"], hp["critic_loss_factor"], hp["epoch"], self.learning_rate, hp["clip_grad_norm"])
+                       hp["entropy_factor"], hp["critic_loss_factor"], hp["epoch"], self.learning_rate, hp["clip_grad_norm"],
+                       loss_hook=self._meter_losses)
         self._modules_stale = True
         self.curr_train_step += 1
         return out
 
+    def _meter_losses(self, actor_loss, critic_loss):
+        """after every epoch of train(), like ppo_gae.cpp:185-186"""
+        self.actor_loss_meter.add(actor_loss)
+        self.critic_loss_meter.add(critic_loss)
+
     def get_metrics(self):
-        return {"steps": self.episode_steps[-64:]}
+        """ppo_gae.cpp:205-207"""
+        return [self.actor_loss_meter, self.critic_loss_meter, self.episode_steps_meter]
 
     def to(self, device):
         return self

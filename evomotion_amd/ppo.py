@@ -202,8 +202,10 @@ class FusedPpoTrainer:
         return a.value, c.value
 
     def train(self, states, actions, rewards, done_u8, logp_old, values, next_values, mask_u8, gamma, lam, epsilon,
-              entropy_factor, critic_loss_factor, epoch, learning_rate, clip_grad_norm):
-        """time-major rollout: states [T, N, S], actions / logp_old [T, N, A], the rest [T, N]"""
+              entropy_factor, critic_loss_factor, epoch, learning_rate, clip_grad_norm, loss_hook=None):
+        """time-major rollout: states [T, N, S], actions / logp_old [T, N, A], the rest [T, N].  loss_hook(actor_loss,
+        critic_loss): called after every epoch with that epoch's losses (the LossMeter adds of ppo_gae.cpp:185-186; reading
+        them synchronises the stream, so the fast path leaves it None)"""
         T, N = rewards.shape
         adv, ret, n_glob = self.gae(rewards, done_u8, values, next_values, mask_u8, gamma, lam)
         # nothing selected on any rank: the device-side count makes every gradient zero (and the losses zero); callers train on
@@ -213,6 +215,8 @@ class FusedPpoTrainer:
         for ep in range(epoch):
             self.epoch(st, ac, lp, adv.reshape(-1), ret.reshape(-1), mask_u8.reshape(-1), n_glob, epsilon, entropy_factor,
                        critic_loss_factor, learning_rate, clip_grad_norm, states_unchanged=ep > 0)
+            if loss_hook is not None:
+                loss_hook(*self.losses())
         return self.losses()
 
     def timing(self, enable):

@@ -420,7 +420,11 @@ class SoftActorCriticAgent(VecSacAgent):
         self.S, self.A = int(state_space[0]), int(action_space[0])
         self.curr_episode_step = self.curr_train_step = self.global_curr_step = 0
         self._act_calls = 0
-        self.episode_steps, self.episode_rewards = [], []
+        from .metrics import LossMeter
+        # soft_actor_critic.cpp:36-38: the six meters of get_metrics(), windows of 64
+        self.actor_loss_meter, self.critic_1_loss_meter = LossMeter("actor", 64), LossMeter("critic_1", 64)
+        self.critic_2_loss_meter, self.entropy_loss_meter = LossMeter("critic_2", 64), LossMeter("entropy", 64)
+        self.episode_steps_meter, self.rewards_meter = LossMeter("steps", 64), LossMeter("rewards", 64)
 
     def _obs(self, state):
         return state.to(device=self.device, dtype=torch.float32).reshape(1, self.S).contiguous()
@@ -457,6 +461,10 @@ class SoftActorCriticAgent(VecSacAgent):
             u = train_uniforms[e] if train_uniforms is not None else (None, None)
             dev = lambda t: None if t is None else t.to(device=self.device, dtype=torch.float32).contiguous()
             self.last_losses = self._train_once_hip(u_next=dev(u[0]), u_curr=dev(u[1]))
+            # soft_actor_critic.cpp:164-167 (float() reads the device values: this is the reference-shaped one-env surface)
+            for meter, key in ((self.actor_loss_meter, "actor"), (self.critic_1_loss_meter, "critic_1"),
+                               (self.critic_2_loss_meter, "critic_2"), (self.entropy_loss_meter, "entropy")):
+                meter.add(float(self.last_losses[key]))
             self.train_steps += 1
             self.curr_train_step += 1
         return self.epoch
@@ -464,15 +472,14 @@ class SoftActorCriticAgent(VecSacAgent):
     def done(self, state, reward):
         """the episode has ended in `state` (its terminal observation) with `reward` (soft_actor_critic.cpp:172-180)"""
         self.replay_buffer.update_last(float(reward), self._obs(state)[0], True)
-        self.episode_rewards.append(float(reward))
-        self.episode_steps.append(self.curr_episode_step)
+        self.rewards_meter.add(float(reward))                          # :175-176
+        self.episode_steps_meter.add(float(self.curr_episode_step))
         self.curr_episode_step = 0
 
     def get_metrics(self):
-        out = {"steps": self.episode_steps[-64:], "rewards": self.episode_rewards[-64:]}
-        if self.last_losses is not None:
-            out.update({k: float(v) for k, v in self.last_losses.items()})
-        return out
+        """soft_actor_critic.cpp:223-226"""
+        return [self.actor_loss_meter, self.critic_1_loss_meter, self.critic_2_loss_meter, self.entropy_loss_meter,
+                self.episode_steps_meter, self.rewards_meter]
 
     def to(self, device):
         return self

@@ -143,12 +143,16 @@ int main(int argc, char **argv) {
             fclose(o);
         }
         const auto metrics = agent->get_metrics();
+        // the reference's own known answers for LossMeter (evo_motion_networks/tests/src/test_metrics.cpp:20-25)
+        auto meter_case = [](std::vector<float> v, int window) { LossMeterHip m("test", window); for (float x : v) m.add(x); return m.loss(); };
+        const float mk[3] = {meter_case({1.f, 2.f, 1.f, 2.f}, 4), meter_case({1.f, 2.f, 1.f, 2.f}, 2), meter_case({1.f, 1.f, 2.f, 2.f}, 2)};
         printf("{\"done\": %s], \"buffer\": %s], \"sample\": %s], \"trains\": %d, \"curr_train_step\": %ld, \"actor_loss\": %.17g, \"critic_loss\": %.17g, "
                "\"metric_names\": [\"%s\", \"%s\", \"%s\"], \"steps_meter\": %.9g, \"missing_key\": \"%s\", \"unknown_name\": \"%s\", \"ckpt_equal\": %s, "
-               "\"count_parameters\": %d}\n",
+               "\"count_parameters\": %d, \"loss_meter_adds\": %d, \"meter_known_answers\": [%.9g, %.9g, %.9g], \"steps_string\": \"%s\"}\n",
                js_done.c_str(), js_buffer.c_str(), js_sample.c_str(), trains, agent->curr_train_step, agent->last_actor_loss, agent->last_critic_loss,
                metrics[0].name().c_str(), metrics[1].name().c_str(), metrics[2].name().c_str(), metrics[2].loss(), missing_key.c_str(),
-               unknown_name.c_str(), ckpt_equal ? "true" : "false", agent->count_parameters());
+               unknown_name.c_str(), ckpt_equal ? "true" : "false", agent->count_parameters(), (int) metrics[0].count(), mk[0], mk[1], mk[2],
+               metrics[2].to_string().c_str());
         (void) hipFree(d_state); (void) hipFree(d_uniform);
     } catch (const std::exception &e) {
         fprintf(stderr, "agent_loop_main: %s\n", e.what());

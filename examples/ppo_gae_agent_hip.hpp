@@ -30,6 +30,7 @@
 #include <deque>
 #include <fstream>
 #include <functional>
+#include <iomanip>
 #include <map>
 #include <memory>
 #include <numeric>
@@ -46,13 +47,20 @@ namespace evm_adapter {
 class LossMeterHip {
 public:
     LossMeterHip(std::string name, int window_size) : name_(std::move(name)), window(window_size) {}
-    void add(float v) {
+    void add(float v) {  // metrics.cpp:17-23: room is made before the value goes in
+        while ((int) results.size() >= window) results.pop_front();
         results.push_back(v);
-        while ((int) results.size() > window) results.pop_front();
+        curr_step++;
     }
     float loss() const { return results.empty() ? 0.f : std::accumulate(results.begin(), results.end(), 0.f) / (float) results.size(); }
-    std::string to_string() const { std::ostringstream s; s << name_ << " = " << loss(); return s.str(); }
+    std::string to_string() const {  // metrics.cpp:52-56,70-74
+        std::ostringstream s;
+        s << name_ << " = " << std::setprecision(6) << std::fixed << loss();
+        return s.str();
+    }
     const std::string &name() const { return name_; }
+    size_t count() const { return results.size(); }
+    long curr_step = 0;
 
 private:
     std::string name_;
@@ -436,12 +444,13 @@ private:
                 check(evm_ppo_grads(trainer, rows, states, actions, logp, adv, ret, mask_d, -1.0, epsilon, entropy_factor, critic_loss_factor,
                                     ep > 0 ? 1 : 0, stream));
                 check(evm_ppo_apply(trainer, learning_rate, clip_grad_norm, stream));
+                // the LossMeter adds of ppo_gae.cpp:185-186, once per epoch (synchronises: the host vectors above may go)
+                double la = 0.0, lc = 0.0;
+                check(evm_ppo_losses(trainer, &la, &lc, stream));
+                actor_loss_meter.add((float) la);
+                critic_loss_meter.add((float) lc);
+                last_actor_loss = la; last_critic_loss = lc;
             }
-            double la = 0.0, lc = 0.0;
-            check(evm_ppo_losses(trainer, &la, &lc, stream));  // (synchronises: the host vectors above may go)
-            actor_loss_meter.add((float) la);
-            critic_loss_meter.add((float) lc);
-            last_actor_loss = la; last_critic_loss = lc;
         } catch (...) {
             (void) hipStreamSynchronize(stream);
             (void) hipFree(fl); (void) hipFree(by);

@@ -63,7 +63,10 @@ def test_product_agent_reproduces_the_reference_episode_loop():
     np.testing.assert_allclose(value.cpu().numpy(), gold["after_value"].ravel(), atol=1e-2)   # (ill-conditioned head: DESIGN.md §6)
     agent.sync_modules()
     np.testing.assert_allclose(agent.actor.head[0].weight[0].detach().cpu().numpy(), gold["after_actor_w0_row0"], atol=3e-5)
-    assert agent.get_metrics()["steps"] == gold["lengths"]
+    meters = agent.get_metrics()
+    assert [m.name for m in meters] == ["actor_loss", "critic_loss", "steps"]                   # ppo_gae.cpp:205-207
+    assert meters[2].values == [float(v) for v in gold["lengths"]]
+    assert len(meters[0].values) == len(meters[1].values) == gold["trains"] * epoch               # one add per epoch (:185-186)
 
 
 def test_vector_form_keeps_one_trajectory_per_env():

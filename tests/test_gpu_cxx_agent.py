@@ -85,6 +85,9 @@ def test_cxx_agent_reproduces_the_reference_episode_loop_and_the_python_agent(tm
     np.testing.assert_allclose(params[:H * S].reshape(H, S)[0], gold["after_actor_w0_row0"], atol=3e-5)
     assert line["metric_names"] == ["actor_loss", "critic_loss", "steps"]                        # ppo_gae.cpp:205-207
     assert abs(line["steps_meter"] - np.mean(lengths)) < 1e-5                                      # episode_steps_meter, window 64
+    assert line["loss_meter_adds"] == gold["trains"] * epoch                                       # one add per epoch (:185-186)
+    assert line["meter_known_answers"] == [1.5, 1.5, 2.0]                                         # test_metrics.cpp:20-25
+    assert line["steps_string"] == "steps = %.6f" % np.mean(lengths)                                # metrics.cpp:52-56,70-74
     assert line["missing_key"] == "gamma" and line["unknown_name"] == "no_such_agent"            # agent_factory.cpp:27,208-209
     assert line["ckpt_equal"] is True and line["count_parameters"] == pa.size + pc.size == 330521
     assert np.isfinite(line["actor_loss"]) and np.isfinite(line["critic_loss"])

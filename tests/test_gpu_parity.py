@@ -100,11 +100,12 @@ def test_teacher_forced_steps(torch_mod, orc_lib):
                 o.reset()
     print("teacher-forced worst:", worst)
     # fp32 tolerances for ONE 1/60 s step from identical state
-    assert worst["pos"] < 5e-6 and worst["quat"] < 5e-6
-    assert worst["lin"] < 5e-4 and worst["ang"] < 2e-3
-    assert worst["obs"] < 2e-3 and worst["rew"] < 1e-4
+    # (observed on MI355X, round 3: pos 4.8e-7, quat 6.6e-7, lin 3.0e-5, ang 7.8e-5, obs 3.0e-5, rew 1.5e-6, no slider flip)
+    assert worst["pos"] < 2e-6 and worst["quat"] < 3e-6
+    assert worst["lin"] < 1.5e-4 and worst["ang"] < 4e-4
+    assert worst["obs"] < 2e-4 and worst["rew"] < 1e-5
     assert worst["done"] == 0 and worst["mf"] == 0
-    assert worst["slider_imp_flips"] <= 0.01 * n * steps * 12
+    assert worst["slider_imp_flips"] <= 0.002 * n * steps * 12
 
 
 def test_free_running_rollout(torch_mod, orc_lib):
@@ -117,7 +118,7 @@ def test_free_running_rollout(torch_mod, orc_lib):
     assert np.isfinite(og).all()
     errs = [np.abs(env.body_poses().cpu().numpy()[i, :17, :3] - orcs[i].poses()[:17, :3]).max() for i in range(n)]
     print("member position error after the 60 settle steps of reset(): max %.3g median %.3g" % (max(errs), np.median(errs)))
-    assert np.median(errs) < 2e-2 and max(errs) < 0.3
+    assert np.median(errs) < 1e-3 and max(errs) < 0.03   # (observed: median 7.5e-6, max 4.9e-3 — 60 free-running settle steps)
     rng = np.random.default_rng(3)
     for k in range(steps):
         a = rng.uniform(-1, 1, (n, 12)).astype(np.float32)
@@ -127,7 +128,8 @@ def test_free_running_rollout(torch_mod, orc_lib):
     pg = env.body_poses().cpu().numpy()
     errs = [np.linalg.norm(pg[i, :17, :3] - orcs[i].poses()[:17, :3], axis=1).max() for i in range(n)]
     print("per-env max member L2 after %d free-running steps: median %.3g max %.3g" % (steps, np.median(errs), max(errs)))
-    assert np.median(errs) < 0.1
+    # chaotic from here on (contacts make or break on rounding differences: one env of 16 is 0.22 m away); observed median 1.6e-4
+    assert np.median(errs) < 5e-3
 
 
 def test_masked_reset_and_ragged_batch(torch_mod, orc_lib):

@@ -66,4 +66,6 @@ def test_product_sac_agent_reproduces_the_reference_episode_loop():
         np.testing.assert_allclose(agent.target_critic_1(x, ac).cpu().numpy(), gold["after_tq1"], atol=1e-3)
         np.testing.assert_allclose(agent.target_critic_2(x, ac).cpu().numpy(), gold["after_tq2"], atol=1e-3)
     np.testing.assert_allclose(agent.entropy.log_alpha.detach().cpu().numpy(), gold["after_log_alpha"], atol=2e-5)
-    assert agent.get_metrics()["steps"] == gold["lengths"]
+    names = [m.name for m in agent.get_metrics()]
+    assert names == ["actor", "critic_1", "critic_2", "entropy", "steps", "rewards"]          # soft_actor_critic.cpp:223-226
+    assert agent.get_metrics()[4].values == [float(v) for v in gold["lengths"]]
