@@ -1,0 +1,88 @@
+"""The narrowphase restatement (oracle/orc_narrow.cpp: GJK closest points after btGjkPairDetector / btVoronoiSimplexSolver) against
+an INDEPENDENT known answer that shares no code and no algorithm with it: convex duality.  For two convex polytopes and ANY unit
+direction n, the support gap  sep(n) = min_i n.a_i - max_j n.b_j  is a LOWER bound of their distance, and the length of ANY
+segment between a point of conv(A) and a point of conv(B) is an UPPER bound; the two meet only at the true distance and the true
+(unique) closest direction.  So a query result is exact if and only if
+    * its witness points lie in the two hulls (checked as linear-programme feasibility, scipy.optimize.linprog, float64), and
+    * the support gap along its normal equals the length of the witness segment.
+Reported quantities follow Bullet's convention: distance = core distance - the two 0.04 margins, the witness on B pushed out by B's
+margin along the normal (from B towards A).  Bullet is not installed here, so this is the analytic pin of the round's new collision
+code; the HIP narrowphase is held to this oracle point for point (tests/test_gpu_selfcol.py).  Touching / penetrating CORES are left
+out: there the restatement uses the sampled-direction penetration solver instead of EPA."""
+import numpy as np
+import pytest
+from scipy.optimize import linprog
+
+import orc
+
+MARGIN = 0.04
+CUBE = np.array([[x, y, z] for x in (-1, 1) for y in (-1, 1) for z in (-1, 1)], np.float32)
+
+
+def _rot(rng):
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    w, x, y, z = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def _world(pts, scale, R, o):
+    return (np.asarray(pts, np.float64) * np.asarray(scale, np.float64)) @ R.T + o
+
+
+def _outside_hull(P, x):
+    """how far x is from conv(P) in the max norm: min t  s.t.  |P^T mu - x| <= t, mu >= 0, sum mu = 1"""
+    n = len(P)
+    c = np.zeros(n + 1); c[-1] = 1.0
+    A_ub = np.block([[P.T, -np.ones((3, 1))], [-P.T, -np.ones((3, 1))]])
+    b_ub = np.concatenate([x, -x])
+    A_eq = np.concatenate([np.ones(n), [0.0]])[None, :]
+    res = linprog(c, A_ub=A_ub, b_ub=b_ub, A_eq=A_eq, b_eq=[1.0], bounds=[(0, None)] * (n + 1), method="highs")
+    assert res.status == 0
+    return float(res.x[-1])
+
+
+def _random_hull(rng, n):
+    p = rng.normal(size=(n, 3))
+    p /= np.linalg.norm(p, axis=1, keepdims=True)
+    return (p * rng.uniform(0.6, 1.0, (n, 1))).astype(np.float32)
+
+
+@pytest.mark.parametrize("kind", ["box_box", "box_hull", "hull_hull", "box_big_hull"])
+def test_gjk_results_are_certified_by_convex_duality(orc_lib, kind):
+    rng = np.random.default_rng({"box_box": 1, "box_hull": 2, "hull_hull": 3, "box_big_hull": 4}[kind])
+    checked = in_margin = 0
+    worst_gap = worst_in = 0.0
+    for trial in range(120):
+        ptsA = CUBE if kind.startswith("box") else _random_hull(rng, 24)
+        ptsB = CUBE if kind == "box_box" else _random_hull(rng, 451 if kind == "box_big_hull" else 32)
+        sA, sB = rng.uniform(0.08, 0.4, 3).astype(np.float32), rng.uniform(0.08, 0.4, 3).astype(np.float32)
+        RA, RB = _rot(rng).astype(np.float32), _rot(rng).astype(np.float32)
+        oA = rng.uniform(-0.2, 0.2, 3).astype(np.float32)
+        d = rng.normal(size=3)
+        oB = (oA + d / np.linalg.norm(d) * rng.uniform(0.15, 0.9)).astype(np.float32)
+        r = orc.gjk_query(ptsA, sA, (RA, oA), ptsB, sB, (RB, oB), lib=orc_lib)
+        assert r["has"], (kind, trial)
+        if r["used_penetration"] or r["distance"] + 2 * MARGIN < 2e-3:   # touching / penetrating cores
+            continue
+        A, B = _world(ptsA, sA, RA.astype(np.float64), oA.astype(np.float64)), _world(ptsB, sB, RB.astype(np.float64), oB.astype(np.float64))
+        n = r["normal"].astype(np.float64)
+        assert abs(np.linalg.norm(n) - 1.0) < 1e-5
+        core = r["distance"] + 2 * MARGIN                              # length of the witness segment between the cores
+        pb = r["point_b"].astype(np.float64) - MARGIN * n            # witness on B's core
+        pa = pb + core * n                                             # ... and on A's
+        lower = float((A @ n).min() - (B @ n).max())                   # support gap along the reported normal <= true distance
+        worst_in = max(worst_in, _outside_hull(A, pa), _outside_hull(B, pb))
+        worst_gap = max(worst_gap, abs(core - lower))
+        assert lower <= core + 2e-5, (kind, trial, lower, core)
+        checked += 1
+        in_margin += core < 2 * MARGIN
+    print("%s: %d queries certified (%d inside the margins): duality gap <= %.2e, witnesses within %.2e of the hulls" % (kind, checked, in_margin, worst_gap, worst_in))
+    assert checked >= 40 and in_margin >= 5
+    assert worst_in < 5e-5
+    # Boxes: exact to fp32 rounding (observed 6e-6).  Many-vertex hulls: Bullet's simplex solver treats a new support point within
+    # 1 cm of a simplex vertex as already in the simplex (BT_USE_EQUAL_VERTEX_THRESHOLD, distance^2 <= 1e-4) and stops there, so the
+    # answer may be short of the optimum by a fraction of that centimetre (observed up to 5.7e-3): restated on purpose, bounded here.
+    assert worst_gap < (2e-5 if kind == "box_box" else 1e-2)
