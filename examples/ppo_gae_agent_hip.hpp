@@ -284,6 +284,7 @@ public:
     }
     // ppo_gae.cpp:47-61: the terminal state, before the environment is reset (src/train.cpp:64-65)
     void done(const float *d_state, float reward) override {
+        if (replay_buffer.trajectory_empty()) throw std::logic_error("done() before the episode's first act()");  // (the reference dereferences an empty vector here)
         forward(d_state, nullptr);
         replay_buffer.last().update_last(reward, true, d_out + 2 * A, stream);
         trained_last_done = check_train();

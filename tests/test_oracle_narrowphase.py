@@ -86,3 +86,43 @@ def test_gjk_results_are_certified_by_convex_duality(orc_lib, kind):
     # 1 cm of a simplex vertex as already in the simplex (BT_USE_EQUAL_VERTEX_THRESHOLD, distance^2 <= 1e-4) and stops there, so the
     # answer may be short of the optimum by a fraction of that centimetre (observed up to 5.7e-3): restated on purpose, bounded here.
     assert worst_gap < (2e-5 if kind == "box_box" else 1e-2)
+
+
+def _sat_depth(RA, hA, oA, RB, hB, oB):
+    """exact penetration depth of two overlapping boxes (the minimal translation that separates them): the smallest overlap over the
+    15 separating-axis candidates — what an exact solver such as Bullet's EPA converges to"""
+    axes = [RA[:, i] for i in range(3)] + [RB[:, i] for i in range(3)]
+    for i in range(3):
+        for j in range(3):
+            c = np.cross(RA[:, i], RB[:, j])
+            if np.linalg.norm(c) > 1e-6:
+                axes.append(c / np.linalg.norm(c))
+    t = oB - oA
+    return min(sum(hA[i] * abs(n @ RA[:, i]) for i in range(3)) + sum(hB[i] * abs(n @ RB[:, i]) for i in range(3)) - abs(n @ t) for n in axes)
+
+
+def test_the_documented_deviation_sampled_penetration_depth_against_the_exact_one(orc_lib):
+    """Cores that overlap go to the penetration solver, and there the restatement deviates from the reference ON PURPOSE (DESIGN.md
+    §2c): btMinkowskiPenetrationDepthSolver's 42 sampled directions instead of EPA.  This test puts numbers on it with boxes, whose
+    exact depth is known (separating-axis theorem): the sampled depth is never below the exact one and exceeds it by 5 % in the median,
+    28 % at worst.  It does not occur in rollouts (0 of 79 728 pair queries needed the solver: the contact rows separate bodies inside
+    the 0.08 m of margins) — the bound is here so that the size of the deviation is a measured fact."""
+    rng = np.random.default_rng(5)
+    ratios = []
+    for trial in range(400):
+        sA, sB = rng.uniform(0.08, 0.4, 3).astype(np.float32), rng.uniform(0.08, 0.4, 3).astype(np.float32)
+        RA, RB = _rot(rng).astype(np.float32), _rot(rng).astype(np.float32)
+        oA = rng.uniform(-0.2, 0.2, 3).astype(np.float32)
+        d = rng.normal(size=3)
+        oB = (oA + d / np.linalg.norm(d) * rng.uniform(0.02, 0.3)).astype(np.float32)
+        core = _sat_depth(RA.astype(np.float64), sA.astype(np.float64), oA.astype(np.float64), RB.astype(np.float64), sB.astype(np.float64), oB.astype(np.float64))
+        if core <= 1e-3:
+            continue
+        r = orc.gjk_query(CUBE, sA, (RA, oA), CUBE, sB, (RB, oB), lib=orc_lib)
+        assert r["has"] and r["used_penetration"] and r["distance"] < 0, (trial, core, r)
+        ratios.append(-r["distance"] / (core + 2 * MARGIN))     # both include the two margins
+    ratios = np.array(ratios)
+    print("sampled / exact penetration depth over %d overlapping box pairs: min %.3f median %.3f p90 %.3f max %.3f"
+          % (len(ratios), ratios.min(), np.median(ratios), np.percentile(ratios, 90), ratios.max()))
+    assert len(ratios) > 300
+    assert ratios.min() > 1 - 1e-3 and np.median(ratios) < 1.1 and ratios.max() < 1.5
