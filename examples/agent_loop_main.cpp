@@ -142,17 +142,32 @@ int main(int argc, char **argv) {
             fwrite(tail.data(), sizeof(float), tail.size(), o);
             fclose(o);
         }
+        // the debug agents through the same factory (debug_agents.cpp:7-39): three actions of the random agent after seed 1234 — the
+        // compiled reference's golden (tests/golden/agent_golden.txt: random_agent_actions) — and the constant agent
+        std::string js_random = "[";
+        {
+            auto ra = get_agent_factory("random", {{"seed", "1234"}})->create_agent({S}, {12});
+            for (int k = 0; k < 3; k++) {
+                const auto a = from_device(ra->act(d_state, 0.f), 12);
+                for (int i = 0; i < 12; i++) { char b[32]; snprintf(b, sizeof b, "%s%.9g", (k || i) ? "," : "", a[i]); js_random += b; }
+            }
+            ra->done(d_state, 0.f); ra->save("/nonexistent"); ra->load("/nonexistent");
+            if (ra->count_parameters() != 0 || !ra->get_metrics().empty()) throw std::runtime_error("debug agent interface");
+        }
+        const auto ca = from_device(get_agent_factory("constant", {{"action_value", "0.25"}})->create_agent({S}, {A})->act(d_state, 0.f), A);
+        std::string constant_missing;
+        try { get_agent_factory("constant", {})->create_agent({S}, {A}); } catch (const std::invalid_argument &e) { constant_missing = e.what(); }
         const auto metrics = agent->get_metrics();
         // the reference's own known answers for LossMeter (evo_motion_networks/tests/src/test_metrics.cpp:20-25)
         auto meter_case = [](std::vector<float> v, int window) { LossMeterHip m("test", window); for (float x : v) m.add(x); return m.loss(); };
         const float mk[3] = {meter_case({1.f, 2.f, 1.f, 2.f}, 4), meter_case({1.f, 2.f, 1.f, 2.f}, 2), meter_case({1.f, 1.f, 2.f, 2.f}, 2)};
         printf("{\"done\": %s], \"buffer\": %s], \"sample\": %s], \"trains\": %d, \"curr_train_step\": %ld, \"actor_loss\": %.17g, \"critic_loss\": %.17g, "
                "\"metric_names\": [\"%s\", \"%s\", \"%s\"], \"steps_meter\": %.9g, \"missing_key\": \"%s\", \"unknown_name\": \"%s\", \"ckpt_equal\": %s, "
-               "\"count_parameters\": %d, \"loss_meter_adds\": %d, \"meter_known_answers\": [%.9g, %.9g, %.9g], \"steps_string\": \"%s\"}\n",
+               "\"count_parameters\": %d, \"loss_meter_adds\": %d, \"meter_known_answers\": [%.9g, %.9g, %.9g], \"steps_string\": \"%s\", \"random_actions\": %s], \"constant_action\": [%.9g, %.9g], \"constant_missing\": \"%s\"}\n",
                js_done.c_str(), js_buffer.c_str(), js_sample.c_str(), trains, agent->curr_train_step, agent->last_actor_loss, agent->last_critic_loss,
                metrics[0].name().c_str(), metrics[1].name().c_str(), metrics[2].name().c_str(), metrics[2].loss(), missing_key.c_str(),
                unknown_name.c_str(), ckpt_equal ? "true" : "false", agent->count_parameters(), (int) metrics[0].count(), mk[0], mk[1], mk[2],
-               metrics[2].to_string().c_str());
+               metrics[2].to_string().c_str(), js_random.c_str(), ca[0], ca[A - 1], constant_missing.c_str());
         (void) hipFree(d_state); (void) hipFree(d_uniform);
     } catch (const std::exception &e) {
         fprintf(stderr, "agent_loop_main: %s\n", e.what());

@@ -15,8 +15,9 @@
 //                               pass is evm_policy_forward (one row), train() is evm_ppo_gae / _gae_normalize / `epoch` x
 //                               (_grads, _apply) on the time-major [T][B] batch — the calls evomotion_amd/agent.py::PpoGaeAgent
 //                               makes, so both produce the same weights bit for bit (tests/test_gpu_cxx_agent.py).
-//   get_agent_factory           agent_factory.cpp:186-211 for the name "ppo_gae" (parameter keys of :137-146; a missing key or
-//                               an unknown name -> std::invalid_argument, :25-29,208-209).
+//   RandomAgentHip / ConstantAgentHip   debug_agents.cpp:7-39; the random agent reproduces the reference's torch::rand stream.
+//   get_agent_factory           agent_factory.cpp:186-211 for the names "ppo_gae", "random", "constant" (parameter keys of :66-80,
+//                               137-146; a missing key or an unknown name -> std::invalid_argument, :25-29,208-209).
 //
 // The steps of a trajectory live on the device (state, action, log_prob, curr_value, next_value), reward / done on the host
 // like the reference's `float reward; bool done;`.  One small kernel per act() appends a step, one per trajectory packs it into
@@ -488,7 +489,60 @@ private:
     unsigned long long act_calls = 0;
 };
 
-// AgentFactory / PpoGaeFactory / get_agent_factory (agent.h:39-60, agent_factory.cpp:22-29,137-146,186-211)
+// DebugAgent / RandomAgent / ConstantAgent (debug_agents.cpp:7-39): no parameters, no metrics, no-op done / save / load.
+// RandomAgent::act is 2 * torch::rand({A}) - 1 from the GLOBAL generator; LibTorch's CPU generator is std::mt19937 and, for the
+// fewer than 16 values an action has, torch::rand takes the low 24 bits of one 32-bit output per value — so a std::mt19937(seed)
+// here IS the reference's stream after at::manual_seed(seed) (PpoGaeAgent's constructor calls it, ppo_gae.cpp:26): the golden
+// actions of the compiled reference come out exactly (tests/test_gpu_cxx_agent.py).
+class DebugAgentHip : public Agent {
+public:
+    explicit DebugAgentHip(const std::vector<int64_t> &action_space, hipStream_t stream = nullptr) : A((int) action_space.at(0)), stream(stream), host(A) {
+        if (A < 1) throw std::invalid_argument("action_space");
+        hip_check(hipMalloc(&d_action, sizeof(float) * A), "hipMalloc");
+    }
+    DebugAgentHip(const DebugAgentHip &) = delete;
+    DebugAgentHip &operator=(const DebugAgentHip &) = delete;
+    ~DebugAgentHip() override { (void) hipFree(d_action); }
+    void done(const float *, float) override {}
+    void save(const std::string &) override {}
+    void load(const std::string &) override {}
+    std::vector<LossMeterHip> get_metrics() override { return {}; }
+    void to(int) override {}
+    void set_eval(bool) override {}
+    int count_parameters() override { return 0; }
+    const int A;
+
+protected:
+    const float *upload() {
+        hip_check(hipMemcpyAsync(d_action, host.data(), sizeof(float) * A, hipMemcpyHostToDevice, stream), "upload");
+        hip_check(hipStreamSynchronize(stream), "sync");  // `host` is rewritten by the next act()
+        return d_action;
+    }
+    hipStream_t stream;
+    std::vector<float> host;
+    float *d_action = nullptr;
+};
+class RandomAgentHip : public DebugAgentHip {
+public:
+    RandomAgentHip(const std::vector<int64_t> &action_space, uint32_t seed) : DebugAgentHip(action_space), gen(seed) {
+        if (A >= 16) throw std::invalid_argument("RandomAgentHip reproduces torch::rand's stream for fewer than 16 values per call");
+    }
+    const float *act(const float *, float) override {
+        for (int i = 0; i < A; i++) host[i] = 2.f * ((float) (gen() & ((1u << 24) - 1u)) * (1.0f / 16777216.0f)) - 1.f;
+        return upload();
+    }
+
+private:
+    std::mt19937 gen;
+};
+class ConstantAgentHip : public DebugAgentHip {
+public:
+    ConstantAgentHip(const std::vector<int64_t> &action_space, float action_value) : DebugAgentHip(action_space) { host.assign(A, action_value); }
+    const float *act(const float *, float) override { return upload(); }
+};
+
+// AgentFactory / PpoGaeFactory / RandomAgentFactory / ConstantAgentFactory / get_agent_factory (agent.h:39-60,
+// agent_factory.cpp:22-29,66-80,137-146,186-211)
 class AgentFactoryHip {
 public:
     explicit AgentFactoryHip(std::map<std::string, std::string> parameters) : parameters(std::move(parameters)) {}
@@ -516,9 +570,28 @@ public:
                                                 get_int("replay_buffer_size"), get_float("learning_rate"), get_float("clip_grad_norm"), device);
     }
 };
+class RandomAgentHipFactory : public AgentFactoryHip {
+public:
+    using AgentFactoryHip::AgentFactoryHip;
+    std::shared_ptr<Agent> create_agent(const std::vector<int64_t> &, const std::vector<int64_t> &action_space) override {
+        // "seed" is this adapter's own key: the at::manual_seed the reference's process made before the first act() (default: LibTorch's)
+        const uint32_t seed = parameters.count("seed") ? (uint32_t) std::stoul(parameters["seed"]) : 5489u;
+        return std::make_shared<RandomAgentHip>(action_space, seed);
+    }
+};
+class ConstantAgentHipFactory : public AgentFactoryHip {
+public:
+    using AgentFactoryHip::AgentFactoryHip;
+    std::shared_ptr<Agent> create_agent(const std::vector<int64_t> &, const std::vector<int64_t> &action_space) override {
+        return std::make_shared<ConstantAgentHip>(action_space, get_float("action_value"));  // agent_factory.cpp:76
+    }
+};
+// the agents of this path (agent_factory.cpp:189-206 lists ten; an unknown name -> std::invalid_argument, :208-209)
 inline std::shared_ptr<AgentFactoryHip> get_agent_factory(const std::string &agent_name, std::map<std::string, std::string> parameters) {
-    if (agent_name != "ppo_gae") throw std::invalid_argument(agent_name);  // agent_factory.cpp:208-209 (the one agent of this path)
-    return std::make_shared<PpoGaeHipFactory>(std::move(parameters));
+    if (agent_name == "ppo_gae") return std::make_shared<PpoGaeHipFactory>(std::move(parameters));
+    if (agent_name == "random") return std::make_shared<RandomAgentHipFactory>(std::move(parameters));
+    if (agent_name == "constant") return std::make_shared<ConstantAgentHipFactory>(std::move(parameters));
+    throw std::invalid_argument(agent_name);
 }
 
 }  // namespace evm_adapter

@@ -88,6 +88,10 @@ def test_cxx_agent_reproduces_the_reference_episode_loop_and_the_python_agent(tm
     assert line["loss_meter_adds"] == gold["trains"] * epoch                                       # one add per epoch (:185-186)
     assert line["meter_known_answers"] == [1.5, 1.5, 2.0]                                         # test_metrics.cpp:20-25
     assert line["steps_string"] == "steps = %.6f" % np.mean(lengths)                                # metrics.cpp:52-56,70-74
+    # RandomAgent / ConstantAgent through the same factory: the random agent's stream IS the reference's (golden from the compiled reference)
+    g0 = tl.golden_io.load()
+    assert np.array_equal(np.array(line["random_actions"], np.float32).reshape(3, 12), g0["random_agent_actions"])
+    assert line["constant_action"] == [0.25, 0.25] and line["constant_missing"] == "action_value"       # agent_factory.cpp:76
     assert line["missing_key"] == "gamma" and line["unknown_name"] == "no_such_agent"            # agent_factory.cpp:27,208-209
     assert line["ckpt_equal"] is True and line["count_parameters"] == pa.size + pc.size == 330521
     assert np.isfinite(line["actor_loss"]) and np.isfinite(line["critic_loss"])
