@@ -25,7 +25,10 @@ VALU_PEAK_TFLOPS = 157.3       # fp32 vector peak = fp32 matrix peak on this par
 # hull scans 13.4 k, integration + observation 7.4 k
 ALG_FLOP_PER_ENV_STEP = 202.4e3
 POLICY_FLOP_PER_ROW = 654848.0  # actor 333 312 + critic 321 536 GEMM FLOP per act
-PREROLL_CALLS = 192             # untimed, after stagger_episodes(): every env is past its first (staggered) episode
+# untimed calls after stagger_episodes().  One episode + reset cycle is ~120 calls; 192 calls (rounds 2 and 3) left the driver's
+# 20-step window inside the transient that follows the staggering (do_step_fraction 0.559 there, 0.595-0.621 in windows taken after
+# 512 ... 8192 calls, 0.606 over 1024 timed steps: gpurun_out/pr_*.json), so the pre-roll is 1024 calls = 0.3 s
+PREROLL_CALLS = int(os.environ.get("EVM_BENCH_PREROLL", "1024"))
 
 
 def measured_traffic(n, self_collision=0):
