@@ -16,8 +16,8 @@
 //                               (_grads, _apply) on the time-major [T][B] batch — the calls evomotion_amd/agent.py::PpoGaeAgent
 //                               makes, so both produce the same weights bit for bit (tests/test_gpu_cxx_agent.py).
 //   RandomAgentHip / ConstantAgentHip   debug_agents.cpp:7-39; the random agent reproduces the reference's torch::rand stream.
-//   get_agent_factory           agent_factory.cpp:186-211 for the names "ppo_gae", "random", "constant" (parameter keys of :66-80,
-//                               137-146; a missing key or an unknown name -> std::invalid_argument, :25-29,208-209).
+//   PpoGaeHipFactory, ...       the factories (agent_factory.cpp:66-80,137-146: the reference's parameter keys, a missing key ->
+//                               std::invalid_argument, :25-29); get_agent_factory(name, parameters) is agent_factory_hip.hpp.
 //
 // The steps of a trajectory live on the device (state, action, log_prob, curr_value, next_value), reward / done on the host
 // like the reference's `float reward; bool done;`.  One small kernel per act() appends a step, one per trajectory packs it into
@@ -586,12 +586,4 @@ public:
         return std::make_shared<ConstantAgentHip>(action_space, get_float("action_value"));  // agent_factory.cpp:76
     }
 };
-// the agents of this path (agent_factory.cpp:189-206 lists ten; an unknown name -> std::invalid_argument, :208-209)
-inline std::shared_ptr<AgentFactoryHip> get_agent_factory(const std::string &agent_name, std::map<std::string, std::string> parameters) {
-    if (agent_name == "ppo_gae") return std::make_shared<PpoGaeHipFactory>(std::move(parameters));
-    if (agent_name == "random") return std::make_shared<RandomAgentHipFactory>(std::move(parameters));
-    if (agent_name == "constant") return std::make_shared<ConstantAgentHipFactory>(std::move(parameters));
-    throw std::invalid_argument(agent_name);
-}
-
 }  // namespace evm_adapter

@@ -24,7 +24,7 @@
 #include <string>
 #include <vector>
 
-#include "ppo_gae_agent_hip.hpp"
+#include "agent_factory_hip.hpp"
 
 using namespace evm_adapter;
 
