@@ -414,14 +414,16 @@ class TrajectoryReplayBuffer:
                          taken — fewer when there are not that many                                             (:80-98)
 
     A step is a dict(state, action, reward, done, log_prob, curr_value, next_value) of device tensors / Python scalars
-    (ppo_episode_step, replay_buffer.h:22-30).  The reference shuffles with its own std::mt19937(seed) + std::shuffle, whose
-    stream is libstdc++'s business; here `shuffle(index_list)` is a hook (default: a numpy Generator seeded with `seed`) —
-    the golden test plugs in the orders the reference's generator produced."""
+    (ppo_episode_step, replay_buffer.h:22-30).  The reference shuffles with its own std::mt19937(seed) + std::shuffle
+    (replay_buffer.cpp:66,83): stdrandom.py restates both (held to g++ / libstdc++ and to the draws recorded from the compiled
+    reference, tests/test_stdrandom.py), so the default draws ARE the reference's for the same seed; `shuffle(index_list)` stays
+    a hook for tests."""
 
     def __init__(self, size, seed):
+        from .stdrandom import Mt19937, std_shuffle
         self.size, self.memory = int(size), []
-        self._rng = np.random.default_rng(seed)
-        self.shuffle = lambda index: [index[i] for i in self._rng.permutation(len(index))]
+        self._rng = Mt19937(seed)
+        self.shuffle = lambda index: std_shuffle(list(index), self._rng)
 
     def empty(self):
         return not self.memory

@@ -370,14 +370,15 @@ class ReplayBuffer:
     """ReplayBuffer (evo_motion_networks/src/replay_buffer.cpp:16-52,146-153): a FIFO of at most `size` transitions
     dict(state, action, reward, done, next_state).  The newest one is still open — add() stores it with reward 0, done false and
     next_state = state; update_last() fills those in — and sample() never returns it: the indices of all the others are shuffled
-    and the first batch_size taken.  The reference shuffles with its own std::mt19937(seed) + std::shuffle, whose stream is
-    libstdc++'s business; here `shuffle(index_list)` is a hook (default: a numpy Generator seeded with `seed`) — the golden test
-    plugs in the orders the reference's generator produced."""
+    and the first batch_size taken.  The reference shuffles with its own std::mt19937(seed) + std::shuffle (replay_buffer.cpp:14,21):
+    stdrandom.py restates both (held to g++ / libstdc++ and to the draws recorded from the compiled reference,
+    tests/test_stdrandom.py), so the default draws ARE the reference's for the same seed; `shuffle(index_list)` stays a hook for tests."""
 
     def __init__(self, size, seed):
+        from .stdrandom import Mt19937, std_shuffle
         self.size, self.memory = int(size), []
-        self._rng = np.random.default_rng(seed)
-        self.shuffle = lambda index: [index[i] for i in self._rng.permutation(len(index))]
+        self._rng = Mt19937(seed)
+        self.shuffle = lambda index: std_shuffle(list(index), self._rng)
 
     def empty(self):
         return not self.memory

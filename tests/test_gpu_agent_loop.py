@@ -24,13 +24,16 @@ def test_product_agent_reproduces_the_reference_episode_loop():
     agent.fused.load_modules(agent.actor, agent.critic)
     draws = []
 
-    def recorded_shuffle(index):
+    default_shuffle = agent.replay_buffer.shuffle     # std::mt19937(seed) + std::shuffle restated (evomotion_amd/stdrandom.py): nothing plugged in
+
+    def spy(index):
         filtered = [i for i, t in enumerate(agent.replay_buffer.memory) if len(t) > 1]
         assert len(index) == len(filtered) - 1
-        order = tl.shuffled_for(gold["sample"][len(draws)], filtered)
+        order = default_shuffle(index)
+        assert [filtered[i] for i in order[:batch_size]] == gold["sample"][len(draws)]      # the trajectories the reference drew
         draws.append(order)
         return order
-    agent.replay_buffer.shuffle = recorded_shuffle
+    agent.replay_buffer.shuffle = spy
     k_act = 0
     worst_action = 0.0
     for k, L in enumerate(gold["lengths"]):

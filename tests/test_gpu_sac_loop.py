@@ -26,11 +26,14 @@ def test_product_sac_agent_reproduces_the_reference_episode_loop():
     agent._push_critics()
     draws = []
 
-    def recorded_shuffle(index):
-        order = tl.shuffled_for(gold["sample"][len(draws)], len(index))
+    default_shuffle = agent.replay_buffer.shuffle     # std::mt19937(seed) + std::shuffle restated (evomotion_amd/stdrandom.py): nothing plugged in
+
+    def spy(index):
+        order = default_shuffle(index)
+        assert order[:batch_size] == gold["sample"][len(draws)]                               # the transitions the reference drew
         draws.append(order)
         return order
-    agent.replay_buffer.shuffle = recorded_shuffle
+    agent.replay_buffer.shuffle = spy
     mem_np = lambda: [dict(state=i["state"].cpu().numpy(), reward=i["reward"], done=i["done"], next_state=i["next_state"].cpu().numpy())
                       for i in agent.replay_buffer.memory]
     k_act = n_train = 0
