@@ -152,11 +152,12 @@ def cpu_baseline(seconds=12.0, self_collision=1):
     return out
 
 
-def pose_parity(device, n_oracles=8, steps=48, self_collision=1):
+def pose_parity(device, n_oracles=64, steps=256, self_collision=1):
     """Second half of BASELINE.json's metric: per-step pose L2 of the HIP path against the CPU restatement (oracle/; Bullet3 is
     not installed, so this is parity with the restatement, not with Bullet).  Teacher-forced: every step both sides start from
-    the restatement's state, take the same action, and the body poses [41][pos xyz, quat xyzw] are compared.  Part of the
-    cpu_baseline leg (rank 0, N = 1), outside every timed region."""
+    the restatement's state, take the same action, and the body poses [41][pos xyz, quat xyzw], the reward and the done flag are
+    compared — SURVEY section 8(d) config 2's sample: 64 environments x 256 steps with resets.  Part of the cpu_baseline leg (rank 0,
+    N = 1), outside every timed region."""
     import numpy as np
     import torch
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -170,16 +171,20 @@ def pose_parity(device, n_oracles=8, steps=48, self_collision=1):
         o.reset()
     rng = np.random.default_rng(7)
     pos_l2, quat_l2 = [], []
+    rew_err, done_mismatch = 0.0, 0
     for k in range(steps):
         blob = env.get_state()
         for i, o in enumerate(oracles):  # the restatement free-runs, the HIP path starts every step from its state
             blob[i] = o.get_state()
         env.set_state(blob)
         act = rng.uniform(-1, 1, (64, env.action_dim)).astype(np.float32)
-        env.do_step(torch.from_numpy(act))
+        st = env.do_step(torch.from_numpy(act))
         poses = env.body_poses().cpu().numpy()
+        rew_g, done_g = st.reward.cpu().numpy(), st.done.cpu().numpy()
         for i, o in enumerate(oracles):
-            _, _, done = o.do_step(act[i])
+            _, rew, done = o.do_step(act[i])
+            rew_err = max(rew_err, abs(float(rew_g[i]) - float(rew)))
+            done_mismatch += int(bool(done_g[i]) != bool(done))
             d = poses[i] - o.poses()
             pos_l2.append(float(np.sqrt((d[:, :3] ** 2).sum())))
             quat_l2.append(float(np.sqrt((d[:, 3:] ** 2).sum())))
@@ -187,7 +192,7 @@ def pose_parity(device, n_oracles=8, steps=48, self_collision=1):
                 o.reset()
     env.close()
     return {"pose_l2_mean": float(np.mean(pos_l2)), "pose_l2_max": float(np.max(pos_l2)), "unit": "m (L2 over the 41 body positions, per env step)",
-            "quat_l2_max": float(np.max(quat_l2)), "env_steps": len(pos_l2),
+            "quat_l2_max": float(np.max(quat_l2)), "reward_abs_max": rew_err, "done_mismatches": done_mismatch, "env_steps": len(pos_l2),
             "against": "CPU restatement (oracle/), one step from identical state (teacher-forced); Bullet3 absent: physics parity unpinned"}
 
 
@@ -367,16 +372,22 @@ def main():
         sac.fused.timing_begin()
         sac.replay.timing_begin()
     ev_begin, ev_end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    import gc
+    gc.collect()
+    gc.disable()  # no collector pause between the two clock reads (the driver's 20-step region is 6 ms)
     t0 = time.perf_counter()
     ev_begin.record()  # on the stream every kernel of the timed region is launched on (torch's current stream)
     run(args.steps, args.warmup)
     ev_end.record()
+    barrier()   # synchronize + (N > 1) barrier + synchronize: the K steps of every rank are done
+    t1 = time.perf_counter()
+    gc.enable()
+    # the event read-outs come AFTER the second clock read: with them inside, a 20-step region once measured 8.5 ms of wall
+    # time around 6.1 ms of kernels (gpurun_out/r3n_bench20.json of that run: ms_per_step 0.423 against launch_ms 0.307)
     ms_kernel, n_launch, ms_sweeps = env.timing_end_detail()
-    region_ms = ev_begin.elapsed_time(ev_end)  # (timing_end_detail synchronised the stream)
+    region_ms = ev_begin.elapsed_time(ev_end)
     ms_policy, n_policy = agent.fused.timing_end() if agent is not None else (sac.fused.timing_end() if sac is not None else (0.0, 0))
     rp = sac.replay.timing_end() if sac is not None else None
-    barrier()
-    t1 = time.perf_counter()
     ppo_ms, ppo_epochs = 0.0, 0
     if agent is not None and not args.no_update:
         # one more update outside the timed region, with HIP events around each epoch (the events synchronise)
