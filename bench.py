@@ -26,9 +26,11 @@ VALU_PEAK_TFLOPS = 157.3       # fp32 vector peak = fp32 matrix peak on this par
 ALG_FLOP_PER_ENV_STEP = 202.4e3
 POLICY_FLOP_PER_ROW = 654848.0  # actor 333 312 + critic 321 536 GEMM FLOP per act
 # untimed calls after stagger_episodes().  One episode + reset cycle is ~120 calls; 192 calls (rounds 2 and 3) left the driver's
-# 20-step window inside the transient that follows the staggering (do_step_fraction 0.559 there, 0.595-0.621 in windows taken after
-# 512 ... 8192 calls, 0.606 over 1024 timed steps: gpurun_out/pr_*.json), so the pre-roll is 1024 calls = 0.3 s
-PREROLL_CALLS = int(os.environ.get("EVM_BENCH_PREROLL", "1024"))
+# 20-step window inside the transient that follows the staggering (do_step_fraction 0.559 there).  A 20-step window is a sample of a
+# population that keeps breathing: windows taken after 512 / 1024 / 2048 / 4096 / 8192 calls gave 8.38 / 7.95 / 8.24 / 7.84 / 7.82 M
+# env-steps/s (do_step_fraction 0.621 / 0.611 / 0.619 / 0.605 / 0.596) around the 8.22 M (0.606) of a 1024-step run, which averages
+# 51 such windows (gpurun_out/pr_*.json).  The pre-roll is the length whose window is closest to that average.
+PREROLL_CALLS = int(os.environ.get("EVM_BENCH_PREROLL", "2048"))
 
 
 def measured_traffic(n, self_collision=0):
