@@ -41,14 +41,20 @@ static __global__ void k_sac_gather(const float *state, const float *action, con
 class ReplayBufferHip {
 public:
     ReplayBufferHip(int size, int seed, int S, int A) : size(size), S(S), A(A), cap(size + 1), rand_gen(seed) {  // replay_buffer.cpp:10-14
-        hip_check(hipMalloc(&state, sizeof(float) * (size_t) cap * S), "hipMalloc");
-        hip_check(hipMalloc(&next_state, sizeof(float) * (size_t) cap * S), "hipMalloc");
-        hip_check(hipMalloc(&action, sizeof(float) * (size_t) cap * A), "hipMalloc");
-        hip_check(hipMalloc(&d_slots, sizeof(int) * (size_t) cap), "hipMalloc");
+        if (size < 1) throw std::invalid_argument("replay_buffer_size");
+        try {  // (on the CURRENT device: the agent selects its device before this member is built)
+            hip_check(hipMalloc(&state, sizeof(float) * (size_t) cap * S), "hipMalloc");
+            hip_check(hipMalloc(&next_state, sizeof(float) * (size_t) cap * S), "hipMalloc");
+            hip_check(hipMalloc(&action, sizeof(float) * (size_t) cap * A), "hipMalloc");
+            hip_check(hipMalloc(&d_slots, sizeof(int) * (size_t) cap), "hipMalloc");
+        } catch (...) {
+            release();
+            throw;
+        }
     }
     ReplayBufferHip(const ReplayBufferHip &) = delete;
     ReplayBufferHip &operator=(const ReplayBufferHip &) = delete;
-    ~ReplayBufferHip() { (void) hipFree(state); (void) hipFree(next_state); (void) hipFree(action); (void) hipFree(d_slots); }
+    ~ReplayBufferHip() { release(); }
     bool empty() const { return count == 0; }
     int length() const { return count; }
     void add(const float *d_state, const float *d_action, hipStream_t s) {  // :30-35 (the transition of act(): reward 0, done false, next_state = state)
@@ -95,6 +101,10 @@ public:
     std::vector<int> last_draw;
 
 private:
+    void release() {
+        (void) hipFree(state); (void) hipFree(next_state); (void) hipFree(action); (void) hipFree(d_slots);
+        state = next_state = action = nullptr; d_slots = nullptr;
+    }
     int slot(int logical) const { return (head + logical) % cap; }
     int size, S, A, cap, head = 0, count = 0;
     std::mt19937 rand_gen;
@@ -110,10 +120,10 @@ public:
                             int critic_hidden_size, int batch_size, int epoch, float learning_rate, float gamma, float tau, int replay_buffer_size,
                             int train_every, int device = 0, hipStream_t stream = nullptr)
         : S((int) state_space.at(0)), A((int) action_space.at(0)), B(batch_size), epoch(epoch), train_every(train_every), lr(learning_rate),
-          gamma(gamma), tau(tau), seed(seed), stream(stream), replay_buffer(replay_buffer_size, seed, (int) state_space.at(0), (int) action_space.at(0)),
+          gamma(gamma), tau(tau), seed(seed), stream(stream), device_(use_device(device)),
+          replay_buffer(replay_buffer_size, seed, (int) state_space.at(0), (int) action_space.at(0)),
           noise((uint32_t) seed ^ 0x5bd1e995u), actor_loss_meter("actor", 64), critic_1_loss_meter("critic_1", 64), critic_2_loss_meter("critic_2", 64),
           entropy_loss_meter("entropy", 64), episode_steps_meter("steps", 64), rewards_meter("rewards", 64) {
-        hip_check(hipSetDevice(device), "hipSetDevice");
         check(evm_policy_create(S, A, actor_hidden_size, device, &pol));
         try {
             check(evm_policy_param_counts(pol, &n_actor, &n_critic));
@@ -311,6 +321,8 @@ private:
     float lr, gamma, tau;
     int seed;
     hipStream_t stream;
+    static int use_device(int d) { hip_check(hipSetDevice(d), "hipSetDevice"); return d; }
+    int device_;  // (declared before the buffer: selected before the buffer allocates)
     ReplayBufferHip replay_buffer;
     std::mt19937 noise;
     LossMeterHip actor_loss_meter, critic_1_loss_meter, critic_2_loss_meter, entropy_loss_meter, episode_steps_meter, rewards_meter;
