@@ -39,7 +39,8 @@ def test_default_form_line():
     assert c["kind"] in ("port", "reference") and c["cores"] == 1 and c["value"] > 0 and c["unit"] == "env-steps/s" and c["sample"]
     assert c["all_cores"]["cores"] >= 1 and c["all_cores"]["value"] >= 0.5 * c["value"]
     p = d["pose_parity"]
-    assert p["pose_l2_max"] < 5e-6 and p["env_steps"] > 100 and "unpinned" in p["against"]
+    assert p["pose_l2_max"] < 5e-6 and p["env_steps"] == 64 * 256 and "unpinned" in p["against"]      # SURVEY 8(d) config 2's sample
+    assert p["reward_abs_max"] < 1e-4 and p["done_mismatches"] == 0
 
 
 def test_training_mode_lines_without_the_cpu_leg():
