@@ -1,0 +1,684 @@
+// Penetration depth of two overlapping hulls: the expanding polytope algorithm, one query per WAVEFRONT.
+// (Included by narrow_dev.h inside namespace evm::gj, in its no-contraction region, after Shape and the support routines.)
+//
+// What it replaces: the reference's world (evo_motion_model/src/environment.cpp:20-31) is built from
+// btDefaultCollisionConfiguration, so every btConvexConvexAlgorithm resolves overlapping cores with
+// btGjkEpaPenetrationDepthSolver::calcPenDepth -> btGjkEpaSolver2::Penetration / Distance (Bullet3's btGjkEpa2.cpp: its own GJK
+// on the margin-inflated shapes in A's local frame, then EPA with at most 128 support points, 256 faces, 255 rounds).  Rounds
+// 2-3 of this repository used the sampled-direction solver here instead; that deviation is gone.
+//
+// The branch is rare (a few of the ~18 000 queries of a 4096-env step take it) and, as a lane-private loop, hopeless: the
+// polytope does not fit a lane's registers.  So the wavefront that finds such a query works on it TOGETHER: the query's two
+// transforms are broadcast, every lane then runs the same scalar programme on the same values (the polytope, face list and the
+// GJK's simplex live in LDS, all lanes writing identical values to identical addresses), and the data-parallel parts are dealt to
+// the lanes: hull support scans (support_group's 16-lane rows for the 451-vertex feet), the visibility of every face from the
+// new support point, and the construction of the horizon's new faces (one per lane).
+//
+// Bit-for-bit the sequential algorithm (oracle/orc_epa.cpp restates it with Bullet's own pointer structure):
+//   * the face stock is a LIFO in the original too (newface takes the list root, a retired face becomes the root): a stack here;
+//   * the hull list only matters through findbest's tie rule (strict `<` while walking from the most recently appended face):
+//     faces carry their append sequence number and the winner is (smallest d^2, LARGEST sequence number);
+//   * expand()'s recursion only needs each face's visibility (a pure function of the face and the new point, evaluated for
+//     all faces up front) and adjacency; it is replayed as an explicit-stack walk that records the horizon edges in creation
+//     order and pops / pushes the stock in the original's order, so every new face gets the original's index;
+//   * any failure inside expand() (a face met twice, a degenerate or non-convex new face, no face left) ends the expansion with
+//     the last `outer` face in the original, whatever was built until then: the geometry of the new faces can therefore be
+//     checked after the walk.
+#pragma once
+
+namespace epa {
+
+#define EPA_MAXV 128
+#define EPA_MAXF 256
+#define EPA_NV (EPA_MAXV + 4)   // + the four vertices of the GJK's own store (ids EPA_MAXV..)
+#define EPA_GJK_MAX_ITER 128
+#define EPA_GJK_ACCURACY 0.0001f
+#define EPA_GJK_MIN_DISTANCE 0.0001f
+#define EPA_GJK_DUP_EPS 0.0001f
+#define EPA_MAX_ITER 255
+#define EPA_ACCURACY 0.0001f
+#define EPA_PLANE_EPS 0.00001f
+
+struct State {
+    gj_f4 svd[EPA_NV];              // support direction of vertex id
+    gj_f4 svw[EPA_NV];              // the vertex of the Minkowski difference
+    gj_f4 fnd[EPA_MAXF];            // face normal, distance
+    unsigned fadj[EPA_MAXF];        // neighbours f0 | f1 << 8 | f2 << 16, their edges e0 << 24 | e1 << 26 | e2 << 28
+    unsigned fc[EPA_MAXF];          // vertices c0 | c1 << 8 | c2 << 16
+    unsigned short fseq[EPA_MAXF];  // hull append sequence number
+    unsigned char fin[EPA_MAXF];    // in the hull list
+    unsigned char fvis[EPA_MAXF];   // this round: 0 beyond the horizon, 1 visible from w, 2 visible and visited (pass == pass)
+    unsigned char stock[EPA_MAXF];  // free faces, top of the stack = the stock list's root
+    unsigned short frame[EPA_MAXF]; // walk frames f | e << 8 | stage << 10
+    unsigned short hz[EPA_MAXF];    // horizon edges in creation order: f | e << 8
+    unsigned char hzn[EPA_MAXF];    // ... and the face made for each
+    int sc[2][4];                   // the GJK's two simplices: vertex slots,
+    float sp[2][4];                 //   weights,
+    int srank[2];                   //   ranks
+    int gfree[4];                   // its free vertex slots
+    int bad;
+};
+__device__ __shared__ State g_epa;
+
+#define EPA_SYNC()                                                 \
+    {                                                              \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     \
+        __builtin_amdgcn_wave_barrier();                           \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");     \
+    }
+DEV bool ub(bool c) { return __builtin_amdgcn_readfirstlane(c ? 1 : 0) != 0; }   // (every lane holds the same value: scalar control flow)
+DEV int ui(int v) { return __builtin_amdgcn_readfirstlane(v); }
+DEV float uf(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+DEV F3 uf3(F3 v) { return f3(uf(v.x), uf(v.y), uf(v.z)); }
+DEV F3 ld3(const gj_f4 &q) { return f3(q[0], q[1], q[2]); }
+DEV float flen(F3 a) { return sqrtf(gj::dot(a, a)); }
+DEV F3 mmul(const M33 &m, F3 v) { return f3(gj::dot(m.r0, v), gj::dot(m.r1, v), gj::dot(m.r2, v)); }
+// btMatrix3x3::transposeTimes: a^T * b
+DEV M33 tmm(const M33 &a, const M33 &b) {
+    const F3 a0 = f3(a.r0.x, a.r1.x, a.r2.x), a1 = f3(a.r0.y, a.r1.y, a.r2.y), a2 = f3(a.r0.z, a.r1.z, a.r2.z);
+#define EPA_ROW(r) f3(b.r0.x * r.x + b.r1.x * r.y + b.r2.x * r.z, b.r0.y * r.x + b.r1.y * r.y + b.r2.y * r.z, b.r0.z * r.x + b.r1.z * r.y + b.r2.z * r.z)
+    return m33(EPA_ROW(a0), EPA_ROW(a1), EPA_ROW(a2));
+#undef EPA_ROW
+}
+DEV float det3(F3 a, F3 b, F3 c) {
+    return a.y * b.z * c.x + a.z * b.x * c.y - a.x * b.z * c.y - a.y * b.x * c.z + a.x * b.y * c.z - a.z * b.y * c.x;
+}
+
+// gjkepa2_impl::MinkowskiDiff, in A's local frame
+template <bool GROUP>
+struct Mink {
+    Shape A, B;
+    M33 toshape1, t0b;
+    F3 t0o;
+    bool margins;
+    DEV F3 hull(const Shape &S, F3 d) const {
+        return GROUP ? gj::support_group(S.hull_off, S.hull_n, d, A.lds_hull_off) : gj::support(S.hull_off, S.hull_n, d);
+    }
+    DEV F3 ls(const Shape &S, F3 d) const {
+        if (!margins) return uf3(hull(S, d));
+        F3 n = d;                                         // btConvexShape::localGetSupportVertexNonVirtual
+        if (ub(gj::len2(n) < EVM_EPS * EVM_EPS)) n = f3(-1.f, -1.f, -1.f);
+        n = gj::scl(n, 1.0f / flen(n));
+        return gj::add(uf3(hull(S, n)), gj::scl(n, MARGIN_F));
+    }
+    DEV F3 support0(F3 d) const { return ls(A, d); }
+    DEV F3 support1(F3 d) const { return gj::xform(t0b, t0o, ls(B, mmul(toshape1, d))); }
+    DEV F3 support(F3 d) const { return gj::sub(support0(d), support1(gj::neg(d))); }
+};
+template <bool GROUP>
+DEV Mink<GROUP> mink_init(const Shape &A, F3 oA, const Shape &B, F3 oB, bool margins) {
+    Mink<GROUP> m;
+    m.A = A; m.B = B;
+    m.toshape1 = tmm(B.R, A.R);
+    m.t0b = tmm(A.R, B.R);
+    m.t0o = gj::vmul(gj::sub(oB, oA), A.R);
+    m.margins = margins;
+    return m;
+}
+
+// ---- gjkepa2_impl::GJK ---------------------------------------------------------------------------------------------------
+DEV float project2(F3 a, F3 b, float *w, unsigned &m) {
+    const F3 d = gj::sub(b, a);
+    const float l = gj::len2(d);
+    if (l > 0.f) {
+        const float t = l > 0.f ? -gj::dot(a, d) / l : 0.f;
+        if (t >= 1.f) { w[0] = 0.f; w[1] = 1.f; m = 2; return gj::len2(b); }
+        else if (t <= 0.f) { w[0] = 1.f; w[1] = 0.f; m = 1; return gj::len2(a); }
+        else { w[0] = 1.f - (w[1] = t); m = 3; return gj::len2(gj::add(a, gj::scl(d, t))); }
+    }
+    return -1.f;
+}
+DEV float project3(F3 a, F3 b, F3 c, float *w, unsigned &m) {
+    const F3 vt[3] = {a, b, c};
+    const F3 dl[3] = {gj::sub(a, b), gj::sub(b, c), gj::sub(c, a)};
+    const F3 n = gj::cross(dl[0], dl[1]);
+    const float l = gj::len2(n);
+    if (l > 0.f) {
+        float mindist = -1.f;
+        float subw[2] = {0.f, 0.f};
+        unsigned subm = 0;
+#pragma unroll
+        for (unsigned i = 0; i < 3; ++i) {
+            const unsigned j = (i + 1) % 3, k = (j + 1) % 3;
+            if (gj::dot(vt[i], gj::cross(dl[i], n)) > 0.f) {
+                const float subd = project2(vt[i], vt[j], subw, subm);
+                if (mindist < 0.f || subd < mindist) {
+                    mindist = subd;
+                    m = ((subm & 1) ? 1u << i : 0u) + ((subm & 2) ? 1u << j : 0u);
+                    w[i] = subw[0];
+                    w[j] = subw[1];
+                    w[k] = 0.f;
+                }
+            }
+        }
+        if (mindist < 0.f) {
+            const float d = gj::dot(a, n);
+            const float s = sqrtf(l);
+            const F3 p = gj::scl(n, d / l);
+            mindist = gj::len2(p);
+            m = 7;
+            w[0] = flen(gj::cross(dl[1], gj::sub(b, p))) / s;
+            w[1] = flen(gj::cross(dl[2], gj::sub(c, p))) / s;
+            w[2] = 1.f - (w[0] + w[1]);
+        }
+        return mindist;
+    }
+    return -1.f;
+}
+DEV float project4(F3 a, F3 b, F3 c, F3 d, float *w, unsigned &m) {
+    const F3 vt[3] = {a, b, c};
+    const F3 dl[3] = {gj::sub(a, d), gj::sub(b, d), gj::sub(c, d)};
+    const float vl = det3(dl[0], dl[1], dl[2]);
+    const bool ng = (vl * gj::dot(a, gj::cross(gj::sub(b, c), gj::sub(a, b)))) <= 0.f;
+    if (ng && fabsf(vl) > 0.f) {
+        float mindist = -1.f;
+        float subw[3] = {0.f, 0.f, 0.f};
+        unsigned subm = 0;
+#pragma unroll
+        for (unsigned i = 0; i < 3; ++i) {
+            const unsigned j = (i + 1) % 3, k = (j + 1) % 3;
+            const float s = vl * gj::dot(d, gj::cross(dl[i], dl[j]));
+            if (s > 0.f) {
+                const float subd = project3(vt[i], vt[j], d, subw, subm);
+                if (mindist < 0.f || subd < mindist) {
+                    mindist = subd;
+                    m = ((subm & 1) ? 1u << i : 0u) + ((subm & 2) ? 1u << j : 0u) + ((subm & 4) ? 8u : 0u);
+                    w[i] = subw[0];
+                    w[j] = subw[1];
+                    w[k] = 0.f;
+                    w[3] = subw[2];
+                }
+            }
+        }
+        if (mindist < 0.f) {
+            mindist = 0.f;
+            m = 15;
+            w[0] = det3(c, b, d) / vl;
+            w[1] = det3(a, c, d) / vl;
+            w[2] = det3(b, a, d) / vl;
+            w[3] = 1.f - (w[0] + w[1] + w[2]);
+        }
+        return mindist;
+    }
+    return -1.f;
+}
+
+template <bool GROUP>
+struct Gjk2 {
+    Mink<GROUP> shape;
+    F3 ray;
+    int nfree, current, status;   // status: 0 Valid, 1 Inside, 2 Failed
+    float distance;
+
+    DEV F3 W(int simplex, int i) const { return ld3(g_epa.svw[EPA_MAXV + g_epa.sc[simplex][i]]); }
+    // getsupport(d, store[slot])
+    DEV void getsupport(F3 d, int id) {
+        const F3 dn = gj::scl(d, 1.0f / flen(d));
+        const F3 w = shape.support(dn);
+        g_epa.svd[id] = gj_f4{dn.x, dn.y, dn.z, 0.f};
+        g_epa.svw[id] = gj_f4{w.x, w.y, w.z, 0.f};
+        EPA_SYNC()
+    }
+    DEV void removevertice(int s) {
+        const int r = ui(g_epa.srank[s]) - 1;
+        g_epa.srank[s] = r;
+        g_epa.gfree[nfree++] = ui(g_epa.sc[s][r]);
+        EPA_SYNC()
+    }
+    DEV void appendvertice(int s, F3 v) {
+        const int r = ui(g_epa.srank[s]);
+        const int slot = ui(g_epa.gfree[--nfree]);
+        g_epa.sp[s][r] = 0.f;
+        g_epa.sc[s][r] = slot;
+        g_epa.srank[s] = r + 1;
+        getsupport(v, EPA_MAXV + slot);
+    }
+    DEV int evaluate(const Mink<GROUP> &shapearg, F3 guess) {
+        unsigned iterations = 0;
+        float sqdist = 0.f, alpha = 0.f;
+        F3 lw0, lw1, lw2, lw3;
+        unsigned clastw = 0;
+        g_epa.gfree[0] = 0; g_epa.gfree[1] = 1; g_epa.gfree[2] = 2; g_epa.gfree[3] = 3;
+        nfree = 4;
+        current = 0;
+        status = 0;
+        shape = shapearg;
+        distance = 0.f;
+        g_epa.srank[0] = 0;
+        EPA_SYNC()
+        ray = guess;
+        const float sqrl = gj::len2(ray);
+        appendvertice(0, ub(sqrl > 0.f) ? gj::neg(ray) : f3(1.f, 0.f, 0.f));
+        g_epa.sp[0][0] = 1.f;
+        EPA_SYNC()
+        ray = W(0, 0);
+        sqdist = sqrl;
+        lw0 = lw1 = lw2 = lw3 = ray;
+        do {
+            const int next = 1 - current, cs = current;
+            const float rl = flen(ray);
+            if (ub(rl < EPA_GJK_MIN_DISTANCE)) { status = 1; break; }
+            appendvertice(cs, gj::neg(ray));
+            const int rank = ui(g_epa.srank[cs]);
+            const F3 w = W(cs, rank - 1);
+            const bool found = gj::len2(gj::sub(w, lw0)) < EPA_GJK_DUP_EPS || gj::len2(gj::sub(w, lw1)) < EPA_GJK_DUP_EPS ||
+                               gj::len2(gj::sub(w, lw2)) < EPA_GJK_DUP_EPS || gj::len2(gj::sub(w, lw3)) < EPA_GJK_DUP_EPS;
+            if (ub(found)) { removevertice(cs); break; }
+            clastw = (clastw + 1) & 3;
+            lw0 = gj::sel3(clastw == 0, w, lw0); lw1 = gj::sel3(clastw == 1, w, lw1);
+            lw2 = gj::sel3(clastw == 2, w, lw2); lw3 = gj::sel3(clastw == 3, w, lw3);
+            const float omega = gj::dot(ray, w) / rl;
+            alpha = omega > alpha ? omega : alpha;
+            if (ub(((rl - alpha) - (EPA_GJK_ACCURACY * rl)) <= 0.f)) { removevertice(cs); break; }
+            float weights[4] = {0.f, 0.f, 0.f, 0.f};
+            unsigned mask = 0;
+            if (rank == 2) sqdist = project2(W(cs, 0), W(cs, 1), weights, mask);
+            else if (rank == 3) sqdist = project3(W(cs, 0), W(cs, 1), W(cs, 2), weights, mask);
+            else sqdist = project4(W(cs, 0), W(cs, 1), W(cs, 2), W(cs, 3), weights, mask);
+            mask = (unsigned) ui((int) mask);
+            if (ub(sqdist >= 0.f)) {
+                int nr = 0;
+                ray = f3(0.f, 0.f, 0.f);
+                current = next;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (i < rank) {
+                        const int slot = ui(g_epa.sc[cs][i]);
+                        if (mask & (1u << i)) {
+                            g_epa.sc[next][nr] = slot;
+                            g_epa.sp[next][nr] = weights[i];
+                            nr++;
+                            ray = gj::add(ray, gj::scl(ld3(g_epa.svw[EPA_MAXV + slot]), weights[i]));
+                        } else {
+                            g_epa.gfree[nfree++] = slot;
+                        }
+                    }
+                }
+                g_epa.srank[next] = nr;
+                EPA_SYNC()
+                ray = uf3(ray);
+                if (mask == 15) status = 1;
+            } else {
+                removevertice(cs);
+                break;
+            }
+            status = ((++iterations) < (unsigned) EPA_GJK_MAX_ITER) ? status : 2;
+        } while (status == 0);
+        if (status == 0) distance = flen(ray);
+        else if (status == 1) distance = 0.f;
+        return status;
+    }
+    // EncloseOrigin, the recursion unrolled over the simplex rank (1 -> 2 -> 3 -> 4)
+    DEV bool enclose4() {
+        const int s = current;
+        return ub(fabsf(det3(gj::sub(W(s, 0), W(s, 3)), gj::sub(W(s, 1), W(s, 3)), gj::sub(W(s, 2), W(s, 3)))) > 0.f);
+    }
+    DEV bool enclose3() {
+        const int s = current;
+        const F3 n = gj::cross(gj::sub(W(s, 1), W(s, 0)), gj::sub(W(s, 2), W(s, 0)));
+        if (ub(gj::len2(n) > 0.f)) {
+            appendvertice(s, n);
+            if (enclose4()) return true;
+            removevertice(s);
+            appendvertice(s, gj::neg(n));
+            if (enclose4()) return true;
+            removevertice(s);
+        }
+        return false;
+    }
+    DEV bool enclose2() {
+        const int s = current;
+        const F3 d = gj::sub(W(s, 1), W(s, 0));
+        for (int i = 0; i < 3; ++i) {
+            const F3 axis = f3(i == 0 ? 1.f : 0.f, i == 1 ? 1.f : 0.f, i == 2 ? 1.f : 0.f);
+            const F3 p = gj::cross(d, axis);
+            if (ub(gj::len2(p) > 0.f)) {
+                appendvertice(s, p);
+                if (enclose3()) return true;
+                removevertice(s);
+                appendvertice(s, gj::neg(p));
+                if (enclose3()) return true;
+                removevertice(s);
+            }
+        }
+        return false;
+    }
+    DEV bool enclose1() {
+        const int s = current;
+        for (int i = 0; i < 3; ++i) {
+            const F3 axis = f3(i == 0 ? 1.f : 0.f, i == 1 ? 1.f : 0.f, i == 2 ? 1.f : 0.f);
+            appendvertice(s, axis);
+            if (enclose2()) return true;
+            removevertice(s);
+            appendvertice(s, gj::neg(axis));
+            if (enclose2()) return true;
+            removevertice(s);
+        }
+        return false;
+    }
+    DEV bool enclose_origin() {
+        const int rank = ui(g_epa.srank[current]);
+        if (rank == 1) return enclose1();
+        if (rank == 2) return enclose2();
+        if (rank == 3) return enclose3();
+        if (rank == 4) return enclose4();
+        return false;
+    }
+};
+
+// ---- gjkepa2_impl::EPA ---------------------------------------------------------------------------------------------------
+struct EpaOut {
+    int status;       // EPA::eStatus (9 = Failed)
+    F3 normal;
+    float depth;
+    int rank, c[3];
+    float p[3];
+};
+struct NewFace {
+    F3 n;
+    float d;
+    bool ok;
+};
+// the geometry half of EPA::newface (getedgedist included)
+DEV bool edgedist(F3 fn, F3 a, F3 b, float &dist) {
+    const F3 ba = gj::sub(b, a);
+    const F3 n_ab = gj::cross(ba, fn);
+    const float a_dot_nab = gj::dot(a, n_ab);
+    if (a_dot_nab < 0.f) {
+        const float ba_l2 = gj::len2(ba);
+        const float a_dot_ba = gj::dot(a, ba);
+        const float b_dot_ba = gj::dot(b, ba);
+        if (a_dot_ba > 0.f) dist = flen(a);
+        else if (b_dot_ba < 0.f) dist = flen(b);
+        else {
+            const float a_dot_b = gj::dot(a, b);
+            const float q = (gj::len2(a) * gj::len2(b) - a_dot_b * a_dot_b) / ba_l2;
+            dist = sqrtf(q > 0.f ? q : 0.f);
+        }
+        return true;
+    }
+    return false;
+}
+DEV NewFace face_geometry(F3 a, F3 b, F3 c, bool forced) {
+    NewFace r;
+    r.n = gj::cross(gj::sub(b, a), gj::sub(c, a));
+    r.d = 0.f;
+    const float l = flen(r.n);
+    r.ok = false;
+    if (l > EPA_ACCURACY) {
+        float d = 0.f;
+        if (!(edgedist(r.n, a, b, d) || edgedist(r.n, b, c, d) || edgedist(r.n, c, a, d))) d = gj::dot(a, r.n) / l;
+        r.d = d;
+        r.n = gj::scl(r.n, 1.0f / l);
+        r.ok = forced || r.d >= -EPA_PLANE_EPS;
+    }
+    return r;
+}
+
+template <bool GROUP>
+DEV EpaOut epa_evaluate(Gjk2<GROUP> &gjk, F3 guess) {
+    State &S = g_epa;
+    EpaOut out;
+    out.status = 9; out.normal = f3(0.f, 0.f, 0.f); out.depth = 0.f; out.rank = 0;
+    out.c[0] = out.c[1] = out.c[2] = 0; out.p[0] = out.p[1] = out.p[2] = 0.f;
+    const int lane = (int) (threadIdx.x & 63);
+    const unsigned long long act = __ballot(true);
+    const int nact = (int) __popcll(act), rank = (int) __popcll(act & ((1ull << lane) - 1ull));
+    const int sx = gjk.current;
+    if (ui(S.srank[sx]) > 1 && gjk.enclose_origin()) {
+        // stock = every face, root = face 0; hull empty
+        for (int i = rank; i < EPA_MAXF; i += nact) { S.stock[i] = (unsigned char) (EPA_MAXF - 1 - i); S.fin[i] = 0; }
+        EPA_SYNC()
+        int nstock = EPA_MAXF, seq = 0, hi = 0, nhull = 0;
+        int nextsv = 0;
+        // orient the simplex
+        if (ub(det3(gj::sub(gjk.W(sx, 0), gjk.W(sx, 3)), gj::sub(gjk.W(sx, 1), gjk.W(sx, 3)), gj::sub(gjk.W(sx, 2), gjk.W(sx, 3))) < 0.f)) {
+            const int tc = ui(S.sc[sx][0]), tc1 = ui(S.sc[sx][1]);
+            const float tp = uf(S.sp[sx][0]), tp1 = uf(S.sp[sx][1]);
+            S.sc[sx][0] = tc1; S.sc[sx][1] = tc;
+            S.sp[sx][0] = tp1; S.sp[sx][1] = tp;
+            EPA_SYNC()
+        }
+        const int g0 = EPA_MAXV + ui(S.sc[sx][0]), g1 = EPA_MAXV + ui(S.sc[sx][1]), g2 = EPA_MAXV + ui(S.sc[sx][2]), g3 = EPA_MAXV + ui(S.sc[sx][3]);
+        const int ta[4] = {g0, g1, g2, g0}, tb[4] = {g1, g0, g1, g2}, tcv[4] = {g2, g3, g3, g3};
+        int tetra[4] = {-1, -1, -1, -1};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {   // newface(a, b, c, forced = true)
+            const int fi = ui(S.stock[nstock - 1]);
+            const NewFace nf = face_geometry(ld3(S.svw[ta[k]]), ld3(S.svw[tb[k]]), ld3(S.svw[tcv[k]]), true);
+            if (ub(nf.ok)) {
+                nstock--;
+                S.fnd[fi] = gj_f4{nf.n.x, nf.n.y, nf.n.z, nf.d};
+                S.fc[fi] = (unsigned) ta[k] | ((unsigned) tb[k] << 8) | ((unsigned) tcv[k] << 16);
+                S.fseq[fi] = (unsigned short) seq++;
+                S.fin[fi] = 1;
+                tetra[k] = fi;
+                nhull++;
+                hi = fi + 1 > hi ? fi + 1 : hi;
+            }
+            EPA_SYNC()
+        }
+        if (nhull == 4) {
+            // bind(tetra[0],0,tetra[1],0) (0,1,2,0) (0,2,3,0) (1,1,3,2) (1,2,2,1) (2,2,3,1)
+            S.fadj[tetra[0]] = (unsigned) tetra[1] | ((unsigned) tetra[2] << 8) | ((unsigned) tetra[3] << 16) | (0u << 24) | (0u << 26) | (0u << 28);
+            S.fadj[tetra[1]] = (unsigned) tetra[0] | ((unsigned) tetra[3] << 8) | ((unsigned) tetra[2] << 16) | (0u << 24) | (2u << 26) | (1u << 28);
+            S.fadj[tetra[2]] = (unsigned) tetra[0] | ((unsigned) tetra[1] << 8) | ((unsigned) tetra[3] << 16) | (1u << 24) | (2u << 26) | (1u << 28);
+            S.fadj[tetra[3]] = (unsigned) tetra[0] | ((unsigned) tetra[2] << 8) | ((unsigned) tetra[1] << 16) | (2u << 24) | (2u << 26) | (1u << 28);
+            EPA_SYNC()
+            // findbest: smallest d^2, the most recently appended face on a tie
+            auto findbest = [&]() {
+                int bf = -1, bs = -1;
+                float bd = 0.f;
+                for (int f = 0; f < hi; f++) {
+                    if (S.fin[f]) {
+                        const float d = S.fnd[f][3], sq = d * d;
+                        const int sq_ = (int) S.fseq[f];
+                        if (bf < 0 || sq < bd || (sq == bd && sq_ > bs)) { bf = f; bd = sq; bs = sq_; }
+                    }
+                }
+                return ui(bf);
+            };
+            int best = findbest();
+            gj_f4 outer_nd = S.fnd[best];
+            unsigned outer_c = S.fc[best];
+            int status = 0;   // Valid
+            unsigned iterations = 0;
+            for (; iterations < (unsigned) EPA_MAX_ITER; ++iterations) {
+                if (nextsv < EPA_MAXV) {
+                    const int w = nextsv++;
+                    const gj_f4 bnd = S.fnd[best];
+                    const F3 bn = uf3(f3(bnd[0], bnd[1], bnd[2]));
+                    const float bdist = uf(bnd[3]);
+                    gjk.getsupport(bn, w);
+                    const F3 ww = ld3(S.svw[w]);
+                    const float wdist = gj::dot(bn, ww) - bdist;
+                    if (ub(wdist > EPA_ACCURACY)) {
+                        // visibility of every hull face from w (best counts as visited: its pass is the current one)
+                        for (int f = rank; f < hi; f += nact) {
+                            const gj_f4 nd = S.fnd[f];
+                            const bool beyond = (gj::dot(f3(nd[0], nd[1], nd[2]), ww) - nd[3]) < -EPA_PLANE_EPS;
+                            S.fvis[f] = f == best ? 2 : (beyond ? 0 : 1);
+                        }
+                        EPA_SYNC()
+                        // expand(pass, w, best->f[j], best->e[j], horizon), j = 0..2, as one explicit-stack walk
+                        bool valid = true;
+                        int nh = 0, sp = 0;
+                        const unsigned badj = (unsigned) ui((int) S.fadj[best]);
+                        for (int j = 0; j < 3 && valid; j++) {
+                            int cf = (int) ((badj >> (8 * j)) & 255u), ce = (int) ((badj >> (24 + 2 * j)) & 3u);
+                            bool calling = true, ret = false;
+                            for (;;) {
+                                if (calling) {
+                                    const int vis = ui((int) S.fvis[cf]);
+                                    if (vis == 2) ret = false;
+                                    else if (vis == 0) {
+                                        if (nstock == 0) ret = false;
+                                        else {
+                                            const int nf = ui((int) S.stock[--nstock]);
+                                            S.hz[nh] = (unsigned short) (cf | (ce << 8));
+                                            S.hzn[nh] = (unsigned char) nf;
+                                            nh++;
+                                            ret = true;
+                                        }
+                                    } else {
+                                        S.fvis[cf] = 2;
+                                        S.frame[sp++] = (unsigned short) (cf | (ce << 8));
+                                        const unsigned adj = (unsigned) ui((int) S.fadj[cf]);
+                                        const int e1 = (ce + 1) % 3;
+                                        cf = (int) ((adj >> (8 * e1)) & 255u); ce = (int) ((adj >> (24 + 2 * e1)) & 3u);
+                                        EPA_SYNC()
+                                        continue;
+                                    }
+                                    calling = false;
+                                    EPA_SYNC()
+                                }
+                                // a call returned `ret`
+                                if (!ret) { valid = false; break; }
+                                if (sp == 0) break;
+                                const int fr = ui((int) S.frame[sp - 1]);
+                                const int f = fr & 255, e = (fr >> 8) & 3, stage = fr >> 10;
+                                if (stage == 0) {
+                                    S.frame[sp - 1] = (unsigned short) (fr | (1 << 10));
+                                    const unsigned adj = (unsigned) ui((int) S.fadj[f]);
+                                    const int e2 = (e + 2) % 3;
+                                    cf = (int) ((adj >> (8 * e2)) & 255u); ce = (int) ((adj >> (24 + 2 * e2)) & 3u);
+                                    calling = true;
+                                    EPA_SYNC()
+                                } else {
+                                    sp--;
+                                    S.fin[f] = 0;                       // remove(m_hull, f); append(m_stock, f)
+                                    S.stock[nstock++] = (unsigned char) f;
+                                    ret = true;
+                                    EPA_SYNC()
+                                }
+                            }
+                        }
+                        if (valid && nh >= 3) {
+                            // the horizon's faces, one per lane: newface(f->c[e1], f->c[e], w, false), bind(nf, 0, f, e), the fan's
+                            // bind(prev, 1, nf, 2) and the closing bind(last, 1, first, 2)
+                            S.bad = 0;
+                            EPA_SYNC()
+                            for (int i = rank; i < nh; i += nact) {
+                                const int he = (int) S.hz[i], f = he & 255, e = he >> 8, e1 = (e + 1) % 3;
+                                const int nf = (int) S.hzn[i];
+                                const int nxt = (int) S.hzn[i + 1 < nh ? i + 1 : 0], prv = (int) S.hzn[i > 0 ? i - 1 : nh - 1];
+                                const unsigned fcw = S.fc[f];
+                                const int ca = (int) ((fcw >> (8 * e1)) & 255u), cb = (int) ((fcw >> (8 * e)) & 255u);
+                                const NewFace g = face_geometry(ld3(S.svw[ca]), ld3(S.svw[cb]), ww, false);
+                                if (!g.ok) S.bad = 1;
+                                S.fnd[nf] = gj_f4{g.n.x, g.n.y, g.n.z, g.d};
+                                S.fc[nf] = (unsigned) ca | ((unsigned) cb << 8) | ((unsigned) w << 16);
+                                S.fadj[nf] = (unsigned) f | ((unsigned) nxt << 8) | ((unsigned) prv << 16) | ((unsigned) e << 24) | (2u << 26) | (1u << 28);
+                                S.fseq[nf] = (unsigned short) (seq + i);
+                                S.fin[nf] = 1;
+                                // f's edge e now borders nf's edge 0 (each lane its own byte / bit field of f's word: by atomics)
+                                atomicAnd(&S.fadj[f], ~((255u << (8 * e)) | (3u << (24 + 2 * e))));
+                                atomicOr(&S.fadj[f], ((unsigned) nf << (8 * e)));
+                            }
+                            EPA_SYNC()
+                            if (ub(S.bad != 0)) { status = 4; break; }   // InvalidHull
+                            for (int i = 0; i < nh; i++) { const int nf = ui((int) S.hzn[i]); hi = nf + 1 > hi ? nf + 1 : hi; }
+                            seq += nh;
+                            S.fin[best] = 0;                                // remove(m_hull, best); append(m_stock, best)
+                            S.stock[nstock++] = (unsigned char) best;
+                            EPA_SYNC()
+                            best = findbest();
+                            outer_nd = S.fnd[best];
+                            outer_c = S.fc[best];
+                        } else { status = 4; break; }
+                    } else { status = 7; break; }   // AccuraryReached
+                } else { status = 6; break; }       // OutOfVertices
+            }
+            const F3 on = uf3(f3(outer_nd[0], outer_nd[1], outer_nd[2]));
+            const float od = uf(outer_nd[3]);
+            outer_c = (unsigned) ui((int) outer_c);
+            const F3 projection = gj::scl(on, od);
+            out.normal = on;
+            out.depth = od;
+            out.rank = 3;
+            out.c[0] = (int) (outer_c & 255u); out.c[1] = (int) ((outer_c >> 8) & 255u); out.c[2] = (int) ((outer_c >> 16) & 255u);
+            const F3 w0 = ld3(S.svw[out.c[0]]), w1 = ld3(S.svw[out.c[1]]), w2 = ld3(S.svw[out.c[2]]);
+            out.p[0] = flen(gj::cross(gj::sub(w1, projection), gj::sub(w2, projection)));
+            out.p[1] = flen(gj::cross(gj::sub(w2, projection), gj::sub(w0, projection)));
+            out.p[2] = flen(gj::cross(gj::sub(w0, projection), gj::sub(w1, projection)));
+            const float sum = out.p[0] + out.p[1] + out.p[2];
+            out.p[0] /= sum; out.p[1] /= sum; out.p[2] /= sum;
+            out.status = status;
+            return out;
+        }
+    }
+    // fallback
+    out.status = 8;
+    out.normal = gj::neg(guess);
+    const float nl = flen(out.normal);
+    if (ub(nl > 0.f)) out.normal = gj::scl(out.normal, 1.0f / nl);
+    else out.normal = f3(1.f, 0.f, 0.f);
+    out.depth = 0.f;
+    out.rank = 1;
+    out.c[0] = EPA_MAXV + ui(S.sc[gjk.current][0]);
+    out.p[0] = 1.f;
+    return out;
+}
+
+// btGjkEpaPenetrationDepthSolver::calcPenDepth for ONE query whose transforms every lane holds (wave-uniform values).
+// A.o / B.o unused: oA, oB are the origins (already shifted by the detector's positionOffset).  Returns Penetration()'s verdict;
+// has_v: m_cachedSeparatingAxis was set.
+template <bool GROUP>
+DEV bool calc_pen_depth(const Shape &A, F3 oA, const Shape &B, F3 oB, F3 &v, F3 &wa, F3 &wb, bool &has_v) {
+    has_v = false;
+    v = f3(0.f, 0.f, 0.f); wa = f3(0.f, 0.f, 0.f); wb = f3(0.f, 0.f, 0.f);
+    for (int gi = 0; gi < 9; gi++) {
+        F3 guess;
+        if (gi < 2) {   // (B - A).safeNormalize(), (A - B).safeNormalize()
+            const F3 d = gi == 0 ? gj::sub(oB, oA) : gj::sub(oA, oB);
+            const float l2 = gj::len2(d);
+            guess = ub(l2 >= EVM_EPS * EVM_EPS) ? gj::scl(d, 1.0f / sqrtf(l2)) : f3(1.f, 0.f, 0.f);
+        } else {
+            const int k = gi - 2;   // (0,0,1) (0,1,0) (1,0,0) (1,1,0) (1,1,1) (0,1,1) (1,0,1)
+            guess = f3((k == 2 || k == 3 || k == 4 || k == 6) ? 1.f : 0.f, (k == 1 || k == 3 || k == 4 || k == 5) ? 1.f : 0.f,
+                       (k == 0 || k == 4 || k == 5 || k == 6) ? 1.f : 0.f);
+        }
+        {   // btGjkEpaSolver2::Penetration
+            const Mink<GROUP> shape = mink_init<GROUP>(A, oA, B, oB, true);
+            Gjk2<GROUP> gjk;
+            const int st = gjk.evaluate(shape, gj::neg(guess));
+            if (st == 1) {
+                const EpaOut e = epa_evaluate<GROUP>(gjk, gj::neg(guess));
+                if (e.status != 9) {
+                    F3 w0 = f3(0.f, 0.f, 0.f);
+                    for (int i = 0; i < e.rank; ++i) w0 = gj::add(w0, gj::scl(shape.support0(ld3(g_epa.svd[e.c[i]])), e.p[i]));
+                    wa = gj::xform(A.R, oA, w0);
+                    wb = gj::xform(A.R, oA, gj::sub(w0, gj::scl(e.normal, e.depth)));
+                    v = gj::neg(e.normal);
+                    has_v = true;
+                    return true;
+                }
+            }
+        }
+        {   // btGjkEpaSolver2::Distance
+            const Mink<GROUP> shape = mink_init<GROUP>(A, oA, B, oB, false);
+            Gjk2<GROUP> gjk;
+            const int st = gjk.evaluate(shape, guess);
+            if (st == 0) {
+                F3 w0 = f3(0.f, 0.f, 0.f), w1 = f3(0.f, 0.f, 0.f);
+                const int s = gjk.current, rank = ui(g_epa.srank[s]);
+                for (int i = 0; i < rank; ++i) {
+                    const float p = uf(g_epa.sp[s][i]);
+                    const F3 d = ld3(g_epa.svd[EPA_MAXV + ui(g_epa.sc[s][i])]);
+                    w0 = gj::add(w0, gj::scl(shape.support0(d), p));
+                    w1 = gj::add(w1, gj::scl(shape.support1(gj::neg(d)), p));
+                }
+                wa = gj::xform(A.R, oA, w0);
+                wb = gj::xform(A.R, oA, w1);
+                F3 n = gj::sub(w0, w1);
+                const float dist = flen(n);
+                v = gj::scl(n, 1.0f / (dist > EPA_GJK_MIN_DISTANCE ? dist : 1.f));
+                has_v = true;
+                return false;
+            }
+        }
+    }
+    return false;
+}
+
+}  // namespace epa

@@ -5,9 +5,8 @@
 // with btVoronoiSimplexSolver, one query per overlapping pair and step (the reference's dispatcher / broadphase:
 // evo_motion_model/src/environment.cpp:20-31; which pairs: evo_motion_model/src/robot/constraint.cpp:65,147; the shapes:
 // btConvexHullShape of the OBJ vertices with local scaling, evo_motion_model/src/item.cpp:17-41), and for overlapping
-// un-margined cores Bullet's btMinkowskiPenetrationDepthSolver (42 fixed directions + a second GJK on the displaced
-// shape) — the data-parallel one of Bullet's two penetration solvers; the reference's configuration selects EPA
-// (DESIGN.md §2c states the deviation and how rarely the branch runs).
+// un-margined cores btGjkEpaPenetrationDepthSolver, the solver the reference's btDefaultCollisionConfiguration selects
+// (epa_dev.h: one such query per wavefront at a time).
 //
 // GJK's exits hang on rounding (is the new support point already in the simplex, did the distance still shrink), and a
 // different exit is a different contact point.  So everything in this header is compiled WITHOUT fma contraction and in
@@ -514,22 +513,7 @@ DEV RunOut gjk_run(const Shape &A, F3 oA, const Shape &B, F3 oB, float max_dist2
     return o;
 }
 
-// btMinkowskiPenetrationDepthSolver::getPenetrationDirections (NUM_UNITSPHERE_POINTS = 42)
-__device__ const float kPenDirs[42][3] = {
-    {0.000000f, -0.000000f, -1.000000f}, {0.723608f, -0.525725f, -0.447219f}, {-0.276388f, -0.850649f, -0.447219f},
-    {-0.894426f, -0.000000f, -0.447216f}, {-0.276388f, 0.850649f, -0.447220f}, {0.723608f, 0.525725f, -0.447219f},
-    {0.276388f, -0.850649f, 0.447220f}, {-0.723608f, -0.525725f, 0.447219f}, {-0.723608f, 0.525725f, 0.447219f},
-    {0.276388f, 0.850649f, 0.447219f}, {0.894426f, 0.000000f, 0.447216f}, {-0.000000f, 0.000000f, 1.000000f},
-    {0.425323f, -0.309011f, -0.850654f}, {-0.162456f, -0.499995f, -0.850654f}, {0.262869f, -0.809012f, -0.525738f},
-    {0.425323f, 0.309011f, -0.850654f}, {0.850648f, -0.000000f, -0.525736f}, {-0.525730f, -0.000000f, -0.850652f},
-    {-0.688190f, -0.499997f, -0.525736f}, {-0.162456f, 0.499995f, -0.850654f}, {-0.688190f, 0.499997f, -0.525736f},
-    {0.262869f, 0.809012f, -0.525738f}, {0.951058f, 0.309013f, 0.000000f}, {0.951058f, -0.309013f, 0.000000f},
-    {0.587786f, -0.809017f, 0.000000f}, {0.000000f, -1.000000f, 0.000000f}, {-0.587786f, -0.809017f, 0.000000f},
-    {-0.951058f, -0.309013f, -0.000000f}, {-0.951058f, 0.309013f, -0.000000f}, {-0.587786f, 0.809017f, -0.000000f},
-    {-0.000000f, 1.000000f, -0.000000f}, {0.587786f, 0.809017f, -0.000000f}, {0.688190f, -0.499997f, 0.525736f},
-    {-0.262869f, -0.809012f, 0.525738f}, {-0.850648f, 0.000000f, 0.525736f}, {-0.262869f, 0.809012f, 0.525738f},
-    {0.688190f, 0.499997f, 0.525736f}, {0.525730f, 0.000000f, 0.850652f}, {0.162456f, -0.499995f, 0.850654f},
-    {-0.425323f, -0.309011f, 0.850654f}, {-0.425323f, 0.309011f, 0.850654f}, {0.162456f, 0.499995f, 0.850654f}};
+#include "epa_dev.h"
 
 // btGjkPairDetector::getClosestPoints for the lanes in `active` (the others return has = false)
 template <bool GROUP>
@@ -560,98 +544,48 @@ DEV Result closest_points(const Shape &A, const Shape &B, float max_dist2, bool 
     }
 #endif
     if (__any(need_pen)) {
-        // btMinkowskiPenetrationDepthSolver::calcPenDepth
-        float minProj = GJ_LARGE;
-        F3 minNorm = f3(0.f, 0.f, 0.f);
-        if (GROUP && A.lds_hull_off != -2) {   // (the block holds one hull only: the sequential form, row by row)
-            for (int i = 0; i < 42; i++) {
-                const F3 norm = f3(kPenDirs[i][0], kPenDirs[i][1], kPenDirs[i][2]);
-                F3 pW, qW;
-                minkowski<GROUP>(A, oA, B, oB, norm, pW, qW);
-                const float delta = gj::dot(norm, gj::sub(qW, pW));
-                if (delta < minProj) { minProj = delta; minNorm = norm; }
-            }
-        } else {
-            // The branch is rare (a few queries per 18 000) and, run as a loop, the longest thing a wavefront can do (42 x two
-            // hull scans: a grouped wave took 300 k ticks for it, three times a whole query).  So the 42 directions of ONE such
-            // query go to 42 lanes of the wavefront — its transforms broadcast; the hulls are wave-uniform in the one-query-per-
-            // lane form and sit in LDS in the grouped form — and a lane-by-lane reduction returns the sequential loop's answer
-            // (smallest projection, the FIRST direction on a tie: `delta < minProj` is strict).
-            // (a ragged wavefront has fewer than 64 lanes: its lanes take several directions each, in increasing order)
-            const int lane = (int) (threadIdx.x & 63);
-            const unsigned long long act = __ballot(true);
-            const int nact = (int) __popcll(act), rank = (int) __popcll(act & ((1ull << lane) - 1ull));
-            unsigned long long todo = __ballot(need_pen);
-            while (todo) {
-                const int src = (int) __builtin_ctzll(todo);
-                todo &= GROUP ? ~(0xFFFFull << (src & ~15)) : todo - 1;   // (grouped: the 16 lanes of a row are one query)
-                auto bc = [&](float x) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), src)); };
-                auto bc3 = [&](F3 x) { return f3(bc(x.x), bc(x.y), bc(x.z)); };
-                Shape As = A, Bs = B;
-                As.hull_off = __builtin_amdgcn_readlane(A.hull_off, src); As.hull_n = __builtin_amdgcn_readlane(A.hull_n, src);   // (grouped: rows hold different pairs)
-                Bs.hull_off = __builtin_amdgcn_readlane(B.hull_off, src); Bs.hull_n = __builtin_amdgcn_readlane(B.hull_n, src);
-                As.R = m33(bc3(A.R.r0), bc3(A.R.r1), bc3(A.R.r2)); Bs.R = m33(bc3(B.R.r0), bc3(B.R.r1), bc3(B.R.r2));
-                const F3 oAs = bc3(oA), oBs = bc3(oB);
-                float dl = GJ_LARGE;
-                int ix = 64;
-                for (int k = 0; k * nact < 42; k++) {
-                    const int i = rank + k * nact, ii = i < 42 ? i : 0;
-                    const F3 norm = f3(kPenDirs[ii][0], kPenDirs[ii][1], kPenDirs[ii][2]);
-                    F3 pW, qW;
-                    if (GROUP) {  // (lane-private direction, hulls from LDS: the row's lanes work apart here)
-                        const F3 sA = gj::vmul(gj::neg(norm), As.R), sB = gj::vmul(norm, Bs.R);
-                        pW = gj::xform(As.R, oAs, gj::support_lane_lds(As.hull_off, As.hull_n, sA));
-                        qW = gj::xform(Bs.R, oBs, gj::support_lane_lds(Bs.hull_off, Bs.hull_n, sB));
-                    } else minkowski<false>(As, oAs, Bs, oBs, norm, pW, qW);
-                    const float delta = gj::dot(norm, gj::sub(qW, pW));
-                    if (i < 42 && delta < dl) { dl = delta; ix = i; }
-                }
-                // the lanes' results meet in wave-uniform registers (lane by lane: a butterfly would need every relay lane alive)
-                float bd = GJ_LARGE;
-                int bx = 64;
-                {
-                    unsigned long long rest = act;
-                    for (int k = 0; k < 42 && rest; k++) {
-                        const int l = (int) __builtin_ctzll(rest);
-                        rest &= rest - 1;
-                        const float od = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dl), l));
-                        const int oi = __builtin_amdgcn_readlane(ix, l);
-                        if (od < bd || (od == bd && oi < bx)) { bd = od; bx = oi; }
+        // btGjkEpaPenetrationDepthSolver::calcPenDepth (epa_dev.h): the wavefront takes its queries that need it one at a time and
+        // works on each together — the query's transforms broadcast, the answer handed back to the lane(s) that own it.
+        const int lane = (int) (threadIdx.x & 63);
+        unsigned long long todo = __ballot(need_pen);
+        while (todo) {
+            const int src = (int) __builtin_ctzll(todo);
+            todo &= GROUP ? ~(0xFFFFull << (src & ~15)) : todo - 1;   // (grouped: the 16 lanes of a row are one query)
+            auto bc = [&](float x) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), src)); };
+            auto bc3 = [&](F3 x) { return f3(bc(x.x), bc(x.y), bc(x.z)); };
+            Shape As = A, Bs = B;
+            As.hull_off = __builtin_amdgcn_readlane(A.hull_off, src); As.hull_n = __builtin_amdgcn_readlane(A.hull_n, src);   // (grouped: rows hold different pairs)
+            Bs.hull_off = __builtin_amdgcn_readlane(B.hull_off, src); Bs.hull_n = __builtin_amdgcn_readlane(B.hull_n, src);
+            As.R = m33(bc3(A.R.r0), bc3(A.R.r1), bc3(A.R.r2)); Bs.R = m33(bc3(B.R.r0), bc3(B.R.r1), bc3(B.R.r2));
+            const F3 oAs = bc3(oA), oBs = bc3(oB);
+            F3 sep, tmpA, tmpB;
+            bool has_v;
+            const bool isValid2 = epa::calc_pen_depth<GROUP>(As, oAs, Bs, oBs, sep, tmpA, tmpB, has_v);
+            const bool mine = GROUP ? (lane >> 4) == (src >> 4) : lane == src;
+            if (mine) {
+                out.used_pen = true;
+                if (has_v && gj::len2(sep) != 0.f) {
+                    if (isValid2) {
+                        F3 tmpN = gj::sub(tmpB, tmpA);
+                        float lenSqr = gj::len2(tmpN);
+                        if (lenSqr <= EVM_EPS * EVM_EPS) { tmpN = sep; lenSqr = gj::len2(sep); }
+                        if (lenSqr > EVM_EPS * EVM_EPS) {
+                            tmpN = gj::scl(tmpN, 1.0f / sqrtf(lenSqr));
+                            const float distance2 = -sqrtf(gj::len2(gj::sub(tmpA, tmpB)));
+                            if (!isValid || distance2 < distance) { distance = distance2; pointOnB = tmpB; normalInB = tmpN; isValid = true; }
+                        }
+                    } else {
+                        // EPA found no overlap of the margin-inflated shapes, Distance() a positive distance of the cores
+                        const float distance2 = sqrtf(gj::len2(gj::sub(tmpA, tmpB))) - margin;
+                        if (!isValid || distance2 < distance) {
+                            distance = distance2;
+                            pointOnB = gj::add(tmpB, gj::scl(sep, marginB));
+                            normalInB = gj::scl(sep, 1.0f / sqrtf(gj::len2(sep)));
+                            isValid = true;
+                        }
                     }
                 }
-                dl = bd; ix = bx;
-                const int jx = ix < 42 ? ix : 0;
-                const bool mine = GROUP ? (lane >> 4) == (src >> 4) : lane == src;
-                if (mine && dl < minProj) { minProj = dl; minNorm = f3(kPenDirs[jx][0], kPenDirs[jx][1], kPenDirs[jx][2]); }
             }
-        }
-        const bool overlap = !(minProj < 0.f);
-        minProj += 0.5f + (marginA + marginB);  // extraSeparation + margins
-        const F3 offset = gj::scl(minNorm, minProj);
-        // the nested detector (no penetration solver of its own) re-centres the displaced pair like every detector run; its
-        // own final normal check can only flip the normal, which calcPenDepth does not read
-        const F3 oAd = gj::add(oA, offset);
-        const F3 po2 = gj::scl(gj::add(oAd, oB), 0.5f);
-        RunOut n2 = gjk_run<GROUP>(A, gj::sub(oAd, po2), B, gj::sub(oB, po2), GJ_LARGE, need_pen && overlap, marginA, marginB);
-        n2.pointOnB = gj::add(n2.pointOnB, po2);
-        const bool nested_has = n2.isValid;
-        if (need_pen) {
-            out.used_pen = true;
-            if (overlap && nested_has) {
-                const float corrected = minProj - n2.distance;
-                const F3 pb = n2.pointOnB;                        // in the offset-free local frame (B was not displaced)
-                const F3 pa = gj::sub(pb, gj::scl(minNorm, corrected));
-                F3 tmpN = gj::sub(pb, pa);
-                float lenSqr = gj::len2(tmpN);
-                if (lenSqr <= EVM_EPS * EVM_EPS) { tmpN = minNorm; lenSqr = gj::len2(minNorm); }
-                if (lenSqr > EVM_EPS * EVM_EPS) {
-                    tmpN = gj::scl(tmpN, 1.0f / sqrtf(lenSqr));
-                    const F3 dd = gj::sub(pa, pb);
-                    const float distance2 = -sqrtf(gj::len2(dd));
-                    if (!isValid || distance2 < distance) { distance = distance2; pointOnB = pb; normalInB = tmpN; isValid = true; }
-                }
-            }
-            // (calcPenDepth returning false leaves m_cachedSeparatingAxis zero: nothing more to take from it)
         }
     }
     if (active && isValid && (distance < 0.f || distance * distance < max_dist2)) out.has = true;

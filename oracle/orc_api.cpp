@@ -6,6 +6,7 @@
 #include <string>
 #include <vector>
 
+#include "orc_epa.h"
 #include "orc_world.h"
 
 using namespace orc;
@@ -103,6 +104,35 @@ void orc_gjk_query(const float *ptsA, int nA, const float *scaleA, const float *
     out[7] = r.distance; out[8] = (float) r.iterations; out[9] = (float) r.degenerate; out[10] = (float) r.method;
     out[11] = r.used_penetration ? 1.f : 0.f;
 }
+// btGjkEpaPenetrationDepthSolver::calcPenDepth on two free hulls (tests of orc_epa.cpp on its own): out = verdict, v (3),
+// witness on A (3), witness on B (3), distance, GJK iterations, EPA status, EPA iterations, EPA support points
+void orc_epa_query(const float *ptsA, int nA, const float *scaleA, const float *xfA, const float *ptsB, int nB, const float *scaleB,
+                   const float *xfB, float *out) {
+    std::vector<V3> pa(nA), pb(nB);
+    for (int i = 0; i < nA; i++) pa[i] = V3(ptsA[3 * i], ptsA[3 * i + 1], ptsA[3 * i + 2]);
+    for (int i = 0; i < nB; i++) pb[i] = V3(ptsB[3 * i], ptsB[3 * i + 1], ptsB[3 * i + 2]);
+    auto mk = [](const std::vector<V3> &p, const float *sc, const float *xf) {
+        ConvexView v;
+        v.pts = p.data(); v.n = (int) p.size();
+        v.scale = V3(sc[0], sc[1], sc[2]);
+        v.xf.b = M3(xf[0], xf[1], xf[2], xf[3], xf[4], xf[5], xf[6], xf[7], xf[8]);
+        v.xf.o = V3(xf[9], xf[10], xf[11]);
+        v.margin = 0.04f;
+        return v;
+    };
+    const ConvexView A = mk(pa, scaleA, xfA), B = mk(pb, scaleB, xfB);
+    V3 v(0, 0, 0), wa, wb;
+    EpaResults d;
+    const bool ok = epa_calc_pen_depth(A, B, A.xf, B.xf, v, wa, wb, &d);
+    out[0] = ok ? 1.f : 0.f;
+    out[1] = v.x; out[2] = v.y; out[3] = v.z;
+    out[4] = wa.x; out[5] = wa.y; out[6] = wa.z;
+    out[7] = wb.x; out[8] = wb.y; out[9] = wb.z;
+    out[10] = d.distance; out[11] = (float) d.gjk_iterations; out[12] = (float) d.epa_status; out[13] = (float) d.epa_iterations;
+    out[14] = (float) d.epa_vertices;
+}
+void orc_set_penetration_solver(int which) { g_penetration_solver = which; }
+int orc_get_penetration_solver() { return g_penetration_solver; }
 int orc_env_obs_dim(void *h) { return ((World *) h)->obs_dim(); }
 int orc_env_act_dim(void *h) { return ((World *) h)->act_dim(); }
 int orc_env_num_bodies(void *h) { return ((World *) h)->nb(); }

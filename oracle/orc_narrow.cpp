@@ -1,7 +1,10 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY (see orc_narrow.h for scope, citations and the stated deviations).
 #include "orc_narrow.h"
+#include "orc_epa.h"
 
 namespace orc {
+
+int g_penetration_solver = 0;
 
 static constexpr float REL_ERROR2 = 1.0e-6f;                    // btGjkPairDetector.cpp, single precision
 static constexpr float GJK_EPA_PENETRATION_TOLERANCE = 0.001f;  // gGjkEpaPenetrationTolerance
@@ -9,7 +12,7 @@ static constexpr int GJK_MAX_ITER = 1000;                       // gGjkMaxIter
 static constexpr float EQUAL_VERTEX_THRESHOLD = 0.0001f;        // VORONOI_DEFAULT_EQUAL_VERTEX_THRESHOLD
 
 // btConvexHullShape::localGetSupportingVertexWithoutMargin (see the header for the product order)
-static V3 local_support(const ConvexView &S, const V3 &dir) {
+V3 local_support(const ConvexView &S, const V3 &dir) {
     float best = -BT_LARGE_FLOAT;
     V3 bp(0.f, 0.f, 0.f);
     for (int i = 0; i < S.n; i++) {
@@ -418,8 +421,10 @@ struct Detector {
     }
 };
 
-// btMinkowskiPenetrationDepthSolver::calcPenDepth (convex hulls add no preferred directions)
+// m_penetrationDepthSolver->calcPenDepth: btGjkEpaPenetrationDepthSolver (the reference's configuration) unless the legacy
+// switch asks for btMinkowskiPenetrationDepthSolver::calcPenDepth (convex hulls add no preferred directions)
 bool Detector::pen_depth(const Xf &transA, const Xf &transB, V3 &v, V3 &pa, V3 &pb) {
+    if (g_penetration_solver == 0) return epa_calc_pen_depth(A, B, transA, transB, v, pa, pb);
     float minProj = BT_LARGE_FLOAT;
     V3 minNorm(0, 0, 0), minA, minB;
     for (int i = 0; i < 42; i++) {

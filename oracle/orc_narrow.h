@@ -50,6 +50,14 @@ struct ClosestResult {
     bool used_penetration = false;
 };
 
+// which btConvexPenetrationDepthSolver the pair detector calls for overlapping cores: 0 = btGjkEpaPenetrationDepthSolver (orc_epa.cpp;
+// what the reference's btDefaultCollisionConfiguration selects), 1 = btMinkowskiPenetrationDepthSolver (rounds 2-3 of this
+// repository; kept so that tests can put a number on the difference)
+extern int g_penetration_solver;
+
+// btConvexHullShape::localGetSupportingVertexWithoutMargin
+V3 local_support(const ConvexView &S, const V3 &dir);
+
 // btGjkPairDetector::getClosestPoints with m_maximumDistanceSquared = max_dist2
 ClosestResult gjk_closest_points(const ConvexView &A, const ConvexView &B, float max_dist2);
 

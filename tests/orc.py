@@ -34,6 +34,8 @@ def load():
     L.orc_env_get_pairs.argtypes = [vp, ip]
     L.orc_env_get_pair_stats.argtypes = [vp, ip, fp]
     L.orc_gjk_query.argtypes = [fp, ctypes.c_int, fp, fp, fp, ctypes.c_int, fp, fp, ctypes.c_float, fp]
+    L.orc_epa_query.argtypes = [fp, ctypes.c_int, fp, fp, fp, ctypes.c_int, fp, fp, fp]
+    L.orc_set_penetration_solver.argtypes = [ctypes.c_int]
     L.orc_env_destroy.argtypes = [vp]
     for f in ["orc_env_obs_dim", "orc_env_act_dim", "orc_env_num_bodies", "orc_env_num_members", "orc_env_state_size"]:
         getattr(L, f).argtypes = [vp]
@@ -75,6 +77,28 @@ def gjk_query(ptsA, scaleA, xfA, ptsB, scaleB, xfB, max_dist2=1e18, lib=None):
                     sb.ctypes.data_as(fp), xb.ctypes.data_as(fp), ctypes.c_float(max_dist2), out.ctypes.data_as(fp))
     return dict(has=bool(out[0]), normal=out[1:4].copy(), point_b=out[4:7].copy(), distance=float(out[7]), iterations=int(out[8]),
                 degenerate=int(out[9]), method=int(out[10]), used_penetration=bool(out[11]))
+
+
+def epa_query(ptsA, scaleA, xfA, ptsB, scaleB, xfB, lib=None):
+    """btGjkEpaPenetrationDepthSolver::calcPenDepth on two hulls (oracle/orc_epa.cpp), with its diagnostics."""
+    L = lib or load()
+    a = np.ascontiguousarray(ptsA, np.float32).reshape(-1, 3)
+    b = np.ascontiguousarray(ptsB, np.float32).reshape(-1, 3)
+    sa = np.ascontiguousarray(scaleA, np.float32)
+    sb = np.ascontiguousarray(scaleB, np.float32)
+    xa = np.ascontiguousarray(np.concatenate([np.asarray(xfA[0], np.float32).ravel(), np.asarray(xfA[1], np.float32)]))
+    xb = np.ascontiguousarray(np.concatenate([np.asarray(xfB[0], np.float32).ravel(), np.asarray(xfB[1], np.float32)]))
+    out = np.zeros(15, np.float32)
+    L.orc_epa_query(a.ctypes.data_as(fp), len(a), sa.ctypes.data_as(fp), xa.ctypes.data_as(fp), b.ctypes.data_as(fp), len(b),
+                    sb.ctypes.data_as(fp), xb.ctypes.data_as(fp), out.ctypes.data_as(fp))
+    return dict(penetrating=bool(out[0]), normal=out[1:4].copy(), witness_a=out[4:7].copy(), witness_b=out[7:10].copy(),
+                distance=float(out[10]), gjk_iterations=int(out[11]), epa_status=int(out[12]), epa_iterations=int(out[13]),
+                epa_vertices=int(out[14]))
+
+
+def set_penetration_solver(which, lib=None):
+    """0 = EPA (the reference's configuration, default), 1 = the sampled-direction solver of rounds 2-3."""
+    (lib or load()).orc_set_penetration_solver(int(which))
 
 
 class OracleEnv:
