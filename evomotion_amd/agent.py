@@ -437,6 +437,13 @@ class TrajectoryReplayBuffer:
             self.memory.pop(0)
         return self.memory[-1]
 
+    def push_closed(self, trajectory):
+        """a finished trajectory that was filled outside the buffer (several environments at once: PpoGaeAgent with n_envs > 1)
+        becomes the newest entry — where the reference's single environment would have left it — with the same FIFO eviction"""
+        self.memory.append(trajectory)
+        while len(self.memory) > self.size:
+            self.memory.pop(0)
+
     def add(self, step, trajectory=None):
         (self.memory[-1] if trajectory is None else trajectory).append(step)
 
@@ -462,9 +469,13 @@ class PpoGaeAgent(VecPpoGaeAgent):
     TrajectoryReplayBuffer, a train() call every `train_every` finished EPISODES on `batch_size` trajectories padded to the
     longest one (done = 1 in the padding, the shifted mask of ppo_gae.cpp:127-132).  The forward pass is the fused HIP kernel,
     train() the HIP trainer behind evm_ppo_* (time-major [T][B] with the same mask) — this class is the bookkeeping around
-    them.  With n_envs > 1 every environment fills its own open trajectory of the ONE buffer (act / done take a batch and
-    an env index); n_envs = 1 is the reference call for call.  The fixed-horizon VecPpoGaeAgent.rollout()/update() stays
-    the fast path for thousands of environments.
+    them.  n_envs = 1 is the reference call for call.  With n_envs > 1 (act / done take a batch and an env index) every
+    environment fills an open trajectory of its own OUTSIDE the buffer, which enters it when done() closes it: the buffer
+    then holds finished episodes only, so that `sample()` — whose "all but the last one" rule is right for one environment,
+    where the last entry is the episode that just ended — can never pick an episode that is still running (its last step would
+    carry the placeholders reward = 0, done = False, next_value = curr_value) and eviction can never drop a trajectory an
+    environment still appends to.  The fixed-horizon VecPpoGaeAgent.rollout()/update() stays the fast path for thousands of
+    environments.
 
     `reward` of act() is the reward of the PREVIOUS transition (ppo_gae.cpp:38); done() gets the terminal state before the
     environment is reset (src/train.cpp:64-65)."""
@@ -478,7 +489,7 @@ class PpoGaeAgent(VecPpoGaeAgent):
         self.replay_buffer = TrajectoryReplayBuffer(replay_buffer_size, seed)
         self.curr_train_step = self.global_curr_step = 0
         self.curr_episode_step = [0] * self.n_envs
-        self._open = [None] * self.n_envs      # the open trajectory of every env (a list inside replay_buffer.memory)
+        self._open = [None] * self.n_envs      # the open trajectory of every env (n_envs = 1: a list inside replay_buffer.memory)
         self._act_calls = 0
         self.S, self.A = int(state_space[0]), int(action_space[0])
         from .metrics import LossMeter
@@ -503,7 +514,7 @@ class PpoGaeAgent(VecPpoGaeAgent):
         assert obs.shape[0] == self.n_envs == len(rewards)
         for e in range(self.n_envs):
             if self._open[e] is None:           # `if (replay_buffer.empty()) new_trajectory()` + the one done() opens
-                self._open[e] = self.replay_buffer.new_trajectory()
+                self._open[e] = self.replay_buffer.new_trajectory() if self.n_envs == 1 else []
             traj = self._open[e]
             if traj:
                 self.replay_buffer.update_last(rewards[e], False, value[e].clone(), traj)
@@ -517,6 +528,8 @@ class PpoGaeAgent(VecPpoGaeAgent):
         obs, (_, _, value) = self._forward(state.reshape(1, -1), None)
         traj = self._open[env]
         self.replay_buffer.update_last(float(reward), True, value[0].clone(), traj)
+        if self.n_envs > 1:
+            self.replay_buffer.push_closed(traj)    # now the newest entry, as the reference's just-finished episode is
         self.check_train()
         self._open[env] = self.replay_buffer.new_trajectory() if self.n_envs == 1 else None   # (n_envs > 1: opened by its next act())
         self.global_curr_step += 1

@@ -122,6 +122,11 @@ int evm_env_create(const char *skeleton_path, int n_envs, int device, uint64_t s
     // the member-vs-member mode needs the lane-group kernel's LDS image and stays refused for such a skeleton (below)
     const bool gtile_only = evm::step_lds_bytes(S.nb, S.nscan) > 160 * 1024;
     if (device < 0 || device >= EVM_MAX_DEVICES) { delete env; return fail(EVM_E_INVALID, "device index out of range"); }
+    // the narrowphase's big-hull work list packs an entry as (pair << 20) | env (pairs_dev.h): 2^20 environments per instance
+    if (S.self_collision && ((size_t) n_envs + 63) / 64 * 64 > ((size_t) 1 << 20)) {
+        delete env;
+        return fail(EVM_E_UNSUPPORTED, "member-vs-member contacts: at most 1 048 576 environments per instance (work-list entry = pair << 20 | env)");
+    }
     hipError_t he = hipSetDevice(device);
     if (he != hipSuccess) { delete env; return fail(EVM_E_HIP, std::string("hipSetDevice: ") + hipGetErrorString(he)); }
 
@@ -603,6 +608,15 @@ int evm_env_get_errors(EvmEnv *env, int *h_out, int clear, void *stream) {
     hipStream_t s = (hipStream_t) stream;
     HIP_TRY(hipMemcpyAsync(h_out, env->d.errs, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
     if (clear) HIP_TRY(hipMemsetAsync(env->d.errs, 0, 2 * sizeof(int), s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return EVM_OK;
+}
+
+int evm_env_get_pair_counters(EvmEnv *env, int *h_out, int clear, void *stream) {
+    if (!env || !h_out) return fail(EVM_E_INVALID, "null argument");
+    hipStream_t s = (hipStream_t) stream;
+    HIP_TRY(hipMemcpyAsync(h_out, env->d.errs + 2, sizeof(int), hipMemcpyDeviceToHost, s));
+    if (clear) HIP_TRY(hipMemsetAsync(env->d.errs + 2, 0, sizeof(int), s));
     HIP_TRY(hipStreamSynchronize(s));
     return EVM_OK;
 }

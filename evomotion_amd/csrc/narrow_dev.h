@@ -166,6 +166,7 @@ struct Shape {  // one member's hull and world transform (the basis may be non-o
     int lds_hull_off;  // GROUP mode: hull table offset of the hull the block holds in LDS (-1: none)
     M33 R;
     F3 o;
+    int *pen_count;    // EnvDev::errs + 2: queries that went through the penetration-depth solver (evm_env_get_pair_counters)
 #ifdef EVM_KSTAMPS
     unsigned long long *ks;  // d.stamps: [17] queries that took the penetration branch, [18] wavefronts with such a query, [19] GJK iterations of the slowest lane summed over waves
 #endif
@@ -564,6 +565,7 @@ DEV Result closest_points(const Shape &A, const Shape &B, float max_dist2, bool 
             const bool mine = GROUP ? (lane >> 4) == (src >> 4) : lane == src;
             if (mine) {
                 out.used_pen = true;
+                if (!GROUP || (lane & 15) == 0) atomicAdd(A.pen_count, 1);
                 if (has_v && gj::len2(sep) != 0.f) {
                     if (isValid2) {
                         F3 tmpN = gj::sub(tmpB, tmpA);

@@ -220,6 +220,7 @@ DEV void pair_item(const Ctx &c, int p, bool drop, int lds_hull_off = -1) {
     gj::Shape SA, SB;
     SA.hull_off = MA.hull_off; SA.hull_n = MA.hull_n; SB.hull_off = MB.hull_off; SB.hull_n = MB.hull_n;
     SA.lds_hull_off = SB.lds_hull_off = lds_hull_off;
+    SA.pen_count = SB.pen_count = c.d.errs + 2;
 #ifdef EVM_KSTAMPS
     SA.ks = SB.ks = c.d.stamps;
 #endif

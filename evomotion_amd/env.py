@@ -221,6 +221,12 @@ class VecRobotWalk:
         check(lib.evm_env_get_errors(self._h, out, 1 if clear else 0, self._stream()))
         return int(out[0]), int(out[1])
 
+    def penetration_queries(self, clear=True):
+        """narrowphase queries since the last clear that went through the penetration-depth solver (overlapping cores)"""
+        out = (ctypes.c_int * 1)()
+        check(lib.evm_env_get_pair_counters(self._h, out, 1 if clear else 0, self._stream()))
+        return int(out[0])
+
     def stats(self):
         out = (ctypes.c_longlong * 2)()
         check(lib.evm_env_get_stats(self._h, out))

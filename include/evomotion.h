@@ -156,6 +156,10 @@ int evm_env_get_residual(EvmEnv *env, float *h_max_delta_impulse, int clear, voi
  * wrong), h_out[1] = contact manifolds left out of a step because an env held more than 32 live manifolds or needed more
  * than 31 contact rounds (member-vs-member mode).  Synchronises `stream`. */
 int evm_env_get_errors(EvmEnv *env, int *h_out /* [2] */, int clear, void *stream);
+/* Member-vs-member mode: h_out[0] = narrowphase queries since the last clear whose cores overlapped and that went through the
+ * penetration-depth solver (Bullet: btGjkEpaPenetrationDepthSolver::calcPenDepth, selected by the btDefaultCollisionConfiguration of
+ * evo_motion_model/src/environment.cpp:20-31); every physics step counts, reset()'s settle steps too.  Synchronises `stream`. */
+int evm_env_get_pair_counters(EvmEnv *env, int *h_out /* [1] */, int clear, void *stream);
 /* Rollout counters since the last clear, summed over envs: h_out[0] = do_step transitions emitted by
  * evm_env_step_autoreset (the reset()'s own step and settle calls are not counted), h_out[1] = resets started. */
 int evm_env_get_stats(EvmEnv *env, long long *h_out /* [2] */);

@@ -80,6 +80,12 @@ void orc_env_get_pair_stats(void *h, int *out, float *out_f) {
     out[3] = w->last_pair_penetration_calls; out[4] = live;
     if (out_f) out_f[0] = w->last_max_pair_penetration;
 }
+// narrowphase work since the env was created, every physics step counted (reset()'s settle steps too): queries, queries that went
+// through the penetration solver, physics steps
+void orc_env_get_pair_totals(void *h, long long *out) {
+    World *w = (World *) h;
+    out[0] = w->total_pair_tests; out[1] = w->total_pair_penetration_calls; out[2] = w->total_physics_steps;
+}
 // one narrowphase query between two free convex hulls given as world-space transforms (tests of orc_narrow.cpp on its own):
 // pts [n, 3] unscaled, xf = basis rows (9) + origin (3); out = has, normalOnB (3), pointOnB (3), distance, iterations,
 // degenerate code, method, used_penetration

@@ -452,6 +452,7 @@ ConvexView World::convex_view(int member) const {
 void World::collide_pairs() {
     last_pair_tests = 0; last_pair_gjk_iters = 0; last_pair_penetration_calls = 0;
     last_max_pair_penetration = 0.f;
+    total_physics_steps++;
     if (pairs.empty()) return;
     // world AABBs as btCollisionWorld::updateAabbs leaves them.  The broadphase only culls: a pair whose boxes are apart
     // cannot be within the breaking threshold, and a cached point is gone (refresh below) long before the boxes part, so
@@ -464,12 +465,12 @@ void World::collide_pairs() {
         const bool overlap = amin[pm.a].x <= amax[pm.b].x && amax[pm.a].x >= amin[pm.b].x && amin[pm.a].y <= amax[pm.b].y &&
                              amax[pm.a].y >= amin[pm.b].y && amin[pm.a].z <= amax[pm.b].z && amax[pm.a].z >= amin[pm.b].z;
         if (overlap) {
-            last_pair_tests++;
+            last_pair_tests++; total_pair_tests++;
             // btConvexConvexAlgorithm: m_maximumDistanceSquared = (marginA + marginB + breaking threshold)^2
             float md = MARGIN + MARGIN + pm.break_thr;
             const ClosestResult r = gjk_closest_points(convex_view(pm.a), convex_view(pm.b), md * md);
             last_pair_gjk_iters += r.iterations;
-            if (r.used_penetration) last_pair_penetration_calls++;
+            if (r.used_penetration) { last_pair_penetration_calls++; total_pair_penetration_calls++; }
             if (r.has && !(r.distance > pm.break_thr)) {
                 // btManifoldResult::addContactPoint(normalOnBInWorld, pointInWorld, depth)
                 const V3 pointA = r.pointOnB + r.normalOnB * r.distance;

@@ -197,6 +197,7 @@ public:
     int last_num_contacts = 0, last_num_joint_rows = 0;
     int last_num_pair_contacts = 0;      // of last_num_contacts: points of member-vs-member manifolds
     int last_pair_tests = 0, last_pair_gjk_iters = 0, last_pair_penetration_calls = 0;  // narrowphase work of the last step
+    long long total_pair_tests = 0, total_pair_penetration_calls = 0, total_physics_steps = 0;  // ... and since creation (settle steps of reset() included)
     float last_max_pair_penetration = 0; // deepest pair contact distance (negative = penetrating) after the last collide()
     float last_residual = 0;
 

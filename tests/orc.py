@@ -33,6 +33,7 @@ def load():
     L.orc_env_num_pairs.argtypes = [vp]
     L.orc_env_get_pairs.argtypes = [vp, ip]
     L.orc_env_get_pair_stats.argtypes = [vp, ip, fp]
+    L.orc_env_get_pair_totals.argtypes = [vp, ctypes.POINTER(ctypes.c_longlong)]
     L.orc_gjk_query.argtypes = [fp, ctypes.c_int, fp, fp, fp, ctypes.c_int, fp, fp, ctypes.c_float, fp]
     L.orc_epa_query.argtypes = [fp, ctypes.c_int, fp, fp, fp, ctypes.c_int, fp, fp, fp]
     L.orc_set_penetration_solver.argtypes = [ctypes.c_int]
@@ -193,6 +194,12 @@ class OracleEnv:
         self.L.orc_env_get_pair_stats(self.h, c.ctypes.data_as(ip), f.ctypes.data_as(fp))
         return dict(pair_contacts=int(c[0]), pair_tests=int(c[1]), gjk_iterations=int(c[2]), penetration_calls=int(c[3]),
                     live_pairs=int(c[4]), deepest=float(f[0]))
+
+    def pair_totals(self):
+        """narrowphase work since creation, every physics step counted (settle steps of reset() too)"""
+        c = (ctypes.c_longlong * 3)()
+        self.L.orc_env_get_pair_totals(self.h, c)
+        return dict(queries=int(c[0]), penetration_calls=int(c[1]), physics_steps=int(c[2]))
 
     def body_constants(self):
         p = np.zeros((self.nb, 19), np.float32)

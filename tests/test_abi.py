@@ -48,6 +48,14 @@ def test_error_mapping(hip_lib, tmp_path):
     assert rc == -2 and b"not found" in hip_lib.lib.evm_last_error()  # skeleton.cpp:55-59
     with pytest.raises(ValueError):
         hip_lib.check(-1)
+    # member-vs-member mode packs a narrowphase work-list entry as (pair << 20) | env: more environments than that are refused
+    # before anything touches the device
+    prm = hip_lib.EvmEnvParams()
+    hip_lib.lib.evm_env_default_params(ctypes.byref(prm))
+    assert prm.self_collision == 1
+    h = ctypes.c_void_p()
+    rc = hip_lib.lib.evm_env_create(hip_lib.DEFAULT_SKELETON.encode(), (1 << 20) + 1, 0, 1, ctypes.byref(prm), ctypes.byref(h))
+    assert rc == -4 and b"1 048 576" in hip_lib.lib.evm_last_error() and not h.value   # EVM_E_UNSUPPORTED
 
 
 def test_fixture_matches_decoded_reference_values():

@@ -93,3 +93,41 @@ def test_vector_form_keeps_one_trajectory_per_env():
     open_lens = sorted(len(agent._open[e]) for e in range(n))
     assert open_lens == sorted(lens)
     assert agent.global_curr_step == 2 and agent.curr_train_step in (0, 1)
+
+
+def test_vector_form_trains_on_finished_episodes_only():
+    """n_envs > 1: open trajectories live outside the buffer, so whatever sample() picks has ended (its last step
+    carries done = True and the real reward, not the placeholders of a running episode), the buffer never evicts a trajectory an
+    environment still appends to, and the episode that has just ended is the one sample() leaves out, as in the reference."""
+    import torch
+    from evomotion_amd.agent import PpoGaeAgent
+    n = 5
+    agent = PpoGaeAgent(11, [371], [12], epoch=1, batch_size=3, train_every=1, replay_buffer_size=4, n_envs=n)
+    sampled = []
+    inner = agent.replay_buffer.sample
+
+    def spy(batch_size):
+        out = inner(batch_size)
+        sampled.append(out)
+        return out
+    agent.replay_buffer.sample = spy
+    g = torch.Generator().manual_seed(3)
+    finished = 0
+    for t in range(40):
+        agent.act(torch.rand(n, 371, generator=g), torch.rand(n, generator=g))
+        if t % 3 == 2:
+            e = (t // 3) % n
+            open_before = [id(agent._open[k]) for k in range(n) if k != e and agent._open[k] is not None]
+            just_ended = agent._open[e]
+            agent.done(torch.rand(371, generator=g), 1.25, env=e)
+            finished += 1
+            assert len(agent.replay_buffer.memory) == min(finished, 4)                      # FIFO of finished episodes
+            assert all(tr[-1]["done"] is True and tr[-1]["reward"] == 1.25 for tr in agent.replay_buffer.memory)
+            assert [id(agent._open[k]) for k in range(n) if k != e and agent._open[k] is not None] == open_before   # untouched, not evicted
+            if sampled and sampled[-1] is not None:
+                assert all(tr is not just_ended for tr in sampled[-1])
+    assert agent.curr_train_step >= 5 and len(sampled) == agent.curr_train_step
+    for batch in sampled:
+        assert 1 <= len(batch) <= 3
+        for tr in batch:
+            assert len(tr) > 1 and tr[-1]["done"] is True and all(not s["done"] for s in tr[:-1])

@@ -1,6 +1,8 @@
 """Narrowphase work of the member-vs-member mode on a 4096-env rollout (diagnostic, GPU box): per step the broadphase's
-work-list sizes per pair class, the wavefront count of the narrowphase kernel and the live manifolds / contact rounds.
-   python tools/pair_stats.py [--steps 40]"""
+work-list sizes per pair class, the wavefront count of the narrowphase kernel, the live manifolds / contact rounds, and how many
+queries went through the penetration-depth solver (EPA) — under random actions and, with --trained N, after N PPO updates with
+the policy's own actions (the regime a trained robot visits).
+   python tools/pair_stats.py [--steps 40] [--trained 250]"""
 import argparse, ctypes, os, sys
 import numpy as np
 import torch
@@ -10,7 +12,7 @@ from evomotion_amd import VecRobotWalk, RandomAgent
 from evomotion_amd._lib import lib, check
 import blob
 
-ap = argparse.ArgumentParser(); ap.add_argument("--steps", type=int, default=40); ap.add_argument("--envs", type=int, default=4096)
+ap = argparse.ArgumentParser(); ap.add_argument("--steps", type=int, default=40); ap.add_argument("--envs", type=int, default=4096); ap.add_argument("--trained", type=int, default=0)
 a = ap.parse_args()
 env = VecRobotWalk(a.envs, seed=1234, device=0)
 env.reset(); env.stagger_episodes()
@@ -28,6 +30,8 @@ big = np.array([s == "feet" for s in shp])
 nbig = big[pairs[:, 0]].astype(int) + big[pairs[:, 1]].astype(int)
 cnt = np.zeros(npairs + 1, np.int32)
 tot = []
+env.penetration_queries()
+st0 = env.stats(); env.clear_stats()
 for k in range(a.steps):
     env.step_autoreset(ag.act(env.obs))
     check(lib.evm_env_debug_pair_counts(env._h, cnt.ctypes.data_as(ctypes.POINTER(ctypes.c_int))))
@@ -51,4 +55,24 @@ for e in range(a.envs):
     R.append(r_)
 R = np.array(R); Rw = R.reshape(-1, 16).max(1)
 print("contact rounds per env: mean %.2f max %d; per 16-env workgroup (max over its envs): mean %.2f max %d" % (R.mean(), R.max(), Rw.mean(), Rw.max()))
+pen = env.penetration_queries(); st = env.stats()
+print("penetration-depth solver (EPA): %d of %.0f queries in %d steps of %d envs = %.2f per step (%.2e of the queries); do_step share of the calls %.2f"
+      % (pen, tot[:, 0].sum(), a.steps, a.envs, pen / a.steps, pen / tot[:, 0].sum(), st["env_steps"] / (a.steps * a.envs)))
 print("errors", env.errors())
+if a.trained:
+    from evomotion_amd import VecPpoGaeAgent
+    agent = VecPpoGaeAgent(5, [env.state_dim], [env.action_dim], hidden_size=256, device=0, horizon=32, epoch=8, learning_rate=3e-4)
+    for u in range(a.trained):
+        agent.rollout(env); agent.update()
+    env.penetration_queries(); env.clear_stats()
+    q = 0
+    nsteps = 8 * 32
+    for u in range(8):
+        for k in range(32):
+            act, _, _ = agent.fused.forward(env.obs, seed=5000 + 32 * u + k)
+            env.step_autoreset(act)
+            check(lib.evm_env_debug_pair_counts(env._h, cnt.ctypes.data_as(ctypes.POINTER(ctypes.c_int))))
+            q += int(cnt.sum())
+    pen = env.penetration_queries(); st = env.stats()
+    print("trained regime (%d PPO updates, policy actions): EPA %d of %d queries in %d steps = %.2f per step (%.2e of the queries); do_step share of the calls %.2f, resets started %d"
+          % (a.trained, pen, q, nsteps, pen / nsteps, pen / max(q, 1), st["env_steps"] / (nsteps * a.envs), st["resets"]))
