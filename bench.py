@@ -198,24 +198,32 @@ def pose_parity(device, n_oracles=64, steps=256, self_collision=1):
             "against": "CPU restatement (oracle/), one step from identical state (teacher-forced); Bullet3 absent: physics parity unpinned"}
 
 
-def launch_ranks(n_ranks, argv, worker=None, timeout=None):
+def launch_ranks(n_ranks, argv, worker=None, timeout=None, log_dir=None):
     """`bench.py --gpus N` without a torchrun environment: start N fresh rank processes (RANK / LOCAL_RANK / WORLD_SIZE /
     MASTER_ADDR / MASTER_PORT set, as torch.distributed.run would) and relay rank 0's JSON line.  The parent never
     imports torch or touches HIP, and the children are started with subprocess (never exec'd from a GPU process).
+    Every rank's stderr (and the stdout of ranks > 0) is kept in a file of its own under log_dir (default: a fresh directory
+    under $TMPDIR) and echoed when the run fails or times out, so that a dead rank says why.
     worker: command prefix of the rank program (tests pass a stub); default = this file.  Returns the exit code."""
     import socket
     import subprocess
+    import tempfile
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
     cmd = list(worker) if worker else [sys.executable, os.path.abspath(__file__)]
-    procs = []
+    log_dir = log_dir or tempfile.mkdtemp(prefix="evm_bench_ranks_%d_" % port)
+    os.makedirs(log_dir, exist_ok=True)
+    procs, logs = [], []
     for r in range(n_ranks):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen(cmd + list(argv), env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+        err = open(os.path.join(log_dir, "rank%d.err" % r), "wb")
+        out = subprocess.PIPE if r == 0 else open(os.path.join(log_dir, "rank%d.out" % r), "wb")
+        logs.append((err, out))
+        procs.append(subprocess.Popen(cmd + list(argv), env=env, stdout=out, stderr=err))
     t0 = time.time()
-    out0, rc = None, 0
+    out0, rc, failed = None, 0, None
     try:
         pending = set(range(n_ranks))
         while pending:
@@ -229,10 +237,12 @@ def launch_ranks(n_ranks, argv, worker=None, timeout=None):
                 code = procs[r].poll()
                 if code is not None:
                     pending.discard(r)
-                    if code != 0:
-                        rc = rc or code
-            if rc or (timeout and time.time() - t0 > timeout):
-                rc = rc or 124
+                    if code != 0 and not rc:
+                        rc, failed = code, r
+            if rc:
+                break
+            if timeout and time.time() - t0 > timeout:
+                rc, failed = 124, None
                 break
             time.sleep(0.05)
     finally:
@@ -244,12 +254,24 @@ def launch_ranks(n_ranks, argv, worker=None, timeout=None):
                 p_.wait(timeout=10)
             except subprocess.TimeoutExpired:
                 p_.kill()
+        for err, out in logs:
+            err.close()
+            if out is not subprocess.PIPE:
+                out.close()
     if rc:
-        sys.stderr.write("bench.py: a rank failed (exit code %d); no result line\n" % rc)
+        sys.stderr.write("bench.py: %s; no result line.  Per-rank logs in %s:\n"
+                         % ("rank %d exited with code %d" % (failed, rc) if failed is not None else "timed out after %.0f s" % timeout, log_dir))
+        for r in range(n_ranks):
+            try:
+                with open(os.path.join(log_dir, "rank%d.err" % r), "rb") as f:
+                    tail = f.read()[-4000:].decode(errors="replace")
+            except OSError:
+                tail = ""
+            sys.stderr.write("---- rank %d stderr (tail) ----\n%s\n" % (r, tail if tail.strip() else "(empty)"))
         return rc
     lines = [l for l in (out0 or b"").decode().splitlines() if l.strip()]
     if not lines:
-        sys.stderr.write("bench.py: rank 0 printed nothing\n")
+        sys.stderr.write("bench.py: rank 0 printed nothing (logs in %s)\n" % log_dir)
         return 1
     sys.stdout.write(lines[-1] + "\n")
     return 0
@@ -307,12 +329,17 @@ def main():
 
     from evomotion_amd import FusedActorCritic, RandomAgent, VecRobotWalk
 
-    # RCCL sanity: the ranks that take part in a real all_reduce over the NCCL (= RCCL) backend
-    rccl_ranks = None
-    if world > 1 and args.backend == "nccl":
-        ones = torch.ones(1, device=dev)
+    # Collective sanity BEFORE anything is timed: every rank takes part in a real all_reduce of ones and the sum must be the
+    # world size — over the NCCL (= RCCL) backend this is `rccl_ranks`; a rehearsal over gloo reports `collective_ranks` only.
+    rccl_ranks = collective_ranks = None
+    if world > 1:
+        ones = torch.ones(1, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(ones)
-        rccl_ranks = int(ones.item())
+        collective_ranks = int(ones.item())
+        if collective_ranks != world:
+            raise RuntimeError("bench.py: all_reduce of ones over %s gave %d, expected the world size %d" % (args.backend, collective_ranks, world))
+        if args.backend == "nccl":
+            rccl_ranks = collective_ranks
 
     n = args.envs
     env = VecRobotWalk(n, seed=1234 + rank * n, device=local_rank, parameters={"self_collision": args.self_collision})
@@ -462,6 +489,8 @@ def main():
                 "resets_started": resets,
             },
             "rccl_ranks": rccl_ranks,
+            "collective_ranks": collective_ranks,
+            "backend": args.backend if world > 1 else None,
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n, args.self_collision)[0], "traffic_source": measured_traffic(n, args.self_collision)[1],

@@ -43,11 +43,11 @@ struct State {
     gj_f4 svd[EPA_NV];              // support direction of vertex id
     gj_f4 svw[EPA_NV];              // the vertex of the Minkowski difference
     gj_f4 fnd[EPA_MAXF];            // face normal, distance
-    unsigned fadj[EPA_MAXF];        // neighbours f0 | f1 << 8 | f2 << 16, their edges e0 << 24 | e1 << 26 | e2 << 28
+    unsigned fadj[EPA_MAXF];        // neighbours f0 | f1 << 8 | f2 << 16, their edges e0 << 24 | e1 << 26 | e2 << 28, and in bits 30-31
+                                    // this round's state: 0 beyond the horizon, 1 visible from w, 2 visible and visited (pass == pass)
     unsigned fc[EPA_MAXF];          // vertices c0 | c1 << 8 | c2 << 16
+    float fkey[EPA_MAXF];           // d^2 of a face in the hull list, +inf otherwise (findbest's key)
     unsigned short fseq[EPA_MAXF];  // hull append sequence number
-    unsigned char fin[EPA_MAXF];    // in the hull list
-    unsigned char fvis[EPA_MAXF];   // this round: 0 beyond the horizon, 1 visible from w, 2 visible and visited (pass == pass)
     unsigned char stock[EPA_MAXF];  // free faces, top of the stack = the stock list's root
     unsigned short frame[EPA_MAXF]; // walk frames f | e << 8 | stage << 10
     unsigned short hz[EPA_MAXF];    // horizon edges in creation order: f | e << 8
@@ -60,6 +60,9 @@ struct State {
 };
 __device__ __shared__ State g_epa;
 
+// All lanes run the same programme on the same values and write identical values to identical LDS addresses, so a lane only ever
+// depends on its OWN earlier writes: no synchronisation is needed — except after the three places where the lanes write DIFFERENT
+// entries (the stock fill, the visibility pass, the horizon's new faces).
 #define EPA_SYNC()                                                 \
     {                                                              \
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     \
@@ -217,13 +220,11 @@ struct Gjk2 {
         const F3 w = shape.support(dn);
         g_epa.svd[id] = gj_f4{dn.x, dn.y, dn.z, 0.f};
         g_epa.svw[id] = gj_f4{w.x, w.y, w.z, 0.f};
-        EPA_SYNC()
     }
     DEV void removevertice(int s) {
         const int r = ui(g_epa.srank[s]) - 1;
         g_epa.srank[s] = r;
         g_epa.gfree[nfree++] = ui(g_epa.sc[s][r]);
-        EPA_SYNC()
     }
     DEV void appendvertice(int s, F3 v) {
         const int r = ui(g_epa.srank[s]);
@@ -245,12 +246,10 @@ struct Gjk2 {
         shape = shapearg;
         distance = 0.f;
         g_epa.srank[0] = 0;
-        EPA_SYNC()
         ray = guess;
         const float sqrl = gj::len2(ray);
         appendvertice(0, ub(sqrl > 0.f) ? gj::neg(ray) : f3(1.f, 0.f, 0.f));
         g_epa.sp[0][0] = 1.f;
-        EPA_SYNC()
         ray = W(0, 0);
         sqdist = sqrl;
         lw0 = lw1 = lw2 = lw3 = ray;
@@ -295,7 +294,6 @@ struct Gjk2 {
                     }
                 }
                 g_epa.srank[next] = nr;
-                EPA_SYNC()
                 ray = uf3(ray);
                 if (mask == 15) status = 1;
             } else {
@@ -427,7 +425,7 @@ DEV EpaOut epa_evaluate(Gjk2<GROUP> &gjk, F3 guess) {
     const int sx = gjk.current;
     if (ui(S.srank[sx]) > 1 && gjk.enclose_origin()) {
         // stock = every face, root = face 0; hull empty
-        for (int i = rank; i < EPA_MAXF; i += nact) { S.stock[i] = (unsigned char) (EPA_MAXF - 1 - i); S.fin[i] = 0; }
+        for (int i = rank; i < EPA_MAXF; i += nact) { S.stock[i] = (unsigned char) (EPA_MAXF - 1 - i); S.fkey[i] = EVM_INF; }
         EPA_SYNC()
         int nstock = EPA_MAXF, seq = 0, hi = 0, nhull = 0;
         int nextsv = 0;
@@ -437,7 +435,6 @@ DEV EpaOut epa_evaluate(Gjk2<GROUP> &gjk, F3 guess) {
             const float tp = uf(S.sp[sx][0]), tp1 = uf(S.sp[sx][1]);
             S.sc[sx][0] = tc1; S.sc[sx][1] = tc;
             S.sp[sx][0] = tp1; S.sp[sx][1] = tp;
-            EPA_SYNC()
         }
         const int g0 = EPA_MAXV + ui(S.sc[sx][0]), g1 = EPA_MAXV + ui(S.sc[sx][1]), g2 = EPA_MAXV + ui(S.sc[sx][2]), g3 = EPA_MAXV + ui(S.sc[sx][3]);
         const int ta[4] = {g0, g1, g2, g0}, tb[4] = {g1, g0, g1, g2}, tcv[4] = {g2, g3, g3, g3};
@@ -451,12 +448,11 @@ DEV EpaOut epa_evaluate(Gjk2<GROUP> &gjk, F3 guess) {
                 S.fnd[fi] = gj_f4{nf.n.x, nf.n.y, nf.n.z, nf.d};
                 S.fc[fi] = (unsigned) ta[k] | ((unsigned) tb[k] << 8) | ((unsigned) tcv[k] << 16);
                 S.fseq[fi] = (unsigned short) seq++;
-                S.fin[fi] = 1;
+                S.fkey[fi] = nf.d * nf.d;
                 tetra[k] = fi;
                 nhull++;
                 hi = fi + 1 > hi ? fi + 1 : hi;
             }
-            EPA_SYNC()
         }
         if (nhull == 4) {
             // bind(tetra[0],0,tetra[1],0) (0,1,2,0) (0,2,3,0) (1,1,3,2) (1,2,2,1) (2,2,3,1)
@@ -464,16 +460,19 @@ DEV EpaOut epa_evaluate(Gjk2<GROUP> &gjk, F3 guess) {
             S.fadj[tetra[1]] = (unsigned) tetra[0] | ((unsigned) tetra[3] << 8) | ((unsigned) tetra[2] << 16) | (0u << 24) | (2u << 26) | (1u << 28);
             S.fadj[tetra[2]] = (unsigned) tetra[0] | ((unsigned) tetra[1] << 8) | ((unsigned) tetra[3] << 16) | (1u << 24) | (2u << 26) | (1u << 28);
             S.fadj[tetra[3]] = (unsigned) tetra[0] | ((unsigned) tetra[2] << 8) | ((unsigned) tetra[1] << 16) | (2u << 24) | (2u << 26) | (1u << 28);
-            EPA_SYNC()
             // findbest: smallest d^2, the most recently appended face on a tie
             auto findbest = [&]() {
-                int bf = -1, bs = -1;
-                float bd = 0.f;
-                for (int f = 0; f < hi; f++) {
-                    if (S.fin[f]) {
-                        const float d = S.fnd[f][3], sq = d * d;
-                        const int sq_ = (int) S.fseq[f];
-                        if (bf < 0 || sq < bd || (sq == bd && sq_ > bs)) { bf = f; bd = sq; bs = sq_; }
+                int bf = 0, bs = -1;
+                float bd = EVM_INF;
+                for (int f0 = 0; f0 < hi; f0 += 8) {     // (unconditional loads, eight in flight: the scan is latency, not work)
+                    float k[8];
+                    int q[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) { k[u] = S.fkey[f0 + u]; q[u] = (int) S.fseq[f0 + u]; }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const bool in = f0 + u < hi && k[u] < EVM_INF;
+                        if (in && (k[u] < bd || (k[u] == bd && q[u] > bs))) { bf = f0 + u; bd = k[u]; bs = q[u]; }
                     }
                 }
                 return ui(bf);
@@ -497,7 +496,7 @@ DEV EpaOut epa_evaluate(Gjk2<GROUP> &gjk, F3 guess) {
                         for (int f = rank; f < hi; f += nact) {
                             const gj_f4 nd = S.fnd[f];
                             const bool beyond = (gj::dot(f3(nd[0], nd[1], nd[2]), ww) - nd[3]) < -EPA_PLANE_EPS;
-                            S.fvis[f] = f == best ? 2 : (beyond ? 0 : 1);
+                            S.fadj[f] = (S.fadj[f] & 0x3FFFFFFFu) | ((f == best ? 2u : (beyond ? 0u : 1u)) << 30);
                         }
                         EPA_SYNC()
                         // expand(pass, w, best->f[j], best->e[j], horizon), j = 0..2, as one explicit-stack walk
@@ -509,7 +508,8 @@ DEV EpaOut epa_evaluate(Gjk2<GROUP> &gjk, F3 guess) {
                             bool calling = true, ret = false;
                             for (;;) {
                                 if (calling) {
-                                    const int vis = ui((int) S.fvis[cf]);
+                                    const unsigned adj = (unsigned) ui((int) S.fadj[cf]);
+                                    const int vis = (int) (adj >> 30);
                                     if (vis == 2) ret = false;
                                     else if (vis == 0) {
                                         if (nstock == 0) ret = false;
@@ -518,19 +518,17 @@ DEV EpaOut epa_evaluate(Gjk2<GROUP> &gjk, F3 guess) {
                                             S.hz[nh] = (unsigned short) (cf | (ce << 8));
                                             S.hzn[nh] = (unsigned char) nf;
                                             nh++;
+                                            hi = nf + 1 > hi ? nf + 1 : hi;
                                             ret = true;
                                         }
                                     } else {
-                                        S.fvis[cf] = 2;
+                                        S.fadj[cf] = adj | (2u << 30);     // (1 -> 3 would do too: bit 31 = visited)
                                         S.frame[sp++] = (unsigned short) (cf | (ce << 8));
-                                        const unsigned adj = (unsigned) ui((int) S.fadj[cf]);
                                         const int e1 = (ce + 1) % 3;
                                         cf = (int) ((adj >> (8 * e1)) & 255u); ce = (int) ((adj >> (24 + 2 * e1)) & 3u);
-                                        EPA_SYNC()
                                         continue;
                                     }
                                     calling = false;
-                                    EPA_SYNC()
                                 }
                                 // a call returned `ret`
                                 if (!ret) { valid = false; break; }
@@ -543,13 +541,11 @@ DEV EpaOut epa_evaluate(Gjk2<GROUP> &gjk, F3 guess) {
                                     const int e2 = (e + 2) % 3;
                                     cf = (int) ((adj >> (8 * e2)) & 255u); ce = (int) ((adj >> (24 + 2 * e2)) & 3u);
                                     calling = true;
-                                    EPA_SYNC()
                                 } else {
                                     sp--;
-                                    S.fin[f] = 0;                       // remove(m_hull, f); append(m_stock, f)
+                                    S.fkey[f] = EVM_INF;                // remove(m_hull, f); append(m_stock, f)
                                     S.stock[nstock++] = (unsigned char) f;
                                     ret = true;
-                                    EPA_SYNC()
                                 }
                             }
                         }
@@ -570,18 +566,16 @@ DEV EpaOut epa_evaluate(Gjk2<GROUP> &gjk, F3 guess) {
                                 S.fc[nf] = (unsigned) ca | ((unsigned) cb << 8) | ((unsigned) w << 16);
                                 S.fadj[nf] = (unsigned) f | ((unsigned) nxt << 8) | ((unsigned) prv << 16) | ((unsigned) e << 24) | (2u << 26) | (1u << 28);
                                 S.fseq[nf] = (unsigned short) (seq + i);
-                                S.fin[nf] = 1;
+                                S.fkey[nf] = g.d * g.d;
                                 // f's edge e now borders nf's edge 0 (each lane its own byte / bit field of f's word: by atomics)
                                 atomicAnd(&S.fadj[f], ~((255u << (8 * e)) | (3u << (24 + 2 * e))));
                                 atomicOr(&S.fadj[f], ((unsigned) nf << (8 * e)));
                             }
                             EPA_SYNC()
                             if (ub(S.bad != 0)) { status = 4; break; }   // InvalidHull
-                            for (int i = 0; i < nh; i++) { const int nf = ui((int) S.hzn[i]); hi = nf + 1 > hi ? nf + 1 : hi; }
                             seq += nh;
-                            S.fin[best] = 0;                                // remove(m_hull, best); append(m_stock, best)
+                            S.fkey[best] = EVM_INF;                         // remove(m_hull, best); append(m_stock, best)
                             S.stock[nstock++] = (unsigned char) best;
-                            EPA_SYNC()
                             best = findbest();
                             outer_nd = S.fnd[best];
                             outer_c = S.fc[best];
@@ -623,8 +617,9 @@ DEV EpaOut epa_evaluate(Gjk2<GROUP> &gjk, F3 guess) {
 // btGjkEpaPenetrationDepthSolver::calcPenDepth for ONE query whose transforms every lane holds (wave-uniform values).
 // A.o / B.o unused: oA, oB are the origins (already shifted by the detector's positionOffset).  Returns Penetration()'s verdict;
 // has_v: m_cachedSeparatingAxis was set.
+// (not inlined: its register allocation — and whatever it spills — stays out of the GJK loop of the common path)
 template <bool GROUP>
-DEV bool calc_pen_depth(const Shape &A, F3 oA, const Shape &B, F3 oB, F3 &v, F3 &wa, F3 &wb, bool &has_v) {
+__device__ __noinline__ bool calc_pen_depth(const Shape &A, F3 oA, const Shape &B, F3 oB, F3 &v, F3 &wa, F3 &wb, bool &has_v) {
     has_v = false;
     v = f3(0.f, 0.f, 0.f); wa = f3(0.f, 0.f, 0.f); wb = f3(0.f, 0.f, 0.f);
     for (int gi = 0; gi < 9; gi++) {

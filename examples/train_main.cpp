@@ -14,6 +14,8 @@
 // Rendezvous: rank 0 writes the ncclUniqueId to $EVM_NCCL_ID_FILE (default /tmp/evm_nccl_id.<MASTER_PORT>), the others poll it.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
+#include <signal.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <chrono>
@@ -21,6 +23,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <string>
 #include <vector>
 
@@ -98,7 +101,17 @@ int main(int argc, char **argv) {
         ncclUniqueId id;
         const char *idf = getenv("EVM_NCCL_ID_FILE");
         const std::string id_path = idf ? idf : std::string("/tmp/evm_nccl_id.") + std::to_string(env_int("MASTER_PORT", 29500));
+        // Rendez-vous through a file.  What can go wrong, and what is done about it:
+        //   * a stale id file of a run that crashed on the same MASTER_PORT: rank 0 removes it (and its .tmp) before it asks for
+        //     the new id, and a reader only accepts a file written after its own start (mtime), so an old id is never used and
+        //     ncclCommInitRank cannot block on mismatched ids;
+        //   * a rank 0 that never comes: the readers give up after EVM_RENDEZVOUS_TIMEOUT_S seconds (default 60) with a message;
+        //   * a communicator that never forms (a rank died after publishing / reading): a watchdog ends the process with a
+        //     message instead of leaving it hung in ncclCommInitRank.
+        const int rdv_timeout = env_int("EVM_RENDEZVOUS_TIMEOUT_S", 60);
+        const time_t t_start = time(nullptr);
         if (rank == 0) {
+            if (world > 1) { unlink(id_path.c_str()); unlink((id_path + ".tmp").c_str()); }
             nccl_check(ncclGetUniqueId(&id), "ncclGetUniqueId");
             if (world > 1) {
                 const std::string tmp = id_path + ".tmp";
@@ -108,13 +121,30 @@ int main(int argc, char **argv) {
                 if (rename(tmp.c_str(), id_path.c_str())) throw std::runtime_error("cannot publish " + id_path);
             }
         } else {
-            FILE *f = nullptr;
-            for (int tries = 0; tries < 600 && !(f = fopen(id_path.c_str(), "rb")); tries++) usleep(100000);
-            if (!f || fread(&id, sizeof(id), 1, f) != 1) throw std::runtime_error("no ncclUniqueId at " + id_path);
-            fclose(f);
+            bool got = false;
+            for (int tries = 0; tries < rdv_timeout * 10 && !got; tries++) {
+                struct stat sb;
+                if (stat(id_path.c_str(), &sb) == 0 && sb.st_mtime >= t_start - 1 && sb.st_size == (off_t) sizeof(id)) {
+                    FILE *f = fopen(id_path.c_str(), "rb");
+                    got = f && fread(&id, sizeof(id), 1, f) == 1;
+                    if (f) fclose(f);
+                }
+                if (!got) usleep(100000);
+            }
+            if (!got) throw std::runtime_error("rank " + std::to_string(rank) + ": no fresh ncclUniqueId at " + id_path + " after " +
+                                               std::to_string(rdv_timeout) + " s (is rank 0 running with the same MASTER_PORT / EVM_NCCL_ID_FILE?)");
         }
         ncclComm_t comm;
-        nccl_check(ncclCommInitRank(&comm, world, id, rank), "ncclCommInitRank");
+        {
+            static char wd_msg[256];
+            snprintf(wd_msg, sizeof(wd_msg), "train_main: rank %d of %d: ncclCommInitRank did not complete within %d s (a peer is missing or "
+                     "read another id); giving up\n", rank, world, 2 * rdv_timeout);
+            signal(SIGALRM, [](int) { (void) !write(2, wd_msg, strlen(wd_msg)); _exit(3); });
+            alarm((unsigned) (2 * rdv_timeout));
+            nccl_check(ncclCommInitRank(&comm, world, id, rank), "ncclCommInitRank");
+            alarm(0);
+            signal(SIGALRM, SIG_DFL);
+        }
         hipStream_t s;
         hip_check(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate");
 

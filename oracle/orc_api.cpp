@@ -109,6 +109,7 @@ void orc_gjk_query(const float *ptsA, int nA, const float *scaleA, const float *
     out[4] = r.pointOnB.x; out[5] = r.pointOnB.y; out[6] = r.pointOnB.z;
     out[7] = r.distance; out[8] = (float) r.iterations; out[9] = (float) r.degenerate; out[10] = (float) r.method;
     out[11] = r.used_penetration ? 1.f : 0.f;
+    out[12] = (float) r.ccd_status; out[13] = (float) r.ccd_iterations;
 }
 // btGjkEpaPenetrationDepthSolver::calcPenDepth on two free hulls (tests of orc_epa.cpp on its own): out = verdict, v (3),
 // witness on A (3), witness on B (3), distance, GJK iterations, EPA status, EPA iterations, EPA support points
@@ -136,6 +137,14 @@ void orc_epa_query(const float *ptsA, int nA, const float *scaleA, const float *
     out[7] = wb.x; out[8] = wb.y; out[9] = wb.z;
     out[10] = d.distance; out[11] = (float) d.gjk_iterations; out[12] = (float) d.epa_status; out[13] = (float) d.epa_iterations;
     out[14] = (float) d.epa_vertices;
+}
+void orc_set_ccd_pretest(int on) { g_ccd_pretest = on; }
+void orc_set_floor_as_hull(int on) { g_floor_as_hull = on; }
+void orc_set_floor_hull_half(float half) { g_floor_hull_half = half; }
+// floor-as-hull measurement mode, last physics step: queries, GJK iterations, penetration-solver calls, pre-test verdicts "intersect"
+void orc_env_get_floor_stats(void *h, int *out) {
+    World *w = (World *) h;
+    out[0] = w->last_floor_queries; out[1] = w->last_floor_gjk_iters; out[2] = w->last_floor_pen_calls; out[3] = w->last_floor_ccd_hits;
 }
 void orc_set_penetration_solver(int which) { g_penetration_solver = which; }
 int orc_get_penetration_solver() { return g_penetration_solver; }

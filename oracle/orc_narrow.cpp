@@ -5,6 +5,7 @@
 namespace orc {
 
 int g_penetration_solver = 0;
+int g_ccd_pretest = 0;
 
 static constexpr float REL_ERROR2 = 1.0e-6f;                    // btGjkPairDetector.cpp, single precision
 static constexpr float GJK_EPA_PENETRATION_TOLERANCE = 0.001f;  // gGjkEpaPenetrationTolerance
@@ -286,10 +287,239 @@ static const float kPenDirs[42][3] = {
     {0.688190f, 0.499997f, 0.525736f}, {0.525730f, 0.000000f, 0.850652f}, {0.162456f, -0.499995f, 0.850654f},
     {-0.425323f, -0.309011f, 0.850654f}, {-0.425323f, 0.309011f, 0.850654f}, {0.162456f, 0.499995f, 0.850654f}};
 
+
+// ------------------------------------------------------------------------------------------------
+// The libccd-derived intersection pre-test at the top of btGjkPairDetector::getClosestPointsNonVirtual (bullet3 >= 2.88:
+// btComputeSupport / btDoSimplex2,3,4 / btVec3PointSegmentDist2 / btVec3PointTriDist2).  It decides `status`: 0 = the un-margined
+// cores intersect (the penetration branch is then forced whatever the Voronoi loop found), -1 = they do not.
+// ------------------------------------------------------------------------------------------------
+struct CcdSupport { V3 v, v1, v2; };
+struct CcdSimplex {
+    CcdSupport ps[4];
+    int last = -1;
+    int size() const { return last + 1; }
+    void add(const CcdSupport &s) { ps[++last] = s; }
+    void set(int pos, const CcdSupport &s) { ps[pos] = s; }
+    void set_size(int n) { last = n - 1; }
+};
+static bool fuzzy_zero(float x) { return std::fabs(x) < SIMD_EPSILON; }
+static bool fuzzy_zero(double x) { return std::fabs(x) < (double) SIMD_EPSILON; }   // btFuzzyZero(btScalar) on a double argument converts: see below
+static int ccd_eq(float _a, float _b) {
+    const float ab = std::fabs(_a - _b);
+    if (std::fabs(ab) < SIMD_EPSILON) return 1;
+    const float a = std::fabs(_a), b = std::fabs(_b);
+    if (b > a) return ab < SIMD_EPSILON * b;
+    return ab < SIMD_EPSILON * a;
+}
+static int ccd_sign(float v) { if (fuzzy_zero(v)) return 0; return v < 0.f ? -1 : 1; }
+static bool ccd_vec_eq(const V3 &a, const V3 &b) { return ccd_eq(a.x, b.x) && ccd_eq(a.y, b.y) && ccd_eq(a.z, b.z); }
+static float ccd_dist2(const V3 &a, const V3 &b) { const V3 ab = a - b; return dot(ab, ab); }
+static V3 triple_cross(const V3 &a, const V3 &b, const V3 &c) { return cross(cross(a, b), c); }
+static float point_segment_dist2(const V3 &P, const V3 &x0, const V3 &b, V3 *witness) {
+    float dist, t;
+    V3 d = b - x0;
+    const V3 a = x0 - P;
+    t = -1.f * dot(a, d);
+    t /= dot(d, d);
+    if (t < 0.f || fuzzy_zero(t)) {
+        dist = ccd_dist2(x0, P);
+        if (witness) *witness = x0;
+    } else if (t > 1.f || ccd_eq(t, 1.f)) {
+        dist = ccd_dist2(b, P);
+        if (witness) *witness = b;
+    } else {
+        if (witness) {
+            *witness = d;
+            *witness = *witness * t;
+            *witness = *witness + x0;
+            dist = ccd_dist2(*witness, P);
+        } else {
+            d = d * t;
+            d = d + a;
+            dist = dot(d, d);
+        }
+    }
+    return dist;
+}
+static float point_tri_dist2(const V3 &P, const V3 &x0, const V3 &B, const V3 &C, V3 *witness) {
+    // (the original keeps u..t and the distances in double)
+    V3 d1 = B - x0, d2 = C - x0;
+    const V3 a = x0 - P;
+    const double u = dot(a, a), v = dot(d1, d1), w = dot(d2, d2), p = dot(a, d1), q = dot(a, d2), r = dot(d1, d2);
+    const double s = (q * r - w * p) / (w * v - r * r);
+    const double t = (-s * r - q) / w;
+    double dist, dist2;
+    V3 witness2;
+    // btFuzzyZero / ccdEq take btScalar: the doubles are converted to float at the call
+    const float sf = (float) s, tf = (float) t, tsf = (float) (t + s);
+    if ((fuzzy_zero(sf) || s > 0.0) && (ccd_eq(sf, 1.f) || s < 1.0) && (fuzzy_zero(tf) || t > 0.0) && (ccd_eq(tf, 1.f) || t < 1.0) &&
+        (ccd_eq(tsf, 1.f) || t + s < 1.0)) {
+        if (witness) {
+            d1 = d1 * (float) s;
+            d2 = d2 * (float) t;
+            *witness = x0;
+            *witness = *witness + d1;
+            *witness = *witness + d2;
+            dist = ccd_dist2(*witness, P);
+        } else {
+            dist = s * s * v;
+            dist += t * t * w;
+            dist += 2.0 * s * t * r;
+            dist += 2.0 * s * p;
+            dist += 2.0 * t * q;
+            dist += u;
+        }
+    } else {
+        dist = point_segment_dist2(P, x0, B, witness);
+        dist2 = point_segment_dist2(P, x0, C, &witness2);
+        if (dist2 < dist) { dist = dist2; if (witness) *witness = witness2; }
+        dist2 = point_segment_dist2(P, B, C, &witness2);
+        if (dist2 < dist) { dist = dist2; if (witness) *witness = witness2; }
+    }
+    return (float) dist;
+}
+static int do_simplex2(CcdSimplex &sx, V3 &dir) {
+    const CcdSupport A = sx.ps[sx.last], B = sx.ps[0];
+    const V3 AB = B.v - A.v;
+    const V3 AO = A.v * -1.f;
+    const float d = dot(AB, AO);
+    const V3 tmp = cross(AB, AO);
+    if (fuzzy_zero(dot(tmp, tmp)) && d > 0.f) return 1;
+    if (fuzzy_zero(d) || d < 0.f) {
+        sx.set(0, A);
+        sx.set_size(1);
+        dir = AO;
+    } else {
+        dir = triple_cross(AB, AO, AB);
+    }
+    return 0;
+}
+static int do_simplex3(CcdSimplex &sx, V3 &dir) {
+    const CcdSupport A = sx.ps[sx.last], B = sx.ps[1], C = sx.ps[0];
+    const V3 origin(0, 0, 0);
+    const float dist = point_tri_dist2(origin, A.v, B.v, C.v, nullptr);
+    if (fuzzy_zero(dist)) return 1;
+    if (ccd_vec_eq(A.v, B.v) || ccd_vec_eq(A.v, C.v)) return -1;
+    const V3 AO = A.v * -1.f;
+    const V3 AB = B.v - A.v, AC = C.v - A.v;
+    const V3 ABC = cross(AB, AC);
+    V3 tmp = cross(ABC, AC);
+    float d = dot(tmp, AO);
+    auto label45 = [&]() {
+        d = dot(AB, AO);
+        if (fuzzy_zero(d) || d > 0.f) {
+            sx.set(0, B);
+            sx.set(1, A);
+            sx.set_size(2);
+            dir = triple_cross(AB, AO, AB);
+        } else {
+            sx.set(0, A);
+            sx.set_size(1);
+            dir = AO;
+        }
+    };
+    if (fuzzy_zero(d) || d > 0.f) {
+        d = dot(AC, AO);
+        if (fuzzy_zero(d) || d > 0.f) {
+            sx.set(1, A);
+            sx.set_size(2);
+            dir = triple_cross(AC, AO, AC);
+        } else {
+            label45();
+        }
+    } else {
+        tmp = cross(AB, ABC);
+        d = dot(tmp, AO);
+        if (fuzzy_zero(d) || d > 0.f) {
+            label45();
+        } else {
+            d = dot(ABC, AO);
+            if (fuzzy_zero(d) || d > 0.f) {
+                dir = ABC;
+            } else {
+                const CcdSupport Ctmp = C;
+                sx.set(0, B);
+                sx.set(1, Ctmp);
+                dir = ABC * -1.f;
+            }
+        }
+    }
+    return 0;
+}
+static int do_simplex4(CcdSimplex &sx, V3 &dir) {
+    const CcdSupport A = sx.ps[sx.last], B = sx.ps[2], C = sx.ps[1], D = sx.ps[0];
+    const V3 origin(0, 0, 0);
+    float dist = point_tri_dist2(A.v, B.v, C.v, D.v, nullptr);
+    if (fuzzy_zero(dist)) return -1;
+    dist = point_tri_dist2(origin, A.v, B.v, C.v, nullptr);
+    if (fuzzy_zero(dist)) return 1;
+    dist = point_tri_dist2(origin, A.v, C.v, D.v, nullptr);
+    if (fuzzy_zero(dist)) return 1;
+    dist = point_tri_dist2(origin, A.v, B.v, D.v, nullptr);
+    if (fuzzy_zero(dist)) return 1;
+    dist = point_tri_dist2(origin, B.v, C.v, D.v, nullptr);
+    if (fuzzy_zero(dist)) return 1;
+    const V3 AO = A.v * -1.f;
+    const V3 AB = B.v - A.v, AC = C.v - A.v, AD = D.v - A.v;
+    const V3 ABC = cross(AB, AC), ACD = cross(AC, AD), ADB = cross(AD, AB);
+    const int B_on_ACD = ccd_sign(dot(ACD, AB)), C_on_ADB = ccd_sign(dot(ADB, AC)), D_on_ABC = ccd_sign(dot(ABC, AD));
+    const bool AB_O = ccd_sign(dot(ACD, AO)) == B_on_ACD, AC_O = ccd_sign(dot(ADB, AO)) == C_on_ADB, AD_O = ccd_sign(dot(ABC, AO)) == D_on_ABC;
+    if (AB_O && AC_O && AD_O) return 1;
+    if (!AB_O) {
+        sx.set(2, A);
+        sx.set_size(3);
+    } else if (!AC_O) {
+        sx.set(1, D);
+        sx.set(0, B);
+        sx.set(2, A);
+        sx.set_size(3);
+    } else {
+        sx.set(0, C);
+        sx.set(1, B);
+        sx.set(2, A);
+        sx.set_size(3);
+    }
+    return do_simplex3(sx, dir);
+}
+static int do_simplex(CcdSimplex &sx, V3 &dir) {
+    if (sx.size() == 2) return do_simplex2(sx, dir);
+    if (sx.size() == 3) return do_simplex3(sx, dir);
+    return do_simplex4(sx, dir);
+}
+static void ccd_support(const ConvexView &A, const Xf &trA, const ConvexView &B, const Xf &trB, const V3 &dir, CcdSupport &out) {
+    const V3 sepInA = dir * trA.b, sepInB = (-dir) * trB.b;
+    out.v1 = trA(local_support(A, sepInA));
+    out.v2 = trB(local_support(B, sepInB));
+    out.v = out.v1 - out.v2;
+}
+// returns status: 0 intersect, -1 not; iterations for the diagnostics
+static int ccd_intersect(const ConvexView &A, const Xf &trA, const ConvexView &B, const Xf &trB, int &iterations) {
+    int status = -2;
+    CcdSimplex sx;
+    V3 dir(1, 0, 0);
+    CcdSupport last;
+    ccd_support(A, trA, B, trB, dir, last);
+    sx.add(last);
+    dir = -last.v;
+    for (iterations = 0; iterations < GJK_MAX_ITER; iterations++) {
+        ccd_support(A, trA, B, trB, dir, last);
+        const float delta = dot(last.v, dir);
+        if (delta < 0) { status = -1; break; }
+        sx.add(last);
+        const int res = do_simplex(sx, dir);
+        if (res == 1) { status = 0; break; }
+        else if (res == -1) { status = -1; break; }
+        if (fuzzy_zero(dot(dir, dir))) status = -1;
+        if (length2(dir) < SIMD_EPSILON) { status = -1; break; }
+        if (length2(dir) < SIMD_EPSILON * SIMD_EPSILON) { status = -1; break; }
+    }
+    return status;
+}
+
 struct Detector {
     const ConvexView &A, &B;
     bool with_penetration;  // the nested detector of the penetration solver has none (no recursion)
-    int cur_iter = 0, degenerate = 0, last_method = -1;
+    int cur_iter = 0, degenerate = 0, last_method = -1, ccd_status = -2, ccd_iters = 0;
     bool used_pen = false;
     Detector(const ConvexView &a, const ConvexView &b, bool pen) : A(a), B(b), with_penetration(pen) {}
 
@@ -314,6 +544,9 @@ struct Detector {
         V3 orgNormalInB(0, 0, 0);
         const float margin = marginA + marginB;
         float squaredDistance = BT_LARGE_FLOAT, delta = 0.f;
+        int status = -2;
+        if (g_ccd_pretest && with_penetration) status = ccd_intersect(A, localA, B, localB, ccd_iters);
+        ccd_status = status;
         Simplex sx;
         sx.reset();
         for (;;) {
@@ -358,7 +591,7 @@ struct Detector {
             } else last_method = 2;
         }
         const bool catchDegenerate = with_penetration && degenerate != 0 && (distance + margin) < GJK_EPA_PENETRATION_TOLERANCE;
-        if (checkPenetration && (!isValid || catchDegenerate)) {
+        if ((checkPenetration && (!isValid || catchDegenerate)) || status == 0) {
             if (with_penetration) {
                 V3 tmpA, tmpB;
                 axis = V3(0, 0, 0);
@@ -470,6 +703,8 @@ ClosestResult gjk_closest_points(const ConvexView &A, const ConvexView &B, float
     o.degenerate = det.degenerate;
     o.method = det.last_method;
     o.used_penetration = det.used_pen;
+    o.ccd_status = det.ccd_status;
+    o.ccd_iterations = det.ccd_iters;
     return o;
 }
 

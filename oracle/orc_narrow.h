@@ -48,12 +48,16 @@ struct ClosestResult {
     // diagnostics
     int iterations = 0, degenerate = 0, method = -1;
     bool used_penetration = false;
+    int ccd_status = -2, ccd_iterations = 0;   // the pre-test's verdict (0 intersect, -1 apart, -2 not run) and its loop trips
 };
 
 // which btConvexPenetrationDepthSolver the pair detector calls for overlapping cores: 0 = btGjkEpaPenetrationDepthSolver (orc_epa.cpp;
 // what the reference's btDefaultCollisionConfiguration selects), 1 = btMinkowskiPenetrationDepthSolver (rounds 2-3 of this
 // repository; kept so that tests can put a number on the difference)
 extern int g_penetration_solver;
+// the libccd-derived intersection pre-test at the top of btGjkPairDetector::getClosestPointsNonVirtual (bullet3 >= 2.88): 1 = run it
+// and force the penetration branch when it reports intersecting cores (`status == 0`), 0 = leave it out (see the deviations above)
+extern int g_ccd_pretest;
 
 // btConvexHullShape::localGetSupportingVertexWithoutMargin
 V3 local_support(const ConvexView &S, const V3 &dir);

@@ -373,30 +373,77 @@ static int sort_cached_points(const Manifold &m, const ManifoldPoint &pt) {
     return maxIndex;
 }
 
+// the reference's floor as what Bullet sees: the eight corners of cube.obj under local scaling (1000, 1, 1000)
+// (evo_motion_model/src/env/robot_walk.cpp:22-25, src/item.cpp:17-41: a btConvexHullShape like every member)
+static const V3 kFloorCube[8] = {V3(-1, -1, -1), V3(-1, -1, 1), V3(-1, 1, -1), V3(-1, 1, 1), V3(1, -1, -1), V3(1, -1, 1), V3(1, 1, -1), V3(1, 1, 1)};
+int g_floor_as_hull = 0;
+float g_floor_hull_half = 1000.f;   // 1000 = the reference's floor; smaller: a well-conditioned box of that half width kept under each member (measurement)
+
 void World::collide() {
+    ConvexView floor_view;
+    V3 fmin, fmax;
+    if (g_floor_as_hull) {
+        floor_view.pts = kFloorCube; floor_view.n = 8;
+        floor_view.scale = V3(1000.f, 1.f, 1000.f);
+        floor_view.xf = floor_xf;
+        floor_view.margin = MARGIN;
+        world_aabb(floor_view, G_BREAK, fmin, fmax);
+    }
+    last_floor_gjk_iters = 0; last_floor_queries = 0; last_floor_pen_calls = 0; last_floor_ccd_hits = 0;
     for (int mi = 0; mi < nmember(); mi++) {
         Body &B = bodies[mi];
         if (!B.contact_response) continue;
         Manifold &mf = manifolds[mi];
         const ShapeDef &sh = skel.shapes[B.shape];
-        // deepest hull vertex (first strict minimum of world y)
-        float best = SIMD_INFINITY;
-        V3 bestw;
-        for (const V3 &p : sh.pts) {
-            V3 w = B.xf(p * B.scale);
-            if (w.y < best) { best = w.y; bestw = w; }
+        bool have = false;
+        ManifoldPoint np{};
+        if (g_floor_as_hull) {
+            // MEASUREMENT MODE (orc_set_floor_as_hull): the floor goes through the same convex-convex path as a member pair —
+            // AABB overlap, one btGjkPairDetector query (body0 = floor, body1 = member), btManifoldResult::addContactPoint
+            V3 mn, mx;
+            world_aabb(convex_view(mi), G_BREAK, mn, mx);
+            const bool overlap = fmin.x <= mx.x && fmax.x >= mn.x && fmin.y <= mx.y && fmax.y >= mn.y && fmin.z <= mx.z && fmax.z >= mn.z;
+            if (overlap) {
+                const float md = MARGIN + MARGIN + B.break_thr;   // the manifold's threshold = the smaller of the two shapes' (the member's)
+                ConvexView fv = floor_view;
+                if (g_floor_hull_half < 1000.f) {   // same top face, a box of human size centred under the member: no 2000 m operands
+                    fv.scale = V3(g_floor_hull_half, 1.f, g_floor_hull_half);
+                    fv.xf.o = V3(std::floor(B.xf.o.x + 0.5f), floor_xf.o.y, std::floor(B.xf.o.z + 0.5f));
+                }
+                const ClosestResult r = gjk_closest_points(fv, convex_view(mi), md * md);
+                if (r.used_penetration) last_floor_pen_calls++;
+                if (r.ccd_status == 0) last_floor_ccd_hits++;
+                last_floor_gjk_iters += r.iterations; last_floor_queries++;
+                if (r.has && !(r.distance > B.break_thr)) {
+                    const V3 pointA = r.pointOnB + r.normalOnB * r.distance;
+                    np.localA = floor_xf.invXform(pointA);
+                    np.localB = B.xf.invXform(r.pointOnB);
+                    np.posA = pointA; np.posB = r.pointOnB; np.normalB = r.normalOnB; np.dist = r.distance;
+                    have = true;
+                }
+            }
+        } else {
+            // deepest hull vertex (first strict minimum of world y)
+            float best = SIMD_INFINITY;
+            V3 bestw;
+            for (const V3 &p : sh.pts) {
+                V3 w = B.xf(p * B.scale);
+                if (w.y < best) { best = w.y; bestw = w; }
+            }
+            const V3 normal(0.f, -1.f, 0.f);  // on B (member), pointing towards A (floor)
+            float dist_core = best - floor_top_y;
+            float depth = dist_core - (MARGIN + MARGIN);
+            if (!(depth > B.break_thr)) {
+                // btManifoldResult::addContactPoint
+                V3 pointOnB(bestw.x, bestw.y - MARGIN, bestw.z);
+                V3 pointA = pointOnB + normal * depth;
+                np.localA = floor_xf.invXform(pointA);
+                np.localB = B.xf.invXform(pointOnB);
+                np.posA = pointA; np.posB = pointOnB; np.normalB = normal; np.dist = depth;
+                have = true;
+            }
         }
-        const V3 normal(0.f, -1.f, 0.f);  // on B (member), pointing towards A (floor)
-        float dist_core = best - floor_top_y;
-        float depth = dist_core - (MARGIN + MARGIN);
-        if (!(depth > B.break_thr)) {
-            // btManifoldResult::addContactPoint
-            V3 pointOnB(bestw.x, bestw.y - MARGIN, bestw.z);
-            V3 pointA = pointOnB + normal * depth;
-            ManifoldPoint np{};
-            np.localA = floor_xf.invXform(pointA);
-            np.localB = B.xf.invXform(pointOnB);
-            np.posA = pointA; np.posB = pointOnB; np.normalB = normal; np.dist = depth;
+        if (have) {
             np.applied = 0; np.applied_lat = 0;
             int idx = get_cache_entry(mf, np.localA, B.break_thr);
             if (idx >= 0) {  // replaceContactPoint keeps the accumulated impulses

@@ -32,6 +32,11 @@
 
 namespace orc {
 
+// MEASUREMENT SWITCH (orc_set_floor_as_hull; default 0): 1 = member-vs-floor contacts through the convex-convex path with the floor as
+// the reference builds it (a cube hull scaled (1000, 1, 1000), robot_walk.cpp:22-25), instead of deepest-vertex-vs-plane.
+extern int g_floor_as_hull;
+extern float g_floor_hull_half;
+
 struct ShapeDef {
     std::string name;
     std::vector<V3> pts;  // unique hull points, first-occurrence order
@@ -197,6 +202,7 @@ public:
     int last_num_contacts = 0, last_num_joint_rows = 0;
     int last_num_pair_contacts = 0;      // of last_num_contacts: points of member-vs-member manifolds
     int last_pair_tests = 0, last_pair_gjk_iters = 0, last_pair_penetration_calls = 0;  // narrowphase work of the last step
+    int last_floor_gjk_iters = 0, last_floor_queries = 0, last_floor_pen_calls = 0, last_floor_ccd_hits = 0;   // floor-as-hull measurement mode only
     long long total_pair_tests = 0, total_pair_penetration_calls = 0, total_physics_steps = 0;  // ... and since creation (settle steps of reset() included)
     float last_max_pair_penetration = 0; // deepest pair contact distance (negative = penetrating) after the last collide()
     float last_residual = 0;

@@ -37,6 +37,10 @@ def load():
     L.orc_gjk_query.argtypes = [fp, ctypes.c_int, fp, fp, fp, ctypes.c_int, fp, fp, ctypes.c_float, fp]
     L.orc_epa_query.argtypes = [fp, ctypes.c_int, fp, fp, fp, ctypes.c_int, fp, fp, fp]
     L.orc_set_penetration_solver.argtypes = [ctypes.c_int]
+    L.orc_set_floor_as_hull.argtypes = [ctypes.c_int]
+    L.orc_set_ccd_pretest.argtypes = [ctypes.c_int]
+    L.orc_set_floor_hull_half.argtypes = [ctypes.c_float]
+    L.orc_env_get_floor_stats.argtypes = [vp, ip]
     L.orc_env_destroy.argtypes = [vp]
     for f in ["orc_env_obs_dim", "orc_env_act_dim", "orc_env_num_bodies", "orc_env_num_members", "orc_env_state_size"]:
         getattr(L, f).argtypes = [vp]
@@ -73,11 +77,11 @@ def gjk_query(ptsA, scaleA, xfA, ptsB, scaleB, xfB, max_dist2=1e18, lib=None):
     sb = np.ascontiguousarray(scaleB, np.float32)
     xa = np.ascontiguousarray(np.concatenate([np.asarray(xfA[0], np.float32).ravel(), np.asarray(xfA[1], np.float32)]))
     xb = np.ascontiguousarray(np.concatenate([np.asarray(xfB[0], np.float32).ravel(), np.asarray(xfB[1], np.float32)]))
-    out = np.zeros(12, np.float32)
+    out = np.zeros(14, np.float32)
     L.orc_gjk_query(a.ctypes.data_as(fp), len(a), sa.ctypes.data_as(fp), xa.ctypes.data_as(fp), b.ctypes.data_as(fp), len(b),
                     sb.ctypes.data_as(fp), xb.ctypes.data_as(fp), ctypes.c_float(max_dist2), out.ctypes.data_as(fp))
     return dict(has=bool(out[0]), normal=out[1:4].copy(), point_b=out[4:7].copy(), distance=float(out[7]), iterations=int(out[8]),
-                degenerate=int(out[9]), method=int(out[10]), used_penetration=bool(out[11]))
+                degenerate=int(out[9]), method=int(out[10]), used_penetration=bool(out[11]), ccd_status=int(out[12]), ccd_iterations=int(out[13]))
 
 
 def epa_query(ptsA, scaleA, xfA, ptsB, scaleB, xfB, lib=None):
@@ -100,6 +104,16 @@ def epa_query(ptsA, scaleA, xfA, ptsB, scaleB, xfB, lib=None):
 def set_penetration_solver(which, lib=None):
     """0 = EPA (the reference's configuration, default), 1 = the sampled-direction solver of rounds 2-3."""
     (lib or load()).orc_set_penetration_solver(int(which))
+
+
+def set_ccd_pretest(on, lib=None):
+    """1 = run the libccd-derived intersection pre-test of btGjkPairDetector (bullet3 >= 2.88) in front of every query"""
+    (lib or load()).orc_set_ccd_pretest(int(on))
+
+
+def set_floor_as_hull(on, lib=None):
+    """measurement switch: 1 = the floor as the reference builds it (cube hull scaled (1000, 1, 1000)) through GJK, 0 = plane (default)"""
+    (lib or load()).orc_set_floor_as_hull(int(on))
 
 
 class OracleEnv:
@@ -194,6 +208,11 @@ class OracleEnv:
         self.L.orc_env_get_pair_stats(self.h, c.ctypes.data_as(ip), f.ctypes.data_as(fp))
         return dict(pair_contacts=int(c[0]), pair_tests=int(c[1]), gjk_iterations=int(c[2]), penetration_calls=int(c[3]),
                     live_pairs=int(c[4]), deepest=float(f[0]))
+
+    def floor_stats(self):
+        c = np.zeros(4, np.int32)
+        self.L.orc_env_get_floor_stats(self.h, c.ctypes.data_as(ip))
+        return dict(queries=int(c[0]), gjk_iterations=int(c[1]), penetration_calls=int(c[2]), ccd_intersect=int(c[3]))
 
     def pair_totals(self):
         """narrowphase work since creation, every physics step counted (settle steps of reset() too)"""

@@ -57,6 +57,42 @@ def test_launcher_propagates_failure(tmp_path, capsys):
     assert capsys.readouterr().out.strip() == ""
 
 
+def test_launcher_keeps_and_echoes_every_ranks_stderr(tmp_path, capsys):
+    """a rank that dies says why: its stderr is in a file of its own and is echoed with the failure"""
+    import bench
+    worker = _stub(tmp_path, """
+        import os, sys, time
+        r = os.environ["RANK"]
+        sys.stderr.write("rank %s: starting\\n" % r)
+        if r == "1":
+            sys.stderr.write("rank 1: hipErrorNoDevice (pretend)\\n")
+            sys.exit(7)
+        time.sleep(60)
+    """)
+    logs = tmp_path / "ranks"
+    rc = bench.launch_ranks(2, [], worker=worker, timeout=30, log_dir=str(logs))
+    assert rc == 7
+    cap = capsys.readouterr()
+    assert cap.out.strip() == ""
+    assert "rank 1 exited with code 7" in cap.err and "hipErrorNoDevice (pretend)" in cap.err and "rank 0: starting" in cap.err
+    assert (logs / "rank0.err").read_text().startswith("rank 0: starting")
+    assert "pretend" in (logs / "rank1.err").read_text()
+
+
+def test_launcher_times_out_with_the_logs(tmp_path, capsys):
+    import bench
+    worker = _stub(tmp_path, """
+        import os, sys, time
+        sys.stderr.write("rank %s waits for a peer that never comes\\n" % os.environ["RANK"])
+        sys.stderr.flush()
+        time.sleep(120)
+    """)
+    rc = bench.launch_ranks(2, [], worker=worker, timeout=3)
+    assert rc == 124
+    err = capsys.readouterr().err
+    assert "timed out" in err and err.count("waits for a peer") == 2
+
+
 def test_bench_fails_cleanly_without_gpu():
     """`python bench.py --gpus 2 --backend gloo` on a box without a GPU: non-zero exit, no result line, no hang"""
     import torch

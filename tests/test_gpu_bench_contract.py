@@ -48,3 +48,18 @@ def test_training_mode_lines_without_the_cpu_leg():
     assert "cpu_baseline" not in d and d["roofline_ppo_update"]["bound"] == "mfma" and 0.2 < d["roofline_ppo_update"]["frac"] < 1
     d = _run("--mode", "sac", "--steps", "32", "--warmup", "32", "--no-cpu-baseline")
     assert d["value"] > 1e6 and "sac" in d["config"]["workload"].lower()
+
+
+def test_two_ranks_on_one_gpu_end_to_end():
+    """The N > 1 form of the driver's call, rehearsed on the one GPU of this box: `bench.py --gpus 2` starts
+    two rank processes itself (launcher, RANK / WORLD_SIZE / MASTER_* environment), each creates its 4096 envs and its agent,
+    the all-reduce-of-ones check passes before anything is timed, the PPO update exchanges its advantage statistics (all-gather)
+    and gradients (all-reduce) over gloo — RCCL refuses two ranks on one device — and rank 0 prints the one line, `n_gpus: 2`.
+    The 8-GPU run differs in the backend only."""
+    d = _run("--gpus", "2", "--backend", "gloo", "--mode", "ppo", "--steps", "32", "--warmup", "32", "--no-cpu-baseline", timeout=600)
+    assert d["n_gpus"] == 2 and d["collective_ranks"] == 2 and d["backend"] == "gloo" and d["rccl_ranks"] is None
+    assert d["steps"] == 32 and d["scaling"] == "weak"
+    # whole-job aggregate: both ranks' transitions over the max of their times
+    assert d["value"] > 5e5 and 0 < d["config"]["do_step_fraction"] <= 1.0
+    assert abs(d["value"] - 2 * d["config"]["envs_per_gpu"] * d["config"]["do_step_fraction"] / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
+    assert d["roofline_ppo_update"]["frac"] > 0.05

@@ -69,3 +69,23 @@ def test_cxx_rccl_training_equals_python_training_bit_for_bit(tmp_path):
     assert abs(la - line["actor_loss"]) == 0.0 and abs(lc - line["critic_loss"]) == 0.0
     moved = np.abs(want - np.concatenate([pa, pc])).max()
     assert moved > 1e-4  # the update did something
+
+
+def test_rendezvous_gives_up_with_a_message_and_never_takes_a_stale_id(tmp_path):
+    """The ncclUniqueId travels through a file.  A rank > 0 whose rank 0 never comes must end with a message after the bounded
+    wait (not block in ncclCommInitRank), and an id file left behind by an earlier run on the same port — older than this
+    process — must not be accepted (ids of two different runs would block the communicator for ever)."""
+    import time
+    if not os.path.exists(os.path.join(BUILD, "train_main")):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "examples")])
+    idf = tmp_path / "evm_nccl_id.test"
+    idf.write_bytes(b"\x07" * 128)                         # sizeof(ncclUniqueId) bytes of a previous run
+    old = time.time() - 3600
+    os.utime(idf, (old, old))
+    env_vars = dict(os.environ, RANK="1", WORLD_SIZE="2", LOCAL_RANK="0", EVM_NCCL_ID_FILE=str(idf), EVM_RENDEZVOUS_TIMEOUT_S="2",
+                    HSA_ENABLE_IPC_MODE_LEGACY="0")
+    t0 = time.time()
+    p = subprocess.run([os.path.join(BUILD, "train_main"), "--skeleton", SKEL, "--envs", "64", "--horizon", "4", "--iters", "1"],
+                       capture_output=True, timeout=120, env=env_vars)
+    assert p.returncode != 0 and time.time() - t0 < 60
+    assert b"no fresh ncclUniqueId" in p.stderr and b"after 2 s" in p.stderr, p.stderr
