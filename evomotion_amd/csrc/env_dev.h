@@ -25,7 +25,7 @@ struct EnvDev {
     float *crec;                    // [(nm+npair)*84][n] two-body contact records of the step (EVM_CR_STRIDE), by manifold id
     int *plist;                     // [npair][n] per pair: the envs whose boxes overlap or that hold a cached point (this step)
     int *blist;                     // [n * npair] (pair << 20 | env) entries of the pairs with a big hull, one flat list
-    int *pcount;                    // [2][EVM_MAX_PAIRS + 1] the lists' lengths, [npair] = the flat list's; two copies: a step appends to
+    int *pcount;                    // [2][EVM_PC_STRIDE] the lists' lengths, [npair] = the flat list's, [npair + 1] = the urgent list's; two copies: a step appends to
                                     // copy pc_cur and zeroes the other one for the next step (the host flips pc_cur per launch)
     int pc_cur;
     int gtile_only;                 // the 64-env tile (3 KB per body) does not fit the CU's LDS: the tile sweeps kernel works on the

@@ -155,7 +155,7 @@ int evm_env_create(const char *skeleton_path, int n_envs, int device, uint64_t s
         segs.push_back({(void **) &env->d.crec, (size_t) EVM_CR_STRIDE * (S.nm + S.npair)});
         segs.push_back({(void **) &env->d.plist, (size_t) (S.npair > 0 ? S.npair : 1)});
         segs.push_back({(void **) &env->d.blist, (size_t) (S.npair > 0 ? S.npair : 1)});
-        segs.push_back({(void **) &env->d.pcount, (size_t) (2 * (EVM_MAX_PAIRS + 1) + 63) / 64});  // >= 2 x (EVM_MAX_PAIRS + 1) ints whatever the batch (n >= 64)
+        segs.push_back({(void **) &env->d.pcount, (size_t) (2 * EVM_PC_STRIDE + 63) / 64});  // >= 2 x EVM_PC_STRIDE ints whatever the batch (n >= 64)
     }
     size_t total = 0;
     for (auto &s : segs) total += s.count * n * 4;
@@ -313,7 +313,13 @@ int evm_env_pairs(const EvmEnv *env, int *n_pairs, int *h_pairs) {
 int evm_env_debug_pair_counts(EvmEnv *env, int *h_out) {
     if (!env || !h_out) return fail(EVM_E_INVALID, "null argument");
     HIP_TRY(hipDeviceSynchronize());
-    if (env->skel.npair > 0) HIP_TRY(hipMemcpy(h_out, env->d.pcount + env->d.pc_cur * (EVM_MAX_PAIRS + 1), (env->skel.npair + 1) * sizeof(int), hipMemcpyDeviceToHost));  // the last step's copy
+    if (env->skel.npair > 0) {   // the last step's copy; the urgent list's entries (pairs_dev.h) are counted with the flat list
+        int urgent = 0;
+        const int *cur = env->d.pcount + env->d.pc_cur * EVM_PC_STRIDE;
+        HIP_TRY(hipMemcpy(h_out, cur, (env->skel.npair + 1) * sizeof(int), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(&urgent, cur + env->skel.npair + 1, sizeof(int), hipMemcpyDeviceToHost));
+        h_out[env->skel.npair] += urgent;
+    }
     return EVM_OK;
 }
 
@@ -518,7 +524,7 @@ int evm_env_get_state(EvmEnv *env, float *h_state) {
                 for (int f = 0; f < 9; f++) o[k++] = j < cnt ? m.mfp[tix(36 * S.nm, (mm * 4 + j) * 9 + f, e)] : 0.f;
         }
         for (int p = 0; p < S.npair; p++) {
-            const int cnt = m.pmn[tix(S.npair, p, e)];
+            const int cnt = m.pmn[tix(S.npair, p, e)] & 0xff;   // (bit 8: the narrowphase's scheduling hint, not state)
             o[k++] = (float) cnt;
             for (int j = 0; j < 4; j++)
                 for (int f = 0; f < 12; f++) o[k++] = j < cnt ? m.pmp[tix((size_t) EVM_PM_STRIDE * S.npair, (p * 4 + j) * 12 + f, e)] : 0.f;
@@ -635,7 +641,7 @@ int evm_env_get_stamps(EvmEnv *env, unsigned long long *h_out /* [n_tiles, 16] *
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(h_out, env->d.stamps, (size_t) (env->d.n / 64) * 16 * 8, hipMemcpyDeviceToHost));
 #ifdef EVM_KSTAMPS  // the narrowphase kernel accumulates with atomics: every read starts a new interval
-    const unsigned long long reset[32] = {0, 0, 0, 0, 0, 0, ~0ull, 0};
+    const unsigned long long reset[48] = {0, 0, 0, 0, 0, 0, ~0ull, 0};
     HIP_TRY(hipMemcpy(env->d.stamps, reset, sizeof(reset), hipMemcpyHostToDevice));
 #endif
     return EVM_OK;

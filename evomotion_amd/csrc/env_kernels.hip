@@ -1916,7 +1916,7 @@ __global__ __launch_bounds__(64 * EVM_SPLIT_WAVES) void k_split_pre_a(EnvDev d, 
     // append to them).  Before the guard: one wavefront of the grid does it whatever the mask leaves of its tile.
     if (c_skel.self_collision && blockIdx.x == 0 && blockIdx.y == gridDim.y - 1 && c.wave == EVM_SPLIT_WAVES - 1) {
         int *nxt = pc_next(d);
-        for (int k = c.lane; k <= c_skel.npair; k += 64) nxt[k] = 0;
+        for (int k = c.lane; k <= c_skel.npair + 1; k += 64) nxt[k] = 0;
     }
     EVM_SPLIT_GUARD()
     const LaneState L = lane_state<MODE>(c);
@@ -2075,11 +2075,12 @@ __global__ __launch_bounds__(64 * EVM_SPLIT_WAVES) __attribute__((amdgpu_waves_p
 //                                block, pairs in decreasing cost order
 // One launch for both, so that the few long big-hull wavefronts and the many short ones share the chip.
 #define EVM_BIG_BLOCKS 2048
+#define EVM_URGENT_BLOCKS 32   // the launch's first blocks: the urgent list (pairs_dev.h), one query per wavefront
 #ifndef EVM_PAIRS_WAVES
 #define EVM_PAIRS_WAVES 2   // wavefronts per SIMD the narrowphase kernel is compiled for (128 arch VGPRs + AGPR spill space at 2)
 #endif
 template <int MODE>
-DEV void narrow_block(const EnvDev &d, int blk, int tiles) {
+DEV void narrow_block(const EnvDev &d, int blk, int tiles) {   // blk: block index in the launch
 #ifdef EVM_KSTAMPS  // diagnostic build (tools/kstamps.py): working wavefronts of the narrowphase kernel, cycles and extent
     struct KStamp {
         unsigned long long *st, t0, r0; int kind;
@@ -2093,9 +2094,11 @@ DEV void narrow_block(const EnvDev &d, int blk, int tiles) {
     } ks;
     ks.st = nullptr;
 #endif
-    if (blk < EVM_BIG_BLOCKS) {
-        const int cnt = pc_cur(d)[c_skel.npair];
-        if (blk * 4 >= cnt) return;
+    const bool urgent_blk = blk < EVM_URGENT_BLOCKS;
+    blk -= EVM_URGENT_BLOCKS;
+    if (urgent_blk || blk < EVM_BIG_BLOCKS) {
+        const int cnt = pc_cur(d)[c_skel.npair + (urgent_blk ? 1 : 0)];
+        if (urgent_blk ? blk + EVM_URGENT_BLOCKS >= cnt : blk * 4 >= cnt) return;
 #ifdef EVM_KSTAMPS
         ks.begin(d.stamps, 0);
 #endif
@@ -2112,6 +2115,18 @@ DEV void narrow_block(const EnvDev &d, int blk, int tiles) {
 #ifdef EVM_KSTAMPS
         if (threadIdx.x == 0) atomicAdd(&d.stamps[16], __builtin_amdgcn_s_memtime() - ks.t0);  // hull staging
 #endif
+        if (urgent_blk) {   // one query per wavefront (row 0; the penetration solver deals its parallel parts to the row's 16 lanes)
+            __builtin_amdgcn_s_setprio(2);
+            for (int i = blk + EVM_URGENT_BLOCKS; i < cnt; i += EVM_URGENT_BLOCKS) {
+                if (threadIdx.x < 16) {
+                    const int e = d.blist[(size_t) c_skel.npair * d.n - 1 - i], p = e >> 20, env = e & 0xfffff;
+                    const Ctx c = make_ctx_env(d, env);
+                    const bool fin = (MODE & 4) && (d.flags[env] & EVM_FLAG_DONE) != 0;
+                    pair_item<true>(c, p, fin, hoff);
+                }
+            }
+            return;
+        }
         for (int i0 = blk * 4; i0 < cnt; i0 += EVM_BIG_BLOCKS * 4) {
             const int i = i0 + (int) (threadIdx.x >> 4);
             if (i < cnt) {  // (a row without an entry sits the iteration out; rows are independent of each other)
@@ -2442,7 +2457,7 @@ namespace evm {
 template <int MODE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EVM_PAIRS_WAVES, EVM_PAIRS_WAVES))) void k_split_pairs_rec(EnvDev d, const float *__restrict__ action,
                                                                         const uint8_t *__restrict__ mask, int tiles, int nvw) {
-    const int narrow = EVM_BIG_BLOCKS + tiles * d.npair_host;
+    const int narrow = EVM_URGENT_BLOCKS + EVM_BIG_BLOCKS + tiles * d.npair_host;
     if ((int) blockIdx.x < narrow) { narrow_block<MODE>(d, (int) blockIdx.x, tiles); return; }
     const int rb = (int) blockIdx.x - narrow, tile = rb / nvw, vw = rb - tile * nvw;
     const Ctx c = make_ctx_at(d, d.gtile + (size_t) tile * d.tile_floats, tile, (int) threadIdx.x, 0);
@@ -2538,10 +2553,10 @@ static hipError_t launch_split(const EnvDev &d, size_t lds, const float *action,
     if (merge < 0) { const char *e = getenv("EVM_PAIRS_MERGE"); merge = (e && e[0] == '0') ? 0 : 1; }
     if (d.pmn && merge) {
         const int nvw = parts * EVM_SPLIT_WAVES;
-        hipLaunchKernelGGL((k_split_pairs_rec<MODE>), dim3(EVM_BIG_BLOCKS + tiles * d.npair_host + tiles * nvw), dim3(64), 0, s, d, action, mask, tiles, nvw);
+        hipLaunchKernelGGL((k_split_pairs_rec<MODE>), dim3(EVM_URGENT_BLOCKS + EVM_BIG_BLOCKS + tiles * d.npair_host + tiles * nvw), dim3(64), 0, s, d, action, mask, tiles, nvw);
     } else {
         hipLaunchKernelGGL((k_split_pre_b<MODE>), gp, bp, 0, s, d, action, mask, 0);
-        if (d.pmn) hipLaunchKernelGGL((k_split_pairs<MODE>), dim3(EVM_BIG_BLOCKS + tiles * d.npair_host), dim3(64), 0, s, d, mask, tiles);
+        if (d.pmn) hipLaunchKernelGGL((k_split_pairs<MODE>), dim3(EVM_URGENT_BLOCKS + EVM_BIG_BLOCKS + tiles * d.npair_host), dim3(64), 0, s, d, mask, tiles);
     }
     if (e0) (void) hipEventRecord(e0, s);
     bool fused_post = false;

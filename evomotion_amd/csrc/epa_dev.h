@@ -52,10 +52,6 @@ struct State {
     unsigned short frame[EPA_MAXF]; // walk frames f | e << 8 | stage << 10
     unsigned short hz[EPA_MAXF];    // horizon edges in creation order: f | e << 8
     unsigned char hzn[EPA_MAXF];    // ... and the face made for each
-    int sc[2][4];                   // the GJK's two simplices: vertex slots,
-    float sp[2][4];                 //   weights,
-    int srank[2];                   //   ranks
-    int gfree[4];                   // its free vertex slots
     int bad;
 };
 __device__ __shared__ State g_epa;
@@ -206,98 +202,117 @@ DEV float project4(F3 a, F3 b, F3 c, F3 d, float *w, unsigned &m) {
     return -1.f;
 }
 
+// The simplex lives in registers (every value is wave-uniform; slot selection by compare-and-select): the four vertices of the
+// store, the current simplex as four packed slot numbers + weights, the free list.  (The original keeps two simplices and flips
+// between them; the next one is only ever built from the current one and then replaces it, so one simplex and a temporary do.)
+// The vertices are also written through to g_epa.svd / svw[EPA_MAXV + slot]: EPA's faces refer to them there.
 template <bool GROUP>
 struct Gjk2 {
     Mink<GROUP> shape;
     F3 ray;
-    int nfree, current, status;   // status: 0 Valid, 1 Inside, 2 Failed
+    F3 gw0, gw1, gw2, gw3, gd0, gd1, gd2, gd3;   // store[slot].w / .d
+    unsigned cpk, fpk;                           // simplex vertex slots / free slots, 8 bits each
+    float p0, p1, p2, p3;                        // simplex weights
+    int rank, nfree, status;                     // status: 0 Valid, 1 Inside, 2 Failed
     float distance;
 
-    DEV F3 W(int simplex, int i) const { return ld3(g_epa.svw[EPA_MAXV + g_epa.sc[simplex][i]]); }
-    // getsupport(d, store[slot])
+    DEV int slot(int i) const { return (int) ((cpk >> (8 * i)) & 255u); }
+    DEV F3 Wslot(int sl) const { return gj::sel3(sl == 0, gw0, gj::sel3(sl == 1, gw1, gj::sel3(sl == 2, gw2, gw3))); }
+    DEV F3 Dslot(int sl) const { return gj::sel3(sl == 0, gd0, gj::sel3(sl == 1, gd1, gj::sel3(sl == 2, gd2, gd3))); }
+    DEV F3 W(int i) const { return Wslot(slot(i)); }
+    DEV float P(int i) const { return i == 0 ? p0 : (i == 1 ? p1 : (i == 2 ? p2 : p3)); }
+    DEV void setP(int i, float v) { p0 = i == 0 ? v : p0; p1 = i == 1 ? v : p1; p2 = i == 2 ? v : p2; p3 = i == 3 ? v : p3; }
+    // getsupport(d, sv): sv = an EPA vertex id (< EPA_MAXV) or EPA_MAXV + store slot
     DEV void getsupport(F3 d, int id) {
         const F3 dn = gj::scl(d, 1.0f / flen(d));
         const F3 w = shape.support(dn);
         g_epa.svd[id] = gj_f4{dn.x, dn.y, dn.z, 0.f};
         g_epa.svw[id] = gj_f4{w.x, w.y, w.z, 0.f};
+        if (id >= EPA_MAXV) {
+            const int sl = id - EPA_MAXV;
+            gw0 = gj::sel3(sl == 0, w, gw0); gw1 = gj::sel3(sl == 1, w, gw1); gw2 = gj::sel3(sl == 2, w, gw2); gw3 = gj::sel3(sl == 3, w, gw3);
+            gd0 = gj::sel3(sl == 0, dn, gd0); gd1 = gj::sel3(sl == 1, dn, gd1); gd2 = gj::sel3(sl == 2, dn, gd2); gd3 = gj::sel3(sl == 3, dn, gd3);
+        }
     }
-    DEV void removevertice(int s) {
-        const int r = ui(g_epa.srank[s]) - 1;
-        g_epa.srank[s] = r;
-        g_epa.gfree[nfree++] = ui(g_epa.sc[s][r]);
+    DEV void removevertice() {
+        rank--;
+        fpk = (fpk & ~(255u << (8 * nfree))) | ((unsigned) slot(rank) << (8 * nfree));
+        nfree++;
     }
-    DEV void appendvertice(int s, F3 v) {
-        const int r = ui(g_epa.srank[s]);
-        const int slot = ui(g_epa.gfree[--nfree]);
-        g_epa.sp[s][r] = 0.f;
-        g_epa.sc[s][r] = slot;
-        g_epa.srank[s] = r + 1;
-        getsupport(v, EPA_MAXV + slot);
+    DEV void appendvertice(F3 v) {
+        nfree--;
+        const int sl = (int) ((fpk >> (8 * nfree)) & 255u);
+        setP(rank, 0.f);
+        cpk = (cpk & ~(255u << (8 * rank))) | ((unsigned) sl << (8 * rank));
+        rank++;
+        getsupport(v, EPA_MAXV + sl);
     }
     DEV int evaluate(const Mink<GROUP> &shapearg, F3 guess) {
         unsigned iterations = 0;
         float sqdist = 0.f, alpha = 0.f;
         F3 lw0, lw1, lw2, lw3;
         unsigned clastw = 0;
-        g_epa.gfree[0] = 0; g_epa.gfree[1] = 1; g_epa.gfree[2] = 2; g_epa.gfree[3] = 3;
+        gw0 = gw1 = gw2 = gw3 = gd0 = gd1 = gd2 = gd3 = f3(0.f, 0.f, 0.f);
+        fpk = 0u | (1u << 8) | (2u << 16) | (3u << 24);
         nfree = 4;
-        current = 0;
+        cpk = 0u; p0 = p1 = p2 = p3 = 0.f; rank = 0;
         status = 0;
         shape = shapearg;
         distance = 0.f;
-        g_epa.srank[0] = 0;
         ray = guess;
         const float sqrl = gj::len2(ray);
-        appendvertice(0, ub(sqrl > 0.f) ? gj::neg(ray) : f3(1.f, 0.f, 0.f));
-        g_epa.sp[0][0] = 1.f;
-        ray = W(0, 0);
+        appendvertice(ub(sqrl > 0.f) ? gj::neg(ray) : f3(1.f, 0.f, 0.f));
+        p0 = 1.f;
+        ray = W(0);
         sqdist = sqrl;
         lw0 = lw1 = lw2 = lw3 = ray;
         do {
-            const int next = 1 - current, cs = current;
             const float rl = flen(ray);
             if (ub(rl < EPA_GJK_MIN_DISTANCE)) { status = 1; break; }
-            appendvertice(cs, gj::neg(ray));
-            const int rank = ui(g_epa.srank[cs]);
-            const F3 w = W(cs, rank - 1);
+            appendvertice(gj::neg(ray));
+            const F3 w = W(rank - 1);
             const bool found = gj::len2(gj::sub(w, lw0)) < EPA_GJK_DUP_EPS || gj::len2(gj::sub(w, lw1)) < EPA_GJK_DUP_EPS ||
                                gj::len2(gj::sub(w, lw2)) < EPA_GJK_DUP_EPS || gj::len2(gj::sub(w, lw3)) < EPA_GJK_DUP_EPS;
-            if (ub(found)) { removevertice(cs); break; }
+            if (ub(found)) { removevertice(); break; }
             clastw = (clastw + 1) & 3;
             lw0 = gj::sel3(clastw == 0, w, lw0); lw1 = gj::sel3(clastw == 1, w, lw1);
             lw2 = gj::sel3(clastw == 2, w, lw2); lw3 = gj::sel3(clastw == 3, w, lw3);
             const float omega = gj::dot(ray, w) / rl;
             alpha = omega > alpha ? omega : alpha;
-            if (ub(((rl - alpha) - (EPA_GJK_ACCURACY * rl)) <= 0.f)) { removevertice(cs); break; }
+            if (ub(((rl - alpha) - (EPA_GJK_ACCURACY * rl)) <= 0.f)) { removevertice(); break; }
             float weights[4] = {0.f, 0.f, 0.f, 0.f};
             unsigned mask = 0;
-            if (rank == 2) sqdist = project2(W(cs, 0), W(cs, 1), weights, mask);
-            else if (rank == 3) sqdist = project3(W(cs, 0), W(cs, 1), W(cs, 2), weights, mask);
-            else sqdist = project4(W(cs, 0), W(cs, 1), W(cs, 2), W(cs, 3), weights, mask);
+            if (rank == 2) sqdist = project2(W(0), W(1), weights, mask);
+            else if (rank == 3) sqdist = project3(W(0), W(1), W(2), weights, mask);
+            else sqdist = project4(W(0), W(1), W(2), W(3), weights, mask);
             mask = (unsigned) ui((int) mask);
             if (ub(sqdist >= 0.f)) {
                 int nr = 0;
+                unsigned ncpk = 0u;
+                float np[4] = {0.f, 0.f, 0.f, 0.f};
                 ray = f3(0.f, 0.f, 0.f);
-                current = next;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     if (i < rank) {
-                        const int slot = ui(g_epa.sc[cs][i]);
+                        const int sl = slot(i);
                         if (mask & (1u << i)) {
-                            g_epa.sc[next][nr] = slot;
-                            g_epa.sp[next][nr] = weights[i];
+                            ncpk |= (unsigned) sl << (8 * nr);
+#pragma unroll
+                            for (int q = 0; q < 4; q++) np[q] = q == nr ? weights[i] : np[q];
                             nr++;
-                            ray = gj::add(ray, gj::scl(ld3(g_epa.svw[EPA_MAXV + slot]), weights[i]));
+                            ray = gj::add(ray, gj::scl(Wslot(sl), weights[i]));
                         } else {
-                            g_epa.gfree[nfree++] = slot;
+                            fpk = (fpk & ~(255u << (8 * nfree))) | ((unsigned) sl << (8 * nfree));
+                            nfree++;
                         }
                     }
                 }
-                g_epa.srank[next] = nr;
+                cpk = ncpk; rank = nr;
+                p0 = np[0]; p1 = np[1]; p2 = np[2]; p3 = np[3];
                 ray = uf3(ray);
                 if (mask == 15) status = 1;
             } else {
-                removevertice(cs);
+                removevertice();
                 break;
             }
             status = ((++iterations) < (unsigned) EPA_GJK_MAX_ITER) ? status : 2;
@@ -308,54 +323,49 @@ struct Gjk2 {
     }
     // EncloseOrigin, the recursion unrolled over the simplex rank (1 -> 2 -> 3 -> 4)
     DEV bool enclose4() {
-        const int s = current;
-        return ub(fabsf(det3(gj::sub(W(s, 0), W(s, 3)), gj::sub(W(s, 1), W(s, 3)), gj::sub(W(s, 2), W(s, 3)))) > 0.f);
+        return ub(fabsf(det3(gj::sub(W(0), W(3)), gj::sub(W(1), W(3)), gj::sub(W(2), W(3)))) > 0.f);
     }
     DEV bool enclose3() {
-        const int s = current;
-        const F3 n = gj::cross(gj::sub(W(s, 1), W(s, 0)), gj::sub(W(s, 2), W(s, 0)));
+        const F3 n = gj::cross(gj::sub(W(1), W(0)), gj::sub(W(2), W(0)));
         if (ub(gj::len2(n) > 0.f)) {
-            appendvertice(s, n);
+            appendvertice(n);
             if (enclose4()) return true;
-            removevertice(s);
-            appendvertice(s, gj::neg(n));
+            removevertice();
+            appendvertice(gj::neg(n));
             if (enclose4()) return true;
-            removevertice(s);
+            removevertice();
         }
         return false;
     }
     DEV bool enclose2() {
-        const int s = current;
-        const F3 d = gj::sub(W(s, 1), W(s, 0));
+        const F3 d = gj::sub(W(1), W(0));
         for (int i = 0; i < 3; ++i) {
             const F3 axis = f3(i == 0 ? 1.f : 0.f, i == 1 ? 1.f : 0.f, i == 2 ? 1.f : 0.f);
             const F3 p = gj::cross(d, axis);
             if (ub(gj::len2(p) > 0.f)) {
-                appendvertice(s, p);
+                appendvertice(p);
                 if (enclose3()) return true;
-                removevertice(s);
-                appendvertice(s, gj::neg(p));
+                removevertice();
+                appendvertice(gj::neg(p));
                 if (enclose3()) return true;
-                removevertice(s);
+                removevertice();
             }
         }
         return false;
     }
     DEV bool enclose1() {
-        const int s = current;
         for (int i = 0; i < 3; ++i) {
             const F3 axis = f3(i == 0 ? 1.f : 0.f, i == 1 ? 1.f : 0.f, i == 2 ? 1.f : 0.f);
-            appendvertice(s, axis);
+            appendvertice(axis);
             if (enclose2()) return true;
-            removevertice(s);
-            appendvertice(s, gj::neg(axis));
+            removevertice();
+            appendvertice(gj::neg(axis));
             if (enclose2()) return true;
-            removevertice(s);
+            removevertice();
         }
         return false;
     }
     DEV bool enclose_origin() {
-        const int rank = ui(g_epa.srank[current]);
         if (rank == 1) return enclose1();
         if (rank == 2) return enclose2();
         if (rank == 3) return enclose3();
@@ -365,6 +375,21 @@ struct Gjk2 {
 };
 
 // ---- gjkepa2_impl::EPA ---------------------------------------------------------------------------------------------------
+#ifdef EVM_KSTAMPS   // (tools/kstamps.py) where a penetration query's cycles go: d.stamps[32..]
+#define EPA_T0() unsigned long long epa_t = __builtin_amdgcn_s_memtime();
+#define EPA_MARK(KS, k)                                                                    \
+    {                                                                                      \
+        __builtin_amdgcn_s_waitcnt(0);                                                     \
+        const unsigned long long epa_n = __builtin_amdgcn_s_memtime();                     \
+        if (threadIdx.x == __builtin_amdgcn_readfirstlane(threadIdx.x)) atomicAdd(&(KS)[k], epa_n - epa_t); \
+        epa_t = epa_n;                                                                     \
+    }
+#define EPA_COUNT(KS, k, v) { if (threadIdx.x == __builtin_amdgcn_readfirstlane(threadIdx.x)) atomicAdd(&(KS)[k], (unsigned long long) (v)); }
+#else
+#define EPA_T0()
+#define EPA_MARK(KS, k)
+#define EPA_COUNT(KS, k, v)
+#endif
 struct EpaOut {
     int status;       // EPA::eStatus (9 = Failed)
     F3 normal;
@@ -422,21 +447,23 @@ DEV EpaOut epa_evaluate(Gjk2<GROUP> &gjk, F3 guess) {
     const int lane = (int) (threadIdx.x & 63);
     const unsigned long long act = __ballot(true);
     const int nact = (int) __popcll(act), rank = (int) __popcll(act & ((1ull << lane) - 1ull));
-    const int sx = gjk.current;
-    if (ui(S.srank[sx]) > 1 && gjk.enclose_origin()) {
+    // rows_ok: every 16-lane row of the wavefront is either whole or absent (always so in the grouped form; a full wavefront in
+    // the one-query-per-lane form): findbest may then reduce across a row with DPP
+    const bool rows_ok = (((act & 0xFFFFull) == 0ull) || ((act & 0xFFFFull) == 0xFFFFull)) && ((((act >> 16) & 0xFFFFull) == 0ull) || (((act >> 16) & 0xFFFFull) == 0xFFFFull)) &&
+                         ((((act >> 32) & 0xFFFFull) == 0ull) || (((act >> 32) & 0xFFFFull) == 0xFFFFull)) && ((((act >> 48) & 0xFFFFull) == 0ull) || (((act >> 48) & 0xFFFFull) == 0xFFFFull));
+    if (gjk.rank > 1 && gjk.enclose_origin()) {
         // stock = every face, root = face 0; hull empty
         for (int i = rank; i < EPA_MAXF; i += nact) { S.stock[i] = (unsigned char) (EPA_MAXF - 1 - i); S.fkey[i] = EVM_INF; }
         EPA_SYNC()
         int nstock = EPA_MAXF, seq = 0, hi = 0, nhull = 0;
         int nextsv = 0;
         // orient the simplex
-        if (ub(det3(gj::sub(gjk.W(sx, 0), gjk.W(sx, 3)), gj::sub(gjk.W(sx, 1), gjk.W(sx, 3)), gj::sub(gjk.W(sx, 2), gjk.W(sx, 3))) < 0.f)) {
-            const int tc = ui(S.sc[sx][0]), tc1 = ui(S.sc[sx][1]);
-            const float tp = uf(S.sp[sx][0]), tp1 = uf(S.sp[sx][1]);
-            S.sc[sx][0] = tc1; S.sc[sx][1] = tc;
-            S.sp[sx][0] = tp1; S.sp[sx][1] = tp;
+        if (ub(det3(gj::sub(gjk.W(0), gjk.W(3)), gj::sub(gjk.W(1), gjk.W(3)), gj::sub(gjk.W(2), gjk.W(3))) < 0.f)) {
+            const unsigned c0 = gjk.cpk & 255u, c1 = (gjk.cpk >> 8) & 255u;
+            gjk.cpk = (gjk.cpk & 0xFFFF0000u) | c1 | (c0 << 8);
+            const float tp = gjk.p0; gjk.p0 = gjk.p1; gjk.p1 = tp;
         }
-        const int g0 = EPA_MAXV + ui(S.sc[sx][0]), g1 = EPA_MAXV + ui(S.sc[sx][1]), g2 = EPA_MAXV + ui(S.sc[sx][2]), g3 = EPA_MAXV + ui(S.sc[sx][3]);
+        const int g0 = EPA_MAXV + gjk.slot(0), g1 = EPA_MAXV + gjk.slot(1), g2 = EPA_MAXV + gjk.slot(2), g3 = EPA_MAXV + gjk.slot(3);
         const int ta[4] = {g0, g1, g2, g0}, tb[4] = {g1, g0, g1, g2}, tcv[4] = {g2, g3, g3, g3};
         int tetra[4] = {-1, -1, -1, -1};
 #pragma unroll
@@ -464,6 +491,20 @@ DEV EpaOut epa_evaluate(Gjk2<GROUP> &gjk, F3 guess) {
             auto findbest = [&]() {
                 int bf = 0, bs = -1;
                 float bd = EVM_INF;
+                if (rows_ok) {   // the row's 16 lanes take a face each (+16, +32, ...), a four-step butterfly inside the row finishes
+                    for (int f = lane & 15; f < hi; f += 16) {
+                        const float k = S.fkey[f];
+                        const int q = (int) S.fseq[f];
+                        if (k < EVM_INF && (k < bd || (k == bd && q > bs))) { bf = f; bd = k; bs = q; }
+                    }
+#pragma unroll
+                    for (int st = 0; st < 4; st++) {
+                        const float ok = __int_as_float(gj::dpp_i(__float_as_int(bd), st));
+                        const int oq = gj::dpp_i(bs, st), of = gj::dpp_i(bf, st);
+                        if (ok < bd || (ok == bd && oq > bs)) { bd = ok; bs = oq; bf = of; }
+                    }
+                    return ui(bf);
+                }
                 for (int f0 = 0; f0 < hi; f0 += 8) {     // (unconditional loads, eight in flight: the scan is latency, not work)
                     float k[8];
                     int q[8];
@@ -485,12 +526,15 @@ DEV EpaOut epa_evaluate(Gjk2<GROUP> &gjk, F3 guess) {
             for (; iterations < (unsigned) EPA_MAX_ITER; ++iterations) {
                 if (nextsv < EPA_MAXV) {
                     const int w = nextsv++;
+                    EPA_T0()
                     const gj_f4 bnd = S.fnd[best];
                     const F3 bn = uf3(f3(bnd[0], bnd[1], bnd[2]));
                     const float bdist = uf(bnd[3]);
                     gjk.getsupport(bn, w);
                     const F3 ww = ld3(S.svw[w]);
                     const float wdist = gj::dot(bn, ww) - bdist;
+                    EPA_MARK(gjk.shape.A.ks, 37)
+                    EPA_COUNT(gjk.shape.A.ks, 36, 1)
                     if (ub(wdist > EPA_ACCURACY)) {
                         // visibility of every hull face from w (best counts as visited: its pass is the current one)
                         for (int f = rank; f < hi; f += nact) {
@@ -499,6 +543,7 @@ DEV EpaOut epa_evaluate(Gjk2<GROUP> &gjk, F3 guess) {
                             S.fadj[f] = (S.fadj[f] & 0x3FFFFFFFu) | ((f == best ? 2u : (beyond ? 0u : 1u)) << 30);
                         }
                         EPA_SYNC()
+                        EPA_MARK(gjk.shape.A.ks, 38)
                         // expand(pass, w, best->f[j], best->e[j], horizon), j = 0..2, as one explicit-stack walk
                         bool valid = true;
                         int nh = 0, sp = 0;
@@ -506,11 +551,12 @@ DEV EpaOut epa_evaluate(Gjk2<GROUP> &gjk, F3 guess) {
                         for (int j = 0; j < 3 && valid; j++) {
                             int cf = (int) ((badj >> (8 * j)) & 255u), ce = (int) ((badj >> (24 + 2 * j)) & 3u);
                             bool calling = true, ret = false;
-                            for (;;) {
+                            for (int guard = 0;; guard++) {
+                                if (guard > 8 * EPA_MAXF) { valid = false; break; }   // (cannot happen: every trip visits a face or pops a frame)
                                 if (calling) {
                                     const unsigned adj = (unsigned) ui((int) S.fadj[cf]);
                                     const int vis = (int) (adj >> 30);
-                                    if (vis == 2) ret = false;
+                                    if (vis >= 2) ret = false;
                                     else if (vis == 0) {
                                         if (nstock == 0) ret = false;
                                         else {
@@ -522,7 +568,7 @@ DEV EpaOut epa_evaluate(Gjk2<GROUP> &gjk, F3 guess) {
                                             ret = true;
                                         }
                                     } else {
-                                        S.fadj[cf] = adj | (2u << 30);     // (1 -> 3 would do too: bit 31 = visited)
+                                        S.fadj[cf] = adj | (2u << 30);     // (1 -> 3: bit 31 = visited)
                                         S.frame[sp++] = (unsigned short) (cf | (ce << 8));
                                         const int e1 = (ce + 1) % 3;
                                         cf = (int) ((adj >> (8 * e1)) & 255u); ce = (int) ((adj >> (24 + 2 * e1)) & 3u);
@@ -549,6 +595,7 @@ DEV EpaOut epa_evaluate(Gjk2<GROUP> &gjk, F3 guess) {
                                 }
                             }
                         }
+                        EPA_MARK(gjk.shape.A.ks, 39)
                         if (valid && nh >= 3) {
                             // the horizon's faces, one per lane: newface(f->c[e1], f->c[e], w, false), bind(nf, 0, f, e), the fan's
                             // bind(prev, 1, nf, 2) and the closing bind(last, 1, first, 2)
@@ -572,6 +619,7 @@ DEV EpaOut epa_evaluate(Gjk2<GROUP> &gjk, F3 guess) {
                                 atomicOr(&S.fadj[f], ((unsigned) nf << (8 * e)));
                             }
                             EPA_SYNC()
+                            EPA_MARK(gjk.shape.A.ks, 40)
                             if (ub(S.bad != 0)) { status = 4; break; }   // InvalidHull
                             seq += nh;
                             S.fkey[best] = EVM_INF;                         // remove(m_hull, best); append(m_stock, best)
@@ -579,6 +627,7 @@ DEV EpaOut epa_evaluate(Gjk2<GROUP> &gjk, F3 guess) {
                             best = findbest();
                             outer_nd = S.fnd[best];
                             outer_c = S.fc[best];
+                            EPA_MARK(gjk.shape.A.ks, 41)
                         } else { status = 4; break; }
                     } else { status = 7; break; }   // AccuraryReached
                 } else { status = 6; break; }       // OutOfVertices
@@ -609,7 +658,7 @@ DEV EpaOut epa_evaluate(Gjk2<GROUP> &gjk, F3 guess) {
     else out.normal = f3(1.f, 0.f, 0.f);
     out.depth = 0.f;
     out.rank = 1;
-    out.c[0] = EPA_MAXV + ui(S.sc[gjk.current][0]);
+    out.c[0] = EPA_MAXV + gjk.slot(0);
     out.p[0] = 1.f;
     return out;
 }
@@ -617,12 +666,17 @@ DEV EpaOut epa_evaluate(Gjk2<GROUP> &gjk, F3 guess) {
 // btGjkEpaPenetrationDepthSolver::calcPenDepth for ONE query whose transforms every lane holds (wave-uniform values).
 // A.o / B.o unused: oA, oB are the origins (already shifted by the detector's positionOffset).  Returns Penetration()'s verdict;
 // has_v: m_cachedSeparatingAxis was set.
-// (not inlined: its register allocation — and whatever it spills — stays out of the GJK loop of the common path)
+#ifndef EPA_CALL
+#define EPA_CALL DEV
+#endif
 template <bool GROUP>
-__device__ __noinline__ bool calc_pen_depth(const Shape &A, F3 oA, const Shape &B, F3 oB, F3 &v, F3 &wa, F3 &wb, bool &has_v) {
+EPA_CALL bool calc_pen_depth(const Shape &A, F3 oA, const Shape &B, F3 oB, F3 &v, F3 &wa, F3 &wb, bool &has_v) {
     has_v = false;
     v = f3(0.f, 0.f, 0.f); wa = f3(0.f, 0.f, 0.f); wb = f3(0.f, 0.f, 0.f);
+    __builtin_amdgcn_s_setprio(3);   // the kernel's longest dependent chain: first in line at its SIMD's issue (lowered again by the caller)
+    EPA_COUNT(A.ks, 32, 1)
     for (int gi = 0; gi < 9; gi++) {
+        EPA_COUNT(A.ks, 42, 1)
         F3 guess;
         if (gi < 2) {   // (B - A).safeNormalize(), (A - B).safeNormalize()
             const F3 d = gi == 0 ? gj::sub(oB, oA) : gj::sub(oA, oB);
@@ -636,9 +690,12 @@ __device__ __noinline__ bool calc_pen_depth(const Shape &A, F3 oA, const Shape &
         {   // btGjkEpaSolver2::Penetration
             const Mink<GROUP> shape = mink_init<GROUP>(A, oA, B, oB, true);
             Gjk2<GROUP> gjk;
+            EPA_T0()
             const int st = gjk.evaluate(shape, gj::neg(guess));
+            EPA_MARK(A.ks, 34)
             if (st == 1) {
                 const EpaOut e = epa_evaluate<GROUP>(gjk, gj::neg(guess));
+                EPA_MARK(A.ks, 35)
                 if (e.status != 9) {
                     F3 w0 = f3(0.f, 0.f, 0.f);
                     for (int i = 0; i < e.rank; ++i) w0 = gj::add(w0, gj::scl(shape.support0(ld3(g_epa.svd[e.c[i]])), e.p[i]));
@@ -656,10 +713,9 @@ __device__ __noinline__ bool calc_pen_depth(const Shape &A, F3 oA, const Shape &
             const int st = gjk.evaluate(shape, guess);
             if (st == 0) {
                 F3 w0 = f3(0.f, 0.f, 0.f), w1 = f3(0.f, 0.f, 0.f);
-                const int s = gjk.current, rank = ui(g_epa.srank[s]);
-                for (int i = 0; i < rank; ++i) {
-                    const float p = uf(g_epa.sp[s][i]);
-                    const F3 d = ld3(g_epa.svd[EPA_MAXV + ui(g_epa.sc[s][i])]);
+                for (int i = 0; i < gjk.rank; ++i) {
+                    const float p = gjk.P(i);
+                    const F3 d = gjk.Dslot(gjk.slot(i));
                     w0 = gj::add(w0, gj::scl(shape.support0(d), p));
                     w1 = gj::add(w1, gj::scl(shape.support1(gj::neg(d)), p));
                 }

@@ -562,6 +562,7 @@ DEV Result closest_points(const Shape &A, const Shape &B, float max_dist2, bool 
             F3 sep, tmpA, tmpB;
             bool has_v;
             const bool isValid2 = epa::calc_pen_depth<GROUP>(As, oAs, Bs, oBs, sep, tmpA, tmpB, has_v);
+            __builtin_amdgcn_s_setprio(0);
             const bool mine = GROUP ? (lane >> 4) == (src >> 4) : lane == src;
             if (mine) {
                 out.used_pen = true;

@@ -141,16 +141,26 @@ DEV void member_box(const EvmMemberC &MB, const M33 &R, F3 o, F3 &ctr, F3 &ext) 
 // holds a cached point, is appended to the pair's work list (one atomic per wavefront).  drop: lanes whose env starts a
 // reset with this step (their cached points are discarded: removeRigidBody / addRigidBody).
 // the step's work-list counters (EnvDev::pcount: the copy this step appends to)
-DEV int *pc_cur(const EnvDev &d) { return d.pcount + d.pc_cur * (EVM_MAX_PAIRS + 1); }
-DEV int *pc_next(const EnvDev &d) { return d.pcount + (d.pc_cur ^ 1) * (EVM_MAX_PAIRS + 1); }
+// counters [0, npair) = the pairs' own lists, [npair] = the flat big-hull list, [npair + 1] = the URGENT list (below)
+DEV int *pc_cur(const EnvDev &d) { return d.pcount + d.pc_cur * EVM_PC_STRIDE; }
+DEV int *pc_next(const EnvDev &d) { return d.pcount + (d.pc_cur ^ 1) * EVM_PC_STRIDE; }
+// A (pair, env) whose query went through the penetration-depth solver in the previous step (bit 8 of its manifold count word)
+// will most likely do so again — a pair that interpenetrates is pushed apart over several steps — and such a query is by far
+// the longest thing in the kernel (GJK + EPA + the records).  It goes to a list of its own, stored from the END of blist
+// downwards, which the narrowphase kernel's FIRST blocks work on, one query per wavefront: it then runs beside the whole
+// rest of the kernel instead of starting when some wavefront of 64 other queries happens to find it.
+#define EVM_PMN_DEEP 0x100
+#define EVM_PMN_COUNT(x) ((x) & 0xff)
 
 // Ra, oa / Rb, ob: the two members' world transforms of this step (k_split_pre_a derives them itself: the bodies are being
 // prepared by other waves of the same kernel)
 DEV void pair_broadphase(const Ctx &c, int p, bool drop, const M33 &Ra, F3 oa, const M33 &Rb, F3 ob) {
     const EvmPairC &PC = c_skel.pair[p];
     const int a = PC.a, b = PC.b;
-    int n = PMN(p);
-    if (drop && n > 0) { PMN(p) = 0; n = 0; }
+    const int nraw = PMN(p);
+    int n = EVM_PMN_COUNT(nraw);
+    const bool urgent = !drop && (nraw & EVM_PMN_DEEP) != 0;
+    if (drop && nraw != 0) { PMN(p) = 0; n = 0; }
     F3 ca, ea, cb, eb;
     member_box(c_skel.member[a], Ra, oa, ca, ea);
     member_box(c_skel.member[b], Rb, ob, cb, eb);
@@ -177,7 +187,12 @@ DEV void pair_broadphase(const Ctx &c, int p, bool drop, const M33 &Ra, F3 oa, c
         const bool pending = (c.d.flags[c.env] & EVM_FLAG_PENDING) != 0 || drop;
         if (n == 0 && !pending && gap > reach) near = false;
     }
-    const bool need = n > 0 || near;
+    const bool need_any = n > 0 || near;
+    if (need_any && urgent) {   // (a few per step in the whole batch: one atomic each)
+        const int at = atomicAdd(&pc_cur(c.d)[c_skel.npair + 1], 1);
+        c.d.blist[(size_t) c_skel.npair * c.d.n - 1 - at] = (p << 20) | c.env;
+    }
+    const bool need = need_any && !urgent;
     const unsigned long long m = __ballot(need);
     if (m == 0ull) return;
     const int lane = c.lane & 63, leader = (int) __builtin_ctzll(m);
@@ -216,7 +231,8 @@ DEV void pair_item(const Ctx &c, int p, bool drop, int lds_hull_off = -1) {
     const EvmPairC &PC = c_skel.pair[p];
     const int a = PC.a, b = PC.b;
     const EvmMemberC &MA = c_skel.member[a], &MB = c_skel.member[b];
-    int n = drop ? 0 : PMN(p);
+    const int nraw_in = PMN(p);
+    int n = drop ? 0 : EVM_PMN_COUNT(nraw_in);
     gj::Shape SA, SB;
     SA.hull_off = MA.hull_off; SA.hull_n = MA.hull_n; SB.hull_off = MB.hull_off; SB.hull_n = MB.hull_n;
     SA.lds_hull_off = SB.lds_hull_off = lds_hull_off;
@@ -232,7 +248,7 @@ DEV void pair_item(const Ctx &c, int p, bool drop, int lds_hull_off = -1) {
     member_box(MB, SB.R, SB.o, cb, eb);
     const bool overlap = fabsf(ca.x - cb.x) <= ea.x + eb.x && fabsf(ca.y - cb.y) <= ea.y + eb.y && fabsf(ca.z - cb.z) <= ea.z + eb.z;
     if (!__any(overlap || n > 0)) {
-        if (__any(drop)) PMN(p) = 0;  // n == 0 in every lane here
+        if (__any(drop || nraw_in != 0)) PMN(p) = 0;  // n == 0 in every lane here (and a stale deep flag goes)
         return;
     }
     const float thr = PC.thr;
@@ -335,7 +351,7 @@ DEV void pair_item(const Ctx &c, int p, bool drop, int lds_hull_off = -1) {
 #undef REMOVE2
     const F3 wA[4] = {wA0, wA1, wA2, wA3}, wB[4] = {wB0, wB1, wB2, wB3};
     store_mp2(c, p, 0, p0); store_mp2(c, p, 1, p1); store_mp2(c, p, 2, p2); store_mp2(c, p, 3, p3);
-    PMN(p) = n;
+    PMN(p) = n | (r.used_pen ? EVM_PMN_DEEP : 0);
     KS_MARK(2)
     if (!__any(n > 0)) return;
     if (n > 0 && lead) atomicOr(&c.t.pact[((p >> 5) << 6) + c.lane], 1u << (p & 31));

@@ -11,6 +11,7 @@
 #define EVM_MAX_MUSCLES 20
 #define EVM_MAX_HULL_PTS 1024
 #define EVM_MAX_PAIRS (EVM_MAX_MEMBERS * (EVM_MAX_MEMBERS - 1) / 2)
+#define EVM_PC_STRIDE (EVM_MAX_PAIRS + 2)   // narrowphase work-list counters per copy: the pairs', the big-hull list's, the urgent list's
 
 // per-constraint scratch strides (floats per env)
 // Constraint records in the scratch tile.  A record starts on a multiple of 4 slots and is stored in QUADS: fields

@@ -22,7 +22,7 @@ for k in range(K + 200):
     if k >= 200:
         st = (ctypes.c_ulonglong * (n // 64 * 16))()
         check(lib.evm_env_get_stamps(env._h, st))
-        rows.append(np.array(st, dtype=np.uint64)[:32].astype(np.float64))
+        rows.append(np.array(st, dtype=np.uint64)[:48].astype(np.float64))
 r = np.array(rows)
 for kind, name in ((0, "big-hull waves (4 queries of 16 lanes)"), (1, "small-hull waves (one env per lane)")):
     print("%-40s %7.1f per step, mean %8.0f cycles, longest %8.0f cycles" % (name, r[:, 3 * kind + 1].mean(), (r[:, 3 * kind] / np.maximum(r[:, 3 * kind + 1], 1)).mean(), r[:, 3 * kind + 2].mean()))
@@ -39,3 +39,8 @@ for kind, name in ((0, "big-hull"), (1, "small-hull")):
     it = np.maximum(r[:, 22 + 4 * kind], 1)
     print("%-10s GJK loop trips %.1f per step (%.1f per working wave): supports (Minkowski difference) %.0f, rest of the iteration (simplex, exits) %.0f cycles per trip"
           % (name, it.mean(), (it / np.maximum(r[:, 3 * kind + 1], 1)).mean(), (r[:, 20 + 4 * kind] / it).mean(), (r[:, 21 + 4 * kind] / it).mean()))
+
+c = np.maximum(r[:, 32].sum(), 1)
+print("penetration queries (EPA): %.2f per step, %.2f guess vectors each; per query: its GJK %.0f cycles, EPA %.0f cycles in %.1f rounds" % (r[:, 32].mean(), r[:, 42].sum() / c, r[:, 34].sum() / c, r[:, 35].sum() / c, r[:, 36].sum() / c))
+it = np.maximum(r[:, 36].sum(), 1)
+print("  per EPA round: support point %.0f, visibility of the faces %.0f, horizon walk %.0f, new faces %.0f, findbest %.0f cycles" % tuple(r[:, k].sum() / it for k in (37, 38, 39, 40, 41)))
