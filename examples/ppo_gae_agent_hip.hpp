@@ -41,6 +41,7 @@
 #include <vector>
 
 #include "robot_walk_hip.hpp"
+#include "th_archive.hpp"
 
 namespace evm_adapter {
 
@@ -294,8 +295,11 @@ public:
         episode_steps_meter.add((float) curr_episode_step);
         curr_episode_step = 0;
     }
-    // Checkpoints: flat binary files of this adapter (parameters, Adam moments, step counts).  The reference's .th archives
-    // (saver.h:13-39) are LibTorch's pickle format: evomotion_amd/checkpoint.py reads and writes them for the same trainer.
+    // Checkpoints: the reference's four files (ppo_gae.cpp:192-204 through saver.h:13-39) — actor.th, actor_optimizer.th, critic.th,
+    // critic_optimizer.th — written and read by th_archive.hpp without LibTorch: module archives with the reference's parameter
+    // names (head.0.weight ... sigma.0.bias / critic.0.weight ... critic.6.bias) and torch::optim::Adam archives (format "1.5.0",
+    // one group, step / exp_avg / exp_avg_sq per parameter).  A folder written here loads in the reference's PpoGaeAgent::load
+    // and the other way round (tests/test_checkpoint.py, tests/test_gpu_cxx_loop.py).
     void save(const std::string &folder) override {
         ensure_trainer(1);
         for (int net = 0; net < 2; net++) {
@@ -308,36 +312,34 @@ public:
             }
             int step = 0;
             check(evm_ppo_adam_step(trainer, net, -1, &step));
-            std::ofstream f(folder + (net == 0 ? "/actor.evm" : "/critic.evm"), std::ios::binary);
-            if (!f) throw std::runtime_error("cannot write " + folder);
-            const uint64_t hdr[2] = {(uint64_t) n, (uint64_t) step};
-            f.write(reinterpret_cast<const char *>(hdr), sizeof(hdr));
-            f.write(reinterpret_cast<const char *>(h.data()), sizeof(float) * h.size());
+            const evm_th::Node module = net == 0 ? evm_th::actor_module(S, A, H, h.data()) : evm_th::critic_module(S, H, h.data());
+            evm_th::save(folder + (net == 0 ? "/actor.th" : "/critic.th"), module);
+            evm_th::save(folder + (net == 0 ? "/actor_optimizer.th" : "/critic_optimizer.th"),
+                         evm_th::adam_archive(evm_th::adam_params_of(module, step, h.data() + n, h.data() + 2 * n), learning_rate));
         }
     }
     void load(const std::string &folder) override {  // a missing file -> std::runtime_error (saver.h:33-34)
         ensure_trainer(1);
-        std::vector<std::vector<float>> h(2);
-        int steps[2];
+        std::vector<float> w[2], m[2], v[2];
+        int64_t steps[2];
         for (int net = 0; net < 2; net++) {
             const size_t n = net == 0 ? n_actor : n_critic;
-            std::ifstream f(folder + (net == 0 ? "/actor.evm" : "/critic.evm"), std::ios::binary);
-            uint64_t hdr[2];
-            if (!f || !f.read(reinterpret_cast<char *>(hdr), sizeof(hdr)) || hdr[0] != n) throw std::runtime_error("cannot read " + folder);
-            h[net].resize(3 * n);
-            if (!f.read(reinterpret_cast<char *>(h[net].data()), sizeof(float) * 3 * n)) throw std::runtime_error("short file in " + folder);
-            steps[net] = (int) hdr[1];
+            const evm_th::Node module = evm_th::load(folder + (net == 0 ? "/actor.th" : "/critic.th"));
+            w[net] = evm_th::flat_parameters(module, n, net == 0 ? "actor.th" : "critic.th");
+            std::vector<evm_th::AdamParam> ps = evm_th::adam_params_of(module, 0, nullptr, nullptr);
+            evm_th::adam_from_archive(evm_th::load(folder + (net == 0 ? "/actor_optimizer.th" : "/critic_optimizer.th")), ps);
+            steps[net] = evm_th::flat_adam(ps, m[net], v[net]);
         }
-        set_parameters(std::vector<float>(h[0].begin(), h[0].begin() + n_actor), std::vector<float>(h[1].begin(), h[1].begin() + n_critic));
+        set_parameters(w[0], w[1]);
         for (int net = 0; net < 2; net++) {
             const size_t n = net == 0 ? n_actor : n_critic;
             for (int what = 1; what < 3; what++) {
-                hip_check(hipMemcpyAsync(d_params, h[net].data() + what * n, sizeof(float) * n, hipMemcpyHostToDevice, stream), "upload");
+                hip_check(hipMemcpyAsync(d_params, (what == 1 ? m[net] : v[net]).data(), sizeof(float) * n, hipMemcpyHostToDevice, stream), "upload");
                 check(evm_ppo_copy(trainer, what + 1, net, 1, d_params, stream));
                 hip_check(hipStreamSynchronize(stream), "sync");
             }
             int s = 0;
-            check(evm_ppo_adam_step(trainer, net, steps[net], &s));
+            check(evm_ppo_adam_step(trainer, net, (int) steps[net], &s));
         }
         check(evm_ppo_copy(trainer, 0, 0, 0, d_params, stream));
         check(evm_ppo_copy(trainer, 0, 1, 0, d_params + n_actor, stream));

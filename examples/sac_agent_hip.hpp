@@ -124,6 +124,7 @@ public:
           replay_buffer(replay_buffer_size, seed, (int) state_space.at(0), (int) action_space.at(0)),
           noise((uint32_t) seed ^ 0x5bd1e995u), actor_loss_meter("actor", 64), critic_1_loss_meter("critic_1", 64), critic_2_loss_meter("critic_2", 64),
           entropy_loss_meter("entropy", 64), episode_steps_meter("steps", 64), rewards_meter("rewards", 64) {
+        actor_hidden = actor_hidden_size; critic_hidden = critic_hidden_size;
         check(evm_policy_create(S, A, actor_hidden_size, device, &pol));
         try {
             check(evm_policy_param_counts(pol, &n_actor, &n_critic));
@@ -212,24 +213,25 @@ public:
         episode_steps_meter.add((float) curr_episode_step);
         curr_episode_step = 0;
     }
-    void save(const std::string &folder) override {  // flat binary (the reference's .th archives: evomotion_amd/checkpoint.py)
+    // Checkpoints: the reference's module files (soft_actor_critic.cpp:182-199 through saver.h:13-39), written and read by
+    // th_archive.hpp without LibTorch: actor.th, critic_1.th, target_critic_1.th, critic_2.th, target_critic_2.th, entropy.th with
+    // the reference's parameter names.  The five `*_optimizer.th` files are not written: the optimisers restart after a load()
+    // (the reference's own load() restores three of the five, :201-215).
+    void save(const std::string &folder) override {
         const std::vector<float> p = get_parameters();
-        std::ofstream f(folder + "/sac.evm", std::ios::binary);
-        if (!f) throw std::runtime_error("cannot write " + folder);
-        const uint64_t n = p.size();
-        f.write(reinterpret_cast<const char *>(&n), sizeof(n));
-        f.write(reinterpret_cast<const char *>(p.data()), sizeof(float) * p.size());
+        evm_th::save(folder + "/actor.th", evm_th::actor_module(S, A, actor_hidden, p.data()));
+        const char *names[4] = {"/critic_1.th", "/critic_2.th", "/target_critic_1.th", "/target_critic_2.th"};
+        for (int i = 0; i < 4; i++) evm_th::save(folder + names[i], evm_th::q_module(S, A, critic_hidden, p.data() + n_actor + i * n_q));
+        evm_th::save(folder + "/entropy.th", evm_th::entropy_module(&p[n_actor + 4 * n_q], 1));
     }
-    void load(const std::string &folder) override {  // weights only: the optimisers restart (a missing file -> std::runtime_error)
-        std::ifstream f(folder + "/sac.evm", std::ios::binary);
-        uint64_t n = 0;
-        if (!f || !f.read(reinterpret_cast<char *>(&n), sizeof(n)) || n != n_actor + 4 * n_q + 1) throw std::runtime_error("cannot read " + folder);
-        std::vector<float> p(n);
-        if (!f.read(reinterpret_cast<char *>(p.data()), sizeof(float) * n)) throw std::runtime_error("short file in " + folder);
+    void load(const std::string &folder) override {  // weights only (a missing file -> std::runtime_error, saver.h:33-34)
+        const std::vector<float> a = evm_th::flat_parameters(evm_th::load(folder + "/actor.th"), n_actor, "actor.th");
+        const char *names[4] = {"/critic_1.th", "/critic_2.th", "/target_critic_1.th", "/target_critic_2.th"};
         std::vector<std::vector<float>> qs;
-        for (int i = 0; i < 4; i++) qs.emplace_back(p.begin() + n_actor + i * n_q, p.begin() + n_actor + (i + 1) * n_q);
-        set_parameters(std::vector<float>(p.begin(), p.begin() + n_actor), qs);
-        hip_check(hipMemcpy(log_alpha, &p[n - 1], sizeof(float), hipMemcpyHostToDevice), "upload");
+        for (int i = 0; i < 4; i++) qs.push_back(evm_th::flat_parameters(evm_th::load(folder + names[i]), n_q, names[i] + 1));
+        const std::vector<float> la = evm_th::flat_parameters(evm_th::load(folder + "/entropy.th"), 1, "entropy.th");
+        set_parameters(a, qs);
+        hip_check(hipMemcpy(log_alpha, la.data(), sizeof(float), hipMemcpyHostToDevice), "upload");
     }
     std::vector<LossMeterHip> get_metrics() override {  // :223-226
         return {actor_loss_meter, critic_1_loss_meter, critic_2_loss_meter, entropy_loss_meter, episode_steps_meter, rewards_meter};
@@ -242,6 +244,7 @@ public:
     long curr_train_step = 0, curr_episode_step = 0, global_curr_step = 0;
     int trained_last_act = 0;
     const int S, A, B;
+    int actor_hidden = 0, critic_hidden = 0;
 
 private:
     static void linear(std::vector<float> &v, std::mt19937 &g, int out, int in) {

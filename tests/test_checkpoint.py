@@ -144,3 +144,117 @@ def test_adam_archives_cross_the_boundary_in_both_directions(tmp_path):
     assert sc["lr"] == pytest.approx(3e-4) and sc["beta1"] == pytest.approx(0.9) and all(sc["step_%d" % i] == 2 for i in range(12))
     np.testing.assert_array_equal(got["exp_avg_0_head"], states[0][1].reshape(-1)[:8].numpy())
     np.testing.assert_array_equal(got["exp_avg_sq_9_head"], states[9][2].reshape(-1)[:8].numpy())
+
+
+# ---- the same files from the torch-free C++ side (examples/th_archive.hpp: what the compiled adapters' save() / load() use) ----
+TH_CHECK = os.path.join(ROOT, "build", "th_check")
+
+
+def _th_check():
+    src = [os.path.join(ROOT, "examples", f) for f in ("th_check.cpp", "th_archive.hpp")]
+    if not os.path.isfile(TH_CHECK) or os.path.getmtime(TH_CHECK) < max(os.path.getmtime(f) for f in src):
+        os.makedirs(os.path.dirname(TH_CHECK), exist_ok=True)
+        subprocess.check_call(["g++", "-std=c++17", "-O2", src[0], "-o", TH_CHECK])     # plain C++: no HIP, no torch
+    return TH_CHECK
+
+
+def _flat(params, shapes):
+    return np.concatenate([params[n].ravel() for n, _ in shapes]).astype(np.float32)
+
+
+def test_cxx_written_archives_are_what_torch_reads(tmp_path):
+    """PpoGaeAgentHip::save (examples/ppo_gae_agent_hip.hpp) writes the reference's files without LibTorch.  What th_archive.hpp
+    writes must be a TorchScript archive with the reference's names, order and bits: torch.jit.load (= the reference's
+    load_torch) reads it, and the Adam archive comes back through load_adam_th with the step, the options and every moment."""
+    th = _th_check()
+    pa, pc = ao.pattern_params(ao.ACTOR_SHAPES, 100), ao.pattern_params(ao.CRITIC_SHAPES, 200)
+    a, _ = pattern_actor()
+    states = _adam_states(a, step=7, seed=3)
+    n = sum(p.numel() for p in a.parameters())
+    _flat(pa, ao.ACTOR_SHAPES).tofile(str(tmp_path / "w.bin"))
+    torch.cat([s[1].reshape(-1) for s in states]).numpy().tofile(str(tmp_path / "m.bin"))
+    torch.cat([s[2].reshape(-1) for s in states]).numpy().tofile(str(tmp_path / "v.bin"))
+    subprocess.check_call([th, "write-actor-folder", str(tmp_path), "371", "12", "256", str(tmp_path / "w.bin"), str(tmp_path / "m.bin"),
+                           str(tmp_path / "v.bin"), "7", "0.0003"])
+    sd = load_th(str(tmp_path / "actor.th"))
+    assert list(sd.keys()) == [n_ for n_, _ in ao.ACTOR_SHAPES]
+    assert all(np.array_equal(sd[n_].numpy(), pa[n_]) and sd[n_].dtype == torch.float32 for n_, _ in ao.ACTOR_SHAPES)
+    m = torch.jit.load(str(tmp_path / "actor.th"))
+    assert all(p.requires_grad for p in m.parameters()) and len(list(m.named_modules())) == 14      # head.0-5, mu.0-1, sigma.0-1 + the three containers + root
+    got, opt = load_adam_th(str(tmp_path / "actor_optimizer.th"))
+    assert opt == dict(lr=pytest.approx(3e-4), betas=(0.9, 0.999), eps=pytest.approx(1e-8), weight_decay=0.0, amsgrad=False)
+    assert len(got) == 12 and all(g[0] == 7 and torch.equal(g[1], w[1]) and torch.equal(g[2], w[2]) for g, w in zip(got, states))
+    assert sum(g[1].numel() for g in got) == n
+    # the critic's module file
+    _flat(pc, ao.CRITIC_SHAPES).tofile(str(tmp_path / "c.bin"))
+    subprocess.check_call([th, "write-critic", str(tmp_path / "critic.th"), "371", "256", str(tmp_path / "c.bin")])
+    sdc = load_th(str(tmp_path / "critic.th"))
+    assert list(sdc.keys()) == [n_ for n_, _ in ao.CRITIC_SHAPES] and all(np.array_equal(sdc[n_].numpy(), pc[n_]) for n_, _ in ao.CRITIC_SHAPES)
+    # a step count of 0 = torch::optim::Adam before its first step: no state entries at all
+    subprocess.check_call([th, "write-actor-folder", str(tmp_path), "371", "12", "256", str(tmp_path / "w.bin"), str(tmp_path / "m.bin"),
+                           str(tmp_path / "v.bin"), "0", "0.001"])
+    got0, _ = load_adam_th(str(tmp_path / "actor_optimizer.th"))
+    assert got0 == [None] * 12
+
+
+def test_cxx_reader_reads_what_torch_writes(tmp_path):
+    """... and PpoGaeAgentHip::load: th_archive.hpp's zip + pickle reader on files written by torch.jit.save / save_adam_th."""
+    th = _th_check()
+    a, pa = pattern_actor()
+    states = _adam_states(a, step=5, seed=9)
+    states[4] = None
+    save_th(a, str(tmp_path / "actor.th"))
+    save_adam_th(str(tmp_path / "actor_optimizer.th"), states, lr=2e-3)
+    out = subprocess.run([th, "read-actor-folder", str(tmp_path), "371", "12", "256", str(tmp_path / "o.bin")], capture_output=True, text=True, check=True).stdout
+    assert "step 5" in out and "lr 0.002" in out
+    got = np.fromfile(str(tmp_path / "o.bin"), np.float32)
+    n = sum(p.numel() for p in a.parameters())
+    assert got.size == 3 * n and np.array_equal(got[:n], _flat(pa, ao.ACTOR_SHAPES))
+    m = np.concatenate([(s[1] if s is not None else torch.zeros_like(p)).reshape(-1).numpy() for s, p in zip(states, a.parameters())])
+    v = np.concatenate([(s[2] if s is not None else torch.zeros_like(p)).reshape(-1).numpy() for s, p in zip(states, a.parameters())])
+    assert np.array_equal(got[n:2 * n], m) and np.array_equal(got[2 * n:], v)
+    names = subprocess.run([th, "read", str(tmp_path / "actor.th"), str(tmp_path / "p.bin")], capture_output=True, text=True, check=True).stdout
+    assert [l.split()[0] for l in names.strip().split("\n")] == [n_ for n_, _ in ao.ACTOR_SHAPES]
+    assert names.split("\n")[0] == "head.0.weight 256 371"
+    r = subprocess.run([th, "read", str(tmp_path / "missing.th"), str(tmp_path / "p.bin")], capture_output=True, text=True)
+    assert r.returncode != 0 and "Could not find" in r.stderr          # saver.h:33-34
+
+
+@pytest.mark.skipif(not os.path.isfile(REF_TH), reason="oracle/_ref not built (authoring container only)")
+def test_cxx_archives_cross_the_boundary_to_the_compiled_reference(tmp_path):
+    """what the torch-free adapter writes loads in the reference itself (its load_torch on its ActorModule and
+    on a fresh torch::optim::Adam), and what the reference's save_torch writes is read by the torch-free side."""
+    th = _th_check()
+    pa = ao.pattern_params(ao.ACTOR_SHAPES, 100)
+    a, _ = pattern_actor()
+    states = _adam_states(a, step=2, seed=1)
+    _flat(pa, ao.ACTOR_SHAPES).tofile(str(tmp_path / "w.bin"))
+    torch.cat([s[1].reshape(-1) for s in states]).numpy().tofile(str(tmp_path / "m.bin"))
+    torch.cat([s[2].reshape(-1) for s in states]).numpy().tofile(str(tmp_path / "v.bin"))
+    (tmp_path / "ours").mkdir()
+    subprocess.check_call([th, "write-actor-folder", str(tmp_path / "ours"), "371", "12", "256", str(tmp_path / "w.bin"), str(tmp_path / "m.bin"),
+                           str(tmp_path / "v.bin"), "2", "0.0003"])
+    out = subprocess.run([REF_TH, "load", str(tmp_path / "ours"), "actor.th"], capture_output=True, text=True, check=True).stdout
+    (tmp_path / "o.txt").write_text(out)
+    got, g = golden_io.load(str(tmp_path / "o.txt")), golden_io.load()
+    assert np.array_equal(got["mu"], g["mu"]) and np.array_equal(got["sigma"], g["sigma"])      # the reference's forward on the loaded weights
+    out = subprocess.run([REF_TH, "loadopt", str(tmp_path / "ours"), "actor_optimizer.th"], capture_output=True, text=True, check=True).stdout
+    (tmp_path / "o2.txt").write_text(out)
+    got = golden_io.load(str(tmp_path / "o2.txt"))
+    sc = {l.split()[1]: float(l.split()[2]) for l in out.split("\n") if l.startswith("scalar ")}
+    assert sc["lr"] == pytest.approx(3e-4) and sc["beta1"] == pytest.approx(0.9) and all(sc["step_%d" % i] == 2 for i in range(12))
+    np.testing.assert_array_equal(got["exp_avg_0_head"], states[0][1].reshape(-1)[:8].numpy())
+    np.testing.assert_array_equal(got["exp_avg_sq_9_head"], states[9][2].reshape(-1)[:8].numpy())
+    # the other direction: the reference's own files
+    (tmp_path / "theirs").mkdir()
+    subprocess.run([REF_TH, "saveopt", str(tmp_path / "theirs")], check=True)
+    os.rename(str(tmp_path / "theirs" / "actor_after.th"), str(tmp_path / "theirs" / "actor.th"))
+    out = subprocess.run([th, "read-actor-folder", str(tmp_path / "theirs"), "371", "12", "256", str(tmp_path / "t.bin")], capture_output=True, text=True, check=True).stdout
+    assert "step 2" in out and "lr 0.001" in out
+    theirs = np.fromfile(str(tmp_path / "t.bin"), np.float32)
+    sd = load_th(str(tmp_path / "theirs" / "actor.th"))
+    st, _ = load_adam_th(str(tmp_path / "theirs" / "actor_optimizer.th"))
+    n = theirs.size // 3
+    assert np.array_equal(theirs[:n], np.concatenate([sd[k].numpy().ravel() for k in sd]))
+    assert np.array_equal(theirs[n:2 * n], np.concatenate([s[1].numpy().ravel() for s in st]))
+    assert np.array_equal(theirs[2 * n:], np.concatenate([s[2].numpy().ravel() for s in st]))

@@ -39,7 +39,17 @@ def test_cxx_train_loop_equals_the_python_driven_loop(tmp_path):
     assert line["state_space"] == S and line["action_space"] == A and line["parameters_count"] == 330521
     assert len(line["lengths"]) == episodes and line["steps"] == sum(line["lengths"]) and line["trains"] >= 2
     assert line["metrics"].startswith("Save -1, actor_loss = ") and ", steps = " in line["metrics"]      # the progress bar's text (train.cpp:67-76)
-    assert sorted(os.listdir(os.path.join(out, "save_0"))) == ["actor.evm", "critic.evm"]
+    # agent->save(out / "save_0") (train.cpp:82-85): the reference's four files (ppo_gae.cpp:192-197), written without LibTorch by
+    # examples/th_archive.hpp — torch reads them, names and bits as the final weights the program dumped
+    save0 = os.path.join(out, "save_0")
+    assert sorted(os.listdir(save0)) == ["actor.th", "actor_optimizer.th", "critic.th", "critic_optimizer.th"]
+    from evomotion_amd.checkpoint import load_adam_th, load_th
+    sa, sc = load_th(os.path.join(save0, "actor.th")), load_th(os.path.join(save0, "critic.th"))
+    assert list(sa.keys())[0] == "head.0.weight" and list(sa.keys())[-1] == "sigma.0.bias" and list(sc.keys())[-1] == "critic.6.bias"
+    saved = np.concatenate([t.numpy().ravel() for t in list(sa.values()) + list(sc.values())])
+    assert np.array_equal(saved, got)
+    st_a, opt_a = load_adam_th(os.path.join(save0, "actor_optimizer.th"))
+    assert opt_a["lr"] == pytest.approx(1e-3) and len(st_a) == 12 and all(s_ is not None and s_[0] == line["trains"] * epoch for s_ in st_a)
 
     # ---- the same loop through the Python adapters ----
     env = VecRobotWalk(1, seed=seed, device=0)
