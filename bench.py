@@ -16,14 +16,22 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ALG_BYTES_PER_ENV_STEP = 8300  # SURVEY.md §8(d); breakdown in DESIGN.md
+# Algorithmic bytes of one env physics step, by collision mode (the line must describe the workload that ran):
+#   0 (floor contacts only): SURVEY.md §8(d)'s 8 300 B — body state 2 132 R + 2 132 W, observation history 408 + 408, floor contact
+#     cache 1 664, counters 16, action 48, observation 1 484, reward + done 8;
+#   1 (member-vs-member contacts, the default): + the pair manifolds' cache: 2.75 live pair manifolds per env with about 1.5 points
+#     each (profiles/r4*_pair_stats.txt) = 4.1 points x 13 f32, read and written: + 430 B = 8 730 B.
+ALG_BYTES_PER_ENV_STEP = {0: 8300, 1: 8730}
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 VALU_PEAK_TFLOPS = 157.3       # fp32 vector peak = fp32 matrix peak on this part (MI355X_MICROARCH.md)
 # Algorithmic fp32 FLOP of one env physics step (fma = 2), from the row counts of DESIGN.md §2 — table in DESIGN.md §5:
 # 10 sweeps x (12 hinges x (3 lin + 2 ang rows) + 4 fixed x (3 ang + 3 lin) + 12 sliders x (2 ang + 2 lin + motor)
 # + 24 p2p x 3 rows + ~8 contact points x (normal + friction)) = 149.7 k, row set-up 23.6 k, bodies 8.3 k,
 # hull scans 13.4 k, integration + observation 7.4 k
-ALG_FLOP_PER_ENV_STEP = 202.4e3
+# member-vs-member mode adds: the pair points' rows (4.1 points x (two-body normal 102 + friction 102) x 10 sweeps = 8.4 k) and the
+# narrowphase (per env-step 3.3 box-box queries x 8.4 GJK iterations x (2 x 8 vertices x 6 + about 300 for the simplex) = 11 k and
+# 1.07 foot queries x 9.1 x (459 x 6 + 300) = 29.8 k; profiles/r4*_pair_stats.txt, r4*_kstamps.txt) = 251.6 kFLOP
+ALG_FLOP_PER_ENV_STEP = {0: 202.4e3, 1: 251.6e3}
 POLICY_FLOP_PER_ROW = 654848.0  # actor 333 312 + critic 321 536 GEMM FLOP per act
 # untimed calls after stagger_episodes().  One episode + reset cycle is ~120 calls; 192 calls (rounds 2 and 3) left the driver's
 # 20-step window inside the transient that follows the staggering (do_step_fraction 0.559 there).  A 20-step window is a sample of a
@@ -33,21 +41,26 @@ POLICY_FLOP_PER_ROW = 654848.0  # actor 333 312 + critic 321 5
 PREROLL_CALLS = int(os.environ.get("EVM_BENCH_PREROLL", "2048"))
 
 
+# the PMC profile of THIS build's kernels, per collision mode (profiles/<tag>_traffic.json, written by tools/profile_round.sh +
+# tools/traffic_json.py): named explicitly — the newest file by sort order need not be the current build's
+TRAFFIC_PROFILE = {1: "r4z_traffic.json", 0: "r4z0_traffic.json"}
+
+
 def measured_traffic(n, self_collision=0):
-    """HBM-side bytes per step of the dynamics pipeline, from the newest committed PMC profile of this exact workload
-    (profiles/r*_traffic.json; rocprofv3 cannot run inside the timed bench); None when the batch size or the collision mode
-    differs from the profiled one.  Returns (bytes, file name)."""
-    import glob
-    best = (None, None)
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json"))):
-        try:
-            with open(path) as f:
-                t = json.load(f)
-            if t["envs_per_launch"] == n and int(t.get("self_collision", 0)) == int(self_collision):
-                best = (t["traffic_bytes_per_launch"], os.path.basename(path))
-        except (OSError, KeyError, ValueError):
-            pass
-    return best
+    """HBM-side bytes per step of the dynamics pipeline, from the committed PMC profile of this build and workload
+    (TRAFFIC_PROFILE; rocprofv3 cannot run inside the timed bench); None when the file is missing or the batch size or the
+    collision mode differs from the profiled one.  Returns (bytes, file name)."""
+    name = TRAFFIC_PROFILE.get(int(self_collision))
+    if not name:
+        return (None, None)
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            t = json.load(f)
+        if t["envs_per_launch"] == n and int(t.get("self_collision", 0)) == int(self_collision):
+            return (t["traffic_bytes_per_launch"], name)
+    except (OSError, KeyError, ValueError):
+        pass
+    return (None, None)
 
 
 def host_cores():
@@ -456,7 +469,8 @@ def main():
         sampled_ms = ms_kernel / max(n_launch, 1)   # mean of the individually bracketed steps (every 4th)
         launch_ms = region_ms / max(args.steps if agent is None and sac is None else n_launch, 1) if agent is None and sac is None else sampled_ms
         phys_per_launch = n  # every lane runs one stepSimulation per launch
-        achieved = ALG_BYTES_PER_ENV_STEP * phys_per_launch / (launch_ms * 1e-3) / 1e9
+        alg_bytes, alg_flop = ALG_BYTES_PER_ENV_STEP[int(args.self_collision)], ALG_FLOP_PER_ENV_STEP[int(args.self_collision)]
+        achieved = alg_bytes * phys_per_launch / (launch_ms * 1e-3) / 1e9
         out = {
             "metric": "env-steps/sec on robot_walk @4096 envs/GPU",
             "value": env_steps / elapsed,
@@ -496,17 +510,18 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n, args.self_collision)[0], "traffic_source": measured_traffic(n, args.self_collision)[1],
                 "kernel": ("k_sweeps_g (dominant: the Gauss-Seidel sweeps) + k_split_pre_a / %s: one step" % ("pairs_rec" if args.self_collision else "pre_b") if ms_sweeps > 0 else "k_env_step<7>"),
                 "launch_ms": launch_ms, "sampled_step_ms": sampled_ms, "dominant_kernel_ms": (ms_sweeps / max(n_launch, 1)) if ms_sweeps > 0 else launch_ms,
-                "note": "algorithmic 8300 B per env physics step x %d envs per step; a step is a pipeline of three kernels (setup, records [+ narrowphase with member-vs-member contacts], sweeps + integration) up to "
+                "alg_bytes_per_env_step": alg_bytes,
+                "note": "algorithmic %d B per env physics step (by collision mode, bench.py) x %d envs per step; a step is a pipeline of three kernels (setup, records [+ narrowphase with member-vs-member contacts], sweeps + integration) up to "
                         "8192 envs (launch_ms = all of them, HIP events on the launch stream; dominant_kernel_ms = the Gauss-Seidel "
                         "sweeps kernel alone), one monolithic kernel above; fp32-VALU/latency bound (about 50 FLOP per algorithmic "
                         "byte); traffic = memory-side bytes per step from the committed rocprofv3 PMC passes "
-                        "(traffic_source under profiles/), see DESIGN.md" % n,
+                        "(traffic_source under profiles/), see DESIGN.md" % (alg_bytes, n),
             },
         }
-        valu_tf = ALG_FLOP_PER_ENV_STEP * phys_per_launch / (launch_ms * 1e-3) / 1e12
+        valu_tf = alg_flop * phys_per_launch / (launch_ms * 1e-3) / 1e12
         out["roofline_valu"] = {"bound": "valu", "achieved": valu_tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                                 "frac": valu_tf / VALU_PEAK_TFLOPS, "traffic": None, "launch_ms": launch_ms,
-                                "flop_per_env_step": ALG_FLOP_PER_ENV_STEP,
+                                "flop_per_env_step": alg_flop,
                                 "note": "algorithmic fp32 FLOP of one stepSimulation (row counts of DESIGN.md, fma = 2) x envs per "
                                         "step / the same step time as `roofline`; peak = packed-fp32 VALU peak"}
         if agent is None and sac is None and n_policy:

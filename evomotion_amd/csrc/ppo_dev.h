@@ -36,6 +36,8 @@ struct PpoDev {
     double *gae;    // [3] n, mean, M2 of the raw advantages
     double *gae_part;  // [blocks of 256 envs][3] partial count, sum, M2
     int *step_dev;  // [1] device-side Adam step count of the actor (evm_ppo_actor_apply: SAC's captured update)
+    int dev_count;  // the last evm_ppo_grads took the count of selected transitions from gae[0] (n_selected_global < 0): an EMPTY
+                    // selection then leaves the weights and moments untouched and reports NaN losses (k_ppo_adam, k_ppo_loss_sum)
 };
 
 constexpr int PPO_SK = 64;       // split-K chunks of the weight-gradient GEMMs

@@ -214,6 +214,7 @@ int evm_ppo_grads(EvmPpo *q, size_t rows, const float *d_states, const float *d_
     if (q->timing) (void) hipEventRecord(q->ev0, s);
     const evm::PolicyDev &p = q->policy->dev;
     hipError_t e = hipSuccess;
+    q->dev.dev_count = n_selected_global < 0.0 ? 1 : 0;
     if (!states_unchanged || rows != q->staged_rows) {
         e = evm::launch_ppo_pad(q->dev, rows, d_states, s);
         q->staged_rows = rows;

@@ -553,6 +553,9 @@ __global__ __launch_bounds__(256) void k_ppo_adam(PolicyDev p, PpoDev d, float m
     const PpoNet &B = blockIdx.y == 0 ? d.actor : d.critic;
     const size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
     const float bc1 = blockIdx.y == 0 ? bc1_a : bc1_c, bc2s = blockIdx.y == 0 ? bc2s_a : bc2s_c;
+    // nothing selected on any rank (the merged count lives on the device; the reference returns before it trains,
+    // ppo_gae.cpp:63-66): no step — the moments do not decay, the weights do not drift on residual momentum
+    if (d.dev_count && d.gae[0] < 1.0) return;
     double sq = 0.0;
 #pragma unroll 8
     for (int k = 0; k < PPO_NORM_PARTS; k++) sq += B.normp[k];
@@ -767,7 +770,7 @@ __global__ __launch_bounds__(256) void k_ppo_loss_sum(PpoDev d, int na, int nc) 
             if ((int) threadIdx.x < m) sh[threadIdx.x] += sh[threadIdx.x + m];
             __syncthreads();
         }
-        if (threadIdx.x == 0) d.loss[which] = sh[0];
+        if (threadIdx.x == 0) d.loss[which] = (d.dev_count && d.gae[0] < 1.0) ? (double) __builtin_nanf("") : sh[0];   // an empty update says so
         __syncthreads();
     }
 }

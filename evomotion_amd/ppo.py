@@ -208,8 +208,10 @@ class FusedPpoTrainer:
         them synchronises the stream, so the fast path leaves it None)"""
         T, N = rewards.shape
         adv, ret, n_glob = self.gae(rewards, done_u8, values, next_values, mask_u8, gamma, lam)
-        # nothing selected on any rank: the device-side count makes every gradient zero (and the losses zero); callers train on
-        # batches that hold transitions (check_train, ppo_gae.cpp:63-66), so this is not read back here
+        # nothing selected on any rank: the count stays on the device (no host read here), and there the update turns into a no-op —
+        # zero gradients, k_ppo_adam leaves weights and moments untouched, the losses read NaN — so a caller can see that an update
+        # was empty (VecPpoGaeAgent.update() returns them).  The host-side Adam step counters still advance: the next real step's
+        # bias corrections are one step ahead, which the reference cannot reach (it returns before training, ppo_gae.cpp:63-66)
         S, A = states.shape[-1], actions.shape[-1]
         st, ac, lp = states.reshape(T * N, S), actions.reshape(T * N, A), logp_old.reshape(T * N, A)
         for ep in range(epoch):

@@ -319,3 +319,32 @@ def test_full_size_gradients_are_the_sum_of_their_halves():
     # and the same call twice gives the same bits (fixed reduction order)
     fa2, fc2, _, _ = grads(0, rows)
     assert torch.equal(fa, fa2) and torch.equal(fc, fc2)
+
+
+def test_an_empty_selection_is_a_no_op_that_says_so():
+    """a rollout whose mask selects no transition must not move anything.  The count of selected transitions stays on
+    the device (no host read in the update), so the no-op happens there: after one real update (the Adam moments are non-zero:
+    residual momentum exists) an update with an all-zero mask leaves weights and both moments bit for bit where they were and
+    reports NaN losses; a real update afterwards works as before."""
+    import math
+    import torch
+    from evomotion_amd import agent
+    actor, critic = _modules(seed=3)
+    T, N = 4, 256
+    states, actions, rewards, done, values, next_values, mask = _rollout(T, N, seed=4)
+    f, tr = _trainer(actor, critic, T * N)
+    with torch.no_grad():
+        mu, sigma = actor(states.reshape(T * N, 371))
+        logp = agent.truncated_normal_log_pdf(actions.reshape(T * N, 12), mu, sigma).reshape(T, N, 12)
+    la, lc = tr.train(states, actions, rewards, done, logp, values, next_values, mask, epoch=2, learning_rate=1e-3, **HP)
+    assert math.isfinite(la) and math.isfinite(lc)
+    before = [[tr.vector(w, net).clone() for w in (0, 2, 3)] for net in (0, 1)]
+    assert float(before[0][1].abs().max()) > 0 and float(before[1][2].abs().max()) > 0        # momentum to drift on
+    la0, lc0 = tr.train(states, actions, rewards, done, logp, values, next_values, torch.zeros_like(mask), epoch=3, learning_rate=1e-3, **HP)
+    assert math.isnan(la0) and math.isnan(lc0)
+    after = [[tr.vector(w, net) for w in (0, 2, 3)] for net in (0, 1)]
+    for net in (0, 1):
+        for b, a_ in zip(before[net], after[net]):
+            assert torch.equal(b, a_)
+    la2, lc2 = tr.train(states, actions, rewards, done, logp, values, next_values, mask, epoch=1, learning_rate=1e-3, **HP)
+    assert math.isfinite(la2) and math.isfinite(lc2) and not torch.equal(tr.vector(0, 0), before[0][0])
