@@ -45,7 +45,7 @@ struct EnvDev {
                                     // (largest |delta impulse| of a row in the LAST sweep), fp32 bits (>= 0: integer order)
     int *errs;                      // [0] version waits that timed out (a schedule bug), [1] manifolds left out of a step's contact
                                     // rounds (more than 32 live manifolds or 31 rounds in one env); sticky until cleared;
-                                    // [2] narrowphase queries that went through the penetration-depth solver (a counter, not an error)
+                                    // [2] narrowphase queries that went through the penetration-depth solver, [3] those of them on the urgent list, [4] entries of the urgent list (counters, not errors)
     float *gtile;                   // [n/64][tile_floats] global staging copy of the LDS tile (split pipeline)
     int tile_floats;                // step_lds_bytes / 4
     const EvmGSchedC *gs;           // lane-group sweep schedule (device copy), or null: the 64-env tile sweeps kernel runs

@@ -621,8 +621,8 @@ int evm_env_get_errors(EvmEnv *env, int *h_out, int clear, void *stream) {
 int evm_env_get_pair_counters(EvmEnv *env, int *h_out, int clear, void *stream) {
     if (!env || !h_out) return fail(EVM_E_INVALID, "null argument");
     hipStream_t s = (hipStream_t) stream;
-    HIP_TRY(hipMemcpyAsync(h_out, env->d.errs + 2, sizeof(int), hipMemcpyDeviceToHost, s));
-    if (clear) HIP_TRY(hipMemsetAsync(env->d.errs + 2, 0, sizeof(int), s));
+    HIP_TRY(hipMemcpyAsync(h_out, env->d.errs + 2, 3 * sizeof(int), hipMemcpyDeviceToHost, s));
+    if (clear) HIP_TRY(hipMemsetAsync(env->d.errs + 2, 0, 3 * sizeof(int), s));
     HIP_TRY(hipStreamSynchronize(s));
     return EVM_OK;
 }
@@ -641,7 +641,7 @@ int evm_env_get_stamps(EvmEnv *env, unsigned long long *h_out /* [n_tiles, 16] *
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(h_out, env->d.stamps, (size_t) (env->d.n / 64) * 16 * 8, hipMemcpyDeviceToHost));
 #ifdef EVM_KSTAMPS  // the narrowphase kernel accumulates with atomics: every read starts a new interval
-    const unsigned long long reset[48] = {0, 0, 0, 0, 0, 0, ~0ull, 0};
+    const unsigned long long reset[64] = {0, 0, 0, 0, 0, 0, ~0ull, 0};
     HIP_TRY(hipMemcpy(env->d.stamps, reset, sizeof(reset), hipMemcpyHostToDevice));
 #endif
     return EVM_OK;

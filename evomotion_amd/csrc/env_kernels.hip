@@ -2075,7 +2075,7 @@ __global__ __launch_bounds__(64 * EVM_SPLIT_WAVES) __attribute__((amdgpu_waves_p
 //                                block, pairs in decreasing cost order
 // One launch for both, so that the few long big-hull wavefronts and the many short ones share the chip.
 #define EVM_BIG_BLOCKS 2048
-#define EVM_URGENT_BLOCKS 32   // the launch's first blocks: the urgent list (pairs_dev.h), one query per wavefront
+#define EVM_URGENT_BLOCKS 256   // the launch's first blocks: the urgent list (pairs_dev.h), one query per wavefront
 #ifndef EVM_PAIRS_WAVES
 #define EVM_PAIRS_WAVES 2   // wavefronts per SIMD the narrowphase kernel is compiled for (128 arch VGPRs + AGPR spill space at 2)
 #endif
@@ -2096,6 +2096,9 @@ DEV void narrow_block(const EnvDev &d, int blk, int tiles) {   // blk: block ind
 #endif
     const bool urgent_blk = blk < EVM_URGENT_BLOCKS;
     blk -= EVM_URGENT_BLOCKS;
+#ifdef EVM_KSTAMPS
+    if (threadIdx.x == 0) { gj::epa::g_ust_on = urgent_blk ? 1 : 0; gj::epa::g_ust[0] = __builtin_amdgcn_s_memtime(); }
+#endif
     if (urgent_blk || blk < EVM_BIG_BLOCKS) {
         const int cnt = pc_cur(d)[c_skel.npair + (urgent_blk ? 1 : 0)];
         if (urgent_blk ? blk + EVM_URGENT_BLOCKS >= cnt : blk * 4 >= cnt) return;
@@ -2115,15 +2118,16 @@ DEV void narrow_block(const EnvDev &d, int blk, int tiles) {   // blk: block ind
 #ifdef EVM_KSTAMPS
         if (threadIdx.x == 0) atomicAdd(&d.stamps[16], __builtin_amdgcn_s_memtime() - ks.t0);  // hull staging
 #endif
-        if (urgent_blk) {   // one query per wavefront (row 0; the penetration solver deals its parallel parts to the row's 16 lanes)
+        if (urgent_blk) {   // ONE query per wavefront, carried by all 64 lanes: the penetration solver's parallel parts get the whole wave
             __builtin_amdgcn_s_setprio(2);
             for (int i = blk + EVM_URGENT_BLOCKS; i < cnt; i += EVM_URGENT_BLOCKS) {
-                if (threadIdx.x < 16) {
-                    const int e = d.blist[(size_t) c_skel.npair * d.n - 1 - i], p = e >> 20, env = e & 0xfffff;
-                    const Ctx c = make_ctx_env(d, env);
-                    const bool fin = (MODE & 4) && (d.flags[env] & EVM_FLAG_DONE) != 0;
-                    pair_item<true>(c, p, fin, hoff);
-                }
+#ifdef EVM_KSTAMPS
+                if (threadIdx.x == 0) { gj::epa::g_ust[1] = __builtin_amdgcn_s_memtime(); for (int k = 0; k < 8; k++) gj::epa::g_uph[k] = 0ull; }
+#endif
+                const int e = d.blist[(size_t) c_skel.npair * d.n - 1 - i], p = e >> 20, env = e & 0xfffff;
+                const Ctx c = make_ctx_env(d, env);
+                const bool fin = (MODE & 4) && (d.flags[env] & EVM_FLAG_DONE) != 0;
+                pair_item<true, true>(c, p, fin, hoff);
             }
             return;
         }

@@ -52,6 +52,10 @@ struct State {
     unsigned short frame[EPA_MAXF]; // walk frames f | e << 8 | stage << 10
     unsigned short hz[EPA_MAXF];    // horizon edges in creation order: f | e << 8
     unsigned char hzn[EPA_MAXF];    // ... and the face made for each
+    int sc[2][4];                   // the GJK's two simplices: vertex slots,
+    float sp[2][4];                 //   weights,
+    int srank[2];                   //   ranks
+    int gfree[4];                   // its free vertex slots
     int bad;
 };
 __device__ __shared__ State g_epa;
@@ -90,7 +94,9 @@ struct Mink {
     M33 toshape1, t0b;
     F3 t0o;
     bool margins;
+    bool full;   // every lane of the wavefront is here: the hull scans use all 64 of them
     DEV F3 hull(const Shape &S, F3 d) const {
+        if (full) return gj::support_wave(S.hull_off, S.hull_n, d, GROUP ? A.lds_hull_off : -1);
         return GROUP ? gj::support_group(S.hull_off, S.hull_n, d, A.lds_hull_off) : gj::support(S.hull_off, S.hull_n, d);
     }
     DEV F3 ls(const Shape &S, F3 d) const {
@@ -112,6 +118,7 @@ DEV Mink<GROUP> mink_init(const Shape &A, F3 oA, const Shape &B, F3 oB, bool mar
     m.t0b = tmm(A.R, B.R);
     m.t0o = gj::vmul(gj::sub(oB, oA), A.R);
     m.margins = margins;
+    m.full = __ballot(true) == ~0ull;
     return m;
 }
 
@@ -202,117 +209,114 @@ DEV float project4(F3 a, F3 b, F3 c, F3 d, float *w, unsigned &m) {
     return -1.f;
 }
 
-// The simplex lives in registers (every value is wave-uniform; slot selection by compare-and-select): the four vertices of the
-// store, the current simplex as four packed slot numbers + weights, the free list.  (The original keeps two simplices and flips
-// between them; the next one is only ever built from the current one and then replaces it, so one simplex and a temporary do.)
-// The vertices are also written through to g_epa.svd / svw[EPA_MAXV + slot]: EPA's faces refer to them there.
+// The GJK's simplices, weights and free list live in LDS (g_epa.sc / sp / srank / gfree; every lane reads and writes the same
+// values): kept in registers they cost the kernel 24 more live registers around the call site and the COMMON path of the
+// narrowphase paid for the spills (measured: + 15 us on every launch).
 template <bool GROUP>
 struct Gjk2 {
     Mink<GROUP> shape;
     F3 ray;
-    F3 gw0, gw1, gw2, gw3, gd0, gd1, gd2, gd3;   // store[slot].w / .d
-    unsigned cpk, fpk;                           // simplex vertex slots / free slots, 8 bits each
-    float p0, p1, p2, p3;                        // simplex weights
-    int rank, nfree, status;                     // status: 0 Valid, 1 Inside, 2 Failed
+    int nfree, current, status;   // status: 0 Valid, 1 Inside, 2 Failed
     float distance;
 
-    DEV int slot(int i) const { return (int) ((cpk >> (8 * i)) & 255u); }
-    DEV F3 Wslot(int sl) const { return gj::sel3(sl == 0, gw0, gj::sel3(sl == 1, gw1, gj::sel3(sl == 2, gw2, gw3))); }
-    DEV F3 Dslot(int sl) const { return gj::sel3(sl == 0, gd0, gj::sel3(sl == 1, gd1, gj::sel3(sl == 2, gd2, gd3))); }
-    DEV F3 W(int i) const { return Wslot(slot(i)); }
-    DEV float P(int i) const { return i == 0 ? p0 : (i == 1 ? p1 : (i == 2 ? p2 : p3)); }
-    DEV void setP(int i, float v) { p0 = i == 0 ? v : p0; p1 = i == 1 ? v : p1; p2 = i == 2 ? v : p2; p3 = i == 3 ? v : p3; }
-    // getsupport(d, sv): sv = an EPA vertex id (< EPA_MAXV) or EPA_MAXV + store slot
+    DEV F3 W(int simplex, int i) const { return ld3(g_epa.svw[EPA_MAXV + g_epa.sc[simplex][i]]); }
+    // the final simplex, as the polytope's start and Distance()'s witnesses read it
+    DEV int rk() const { return ui(g_epa.srank[current]); }
+    DEV int slot(int i) const { return ui(g_epa.sc[current][i]); }
+    DEV F3 W(int i) const { return W(current, i); }
+    DEV float P(int i) const { return uf(g_epa.sp[current][i]); }
+    DEV F3 Dslot(int sl) const { return ld3(g_epa.svd[EPA_MAXV + sl]); }
+    DEV void swap01() {
+        const int s = current;
+        const int tc = ui(g_epa.sc[s][0]), tc1 = ui(g_epa.sc[s][1]);
+        const float tp = uf(g_epa.sp[s][0]), tp1 = uf(g_epa.sp[s][1]);
+        g_epa.sc[s][0] = tc1; g_epa.sc[s][1] = tc;
+        g_epa.sp[s][0] = tp1; g_epa.sp[s][1] = tp;
+    }
+    // getsupport(d, store[slot])
     DEV void getsupport(F3 d, int id) {
         const F3 dn = gj::scl(d, 1.0f / flen(d));
         const F3 w = shape.support(dn);
         g_epa.svd[id] = gj_f4{dn.x, dn.y, dn.z, 0.f};
         g_epa.svw[id] = gj_f4{w.x, w.y, w.z, 0.f};
-        if (id >= EPA_MAXV) {
-            const int sl = id - EPA_MAXV;
-            gw0 = gj::sel3(sl == 0, w, gw0); gw1 = gj::sel3(sl == 1, w, gw1); gw2 = gj::sel3(sl == 2, w, gw2); gw3 = gj::sel3(sl == 3, w, gw3);
-            gd0 = gj::sel3(sl == 0, dn, gd0); gd1 = gj::sel3(sl == 1, dn, gd1); gd2 = gj::sel3(sl == 2, dn, gd2); gd3 = gj::sel3(sl == 3, dn, gd3);
-        }
     }
-    DEV void removevertice() {
-        rank--;
-        fpk = (fpk & ~(255u << (8 * nfree))) | ((unsigned) slot(rank) << (8 * nfree));
-        nfree++;
+    DEV void removevertice(int s) {
+        const int r = ui(g_epa.srank[s]) - 1;
+        g_epa.srank[s] = r;
+        g_epa.gfree[nfree++] = ui(g_epa.sc[s][r]);
     }
-    DEV void appendvertice(F3 v) {
-        nfree--;
-        const int sl = (int) ((fpk >> (8 * nfree)) & 255u);
-        setP(rank, 0.f);
-        cpk = (cpk & ~(255u << (8 * rank))) | ((unsigned) sl << (8 * rank));
-        rank++;
-        getsupport(v, EPA_MAXV + sl);
+    DEV void appendvertice(int s, F3 v) {
+        const int r = ui(g_epa.srank[s]);
+        const int slot = ui(g_epa.gfree[--nfree]);
+        g_epa.sp[s][r] = 0.f;
+        g_epa.sc[s][r] = slot;
+        g_epa.srank[s] = r + 1;
+        getsupport(v, EPA_MAXV + slot);
     }
     DEV int evaluate(const Mink<GROUP> &shapearg, F3 guess) {
         unsigned iterations = 0;
         float sqdist = 0.f, alpha = 0.f;
         F3 lw0, lw1, lw2, lw3;
         unsigned clastw = 0;
-        gw0 = gw1 = gw2 = gw3 = gd0 = gd1 = gd2 = gd3 = f3(0.f, 0.f, 0.f);
-        fpk = 0u | (1u << 8) | (2u << 16) | (3u << 24);
+        g_epa.gfree[0] = 0; g_epa.gfree[1] = 1; g_epa.gfree[2] = 2; g_epa.gfree[3] = 3;
         nfree = 4;
-        cpk = 0u; p0 = p1 = p2 = p3 = 0.f; rank = 0;
+        current = 0;
         status = 0;
         shape = shapearg;
         distance = 0.f;
+        g_epa.srank[0] = 0;
         ray = guess;
         const float sqrl = gj::len2(ray);
-        appendvertice(ub(sqrl > 0.f) ? gj::neg(ray) : f3(1.f, 0.f, 0.f));
-        p0 = 1.f;
-        ray = W(0);
+        appendvertice(0, ub(sqrl > 0.f) ? gj::neg(ray) : f3(1.f, 0.f, 0.f));
+        g_epa.sp[0][0] = 1.f;
+        ray = W(0, 0);
         sqdist = sqrl;
         lw0 = lw1 = lw2 = lw3 = ray;
         do {
+            const int next = 1 - current, cs = current;
             const float rl = flen(ray);
             if (ub(rl < EPA_GJK_MIN_DISTANCE)) { status = 1; break; }
-            appendvertice(gj::neg(ray));
-            const F3 w = W(rank - 1);
+            appendvertice(cs, gj::neg(ray));
+            const int rank = ui(g_epa.srank[cs]);
+            const F3 w = W(cs, rank - 1);
             const bool found = gj::len2(gj::sub(w, lw0)) < EPA_GJK_DUP_EPS || gj::len2(gj::sub(w, lw1)) < EPA_GJK_DUP_EPS ||
                                gj::len2(gj::sub(w, lw2)) < EPA_GJK_DUP_EPS || gj::len2(gj::sub(w, lw3)) < EPA_GJK_DUP_EPS;
-            if (ub(found)) { removevertice(); break; }
+            if (ub(found)) { removevertice(cs); break; }
             clastw = (clastw + 1) & 3;
             lw0 = gj::sel3(clastw == 0, w, lw0); lw1 = gj::sel3(clastw == 1, w, lw1);
             lw2 = gj::sel3(clastw == 2, w, lw2); lw3 = gj::sel3(clastw == 3, w, lw3);
             const float omega = gj::dot(ray, w) / rl;
             alpha = omega > alpha ? omega : alpha;
-            if (ub(((rl - alpha) - (EPA_GJK_ACCURACY * rl)) <= 0.f)) { removevertice(); break; }
+            if (ub(((rl - alpha) - (EPA_GJK_ACCURACY * rl)) <= 0.f)) { removevertice(cs); break; }
             float weights[4] = {0.f, 0.f, 0.f, 0.f};
             unsigned mask = 0;
-            if (rank == 2) sqdist = project2(W(0), W(1), weights, mask);
-            else if (rank == 3) sqdist = project3(W(0), W(1), W(2), weights, mask);
-            else sqdist = project4(W(0), W(1), W(2), W(3), weights, mask);
+            if (rank == 2) sqdist = project2(W(cs, 0), W(cs, 1), weights, mask);
+            else if (rank == 3) sqdist = project3(W(cs, 0), W(cs, 1), W(cs, 2), weights, mask);
+            else sqdist = project4(W(cs, 0), W(cs, 1), W(cs, 2), W(cs, 3), weights, mask);
             mask = (unsigned) ui((int) mask);
             if (ub(sqdist >= 0.f)) {
                 int nr = 0;
-                unsigned ncpk = 0u;
-                float np[4] = {0.f, 0.f, 0.f, 0.f};
                 ray = f3(0.f, 0.f, 0.f);
+                current = next;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     if (i < rank) {
-                        const int sl = slot(i);
+                        const int slot = ui(g_epa.sc[cs][i]);
                         if (mask & (1u << i)) {
-                            ncpk |= (unsigned) sl << (8 * nr);
-#pragma unroll
-                            for (int q = 0; q < 4; q++) np[q] = q == nr ? weights[i] : np[q];
+                            g_epa.sc[next][nr] = slot;
+                            g_epa.sp[next][nr] = weights[i];
                             nr++;
-                            ray = gj::add(ray, gj::scl(Wslot(sl), weights[i]));
+                            ray = gj::add(ray, gj::scl(ld3(g_epa.svw[EPA_MAXV + slot]), weights[i]));
                         } else {
-                            fpk = (fpk & ~(255u << (8 * nfree))) | ((unsigned) sl << (8 * nfree));
-                            nfree++;
+                            g_epa.gfree[nfree++] = slot;
                         }
                     }
                 }
-                cpk = ncpk; rank = nr;
-                p0 = np[0]; p1 = np[1]; p2 = np[2]; p3 = np[3];
+                g_epa.srank[next] = nr;
                 ray = uf3(ray);
                 if (mask == 15) status = 1;
             } else {
-                removevertice();
+                removevertice(cs);
                 break;
             }
             status = ((++iterations) < (unsigned) EPA_GJK_MAX_ITER) ? status : 2;
@@ -321,60 +325,74 @@ struct Gjk2 {
         else if (status == 1) distance = 0.f;
         return status;
     }
-    // EncloseOrigin, the recursion unrolled over the simplex rank (1 -> 2 -> 3 -> 4)
+    // EncloseOrigin.  The original recurses over the simplex rank (1 -> 2 -> 3 -> 4), trying at rank 1 the six signed axes, at rank
+    // 2 the cross products of the segment with the axes (both signs, skipped when zero), at rank 3 the two signed triangle normals,
+    // each time appending the support vertex and descending.  The same search as ONE loop with a candidate counter per level and a
+    // single appendvertice site: inlined as nested calls it put 22 copies of the support code into the kernel, and this code runs
+    // once per query — every instruction of it fetched cold.
     DEV bool enclose4() {
-        return ub(fabsf(det3(gj::sub(W(0), W(3)), gj::sub(W(1), W(3)), gj::sub(W(2), W(3)))) > 0.f);
-    }
-    DEV bool enclose3() {
-        const F3 n = gj::cross(gj::sub(W(1), W(0)), gj::sub(W(2), W(0)));
-        if (ub(gj::len2(n) > 0.f)) {
-            appendvertice(n);
-            if (enclose4()) return true;
-            removevertice();
-            appendvertice(gj::neg(n));
-            if (enclose4()) return true;
-            removevertice();
-        }
-        return false;
-    }
-    DEV bool enclose2() {
-        const F3 d = gj::sub(W(1), W(0));
-        for (int i = 0; i < 3; ++i) {
-            const F3 axis = f3(i == 0 ? 1.f : 0.f, i == 1 ? 1.f : 0.f, i == 2 ? 1.f : 0.f);
-            const F3 p = gj::cross(d, axis);
-            if (ub(gj::len2(p) > 0.f)) {
-                appendvertice(p);
-                if (enclose3()) return true;
-                removevertice();
-                appendvertice(gj::neg(p));
-                if (enclose3()) return true;
-                removevertice();
-            }
-        }
-        return false;
-    }
-    DEV bool enclose1() {
-        for (int i = 0; i < 3; ++i) {
-            const F3 axis = f3(i == 0 ? 1.f : 0.f, i == 1 ? 1.f : 0.f, i == 2 ? 1.f : 0.f);
-            appendvertice(axis);
-            if (enclose2()) return true;
-            removevertice();
-            appendvertice(gj::neg(axis));
-            if (enclose2()) return true;
-            removevertice();
-        }
-        return false;
+        const int s = current;
+        return ub(fabsf(det3(gj::sub(W(s, 0), W(s, 3)), gj::sub(W(s, 1), W(s, 3)), gj::sub(W(s, 2), W(s, 3)))) > 0.f);
     }
     DEV bool enclose_origin() {
-        if (rank == 1) return enclose1();
-        if (rank == 2) return enclose2();
-        if (rank == 3) return enclose3();
-        if (rank == 4) return enclose4();
-        return false;
+        const int s = current;
+        const int base = ui(g_epa.srank[s]);
+        int lvl = base, k1 = 0, k2 = 0, k3 = 0;
+        if (lvl < 1 || lvl > 4) return false;
+#pragma nounroll
+        for (;;) {
+            if (lvl == 4) {
+                if (enclose4()) return true;
+                if (base == 4) return false;
+                removevertice(s);
+                lvl = 3;
+                continue;
+            }
+            const int ncand = lvl == 3 ? 2 : 6;
+            int k = lvl == 1 ? k1 : (lvl == 2 ? k2 : k3);
+            bool pushed = false;
+            F3 dir = f3(0.f, 0.f, 0.f);
+#pragma nounroll
+            while (k < ncand && !pushed) {
+                const int c = k++;
+                const int i = c >> 1;
+                const F3 axis = f3(i == 0 ? 1.f : 0.f, i == 1 ? 1.f : 0.f, i == 2 ? 1.f : 0.f);
+                F3 v;
+                if (lvl == 1) v = axis;
+                else if (lvl == 2) v = gj::cross(gj::sub(W(s, 1), W(s, 0)), axis);
+                else v = gj::cross(gj::sub(W(s, 1), W(s, 0)), gj::sub(W(s, 2), W(s, 0)));
+                if (lvl == 1 || ub(gj::len2(v) > 0.f)) { dir = (c & 1) ? gj::neg(v) : v; pushed = true; }
+            }
+            if (lvl == 1) k1 = k; else if (lvl == 2) k2 = k; else k3 = k;
+            if (pushed) {
+                appendvertice(s, dir);
+                lvl++;
+                if (lvl == 2) k2 = 0;
+                if (lvl == 3) k3 = 0;
+                continue;
+            }
+            if (lvl == base) return false;   // this level is exhausted: back to the parent, which takes its vertex away and goes on
+            removevertice(s);
+            lvl--;
+        }
     }
 };
 
 // ---- gjkepa2_impl::EPA ---------------------------------------------------------------------------------------------------
+#ifdef EVM_KSTAMPS
+// the urgent list's blocks (one query per wavefront): s_memtime at the way-points of one query, kept in LDS (no atomics, no waits in
+// between) and flushed by the block when the query did go through the penetration solver: d.stamps[48..] (tools/kstamps.py)
+__device__ __shared__ unsigned long long g_ust[12];
+__device__ __shared__ int g_ust_on;
+__device__ __shared__ unsigned long long g_uph[8];   // per EPA round phase, summed over the query's rounds: support, visibility, walk, new faces, findbest + reload
+#define UPH_T0() unsigned long long uph_t = __builtin_amdgcn_s_memtime();
+#define UPH(k) { const unsigned long long uph_n = __builtin_amdgcn_s_memtime(); if (::evm::gj::epa::g_ust_on && threadIdx.x == 0) ::evm::gj::epa::g_uph[k] += uph_n - uph_t; uph_t = uph_n; }
+#define UST(k) { if (::evm::gj::epa::g_ust_on && threadIdx.x == 0) ::evm::gj::epa::g_ust[k] = __builtin_amdgcn_s_memtime(); }
+#else
+#define UST(k)
+#define UPH_T0()
+#define UPH(k)
+#endif
 #ifdef EVM_KSTAMPS   // (tools/kstamps.py) where a penetration query's cycles go: d.stamps[32..]
 #define EPA_T0() unsigned long long epa_t = __builtin_amdgcn_s_memtime();
 #define EPA_MARK(KS, k)                                                                    \
@@ -451,7 +469,7 @@ DEV EpaOut epa_evaluate(Gjk2<GROUP> &gjk, F3 guess) {
     // the one-query-per-lane form): findbest may then reduce across a row with DPP
     const bool rows_ok = (((act & 0xFFFFull) == 0ull) || ((act & 0xFFFFull) == 0xFFFFull)) && ((((act >> 16) & 0xFFFFull) == 0ull) || (((act >> 16) & 0xFFFFull) == 0xFFFFull)) &&
                          ((((act >> 32) & 0xFFFFull) == 0ull) || (((act >> 32) & 0xFFFFull) == 0xFFFFull)) && ((((act >> 48) & 0xFFFFull) == 0ull) || (((act >> 48) & 0xFFFFull) == 0xFFFFull));
-    if (gjk.rank > 1 && gjk.enclose_origin()) {
+    if (gjk.rk() > 1 && gjk.enclose_origin()) {
         // stock = every face, root = face 0; hull empty
         for (int i = rank; i < EPA_MAXF; i += nact) { S.stock[i] = (unsigned char) (EPA_MAXF - 1 - i); S.fkey[i] = EVM_INF; }
         EPA_SYNC()
@@ -459,24 +477,22 @@ DEV EpaOut epa_evaluate(Gjk2<GROUP> &gjk, F3 guess) {
         int nextsv = 0;
         // orient the simplex
         if (ub(det3(gj::sub(gjk.W(0), gjk.W(3)), gj::sub(gjk.W(1), gjk.W(3)), gj::sub(gjk.W(2), gjk.W(3))) < 0.f)) {
-            const unsigned c0 = gjk.cpk & 255u, c1 = (gjk.cpk >> 8) & 255u;
-            gjk.cpk = (gjk.cpk & 0xFFFF0000u) | c1 | (c0 << 8);
-            const float tp = gjk.p0; gjk.p0 = gjk.p1; gjk.p1 = tp;
+            gjk.swap01();
         }
         const int g0 = EPA_MAXV + gjk.slot(0), g1 = EPA_MAXV + gjk.slot(1), g2 = EPA_MAXV + gjk.slot(2), g3 = EPA_MAXV + gjk.slot(3);
-        const int ta[4] = {g0, g1, g2, g0}, tb[4] = {g1, g0, g1, g2}, tcv[4] = {g2, g3, g3, g3};
         int tetra[4] = {-1, -1, -1, -1};
-#pragma unroll
-        for (int k = 0; k < 4; k++) {   // newface(a, b, c, forced = true)
+#pragma nounroll
+        for (int k = 0; k < 4; k++) {   // newface(a, b, c, forced = true): (g0 g1 g2) (g1 g0 g3) (g2 g1 g3) (g0 g2 g3)
+            const int va = k == 0 ? g0 : (k == 1 ? g1 : (k == 2 ? g2 : g0)), vb = k == 0 ? g1 : (k == 1 ? g0 : (k == 2 ? g1 : g2)), vc = k == 0 ? g2 : g3;
             const int fi = ui(S.stock[nstock - 1]);
-            const NewFace nf = face_geometry(ld3(S.svw[ta[k]]), ld3(S.svw[tb[k]]), ld3(S.svw[tcv[k]]), true);
+            const NewFace nf = face_geometry(ld3(S.svw[va]), ld3(S.svw[vb]), ld3(S.svw[vc]), true);
             if (ub(nf.ok)) {
                 nstock--;
                 S.fnd[fi] = gj_f4{nf.n.x, nf.n.y, nf.n.z, nf.d};
-                S.fc[fi] = (unsigned) ta[k] | ((unsigned) tb[k] << 8) | ((unsigned) tcv[k] << 16);
+                S.fc[fi] = (unsigned) va | ((unsigned) vb << 8) | ((unsigned) vc << 16);
                 S.fseq[fi] = (unsigned short) seq++;
                 S.fkey[fi] = nf.d * nf.d;
-                tetra[k] = fi;
+                tetra[0] = k == 0 ? fi : tetra[0]; tetra[1] = k == 1 ? fi : tetra[1]; tetra[2] = k == 2 ? fi : tetra[2]; tetra[3] = k == 3 ? fi : tetra[3];
                 nhull++;
                 hi = fi + 1 > hi ? fi + 1 : hi;
             }
@@ -487,10 +503,48 @@ DEV EpaOut epa_evaluate(Gjk2<GROUP> &gjk, F3 guess) {
             S.fadj[tetra[1]] = (unsigned) tetra[0] | ((unsigned) tetra[3] << 8) | ((unsigned) tetra[2] << 16) | (0u << 24) | (2u << 26) | (1u << 28);
             S.fadj[tetra[2]] = (unsigned) tetra[0] | ((unsigned) tetra[1] << 8) | ((unsigned) tetra[3] << 16) | (1u << 24) | (2u << 26) | (1u << 28);
             S.fadj[tetra[3]] = (unsigned) tetra[0] | ((unsigned) tetra[2] << 8) | ((unsigned) tetra[1] << 16) | (2u << 24) | (2u << 26) | (1u << 28);
+            // FULL wavefront (the urgent list's blocks; a full wave of the other forms): face f < 64 also lives in lane f's registers —
+            // normal, distance, adjacency, key, sequence number — re-read from LDS (the authoritative copy: every write below goes
+            // through to it) after every batch of new faces.  Visibility then is a ballot (two scalar masks), the horizon walk reads a
+            // face's adjacency with v_readlane and runs on the scalar unit, findbest is a reduction over the lanes: none of them
+            // touches LDS.  A polytope that grows past 64 faces simply goes on with the LDS forms below.
+            bool regs = act == ~0ull;
+            F3 rn = f3(0.f, 0.f, 0.f);
+            float rd = 0.f, rkey = EVM_INF;
+            unsigned radj = 0u;
+            int rseq = -1;
+            auto reload = [&]() {
+                if (!regs) return;
+                if (hi > 64) { regs = false; return; }
+                const gj_f4 nd = S.fnd[lane];
+                rn = f3(nd[0], nd[1], nd[2]); rd = nd[3];
+                radj = S.fadj[lane];
+                rkey = lane < hi ? S.fkey[lane] : EVM_INF;
+                rseq = (int) S.fseq[lane];
+            };
+            reload();
             // findbest: smallest d^2, the most recently appended face on a tie
             auto findbest = [&]() {
                 int bf = 0, bs = -1;
                 float bd = EVM_INF;
+                if (regs) {
+                    bf = lane; bd = rkey; bs = rkey < EVM_INF ? rseq : -1;
+#pragma unroll
+                    for (int st = 0; st < 4; st++) {
+                        const float ok = __int_as_float(gj::dpp_i(__float_as_int(bd), st));
+                        const int oq = gj::dpp_i(bs, st), of = gj::dpp_i(bf, st);
+                        if (ok < bd || (ok == bd && oq > bs)) { bd = ok; bs = oq; bf = of; }
+                    }
+                    float wd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bd), 0));
+                    int ws = __builtin_amdgcn_readlane(bs, 0), wf = __builtin_amdgcn_readlane(bf, 0);
+#pragma unroll
+                    for (int r = 1; r < 4; r++) {
+                        const float ok = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bd), 16 * r));
+                        const int oq = __builtin_amdgcn_readlane(bs, 16 * r), of = __builtin_amdgcn_readlane(bf, 16 * r);
+                        if (ok < wd || (ok == wd && oq > ws)) { wd = ok; ws = oq; wf = of; }
+                    }
+                    return wf;
+                }
                 if (rows_ok) {   // the row's 16 lanes take a face each (+16, +32, ...), a four-step butterfly inside the row finishes
                     for (int f = lane & 15; f < hi; f += 16) {
                         const float k = S.fkey[f];
@@ -526,24 +580,37 @@ DEV EpaOut epa_evaluate(Gjk2<GROUP> &gjk, F3 guess) {
             for (; iterations < (unsigned) EPA_MAX_ITER; ++iterations) {
                 if (nextsv < EPA_MAXV) {
                     const int w = nextsv++;
-                    EPA_T0()
-                    const gj_f4 bnd = S.fnd[best];
-                    const F3 bn = uf3(f3(bnd[0], bnd[1], bnd[2]));
-                    const float bdist = uf(bnd[3]);
+                    UPH_T0()
+                    F3 bn;
+                    float bdist;
+                    if (regs) {
+                        auto rl = [&](float x) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), best)); };
+                        bn = f3(rl(rn.x), rl(rn.y), rl(rn.z)); bdist = rl(rd);
+                    } else {
+                        const gj_f4 bnd = S.fnd[best];
+                        bn = uf3(f3(bnd[0], bnd[1], bnd[2]));
+                        bdist = uf(bnd[3]);
+                    }
                     gjk.getsupport(bn, w);
                     const F3 ww = ld3(S.svw[w]);
                     const float wdist = gj::dot(bn, ww) - bdist;
-                    EPA_MARK(gjk.shape.A.ks, 37)
+                    UPH(0)
                     EPA_COUNT(gjk.shape.A.ks, 36, 1)
                     if (ub(wdist > EPA_ACCURACY)) {
                         // visibility of every hull face from w (best counts as visited: its pass is the current one)
+                        unsigned long long vmask = 0ull, dmask = 0ull;   // register form: faces visible from w / visited in this round
+                        if (regs) {
+                            const bool beyond = (gj::dot(rn, ww) - rd) < -EPA_PLANE_EPS;
+                            vmask = __ballot(rkey < EVM_INF && !beyond);
+                            dmask = 1ull << best;
+                        } else
                         for (int f = rank; f < hi; f += nact) {
                             const gj_f4 nd = S.fnd[f];
                             const bool beyond = (gj::dot(f3(nd[0], nd[1], nd[2]), ww) - nd[3]) < -EPA_PLANE_EPS;
                             S.fadj[f] = (S.fadj[f] & 0x3FFFFFFFu) | ((f == best ? 2u : (beyond ? 0u : 1u)) << 30);
                         }
                         EPA_SYNC()
-                        EPA_MARK(gjk.shape.A.ks, 38)
+                        UPH(1)
                         // expand(pass, w, best->f[j], best->e[j], horizon), j = 0..2, as one explicit-stack walk
                         bool valid = true;
                         int nh = 0, sp = 0;
@@ -554,8 +621,8 @@ DEV EpaOut epa_evaluate(Gjk2<GROUP> &gjk, F3 guess) {
                             for (int guard = 0;; guard++) {
                                 if (guard > 8 * EPA_MAXF) { valid = false; break; }   // (cannot happen: every trip visits a face or pops a frame)
                                 if (calling) {
-                                    const unsigned adj = (unsigned) ui((int) S.fadj[cf]);
-                                    const int vis = (int) (adj >> 30);
+                                    const unsigned adj = regs ? (unsigned) __builtin_amdgcn_readlane((int) radj, cf) : (unsigned) ui((int) S.fadj[cf]);
+                                    const int vis = regs ? (((dmask >> cf) & 1ull) ? 2 : (int) ((vmask >> cf) & 1ull)) : (int) (adj >> 30);
                                     if (vis >= 2) ret = false;
                                     else if (vis == 0) {
                                         if (nstock == 0) ret = false;
@@ -568,7 +635,8 @@ DEV EpaOut epa_evaluate(Gjk2<GROUP> &gjk, F3 guess) {
                                             ret = true;
                                         }
                                     } else {
-                                        S.fadj[cf] = adj | (2u << 30);     // (1 -> 3: bit 31 = visited)
+                                        if (regs) dmask |= 1ull << cf;
+                                        else S.fadj[cf] = adj | (2u << 30);     // (1 -> 3: bit 31 = visited)
                                         S.frame[sp++] = (unsigned short) (cf | (ce << 8));
                                         const int e1 = (ce + 1) % 3;
                                         cf = (int) ((adj >> (8 * e1)) & 255u); ce = (int) ((adj >> (24 + 2 * e1)) & 3u);
@@ -583,19 +651,20 @@ DEV EpaOut epa_evaluate(Gjk2<GROUP> &gjk, F3 guess) {
                                 const int f = fr & 255, e = (fr >> 8) & 3, stage = fr >> 10;
                                 if (stage == 0) {
                                     S.frame[sp - 1] = (unsigned short) (fr | (1 << 10));
-                                    const unsigned adj = (unsigned) ui((int) S.fadj[f]);
+                                    const unsigned adj = regs ? (unsigned) __builtin_amdgcn_readlane((int) radj, f) : (unsigned) ui((int) S.fadj[f]);
                                     const int e2 = (e + 2) % 3;
                                     cf = (int) ((adj >> (8 * e2)) & 255u); ce = (int) ((adj >> (24 + 2 * e2)) & 3u);
                                     calling = true;
                                 } else {
                                     sp--;
                                     S.fkey[f] = EVM_INF;                // remove(m_hull, f); append(m_stock, f)
+                                    if (regs && lane == f) rkey = EVM_INF;
                                     S.stock[nstock++] = (unsigned char) f;
                                     ret = true;
                                 }
                             }
                         }
-                        EPA_MARK(gjk.shape.A.ks, 39)
+                        UPH(2)
                         if (valid && nh >= 3) {
                             // the horizon's faces, one per lane: newface(f->c[e1], f->c[e], w, false), bind(nf, 0, f, e), the fan's
                             // bind(prev, 1, nf, 2) and the closing bind(last, 1, first, 2)
@@ -619,15 +688,16 @@ DEV EpaOut epa_evaluate(Gjk2<GROUP> &gjk, F3 guess) {
                                 atomicOr(&S.fadj[f], ((unsigned) nf << (8 * e)));
                             }
                             EPA_SYNC()
-                            EPA_MARK(gjk.shape.A.ks, 40)
+                            UPH(3)
                             if (ub(S.bad != 0)) { status = 4; break; }   // InvalidHull
                             seq += nh;
                             S.fkey[best] = EVM_INF;                         // remove(m_hull, best); append(m_stock, best)
                             S.stock[nstock++] = (unsigned char) best;
+                            reload();
                             best = findbest();
                             outer_nd = S.fnd[best];
                             outer_c = S.fc[best];
-                            EPA_MARK(gjk.shape.A.ks, 41)
+                            UPH(4)
                         } else { status = 4; break; }
                     } else { status = 7; break; }   // AccuraryReached
                 } else { status = 6; break; }       // OutOfVertices
@@ -675,6 +745,7 @@ EPA_CALL bool calc_pen_depth(const Shape &A, F3 oA, const Shape &B, F3 oB, F3 &v
     v = f3(0.f, 0.f, 0.f); wa = f3(0.f, 0.f, 0.f); wb = f3(0.f, 0.f, 0.f);
     __builtin_amdgcn_s_setprio(3);   // the kernel's longest dependent chain: first in line at its SIMD's issue (lowered again by the caller)
     EPA_COUNT(A.ks, 32, 1)
+#pragma nounroll
     for (int gi = 0; gi < 9; gi++) {
         EPA_COUNT(A.ks, 42, 1)
         F3 guess;
@@ -687,33 +758,35 @@ EPA_CALL bool calc_pen_depth(const Shape &A, F3 oA, const Shape &B, F3 oB, F3 &v
             guess = f3((k == 2 || k == 3 || k == 4 || k == 6) ? 1.f : 0.f, (k == 1 || k == 3 || k == 4 || k == 5) ? 1.f : 0.f,
                        (k == 0 || k == 4 || k == 5 || k == 6) ? 1.f : 0.f);
         }
-        {   // btGjkEpaSolver2::Penetration
-            const Mink<GROUP> shape = mink_init<GROUP>(A, oA, B, oB, true);
+#pragma nounroll
+        for (int phase = 0; phase < 2; phase++) {   // 0: btGjkEpaSolver2::Penetration (margins), 1: ::Distance (cores) — one evaluate() site
+            const Mink<GROUP> shape = mink_init<GROUP>(A, oA, B, oB, phase == 0);
             Gjk2<GROUP> gjk;
             EPA_T0()
-            const int st = gjk.evaluate(shape, gj::neg(guess));
-            EPA_MARK(A.ks, 34)
-            if (st == 1) {
-                const EpaOut e = epa_evaluate<GROUP>(gjk, gj::neg(guess));
-                EPA_MARK(A.ks, 35)
-                if (e.status != 9) {
-                    F3 w0 = f3(0.f, 0.f, 0.f);
-                    for (int i = 0; i < e.rank; ++i) w0 = gj::add(w0, gj::scl(shape.support0(ld3(g_epa.svd[e.c[i]])), e.p[i]));
-                    wa = gj::xform(A.R, oA, w0);
-                    wb = gj::xform(A.R, oA, gj::sub(w0, gj::scl(e.normal, e.depth)));
-                    v = gj::neg(e.normal);
-                    has_v = true;
-                    return true;
+            const int st = gjk.evaluate(shape, phase == 0 ? gj::neg(guess) : guess);
+            if (phase == 0) {
+                EPA_MARK(A.ks, 34)
+                if (gi == 0) { UST(4) }
+                if (st == 1) {
+                    const EpaOut e = epa_evaluate<GROUP>(gjk, gj::neg(guess));
+                    EPA_MARK(A.ks, 35)
+                    UST(5)
+                    if (e.status != 9) {
+                        F3 w0 = f3(0.f, 0.f, 0.f);
+#pragma nounroll
+                        for (int i = 0; i < e.rank; ++i) w0 = gj::add(w0, gj::scl(shape.support0(ld3(g_epa.svd[e.c[i]])), e.p[i]));
+                        wa = gj::xform(A.R, oA, w0);
+                        wb = gj::xform(A.R, oA, gj::sub(w0, gj::scl(e.normal, e.depth)));
+                        v = gj::neg(e.normal);
+                        has_v = true;
+                        return true;
+                    }
                 }
-            }
-        }
-        {   // btGjkEpaSolver2::Distance
-            const Mink<GROUP> shape = mink_init<GROUP>(A, oA, B, oB, false);
-            Gjk2<GROUP> gjk;
-            const int st = gjk.evaluate(shape, guess);
-            if (st == 0) {
+            } else if (st == 0) {
                 F3 w0 = f3(0.f, 0.f, 0.f), w1 = f3(0.f, 0.f, 0.f);
-                for (int i = 0; i < gjk.rank; ++i) {
+                const int grank = gjk.rk();
+#pragma nounroll
+                for (int i = 0; i < grank; ++i) {
                     const float p = gjk.P(i);
                     const F3 d = gjk.Dslot(gjk.slot(i));
                     w0 = gj::add(w0, gj::scl(shape.support0(d), p));
@@ -730,6 +803,34 @@ EPA_CALL bool calc_pen_depth(const Shape &A, F3 oA, const Shape &B, F3 oB, F3 &v
         }
     }
     return false;
+}
+
+// The same behind a real call (EPA_NOINLINE): the solver's register allocation, and whatever it spills, then stays out of the
+// narrowphase's common path.  Everything crosses the call by value in registers: no reference parameter, no stack object.
+struct PenOut { float vx, vy, vz, ax, ay, az, bx, by, bz; int flags; };   // flags: bit 0 Penetration()'s verdict, bit 1 v was set
+template <bool GROUP>
+__device__ __attribute__((noinline)) PenOut calc_pen_depth_call(int hoA, int hnA, int hoB, int hnB, int ldsoff, float a0, float a1, float a2, float a3,
+                                                                float a4, float a5, float a6, float a7, float a8, float oax, float oay, float oaz, float b0,
+                                                                float b1, float b2, float b3, float b4, float b5, float b6, float b7, float b8, float obx,
+                                                                float oby, float obz, void *ks) {
+    Shape A, B;
+    A.hull_off = hoA; A.hull_n = hnA; B.hull_off = hoB; B.hull_n = hnB;
+    A.lds_hull_off = B.lds_hull_off = ldsoff;
+    A.R = m33(f3(a0, a1, a2), f3(a3, a4, a5), f3(a6, a7, a8)); B.R = m33(f3(b0, b1, b2), f3(b3, b4, b5), f3(b6, b7, b8));
+    A.o = f3(oax, oay, oaz); B.o = f3(obx, oby, obz);
+    A.pen_count = B.pen_count = nullptr;
+#ifdef EVM_KSTAMPS
+    A.ks = B.ks = (unsigned long long *) ks;
+#else
+    (void) ks;
+#endif
+    F3 v, wa, wb;
+    bool has_v;
+    const bool ok = calc_pen_depth<GROUP>(A, A.o, B, B.o, v, wa, wb, has_v);
+    PenOut o;
+    o.vx = v.x; o.vy = v.y; o.vz = v.z; o.ax = wa.x; o.ay = wa.y; o.az = wa.z; o.bx = wb.x; o.by = wb.y; o.bz = wb.z;
+    o.flags = (ok ? 1 : 0) | (has_v ? 2 : 0);
+    return o;
 }
 
 }  // namespace epa

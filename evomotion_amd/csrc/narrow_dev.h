@@ -146,6 +146,41 @@ DEV F3 support_group(int hull_off, int hull_n, F3 dir, int lds_hull_off) {
     return f3(c_skel.hull[hb], c_skel.hull[hb + 2], c_skel.hull[hb + 4]);
 }
 
+// ... and by a FULL wavefront working on one query (the penetration-depth solver, epa_dev.h): lane l takes vertices l, l + 64, ...;
+// a butterfly inside every 16-lane row, then the four rows' winners (read from their first lanes) meet in wave-uniform registers.
+// First maximum (larger value, lower index on a tie), like support() and support_group().  dir is equal across the wavefront.
+DEV F3 support_wave(int hull_off, int hull_n, F3 dir, int lds_hull_off) {
+    const int lane = (int) (threadIdx.x & 63);
+    float best = -GJ_LARGE;
+    int bi = 0x7fffffff;
+    const bool in_lds = lds_hull_off == -2 || hull_off == lds_hull_off;
+    const gj_f4 *lh = g_lds_hull + (lds_hull_off == -2 ? hull_off : 0);
+    for (int v = lane; v < hull_n; v += 64) {
+        float x, y, z;
+        if (in_lds) { const gj_f4 w = lh[v]; x = w[0]; y = w[1]; z = w[2]; }
+        else { const int g = hull_off + v, hb = 6 * (g >> 1) + (g & 1); x = c_skel.hull[hb]; y = c_skel.hull[hb + 2]; z = c_skel.hull[hb + 4]; }
+        const float d = (dir.x * x + dir.y * y) + dir.z * z;
+        if (d > best) { best = d; bi = v; }
+    }
+#pragma unroll
+    for (int st = 0; st < 4; st++) {
+        const float ob = __int_as_float(dpp_i(__float_as_int(best), st));
+        const int oi = dpp_i(bi, st);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    float wb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(best), 0));
+    int wi = __builtin_amdgcn_readlane(bi, 0);
+#pragma unroll
+    for (int r = 1; r < 4; r++) {
+        const float ob = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(best), 16 * r));
+        const int oi = __builtin_amdgcn_readlane(bi, 16 * r);
+        if (ob > wb || (ob == wb && oi < wi)) { wb = ob; wi = oi; }
+    }
+    if (in_lds) { const gj_f4 w = lh[wi]; return f3(w[0], w[1], w[2]); }
+    const int g = hull_off + wi, hb = 6 * (g >> 1) + (g & 1);
+    return f3(c_skel.hull[hb], c_skel.hull[hb + 2], c_skel.hull[hb + 4]);
+}
+
 // Support vertex of a hull held in LDS for a direction of the lane's own (all lanes read the same vertex at a time: a broadcast
 // read); first maximum in table order like support() — used by the penetration branch of the grouped form
 DEV F3 support_lane_lds(int hull_off, int hull_n, F3 dir) {
@@ -514,10 +549,14 @@ DEV RunOut gjk_run(const Shape &A, F3 oA, const Shape &B, F3 oB, float max_dist2
     return o;
 }
 
+// The penetration solver sits behind a real call (epa::calc_pen_depth_call): inlined, its registers competed with the common path's
+// around the call site and every launch paid for the spills (no-EPA launches 70-80 us -> 85-95 us).
+#define EPA_NOINLINE 1
 #include "epa_dev.h"
 
 // btGjkPairDetector::getClosestPoints for the lanes in `active` (the others return has = false)
-template <bool GROUP>
+// SOLO (grouped form only): all 64 lanes of the wavefront carry the SAME query (the urgent list's blocks, pairs_dev.h)
+template <bool GROUP, bool SOLO = false>
 DEV Result closest_points(const Shape &A, const Shape &B, float max_dist2, bool active) {
     const float marginA = MARGIN_F, marginB = MARGIN_F, margin = marginA + marginB;
     Result out;
@@ -525,6 +564,7 @@ DEV Result closest_points(const Shape &A, const Shape &B, float max_dist2, bool 
     const F3 positionOffset = gj::scl(gj::add(A.o, B.o), 0.5f);
     const F3 oA = gj::sub(A.o, positionOffset), oB = gj::sub(B.o, positionOffset);
     const RunOut r = gjk_run<GROUP>(A, oA, B, oB, max_dist2, active, marginA, marginB);
+    if (SOLO) { UST(3) }
     bool isValid = r.isValid;
     float distance = r.distance;
     F3 normalInB = r.normalInB, pointOnB = r.pointOnB;
@@ -549,6 +589,7 @@ DEV Result closest_points(const Shape &A, const Shape &B, float max_dist2, bool 
         // works on each together — the query's transforms broadcast, the answer handed back to the lane(s) that own it.
         const int lane = (int) (threadIdx.x & 63);
         unsigned long long todo = __ballot(need_pen);
+        if (SOLO) todo &= 1ull;   // (one query in the whole wavefront)
         while (todo) {
             const int src = (int) __builtin_ctzll(todo);
             todo &= GROUP ? ~(0xFFFFull << (src & ~15)) : todo - 1;   // (grouped: the 16 lanes of a row are one query)
@@ -561,12 +602,27 @@ DEV Result closest_points(const Shape &A, const Shape &B, float max_dist2, bool 
             const F3 oAs = bc3(oA), oBs = bc3(oB);
             F3 sep, tmpA, tmpB;
             bool has_v;
+#ifdef EPA_NOINLINE
+#ifdef EVM_KSTAMPS
+            void *const ksp = (void *) A.ks;
+#else
+            void *const ksp = nullptr;
+#endif
+            const epa::PenOut po = epa::calc_pen_depth_call<GROUP>(As.hull_off, As.hull_n, Bs.hull_off, Bs.hull_n, A.lds_hull_off, As.R.r0.x, As.R.r0.y, As.R.r0.z,
+                                                                   As.R.r1.x, As.R.r1.y, As.R.r1.z, As.R.r2.x, As.R.r2.y, As.R.r2.z, oAs.x, oAs.y, oAs.z, Bs.R.r0.x,
+                                                                   Bs.R.r0.y, Bs.R.r0.z, Bs.R.r1.x, Bs.R.r1.y, Bs.R.r1.z, Bs.R.r2.x, Bs.R.r2.y, Bs.R.r2.z, oBs.x,
+                                                                   oBs.y, oBs.z, ksp);
+            sep = f3(po.vx, po.vy, po.vz); tmpA = f3(po.ax, po.ay, po.az); tmpB = f3(po.bx, po.by, po.bz);
+            has_v = (po.flags & 2) != 0;
+            const bool isValid2 = (po.flags & 1) != 0;
+#else
             const bool isValid2 = epa::calc_pen_depth<GROUP>(As, oAs, Bs, oBs, sep, tmpA, tmpB, has_v);
+#endif
             __builtin_amdgcn_s_setprio(0);
-            const bool mine = GROUP ? (lane >> 4) == (src >> 4) : lane == src;
+            const bool mine = SOLO ? true : (GROUP ? (lane >> 4) == (src >> 4) : lane == src);
             if (mine) {
                 out.used_pen = true;
-                if (!GROUP || (lane & 15) == 0) atomicAdd(A.pen_count, 1);
+                if (SOLO ? lane == 0 : (!GROUP || (lane & 15) == 0)) { atomicAdd(A.pen_count, 1); if (SOLO) atomicAdd(A.pen_count + 1, 1); }   // [+1]: ... of them predicted (urgent list)
                 if (has_v && gj::len2(sep) != 0.f) {
                     if (isValid2) {
                         F3 tmpN = gj::sub(tmpB, tmpA);

@@ -150,6 +150,7 @@ DEV int *pc_next(const EnvDev &d) { return d.pcount + (d.pc_cur ^ 1) * EVM_PC_ST
 // downwards, which the narrowphase kernel's FIRST blocks work on, one query per wavefront: it then runs beside the whole
 // rest of the kernel instead of starting when some wavefront of 64 other queries happens to find it.
 #define EVM_PMN_DEEP 0x100
+#define EVM_DEEP_SOON (-0.06f)   // distance (margins subtracted) below which a pair is expected to need the penetration solver next step: cores 2 cm apart
 #define EVM_PMN_COUNT(x) ((x) & 0xff)
 
 // Ra, oa / Rb, ob: the two members' world transforms of this step (k_split_pre_a derives them itself: the bodies are being
@@ -159,7 +160,7 @@ DEV void pair_broadphase(const Ctx &c, int p, bool drop, const M33 &Ra, F3 oa, c
     const int a = PC.a, b = PC.b;
     const int nraw = PMN(p);
     int n = EVM_PMN_COUNT(nraw);
-    const bool urgent = !drop && (nraw & EVM_PMN_DEEP) != 0;
+    bool urgent = !drop && (nraw & EVM_PMN_DEEP) != 0;
     if (drop && nraw != 0) { PMN(p) = 0; n = 0; }
     F3 ca, ea, cb, eb;
     member_box(c_skel.member[a], Ra, oa, ca, ea);
@@ -186,10 +187,15 @@ DEV void pair_broadphase(const Ctx &c, int p, bool drop, const M33 &Ra, F3 oa, c
         gap = fmaxf(gap, fabsf(dot(t, b2)) - hb.z - (ha.x * fabsf(dot(b2, a0)) + ha.y * fabsf(dot(b2, a1)) + ha.z * fabsf(dot(b2, a2))));
         const bool pending = (c.d.flags[c.env] & EVM_FLAG_PENDING) != 0 || drop;
         if (n == 0 && !pending && gap > reach) near = false;
+        // ... and the other end of the same test: core boxes that overlap along all six face normals (a pair that starts out
+        // interpenetrating, typically in the step after a reset, where no history can flag it) will most likely need the
+        // penetration solver: urgent list
+        if (n == 0 && near && gap < 0.f) urgent = true;
     }
     const bool need_any = n > 0 || near;
     if (need_any && urgent) {   // (a few per step in the whole batch: one atomic each)
         const int at = atomicAdd(&pc_cur(c.d)[c_skel.npair + 1], 1);
+        atomicAdd(&c.d.errs[4], 1);
         c.d.blist[(size_t) c_skel.npair * c.d.n - 1 - at] = (p << 20) | c.env;
     }
     const bool need = need_any && !urgent;
@@ -213,9 +219,11 @@ DEV void pair_broadphase(const Ctx &c, int p, bool drop, const M33 &Ra, F3 oa, c
 // one pair for one env per lane (any envs: the narrowphase kernel's compacted work list): narrowphase, manifold
 // maintenance, rows.  drop: as above.  GROUP: the 16 lanes of a row carry the SAME (pair, env) and share the hull scans
 // (every lane computes and stores the same values; lane 0 of the row does the atomics); p may then differ between rows.
-template <bool GROUP>
+// SOLO: all 64 lanes carry the same (pair, env) — the urgent list's blocks: the penetration-depth solver then has the whole
+// wavefront for its parallel parts; every lane stores the same values to the same addresses, lane 0 does the atomics.
+template <bool GROUP, bool SOLO = false>
 DEV void pair_item(const Ctx &c, int p, bool drop, int lds_hull_off = -1) {
-    const bool lead = !GROUP || (threadIdx.x & 15) == 0;
+    const bool lead = SOLO ? threadIdx.x == 0 : (!GROUP || (threadIdx.x & 15) == 0);
 #ifdef EVM_KSTAMPS  // (tools/kstamps.py) cycles of a working wavefront by phase; a mark waits for the outstanding memory traffic first
     unsigned long long ks_prev = __builtin_amdgcn_s_memtime();
 #define KS_MARK(k)                                                                                        \
@@ -258,10 +266,12 @@ DEV void pair_item(const Ctx &c, int p, bool drop, int lds_hull_off = -1) {
     gj::Result r;
     r.has = false; r.distance = 0.f; r.normalOnB = f3(0.f, 0.f, 0.f); r.pointOnB = f3(0.f, 0.f, 0.f); r.iterations = 0; r.used_pen = false;
     const bool any_overlap = __any(overlap);
+    if (SOLO) { UST(2) }
     if (any_overlap) {
         const float md = MARGIN_F + MARGIN_F + thr;
-        r = gj::closest_points<GROUP>(SA, SB, md * md, overlap);
+        r = gj::closest_points<GROUP, SOLO>(SA, SB, md * md, overlap);
     }
+    if (SOLO) { UST(6) }
     KS_MARK(1)
     MPoint2 p0 = load_mp2(c, p, 0), p1 = load_mp2(c, p, 1), p2 = load_mp2(c, p, 2), p3 = load_mp2(c, p, 3);
     if (any_overlap) {
@@ -351,7 +361,9 @@ DEV void pair_item(const Ctx &c, int p, bool drop, int lds_hull_off = -1) {
 #undef REMOVE2
     const F3 wA[4] = {wA0, wA1, wA2, wA3}, wB[4] = {wB0, wB1, wB2, wB3};
     store_mp2(c, p, 0, p0); store_mp2(c, p, 1, p1); store_mp2(c, p, 2, p2); store_mp2(c, p, 3, p3);
-    PMN(p) = n | (r.used_pen ? EVM_PMN_DEEP : 0);
+    // (flagged for the next step's urgent list: it took the penetration branch, or its cores are about to touch)
+    PMN(p) = n | ((r.used_pen || (r.has && r.distance < EVM_DEEP_SOON)) ? EVM_PMN_DEEP : 0);
+    if (SOLO) { UST(7) }
     KS_MARK(2)
     if (!__any(n > 0)) return;
     if (n > 0 && lead) atomicOr(&c.t.pact[((p >> 5) << 6) + c.lane], 1u << (p & 31));
@@ -359,6 +371,17 @@ DEV void pair_item(const Ctx &c, int p, bool drop, int lds_hull_off = -1) {
     F3 nrm[4] = {p0.nb, p1.nb, p2.nb, p3.nb};
     float dist[4] = {p0.dist, p1.dist, p2.dist, p3.dist}, ap[4] = {p0.ap, p1.ap, p2.ap, p3.ap}, apl[4] = {p0.apl, p1.apl, p2.apl, p3.apl};
     contact_record(c, c_skel.nm + p, n, true, A, B, wA, wB, nrm, dist, ap, apl, PC.mu, lead);
+    if (SOLO) {
+        UST(8)
+#ifdef EVM_KSTAMPS
+        __builtin_amdgcn_s_waitcnt(0);
+        if (gj::epa::g_ust_on && threadIdx.x == 0 && r.used_pen) {
+            atomicAdd(&c.d.stamps[47], 1ull);
+            for (int k = 0; k < 8; k++) atomicAdd(&c.d.stamps[48 + k], gj::epa::g_ust[k + 1] - gj::epa::g_ust[k]);
+            for (int k = 0; k < 5; k++) atomicAdd(&c.d.stamps[56 + k], gj::epa::g_uph[k]);
+        }
+#endif
+    }
     KS_MARK(3)
 }
 #undef KS_MARK

@@ -223,8 +223,10 @@ class VecRobotWalk:
 
     def penetration_queries(self, clear=True):
         """narrowphase queries since the last clear that went through the penetration-depth solver (overlapping cores)"""
-        out = (ctypes.c_int * 1)()
+        out = (ctypes.c_int * 3)()
         check(lib.evm_env_get_pair_counters(self._h, out, 1 if clear else 0, self._stream()))
+        self.predicted_penetration_queries = int(out[1])   # ... of which the previous step had predicted (urgent list)
+        self.urgent_entries = int(out[2])                  # entries of the urgent list (predictions, right or wrong)
         return int(out[0])
 
     def stats(self):

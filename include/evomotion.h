@@ -158,8 +158,10 @@ int evm_env_get_residual(EvmEnv *env, float *h_max_delta_impulse, int clear, voi
 int evm_env_get_errors(EvmEnv *env, int *h_out /* [2] */, int clear, void *stream);
 /* Member-vs-member mode: h_out[0] = narrowphase queries since the last clear whose cores overlapped and that went through the
  * penetration-depth solver (Bullet: btGjkEpaPenetrationDepthSolver::calcPenDepth, selected by the btDefaultCollisionConfiguration of
- * evo_motion_model/src/environment.cpp:20-31); every physics step counts, reset()'s settle steps too.  Synchronises `stream`. */
-int evm_env_get_pair_counters(EvmEnv *env, int *h_out /* [1] */, int clear, void *stream);
+ * evo_motion_model/src/environment.cpp:20-31); every physics step counts, reset()'s settle steps too; h_out[1] = how many of them
+ * the previous step had predicted (they were worked on first, one per wavefront), h_out[2] = entries of that urgent list (predictions,
+ * right or wrong).  Synchronises `stream`. */
+int evm_env_get_pair_counters(EvmEnv *env, int *h_out /* [3] */, int clear, void *stream);
 /* Rollout counters since the last clear, summed over envs: h_out[0] = do_step transitions emitted by
  * evm_env_step_autoreset (the reset()'s own step and settle calls are not counted), h_out[1] = resets started. */
 int evm_env_get_stats(EvmEnv *env, long long *h_out /* [2] */);

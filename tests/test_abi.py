@@ -141,3 +141,33 @@ def test_default_params_by_environment_name(hip_lib):
     assert w.initial_remaining_seconds == j.initial_remaining_seconds == 1.0 and w.max_episode_seconds == j.max_episode_seconds == 30.0
     assert hip_lib.lib.evm_env_default_params_for(b"robot_fly", ctypes.byref(x)) == -1  # std::invalid_argument(env_name)
     assert b"robot_fly" in hip_lib.lib.evm_last_error()
+
+
+def test_no_product_path_reaches_the_oracle():
+    """The oracle is test infrastructure: nothing the product ships may import, link or load it.  Checked three ways (the
+    old `hasattr` check proved nothing): (1) no source under evomotion_amd/, examples/ or include/ names it; (2) in bench.py it is
+    imported only inside the functions of the cpu_baseline leg; (3) a fresh interpreter that imports the package has neither the
+    module nor the library loaded."""
+    import ast
+    import subprocess
+    import sys
+    pat = re.compile(r"\bimport\s+orc\b|\bfrom\s+orc\b|liborc|orc_world|orc_narrow|orc_epa|agent_oracle|replay_oracle|oracle/")
+    for top in ("evomotion_amd", "examples", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, top)):
+            for f in files:
+                if f.endswith((".py", ".cpp", ".hpp", ".h", ".hip")):
+                    text = open(os.path.join(dirpath, f), errors="replace").read()
+                    hits = [l for l in text.split("\n") if pat.search(l) and not l.lstrip().startswith(("//", "#", "*"))]
+                    assert not hits, (os.path.join(dirpath, f), hits[:3])
+    tree = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
+    allowed = {"cpu_worker", "cpu_baseline", "pose_parity"}
+    for fn in [n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef)]:
+        imports = [n for n in ast.walk(fn) if isinstance(n, (ast.Import, ast.ImportFrom))]
+        names = {a.name for n in imports for a in n.names} | {n.module for n in imports if isinstance(n, ast.ImportFrom)}
+        if "orc" in names:
+            assert fn.name in allowed, fn.name
+    top_level = [n for n in tree.body if isinstance(n, (ast.Import, ast.ImportFrom))]
+    assert "orc" not in {a.name for n in top_level for a in n.names}
+    code = ("import sys; sys.path.insert(0, %r); import evomotion_amd; m = open('/proc/self/maps').read(); "
+            "assert 'libevomotion_hip.so' in m and 'liborc' not in m and 'orc' not in sys.modules; print('ok')" % ROOT)
+    assert subprocess.check_output([sys.executable, "-c", code]).decode().strip() == "ok"

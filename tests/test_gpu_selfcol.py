@@ -194,6 +194,56 @@ def test_deep_interpenetration_takes_the_penetration_branch(tmp_path, orc_lib, s
     assert env.errors() == (0, 0)
 
 
+@pytest.mark.parametrize("shape_b", ["cube", "feet"])
+def test_deep_pairs_stay_in_step_with_the_oracle_through_the_urgent_list(tmp_path, orc_lib, shape_b):
+    """A pair whose query went through the penetration solver is flagged (bit 8 of its manifold count word) and its next query goes
+    to the narrowphase kernel's urgent list: first blocks of the launch, one query carried by all 64 lanes of a wavefront, EPA's
+    polytope cached in the lanes' registers.  Same results by construction — checked here: the scene of the test above stepped THREE
+    times without touching the state in between (steps 2 and 3 take the urgent list), against the oracle doing the same."""
+    from evomotion_amd import VecRobotWalk
+    sk = write_skeleton(tmp_path / "two_bodies.skel", [dict(name="body", mass=4.0, scale=(0.5, 0.2, 0.5)),
+                                                       dict(name="other", mass=0.5, t=(0.0, 1.0, 0.0), scale=(0.3, 0.25, 0.2), shape=shape_b)])
+    n = 70
+    env = VecRobotWalk(n, seed=1, device=0, parameters={"skeleton_json_path": sk, "self_collision": 1})
+    env.debug_reset_begin()
+    ow = pc.OracleWorld(sk, lib=orc_lib, self_collision=1)
+    tmpl = pc.clean_state(ow, [[0.0, 3000.0, 0.0], [0.0, 3000.0, 0.0]])
+    f = pc.fields(ow)
+    rng = np.random.default_rng(11)
+    S = np.repeat(tmpl[None], n, 0).copy()
+    for i in range(n):
+        b = S[i, f["bodies"]].reshape(ow.nb, 13)
+        d = rng.normal(size=3); d /= np.linalg.norm(d)
+        b[1, 0:3] = b[0, 0:3] + (d * np.array([0.5, 0.25, 0.4]) * rng.uniform(0.0, 0.8)).astype(np.float32)   # deep: stays deep for steps
+        q = rng.normal(size=4); q /= np.linalg.norm(q)
+        b[1, 3:7] = q.astype(np.float32)
+        S[i, f["ms"]] = b[: ow.nm, 0:3].ravel()
+    env.set_state(S)
+    env.penetration_queries()
+    env.debug_physics_steps(3)
+    got = env.get_state()
+    pen_dev = env.penetration_queries()
+    pen_orc = 0
+    worst = dict(pos=0.0, geom=0.0, imp=0.0, count=0)
+    for i in range(n):
+        ow.set_state(S[i])
+        for k in range(3):
+            ow.step(1)
+            pen_orc += ow.e.pair_stats()["penetration_calls"]
+        want = ow.state()
+        pg, pw = got[i, f["pairs"]].reshape(1, 49), want[f["pairs"]].reshape(1, 49)
+        worst["count"] += int(pg[0, 0] != pw[0, 0])
+        if pw[0, 0] > 0 and pg[0, 0] == pw[0, 0]:
+            worst["geom"] = max(worst["geom"], float(np.abs(pg[0, 1:11] - pw[0, 1:11]).max()))
+            worst["imp"] = max(worst["imp"], float(np.abs(pg[0, 11:13] - pw[0, 11:13]).max()))
+        bg, bw = got[i, f["bodies"]].reshape(ow.nb, 13), want[f["bodies"]].reshape(ow.nb, 13)
+        worst["pos"] = max(worst["pos"], float(np.abs(bg[:, 0:3] - bw[:, 0:3]).max()))
+    print("penetration queries over three steps: device %d, oracle %d; worst" % (pen_dev, pen_orc), worst)
+    assert pen_dev == pen_orc and pen_orc >= 2 * n            # the same queries took the branch, most of them in every step
+    assert worst["count"] == 0 and worst["geom"] < 5e-6 and worst["pos"] < 1e-4 and worst["imp"] < 2e-3, worst
+    assert env.errors() == (0, 0)
+
+
 def test_masked_reset_leaves_the_other_envs_untouched(torch_mod):
     """evm_env_reset with a mask steps only the selected envs through reset().  The narrowphase works on lists compacted over the
     whole batch, whose counters are zeroed by one wavefront of the first setup kernel: when the mask excluded that wavefront's

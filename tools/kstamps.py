@@ -22,7 +22,7 @@ for k in range(K + 200):
     if k >= 200:
         st = (ctypes.c_ulonglong * (n // 64 * 16))()
         check(lib.evm_env_get_stamps(env._h, st))
-        rows.append(np.array(st, dtype=np.uint64)[:48].astype(np.float64))
+        rows.append(np.array(st, dtype=np.uint64)[:64].astype(np.float64))
 r = np.array(rows)
 for kind, name in ((0, "big-hull waves (4 queries of 16 lanes)"), (1, "small-hull waves (one env per lane)")):
     print("%-40s %7.1f per step, mean %8.0f cycles, longest %8.0f cycles" % (name, r[:, 3 * kind + 1].mean(), (r[:, 3 * kind] / np.maximum(r[:, 3 * kind + 1], 1)).mean(), r[:, 3 * kind + 2].mean()))
@@ -44,3 +44,12 @@ c = np.maximum(r[:, 32].sum(), 1)
 print("penetration queries (EPA): %.2f per step, %.2f guess vectors each; per query: its GJK %.0f cycles, EPA %.0f cycles in %.1f rounds" % (r[:, 32].mean(), r[:, 42].sum() / c, r[:, 34].sum() / c, r[:, 35].sum() / c, r[:, 36].sum() / c))
 it = np.maximum(r[:, 36].sum(), 1)
 print("  per EPA round: support point %.0f, visibility of the faces %.0f, horizon walk %.0f, new faces %.0f, findbest %.0f cycles" % tuple(r[:, k].sum() / it for k in (37, 38, 39, 40, 41)))
+
+u = np.maximum(r[:, 47].sum(), 1)
+names = ["block start -> entry (hull staging)", "set-up (transforms, boxes)", "Voronoi GJK", "EPA's own GJK", "EPA rounds", "witnesses, normal check", "manifold refresh + stores", "contact record"]
+print("urgent-list queries that took the penetration solver: %.2f per step; cycles of one such query by way-point:" % r[:, 47].mean())
+for k, nm in enumerate(names):
+    print("   %-40s %8.0f" % (nm, r[:, 48 + k].sum() / u))
+print("   %-40s %8.0f" % ("total", r[:, 48:56].sum() / u))
+print("   EPA rounds by phase (sums over the query's rounds): support point %.0f, visibility %.0f, horizon walk %.0f, new faces %.0f, findbest + register reload %.0f"
+      % tuple(r[:, 56 + k].sum() / u for k in range(5)))

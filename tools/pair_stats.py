@@ -56,8 +56,8 @@ for e in range(a.envs):
 R = np.array(R); Rw = R.reshape(-1, 16).max(1)
 print("contact rounds per env: mean %.2f max %d; per 16-env workgroup (max over its envs): mean %.2f max %d" % (R.mean(), R.max(), Rw.mean(), Rw.max()))
 pen = env.penetration_queries(); st = env.stats()
-print("penetration-depth solver (EPA): %d of %.0f queries in %d steps of %d envs = %.2f per step (%.2e of the queries); do_step share of the calls %.2f"
-      % (pen, tot[:, 0].sum(), a.steps, a.envs, pen / a.steps, pen / tot[:, 0].sum(), st["env_steps"] / (a.steps * a.envs)))
+print("penetration-depth solver (EPA): %d of %.0f queries in %d steps of %d envs = %.2f per step (%.2e of the queries), %d of them predicted (urgent list: %d entries in all); do_step share of the calls %.2f"
+      % (pen, tot[:, 0].sum(), a.steps, a.envs, pen / a.steps, pen / tot[:, 0].sum(), env.predicted_penetration_queries, env.urgent_entries, st["env_steps"] / (a.steps * a.envs)))
 print("errors", env.errors())
 if a.trained:
     from evomotion_amd import VecPpoGaeAgent
