@@ -87,6 +87,52 @@ DEV float det3(F3 a, F3 b, F3 c) {
     return a.y * b.z * c.x + a.z * b.x * c.y - a.x * b.z * c.y - a.y * b.x * c.z + a.x * b.y * c.z - a.z * b.y * c.x;
 }
 
+// A small hull held in the registers of a FULL wavefront (a member box: eight vertices, lane l keeps vertex l).  The narrowphase's big-hull
+// wavefronts read their hulls from LDS all the time; under that load an LDS round trip of this wave took ~1 k cycles and the hull
+// scans — two per support point, reading the vertices and then the winner — were 40 % of a penetration query.  From registers
+// a scan is dot products, a DPP butterfly per row, four v_readlane for the rows' winners and three more for the winning vertex.
+struct RegHull {   // a hull of at most 64 vertices: lane l keeps vertex l (n = 0: not in registers, scanned from LDS by support_wave)
+    float x, y, z;
+    int n;
+};
+DEV RegHull reg_hull_load(int hull_off, int hull_n, int lds_hull_off) {
+    RegHull h;
+    h.n = hull_n <= 64 ? hull_n : 0;
+    h.x = h.y = h.z = 0.f;
+    const int v = (int) (threadIdx.x & 63);
+    if (v < h.n) {
+        const bool in_lds = lds_hull_off == -2 || hull_off == lds_hull_off;
+        if (in_lds) { const gj_f4 w = (g_lds_hull + (lds_hull_off == -2 ? hull_off : 0))[v]; h.x = w[0]; h.y = w[1]; h.z = w[2]; }
+        else { const int g = hull_off + v, hb = 6 * (g >> 1) + (g & 1); h.x = c_skel.hull[hb]; h.y = c_skel.hull[hb + 2]; h.z = c_skel.hull[hb + 4]; }
+    }
+    return h;
+}
+// first maximum of dot(dir, vertex) (larger value, lower index on a tie), like support(); dir is equal across the wavefront
+DEV F3 reg_hull_support(const RegHull &h, F3 dir) {
+    const int lane = (int) (threadIdx.x & 63);
+    const float d = (dir.x * h.x + dir.y * h.y) + dir.z * h.z;
+    float best = lane < h.n ? d : -GJ_LARGE;
+    int bi = lane < h.n ? lane : 0x7fffffff;
+#pragma unroll
+    for (int st = 0; st < 4; st++) {
+        const float ob = __int_as_float(gj::dpp_i(__float_as_int(best), st));
+        const int oi = gj::dpp_i(bi, st);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    float wb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(best), 0));
+    int wi = __builtin_amdgcn_readlane(bi, 0);
+    if (h.n > 16) {   // (wave-uniform; a box fits one row)
+#pragma unroll
+        for (int r = 1; r < 4; r++) {
+            const float ob = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(best), 16 * r));
+            const int oi = __builtin_amdgcn_readlane(bi, 16 * r);
+            if (ob > wb || (ob == wb && oi < wi)) { wb = ob; wi = oi; }
+        }
+    }
+    return f3(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(h.x), wi)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h.y), wi)),
+              __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h.z), wi)));
+}
+
 // gjkepa2_impl::MinkowskiDiff, in A's local frame
 template <bool GROUP>
 struct Mink {
@@ -94,31 +140,37 @@ struct Mink {
     M33 toshape1, t0b;
     F3 t0o;
     bool margins;
-    bool full;   // every lane of the wavefront is here: the hull scans use all 64 of them
-    DEV F3 hull(const Shape &S, F3 d) const {
-        if (full) return gj::support_wave(S.hull_off, S.hull_n, d, GROUP ? A.lds_hull_off : -1);
+    bool full;   // every lane of the wavefront is here: both hulls sit in its registers
+    const RegHull *ha, *hb;
+    DEV F3 hull(const Shape &S, bool first, F3 d) const {
+        if (full) {
+            const RegHull &h = first ? *ha : *hb;
+            if (h.n > 0) return reg_hull_support(h, d);
+            return gj::support_wave(S.hull_off, S.hull_n, d, GROUP ? A.lds_hull_off : -1);
+        }
         return GROUP ? gj::support_group(S.hull_off, S.hull_n, d, A.lds_hull_off) : gj::support(S.hull_off, S.hull_n, d);
     }
-    DEV F3 ls(const Shape &S, F3 d) const {
-        if (!margins) return uf3(hull(S, d));
+    DEV F3 ls(const Shape &S, bool first, F3 d) const {
+        if (!margins) return uf3(hull(S, first, d));
         F3 n = d;                                         // btConvexShape::localGetSupportVertexNonVirtual
         if (ub(gj::len2(n) < EVM_EPS * EVM_EPS)) n = f3(-1.f, -1.f, -1.f);
         n = gj::scl(n, 1.0f / flen(n));
-        return gj::add(uf3(hull(S, n)), gj::scl(n, MARGIN_F));
+        return gj::add(uf3(hull(S, first, n)), gj::scl(n, MARGIN_F));
     }
-    DEV F3 support0(F3 d) const { return ls(A, d); }
-    DEV F3 support1(F3 d) const { return gj::xform(t0b, t0o, ls(B, mmul(toshape1, d))); }
+    DEV F3 support0(F3 d) const { return ls(A, true, d); }
+    DEV F3 support1(F3 d) const { return gj::xform(t0b, t0o, ls(B, false, mmul(toshape1, d))); }
     DEV F3 support(F3 d) const { return gj::sub(support0(d), support1(gj::neg(d))); }
 };
 template <bool GROUP>
-DEV Mink<GROUP> mink_init(const Shape &A, F3 oA, const Shape &B, F3 oB, bool margins) {
+DEV Mink<GROUP> mink_init(const Shape &A, F3 oA, const Shape &B, F3 oB, bool margins, const RegHull *ha, const RegHull *hb, bool full) {
     Mink<GROUP> m;
     m.A = A; m.B = B;
     m.toshape1 = tmm(B.R, A.R);
     m.t0b = tmm(A.R, B.R);
     m.t0o = gj::vmul(gj::sub(oB, oA), A.R);
     m.margins = margins;
-    m.full = __ballot(true) == ~0ull;
+    m.full = full;
+    m.ha = ha; m.hb = hb;
     return m;
 }
 
@@ -744,6 +796,10 @@ EPA_CALL bool calc_pen_depth(const Shape &A, F3 oA, const Shape &B, F3 oB, F3 &v
     has_v = false;
     v = f3(0.f, 0.f, 0.f); wa = f3(0.f, 0.f, 0.f); wb = f3(0.f, 0.f, 0.f);
     __builtin_amdgcn_s_setprio(3);   // the kernel's longest dependent chain: first in line at its SIMD's issue (lowered again by the caller)
+    const bool full = __ballot(true) == ~0ull;
+    RegHull ha, hb;
+    ha.n = hb.n = 0;
+    if (full) { ha = reg_hull_load(A.hull_off, A.hull_n, GROUP ? A.lds_hull_off : -1); hb = reg_hull_load(B.hull_off, B.hull_n, GROUP ? A.lds_hull_off : -1); }
     EPA_COUNT(A.ks, 32, 1)
 #pragma nounroll
     for (int gi = 0; gi < 9; gi++) {
@@ -760,7 +816,7 @@ EPA_CALL bool calc_pen_depth(const Shape &A, F3 oA, const Shape &B, F3 oB, F3 &v
         }
 #pragma nounroll
         for (int phase = 0; phase < 2; phase++) {   // 0: btGjkEpaSolver2::Penetration (margins), 1: ::Distance (cores) — one evaluate() site
-            const Mink<GROUP> shape = mink_init<GROUP>(A, oA, B, oB, phase == 0);
+            const Mink<GROUP> shape = mink_init<GROUP>(A, oA, B, oB, phase == 0, &ha, &hb, full);
             Gjk2<GROUP> gjk;
             EPA_T0()
             const int st = gjk.evaluate(shape, phase == 0 ? gj::neg(guess) : guess);
