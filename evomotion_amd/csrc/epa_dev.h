@@ -28,6 +28,22 @@
 
 namespace epa {
 
+#ifdef EVM_KSTAMPS
+// the urgent list's blocks (one query per wavefront): s_memtime at the way-points of one query, kept in LDS (no atomics, no waits in
+// between) and flushed by the block when the query did go through the penetration solver: d.stamps[48..] (tools/kstamps.py)
+__device__ __shared__ unsigned long long g_ust[12];
+__device__ __shared__ int g_ust_on;
+__device__ __shared__ unsigned long long g_uph[8];   // per EPA round phase, summed over the query's rounds: support, visibility, walk, new faces, findbest + reload; [5..7] hull scans of A, of B, scans
+#define UPH_T0() unsigned long long uph_t = __builtin_amdgcn_s_memtime();
+#define UPH(k) { const unsigned long long uph_n = __builtin_amdgcn_s_memtime(); if (::evm::gj::epa::g_ust_on && threadIdx.x == 0) ::evm::gj::epa::g_uph[k] += uph_n - uph_t; uph_t = uph_n; }
+#define UST(k) { if (::evm::gj::epa::g_ust_on && threadIdx.x == 0) ::evm::gj::epa::g_ust[k] = __builtin_amdgcn_s_memtime(); }
+#else
+#define UST(k)
+#define UPH_T0()
+#define UPH(k)
+#endif
+
+
 #define EPA_MAXV 128
 #define EPA_MAXF 256
 #define EPA_NV (EPA_MAXV + 4)   // + the four vertices of the GJK's own store (ids EPA_MAXV..)
@@ -155,7 +171,13 @@ struct Mink {
         F3 n = d;                                         // btConvexShape::localGetSupportVertexNonVirtual
         if (ub(gj::len2(n) < EVM_EPS * EVM_EPS)) n = f3(-1.f, -1.f, -1.f);
         n = gj::scl(n, 1.0f / flen(n));
-        return gj::add(uf3(hull(S, first, n)), gj::scl(n, MARGIN_F));
+        UPH_T0()
+        const F3 hv = uf3(hull(S, first, n));
+#ifdef EVM_KSTAMPS
+        if (first) UPH(5) else UPH(6)
+        if (g_ust_on && threadIdx.x == 0) g_uph[7] += 1ull;
+#endif
+        return gj::add(hv, gj::scl(n, MARGIN_F));
     }
     DEV F3 support0(F3 d) const { return ls(A, true, d); }
     DEV F3 support1(F3 d) const { return gj::xform(t0b, t0o, ls(B, false, mmul(toshape1, d))); }
@@ -431,20 +453,6 @@ struct Gjk2 {
 };
 
 // ---- gjkepa2_impl::EPA ---------------------------------------------------------------------------------------------------
-#ifdef EVM_KSTAMPS
-// the urgent list's blocks (one query per wavefront): s_memtime at the way-points of one query, kept in LDS (no atomics, no waits in
-// between) and flushed by the block when the query did go through the penetration solver: d.stamps[48..] (tools/kstamps.py)
-__device__ __shared__ unsigned long long g_ust[12];
-__device__ __shared__ int g_ust_on;
-__device__ __shared__ unsigned long long g_uph[8];   // per EPA round phase, summed over the query's rounds: support, visibility, walk, new faces, findbest + reload
-#define UPH_T0() unsigned long long uph_t = __builtin_amdgcn_s_memtime();
-#define UPH(k) { const unsigned long long uph_n = __builtin_amdgcn_s_memtime(); if (::evm::gj::epa::g_ust_on && threadIdx.x == 0) ::evm::gj::epa::g_uph[k] += uph_n - uph_t; uph_t = uph_n; }
-#define UST(k) { if (::evm::gj::epa::g_ust_on && threadIdx.x == 0) ::evm::gj::epa::g_ust[k] = __builtin_amdgcn_s_memtime(); }
-#else
-#define UST(k)
-#define UPH_T0()
-#define UPH(k)
-#endif
 #ifdef EVM_KSTAMPS   // (tools/kstamps.py) where a penetration query's cycles go: d.stamps[32..]
 #define EPA_T0() unsigned long long epa_t = __builtin_amdgcn_s_memtime();
 #define EPA_MARK(KS, k)                                                                    \

@@ -155,10 +155,29 @@ DEV F3 support_wave(int hull_off, int hull_n, F3 dir, int lds_hull_off) {
     int bi = 0x7fffffff;
     const bool in_lds = lds_hull_off == -2 || hull_off == lds_hull_off;
     const gj_f4 *lh = g_lds_hull + (lds_hull_off == -2 ? hull_off : 0);
+    if (in_lds) {
+        // four vertices per lane and trip, the next trip's reads in flight while this one's dot products run (a 451-vertex foot:
+        // two trips; one LDS round trip of latency instead of eight)
+        gj_f4 cur[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const int v = 64 * k + lane; cur[k] = lh[v < hull_n ? v : 0]; }
+        for (int v0 = 0; v0 < hull_n; v0 += 256) {   // (hull_n is wave-uniform)
+            gj_f4 nxt[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) { const int v = v0 + 256 + 64 * k + lane; nxt[k] = lh[v < hull_n ? v : 0]; }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int v = v0 + 64 * k + lane;
+                const float d = (dir.x * cur[k][0] + dir.y * cur[k][1]) + dir.z * cur[k][2];
+                if (v < hull_n && d > best) { best = d; bi = v; }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) cur[k] = nxt[k];
+        }
+    } else
     for (int v = lane; v < hull_n; v += 64) {
-        float x, y, z;
-        if (in_lds) { const gj_f4 w = lh[v]; x = w[0]; y = w[1]; z = w[2]; }
-        else { const int g = hull_off + v, hb = 6 * (g >> 1) + (g & 1); x = c_skel.hull[hb]; y = c_skel.hull[hb + 2]; z = c_skel.hull[hb + 4]; }
+        const int g = hull_off + v, hb = 6 * (g >> 1) + (g & 1);
+        const float x = c_skel.hull[hb], y = c_skel.hull[hb + 2], z = c_skel.hull[hb + 4];
         const float d = (dir.x * x + dir.y * y) + dir.z * z;
         if (d > best) { best = d; bi = v; }
     }

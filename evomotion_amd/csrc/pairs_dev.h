@@ -378,7 +378,7 @@ DEV void pair_item(const Ctx &c, int p, bool drop, int lds_hull_off = -1) {
         if (gj::epa::g_ust_on && threadIdx.x == 0 && r.used_pen) {
             atomicAdd(&c.d.stamps[47], 1ull);
             for (int k = 0; k < 8; k++) atomicAdd(&c.d.stamps[48 + k], gj::epa::g_ust[k + 1] - gj::epa::g_ust[k]);
-            for (int k = 0; k < 5; k++) atomicAdd(&c.d.stamps[56 + k], gj::epa::g_uph[k]);
+            for (int k = 0; k < 8; k++) atomicAdd(&c.d.stamps[56 + k], gj::epa::g_uph[k]);
         }
 #endif
     }

@@ -53,3 +53,5 @@ for k, nm in enumerate(names):
 print("   %-40s %8.0f" % ("total", r[:, 48:56].sum() / u))
 print("   EPA rounds by phase (sums over the query's rounds): support point %.0f, visibility %.0f, horizon walk %.0f, new faces %.0f, findbest + register reload %.0f"
       % tuple(r[:, 56 + k].sum() / u for k in range(5)))
+print("   hull scans with margins (EPA's GJK + rounds + witnesses): %.1f per query; %.0f cycles per scan of A's hull, %.0f of B's"
+      % (r[:, 63].sum() / u, 2 * r[:, 61].sum() / max(r[:, 63].sum(), 1), 2 * r[:, 62].sum() / max(r[:, 63].sum(), 1)))
