@@ -66,6 +66,7 @@ def _load():
     lib.evm_env_get_residual.argtypes = [vp, fp, ctypes.c_int, vp]
     lib.evm_env_get_errors.argtypes = [vp, ip, ctypes.c_int, vp]
     lib.evm_env_get_pair_counters.argtypes = [vp, ip, ctypes.c_int, vp]
+    lib.evm_env_get_speculation_counters.argtypes = [vp, ip, ctypes.c_int, vp]
     lib.evm_env_get_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_longlong)]
     lib.evm_env_clear_stats.argtypes = [vp]
     lib.evm_env_get_stamps.argtypes = [vp, ctypes.POINTER(ctypes.c_ulonglong)]

@@ -48,6 +48,11 @@ struct EvmEnv {
     int split;  // -1: by batch size (default), 1: split pipeline, 0: monolithic step kernel (EVM_MONOLITHIC=0/1 forces: A/B runs)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_sweeps;  // timed launches: around the sweeps kernel of the split pipeline
     void *gsched;  // device copy of the lane-group sweep schedule (EvmGSchedC), or null
+    // penetration queries started ahead of time (narrow_dev.h): the slots + the two lists (one allocation), the stream k_speculate runs
+    // on beside the next step's kernels (non-blocking: the legacy default stream must not wait for it), the event it waits for
+    void *spec_mem;
+    hipStream_t spec_stream;
+    hipEvent_t spec_event;
 };
 
 #ifndef EVM_MAX_DEVICES
@@ -167,6 +172,23 @@ int evm_env_create(const char *skeleton_path, int n_envs, int device, uint64_t s
     for (auto &s : segs) { *s.p = base; base += s.count * n * 4; }
     hipEventCreate(&env->ev0);
     hipEventCreate(&env->ev1);
+    env->spec_mem = nullptr; env->spec_stream = nullptr; env->spec_event = nullptr;
+    { const char *ds = getenv("EVM_DEEP_SOON"); env->d.deep_soon = ds ? (float) atof(ds) : EVM_DEEP_SOON_DEFAULT; }   // (scheduling only: A/B runs)
+    {
+        // member-vs-member contacts: the slots and lists of the penetration queries started ahead of time (EVM_SPECULATE=0 turns them
+        // off: A/B runs; the physics is the same bit for bit either way)
+        const char *sp = getenv("EVM_SPECULATE");
+        if (S.self_collision && !(sp && sp[0] == '0')) {
+            const size_t words = (size_t) EVM_SPEC_SLOTS * EVM_SPEC_WORDS + 2 * EVM_SLIST_STRIDE;
+            he = hipMalloc(&env->spec_mem, words * sizeof(int));
+            if (he == hipSuccess) he = hipMemset(env->spec_mem, 0, words * sizeof(int));
+            if (he == hipSuccess) he = hipStreamCreateWithFlags(&env->spec_stream, hipStreamNonBlocking);
+            if (he == hipSuccess) he = hipEventCreateWithFlags(&env->spec_event, hipEventDisableTiming);
+            if (he != hipSuccess) { evm_env_destroy(env); return fail(EVM_E_HIP, std::string("speculation buffers: ") + hipGetErrorString(he)); }
+            env->d.spec = (int *) env->spec_mem;
+            env->d.slist = env->d.spec + (size_t) EVM_SPEC_SLOTS * EVM_SPEC_WORDS;
+        }
+    }
     // Sweeps kernel of the split pipeline: the lane-group kernel (16-env workgroups, joint records resident in LDS) when the
     // skeleton's records fit its LDS image, else the 64-env tile kernel.  EVM_SWEEPS=tile forces the latter, EVM_G_WAVES=1..4
     // sets the waves per 16-env workgroup (A/B runs).
@@ -212,6 +234,8 @@ void evm_env_destroy(EvmEnv *env) {
     if (env->device >= 0 && env->device < EVM_MAX_DEVICES && g_skel_owner[env->device] == env) g_skel_owner[env->device] = nullptr;
     if (env->arena) hipFree(env->arena);
     if (env->gsched) hipFree(env->gsched);
+    if (env->spec_stream) { (void) hipStreamSynchronize(env->spec_stream); (void) hipStreamDestroy(env->spec_stream); (void) hipEventDestroy(env->spec_event); }
+    if (env->spec_mem) hipFree(env->spec_mem);
     (void) hipEventDestroy(env->ev0);
     (void) hipEventDestroy(env->ev1);
     for (auto &pr : env->ev_pairs) { (void) hipEventDestroy(pr.first); (void) hipEventDestroy(pr.second); }
@@ -255,6 +279,13 @@ static int step_launch(EvmEnv *env, int mode, const float *a, float *obs, float 
         HIP_TRY(hipEventRecord(env->ev_pairs[env->ev_used].first, s));
     }
     env->d.pc_cur ^= 1;  // this step's copy of the narrowphase list counters (zeroed by the previous step's first kernel)
+    // the speculation slots' epoch (a slot is valid when its word 0 equals the launch's epoch; memory starts as 0)
+    if (env->d.spec && env->d.spec_epoch >= 0x1ffffff0) {   // ((epoch << 2) | code must stay positive)
+        HIP_TRY(hipStreamSynchronize(env->spec_stream));
+        HIP_TRY(hipMemsetAsync(env->d.spec, 0, (size_t) EVM_SPEC_SLOTS * EVM_SPEC_WORDS * sizeof(int), s));
+        env->d.spec_epoch = 0;
+    }
+    env->d.spec_epoch++;
     HIP_TRY(evm::launch_step(env->d, evm::step_lds_bytes(env->skel.nb, env->skel.nscan), env->split, mode, a, obs, rew, done, valid, mask, s,
                              // every 8th step also brackets its sweeps kernel
                              (sample && env->ev_used % 2 == 0) ? env->ev_sweeps[env->ev_used].first : nullptr,
@@ -264,6 +295,13 @@ static int step_launch(EvmEnv *env, int mode, const float *a, float *obs, float 
         env->ev_used++;
     }
     if (env->timing) env->timed_launches++;
+    if (env->d.spec) {
+        // the next step's flagged penetration queries start now, beside that step's first kernels (k_speculate waits for this step's
+        // last kernel only; nothing waits for it)
+        HIP_TRY(hipEventRecord(env->spec_event, s));
+        HIP_TRY(hipStreamWaitEvent(env->spec_stream, env->spec_event, 0));
+        HIP_TRY(evm::launch_speculate(env->d, env->d.spec_epoch + 1, env->spec_stream));
+    }
     return EVM_OK;
 }
 
@@ -623,6 +661,20 @@ int evm_env_get_pair_counters(EvmEnv *env, int *h_out, int clear, void *stream) 
     hipStream_t s = (hipStream_t) stream;
     HIP_TRY(hipMemcpyAsync(h_out, env->d.errs + 2, 3 * sizeof(int), hipMemcpyDeviceToHost, s));
     if (clear) HIP_TRY(hipMemsetAsync(env->d.errs + 2, 0, 3 * sizeof(int), s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return EVM_OK;
+}
+
+int evm_env_get_speculation_counters(EvmEnv *env, int *h_out, int clear, void *stream) {
+    if (!env || !h_out) return fail(EVM_E_INVALID, "null argument");
+    hipStream_t s = (hipStream_t) stream;
+#ifdef EVM_DIAG_PEN
+    const int nspec = 19;   // + [3..8]: solver queries by origin: reset starting, pending, flagged by the previous step, other with / without cached points; in a settle step
+#else
+    const int nspec = 3;
+#endif
+    HIP_TRY(hipMemcpyAsync(h_out, env->d.errs + 5, nspec * sizeof(int), hipMemcpyDeviceToHost, s));
+    if (clear) HIP_TRY(hipMemsetAsync(env->d.errs + 5, 0, nspec * sizeof(int), s));
     HIP_TRY(hipStreamSynchronize(s));
     return EVM_OK;
 }

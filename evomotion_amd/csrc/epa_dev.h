@@ -517,7 +517,10 @@ DEV NewFace face_geometry(F3 a, F3 b, F3 c, bool forced) {
 }
 
 template <bool GROUP>
-DEV EpaOut epa_evaluate(Gjk2<GROUP> &gjk, F3 guess) {
+// ctl / ctl_epoch (speculative runs, narrow_dev.h: speculate_pen_depth; else null): the word through which the query's owner says, once it
+// knows, whether the answer is wanted — (epoch << 2) | 1: wanted, the wave moves to the front of its SIMD's issue; | 2: not wanted,
+// the expansion stops (status 10).  Read once per round, the load in flight while the round runs.
+DEV EpaOut epa_evaluate(Gjk2<GROUP> &gjk, F3 guess, const int *ctl = nullptr, int ctl_epoch = 0) {
     State &S = g_epa;
     EpaOut out;
     out.status = 9; out.normal = f3(0.f, 0.f, 0.f); out.depth = 0.f; out.rank = 0;
@@ -638,6 +641,13 @@ DEV EpaOut epa_evaluate(Gjk2<GROUP> &gjk, F3 guess) {
             int status = 0;   // Valid
             unsigned iterations = 0;
             for (; iterations < (unsigned) EPA_MAX_ITER; ++iterations) {
+                if (ctl != nullptr) {
+                    const int cw = ui(__hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    if ((cw >> 2) == ctl_epoch) {
+                        if ((cw & 3) == 2) { status = 10; break; }
+                        if ((cw & 3) == 1) __builtin_amdgcn_s_setprio(3);
+                    }
+                }
                 if (nextsv < EPA_MAXV) {
                     const int w = nextsv++;
                     UPH_T0()
@@ -800,10 +810,13 @@ DEV EpaOut epa_evaluate(Gjk2<GROUP> &gjk, F3 guess) {
 #define EPA_CALL DEV
 #endif
 template <bool GROUP>
-EPA_CALL bool calc_pen_depth(const Shape &A, F3 oA, const Shape &B, F3 oB, F3 &v, F3 &wa, F3 &wb, bool &has_v) {
+EPA_CALL bool calc_pen_depth(const Shape &A, F3 oA, const Shape &B, F3 oB, F3 &v, F3 &wa, F3 &wb, bool &has_v, const int *ctl, int ctl_epoch, bool &cancelled) {
     has_v = false;
+    cancelled = false;
     v = f3(0.f, 0.f, 0.f); wa = f3(0.f, 0.f, 0.f); wb = f3(0.f, 0.f, 0.f);
-    __builtin_amdgcn_s_setprio(3);   // the kernel's longest dependent chain: first in line at its SIMD's issue (lowered again by the caller)
+    // the kernel's longest dependent chain: first in line at its SIMD's issue (lowered again by the caller); a speculative run only once
+    // its answer is known to be wanted (epa_evaluate)
+    if (ctl == nullptr) __builtin_amdgcn_s_setprio(3);
     const bool full = __ballot(true) == ~0ull;
     RegHull ha, hb;
     ha.n = hb.n = 0;
@@ -824,6 +837,11 @@ EPA_CALL bool calc_pen_depth(const Shape &A, F3 oA, const Shape &B, F3 oB, F3 &v
         }
 #pragma nounroll
         for (int phase = 0; phase < 2; phase++) {   // 0: btGjkEpaSolver2::Penetration (margins), 1: ::Distance (cores) — one evaluate() site
+            if (ctl != nullptr) {
+                const int cw = ui(__hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                if ((cw >> 2) == ctl_epoch && (cw & 3) == 2) { cancelled = true; return false; }
+                if ((cw >> 2) == ctl_epoch && (cw & 3) == 1) __builtin_amdgcn_s_setprio(3);
+            }
             const Mink<GROUP> shape = mink_init<GROUP>(A, oA, B, oB, phase == 0, &ha, &hb, full);
             Gjk2<GROUP> gjk;
             EPA_T0()
@@ -832,9 +850,10 @@ EPA_CALL bool calc_pen_depth(const Shape &A, F3 oA, const Shape &B, F3 oB, F3 &v
                 EPA_MARK(A.ks, 34)
                 if (gi == 0) { UST(4) }
                 if (st == 1) {
-                    const EpaOut e = epa_evaluate<GROUP>(gjk, gj::neg(guess));
+                    const EpaOut e = epa_evaluate<GROUP>(gjk, gj::neg(guess), ctl, ctl_epoch);
                     EPA_MARK(A.ks, 35)
                     UST(5)
+                    if (e.status == 10) { cancelled = true; return false; }
                     if (e.status != 9) {
                         F3 w0 = f3(0.f, 0.f, 0.f);
 #pragma nounroll
@@ -871,29 +890,30 @@ EPA_CALL bool calc_pen_depth(const Shape &A, F3 oA, const Shape &B, F3 oB, F3 &v
 
 // The same behind a real call (EPA_NOINLINE): the solver's register allocation, and whatever it spills, then stays out of the
 // narrowphase's common path.  Everything crosses the call by value in registers: no reference parameter, no stack object.
-struct PenOut { float vx, vy, vz, ax, ay, az, bx, by, bz; int flags; };   // flags: bit 0 Penetration()'s verdict, bit 1 v was set
+struct PenOut { float vx, vy, vz, ax, ay, az, bx, by, bz; int flags; };   // flags: bit 0 Penetration()'s verdict, bit 1 v was set, bit 2 a speculative run was called off
 template <bool GROUP>
 __device__ __attribute__((noinline)) PenOut calc_pen_depth_call(int hoA, int hnA, int hoB, int hnB, int ldsoff, float a0, float a1, float a2, float a3,
                                                                 float a4, float a5, float a6, float a7, float a8, float oax, float oay, float oaz, float b0,
                                                                 float b1, float b2, float b3, float b4, float b5, float b6, float b7, float b8, float obx,
-                                                                float oby, float obz, void *ks) {
+                                                                float oby, float obz, void *ks, const int *ctl, int ctl_epoch) {
     Shape A, B;
     A.hull_off = hoA; A.hull_n = hnA; B.hull_off = hoB; B.hull_n = hnB;
     A.lds_hull_off = B.lds_hull_off = ldsoff;
     A.R = m33(f3(a0, a1, a2), f3(a3, a4, a5), f3(a6, a7, a8)); B.R = m33(f3(b0, b1, b2), f3(b3, b4, b5), f3(b6, b7, b8));
     A.o = f3(oax, oay, oaz); B.o = f3(obx, oby, obz);
     A.pen_count = B.pen_count = nullptr;
+    A.spec = B.spec = nullptr; A.spec_epoch = B.spec_epoch = 0;
 #ifdef EVM_KSTAMPS
     A.ks = B.ks = (unsigned long long *) ks;
 #else
     (void) ks;
 #endif
     F3 v, wa, wb;
-    bool has_v;
-    const bool ok = calc_pen_depth<GROUP>(A, A.o, B, B.o, v, wa, wb, has_v);
+    bool has_v, cancelled;
+    const bool ok = calc_pen_depth<GROUP>(A, A.o, B, B.o, v, wa, wb, has_v, ctl, ctl_epoch, cancelled);
     PenOut o;
     o.vx = v.x; o.vy = v.y; o.vz = v.z; o.ax = wa.x; o.ay = wa.y; o.az = wa.z; o.bx = wb.x; o.by = wb.y; o.bz = wb.z;
-    o.flags = (ok ? 1 : 0) | (has_v ? 2 : 0);
+    o.flags = (ok ? 1 : 0) | (has_v ? 2 : 0) | (cancelled ? 4 : 0);
     return o;
 }
 

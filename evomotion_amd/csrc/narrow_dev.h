@@ -221,6 +221,8 @@ struct Shape {  // one member's hull and world transform (the basis may be non-o
     M33 R;
     F3 o;
     int *pen_count;    // EnvDev::errs + 2: queries that went through the penetration-depth solver (evm_env_get_pair_counters)
+    int *spec;         // SOLO form: the slot in which a partner block leaves this query's penetration answer (speculate_pen_depth), or null
+    int spec_epoch;
 #ifdef EVM_KSTAMPS
     unsigned long long *ks;  // d.stamps: [17] queries that took the penetration branch, [18] wavefronts with such a query, [19] GJK iterations of the slowest lane summed over waves
 #endif
@@ -573,6 +575,50 @@ DEV RunOut gjk_run(const Shape &A, F3 oA, const Shape &B, F3 oB, float max_dist2
 #define EPA_NOINLINE 1
 #include "epa_dev.h"
 
+// ---- penetration queries AHEAD of their turn ------------------------------------------------------------------------------------
+// A pair that needed the penetration solver in a step, or whose cores came within 2 cm, will most likely need it in the next one, and
+// calcPenDepth's answer depends on the two shapes and transforms only (its nine guess vectors come from the origins, not from the GJK's
+// axis).  So the query of step t + 1 is started when step t's poses are final — by k_speculate (env_kernels.hip), on a stream of its
+// own, beside step t + 1's first kernel and the narrowphase kernel's set-up and GJK — instead of ~45 us into the narrowphase
+// kernel.  A SLOT (EVM_SPEC_WORDS ints) carries it:
+//   [0]       -E once the inputs below are in place, E once the answer is (E = epoch of the step that will use it)
+//   [1..10]   epa::PenOut
+//   [11]      the owner's word to the speculative run: (E << 2) | 1 "wanted" (run at the front of the SIMD's issue), | 2 "not wanted" (stop)
+//   [12..35]  the inputs the run read: A.R (9), A.o (3), B.R (9), B.o (3), bit patterns
+// The owner (closest_points<true, true>) takes the answer only if the inputs are, bit for bit, the transforms it holds itself — a
+// reset or set_state in between, or the non-orthonormal basis of the step after reset(), simply fails the comparison — and every wait
+// is bounded: past the bound the query is run in place, as it always was.
+DEV void speculate_pen_depth(const Shape &A, const Shape &B, int lds_hull_off, int *slot, int epoch) {
+    const bool lead = (threadIdx.x & 63) == 0;
+    if (lead) {
+        float *w = reinterpret_cast<float *>(slot) + 12;
+        w[0] = A.R.r0.x; w[1] = A.R.r0.y; w[2] = A.R.r0.z; w[3] = A.R.r1.x; w[4] = A.R.r1.y; w[5] = A.R.r1.z; w[6] = A.R.r2.x; w[7] = A.R.r2.y; w[8] = A.R.r2.z;
+        w[9] = A.o.x; w[10] = A.o.y; w[11] = A.o.z;
+        w[12] = B.R.r0.x; w[13] = B.R.r0.y; w[14] = B.R.r0.z; w[15] = B.R.r1.x; w[16] = B.R.r1.y; w[17] = B.R.r1.z; w[18] = B.R.r2.x; w[19] = B.R.r2.y; w[20] = B.R.r2.z;
+        w[21] = B.o.x; w[22] = B.o.y; w[23] = B.o.z;
+        __hip_atomic_store(slot, -epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const F3 positionOffset = gj::scl(gj::add(A.o, B.o), 0.5f);
+    const F3 oA = gj::sub(A.o, positionOffset), oB = gj::sub(B.o, positionOffset);
+#ifdef EVM_KSTAMPS
+    void *const ksp = (void *) A.ks;
+#else
+    void *const ksp = nullptr;
+#endif
+    const epa::PenOut po = epa::calc_pen_depth_call<true>(A.hull_off, A.hull_n, B.hull_off, B.hull_n, lds_hull_off, A.R.r0.x, A.R.r0.y, A.R.r0.z, A.R.r1.x, A.R.r1.y,
+                                                          A.R.r1.z, A.R.r2.x, A.R.r2.y, A.R.r2.z, oA.x, oA.y, oA.z, B.R.r0.x, B.R.r0.y, B.R.r0.z, B.R.r1.x, B.R.r1.y,
+                                                          B.R.r1.z, B.R.r2.x, B.R.r2.y, B.R.r2.z, oB.x, oB.y, oB.z, ksp, slot + 11, epoch);
+    __builtin_amdgcn_s_setprio(0);
+    if (lead && !(po.flags & 4)) {
+        float *w = reinterpret_cast<float *>(slot);
+        w[1] = po.vx; w[2] = po.vy; w[3] = po.vz; w[4] = po.ax; w[5] = po.ay; w[6] = po.az; w[7] = po.bx; w[8] = po.by; w[9] = po.bz;
+        slot[10] = po.flags;
+        __hip_atomic_store(slot, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+DEV bool ub1(bool c) { return __builtin_amdgcn_readfirstlane(c ? 1 : 0) != 0; }
+DEV int ui(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // btGjkPairDetector::getClosestPoints for the lanes in `active` (the others return has = false)
 // SOLO (grouped form only): all 64 lanes of the wavefront carry the SAME query (the urgent list's blocks, pairs_dev.h)
 template <bool GROUP, bool SOLO = false>
@@ -603,6 +649,8 @@ DEV Result closest_points(const Shape &A, const Shape &B, float max_dist2, bool 
         }
     }
 #endif
+    if (SOLO && A.spec != nullptr && !__any(need_pen) && (threadIdx.x & 63) == 0)   // the speculative run's answer is not wanted: call it off
+        __hip_atomic_store(A.spec + 11, (A.spec_epoch << 2) | 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (__any(need_pen)) {
         // btGjkEpaPenetrationDepthSolver::calcPenDepth (epa_dev.h): the wavefront takes its queries that need it one at a time and
         // works on each together — the query's transforms broadcast, the answer handed back to the lane(s) that own it.
@@ -627,15 +675,57 @@ DEV Result closest_points(const Shape &A, const Shape &B, float max_dist2, bool 
 #else
             void *const ksp = nullptr;
 #endif
-            const epa::PenOut po = epa::calc_pen_depth_call<GROUP>(As.hull_off, As.hull_n, Bs.hull_off, Bs.hull_n, A.lds_hull_off, As.R.r0.x, As.R.r0.y, As.R.r0.z,
-                                                                   As.R.r1.x, As.R.r1.y, As.R.r1.z, As.R.r2.x, As.R.r2.y, As.R.r2.z, oAs.x, oAs.y, oAs.z, Bs.R.r0.x,
-                                                                   Bs.R.r0.y, Bs.R.r0.z, Bs.R.r1.x, Bs.R.r1.y, Bs.R.r1.z, Bs.R.r2.x, Bs.R.r2.y, Bs.R.r2.z, oBs.x,
-                                                                   oBs.y, oBs.z, ksp);
+            epa::PenOut po;
+            bool answered = false;
+            if (SOLO && A.spec != nullptr) {
+                // a speculative run has had this pair since the previous step's poses were final (above): tell it the answer is
+                // wanted, check that it read the transforms held here, wait for the answer.  Bounded waits; on any doubt the query is
+                // run in place.
+                const int E = A.spec_epoch;
+                if (lane == 0) __hip_atomic_store(A.spec + 11, (E << 2) | 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                int w0 = 0;
+                // (the polls are relaxed loads — an acquire in a loop would invalidate caches under everybody else's feet — with one
+                // acquire fence once the awaited value is seen)
+                for (int tries = 0; tries < 256; tries++) {          // the run is under way (it started a kernel ago)?
+                    w0 = ui(__hip_atomic_load(A.spec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    if (w0 == E || w0 == -E) break;
+                    __builtin_amdgcn_s_sleep(16);
+                }
+                bool same = w0 == E || w0 == -E;
+                if (same) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    const int *in = A.spec + 12;
+                    const float mine[24] = {As.R.r0.x, As.R.r0.y, As.R.r0.z, As.R.r1.x, As.R.r1.y, As.R.r1.z, As.R.r2.x, As.R.r2.y, As.R.r2.z, bc(A.o.x), bc(A.o.y), bc(A.o.z),
+                                            Bs.R.r0.x, Bs.R.r0.y, Bs.R.r0.z, Bs.R.r1.x, Bs.R.r1.y, Bs.R.r1.z, Bs.R.r2.x, Bs.R.r2.y, Bs.R.r2.z, bc(B.o.x), bc(B.o.y), bc(B.o.z)};
+#pragma unroll
+                    for (int k = 0; k < 24; k++) same = same && in[k] == __float_as_int(mine[k]);
+                }
+                if (ub1(same)) {
+                    for (int tries = 0; tries < 4096 && w0 != E; tries++) {
+                        __builtin_amdgcn_s_sleep(16);
+                        w0 = ui(__hip_atomic_load(A.spec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    }
+                    answered = w0 == E;
+                    if (answered) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                }
+                if (lane == 0 && A.pen_count != nullptr) atomicAdd(A.pen_count + (answered ? 4 : 5), 1);   // errs[6] answers used, [7] runs not usable (inputs differ, or a wait ran out)
+                if (answered) {
+                    const float *w = reinterpret_cast<const float *>(A.spec);
+                    po.vx = w[1]; po.vy = w[2]; po.vz = w[3]; po.ax = w[4]; po.ay = w[5]; po.az = w[6]; po.bx = w[7]; po.by = w[8]; po.bz = w[9];
+                    po.flags = A.spec[10];
+                } else if (lane == 0) __hip_atomic_store(A.spec + 11, (E << 2) | 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (!answered)
+                po = epa::calc_pen_depth_call<GROUP>(As.hull_off, As.hull_n, Bs.hull_off, Bs.hull_n, A.lds_hull_off, As.R.r0.x, As.R.r0.y, As.R.r0.z,
+                                                     As.R.r1.x, As.R.r1.y, As.R.r1.z, As.R.r2.x, As.R.r2.y, As.R.r2.z, oAs.x, oAs.y, oAs.z, Bs.R.r0.x,
+                                                     Bs.R.r0.y, Bs.R.r0.z, Bs.R.r1.x, Bs.R.r1.y, Bs.R.r1.z, Bs.R.r2.x, Bs.R.r2.y, Bs.R.r2.z, oBs.x,
+                                                     oBs.y, oBs.z, ksp, nullptr, 0);
             sep = f3(po.vx, po.vy, po.vz); tmpA = f3(po.ax, po.ay, po.az); tmpB = f3(po.bx, po.by, po.bz);
             has_v = (po.flags & 2) != 0;
             const bool isValid2 = (po.flags & 1) != 0;
 #else
-            const bool isValid2 = epa::calc_pen_depth<GROUP>(As, oAs, Bs, oBs, sep, tmpA, tmpB, has_v);
+            bool called_off;
+            const bool isValid2 = epa::calc_pen_depth<GROUP>(As, oAs, Bs, oBs, sep, tmpA, tmpB, has_v, nullptr, 0, called_off);
 #endif
             __builtin_amdgcn_s_setprio(0);
             const bool mine = SOLO ? true : (GROUP ? (lane >> 4) == (src >> 4) : lane == src);

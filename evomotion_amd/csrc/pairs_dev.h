@@ -150,8 +150,27 @@ DEV int *pc_next(const EnvDev &d) { return d.pcount + (d.pc_cur ^ 1) * EVM_PC_ST
 // downwards, which the narrowphase kernel's FIRST blocks work on, one query per wavefront: it then runs beside the whole
 // rest of the kernel instead of starting when some wavefront of 64 other queries happens to find it.
 #define EVM_PMN_DEEP 0x100
-#define EVM_DEEP_SOON (-0.06f)   // distance (margins subtracted) below which a pair is expected to need the penetration solver next step: cores 2 cm apart
+#define EVM_PMN_SLOT(x) (((x) >> 16) & 0x1ff)   // 1 + the slot of the pair's speculative penetration query (narrow_dev.h), 0: none
+// the speculation list of a step: [0] = entries, [16 + k] = (pair << 20) | env of slot k; two copies (the step's pc_cur picks one): the
+// narrowphase of step t fills the one k_speculate reads while step t + 1's narrowphase fills the other
 #define EVM_PMN_COUNT(x) ((x) & 0xff)
+
+// largest separation of the two members' CORE boxes (oriented local boxes of the un-margined hulls) along the six face normals;
+// t = centre of B's box - centre of A's.  > 0: that far apart at least; < 0: overlapping along all six
+DEV float core_box_gap(const EvmMemberC &MA, const EvmMemberC &MB, const M33 &Ra, const M33 &Rb, F3 t) {
+    const F3 ha = f3(MA.aabb_h[0] - 2.f * MARGIN_F, MA.aabb_h[1] - 2.f * MARGIN_F, MA.aabb_h[2] - 2.f * MARGIN_F);  // core half extents
+    const F3 hb = f3(MB.aabb_h[0] - 2.f * MARGIN_F, MB.aabb_h[1] - 2.f * MARGIN_F, MB.aabb_h[2] - 2.f * MARGIN_F);
+    const F3 a0 = col0(Ra), a1 = col1(Ra), a2 = col2(Ra), b0 = col0(Rb), b1 = col1(Rb), b2 = col2(Rb);
+    float gap = -EVM_INF;
+    // axes of A: radius of A = ha_i, radius of B = sum_j hb_j |a_i . b_j|
+    gap = fmaxf(gap, fabsf(dot(t, a0)) - ha.x - (hb.x * fabsf(dot(a0, b0)) + hb.y * fabsf(dot(a0, b1)) + hb.z * fabsf(dot(a0, b2))));
+    gap = fmaxf(gap, fabsf(dot(t, a1)) - ha.y - (hb.x * fabsf(dot(a1, b0)) + hb.y * fabsf(dot(a1, b1)) + hb.z * fabsf(dot(a1, b2))));
+    gap = fmaxf(gap, fabsf(dot(t, a2)) - ha.z - (hb.x * fabsf(dot(a2, b0)) + hb.y * fabsf(dot(a2, b1)) + hb.z * fabsf(dot(a2, b2))));
+    gap = fmaxf(gap, fabsf(dot(t, b0)) - hb.x - (ha.x * fabsf(dot(b0, a0)) + ha.y * fabsf(dot(b0, a1)) + ha.z * fabsf(dot(b0, a2))));
+    gap = fmaxf(gap, fabsf(dot(t, b1)) - hb.y - (ha.x * fabsf(dot(b1, a0)) + ha.y * fabsf(dot(b1, a1)) + ha.z * fabsf(dot(b1, a2))));
+    gap = fmaxf(gap, fabsf(dot(t, b2)) - hb.z - (ha.x * fabsf(dot(b2, a0)) + ha.y * fabsf(dot(b2, a1)) + ha.z * fabsf(dot(b2, a2))));
+    return gap;
+}
 
 // Ra, oa / Rb, ob: the two members' world transforms of this step (k_split_pre_a derives them itself: the bodies are being
 // prepared by other waves of the same kernel)
@@ -171,20 +190,8 @@ DEV void pair_broadphase(const Ctx &c, int p, bool drop, const M33 &Ra, F3 oa, c
         // face normal of either box separates the boxes by more than the two margins + the breaking threshold, GJK could only
         // report a distance beyond the manifold's reach: same result, no query.  (Four out of five box overlaps end here.)
         // Not applied in the step that follows reset(): that step's bases are not orthonormal.
-        const EvmMemberC &MA = c_skel.member[a], &MB = c_skel.member[b];
-        const F3 ha = f3(MA.aabb_h[0] - 2.f * MARGIN_F, MA.aabb_h[1] - 2.f * MARGIN_F, MA.aabb_h[2] - 2.f * MARGIN_F);  // core half extents
-        const F3 hb = f3(MB.aabb_h[0] - 2.f * MARGIN_F, MB.aabb_h[1] - 2.f * MARGIN_F, MB.aabb_h[2] - 2.f * MARGIN_F);
-        const F3 t = cb - ca;                                   // (the fattened boxes share their centres with the core boxes)
-        const F3 a0 = col0(Ra), a1 = col1(Ra), a2 = col2(Ra), b0 = col0(Rb), b1 = col1(Rb), b2 = col2(Rb);
         const float reach = MARGIN_F + MARGIN_F + PC.thr + 1e-4f;
-        float gap = -EVM_INF;
-        // axes of A: radius of A = ha_i, radius of B = sum_j hb_j |a_i . b_j|
-        gap = fmaxf(gap, fabsf(dot(t, a0)) - ha.x - (hb.x * fabsf(dot(a0, b0)) + hb.y * fabsf(dot(a0, b1)) + hb.z * fabsf(dot(a0, b2))));
-        gap = fmaxf(gap, fabsf(dot(t, a1)) - ha.y - (hb.x * fabsf(dot(a1, b0)) + hb.y * fabsf(dot(a1, b1)) + hb.z * fabsf(dot(a1, b2))));
-        gap = fmaxf(gap, fabsf(dot(t, a2)) - ha.z - (hb.x * fabsf(dot(a2, b0)) + hb.y * fabsf(dot(a2, b1)) + hb.z * fabsf(dot(a2, b2))));
-        gap = fmaxf(gap, fabsf(dot(t, b0)) - hb.x - (ha.x * fabsf(dot(b0, a0)) + ha.y * fabsf(dot(b0, a1)) + ha.z * fabsf(dot(b0, a2))));
-        gap = fmaxf(gap, fabsf(dot(t, b1)) - hb.y - (ha.x * fabsf(dot(b1, a0)) + ha.y * fabsf(dot(b1, a1)) + ha.z * fabsf(dot(b1, a2))));
-        gap = fmaxf(gap, fabsf(dot(t, b2)) - hb.z - (ha.x * fabsf(dot(b2, a0)) + ha.y * fabsf(dot(b2, a1)) + ha.z * fabsf(dot(b2, a2))));
+        const float gap = core_box_gap(c_skel.member[a], c_skel.member[b], Ra, Rb, cb - ca);
         const bool pending = (c.d.flags[c.env] & EVM_FLAG_PENDING) != 0 || drop;
         if (n == 0 && !pending && gap > reach) near = false;
         // ... and the other end of the same test: core boxes that overlap along all six face normals (a pair that starts out
@@ -193,6 +200,7 @@ DEV void pair_broadphase(const Ctx &c, int p, bool drop, const M33 &Ra, F3 oa, c
         if (n == 0 && near && gap < 0.f) urgent = true;
     }
     const bool need_any = n > 0 || near;
+    if (!need_any && nraw != 0 && !drop) PMN(p) = 0;   // (no query this step: scheduling hints of the previous one — flag, slot — end here)
     if (need_any && urgent) {   // (a few per step in the whole batch: one atomic each)
         const int at = atomicAdd(&pc_cur(c.d)[c_skel.npair + 1], 1);
         atomicAdd(&c.d.errs[4], 1);
@@ -213,6 +221,60 @@ DEV void pair_broadphase(const Ctx &c, int p, bool drop, const M33 &Ra, F3 oa, c
     if (need) {
         if (big) c.d.blist[at] = (p << 20) | c.env;
         else c.d.plist[(size_t) p * c.d.n + at] = c.env;
+    }
+}
+
+// Pair p of c's environment for k_speculate (env_kernels.hip): the two shapes from the environment's STATE (the poses the previous
+// step left: position, quaternion -> basis exactly as body_prepare derives it), then the penetration query into `slot`
+// (gj::speculate_pen_depth).  All 64 lanes carry the same pair.
+DEV void pair_speculate(const Ctx &c, int p, int lds_hull_off, int *slot, int epoch) {
+    const EvmPairC &PC = c_skel.pair[p];
+    const int a = PC.a, b = PC.b;
+    const EvmMemberC &MA = c_skel.member[a], &MB = c_skel.member[b];
+    gj::Shape SA, SB;
+    SA.hull_off = MA.hull_off; SA.hull_n = MA.hull_n; SB.hull_off = MB.hull_off; SB.hull_n = MB.hull_n;
+    SA.lds_hull_off = SB.lds_hull_off = lds_hull_off;
+    SA.pen_count = SB.pen_count = nullptr;
+    SA.spec = SB.spec = nullptr; SA.spec_epoch = SB.spec_epoch = 0;
+#ifdef EVM_KSTAMPS
+    SA.ks = SB.ks = c.d.stamps;
+#endif
+    SA.o = G3(pos, 3 * a); SB.o = G3(pos, 3 * b);
+    SA.R = mat_from_quat(q4(GS(quat, 4 * a), GS(quat, 4 * a + 1), GS(quat, 4 * a + 2), GS(quat, 4 * a + 3)));
+    SB.R = mat_from_quat(q4(GS(quat, 4 * b), GS(quat, 4 * b + 1), GS(quat, 4 * b + 2), GS(quat, 4 * b + 3)));
+    gj::speculate_pen_depth(SA, SB, lds_hull_off, slot, epoch);
+}
+
+// ... and the pairs no previous step can flag: in the rollout form nine out of ten unflagged penetration queries belong to ONE step of
+// an episode's start — the first whose poses come from the integrated state after reset()'s own step (settle_steps - settle_left == 2:
+// tools/diag_pen.py), where members that the reset pose leaves interpenetrating meet.  k_speculate's first blocks look for them the way
+// the next step's broadphase will (core boxes overlapping along all six face normals, no cached point), on the poses this step left:
+// all 64 lanes take the pairs of environment c.env between them; every hit gets a slot (after the list's: cnt0 + a counter of its
+// own), the slot's number goes into the pair's count word where the urgent block will look for it, and the entry is published (entry,
+// then its epoch tag) for the block of k_speculate that has been waiting for it.
+DEV void env_speculate(const Ctx &c, int cnt0, int *L, int epoch) {
+    const int lane = (int) (threadIdx.x & 63);
+    for (int p0 = 0; p0 < c_skel.npair; p0 += 64) {
+        const int p = p0 + lane;
+        bool hit = false;
+        if (p < c_skel.npair && c.t.pmn[(p << 6) + c.lane] == 0) {
+            const int a = c_skel.pair[p].a, b = c_skel.pair[p].b;
+            const M33 Ra = mat_from_quat(q4(GS(quat, 4 * a), GS(quat, 4 * a + 1), GS(quat, 4 * a + 2), GS(quat, 4 * a + 3)));
+            const M33 Rb = mat_from_quat(q4(GS(quat, 4 * b), GS(quat, 4 * b + 1), GS(quat, 4 * b + 2), GS(quat, 4 * b + 3)));
+            F3 ca, ea, cb, eb;
+            member_box(c_skel.member[a], Ra, G3(pos, 3 * a), ca, ea);
+            member_box(c_skel.member[b], Rb, G3(pos, 3 * b), cb, eb);
+            const bool near = fabsf(ca.x - cb.x) <= ea.x + eb.x && fabsf(ca.y - cb.y) <= ea.y + eb.y && fabsf(ca.z - cb.z) <= ea.z + eb.z;
+            hit = near && core_box_gap(c_skel.member[a], c_skel.member[b], Ra, Rb, cb - ca) < 0.f;
+        }
+        if (hit) {
+            const int k = atomicAdd(L + 1, 1), at = cnt0 + k;
+            if (k < EVM_SPEC_EXTRA && at < EVM_SPEC_SLOTS) {
+                __hip_atomic_fetch_or(&c.t.pmn[(p << 6) + c.lane], (at + 1) << 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(L + 16 + at, (p << 20) | c.env, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(L + 16 + EVM_SPEC_SLOTS + at, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
 }
 
@@ -245,6 +307,12 @@ DEV void pair_item(const Ctx &c, int p, bool drop, int lds_hull_off = -1) {
     SA.hull_off = MA.hull_off; SA.hull_n = MA.hull_n; SB.hull_off = MB.hull_off; SB.hull_n = MB.hull_n;
     SA.lds_hull_off = SB.lds_hull_off = lds_hull_off;
     SA.pen_count = SB.pen_count = c.d.errs + 2;
+    {   // (SOLO: the slot of the pair's speculative penetration query, if the previous step started one)
+        // (agent-scope load: k_speculate may have set the bits while this step's first kernel ran, from another XCD)
+        const int sl = SOLO ? EVM_PMN_SLOT(__hip_atomic_load(&PMN(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0;
+        SA.spec = SB.spec = (SOLO && !drop && sl > 0 && c.d.spec != nullptr) ? c.d.spec + (size_t) EVM_SPEC_WORDS * (sl - 1) : nullptr;
+        SA.spec_epoch = SB.spec_epoch = c.d.spec_epoch;
+    }
 #ifdef EVM_KSTAMPS
     SA.ks = SB.ks = c.d.stamps;
 #endif
@@ -362,7 +430,27 @@ DEV void pair_item(const Ctx &c, int p, bool drop, int lds_hull_off = -1) {
     const F3 wA[4] = {wA0, wA1, wA2, wA3}, wB[4] = {wB0, wB1, wB2, wB3};
     store_mp2(c, p, 0, p0); store_mp2(c, p, 1, p1); store_mp2(c, p, 2, p2); store_mp2(c, p, 3, p3);
     // (flagged for the next step's urgent list: it took the penetration branch, or its cores are about to touch)
-    PMN(p) = n | ((r.used_pen || (r.has && r.distance < EVM_DEEP_SOON)) ? EVM_PMN_DEEP : 0);
+    const bool deep = r.used_pen || (r.has && r.distance < c.d.deep_soon);
+#ifdef EVM_DIAG_PEN
+    if (r.used_pen && lead) {
+        const int fl = c.d.flags[c.env];
+        atomicAdd(&c.d.errs[8 + (drop ? 0 : ((fl & EVM_FLAG_PENDING) ? 1 : ((nraw_in & EVM_PMN_DEEP) ? 2 : (EVM_PMN_COUNT(nraw_in) > 0 ? 3 : 4))))], 1);
+        if (c.d.settle_left[c.env] > 0) atomicAdd(&c.d.errs[13], 1);
+        if (!(nraw_in & EVM_PMN_DEEP)) { const int k = c_skel.settle_steps - c.d.settle_left[c.env]; atomicAdd(&c.d.errs[14 + (k < 0 ? 0 : (k > 9 ? 9 : k))], 1); }
+    }
+#endif
+    int slotbits = 0;
+    if (c.d.slist != nullptr && __any(deep)) {   // ... and its penetration query of the next step is started ahead of time (narrow_dev.h)
+        int *L = c.d.slist + c.d.pc_cur * EVM_SLIST_STRIDE;
+        int at = -1;
+        if (deep && lead) at = atomicAdd(L, 1);
+        at = SOLO ? __shfl(at, 0) : (GROUP ? __shfl(at, (int) (threadIdx.x & 63) & ~15) : at);
+        if (deep && at >= 0 && at < EVM_SPEC_SLOTS) {
+            if (lead) L[16 + at] = (p << 20) | c.env;
+            slotbits = (at + 1) << 16;
+        }
+    }
+    PMN(p) = n | (deep ? EVM_PMN_DEEP : 0) | slotbits;
     if (SOLO) { UST(7) }
     KS_MARK(2)
     if (!__any(n > 0)) return;

@@ -229,6 +229,12 @@ class VecRobotWalk:
         self.urgent_entries = int(out[2])                  # entries of the urgent list (predictions, right or wrong)
         return int(out[0])
 
+    def speculation_counters(self, clear=True):
+        """penetration queries run ahead of time for pairs that needed the solver in the previous step: (run, answers used, waits that ran out)"""
+        out = (ctypes.c_int * 3)()
+        check(lib.evm_env_get_speculation_counters(self._h, out, 1 if clear else 0, self._stream()))
+        return int(out[0]), int(out[1]), int(out[2])
+
     def stats(self):
         out = (ctypes.c_longlong * 2)()
         check(lib.evm_env_get_stats(self._h, out))

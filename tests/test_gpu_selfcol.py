@@ -265,3 +265,38 @@ def test_masked_reset_leaves_the_other_envs_untouched(torch_mod):
     assert np.array_equal(before[:64], after[:64]), int((before[:64] != after[:64]).sum())
     assert not np.array_equal(before[64:], after[64:])
     assert np.isfinite(after).all() and env.errors() == (0, 0)
+
+
+def test_queries_started_ahead_of_time_change_nothing_but_the_schedule(torch_mod, monkeypatch):
+    """The penetration queries that k_speculate starts a step early (narrow_dev.h, "ahead of their turn": pairs the previous step flagged,
+    and the episode-start pairs it finds itself) are scheduling only: with EVM_SPECULATE=0 the same rollout — resets, settle steps,
+    flagged pairs and all — must come out bit for bit, observations every step and the full state blob at the end.  And the path
+    must have been exercised: answers were used, and none was refused (inputs that differ) or waited for in vain."""
+    torch = torch_mod
+    n, steps = 512, 260
+
+    def run(speculate):
+        if speculate:
+            monkeypatch.delenv("EVM_SPECULATE", raising=False)
+        else:
+            monkeypatch.setenv("EVM_SPECULATE", "0")
+        env = make(n, seed=77)
+        env.reset()
+        env.stagger_episodes()
+        env.penetration_queries(); env.speculation_counters()
+        rng = np.random.default_rng(3)
+        obs = []
+        for k in range(steps):
+            r = env.step_autoreset(torch.from_numpy(rng.uniform(-1, 1, (n, 12)).astype(np.float32)))
+            obs.append(r.state.cpu().numpy().copy())
+        return np.stack(obs), env.get_state(), env.penetration_queries(), env.speculation_counters(), env.errors()
+
+    o1, s1, q1, c1, e1 = run(True)
+    o0, s0, q0, c0, e0 = run(False)
+    print("solver queries %d; started ahead of time %d, answers used %d, not usable %d" % ((q1,) + c1))
+    assert c0 == (0, 0, 0) and q0 == q1 > 20
+    assert c1[1] >= q1 // 2, "most solver queries of a rollout are flagged a step ahead or belong to an episode's start"
+    assert c1[2] == 0
+    assert e1 == e0 == (0, 0)
+    assert np.array_equal(o1, o0), int((o1 != o0).sum())
+    assert np.array_equal(s1, s0), int((s1 != s0).sum())
