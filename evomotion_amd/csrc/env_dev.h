@@ -45,20 +45,18 @@ struct EnvDev {
                                     // (largest |delta impulse| of a row in the LAST sweep), fp32 bits (>= 0: integer order)
     int *errs;                      // [0] version waits that timed out (a schedule bug), [1] manifolds left out of a step's contact
                                     // rounds (more than 32 live manifolds or 31 rounds in one env); sticky until cleared;
-                                    // [2] narrowphase queries that went through the penetration-depth solver, [3] those of them on the urgent list, [4] entries of the urgent list, [5] speculation blocks that ran a penetration query ahead of time, [6] their answers used, [7] waits for an answer that ran out (counters, not errors)
+                                    // [2] narrowphase queries that went through the penetration-depth solver, [3] those of them on the urgent list, [4] entries of the urgent list, [5] penetration queries run by speculation blocks, [6] their answers used, [7] waits for an answer that ran out (counters, not errors)
     float *gtile;                   // [n/64][tile_floats] global staging copy of the LDS tile (split pipeline)
     int tile_floats;                // step_lds_bytes / 4
     const EvmGSchedC *gs;           // lane-group sweep schedule (device copy), or null: the 64-env tile sweeps kernel runs
     int g_waves, g_lds;             // waves per 16-env workgroup and dynamic LDS bytes of k_sweeps_g
-    int *spec;                      // [EVM_SPEC_SLOTS][EVM_SPEC_WORDS] slots of the penetration queries started ahead of time (narrow_dev.h); null: none
-    int *slist;                     // [2][EVM_SLIST_STRIDE] the pairs to start them for (pairs_dev.h); null: none
-    float deep_soon;                // distance below which a pair goes to the next step's urgent list and has its penetration query started ahead of time (EVM_DEEP_SOON)
-    int spec_epoch;                 // this step's epoch (the host counts the steps; never 0): a slot's answer is for exactly one step
+    int *spec;                      // [EVM_SPEC_SLOTS][EVM_SPEC_WORDS] slots of the urgent list's speculation blocks (narrow_dev.h); null: none
+    float deep_soon;                // distance below which a pair goes to the next step's urgent list (EVM_DEEP_SOON)
+    int spec_epoch;                 // this launch's epoch (the host counts the steps; never 0): a slot's answer is for exactly one launch
 };
 
 hipError_t upload_skeleton(const EvmSkelC *h, hipStream_t s);
 size_t step_lds_bytes(int nb, int nscan);
-hipError_t launch_speculate(const EnvDev &d, int epoch, hipStream_t s);   // (after the step's kernels, on a stream of its own)
 // split = 1: pre / sweeps / post kernels (the throughput phases spread over the whole chip); 0: one monolithic kernel
 // ev_sweeps0/1 (optional): recorded around the sweeps kernel of the split pipeline
 hipError_t launch_step(const EnvDev &d, size_t lds_bytes, int split, int mode, const float *action, float *obs, float *reward,

@@ -48,11 +48,7 @@ struct EvmEnv {
     int split;  // -1: by batch size (default), 1: split pipeline, 0: monolithic step kernel (EVM_MONOLITHIC=0/1 forces: A/B runs)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_sweeps;  // timed launches: around the sweeps kernel of the split pipeline
     void *gsched;  // device copy of the lane-group sweep schedule (EvmGSchedC), or null
-    // penetration queries started ahead of time (narrow_dev.h): the slots + the two lists (one allocation), the stream k_speculate runs
-    // on beside the next step's kernels (non-blocking: the legacy default stream must not wait for it), the event it waits for
-    void *spec_mem;
-    hipStream_t spec_stream;
-    hipEvent_t spec_event;
+    void *spec_mem;   // the speculation blocks' slots (narrow_dev.h), or null
 };
 
 #ifndef EVM_MAX_DEVICES
@@ -172,21 +168,18 @@ int evm_env_create(const char *skeleton_path, int n_envs, int device, uint64_t s
     for (auto &s : segs) { *s.p = base; base += s.count * n * 4; }
     hipEventCreate(&env->ev0);
     hipEventCreate(&env->ev1);
-    env->spec_mem = nullptr; env->spec_stream = nullptr; env->spec_event = nullptr;
+    env->spec_mem = nullptr;
     { const char *ds = getenv("EVM_DEEP_SOON"); env->d.deep_soon = ds ? (float) atof(ds) : EVM_DEEP_SOON_DEFAULT; }   // (scheduling only: A/B runs)
     {
-        // member-vs-member contacts: the slots and lists of the penetration queries started ahead of time (EVM_SPECULATE=0 turns them
-        // off: A/B runs; the physics is the same bit for bit either way)
+        // member-vs-member contacts: the slots of the urgent list's speculation blocks (EVM_SPECULATE=0 turns them off: A/B runs; the
+        // physics is the same bit for bit either way)
         const char *sp = getenv("EVM_SPECULATE");
         if (S.self_collision && !(sp && sp[0] == '0')) {
-            const size_t words = (size_t) EVM_SPEC_SLOTS * EVM_SPEC_WORDS + 2 * EVM_SLIST_STRIDE;
+            const size_t words = (size_t) EVM_SPEC_SLOTS * EVM_SPEC_WORDS;
             he = hipMalloc(&env->spec_mem, words * sizeof(int));
             if (he == hipSuccess) he = hipMemset(env->spec_mem, 0, words * sizeof(int));
-            if (he == hipSuccess) he = hipStreamCreateWithFlags(&env->spec_stream, hipStreamNonBlocking);
-            if (he == hipSuccess) he = hipEventCreateWithFlags(&env->spec_event, hipEventDisableTiming);
-            if (he != hipSuccess) { evm_env_destroy(env); return fail(EVM_E_HIP, std::string("speculation buffers: ") + hipGetErrorString(he)); }
+            if (he != hipSuccess) { evm_env_destroy(env); return fail(EVM_E_HIP, std::string("speculation slots: ") + hipGetErrorString(he)); }
             env->d.spec = (int *) env->spec_mem;
-            env->d.slist = env->d.spec + (size_t) EVM_SPEC_SLOTS * EVM_SPEC_WORDS;
         }
     }
     // Sweeps kernel of the split pipeline: the lane-group kernel (16-env workgroups, joint records resident in LDS) when the
@@ -234,7 +227,6 @@ void evm_env_destroy(EvmEnv *env) {
     if (env->device >= 0 && env->device < EVM_MAX_DEVICES && g_skel_owner[env->device] == env) g_skel_owner[env->device] = nullptr;
     if (env->arena) hipFree(env->arena);
     if (env->gsched) hipFree(env->gsched);
-    if (env->spec_stream) { (void) hipStreamSynchronize(env->spec_stream); (void) hipStreamDestroy(env->spec_stream); (void) hipEventDestroy(env->spec_event); }
     if (env->spec_mem) hipFree(env->spec_mem);
     (void) hipEventDestroy(env->ev0);
     (void) hipEventDestroy(env->ev1);
@@ -281,7 +273,6 @@ static int step_launch(EvmEnv *env, int mode, const float *a, float *obs, float 
     env->d.pc_cur ^= 1;  // this step's copy of the narrowphase list counters (zeroed by the previous step's first kernel)
     // the speculation slots' epoch (a slot is valid when its word 0 equals the launch's epoch; memory starts as 0)
     if (env->d.spec && env->d.spec_epoch >= 0x1ffffff0) {   // ((epoch << 2) | code must stay positive)
-        HIP_TRY(hipStreamSynchronize(env->spec_stream));
         HIP_TRY(hipMemsetAsync(env->d.spec, 0, (size_t) EVM_SPEC_SLOTS * EVM_SPEC_WORDS * sizeof(int), s));
         env->d.spec_epoch = 0;
     }
@@ -295,13 +286,6 @@ static int step_launch(EvmEnv *env, int mode, const float *a, float *obs, float 
         env->ev_used++;
     }
     if (env->timing) env->timed_launches++;
-    if (env->d.spec) {
-        // the next step's flagged penetration queries start now, beside that step's first kernels (k_speculate waits for this step's
-        // last kernel only; nothing waits for it)
-        HIP_TRY(hipEventRecord(env->spec_event, s));
-        HIP_TRY(hipStreamWaitEvent(env->spec_stream, env->spec_event, 0));
-        HIP_TRY(evm::launch_speculate(env->d, env->d.spec_epoch + 1, env->spec_stream));
-    }
     return EVM_OK;
 }
 

@@ -1917,8 +1917,6 @@ __global__ __launch_bounds__(64 * EVM_SPLIT_WAVES) void k_split_pre_a(EnvDev d, 
     if (c_skel.self_collision && blockIdx.x == 0 && blockIdx.y == gridDim.y - 1 && c.wave == EVM_SPLIT_WAVES - 1) {
         int *nxt = pc_next(d);
         for (int k = c.lane; k <= c_skel.npair + 1; k += 64) nxt[k] = 0;
-        // ... and THIS step's speculation list (its last reader, k_speculate two steps ago, read it a step and a half ago)
-        if (d.slist != nullptr && c.lane < 3) d.slist[d.pc_cur * EVM_SLIST_STRIDE + c.lane] = 0;   // ([1], [2]: k_speculate's own additions)
     }
     EVM_SPLIT_GUARD()
     const LaneState L = lane_state<MODE>(c);
@@ -2096,6 +2094,35 @@ DEV void narrow_block(const EnvDev &d, int blk, int tiles) {   // blk: block ind
     } ks;
     ks.st = nullptr;
 #endif
+    if (blk < EVM_SPEC_SLOTS) {
+        // Speculation blocks, the launch's very first: entry i (< EVM_SPEC_SLOTS) of the urgent list is ALSO taken by block i here,
+        // which runs the pair's penetration query at once and leaves the answer in slot i (narrow_dev.h: speculate_pen_depth); the
+        // urgent block that owns the entry (below) asks for it, or calls the run off, when its GJK is through.
+        const int cnt = pc_cur(d)[c_skel.npair + 1];
+        if (blk >= cnt || d.spec == nullptr) return;
+#ifdef EVM_KSTAMPS
+        if (threadIdx.x == 0) gj::epa::g_ust_on = 0;
+#endif
+        const int e = d.blist[(size_t) c_skel.npair * d.n - 1 - blk], p = e >> 20, env = e & 0xfffff;
+        // hulls of at most 64 vertices live in the solver's registers: only a bigger one needs the table in LDS
+        const bool small = c_skel.member[c_skel.pair[p].a].hull_n <= 64 && c_skel.member[c_skel.pair[p].b].hull_n <= 64;
+        int hoff = -1;
+        if (!small) {
+            const bool all = c_skel.hull_pts <= EVM_LDS_HULL_PTS;
+            const int h0 = all ? 0 : c_skel.big_hull_off, hn = all ? c_skel.hull_pts : c_skel.big_hull_n;
+            hoff = all ? -2 : c_skel.big_hull_off;
+            for (int v = threadIdx.x; v < hn; v += 64) {
+                const int g = h0 + v, hb = 6 * (g >> 1) + (g & 1);
+                gj::g_lds_hull[v] = gj::gj_f4{c_skel.hull[hb], c_skel.hull[hb + 2], c_skel.hull[hb + 4], 0.f};
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) atomicAdd(&d.errs[5], 1);
+        const Ctx c = make_ctx_env(d, env);
+        pair_speculate(c, p, hoff, d.spec + (size_t) EVM_SPEC_WORDS * blk);
+        return;
+    }
+    blk -= EVM_SPEC_SLOTS;
     const bool urgent_blk = blk < EVM_URGENT_BLOCKS;
     blk -= EVM_URGENT_BLOCKS;
 #ifdef EVM_KSTAMPS
@@ -2126,10 +2153,10 @@ DEV void narrow_block(const EnvDev &d, int blk, int tiles) {   // blk: block ind
 #ifdef EVM_KSTAMPS
                 if (threadIdx.x == 0) { gj::epa::g_ust[1] = __builtin_amdgcn_s_memtime(); for (int k = 0; k < 8; k++) gj::epa::g_uph[k] = 0ull; }
 #endif
-                const int e = d.blist[(size_t) c_skel.npair * d.n - 1 - i], p = (e >> 20) & 0x3ff, env = e & 0xfffff;
+                const int e = d.blist[(size_t) c_skel.npair * d.n - 1 - i], p = e >> 20, env = e & 0xfffff;
                 const Ctx c = make_ctx_env(d, env);
                 const bool fin = (MODE & 4) && (d.flags[env] & EVM_FLAG_DONE) != 0;
-                pair_item<true, true>(c, p, fin, hoff);
+                pair_item<true, true>(c, p, fin, hoff, (i < EVM_SPEC_SLOTS && d.spec != nullptr) ? d.spec + (size_t) EVM_SPEC_WORDS * i : nullptr);
             }
             return;
         }
@@ -2463,7 +2490,7 @@ namespace evm {
 template <int MODE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EVM_PAIRS_WAVES, EVM_PAIRS_WAVES))) void k_split_pairs_rec(EnvDev d, const float *__restrict__ action,
                                                                         const uint8_t *__restrict__ mask, int tiles, int nvw) {
-    const int narrow = EVM_URGENT_BLOCKS + EVM_BIG_BLOCKS + tiles * d.npair_host;
+    const int narrow = EVM_SPEC_SLOTS + EVM_URGENT_BLOCKS + EVM_BIG_BLOCKS + tiles * d.npair_host;
     if ((int) blockIdx.x < narrow) { narrow_block<MODE>(d, (int) blockIdx.x, tiles); return; }
     const int rb = (int) blockIdx.x - narrow, tile = rb / nvw, vw = rb - tile * nvw;
     const Ctx c = make_ctx_at(d, d.gtile + (size_t) tile * d.tile_floats, tile, (int) threadIdx.x, 0);
@@ -2511,81 +2538,6 @@ namespace evm {
 hipError_t upload_skeleton(const EvmSkelC *h, hipStream_t s) {
     return hipMemcpyToSymbolAsync(HIP_SYMBOL(c_skel), h, sizeof(EvmSkelC), 0, hipMemcpyHostToDevice, s);
 }
-// The penetration queries of the NEXT step's flagged pairs, started as soon as this step's poses are final (narrow_dev.h, "ahead of
-// their turn"; launched by launch_speculate on a stream of its own after the step's last kernel): block k takes entry k of the list
-// this step's narrowphase wrote, one query per wavefront, and leaves the answer in slot k for `epoch` = the next step.
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_speculate(EnvDev d, int epoch) {
-    int blk = (int) blockIdx.x;
-    const int nenv_blocks = d.n / 64;
-    int *L = d.slist + d.pc_cur * EVM_SLIST_STRIDE;
-    const int cnt = min(L[0], EVM_SPEC_SLOTS);
-    if (blk < nenv_blocks) {
-        // the launch's FIRST blocks, 64 environments each: the episode-start pairs (pairs_dev.h: env_speculate) are looked for and
-        // added to the list; the blocks below run them
-        const int env0 = blk * 64 + (int) threadIdx.x;
-        const bool cand = c_skel.settle_steps - d.settle_left[env0] == 2 && (d.flags[env0] & (EVM_FLAG_PENDING | EVM_FLAG_DONE)) == 0;
-        unsigned long long m = __ballot(cand);
-        while (m) {
-            const int env = blk * 64 + (int) __builtin_ctzll(m);
-            m &= m - 1ull;
-            const Ctx c = make_ctx_env(d, env);
-            env_speculate(c, cnt, L, epoch);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(L + 2, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        return;
-    }
-    blk -= nenv_blocks;   // = the slot
-    int e;
-    if (blk < cnt) e = L[16 + blk];
-    else if (blk >= cnt + EVM_SPEC_EXTRA) return;
-    else {
-        // an entry the blocks above may add: wait for its tag, or for all of them to be done without it.  Bounded (they were dispatched
-        // first and take a few microseconds): past the bound the entry simply goes unanswered and its owner runs the query in place.
-        bool there = false;
-        // (relaxed polls, a microsecond apart: ~250 waves do this at once beside the next step's first kernel)
-        for (int tries = 0; tries < 128 && !there; tries++) {
-            there = __hip_atomic_load(L + 16 + EVM_SPEC_SLOTS + blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
-            if (!there) {
-                if (__hip_atomic_load(L + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= nenv_blocks) {
-                    there = __hip_atomic_load(L + 16 + EVM_SPEC_SLOTS + blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(32);
-            }
-        }
-        if (!there) return;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        e = __hip_atomic_load(L + 16 + blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    const int p = (e >> 20) & 0x3ff, env = e & 0xfffff;
-    if (p >= c_skel.npair || env >= d.n) return;   // (a list read too late — the stream was held up — may hold anything)
-#ifdef EVM_KSTAMPS
-    if (threadIdx.x == 0) gj::epa::g_ust_on = 0;
-#endif
-    // hulls of at most 64 vertices live in the solver's registers: only a bigger one needs the table in LDS
-    const bool small = c_skel.member[c_skel.pair[p].a].hull_n <= 64 && c_skel.member[c_skel.pair[p].b].hull_n <= 64;
-    int hoff = -1;
-    if (!small) {
-        const bool all = c_skel.hull_pts <= EVM_LDS_HULL_PTS;
-        const int h0 = all ? 0 : c_skel.big_hull_off, hn = all ? c_skel.hull_pts : c_skel.big_hull_n;
-        hoff = all ? -2 : c_skel.big_hull_off;
-        for (int v = threadIdx.x; v < hn; v += 64) {
-            const int g = h0 + v, hb = 6 * (g >> 1) + (g & 1);
-            gj::g_lds_hull[v] = gj::gj_f4{c_skel.hull[hb], c_skel.hull[hb + 2], c_skel.hull[hb + 4], 0.f};
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) atomicAdd(&d.errs[5], 1);
-    const Ctx c = make_ctx_env(d, env);
-    pair_speculate(c, p, hoff, d.spec + (size_t) EVM_SPEC_WORDS * blk, epoch);
-}
-hipError_t launch_speculate(const EnvDev &d, int epoch, hipStream_t s) {
-    if (d.spec == nullptr || d.slist == nullptr) return hipSuccess;
-    hipLaunchKernelGGL(k_speculate, dim3(EVM_SPEC_SLOTS + d.n / 64), dim3(64), 0, s, d, epoch);
-    return hipGetLastError();
-}
-
 size_t step_lds_bytes(int nb, int nscan) {  // tiles + version counters + hull-scan partials
     return (size_t) nb * 12 * 64 * sizeof(float) + (size_t) ((nb + 63) / 64) * 256 + (size_t) nscan * 2 * 64 * sizeof(float);
 }
@@ -2634,10 +2586,10 @@ static hipError_t launch_split(const EnvDev &d, size_t lds, const float *action,
     if (merge < 0) { const char *e = getenv("EVM_PAIRS_MERGE"); merge = (e && e[0] == '0') ? 0 : 1; }
     if (d.pmn && merge) {
         const int nvw = parts * EVM_SPLIT_WAVES;
-        hipLaunchKernelGGL((k_split_pairs_rec<MODE>), dim3(EVM_URGENT_BLOCKS + EVM_BIG_BLOCKS + tiles * d.npair_host + tiles * nvw), dim3(64), 0, s, d, action, mask, tiles, nvw);
+        hipLaunchKernelGGL((k_split_pairs_rec<MODE>), dim3(EVM_SPEC_SLOTS + EVM_URGENT_BLOCKS + EVM_BIG_BLOCKS + tiles * d.npair_host + tiles * nvw), dim3(64), 0, s, d, action, mask, tiles, nvw);
     } else {
         hipLaunchKernelGGL((k_split_pre_b<MODE>), gp, bp, 0, s, d, action, mask, 0);
-        if (d.pmn) hipLaunchKernelGGL((k_split_pairs<MODE>), dim3(EVM_URGENT_BLOCKS + EVM_BIG_BLOCKS + tiles * d.npair_host), dim3(64), 0, s, d, mask, tiles);
+        if (d.pmn) hipLaunchKernelGGL((k_split_pairs<MODE>), dim3(EVM_SPEC_SLOTS + EVM_URGENT_BLOCKS + EVM_BIG_BLOCKS + tiles * d.npair_host), dim3(64), 0, s, d, mask, tiles);
     }
     if (e0) (void) hipEventRecord(e0, s);
     bool fused_post = false;

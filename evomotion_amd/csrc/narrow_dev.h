@@ -575,29 +575,23 @@ DEV RunOut gjk_run(const Shape &A, F3 oA, const Shape &B, F3 oB, float max_dist2
 #define EPA_NOINLINE 1
 #include "epa_dev.h"
 
-// ---- penetration queries AHEAD of their turn ------------------------------------------------------------------------------------
-// A pair that needed the penetration solver in a step, or whose cores came within 2 cm, will most likely need it in the next one, and
-// calcPenDepth's answer depends on the two shapes and transforms only (its nine guess vectors come from the origins, not from the GJK's
-// axis).  So the query of step t + 1 is started when step t's poses are final — by k_speculate (env_kernels.hip), on a stream of its
-// own, beside step t + 1's first kernel and the narrowphase kernel's set-up and GJK — instead of ~45 us into the narrowphase
-// kernel.  A SLOT (EVM_SPEC_WORDS ints) carries it:
-//   [0]       -E once the inputs below are in place, E once the answer is (E = epoch of the step that will use it)
+// ---- penetration queries BESIDE the pair's own query ----------------------------------------------------------------------------
+// Even first in line (the urgent list, pairs_dev.h) a query that goes through the solver is ~75 us of one wavefront's dependent
+// instructions AFTER ~25 us of set-up and GJK, and ~15 us of normal check, manifold and contact record follow: longer than everything
+// else in the kernel (~80 us).  But calcPenDepth's answer depends on the two shapes and transforms only (its nine guess vectors come from
+// the origins, not from the GJK's axis).  So every entry of the urgent list is taken TWICE: by its urgent block, as before, and by a
+// SPECULATION block (the launch's very first blocks, env_kernels.hip: narrow_block) that runs calcPenDepth at once and leaves the
+// answer in the entry's SLOT (EVM_SPEC_WORDS ints):
+//   [0]       E once the answer is in place (E = the launch's epoch: the host counts the steps, so nothing is ever reset)
 //   [1..10]   epa::PenOut
-//   [11]      the owner's word to the speculative run: (E << 2) | 1 "wanted" (run at the front of the SIMD's issue), | 2 "not wanted" (stop)
-//   [12..35]  the inputs the run read: A.R (9), A.o (3), B.R (9), B.o (3), bit patterns
-// The owner (closest_points<true, true>) takes the answer only if the inputs are, bit for bit, the transforms it holds itself — a
-// reset or set_state in between, or the non-orthonormal basis of the step after reset(), simply fails the comparison — and every wait
-// is bounded: past the bound the query is run in place, as it always was.
+//   [11]      the owner's word to the speculative run: (E << 2) | 1 "wanted" (the run moves to the front of its SIMD's issue; until
+//             then it has the ordinary priority, so a run that turns out unneeded never starves a neighbour), | 2 "not wanted" (the
+//             run stops at its next EPA round: nine runs out of ten)
+// Same kernel, same state, same function, same arguments: the answer is the one the call in place would give, bit for bit.  The
+// wait is bounded (the speculation blocks have the lower block indices, so they are running or done; but nothing here may hang):
+// past the bound the query is run in place, as it always was.
 DEV void speculate_pen_depth(const Shape &A, const Shape &B, int lds_hull_off, int *slot, int epoch) {
     const bool lead = (threadIdx.x & 63) == 0;
-    if (lead) {
-        float *w = reinterpret_cast<float *>(slot) + 12;
-        w[0] = A.R.r0.x; w[1] = A.R.r0.y; w[2] = A.R.r0.z; w[3] = A.R.r1.x; w[4] = A.R.r1.y; w[5] = A.R.r1.z; w[6] = A.R.r2.x; w[7] = A.R.r2.y; w[8] = A.R.r2.z;
-        w[9] = A.o.x; w[10] = A.o.y; w[11] = A.o.z;
-        w[12] = B.R.r0.x; w[13] = B.R.r0.y; w[14] = B.R.r0.z; w[15] = B.R.r1.x; w[16] = B.R.r1.y; w[17] = B.R.r1.z; w[18] = B.R.r2.x; w[19] = B.R.r2.y; w[20] = B.R.r2.z;
-        w[21] = B.o.x; w[22] = B.o.y; w[23] = B.o.z;
-        __hip_atomic_store(slot, -epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    }
     const F3 positionOffset = gj::scl(gj::add(A.o, B.o), 0.5f);
     const F3 oA = gj::sub(A.o, positionOffset), oB = gj::sub(B.o, positionOffset);
 #ifdef EVM_KSTAMPS
@@ -678,38 +672,21 @@ DEV Result closest_points(const Shape &A, const Shape &B, float max_dist2, bool 
             epa::PenOut po;
             bool answered = false;
             if (SOLO && A.spec != nullptr) {
-                // a speculative run has had this pair since the previous step's poses were final (above): tell it the answer is
-                // wanted, check that it read the transforms held here, wait for the answer.  Bounded waits; on any doubt the query is
-                // run in place.
+                // the entry's speculation block has been on this very query since the launch began (above): tell it the answer is
+                // wanted and wait for it.  (The polls are relaxed loads a microsecond apart — an acquire in a loop would invalidate
+                // caches under everybody else's feet — with one acquire fence once the value is seen.)
                 const int E = A.spec_epoch;
                 if (lane == 0) __hip_atomic_store(A.spec + 11, (E << 2) | 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 int w0 = 0;
-                // (the polls are relaxed loads — an acquire in a loop would invalidate caches under everybody else's feet — with one
-                // acquire fence once the awaited value is seen)
-                for (int tries = 0; tries < 256; tries++) {          // the run is under way (it started a kernel ago)?
+                for (int tries = 0; tries < 4096; tries++) {
                     w0 = ui(__hip_atomic_load(A.spec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                    if (w0 == E || w0 == -E) break;
+                    if (w0 == E) break;
                     __builtin_amdgcn_s_sleep(16);
                 }
-                bool same = w0 == E || w0 == -E;
-                if (same) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    const int *in = A.spec + 12;
-                    const float mine[24] = {As.R.r0.x, As.R.r0.y, As.R.r0.z, As.R.r1.x, As.R.r1.y, As.R.r1.z, As.R.r2.x, As.R.r2.y, As.R.r2.z, bc(A.o.x), bc(A.o.y), bc(A.o.z),
-                                            Bs.R.r0.x, Bs.R.r0.y, Bs.R.r0.z, Bs.R.r1.x, Bs.R.r1.y, Bs.R.r1.z, Bs.R.r2.x, Bs.R.r2.y, Bs.R.r2.z, bc(B.o.x), bc(B.o.y), bc(B.o.z)};
-#pragma unroll
-                    for (int k = 0; k < 24; k++) same = same && in[k] == __float_as_int(mine[k]);
-                }
-                if (ub1(same)) {
-                    for (int tries = 0; tries < 4096 && w0 != E; tries++) {
-                        __builtin_amdgcn_s_sleep(16);
-                        w0 = ui(__hip_atomic_load(A.spec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                    }
-                    answered = w0 == E;
-                    if (answered) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                }
-                if (lane == 0 && A.pen_count != nullptr) atomicAdd(A.pen_count + (answered ? 4 : 5), 1);   // errs[6] answers used, [7] runs not usable (inputs differ, or a wait ran out)
+                answered = w0 == E;
+                if (lane == 0 && A.pen_count != nullptr) atomicAdd(A.pen_count + (answered ? 4 : 5), 1);   // errs[6] answers used, [7] waits that ran out
                 if (answered) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                     const float *w = reinterpret_cast<const float *>(A.spec);
                     po.vx = w[1]; po.vy = w[2]; po.vz = w[3]; po.ax = w[4]; po.ay = w[5]; po.az = w[6]; po.bx = w[7]; po.by = w[8]; po.bz = w[9];
                     po.flags = A.spec[10];

@@ -150,9 +150,6 @@ DEV int *pc_next(const EnvDev &d) { return d.pcount + (d.pc_cur ^ 1) * EVM_PC_ST
 // downwards, which the narrowphase kernel's FIRST blocks work on, one query per wavefront: it then runs beside the whole
 // rest of the kernel instead of starting when some wavefront of 64 other queries happens to find it.
 #define EVM_PMN_DEEP 0x100
-#define EVM_PMN_SLOT(x) (((x) >> 16) & 0x1ff)   // 1 + the slot of the pair's speculative penetration query (narrow_dev.h), 0: none
-// the speculation list of a step: [0] = entries, [16 + k] = (pair << 20) | env of slot k; two copies (the step's pc_cur picks one): the
-// narrowphase of step t fills the one k_speculate reads while step t + 1's narrowphase fills the other
 #define EVM_PMN_COUNT(x) ((x) & 0xff)
 
 // largest separation of the two members' CORE boxes (oriented local boxes of the un-margined hulls) along the six face normals;
@@ -224,10 +221,9 @@ DEV void pair_broadphase(const Ctx &c, int p, bool drop, const M33 &Ra, F3 oa, c
     }
 }
 
-// Pair p of c's environment for k_speculate (env_kernels.hip): the two shapes from the environment's STATE (the poses the previous
-// step left: position, quaternion -> basis exactly as body_prepare derives it), then the penetration query into `slot`
-// (gj::speculate_pen_depth).  All 64 lanes carry the same pair.
-DEV void pair_speculate(const Ctx &c, int p, int lds_hull_off, int *slot, int epoch) {
+// The urgent list's entry (pair p of c's environment) for its speculation block (env_kernels.hip: narrow_block): the two shapes exactly
+// as pair_item builds them, then the penetration query into `slot` (gj::speculate_pen_depth).  No box test, no early exit.
+DEV void pair_speculate(const Ctx &c, int p, int lds_hull_off, int *slot) {
     const EvmPairC &PC = c_skel.pair[p];
     const int a = PC.a, b = PC.b;
     const EvmMemberC &MA = c_skel.member[a], &MB = c_skel.member[b];
@@ -240,42 +236,9 @@ DEV void pair_speculate(const Ctx &c, int p, int lds_hull_off, int *slot, int ep
     SA.ks = SB.ks = c.d.stamps;
 #endif
     SA.o = G3(pos, 3 * a); SB.o = G3(pos, 3 * b);
-    SA.R = mat_from_quat(q4(GS(quat, 4 * a), GS(quat, 4 * a + 1), GS(quat, 4 * a + 2), GS(quat, 4 * a + 3)));
-    SB.R = mat_from_quat(q4(GS(quat, 4 * b), GS(quat, 4 * b + 1), GS(quat, 4 * b + 2), GS(quat, 4 * b + 3)));
-    gj::speculate_pen_depth(SA, SB, lds_hull_off, slot, epoch);
-}
-
-// ... and the pairs no previous step can flag: in the rollout form nine out of ten unflagged penetration queries belong to ONE step of
-// an episode's start — the first whose poses come from the integrated state after reset()'s own step (settle_steps - settle_left == 2:
-// tools/diag_pen.py), where members that the reset pose leaves interpenetrating meet.  k_speculate's first blocks look for them the way
-// the next step's broadphase will (core boxes overlapping along all six face normals, no cached point), on the poses this step left:
-// all 64 lanes take the pairs of environment c.env between them; every hit gets a slot (after the list's: cnt0 + a counter of its
-// own), the slot's number goes into the pair's count word where the urgent block will look for it, and the entry is published (entry,
-// then its epoch tag) for the block of k_speculate that has been waiting for it.
-DEV void env_speculate(const Ctx &c, int cnt0, int *L, int epoch) {
-    const int lane = (int) (threadIdx.x & 63);
-    for (int p0 = 0; p0 < c_skel.npair; p0 += 64) {
-        const int p = p0 + lane;
-        bool hit = false;
-        if (p < c_skel.npair && c.t.pmn[(p << 6) + c.lane] == 0) {
-            const int a = c_skel.pair[p].a, b = c_skel.pair[p].b;
-            const M33 Ra = mat_from_quat(q4(GS(quat, 4 * a), GS(quat, 4 * a + 1), GS(quat, 4 * a + 2), GS(quat, 4 * a + 3)));
-            const M33 Rb = mat_from_quat(q4(GS(quat, 4 * b), GS(quat, 4 * b + 1), GS(quat, 4 * b + 2), GS(quat, 4 * b + 3)));
-            F3 ca, ea, cb, eb;
-            member_box(c_skel.member[a], Ra, G3(pos, 3 * a), ca, ea);
-            member_box(c_skel.member[b], Rb, G3(pos, 3 * b), cb, eb);
-            const bool near = fabsf(ca.x - cb.x) <= ea.x + eb.x && fabsf(ca.y - cb.y) <= ea.y + eb.y && fabsf(ca.z - cb.z) <= ea.z + eb.z;
-            hit = near && core_box_gap(c_skel.member[a], c_skel.member[b], Ra, Rb, cb - ca) < 0.f;
-        }
-        if (hit) {
-            const int k = atomicAdd(L + 1, 1), at = cnt0 + k;
-            if (k < EVM_SPEC_EXTRA && at < EVM_SPEC_SLOTS) {
-                __hip_atomic_fetch_or(&c.t.pmn[(p << 6) + c.lane], (at + 1) << 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(L + 16 + at, (p << 20) | c.env, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(L + 16 + EVM_SPEC_SLOTS + at, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    }
+    SA.R = m33(SC3(c_skel.sc_r + 9 * a), SC3(c_skel.sc_r + 9 * a + 3), SC3(c_skel.sc_r + 9 * a + 6));
+    SB.R = m33(SC3(c_skel.sc_r + 9 * b), SC3(c_skel.sc_r + 9 * b + 3), SC3(c_skel.sc_r + 9 * b + 6));
+    gj::speculate_pen_depth(SA, SB, lds_hull_off, slot, c.d.spec_epoch);
 }
 
 // one pair for one env per lane (any envs: the narrowphase kernel's compacted work list): narrowphase, manifold
@@ -284,7 +247,7 @@ DEV void env_speculate(const Ctx &c, int cnt0, int *L, int epoch) {
 // SOLO: all 64 lanes carry the same (pair, env) — the urgent list's blocks: the penetration-depth solver then has the whole
 // wavefront for its parallel parts; every lane stores the same values to the same addresses, lane 0 does the atomics.
 template <bool GROUP, bool SOLO = false>
-DEV void pair_item(const Ctx &c, int p, bool drop, int lds_hull_off = -1) {
+DEV void pair_item(const Ctx &c, int p, bool drop, int lds_hull_off = -1, int *spec = nullptr) {
     const bool lead = SOLO ? threadIdx.x == 0 : (!GROUP || (threadIdx.x & 15) == 0);
 #ifdef EVM_KSTAMPS  // (tools/kstamps.py) cycles of a working wavefront by phase; a mark waits for the outstanding memory traffic first
     unsigned long long ks_prev = __builtin_amdgcn_s_memtime();
@@ -307,12 +270,7 @@ DEV void pair_item(const Ctx &c, int p, bool drop, int lds_hull_off = -1) {
     SA.hull_off = MA.hull_off; SA.hull_n = MA.hull_n; SB.hull_off = MB.hull_off; SB.hull_n = MB.hull_n;
     SA.lds_hull_off = SB.lds_hull_off = lds_hull_off;
     SA.pen_count = SB.pen_count = c.d.errs + 2;
-    {   // (SOLO: the slot of the pair's speculative penetration query, if the previous step started one)
-        // (agent-scope load: k_speculate may have set the bits while this step's first kernel ran, from another XCD)
-        const int sl = SOLO ? EVM_PMN_SLOT(__hip_atomic_load(&PMN(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0;
-        SA.spec = SB.spec = (SOLO && !drop && sl > 0 && c.d.spec != nullptr) ? c.d.spec + (size_t) EVM_SPEC_WORDS * (sl - 1) : nullptr;
-        SA.spec_epoch = SB.spec_epoch = c.d.spec_epoch;
-    }
+    SA.spec = SB.spec = SOLO ? spec : nullptr; SA.spec_epoch = SB.spec_epoch = c.d.spec_epoch;   // (the slot of the entry's speculation block, narrow_dev.h)
 #ifdef EVM_KSTAMPS
     SA.ks = SB.ks = c.d.stamps;
 #endif
@@ -439,18 +397,7 @@ DEV void pair_item(const Ctx &c, int p, bool drop, int lds_hull_off = -1) {
         if (!(nraw_in & EVM_PMN_DEEP)) { const int k = c_skel.settle_steps - c.d.settle_left[c.env]; atomicAdd(&c.d.errs[14 + (k < 0 ? 0 : (k > 9 ? 9 : k))], 1); }
     }
 #endif
-    int slotbits = 0;
-    if (c.d.slist != nullptr && __any(deep)) {   // ... and its penetration query of the next step is started ahead of time (narrow_dev.h)
-        int *L = c.d.slist + c.d.pc_cur * EVM_SLIST_STRIDE;
-        int at = -1;
-        if (deep && lead) at = atomicAdd(L, 1);
-        at = SOLO ? __shfl(at, 0) : (GROUP ? __shfl(at, (int) (threadIdx.x & 63) & ~15) : at);
-        if (deep && at >= 0 && at < EVM_SPEC_SLOTS) {
-            if (lead) L[16 + at] = (p << 20) | c.env;
-            slotbits = (at + 1) << 16;
-        }
-    }
-    PMN(p) = n | (deep ? EVM_PMN_DEEP : 0) | slotbits;
+    PMN(p) = n | (deep ? EVM_PMN_DEEP : 0);
     if (SOLO) { UST(7) }
     KS_MARK(2)
     if (!__any(n > 0)) return;

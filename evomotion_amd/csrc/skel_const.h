@@ -13,12 +13,8 @@
 #define EVM_MAX_PAIRS (EVM_MAX_MEMBERS * (EVM_MAX_MEMBERS - 1) / 2)
 #define EVM_PC_STRIDE (EVM_MAX_PAIRS + 2)   // narrowphase work-list counters per copy: the pairs', the big-hull list's, the urgent list's
 #define EVM_DEEP_SOON_DEFAULT (-0.06f)  // EnvDev::deep_soon: distance (margins subtracted) below which a pair is expected to need the penetration solver next step (cores 2 cm apart)
-#define EVM_SPEC_SLOTS 256             // penetration queries started ahead of time per step (narrow_dev.h: speculate_pen_depth), one slot each
-#define EVM_SPEC_EXTRA 32              // ... of which at most this many for the entries k_speculate adds itself (episode-start pairs)
-#define EVM_SPEC_WORDS 64              // ints per slot
-// ints per copy of the list of pairs to start them for: [0] = entries the narrowphase wrote, [1] = entries k_speculate added itself,
-// [2] = k_speculate blocks that are done adding, [16 + k] = entry k = (pair << 20) | env, [16 + EVM_SPEC_SLOTS + k] = epoch once an ADDED entry k is in place
-#define EVM_SLIST_STRIDE (16 + 2 * EVM_SPEC_SLOTS)
+#define EVM_SPEC_SLOTS 256             // urgent-list entries whose penetration query a speculation block runs beside the pair's own query (narrow_dev.h), one slot each
+#define EVM_SPEC_WORDS 16              // ints per slot
 
 // per-constraint scratch strides (floats per env)
 // Constraint records in the scratch tile.  A record starts on a multiple of 4 slots and is stored in QUADS: fields
