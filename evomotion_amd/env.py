@@ -230,7 +230,7 @@ class VecRobotWalk:
         return int(out[0])
 
     def speculation_counters(self, clear=True):
-        """penetration queries run ahead of time for pairs that needed the solver in the previous step: (run, answers used, waits that ran out)"""
+        """the urgent list's speculation blocks (penetration queries run beside the pair's own query): (runs, answers used, waits that ran out)"""
         out = (ctypes.c_int * 3)()
         check(lib.evm_env_get_speculation_counters(self._h, out, 1 if clear else 0, self._stream()))
         return int(out[0]), int(out[1]), int(out[2])

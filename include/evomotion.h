@@ -162,11 +162,11 @@ int evm_env_get_errors(EvmEnv *env, int *h_out /* [2] */, int clear, void *strea
  * the previous step had predicted (they were worked on first, one per wavefront), h_out[2] = entries of that urgent list (predictions,
  * right or wrong).  Synchronises `stream`. */
 int evm_env_get_pair_counters(EvmEnv *env, int *h_out /* [3] */, int clear, void *stream);
-/* ... and of those predictions the ones taken one step further: a pair whose query went through the solver in the previous step has
- * its penetration query run AHEAD of time by a block of its own (the answer depends on the two transforms only), beside the pair's
- * set-up and GJK instead of after them.  h_out[0] = such queries run, h_out[1] = answers that were used, h_out[2] = waits for an
- * answer that ran out (the query was then run in place: slower, same result).  No reference counterpart (scheduling only).
- * Synchronises `stream`. */
+/* ... and the speculation blocks of that list: every entry is also taken by a block of its own that runs the pair's penetration query
+ * from the first cycle of the launch, beside the pair's set-up and GJK instead of after them (the answer depends on the two transforms
+ * only); the entry's owner asks for the answer or calls the run off.  h_out[0] = such runs, h_out[1] = answers that were used,
+ * h_out[2] = waits for an answer that ran out (the query was then run in place: slower, same result).  EVM_SPECULATE=0 in the
+ * environment turns the blocks off.  No reference counterpart (scheduling only).  Synchronises `stream`. */
 int evm_env_get_speculation_counters(EvmEnv *env, int *h_out /* [3] */, int clear, void *stream);
 /* Rollout counters since the last clear, summed over envs: h_out[0] = do_step transitions emitted by
  * evm_env_step_autoreset (the reset()'s own step and settle calls are not counted), h_out[1] = resets started. */

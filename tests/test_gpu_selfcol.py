@@ -268,10 +268,11 @@ def test_masked_reset_leaves_the_other_envs_untouched(torch_mod):
 
 
 def test_queries_started_ahead_of_time_change_nothing_but_the_schedule(torch_mod, monkeypatch):
-    """The penetration queries that k_speculate starts a step early (narrow_dev.h, "ahead of their turn": pairs the previous step flagged,
-    and the episode-start pairs it finds itself) are scheduling only: with EVM_SPECULATE=0 the same rollout — resets, settle steps,
-    flagged pairs and all — must come out bit for bit, observations every step and the full state blob at the end.  And the path
-    must have been exercised: answers were used, and none was refused (inputs that differ) or waited for in vain."""
+    """The urgent list's speculation blocks (narrow_dev.h: every urgent entry's penetration query is also run by a block of its own from the
+    first cycle of the launch; the entry's owner takes the answer or calls the run off) are scheduling only: with EVM_SPECULATE=0 the
+    same rollout — resets, settle steps, flagged pairs and all — must come out bit for bit, observations every step and the full state
+    blob at the end.  And the path must have been exercised: every predicted solver query took its answer from a speculation block,
+    and no wait ran out."""
     torch = torch_mod
     n, steps = 512, 260
 
@@ -293,9 +294,9 @@ def test_queries_started_ahead_of_time_change_nothing_but_the_schedule(torch_mod
 
     o1, s1, q1, c1, e1 = run(True)
     o0, s0, q0, c0, e0 = run(False)
-    print("solver queries %d; started ahead of time %d, answers used %d, not usable %d" % ((q1,) + c1))
+    print("solver queries %d; speculation runs %d, answers used %d, waits run out %d" % ((q1,) + c1))
     assert c0 == (0, 0, 0) and q0 == q1 > 20
-    assert c1[1] >= q1 // 2, "most solver queries of a rollout are flagged a step ahead or belong to an episode's start"
+    assert c1[1] >= (9 * q1) // 10, "solver queries are predicted (urgent list) all but once in a few hundred: each of those has its speculation block"
     assert c1[2] == 0
     assert e1 == e0 == (0, 0)
     assert np.array_equal(o1, o0), int((o1 != o0).sum())

@@ -11,7 +11,7 @@ for v in ${1:--0.06 -0.03 0.0}; do
   rm -rf $O/prof_ab
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_ab -o run -- python3 $R/bench.py --steps 256 --warmup 64 --no-cpu-baseline --self-collision 1 > $O/prof_ab.log 2>&1 || exit 1
   f=$(find $O/prof_ab -name '*kernel_stats.csv' | head -1)
-  grep -E "k_split_pairs_rec<7>|k_speculate|k_sweeps_g|k_split_pre_a" $f | cut -d, -f1-4,6,7 | cut -c1-160
+  grep -E "k_split_pairs_rec<7>|k_sweeps_g|k_split_pre_a" $f | cut -d, -f1-4,6,7 | cut -c1-160
   grep -o '"value": [0-9.]*' $O/prof_ab.log | head -1
 done
 rm -rf $O/prof_ab

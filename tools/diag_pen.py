@@ -1,5 +1,9 @@
+"""Where the penetration-solver queries of a rollout come from (GPU box, a library built with `make -C evomotion_amd/csrc EXTRA=-DEVM_DIAG_PEN`):
+by origin (reset starting, pending, flagged by the previous step, other) and, for the unflagged ones, by the settle step of the episode's start
+they fall in.  python tools/diag_pen.py"""
 import sys, ctypes, torch
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from evomotion_amd import VecRobotWalk
 from evomotion_amd._lib import lib, check
 n = 4096

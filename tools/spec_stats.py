@@ -1,5 +1,8 @@
+"""Per step over 400 random-action rollout steps of 4096 envs: penetration-solver queries, how many the urgent list predicted, and what the
+speculation blocks did (runs, answers used, waits that ran out).  GPU box: python tools/spec_stats.py"""
 import sys, torch
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from evomotion_amd import VecRobotWalk
 n = 4096
 env = VecRobotWalk(n, seed=1234); env.reset(); env.stagger_episodes()
