@@ -43,7 +43,7 @@ PREROLL_CALLS = int(os.environ.get("EVM_BENCH_PREROLL", "2048"))
 
 # the PMC profile of THIS build's kernels, per collision mode (profiles/<tag>_traffic.json, written by tools/profile_round.sh +
 # tools/traffic_json.py): named explicitly — the newest file by sort order need not be the current build's
-TRAFFIC_PROFILE = {1: "r4y_traffic.json", 0: "r4y0_traffic.json"}
+TRAFFIC_PROFILE = {1: "r4z_traffic.json", 0: "r4z0_traffic.json"}
 
 
 def measured_traffic(n, self_collision=0):
@@ -257,6 +257,9 @@ def launch_ranks(n_ranks, argv, worker=None, timeout=None, log_dir=None):
                         rc, failed = code, r
             if rc:
                 break
+            if out0 is None and 0 not in pending:
+                # rank 0 ended between the timed-out communicate() above and the poll(): what it printed is still in the pipe
+                out0, _ = procs[0].communicate()
             if timeout and time.time() - t0 > timeout:
                 rc, failed = 124, None
                 break
