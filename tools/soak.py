@@ -25,6 +25,9 @@ errs = env.errors()   # (version waits that timed out, manifolds left out of a s
 print("dynamics: %d calls x %d envs in %.1f s, stats %s, worst batch residual %.3g, error counters %s, member pairs %d"
       % (n_dyn, n, time.time() - t0, episodes, worst_res, errs, env.n_pairs))
 assert errs[0] == 0, errs
+q = env.penetration_queries(); sp = env.speculation_counters()
+print("penetration-solver queries %d (predicted %d); speculation blocks: %d runs, %d answers used, %d waits ran out" % (q, env.predicted_penetration_queries, sp[0], sp[1], sp[2]))
+assert sp[2] == 0, sp
 agent = VecPpoGaeAgent(7, [env.state_dim], [env.action_dim], hidden_size=256, device=0, horizon=32, epoch=8, learning_rate=3e-4)
 t0 = time.time(); updates = 0
 for k in range(n_ppo // 32):
