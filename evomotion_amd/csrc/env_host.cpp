@@ -653,7 +653,7 @@ int evm_env_get_speculation_counters(EvmEnv *env, int *h_out, int clear, void *s
     if (!env || !h_out) return fail(EVM_E_INVALID, "null argument");
     hipStream_t s = (hipStream_t) stream;
 #ifdef EVM_DIAG_PEN
-    const int nspec = 19;   // + [3..8]: solver queries by origin: reset starting, pending, flagged by the previous step, other with / without cached points; in a settle step
+    const int nspec = 30;   // + [3..8]: solver queries by origin: reset starting, pending, flagged by the previous step, other with / without cached points; in a settle step
 #else
     const int nspec = 3;
 #endif

@@ -397,7 +397,17 @@ DEV void pair_item(const Ctx &c, int p, bool drop, int lds_hull_off = -1, int *s
         if (!(nraw_in & EVM_PMN_DEEP)) { const int k = c_skel.settle_steps - c.d.settle_left[c.env]; atomicAdd(&c.d.errs[14 + (k < 0 ? 0 : (k > 9 ? 9 : k))], 1); }
     }
 #endif
+#ifdef EVM_DIAG_PEN
+    if (GROUP && !SOLO && lead && any_overlap && overlap) {   // big-hull queries: GJK iterations, and how well the previous step's count predicts them
+        const int it = r.iterations, prev = (nraw_in >> 9) & 31;
+        atomicAdd(&c.d.errs[24 + (it / 4 > 7 ? 7 : it / 4)], 1);
+        if (it >= 12) { atomicAdd(&c.d.errs[32], 1); if (prev >= 10) atomicAdd(&c.d.errs[33], 1); }
+        if (prev >= 10) atomicAdd(&c.d.errs[34], 1);
+    }
+    PMN(p) = n | (deep ? EVM_PMN_DEEP : 0) | ((r.iterations > 31 ? 31 : r.iterations) << 9);
+#else
     PMN(p) = n | (deep ? EVM_PMN_DEEP : 0);
+#endif
     if (SOLO) { UST(7) }
     KS_MARK(2)
     if (!__any(n > 0)) return;
