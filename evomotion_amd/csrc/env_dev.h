@@ -51,6 +51,7 @@ struct EnvDev {
     const EvmGSchedC *gs;           // lane-group sweep schedule (device copy), or null: the 64-env tile sweeps kernel runs
     int g_waves, g_lds;             // waves per 16-env workgroup and dynamic LDS bytes of k_sweeps_g
     int *spec;                      // [EVM_SPEC_SLOTS][EVM_SPEC_WORDS] slots of the urgent list's speculation blocks (narrow_dev.h); null: none
+    float gap_soon;                 // core-box separation below which a pair without cached points goes to the urgent list (EVM_GAP_SOON; 0: the boxes overlap)
     float deep_soon;                // distance below which a pair goes to the next step's urgent list (EVM_DEEP_SOON)
     int spec_epoch;                 // this launch's epoch (the host counts the steps; never 0): a slot's answer is for exactly one launch
 };

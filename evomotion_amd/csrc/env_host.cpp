@@ -169,6 +169,7 @@ int evm_env_create(const char *skeleton_path, int n_envs, int device, uint64_t s
     hipEventCreate(&env->ev0);
     hipEventCreate(&env->ev1);
     env->spec_mem = nullptr;
+    { const char *gs = getenv("EVM_GAP_SOON"); env->d.gap_soon = gs ? (float) atof(gs) : 0.f; }
     { const char *ds = getenv("EVM_DEEP_SOON"); env->d.deep_soon = ds ? (float) atof(ds) : EVM_DEEP_SOON_DEFAULT; }   // (scheduling only: A/B runs)
     {
         // member-vs-member contacts: the slots of the urgent list's speculation blocks (EVM_SPECULATE=0 turns them off: A/B runs; the

@@ -194,7 +194,7 @@ DEV void pair_broadphase(const Ctx &c, int p, bool drop, const M33 &Ra, F3 oa, c
         // ... and the other end of the same test: core boxes that overlap along all six face normals (a pair that starts out
         // interpenetrating, typically in the step after a reset, where no history can flag it) will most likely need the
         // penetration solver: urgent list
-        if (n == 0 && near && gap < 0.f) urgent = true;
+        if (n == 0 && near && gap < c.d.gap_soon) urgent = true;
     }
     const bool need_any = n > 0 || near;
     if (!need_any && nraw != 0 && !drop) PMN(p) = 0;   // (no query this step: scheduling hints of the previous one — flag, slot — end here)
