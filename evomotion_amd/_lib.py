@@ -77,6 +77,7 @@ def _load():
     lib.evm_policy_set_weights.argtypes = [vp, fp, ctypes.c_size_t, fp, ctypes.c_size_t]
     lib.evm_policy_set_weights_device.argtypes = [vp, vp, vp, vp]
     lib.evm_policy_forward.argtypes = [vp, ctypes.c_int, vp, vp, ctypes.c_uint64, vp, vp, vp, vp, vp, vp]
+    lib.evm_policy_set_tile_rows.argtypes = [vp, ctypes.c_int]
     lib.evm_policy_timing_begin.argtypes = [vp]
     lib.evm_policy_timing_end.argtypes = [vp, vp, fp, ip]
     lib.evm_replay_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(vp)]

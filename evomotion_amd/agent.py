@@ -134,6 +134,10 @@ class FusedActorCritic:
         except Exception:
             pass
 
+    def set_tile_rows(self, rows):
+        """0 = per launch (32-row tiles unless they would leave CUs idle, then 16-row tiles), 16 / 32 = that form always."""
+        check(lib.evm_policy_set_tile_rows(self._h, rows))
+
     def timing_begin(self):
         check(lib.evm_policy_timing_begin(self._h))
 

@@ -235,6 +235,172 @@ __device__ __forceinline__ void head_gemm(const float *hb, const float *__restri
     for (int r = 0; r < 16; r++) hs4[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = hacc[r];
 }
 
+// ---- 16-row tiles on v_mfma_f32_16x16x4_f32 (rollout forward when 32-row tiles would leave CUs without a workgroup) ----
+// Lane l = (c = l & 15, kq = l >> 4) supplies A[row c][k] and B[k][col c] of one k per step.  The k-split operand layouts
+// above serve unchanged: a lane's 16-byte slot (s4 = 2 j + (kq >> 1), h = kq & 1) holds k = 8 s4 + h + 2 t for t = 0 .. 3,
+// so ONE ds_read_b128 / global_load_dwordx4 per lane feeds four MFMA steps, and step t of block pair j contracts
+// k in {16 j + 2 t, + 1, + 8, + 9}: every k once, in an order of its own (fp32 sums agree with the 32-row form to rounding,
+// not bit for bit).  C/D layout: col = l & 15, row = 4 (l >> 4) + reg.
+typedef float f32x4c __attribute__((ext_vector_type(4)));
+
+// Wave `wave` of four owns 16 rows x 64 columns = 4 accumulator tiles (columns wave * 64 + 16 j + c).
+// The weight ring is the caller's: dense16_prefetch requests the first DEPTH16 - 1 block pairs (they depend on nothing the
+// workgroup computes), so a caller issues it BEFORE the phase that produces the A tile (staging, the previous layer's
+// epilogue) and the layer starts on operands that are already there instead of on a cold L2 round trip.
+#define DEPTH16 4
+__device__ __forceinline__ const float *dense16_bptr(const float *__restrict__ Wp, int wave, int lane) {
+    const int c = lane & 15, kq = lane >> 4;
+    return Wp + ((size_t) (kq >> 1) * 256 + wave * 64 + c) * 8 + (kq & 1) * 4;  // Wp[s4][col][h][t]: ((s4 * 256 + col) * 2 + h) * 4
+}
+__device__ __forceinline__ void dense16_prefetch(const float *__restrict__ Wp, int wave, int lane, f32x4 (&b)[DEPTH16][4]) {
+    const float *bp = dense16_bptr(Wp, wave, lane);
+#pragma unroll
+    for (int q = 0; q < DEPTH16 - 1; q++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) b[q][j] = *reinterpret_cast<const f32x4 *>(bp + (size_t) q * 4096 + j * 128);
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int K>
+__device__ __forceinline__ void dense_layer16(const float *as, int ald, const float *__restrict__ Wp, int wave, int lane,
+                                              f32x4c (&acc)[4], f32x4 (&b)[DEPTH16][4]) {
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc[j][r] = 0.f;
+    const int c = lane & 15, kq = lane >> 4;
+    constexpr int KH = K / 2;
+    const float *ap = as + c * ald + (kq & 1) * KH + 4 * (kq >> 1);
+    const float *bp = dense16_bptr(Wp, wave, lane);
+    constexpr int NB = K / 16;  // block pairs
+    constexpr int DEPTH = DEPTH16;
+    static_assert(NB % DEPTH == 0, "K / 16 must be a multiple of the ring depth");
+    f32x4 a[DEPTH];
+#pragma unroll
+    for (int q = 0; q < DEPTH - 1; q++) a[q] = *reinterpret_cast<const f32x4 *>(ap + 8 * q);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int s0 = 0; s0 < NB; s0 += DEPTH) {
+#pragma unroll
+        for (int q = 0; q < DEPTH; q++) {
+            const int sn = min(s0 + q + DEPTH - 1, NB - 1);
+            const int qn = (q + DEPTH - 1) % DEPTH;
+            a[qn] = *reinterpret_cast<const f32x4 *>(ap + 8 * sn);
+#pragma unroll
+            for (int j = 0; j < 4; j++) b[qn][j] = *reinterpret_cast<const f32x4 *>(bp + (size_t) sn * 4096 + j * 128);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q][t], b[q][j][t], acc[j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// sum over the 16 lanes of each DPP row, result in every lane of the row
+__device__ __forceinline__ float row16_sum(float v) {
+#define EVM_DPP_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false));
+    EVM_DPP_ADD(0xB1)
+    EVM_DPP_ADD(0x4E)
+    EVM_DPP_ADD(0x141)
+    EVM_DPP_ADD(0x140)
+#undef EVM_DPP_ADD
+    return v;
+}
+
+// mish_ln_epilogue for the 16-row accumulator layout (rollout only: nothing goes to HBM).  red: 256 floats
+// ([16 rows][4 waves][2] partials, then [4 waves][16 rows][2] results).
+// this lane's bias / LayerNorm weight / LayerNorm bias of its four columns: requested ahead of the GEMM by the caller
+struct LnParams16 { float bi[4], ga[4], be[4]; };
+__device__ __forceinline__ LnParams16 ln_params16(const float *__restrict__ bias, const float *__restrict__ gamma,
+                                                  const float *__restrict__ beta, int wave, int lane) {
+    LnParams16 P;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int col = wave * 64 + 16 * j + (lane & 15);
+        P.bi[j] = bias[col]; P.ga[j] = gamma[col]; P.be[j] = beta[col];
+    }
+    return P;
+}
+__device__ __forceinline__ void mish_ln_epilogue16(f32x4c (&acc)[4], const LnParams16 &P, float *hb, float *red, int wave, int lane) {
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    const int c = lane & 15, kq = lane >> 4;
+    const float (&bi)[4] = P.bi, (&ga)[4] = P.ga, (&be)[4] = P.be;
+    float s[4], q[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[j][r] = mish_f(acc[j][r] + bi[j]);
+        s[r] = row16_sum((acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r])) * (1.0f / 64.0f);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const float d0 = acc[0][r] - s[r], d1 = acc[1][r] - s[r], d2 = acc[2][r] - s[r], d3 = acc[3][r] - s[r];
+        q[r] = row16_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+    }
+    if (c == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) *reinterpret_cast<f32x2_ *>(red + ((4 * kq + r) * 4 + wave) * 2) = f32x2_{s[r], q[r]};
+    }
+    lds_barrier();
+    float *mine = red + 128 + wave * 32;  // this wave's [16 rows][mean, rstd]
+    {
+        const f32x4 p0 = *reinterpret_cast<const f32x4 *>(red + c * 8), p1 = *reinterpret_cast<const f32x4 *>(red + c * 8 + 4);
+        const float mean = ((p0[0] + p0[2]) + (p1[0] + p1[2])) * 0.25f;
+        const float da = p0[0] - mean, db = p0[2] - mean, dc = p1[0] - mean, dd = p1[2] - mean;
+        const float m2 = ((p0[1] + p0[3]) + (p1[1] + p1[3])) + 64.0f * ((da * da + db * db) + (dc * dc + dd * dd));
+        const float rstd = 1.0f / sqrtf(m2 * (1.0f / 256.0f) + 1e-5f);
+        if (kq == 0) *reinterpret_cast<f32x2_ *>(mine + c * 2) = f32x2_{mean, rstd};
+    }
+    // (LDS operations of one wave complete in order: the reads below see this wave's line without a barrier)
+    const f32x4 ma = *reinterpret_cast<const f32x4 *>(mine + 8 * kq), mb = *reinterpret_cast<const f32x4 *>(mine + 8 * kq + 4);
+    const float mean[4] = {ma[0], ma[2], mb[0], mb[2]}, rstd[4] = {ma[1], ma[3], mb[1], mb[3]};
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            hb[HIDX(4 * kq + r, wave * 64 + 16 * j + c)] = (acc[j][r] - mean[r]) * rstd[r] * ga[j] + be[j];
+    lds_barrier();
+}
+#define EVM_RED16_FLOATS 256
+
+// head GEMM [16 x 256] x [256 x 32] for the 16-row tile: K split over the four waves (64 each), two 16-column tiles;
+// wave w leaves its partial in hs4[w][row 0..15][col 0..31]
+struct HeadB16 { f32x4 b0[4], b1[4]; };
+__device__ __forceinline__ HeadB16 head16_prefetch(const float *__restrict__ whp, int wave, int lane) {
+    HeadB16 H;
+    const int c = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int s4 = 8 * wave + 2 * j + (kq >> 1);
+        H.b0[j] = *reinterpret_cast<const f32x4 *>(whp + ((size_t) (s4 * 32 + c) * 2 + (kq & 1)) * 4);
+        H.b1[j] = *reinterpret_cast<const f32x4 *>(whp + ((size_t) (s4 * 32 + 16 + c) * 2 + (kq & 1)) * 4);
+    }
+    return H;
+}
+__device__ __forceinline__ void head_gemm16(const float *hb, const HeadB16 &H, float *hs4, int wave, int lane) {
+    f32x4c h0 = {0.f, 0.f, 0.f, 0.f}, h1 = {0.f, 0.f, 0.f, 0.f};
+    const int c = lane & 15, kq = lane >> 4;
+    f32x4 a4[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int s4 = 8 * wave + 2 * j + (kq >> 1);
+        a4[j] = *reinterpret_cast<const f32x4 *>(hb + c * ALD2 + (kq & 1) * 128 + 4 * s4);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            h0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[j][t], H.b0[j][t], h0, 0, 0, 0);
+            h1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[j][t], H.b1[j][t], h1, 0, 0, 0);
+        }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        hs4[(wave * 16 + 4 * kq + r) * 32 + c] = h0[r];
+        hs4[(wave * 16 + 4 * kq + r) * 32 + 16 + c] = h1[r];
+    }
+}
+
 // stage a TM_ x S tile of a row-major [n][S] matrix, zero padded to K1 columns, k-split in LDS (row stride ALD1)
 template <int TM_>
 __device__ __forceinline__ void stage_rows_ksplit(float *xs, const float *__restrict__ obs, int row0, int n, int S) {

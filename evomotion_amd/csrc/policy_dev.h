@@ -86,13 +86,14 @@ size_t policy_lds_bytes();
 hipError_t launch_policy_pack(const NetDev &n, int S, int A, bool actor, const float *flat, hipStream_t s);
 hipError_t launch_policy_forward(const PolicyDev &p, int n, const float *obs, const float *uniform, uint64_t seed,
                                  uint64_t counter, float *action, float *logp, float *value, float *mu, float *sigma,
-                                 hipStream_t s);
+                                 hipStream_t s, int tile_rows = 0);
 
 }  // namespace evm
 
 // the handle behind evm_policy_* (policy_host.cpp); the PPO trainer (ppo_host.cpp) repacks its weights
 struct EvmPolicy {
     int S, A, H, K1pad, device;
+    int tile_rows;  // 0 = chosen per launch, 16 / 32 forced (evm_policy_set_tile_rows)
     float *arena;
     size_t arena_floats;
     evm::PolicyDev dev;

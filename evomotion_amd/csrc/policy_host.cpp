@@ -27,7 +27,7 @@ int evm_policy_create(int state_dim, int action_dim, int hidden_size, int device
     if (state_dim < 1 || state_dim > 384 || action_dim < 1 || 2 * action_dim > 32) return pfail(EVM_E_INVALID, "unsupported state/action size");
     if (hipSetDevice(device) != hipSuccess) return pfail(EVM_E_HIP, "hipSetDevice failed");
     EvmPolicy *p = new EvmPolicy();
-    p->S = state_dim; p->A = action_dim; p->H = hidden_size; p->device = device; p->counter = 0; p->timing = false; p->ev_used = 0;
+    p->S = state_dim; p->A = action_dim; p->H = hidden_size; p->device = device; p->counter = 0; p->timing = false; p->ev_used = 0; p->tile_rows = 0;
     p->K1pad = 384;  // K1 of policy_kernels.hip
     const size_t per_net = (size_t) p->K1pad * 256 + 3 * 256 + 256 * 256 + 3 * 256;
     p->arena_floats = 2 * per_net + ((size_t) 2 * action_dim * 256 + 2 * action_dim) + (256 + 1) + 2 * 8192 + 4;
@@ -149,9 +149,16 @@ int evm_policy_forward(EvmPolicy *p, int n, const float *d_obs, const float *d_u
         (void) hipEventRecord(p->ev_pairs[p->ev_used].first, s);
     }
     hipError_t e = evm::launch_policy_forward(p->dev, n, d_obs, d_uniform, seed, p->counter++, d_action, d_logp, d_value,
-                                              d_mu, d_sigma, s);
+                                              d_mu, d_sigma, s, p->tile_rows);
     if (e != hipSuccess) return pfail(EVM_E_HIP, std::string("policy forward: ") + hipGetErrorString(e));
     if (p->timing) { (void) hipEventRecord(p->ev_pairs[p->ev_used].second, s); p->ev_used++; }
+    return EVM_OK;
+}
+
+int evm_policy_set_tile_rows(EvmPolicy *p, int rows) {
+    if (!p) return pfail(EVM_E_INVALID, "policy is null");
+    if (rows != 0 && rows != 16 && rows != 32) return pfail(EVM_E_INVALID, "tile rows: 0 (automatic), 16 or 32");
+    p->tile_rows = rows;
     return EVM_OK;
 }
 

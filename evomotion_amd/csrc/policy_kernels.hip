@@ -14,6 +14,7 @@
 // LayerNorm, the tanh/softplus heads, inverse-CDF sampling and the log-pdf are fused behind the GEMMs.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "policy_dev.h"
 #include "mlp_tile.h"
@@ -125,6 +126,103 @@ __global__ __launch_bounds__(PT) void k_policy_forward(PolicyDev p, int n, const
     }
 }
 
+// The same forward on 16-row tiles (v_mfma_f32_16x16x4_f32, mlp_tile.h): twice the workgroups of half the size.  Chosen by
+// launch_policy_forward when the 32-row grid would leave CUs without a workgroup (SAC's actor-only act() at 4096 rows: 128
+// workgroups on 256 CUs).  Same operand layouts, same outputs to rounding (another k order inside the fp32 sums).
+#define TM16 16
+#define POLICY_TILE16_FLOATS (TM16 * ALD1 > TM16 * ALD2 + 4 * 16 * 32 + TM16 * 32 ? TM16 * ALD1 : TM16 * ALD2 + 4 * 16 * 32 + TM16 * 32)
+
+__device__ __forceinline__ void sample_action(const PolicyDev &p, const float *hs, int row, int gr, int a,
+                                              const float *__restrict__ uniform, uint64_t seed, uint64_t counter, float *action,
+                                              float *logp, float *mu_out, float *sigma_out) {
+    const int A = p.A;
+    const float mu = tanhf(hs[row * 32 + a]);
+    const float sigma = softplus_f(hs[row * 32 + A + a]);
+    const float ss = fminf(fmaxf(sigma, 1e-6f), 1e6f);
+    const float al = fminf(fmaxf((-1.f - mu) / ss, -5.f), 5.f);
+    const float be = fminf(fmaxf((1.f - mu) / ss, -5.f), 5.f);
+    const float ta = theta_f(al), tb = theta_f(be);
+    const float u = uniform ? uniform[(size_t) gr * A + a] : rng_uniform(seed, counter, (uint32_t) gr, (uint32_t) a);
+    const float cdf = fminf(fmaxf(ta + u * (tb - ta), 0.f), 1.f);
+    const float inv = 1.41421356237309504880f * erfinvf(2.0f * cdf - 1.0f);
+    const float act = fminf(fmaxf(inv * ss + mu, -1.f), 1.f);
+    const float z = tb - ta;
+    const float q = (act - mu) / ss;
+    const float lp = -0.91893853320467274178f - logf(ss) - 0.5f * (q * q) - logf(z);
+    const size_t o = (size_t) gr * A + a;
+    action[o] = act;
+    logp[o] = lp;
+    if (mu_out) mu_out[o] = mu;
+    if (sigma_out) sigma_out[o] = sigma;
+}
+
+__global__ __launch_bounds__(PT) void k_policy_forward16(PolicyDev p, int n, const float *__restrict__ obs,
+                                                         const float *__restrict__ uniform, uint64_t seed, uint64_t counter,
+                                                         float *action, float *logp, float *value, float *mu_out,
+                                                         float *sigma_out) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *xs = sm;
+    float *hb = sm;
+    float *red = sm + POLICY_TILE16_FLOATS;
+    const int net = blockIdx.y;
+    const int row0 = blockIdx.x * TM16;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const NetDev &N = net == 0 ? p.actor : p.critic;
+    // every operand that does not depend on this workgroup's own results is requested a phase ahead of its use: the first
+    // weight blocks of a layer before the phase that produces its A tile, the epilogue's vectors before the GEMM
+    f32x4 ring[DEPTH16][4];
+#ifndef EVM_NO_PREFETCH16
+    dense16_prefetch(N.w1t, wave, lane, ring);
+    stage_rows_ksplit<TM16>(xs, obs, row0, n, p.S);
+    LnParams16 P = ln_params16(N.b1, N.g1, N.be1, wave, lane);
+    __syncthreads();
+    f32x4c acc[4];
+    dense_layer16<K1>(xs, ALD1, N.w1t, wave, lane, acc, ring);
+    dense16_prefetch(N.w2t, wave, lane, ring);
+    mish_ln_epilogue16(acc, P, hb, red, wave, lane);
+    P = ln_params16(N.b2, N.g2, N.be2, wave, lane);
+    dense_layer16<256>(hb, ALD2, N.w2t, wave, lane, acc, ring);
+    const HeadB16 HB = head16_prefetch(N.whp, wave, lane);
+    mish_ln_epilogue16(acc, P, hb, red, wave, lane);
+#else  // A/B build (tools/policy_tiles.py): every operand requested where it is used
+    stage_rows_ksplit<TM16>(xs, obs, row0, n, p.S);
+    __syncthreads();
+    f32x4c acc[4];
+    dense16_prefetch(N.w1t, wave, lane, ring);
+    dense_layer16<K1>(xs, ALD1, N.w1t, wave, lane, acc, ring);
+    LnParams16 P = ln_params16(N.b1, N.g1, N.be1, wave, lane);
+    mish_ln_epilogue16(acc, P, hb, red, wave, lane);
+    dense16_prefetch(N.w2t, wave, lane, ring);
+    dense_layer16<256>(hb, ALD2, N.w2t, wave, lane, acc, ring);
+    P = ln_params16(N.b2, N.g2, N.be2, wave, lane);
+    mish_ln_epilogue16(acc, P, hb, red, wave, lane);
+    const HeadB16 HB = head16_prefetch(N.whp, wave, lane);
+#endif
+    float *hs4 = sm + TM16 * ALD2;   // [4 waves][16 rows][32 cols] partial sums
+    float *hs = hs4 + 4 * 16 * 32;   // [16][32] pre-activations
+    head_gemm16(hb, HB, hs4, wave, lane);
+    __syncthreads();
+    const int A = p.A;
+    const int nout = net == 1 ? 1 : 2 * A;
+    for (int e = threadIdx.x; e < TM16 * 32; e += PT) {
+        const int row = e >> 5, o = e & 31;
+        if (o < nout)
+            hs[e] = ((hs4[e] + hs4[16 * 32 + e]) + (hs4[2 * 16 * 32 + e] + hs4[3 * 16 * 32 + e])) + N.bh[o];
+        (void) row;
+    }
+    __syncthreads();
+    if (net == 1) {
+        if (threadIdx.x < TM16 && row0 + (int) threadIdx.x < n) value[row0 + threadIdx.x] = hs[threadIdx.x * 32];
+        return;
+    }
+    for (int e = threadIdx.x; e < TM16 * A; e += PT) {  // (row, action) pairs dealt flat: 384 over 256 threads at A = 24
+        const int row = e / A, a = e - row * A;
+        if (row0 + row < n) sample_action(p, hs, row, row0 + row, a, uniform, seed, counter, action, logp, mu_out, sigma_out);
+    }
+}
+
+size_t policy_lds16_bytes() { return (size_t) (POLICY_TILE16_FLOATS + EVM_RED16_FLOATS) * sizeof(float); }
+
 // flat parameters of one network -> the operand layout of the forward kernel; one thread per source element
 __global__ __launch_bounds__(256) void k_policy_pack(NetDev n, int S, int A, int actor, const float *__restrict__ flat) {
     const size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x;
@@ -147,9 +245,30 @@ static bool &evm_attr_done_for_current_device() {
 
 size_t policy_lds_bytes() { return (size_t) (POLICY_TILE_FLOATS + EVM_RED_FLOATS) * sizeof(float); }
 
+// Tile height of a launch: 32 rows unless that grid would leave CUs without a workgroup (then 16 rows = twice the
+// workgroups); EVM_POLICY_TILE = 16 | 32 (read once) forces one form, for measurements.
+static int policy_tile_rows(int n, int nets, int asked) {
+    static int forced = -1, cus[64] = {};
+    if (asked == 16 || asked == 32) return asked;
+    if (forced < 0) {
+        const char *e = getenv("EVM_POLICY_TILE");
+        forced = e ? atoi(e) : 0;
+    }
+    if (forced == 16 || forced == 32) return forced;
+    int dev = 0;
+    (void) hipGetDevice(&dev);
+    dev = dev >= 0 && dev < 64 ? dev : 0;
+    if (!cus[dev]) {
+        int c = 0;
+        if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c < 1) c = 256;
+        cus[dev] = c;
+    }
+    return ((n + TM - 1) / TM) * nets < cus[dev] ? 16 : 32;
+}
+
 hipError_t launch_policy_forward(const PolicyDev &p, int n, const float *obs, const float *uniform, uint64_t seed,
                                  uint64_t counter, float *action, float *logp, float *value, float *mu, float *sigma,
-                                 hipStream_t s) {
+                                 hipStream_t s, int tile_rows) {
     bool &attr = evm_attr_done_for_current_device();
     if (!attr) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_policy_forward),
@@ -157,7 +276,13 @@ hipError_t launch_policy_forward(const PolicyDev &p, int n, const float *obs, co
         if (e != hipSuccess) return e;
         attr = true;
     }
-    dim3 grid((n + TM - 1) / TM, value ? 2 : 1);  // value == NULL: the critic network is not run (SAC's act)
+    const int nets = value ? 2 : 1;  // value == NULL: the critic network is not run (SAC's act)
+    if (policy_tile_rows(n, nets, tile_rows) == 16) {
+        hipLaunchKernelGGL(k_policy_forward16, dim3((n + TM16 - 1) / TM16, nets), dim3(PT), policy_lds16_bytes(), s, p, n, obs,
+                           uniform, seed, counter, action, logp, value, mu, sigma);
+        return hipGetLastError();
+    }
+    dim3 grid((n + TM - 1) / TM, nets);
     hipLaunchKernelGGL(k_policy_forward, grid, dim3(PT), policy_lds_bytes(), s, p, n, obs, uniform, seed, counter, action,
                        logp, value, mu, sigma);
     return hipGetLastError();

@@ -206,6 +206,11 @@ int evm_policy_set_weights_device(EvmPolicy *p, const float *d_actor, const floa
 int evm_policy_forward(EvmPolicy *p, int n, const float *d_obs, const float *d_uniform, uint64_t seed, float *d_action,
                        float *d_logp, float *d_value, float *d_mu, float *d_sigma, void *stream);
 
+/* Rows per workgroup tile of evm_policy_forward: 0 (default) = 32 rows on v_mfma_f32_32x32x2_f32 unless that grid would leave
+ * CUs without a workgroup, then 16 rows on v_mfma_f32_16x16x4_f32 (twice the workgroups: SAC's actor-only act() at 4096 rows);
+ * 16 / 32 force one form (measurements, tests).  The two forms agree to fp32 rounding (another k order), not bit for bit. */
+int evm_policy_set_tile_rows(EvmPolicy *p, int rows);
+
 int evm_policy_timing_begin(EvmPolicy *p);
 int evm_policy_timing_end(EvmPolicy *p, void *stream, float *ms_total, int *n_launches);
 

@@ -156,6 +156,44 @@ def test_actor_only_forward_is_the_same_actor(fused):
         assert torch.equal(r, o)
 
 
+def test_16_row_tiles_equal_32_row_tiles_to_rounding(fused, gold):
+    """evm_policy_set_tile_rows: the 16-row form (v_mfma_f32_16x16x4_f32; chosen by itself when the 32-row grid would leave
+    CUs idle, e.g. SAC's actor-only act at 4096 rows) against the 32-row form on full, ragged and single-row batches, both
+    networks and actor only; same draws (the built-in generator is keyed by row, not by tile) -> same actions to rounding.
+    Both forms are also held to the reference's golden vectors."""
+    import torch
+    f, pa, pc = fused
+    g = torch.Generator(device="cpu").manual_seed(77)
+    try:
+        for n in (1, 15, 16, 17, 333, 4096):
+            x = (torch.rand(n, 371, generator=g) * 2 - 1).cuda()
+            u = torch.rand(n, 12, generator=g).cuda()
+            for actor_only in (False, True):
+                f.set_tile_rows(32)
+                r32 = f.forward(x, uniform=u, want_dist=True, actor_only=actor_only)
+                f.set_tile_rows(16)
+                r16 = f.forward(x, uniform=u, want_dist=True, actor_only=actor_only)
+                names = ("action", "logp", "value", "mu", "sigma")
+                tol = {"action": 2e-4, "logp": 2e-4, "value": 2e-5, "mu": 5e-6, "sigma": 5e-6}
+                for name, a, b in zip(names, r32, r16):
+                    if a is None:
+                        assert b is None
+                        continue
+                    assert torch.isfinite(b).all()
+                    d = float((a - b).abs().max())
+                    assert d <= tol[name], (n, actor_only, name, d)
+        x = torch.from_numpy(gold["X"]).cuda()
+        u = torch.full((8, 12), 0.5, device="cuda")
+        for rows in (16, 32):
+            f.set_tile_rows(rows)
+            action, logp, value, mu, sigma = f.forward(x, uniform=u, want_dist=True)
+            np.testing.assert_allclose(mu.cpu().numpy(), gold["mu"], atol=2e-5)
+            np.testing.assert_allclose(sigma.cpu().numpy(), gold["sigma"], atol=2e-5, rtol=2e-5)
+            np.testing.assert_allclose(value.cpu().numpy()[:, None], gold["value"], atol=5e-5)
+    finally:
+        f.set_tile_rows(0)
+
+
 def test_device_side_weight_repack_equals_host_packing(fused):
     import torch
     from evomotion_amd import ActorModule, CriticModule, FusedActorCritic
