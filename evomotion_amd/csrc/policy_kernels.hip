@@ -127,8 +127,9 @@ __global__ __launch_bounds__(PT) void k_policy_forward(PolicyDev p, int n, const
 }
 
 // The same forward on 16-row tiles (v_mfma_f32_16x16x4_f32, mlp_tile.h): twice the workgroups of half the size.  Chosen by
-// launch_policy_forward when the 32-row grid would leave CUs without a workgroup (SAC's actor-only act() at 4096 rows: 128
-// workgroups on 256 CUs).  Same operand layouts, same outputs to rounding (another k order inside the fp32 sums).
+// launch_policy_forward while the 32-row grid has no more than one workgroup per CU (the 4096-row rollout: 256; SAC's
+// actor-only act(): 128 workgroups on 256 CUs).  Same operand layouts, same outputs to rounding (another k order inside the
+// fp32 sums).
 #define TM16 16
 #define POLICY_TILE16_FLOATS (TM16 * ALD1 > TM16 * ALD2 + 4 * 16 * 32 + TM16 * 32 ? TM16 * ALD1 : TM16 * ALD2 + 4 * 16 * 32 + TM16 * 32)
 
@@ -152,7 +153,9 @@ __device__ __forceinline__ void sample_action(const PolicyDev &p, const float *h
     const size_t o = (size_t) gr * A + a;
     action[o] = act;
     logp[o] = lp;
+#ifndef EVM_PSTAMPS
     if (mu_out) mu_out[o] = mu;
+#endif
     if (sigma_out) sigma_out[o] = sigma;
 }
 
@@ -171,19 +174,28 @@ __global__ __launch_bounds__(PT) void k_policy_forward16(PolicyDev p, int n, con
     // every operand that does not depend on this workgroup's own results is requested a phase ahead of its use: the first
     // weight blocks of a layer before the phase that produces its A tile, the epilogue's vectors before the GEMM
     f32x4 ring[DEPTH16][4];
+#ifdef EVM_PSTAMPS
+    unsigned long long ps_t[8];
+#endif
+    PSTAMP(0)
 #ifndef EVM_NO_PREFETCH16
     dense16_prefetch(N.w1t, wave, lane, ring);
     stage_rows_ksplit<TM16>(xs, obs, row0, n, p.S);
     LnParams16 P = ln_params16(N.b1, N.g1, N.be1, wave, lane);
     __syncthreads();
+    PSTAMP(1)
     f32x4c acc[4];
     dense_layer16<K1>(xs, ALD1, N.w1t, wave, lane, acc, ring);
+    PSTAMP(2)
     dense16_prefetch(N.w2t, wave, lane, ring);
     mish_ln_epilogue16(acc, P, hb, red, wave, lane);
+    PSTAMP(3)
     P = ln_params16(N.b2, N.g2, N.be2, wave, lane);
     dense_layer16<256>(hb, ALD2, N.w2t, wave, lane, acc, ring);
+    PSTAMP(4)
     const HeadB16 HB = head16_prefetch(N.whp, wave, lane);
     mish_ln_epilogue16(acc, P, hb, red, wave, lane);
+    PSTAMP(5)
 #else  // A/B build (tools/policy_tiles.py): every operand requested where it is used
     stage_rows_ksplit<TM16>(xs, obs, row0, n, p.S);
     __syncthreads();
@@ -211,6 +223,13 @@ __global__ __launch_bounds__(PT) void k_policy_forward16(PolicyDev p, int n, con
         (void) row;
     }
     __syncthreads();
+    PSTAMP(6)
+#ifdef EVM_PSTAMPS
+    if (net == 0 && mu_out && threadIdx.x == 0 && blockIdx.x < 256) {
+        unsigned long long *o = reinterpret_cast<unsigned long long *>(mu_out) + (size_t) blockIdx.x * 8;
+        for (int i = 0; i < 7; i++) o[i] = ps_t[i];
+    }
+#endif
     if (net == 1) {
         if (threadIdx.x < TM16 && row0 + (int) threadIdx.x < n) value[row0 + threadIdx.x] = hs[threadIdx.x * 32];
         return;
@@ -245,8 +264,10 @@ static bool &evm_attr_done_for_current_device() {
 
 size_t policy_lds_bytes() { return (size_t) (POLICY_TILE_FLOATS + EVM_RED_FLOATS) * sizeof(float); }
 
-// Tile height of a launch: 32 rows unless that grid would leave CUs without a workgroup (then 16 rows = twice the
-// workgroups); EVM_POLICY_TILE = 16 | 32 (read once) forces one form, for measurements.
+// Tile height of a launch: 16 rows while the 32-row grid has at most one workgroup per CU (measured at 4096 rows,
+// tools/policy_tiles.py: both networks 33.7 against 35.2 us, actor only 20.5 against 34.7 us; from two 32-row workgroups per
+// CU on the forms are level and the 32-row one reads each weight half as often); EVM_POLICY_TILE = 16 | 32 (read once)
+// forces one form, for measurements.
 static int policy_tile_rows(int n, int nets, int asked) {
     static int forced = -1, cus[64] = {};
     if (asked == 16 || asked == 32) return asked;
@@ -263,7 +284,7 @@ static int policy_tile_rows(int n, int nets, int asked) {
         if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c < 1) c = 256;
         cus[dev] = c;
     }
-    return ((n + TM - 1) / TM) * nets < cus[dev] ? 16 : 32;
+    return ((n + TM - 1) / TM) * nets <= cus[dev] ? 16 : 32;
 }
 
 hipError_t launch_policy_forward(const PolicyDev &p, int n, const float *obs, const float *uniform, uint64_t seed,

@@ -206,8 +206,9 @@ int evm_policy_set_weights_device(EvmPolicy *p, const float *d_actor, const floa
 int evm_policy_forward(EvmPolicy *p, int n, const float *d_obs, const float *d_uniform, uint64_t seed, float *d_action,
                        float *d_logp, float *d_value, float *d_mu, float *d_sigma, void *stream);
 
-/* Rows per workgroup tile of evm_policy_forward: 0 (default) = 32 rows on v_mfma_f32_32x32x2_f32 unless that grid would leave
- * CUs without a workgroup, then 16 rows on v_mfma_f32_16x16x4_f32 (twice the workgroups: SAC's actor-only act() at 4096 rows);
+/* Rows per workgroup tile of evm_policy_forward: 0 (default) = 16 rows on v_mfma_f32_16x16x4_f32 while 32-row tiles would give
+ * the device at most one workgroup per CU (up to 4096 rows with both networks, 8192 actor only), 32 rows on
+ * v_mfma_f32_32x32x2_f32 beyond;
  * 16 / 32 force one form (measurements, tests).  The two forms agree to fp32 rounding (another k order), not bit for bit. */
 int evm_policy_set_tile_rows(EvmPolicy *p, int rows);
 
