@@ -46,6 +46,16 @@ PREROLL_CALLS = int(os.environ.get("EVM_BENCH_PREROLL", "2048"))
 TRAFFIC_PROFILE = {1: "r4z_traffic.json", 0: "r4z0_traffic.json"}
 
 
+def policy_kernel_name(rows, nets, dev):
+    """The form evm_policy_forward picks for this batch (policy_kernels.hip, policy_tile_rows): 16-row tiles while 32-row
+    tiles give the device at most one workgroup per CU."""
+    import torch
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    if -(-rows // 32) * nets <= cus:
+        return "k_policy_forward16 (16-row tiles, v_mfma_f32_16x16x4_f32)"
+    return "k_policy_forward (32-row tiles, v_mfma_f32_32x32x2_f32)"
+
+
 def measured_traffic(n, self_collision=0):
     """HBM-side bytes per step of the dynamics pipeline, from the committed PMC profile of this build and workload
     (TRAFFIC_PROFILE; rocprofv3 cannot run inside the timed bench); None when the file is missing or the batch size or the
@@ -534,7 +544,7 @@ def main():
             pol_ms = ms_policy / n_policy
             tf = POLICY_FLOP_PER_ROW * n / (pol_ms * 1e-3) / 1e12
             out["roofline_policy"] = {"bound": "mfma", "achieved": tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                      "frac": tf / VALU_PEAK_TFLOPS, "traffic": None, "kernel": "k_policy_forward",
+                                      "frac": tf / VALU_PEAK_TFLOPS, "traffic": None, "kernel": policy_kernel_name(n, 2, dev),
                                       "launch_ms": pol_ms, "rows": n,
                                       "note": "50 launches after the timed region (not part of `value`); fp32-input MFMA, dense fp32 "
                                               "matrix peak; 654 848 GEMM FLOP per row"}
@@ -542,8 +552,9 @@ def main():
             pol_ms = ms_policy / n_policy
             tf = 333312.0 * n / (pol_ms * 1e-3) / 1e12  # actor 333 312 GEMM FLOP per act
             out["roofline_policy"] = {"bound": "mfma", "achieved": tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                      "frac": tf / VALU_PEAK_TFLOPS, "traffic": None, "kernel": "k_policy_forward (actor only)",
-                                      "launch_ms": pol_ms, "note": "fp32-input MFMA (v_mfma_f32_32x32x2_f32), dense fp32 matrix peak"}
+                                      "frac": tf / VALU_PEAK_TFLOPS, "traffic": None,
+                                      "kernel": policy_kernel_name(n, 1, dev) + ", actor only",
+                                      "launch_ms": pol_ms, "note": "fp32-input MFMA, dense fp32 matrix peak"}
             # replay ring: pure byte movement.  push = one rollout step of all envs read + written once; sample = per drawn
             # row state + next state + action + reward + done read and written once
             S_, A_ = env.state_dim, env.action_dim
@@ -563,8 +574,8 @@ def main():
             pol_ms = ms_policy / n_policy
             tf = POLICY_FLOP_PER_ROW * n / (pol_ms * 1e-3) / 1e12
             out["roofline_policy"] = {"bound": "mfma", "achieved": tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                      "frac": tf / VALU_PEAK_TFLOPS, "traffic": None, "kernel": "k_policy_forward",
-                                      "launch_ms": pol_ms, "note": "fp32-input MFMA (v_mfma_f32_32x32x2_f32), dense fp32 matrix peak"}
+                                      "frac": tf / VALU_PEAK_TFLOPS, "traffic": None, "kernel": policy_kernel_name(n, 2, dev),
+                                      "launch_ms": pol_ms, "note": "fp32-input MFMA, dense fp32 matrix peak"}
         if agent is not None and ppo_epochs:
             ep_ms = ppo_ms / ppo_epochs
             rows = n * args.horizon

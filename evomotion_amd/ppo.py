@@ -76,6 +76,7 @@ class FusedPpoTrainer:
         check(lib.evm_ppo_grad_buffer(self._h, None, ctypes.byref(gp), ctypes.byref(gn), ctypes.byref(go)))
         self.grad_floats, self.critic_grad_offset = gn.value, go.value
         self._grads = None
+        self.compact_rows = True  # train(): run the epochs on the selected rows only (False: all rows, the mask zeroes the rest)
 
     def grad_buffer(self):
         """[grad_floats] device vector, actor gradients at 0, critic gradients at critic_grad_offset; owned by this object and
@@ -214,8 +215,20 @@ class FusedPpoTrainer:
         # bias corrections are one step ahead, which the reference cannot reach (it returns before training, ppo_gae.cpp:63-66)
         S, A = states.shape[-1], actions.shape[-1]
         st, ac, lp = states.reshape(T * N, S), actions.reshape(T * N, A), logp_old.reshape(T * N, A)
+        advf, retf, mk = adv.reshape(-1), ret.reshape(-1), mask_u8.reshape(-1)
+        if self.compact_rows and not torch.cuda.is_current_stream_capturing():
+            # Rows outside the mask (reset()'s settle calls and emissions: 40 % of a random-action rollout) weigh nothing in either
+            # loss, yet every epoch would push them through forward, backward and the weight-gradient GEMMs.  After GAE — which
+            # needs the time structure — the update is a sum over rows, so only the selected rows are kept (in their order: the
+            # sums see the same terms, grouped into other tiles).  Costs one host read of the local count per train() call.
+            idx = torch.nonzero(mk).squeeze(1)
+            nv = int(idx.numel())
+            if 0 < nv <= 0.97 * mk.numel():
+                st, ac, lp = st.index_select(0, idx), ac.index_select(0, idx), lp.index_select(0, idx)
+                advf, retf = advf.index_select(0, idx), retf.index_select(0, idx)
+                mk = torch.ones(nv, dtype=torch.uint8, device=self.device)
         for ep in range(epoch):
-            self.epoch(st, ac, lp, adv.reshape(-1), ret.reshape(-1), mask_u8.reshape(-1), n_glob, epsilon, entropy_factor,
+            self.epoch(st, ac, lp, advf, retf, mk, n_glob, epsilon, entropy_factor,
                        critic_loss_factor, learning_rate, clip_grad_norm, states_unchanged=ep > 0)
             if loss_hook is not None:
                 loss_hook(*self.losses())

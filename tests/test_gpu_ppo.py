@@ -321,6 +321,34 @@ def test_full_size_gradients_are_the_sum_of_their_halves():
     assert torch.equal(fa, fa2) and torch.equal(fc, fc2)
 
 
+def test_selected_rows_only_equals_all_rows_with_a_mask():
+    """FusedPpoTrainer.train() runs its epochs on the selected rows alone (compact_rows, the default); rows outside the mask weigh
+    nothing in either loss, so one epoch from the same weights must give the same gradients and losses as the pass over every row
+    with the mask (to rounding: the same terms, summed in other tiles) — here with 40 % of the rows unselected, a ragged last
+    tile, and the first / last rows unselected."""
+    import torch
+    from evomotion_amd import agent
+    T, N = 8, 500
+    states, actions, rewards, done, values, next_values, mask = _rollout(T, N, seed=11, p_invalid=0.4)
+    mask[0, :7] = 0
+    mask[-1, -9:] = 0
+    res = []
+    for compact in (False, True):
+        actor, critic = _modules(seed=5)
+        f, tr = _trainer(actor, critic, T * N)
+        tr.compact_rows = compact
+        with torch.no_grad():
+            mu, sigma = actor(states.reshape(T * N, 371))
+            logp = agent.truncated_normal_log_pdf(actions.reshape(T * N, 12), mu, sigma).reshape(T, N, 12) + 0.05
+        la, lc = tr.train(states, actions, rewards, done, logp, values, next_values, mask, epoch=1, learning_rate=1e-3, **HP)
+        res.append((la, lc, tr.vector(1, 0).clone(), tr.vector(1, 1).clone()))
+    (la0, lc0, ga0, gc0), (la1, lc1, ga1, gc1) = res
+    assert abs(la0 - la1) <= 2e-5 * max(1.0, abs(la0)) and abs(lc0 - lc1) <= 2e-5 * max(1.0, abs(lc0)), (la0, la1, lc0, lc1)
+    for g0, g1 in ((ga0, ga1), (gc0, gc1)):
+        assert float(g0.abs().max()) > 0
+        assert float((g0 - g1).abs().max()) <= 2e-5 * float(g0.abs().max()), float((g0 - g1).abs().max()) / float(g0.abs().max())
+
+
 def test_an_empty_selection_is_a_no_op_that_says_so():
     """a rollout whose mask selects no transition must not move anything.  The count of selected transitions stays on
     the device (no host read in the update), so the no-op happens there: after one real update (the Adam moments are non-zero:
