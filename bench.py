@@ -578,7 +578,9 @@ def main():
                                       "launch_ms": pol_ms, "note": "fp32-input MFMA, dense fp32 matrix peak"}
         if agent is not None and ppo_epochs:
             ep_ms = ppo_ms / ppo_epochs
-            rows = n * args.horizon
+            # the rows the epoch's kernels really worked on: the selected transitions of the rollout (FusedPpoTrainer.train keeps
+            # only those), not horizon x envs
+            rows = int(agent._trainer.last_rows) or n * args.horizon
             # GEMM FLOP of one epoch, both networks: forward 654 848 per row + backward: the Linear(256,256)
             # dgrad and the three weight-gradient GEMMs per network (no dgrad into the observations)
             S_, A_ = env.state_dim, env.action_dim
@@ -586,6 +588,7 @@ def main():
             tf = (POLICY_FLOP_PER_ROW + bwd) * rows / (ep_ms * 1e-3) / 1e12
             out["roofline_ppo_update"] = {"bound": "mfma", "achieved": tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                                           "frac": tf / VALU_PEAK_TFLOPS, "traffic": None, "launch_ms": ep_ms, "rows": rows,
+                                          "rollout_rows": n * args.horizon,
                                           "kernel": "k_ppo_forward + k_ppo_loss_* + k_ppo_backward + k_ppo_wgrad (x6) + reductions + k_ppo_adam: one epoch",
                                           "note": "HIP events around evm_ppo_grads .. evm_ppo_apply; fp32-input MFMA, dense fp32 matrix peak"}
         if not args.no_cpu_baseline and world == 1:

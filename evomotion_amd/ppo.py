@@ -76,6 +76,7 @@ class FusedPpoTrainer:
         check(lib.evm_ppo_grad_buffer(self._h, None, ctypes.byref(gp), ctypes.byref(gn), ctypes.byref(go)))
         self.grad_floats, self.critic_grad_offset = gn.value, go.value
         self._grads = None
+        self.last_rows = 0
         self.compact_rows = True  # train(): run the epochs on the selected rows only (False: all rows, the mask zeroes the rest)
 
     def grad_buffer(self):
@@ -161,6 +162,7 @@ class FusedPpoTrainer:
         call (later epochs of one train call), the trainer reuses its aligned copy"""
         rows = states.shape[0]
         assert rows <= self.max_rows
+        self.last_rows = rows  # what the epoch's kernels work on (bench.py prices its roofline on this)
         for t in (states, actions, logp_old, adv, returns, mask_u8):
             assert t.is_cuda and t.is_contiguous()
         s = self._stream()
