@@ -101,6 +101,9 @@ def _load():
     lib.evm_ppo_gae_normalize.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp]
     lib.evm_ppo_grads.argtypes = [vp, ctypes.c_size_t, vp, vp, vp, vp, vp, vp, ctypes.c_double, ctypes.c_float, ctypes.c_float,
                                   ctypes.c_float, ctypes.c_int, vp]
+    pvp = ctypes.POINTER(vp)
+    lib.evm_ppo_select_rows.argtypes = [vp, ctypes.c_size_t, vp, vp, vp, vp, vp, vp, ctypes.POINTER(ctypes.c_size_t), pvp, pvp, pvp, pvp,
+                                        pvp, pvp, vp]
     lib.evm_ppo_apply.argtypes = [vp, ctypes.c_float, ctypes.c_float, vp]
     lib.evm_ppo_losses.argtypes = [vp, dp, dp, vp]
     lib.evm_ppo_timing.argtypes = [vp, ctypes.c_int, fp, ip]

@@ -61,6 +61,11 @@ hipError_t launch_ppo_gae_scan(const PpoDev &d, int T, int N, const float *rewar
                                const float *next_values, const uint8_t *mask, float gamma, float lam, float *adv, hipStream_t s);
 hipError_t launch_ppo_gae_finish(int T, int N, const double *stats, const float *curr_values, const uint8_t *mask, float *adv,
                                  float *returns, hipStream_t s);
+// rows selected by mask (in order) gathered into dense copies; sel_idx / sel_count are trainer scratch
+hipError_t launch_ppo_select_scan(size_t rows, const uint8_t *mask, int *sel_idx, int *sel_count, hipStream_t s);
+hipError_t launch_ppo_select_gather(size_t n_sel, const int *sel_idx, int S, int A, const float *states, const float *actions,
+                                    const float *logp, const float *adv, const float *returns, float *o_states, float *o_actions,
+                                    float *o_logp, float *o_adv, float *o_returns, hipStream_t s);
 size_t ppo_wpart_floats();
 // generic pieces reused by the Q-network trainer (q_kernels.hip)
 //   C[i][j] = sum_m P[m][i] Q[m][j] (split-K MFMA, partials in `part`) -> dst[i * dst_ld + j (+ extra for i >= split_row)]

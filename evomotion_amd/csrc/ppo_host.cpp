@@ -21,6 +21,10 @@ struct EvmPpo {
     int n_timed;
     size_t staged_rows;  // rows of the observation copy made by the last evm_ppo_grads
     float *own_grads;    // the trainer's own contiguous [actor | critic] gradient vector (unless the caller supplied one)
+    // evm_ppo_select_rows (allocated at its first call): row numbers, count, dense copies of the selected rows, a mask of ones
+    int *sel_idx, *sel_count;
+    float *sel_states, *sel_actions, *sel_logp, *sel_adv, *sel_returns;
+    uint8_t *sel_mask;
 };
 
 static int qfail(int code, const std::string &m) { evm::set_last_error(m); return code; }
@@ -38,6 +42,7 @@ int evm_ppo_create(EvmPolicy *policy, size_t max_rows, EvmPpo **out) {
     q->have_params = false;
     q->timing = false; q->ms_acc = 0.f; q->n_timed = 0; q->staged_rows = 0;
     q->ev0 = q->ev1 = nullptr;
+    q->sel_idx = q->sel_count = nullptr; q->sel_states = q->sel_actions = q->sel_logp = q->sel_adv = q->sel_returns = nullptr; q->sel_mask = nullptr;
     evm::PpoDev &d = q->dev;
     d.S = policy->S; d.A = policy->A; d.max_rows = max_rows;
     bool ok = true;
@@ -225,6 +230,54 @@ int evm_ppo_grads(EvmPpo *q, size_t rows, const float *d_states, const float *d_
     if (e == hipSuccess) e = evm::launch_ppo_backward(p, q->dev, rows, s);
     if (e == hipSuccess) e = evm::launch_ppo_wgrads(q->dev, rows, d_states, s);
     if (e != hipSuccess) return qfail(EVM_E_HIP, std::string("ppo grads: ") + hipGetErrorString(e));
+    return EVM_OK;
+}
+
+// The selected rows of a rollout as dense copies owned by the trainer (valid until the next call): what evm_ppo_grads should be
+// given for every epoch of one update — rows = *n_selected, the returned pointers, states_unchanged from the second epoch on.
+// Reads the count back (one stream synchronisation per update).  *n_selected == 0: nothing was copied, the caller keeps its
+// own buffers (evm_ppo_grads then does its device-side no-op on the all-zero mask).
+int evm_ppo_select_rows(EvmPpo *q, size_t rows, const uint8_t *d_mask, const float *d_states, const float *d_actions,
+                        const float *d_logp_old, const float *d_adv, const float *d_returns, size_t *n_selected,
+                        const float **s_states, const float **s_actions, const float **s_logp_old, const float **s_adv,
+                        const float **s_returns, const uint8_t **s_mask, void *stream) {
+    if (!q || !d_mask || !d_states || !d_actions || !d_logp_old || !d_adv || !d_returns || !n_selected || !s_states || !s_actions ||
+        !s_logp_old || !s_adv || !s_returns || !s_mask)
+        return qfail(EVM_E_INVALID, "null argument");
+    if (rows < 1 || rows > q->dev.max_rows) return qfail(EVM_E_INVALID, "rows exceeds the trainer's capacity");
+    hipStream_t s = (hipStream_t) stream;
+    const evm::PpoDev &d = q->dev;
+    if (!q->sel_idx) {
+        if (hipSetDevice(q->policy->device) != hipSuccess) return qfail(EVM_E_HIP, "hipSetDevice failed");
+        bool ok = true;
+        auto alloc = [&](size_t bytes) -> void * {
+            void *p = nullptr;
+            if (!ok) return nullptr;
+            if (hipMalloc(&p, bytes) != hipSuccess) { ok = false; return nullptr; }
+            q->allocs.push_back(p);
+            return p;
+        };
+        const size_t m = d.max_rows;
+        int *idx = (int *) alloc(m * sizeof(int));
+        q->sel_count = (int *) alloc(sizeof(int));
+        q->sel_states = (float *) alloc(m * d.S * 4); q->sel_actions = (float *) alloc(m * d.A * 4); q->sel_logp = (float *) alloc(m * d.A * 4);
+        q->sel_adv = (float *) alloc(m * 4); q->sel_returns = (float *) alloc(m * 4);
+        q->sel_mask = (uint8_t *) alloc(m);
+        if (!ok || hipMemset(q->sel_mask, 1, m) != hipSuccess) return qfail(EVM_E_HIP, "hipMalloc failed (selected-row buffers)");
+        q->sel_idx = idx;
+    }
+    hipError_t e = evm::launch_ppo_select_scan(rows, d_mask, q->sel_idx, q->sel_count, s);
+    int h = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&h, q->sel_count, sizeof(int), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e == hipSuccess && h > 0)
+        e = evm::launch_ppo_select_gather((size_t) h, q->sel_idx, d.S, d.A, d_states, d_actions, d_logp_old, d_adv, d_returns, q->sel_states,
+                                          q->sel_actions, q->sel_logp, q->sel_adv, q->sel_returns, s);
+    if (e != hipSuccess) return qfail(EVM_E_HIP, std::string("ppo select rows: ") + hipGetErrorString(e));
+    *n_selected = (size_t) h;
+    *s_states = q->sel_states; *s_actions = q->sel_actions; *s_logp_old = q->sel_logp; *s_adv = q->sel_adv; *s_returns = q->sel_returns;
+    *s_mask = q->sel_mask;
+    q->staged_rows = 0;  // the observation copy of an earlier update no longer matches
     return EVM_OK;
 }
 

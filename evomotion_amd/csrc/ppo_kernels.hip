@@ -914,6 +914,59 @@ hipError_t launch_ppo_gae_finish(int T, int N, const double *stats, const float 
     return hipGetLastError();
 }
 
+
+// ---- selected rows only -------------------------------------------------------------------------------------------------
+// After GAE the update is a sum over rows in which the rows outside the mask (reset()'s settle calls and emissions) weigh
+// nothing; evm_ppo_select_rows gathers the selected ones, in their order, so that the epochs' GEMMs do not push the others
+// through forward, backward and weight gradients.  One block: every thread counts a contiguous slice, the block scans the
+// counts, every thread writes its slice's row numbers.
+__global__ __launch_bounds__(1024) void k_ppo_select_scan(size_t rows, const uint8_t *__restrict__ mask, int *__restrict__ sel_idx,
+                                                          int *__restrict__ sel_count) {
+    __shared__ int part[1024];
+    const size_t per = (rows + 1023) / 1024;
+    const size_t lo = (size_t) threadIdx.x * per, hi = lo + per < rows ? lo + per : rows;
+    int c = 0;
+    for (size_t r = lo; r < hi; r++) c += mask[r] != 0;
+    part[threadIdx.x] = c;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {  // inclusive Hillis-Steele scan
+        const int v = (int) threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int at = part[threadIdx.x] - c;
+    for (size_t r = lo; r < hi; r++)
+        if (mask[r] != 0) sel_idx[at++] = (int) r;
+    if (threadIdx.x == 1023) sel_count[0] = part[1023];
+}
+// one wavefront per selected row
+__global__ __launch_bounds__(256) void k_ppo_select_gather(size_t n_sel, const int *__restrict__ sel_idx, int S, int A,
+                                                           const float *__restrict__ states, const float *__restrict__ actions,
+                                                           const float *__restrict__ logp, const float *__restrict__ adv,
+                                                           const float *__restrict__ returns, float *o_states, float *o_actions,
+                                                           float *o_logp, float *o_adv, float *o_returns) {
+    const size_t i = (size_t) blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n_sel) return;
+    const int lane = threadIdx.x & 63;
+    const size_t r = (size_t) sel_idx[i];
+    for (int k = lane; k < S; k += 64) o_states[i * S + k] = states[r * S + k];
+    if (lane < A) { o_actions[i * A + lane] = actions[r * A + lane]; o_logp[i * A + lane] = logp[r * A + lane]; }
+    if (lane == 0) { o_adv[i] = adv[r]; o_returns[i] = returns[r]; }
+}
+hipError_t launch_ppo_select_scan(size_t rows, const uint8_t *mask, int *sel_idx, int *sel_count, hipStream_t s) {
+    hipLaunchKernelGGL(k_ppo_select_scan, dim3(1), dim3(1024), 0, s, rows, mask, sel_idx, sel_count);
+    return hipGetLastError();
+}
+hipError_t launch_ppo_select_gather(size_t n_sel, const int *sel_idx, int S, int A, const float *states, const float *actions,
+                                    const float *logp, const float *adv, const float *returns, float *o_states, float *o_actions,
+                                    float *o_logp, float *o_adv, float *o_returns, hipStream_t s) {
+    if (n_sel == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_ppo_select_gather, dim3((unsigned) ((n_sel + 3) / 4)), dim3(256), 0, s, n_sel, sel_idx, S, A, states, actions,
+                       logp, adv, returns, o_states, o_actions, o_logp, o_adv, o_returns);
+    return hipGetLastError();
+}
+
 }  // namespace evm
 
 #ifdef EVM_FSTAMPS

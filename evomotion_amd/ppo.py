@@ -161,23 +161,42 @@ class FusedPpoTrainer:
         """one forward / backward / optimiser step over the rows; states_unchanged: `states` holds what it held in the previous
         call (later epochs of one train call), the trainer reuses its aligned copy"""
         rows = states.shape[0]
-        assert rows <= self.max_rows
-        self.last_rows = rows  # what the epoch's kernels work on (bench.py prices its roofline on this)
         for t in (states, actions, logp_old, adv, returns, mask_u8):
             assert t.is_cuda and t.is_contiguous()
+        self._epoch_ptrs(rows, [_ptr(t) for t in (states, actions, logp_old, adv, returns, mask_u8)], n_selected_global, epsilon,
+                         entropy_factor, critic_loss_factor, learning_rate, clip_grad_norm, states_unchanged)
+
+    def _epoch_ptrs(self, rows, ptrs, n_selected_global, epsilon, entropy_factor, critic_loss_factor, learning_rate, clip_grad_norm,
+                    states_unchanged):
+        """epoch() on device addresses (states, actions, logp_old, adv, returns, mask): the caller's tensors or the trainer's own
+        dense copies of the selected rows (select_rows)"""
+        assert 1 <= rows <= self.max_rows
+        self.last_rows = rows  # what the epoch's kernels work on (bench.py prices its roofline on this)
         s = self._stream()
         dist = _dist_ready()
         g = self.grad_buffer() if dist else None
         # a DeviceCount (what gae() returns) stays on the device: the loss kernels read 1 / count there
         n_sel = -1.0 if isinstance(n_selected_global, DeviceCount) else float(n_selected_global)
-        check(lib.evm_ppo_grads(self._h, rows, _ptr(states), _ptr(actions), _ptr(logp_old), _ptr(adv), _ptr(returns), _ptr(mask_u8),
-                                n_sel, epsilon, entropy_factor, critic_loss_factor, 1 if states_unchanged else 0, s))
+        check(lib.evm_ppo_grads(self._h, rows, *ptrs, n_sel, epsilon, entropy_factor, critic_loss_factor,
+                                1 if states_unchanged else 0, s))
         if dist:
             # the losses are normalised by the global count, so the SUM over ranks is the global gradient.  One collective over
             # [actor | critic], in place in the buffer the gradient kernels wrote and the optimiser kernel reads, ordered by the
             # stream: no copy, no synchronize()
             _all_reduce_sum(g)
         check(lib.evm_ppo_apply(self._h, learning_rate, clip_grad_norm, s))
+
+    def select_rows(self, states, actions, logp_old, adv, returns, mask_u8):
+        """evm_ppo_select_rows: the rows inside the mask, in order, as dense copies owned by the trainer -> (count, addresses of
+        states, actions, logp_old, adv, returns, mask of ones).  One host read of the count."""
+        rows = states.shape[0]
+        for t in (states, actions, logp_old, adv, returns, mask_u8):
+            assert t.is_cuda and t.is_contiguous()
+        n = ctypes.c_size_t()
+        out = [ctypes.c_void_p() for _ in range(6)]
+        check(lib.evm_ppo_select_rows(self._h, rows, _ptr(mask_u8), _ptr(states), _ptr(actions), _ptr(logp_old), _ptr(adv), _ptr(returns),
+                                      ctypes.byref(n), *[ctypes.byref(o) for o in out], self._stream()))
+        return int(n.value), out
 
     # ---- SAC's actor step on the same kernels ----------------------------------------------------------------------
     def actor_forward(self, states, mu=None, sigma=None):
@@ -217,21 +236,22 @@ class FusedPpoTrainer:
         # bias corrections are one step ahead, which the reference cannot reach (it returns before training, ppo_gae.cpp:63-66)
         S, A = states.shape[-1], actions.shape[-1]
         st, ac, lp = states.reshape(T * N, S), actions.reshape(T * N, A), logp_old.reshape(T * N, A)
-        advf, retf, mk = adv.reshape(-1), ret.reshape(-1), mask_u8.reshape(-1)
+        advf, retf, mk = adv.reshape(-1).contiguous(), ret.reshape(-1).contiguous(), mask_u8.reshape(-1).contiguous()
+        rows, ptrs = T * N, [_ptr(t) for t in (st, ac, lp, advf, retf, mk)]
+        for t in (st, ac, lp):
+            assert t.is_cuda and t.is_contiguous()
         if self.compact_rows and not torch.cuda.is_current_stream_capturing():
-            # Rows outside the mask (reset()'s settle calls and emissions: 40 % of a random-action rollout) weigh nothing in either
-            # loss, yet every epoch would push them through forward, backward and the weight-gradient GEMMs.  After GAE — which
-            # needs the time structure — the update is a sum over rows, so only the selected rows are kept (in their order: the
-            # sums see the same terms, grouped into other tiles).  Costs one host read of the local count per train() call.
-            idx = torch.nonzero(mk).squeeze(1)
-            nv = int(idx.numel())
-            if 0 < nv <= 0.97 * mk.numel():
-                st, ac, lp = st.index_select(0, idx), ac.index_select(0, idx), lp.index_select(0, idx)
-                advf, retf = advf.index_select(0, idx), retf.index_select(0, idx)
-                mk = torch.ones(nv, dtype=torch.uint8, device=self.device)
+            # Rows outside the mask (reset()'s settle calls and emissions: 30-40 % of a rollout) weigh nothing in either loss
+            # (ppo_gae.cpp:167-168, 178: means over masked_select), yet every epoch would push them through forward, backward and
+            # the weight-gradient GEMMs.  After GAE — which needs the time structure — the update is a sum over rows, so only the
+            # selected rows are kept (in their order: the sums see the same terms, grouped into other tiles).  Costs one host read
+            # of the local count per train() call.
+            nv, sel = self.select_rows(st, ac, lp, advf, retf, mk)
+            if 0 < nv < rows:
+                rows, ptrs = nv, sel
         for ep in range(epoch):
-            self.epoch(st, ac, lp, advf, retf, mk, n_glob, epsilon, entropy_factor,
-                       critic_loss_factor, learning_rate, clip_grad_norm, states_unchanged=ep > 0)
+            self._epoch_ptrs(rows, ptrs, n_glob, epsilon, entropy_factor, critic_loss_factor, learning_rate, clip_grad_norm,
+                             states_unchanged=ep > 0)
             if loss_hook is not None:
                 loss_hook(*self.losses())
         return self.losses()

@@ -444,8 +444,18 @@ private:
             hip_check(hipMemcpyAsync(mask_d, h_mask.data(), rows, hipMemcpyHostToDevice, stream), "upload");
             check(evm_ppo_gae(trainer, T, B, rewards, done_d, values, next_values, mask_d, gamma, lambda, adv, nullptr, stream));
             check(evm_ppo_gae_normalize(trainer, T, B, nullptr, values, adv, ret, stream));
+            // the padding rows weigh nothing (ppo_gae.cpp:167-168, 178): the epochs run on the selected rows (as FusedPpoTrainer.train)
+            size_t nsel = 0;
+            const float *u_states = states, *u_actions = actions, *u_logp = logp, *u_adv = adv, *u_ret = ret;
+            const uint8_t *u_mask = mask_d;
+            {
+                const float *c0, *c1, *c2, *c3, *c4; const uint8_t *c5;
+                check(evm_ppo_select_rows(trainer, rows, mask_d, states, actions, logp, adv, ret, &nsel, &c0, &c1, &c2, &c3, &c4, &c5, stream));
+                if (nsel > 0 && nsel < (size_t) rows) { u_states = c0; u_actions = c1; u_logp = c2; u_adv = c3; u_ret = c4; u_mask = c5; }
+                else nsel = (size_t) rows;
+            }
             for (int ep = 0; ep < epoch; ep++) {
-                check(evm_ppo_grads(trainer, rows, states, actions, logp, adv, ret, mask_d, -1.0, epsilon, entropy_factor, critic_loss_factor,
+                check(evm_ppo_grads(trainer, nsel, u_states, u_actions, u_logp, u_adv, u_ret, u_mask, -1.0, epsilon, entropy_factor, critic_loss_factor,
                                     ep > 0 ? 1 : 0, stream));
                 check(evm_ppo_apply(trainer, learning_rate, clip_grad_norm, stream));
                 // the LossMeter adds of ppo_gae.cpp:185-186, once per epoch (synchronises: the host vectors above may go)

@@ -207,8 +207,19 @@ int main(int argc, char **argv) {
             nccl_check(ncclAllGather(stats, all_stats, 3, ncclDouble, comm, s), "ncclAllGather");            // 24 B per rank
             check(evm_ppo_gae_merge(tr, all_stats, world, nullptr, s));
             check(evm_ppo_gae_normalize(tr, T, n, nullptr, values, adv, ret, s));
+            // the epochs run on the selected rows alone (settle calls and reset emissions weigh nothing): the one host read of an
+            // iteration, of this rank's count
+            size_t nsel = 0;
+            const float *u_states = states, *u_actions = actions, *u_logp = logp, *u_adv = adv, *u_ret = ret;
+            const uint8_t *u_mask = mask;
+            {
+                const float *c0, *c1, *c2, *c3, *c4; const uint8_t *c5;
+                check(evm_ppo_select_rows(tr, rows, mask, states, actions, logp, adv, ret, &nsel, &c0, &c1, &c2, &c3, &c4, &c5, s));
+                if (nsel > 0 && nsel < rows) { u_states = c0; u_actions = c1; u_logp = c2; u_adv = c3; u_ret = c4; u_mask = c5; }
+                else nsel = rows;
+            }
             for (int ep = 0; ep < epoch; ep++) {
-                check(evm_ppo_grads(tr, rows, states, actions, logp, adv, ret, mask, -1.0 /* count on the device */, eps, ef, cf, ep > 0, s));
+                check(evm_ppo_grads(tr, nsel, u_states, u_actions, u_logp, u_adv, u_ret, u_mask, -1.0 /* count on the device */, eps, ef, cf, ep > 0, s));
                 nccl_check(ncclAllReduce(d_grads, d_grads, gn, ncclFloat, ncclSum, comm, s), "ncclAllReduce");  // one collective per epoch
                 check(evm_ppo_apply(tr, lr, clip, s));
             }

@@ -286,6 +286,16 @@ int evm_ppo_gae(EvmPpo *q, int horizon, int n_envs, const float *d_rewards, cons
  * uses the statistics of this trainer's last evm_ppo_gae. */
 int evm_ppo_gae_normalize(EvmPpo *q, int horizon, int n_envs, const double *d_stats, const float *d_curr_values, float *d_adv,
                           float *d_returns, void *stream);
+/* The rows with d_mask != 0, in their order, as dense copies owned by the trainer (valid until the next call): both
+ * losses are means over masked_select(..., mask) (ppo_gae.cpp:167-168, 178), so the rows outside the mask — the reference's padding,
+ * here reset()'s settle calls and emissions — weigh nothing,
+ * so after GAE (which needs the time structure) the epochs can run on the selected rows alone: pass *n_selected and the returned
+ * pointers to evm_ppo_grads for every epoch of the update.  Same gradients to rounding (the same terms, summed in other tiles).
+ * Reads the count back: one stream synchronisation per update.  *n_selected == 0: nothing copied, keep the original buffers. */
+int evm_ppo_select_rows(EvmPpo *q, size_t rows, const uint8_t *d_mask, const float *d_states, const float *d_actions,
+                        const float *d_logp_old, const float *d_adv, const float *d_returns, size_t *n_selected,
+                        const float **s_states, const float **s_actions, const float **s_logp_old, const float **s_adv,
+                        const float **s_returns, const uint8_t **s_mask, void *stream);
 /* Forward, losses and backward of both networks over `rows` transitions: gradients land in the trainer (evm_ppo_copy).
  * n_selected_global = number of rows with d_mask == 1 over ALL ranks (the losses are means over them, so summing the
  * ranks' gradients gives the global gradient); negative: use the count of the trainer's own statistics on the device
