@@ -564,7 +564,7 @@ def main():
             out["roofline_replay_push"] = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "traffic": None,
                                            "launch_ms": rp["ms_push"] / max(rp["n_push"], 1),
                                            "achieved": push_bytes / (rp["ms_push"] / max(rp["n_push"], 1) * 1e-3) / 1e9,
-                                           "kernel": "k_replay_index + k_replay_copy"}
+                                           "kernel": "k_replay_copy (copies + the index block)"}
             out["roofline_replay_push"]["frac"] = out["roofline_replay_push"]["achieved"] / HBM_PEAK_GBS
             if rp["n_sample"]:
                 smp_bytes = 2.0 * args.sac_batch * (2 * S_ + A_ + 2) * 4

@@ -5,8 +5,8 @@
 //   AbstractReplayBuffer::sample       evo_motion_networks/src/replay_buffer.cpp:16-28
 //   the stacking of the sampled batch  evo_motion_networks/src/agents/soft_actor_critic.cpp:68-87
 //
-// push:   k_replay_index (one workgroup: ordered compaction of the valid rows of the new slot) +
-//         k_replay_copy (grid-stride float4 copies of the [N, S] / [N, A] blocks into the slot, coalesced)
+// push:   k_replay_copy: grid-stride float4 copies of the [N, S] / [N, A] blocks into the slot, coalesced; its last block
+//         does the ordered compaction of the valid rows of the new slot beside them (one launch)
 // sample: k_replay_plan (one workgroup: prefix sum of the per-slot counts over the live slots in age order, then per
 //         draw a keyed permutation rank -> (slot, env) by binary search) + k_replay_gather (one wave per drawn row:
 //         1 484-byte contiguous reads of state and next state)
@@ -19,15 +19,17 @@ namespace evm {
 
 #define RP_T 1024
 
-// ordered compaction of the slot's transitions: valid_idx[slot][k] = k-th env (ascending) with valid == 1
-__global__ __launch_bounds__(RP_T) void k_replay_index(ReplayDev d, int slot, const uint8_t *__restrict__ valid) {
-    __shared__ int wave_sum[RP_T / 64];
+// ordered compaction of the slot's transitions: valid_idx[slot][k] = k-th env (ascending) with valid == 1.  One workgroup of NT
+// threads (the last block of k_replay_copy: the copies of the other blocks run beside its serial passes).
+template <int NT>
+__device__ __forceinline__ void replay_index_block(const ReplayDev &d, int slot, const uint8_t *__restrict__ valid) {
+    __shared__ int wave_sum[NT / 64];
     __shared__ int base;
     if (threadIdx.x == 0) base = 0;
     __syncthreads();
     int *out = d.valid_idx + (size_t) slot * d.N;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i0 = 0; i0 < d.N; i0 += RP_T) {
+    for (int i0 = 0; i0 < d.N; i0 += NT) {
         const int i = i0 + (int) threadIdx.x;
         const bool v = i < d.N && (valid ? valid[i] == 1 : true);
         const unsigned long long m = __ballot(v);
@@ -40,7 +42,7 @@ __global__ __launch_bounds__(RP_T) void k_replay_index(ReplayDev d, int slot, co
         __syncthreads();
         if (threadIdx.x == 0) {
             int t = 0;
-            for (int w = 0; w < RP_T / 64; w++) t += wave_sum[w];
+            for (int w = 0; w < NT / 64; w++) t += wave_sum[w];
             base += t;
         }
         __syncthreads();
@@ -64,8 +66,9 @@ __device__ __forceinline__ void copy_block_scalar(float *dst, const float *src, 
 __global__ __launch_bounds__(256) void k_replay_copy(ReplayDev d, int slot, const float *__restrict__ state,
                                                      const float *__restrict__ action, const float *__restrict__ reward,
                                                      const uint8_t *__restrict__ done, const float *__restrict__ next_state,
-                                                     int aligned) {
-    const size_t tid = blockIdx.x * (size_t) blockDim.x + threadIdx.x, nt = (size_t) gridDim.x * blockDim.x;
+                                                     const uint8_t *__restrict__ valid, int aligned) {
+    if (blockIdx.x == gridDim.x - 1) { replay_index_block<256>(d, slot, valid); return; }  // (uniform per block)
+    const size_t tid = blockIdx.x * (size_t) blockDim.x + threadIdx.x, nt = (size_t) (gridDim.x - 1) * blockDim.x;
     const size_t ns = (size_t) d.N * d.S, na = (size_t) d.N * d.A;
     if (aligned) {
         copy_block(d.state + (size_t) slot * ns, state, ns, tid, nt);
@@ -152,25 +155,46 @@ __global__ __launch_bounds__(256) void k_replay_gather(ReplayDev d, int head, in
     const float *sp = d.state + ((size_t) slot * d.N + env) * d.S;
     const float *np = slot == newest ? d.pending + (size_t) env * d.S : d.state + ((size_t) ((slot + 1) % d.C) * d.N + env) * d.S;
     const float *ap = d.action + ((size_t) slot * d.N + env) * d.A;
-    for (int k = lane; k < d.S; k += 64) { so[k] = sp[k]; no[k] = np[k]; }
-    for (int k = lane; k < d.A; k += 64) ao[k] = ap[k];
-    if (lane == 0) {
-        rewards[b] = d.reward[(size_t) slot * d.N + env];
-        done[b] = d.done[(size_t) slot * d.N + env];
-        if (index) { index[2 * b] = slot; index[2 * b + 1] = env; }
+    // every load of the row in flight before its first store (as a load / store loop the compiler, which cannot rule out that the
+    // outputs alias the ring, waits for each pair: six dependent round trips per row instead of one)
+    constexpr int RP_KMAX = 8;  // 64 * 8 = 512 floats per row cover S <= 512 in one batch
+    float vs[RP_KMAX], vn[RP_KMAX];
+    for (int k0 = 0; k0 < d.S; k0 += 64 * RP_KMAX) {
+#pragma unroll
+        for (int u = 0; u < RP_KMAX; u++) {
+            const int k = k0 + 64 * u + lane;
+            const int kc = k < d.S ? k : d.S - 1;
+            vs[u] = sp[kc]; vn[u] = np[kc];
+        }
+        float va = 0.f, vr = 0.f, vd = 0.f;
+        if (k0 == 0) {
+            if (lane < d.A) va = ap[lane];
+            if (lane == 0) { vr = d.reward[(size_t) slot * d.N + env]; vd = d.done[(size_t) slot * d.N + env]; }
+        }
+#pragma unroll
+        for (int u = 0; u < RP_KMAX; u++) {
+            const int k = k0 + 64 * u + lane;
+            if (k < d.S) { so[k] = vs[u]; no[k] = vn[u]; }
+        }
+        if (k0 == 0) {
+            if (lane < d.A) ao[lane] = va;
+            if (lane == 0) { rewards[b] = vr; done[b] = vd; }
+        }
     }
+    for (int k = 64 + lane; k < d.A; k += 64) ao[k] = ap[k];  // (A > 64: not the case of any shipped skeleton)
+    if (lane == 0 && index) { index[2 * b] = slot; index[2 * b + 1] = env; }
 }
 
 hipError_t launch_replay_push(const ReplayDev &d, int slot, const float *state, const float *action, const float *reward,
                               const uint8_t *done, const uint8_t *valid, const float *next_state, hipStream_t s) {
-    hipLaunchKernelGGL(k_replay_index, dim3(1), dim3(RP_T), 0, s, d, slot, valid);
     const size_t ns = (size_t) d.N * d.S, na = (size_t) d.N * d.A;
     const int aligned = ((uintptr_t) state % 16 == 0) && ((uintptr_t) next_state % 16 == 0) && ((uintptr_t) action % 16 == 0) &&
                         (ns * sizeof(float)) % 16 == 0 && (na * sizeof(float)) % 16 == 0;
     int blocks = (int) ((ns / 4 + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_replay_copy, dim3(blocks), dim3(256), 0, s, d, slot, state, action, reward, done, next_state, aligned);
+    // + 1: the block that compacts the slot's valid rows (replay_index_block)
+    hipLaunchKernelGGL(k_replay_copy, dim3(blocks + 1), dim3(256), 0, s, d, slot, state, action, reward, done, next_state, valid, aligned);
     return hipGetLastError();
 }
 
