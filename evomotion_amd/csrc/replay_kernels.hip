@@ -7,8 +7,8 @@
 //
 // push:   k_replay_copy: grid-stride float4 copies of the [N, S] / [N, A] blocks into the slot, coalesced; its last block
 //         does the ordered compaction of the valid rows of the new slot beside them (one launch)
-// sample: k_replay_plan (one workgroup: prefix sum of the per-slot counts over the live slots in age order, then per
-//         draw a keyed permutation rank -> (slot, env) by binary search) + k_replay_gather (one wave per drawn row:
+// sample: k_replay_plan (per workgroup: prefix sum of the per-slot counts over the live slots in age order, then one draw per
+//         thread: keyed permutation rank -> (slot, env) by binary search) + k_replay_gather (one wave per drawn row:
 //         1 484-byte contiguous reads of state and next state)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -63,11 +63,11 @@ __device__ __forceinline__ void copy_block_scalar(float *dst, const float *src, 
     for (size_t i = tid; i < n; i += nthreads) dst[i] = src[i];
 }
 
-__global__ __launch_bounds__(256) void k_replay_copy(ReplayDev d, int slot, const float *__restrict__ state,
+__global__ __launch_bounds__(RP_T) void k_replay_copy(ReplayDev d, int slot, const float *__restrict__ state,
                                                      const float *__restrict__ action, const float *__restrict__ reward,
                                                      const uint8_t *__restrict__ done, const float *__restrict__ next_state,
                                                      const uint8_t *__restrict__ valid, int aligned) {
-    if (blockIdx.x == gridDim.x - 1) { replay_index_block<256>(d, slot, valid); return; }  // (uniform per block)
+    if (blockIdx.x == gridDim.x - 1) { replay_index_block<RP_T>(d, slot, valid); return; }  // (uniform per block)
     const size_t tid = blockIdx.x * (size_t) blockDim.x + threadIdx.x, nt = (size_t) (gridDim.x - 1) * blockDim.x;
     const size_t ns = (size_t) d.N * d.S, na = (size_t) d.N * d.A;
     if (aligned) {
@@ -117,8 +117,11 @@ __global__ __launch_bounds__(RP_T) void k_replay_plan(ReplayDev d, int head, int
         __syncthreads();
     }
     const int m = prefix[live];
-    if (threadIdx.x == 0) d.total[0] = m;
-    for (int b = threadIdx.x; b < batch; b += RP_T) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) d.total[0] = m;
+    // one draw per thread and trip; the grid's blocks (each with its own copy of the prefix sums: one pass over the slot counts)
+    // share the draws — as ONE block the 4 096 draws of a batch were four dependent trips of rank, binary search and a global
+    // read per thread: 13.8 us, longer than the gather they feed
+    for (int b = blockIdx.x * RP_T + threadIdx.x; b < batch; b += gridDim.x * RP_T) {
         int slot = -1, env = -1;
         if (m > 0) {
             const uint32_t r = replay_rank((uint32_t) (b % m), (uint32_t) m, seed);
@@ -190,17 +193,20 @@ hipError_t launch_replay_push(const ReplayDev &d, int slot, const float *state, 
     const size_t ns = (size_t) d.N * d.S, na = (size_t) d.N * d.A;
     const int aligned = ((uintptr_t) state % 16 == 0) && ((uintptr_t) next_state % 16 == 0) && ((uintptr_t) action % 16 == 0) &&
                         (ns * sizeof(float)) % 16 == 0 && (na * sizeof(float)) % 16 == 0;
-    int blocks = (int) ((ns / 4 + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
+    int blocks = (int) ((ns / 4 + RP_T - 1) / RP_T);
+    if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
     // + 1: the block that compacts the slot's valid rows (replay_index_block)
-    hipLaunchKernelGGL(k_replay_copy, dim3(blocks + 1), dim3(256), 0, s, d, slot, state, action, reward, done, next_state, valid, aligned);
+    hipLaunchKernelGGL(k_replay_copy, dim3(blocks + 1), dim3(RP_T), 0, s, d, slot, state, action, reward, done, next_state, valid, aligned);
     return hipGetLastError();
 }
 
 hipError_t launch_replay_sample(const ReplayDev &d, int head, int live, int batch, uint64_t seed, float *states, float *actions,
                                 float *rewards, float *done, float *next_states, int *index, hipStream_t s) {
-    hipLaunchKernelGGL(k_replay_plan, dim3(1), dim3(RP_T), (size_t) (live + 1) * sizeof(int), s, d, head, live, batch, seed);
+    int plan_blocks = (batch + RP_T - 1) / RP_T;
+    if (plan_blocks < 1) plan_blocks = 1;
+    if (plan_blocks > 64) plan_blocks = 64;
+    hipLaunchKernelGGL(k_replay_plan, dim3(plan_blocks), dim3(RP_T), (size_t) (live + 1) * sizeof(int), s, d, head, live, batch, seed);
     hipLaunchKernelGGL(k_replay_gather, dim3((batch + 3) / 4), dim3(256), 0, s, d, head, batch, states, actions, rewards, done,
                        next_states, index);
     return hipGetLastError();
