@@ -171,3 +171,34 @@ def test_no_product_path_reaches_the_oracle():
     code = ("import sys; sys.path.insert(0, %r); import evomotion_amd; m = open('/proc/self/maps').read(); "
             "assert 'libevomotion_hip.so' in m and 'liborc' not in m and 'orc' not in sys.modules; print('ok')" % ROOT)
     assert subprocess.check_output([sys.executable, "-c", code]).decode().strip() == "ok"
+
+
+def test_product_sources_never_reach_for_the_oracle():
+    """oracle/ is test infrastructure: no file of the package, of the compiled hosts or of the C ABI may import, include, link or
+    open anything under it (a source scan — `hasattr` on the imported package would prove nothing); bench.py may, but only inside
+    its cpu_baseline / pose_parity legs and the child worker they start."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pat = re.compile(r"oracle|\borc\b|liborc|orc_api|agent_oracle|replay_oracle")
+    offenders = []
+    for sub, exts in (("evomotion_amd", (".py", ".h", ".hip", ".cpp")), ("examples", (".hpp", ".cpp", ".h")), ("include", (".h",))):
+        for dp, _, fs in os.walk(os.path.join(root, sub)):
+            for f in fs:
+                if not f.endswith(exts) and f != "Makefile":
+                    continue
+                for ln, line in enumerate(open(os.path.join(dp, f), errors="replace"), 1):
+                    code = line.split("//")[0].split("#")[0] if not f.endswith(".py") else line.split("#")[0]
+                    if f.endswith(".py") and (code.lstrip().startswith(('"', "'")) or '"""' in code):
+                        continue
+                    if pat.search(code) and ("import" in code or "include" in code or "CDLL" in code or "open(" in code or "-l" in code):
+                        offenders.append(f"{os.path.relpath(os.path.join(dp, f), root)}:{ln}: {line.strip()}")
+    assert not offenders, "\n".join(offenders)
+    # bench.py: every mention of the oracle sits in the cpu_baseline leg (cpu_worker, cpu_baseline, pose_parity) or in main()'s dispatch to it
+    src = open(os.path.join(root, "bench.py")).read()
+    func = None
+    for line in src.splitlines():
+        m = re.match(r"def (\w+)\(", line)
+        if m:
+            func = m.group(1)
+        if re.search(r"import orc\b|sys\.path\.insert\(.*oracle|liborc", line):
+            assert func in ("cpu_worker", "cpu_baseline", "pose_parity"), (func, line)
