@@ -402,7 +402,7 @@ __device__ __forceinline__ void head_gemm16(const float *hb, const HeadB16 &H, f
 }
 
 // stage a TM_ x S tile of a row-major [n][S] matrix, zero padded to K1 columns, k-split in LDS (row stride ALD1)
-template <int TM_>
+template <int TM_, int NT = PT>
 __device__ __forceinline__ void stage_rows_ksplit(float *xs, const float *__restrict__ obs, int row0, int n, int S) {
                 const size_t base = (size_t) row0 * S;
         const int tile = TM_ * S;  // floats; rows of the tile are contiguous in memory
@@ -410,21 +410,21 @@ __device__ __forceinline__ void stage_rows_ksplit(float *xs, const float *__rest
             // full, 16-byte aligned tile: flat float4 loads, all in flight together
             const f32x4 *src = reinterpret_cast<const f32x4 *>(obs + base);
             const int nq = tile >> 2;
-            constexpr int NIT = (TM_ * K1 / 4 + PT - 1) / PT;  // upper bound (S <= K1)
+            constexpr int NIT = (TM_ * K1 / 4 + NT - 1) / NT;  // upper bound (S <= K1)
             f32x4 v[NIT];
 #pragma unroll
             for (int it = 0; it < NIT; it++) {
-                const int q = it * PT + (int) threadIdx.x;
+                const int q = it * NT + (int) threadIdx.x;
                 v[it] = src[min(q, nq - 1)];
             }
             // (row, column) of a flat element without a division per element: one division for the thread's first element,
             // then a constant (row, column) stride per trip, with carry
             const int e0 = 4 * (int) threadIdx.x;
             int r = e0 / S, k = e0 - r * S;
-            const int dr = (4 * PT) / S, dk = 4 * PT - dr * S;
+            const int dr = (4 * NT) / S, dk = 4 * NT - dr * S;
 #pragma unroll
             for (int it = 0; it < NIT; it++) {
-                const int q = it * PT + (int) threadIdx.x;
+                const int q = it * NT + (int) threadIdx.x;
                 if (q < nq) {
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
@@ -436,14 +436,14 @@ __device__ __forceinline__ void stage_rows_ksplit(float *xs, const float *__rest
                 r += dr; k += dk;
                 if (k >= S) { k -= S; r++; }
             }
-            for (int e = threadIdx.x; e < TM_ * (K1 - S); e += PT) {
+            for (int e = threadIdx.x; e < TM_ * (K1 - S); e += NT) {
                 const int r = e / (K1 - S), k = S + e % (K1 - S);
                 xs[r * ALD1 + (k & 1) * (K1 / 2) + (k >> 1)] = 0.f;
             }
         } else {
             // ragged last tile or unaligned caller buffer: scalar loads, clamped address + select (no branches)
             const size_t last = (size_t) n * S - 1;
-            for (int e = threadIdx.x; e < TM_ * K1; e += PT) {
+            for (int e = threadIdx.x; e < TM_ * K1; e += NT) {
                 const int r = e / K1, k = e % K1;
                 const bool ok = row0 + r < n && k < S;
                 const size_t g = base + (size_t) r * S + k;
