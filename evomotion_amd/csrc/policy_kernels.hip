@@ -246,58 +246,6 @@ __global__ __launch_bounds__(PT) void k_policy_forward16(PolicyDev p, int n, con
     }
 }
 
-// Both networks of a 16-row tile in ONE workgroup of eight waves (waves 0-3 the actor, 4-7 the critic): the observation tile is
-// staged once for the two, by twice the threads, and the sampling tail is dealt over all 512 threads.  The two networks walk
-// the same phases behind the same workgroup barriers.
-#define F16_NET_FLOATS (TM16 * ALD2 + 4 * 16 * 32 + TM16 * 32)   // activation tile + head partials + head pre-activations of one network
-#define POLICY_F16_FLOATS (2 * F16_NET_FLOATS > TM16 * ALD1 ? 2 * F16_NET_FLOATS : TM16 * ALD1)
-__global__ __launch_bounds__(2 * PT) void k_policy_forward16f(PolicyDev p, int n, const float *__restrict__ obs,
-                                                              const float *__restrict__ uniform, uint64_t seed, uint64_t counter,
-                                                              float *action, float *logp, float *value, float *mu_out,
-                                                              float *sigma_out) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    static_assert(F16_NET_FLOATS >= TM16 * ALD1, "the actor's region has to cover the observation tile it overlays");
-    const int row0 = blockIdx.x * TM16;
-    const int net = threadIdx.x >> 8, tid = threadIdx.x & 255;
-    const int wave = tid >> 6, lane = tid & 63;
-    const NetDev &N = net == 0 ? p.actor : p.critic;
-    float *xs = sm;
-    float *hb = sm + net * F16_NET_FLOATS;           // the actor's overlays the observation tile, the critic's lies behind it
-    float *red = sm + POLICY_F16_FLOATS + net * EVM_RED16_FLOATS;
-    stage_rows_ksplit<TM16, 2 * PT>(xs, obs, row0, n, p.S);
-    __syncthreads();
-    f32x4 ring[DEPTH16][4];
-    f32x4c acc[4];
-    dense16_prefetch(N.w1t, wave, lane, ring);
-    dense_layer16<K1>(xs, ALD1, N.w1t, wave, lane, acc, ring);
-    LnParams16 P = ln_params16(N.b1, N.g1, N.be1, wave, lane);
-    // (the epilogue's first barrier is the workgroup's: both networks are through with the observation tile before either writes)
-    mish_ln_epilogue16(acc, P, hb, red, wave, lane);
-    dense16_prefetch(N.w2t, wave, lane, ring);
-    dense_layer16<256>(hb, ALD2, N.w2t, wave, lane, acc, ring);
-    P = ln_params16(N.b2, N.g2, N.be2, wave, lane);
-    mish_ln_epilogue16(acc, P, hb, red, wave, lane);
-    const HeadB16 HB = head16_prefetch(N.whp, wave, lane);
-    float *hs4 = hb + TM16 * ALD2;
-    float *hs = hs4 + 4 * 16 * 32;
-    head_gemm16(hb, HB, hs4, wave, lane);
-    __syncthreads();
-    const int A = p.A;
-    const int nout = net == 1 ? 1 : 2 * A;
-    for (int e = tid; e < TM16 * 32; e += PT) {
-        const int o = e & 31;
-        if (o < nout) hs[e] = ((hs4[e] + hs4[16 * 32 + e]) + (hs4[2 * 16 * 32 + e] + hs4[3 * 16 * 32 + e])) + N.bh[o];
-    }
-    __syncthreads();
-    const float *hs_actor = sm + TM16 * ALD2 + 4 * 16 * 32, *hs_critic = hs_actor + F16_NET_FLOATS;
-    if (net == 1 && tid < TM16 && row0 + tid < n) value[row0 + tid] = hs_critic[tid * 32];
-    for (int e = threadIdx.x; e < TM16 * A; e += 2 * PT) {
-        const int row = e / A, a = e - row * A;
-        if (row0 + row < n) sample_action(p, hs_actor, row, row0 + row, a, uniform, seed, counter, action, logp, mu_out, sigma_out);
-    }
-}
-size_t policy_lds16f_bytes() { return (size_t) (POLICY_F16_FLOATS + 2 * EVM_RED16_FLOATS) * sizeof(float); }
-
 size_t policy_lds16_bytes() { return (size_t) (POLICY_TILE16_FLOATS + EVM_RED16_FLOATS) * sizeof(float); }
 
 // flat parameters of one network -> the operand layout of the forward kernel; one thread per source element
@@ -357,13 +305,6 @@ hipError_t launch_policy_forward(const PolicyDev &p, int n, const float *obs, co
     }
     const int nets = value ? 2 : 1;  // value == NULL: the critic network is not run (SAC's act)
     if (policy_tile_rows(n, nets, tile_rows) == 16) {
-        static int fused = -1;   // EVM_POLICY_FUSED=1 (read once): both networks of a tile in one eight-wave workgroup
-        if (fused < 0) { const char *e = getenv("EVM_POLICY_FUSED"); fused = e ? atoi(e) : 0; }
-        if (fused && nets == 2) {
-            hipLaunchKernelGGL(k_policy_forward16f, dim3((n + TM16 - 1) / TM16), dim3(2 * PT), policy_lds16f_bytes(), s, p, n, obs,
-                               uniform, seed, counter, action, logp, value, mu, sigma);
-            return hipGetLastError();
-        }
         hipLaunchKernelGGL(k_policy_forward16, dim3((n + TM16 - 1) / TM16, nets), dim3(PT), policy_lds16_bytes(), s, p, n, obs,
                            uniform, seed, counter, action, logp, value, mu, sigma);
         return hipGetLastError();
