@@ -349,6 +349,46 @@ def test_selected_rows_only_equals_all_rows_with_a_mask():
         assert float((g0 - g1).abs().max()) <= 2e-5 * float(g0.abs().max()), float((g0 - g1).abs().max()) / float(g0.abs().max())
 
 
+def test_select_rows_gathers_exactly_the_masked_rows_in_order():
+    """evm_ppo_select_rows against torch.index_select: ragged sizes (the scan deals 1024 slices), nothing / everything / one row
+    selected; the dense copies are bit-equal to the source rows, in source order, and the mask handed back is all ones."""
+    import ctypes
+    import torch
+    actor, critic = _modules(seed=1)
+    f, tr = _trainer(actor, critic, 5000)
+    g = torch.Generator(device="cuda"); g.manual_seed(17)
+
+    class Dev:  # a device buffer of the trainer, seen through the CUDA array interface (no copy, no second HIP runtime)
+        def __init__(self, addr, shape, typestr):
+            self.__cuda_array_interface__ = {"data": (int(addr.value), False), "shape": tuple(shape), "typestr": typestr, "version": 2}
+
+    def view(addr, shape, dtype=torch.float32):
+        torch.cuda.current_stream().synchronize()
+        return torch.as_tensor(Dev(addr, shape, "|u1" if dtype == torch.uint8 else "<f4"), device="cuda").clone()
+
+    for rows, p_sel in ((1, 1.0), (37, 0.5), (1024, 0.5), (1025, 0.7), (4999, 0.6), (5000, 1.0), (777, 0.0), (3000, None)):
+        st = torch.rand(rows, 371, device="cuda", generator=g)
+        ac = torch.rand(rows, 12, device="cuda", generator=g)
+        lp = torch.rand(rows, 12, device="cuda", generator=g)
+        adv = torch.rand(rows, device="cuda", generator=g)
+        ret = torch.rand(rows, device="cuda", generator=g)
+        if p_sel is None:
+            mask = torch.zeros(rows, dtype=torch.uint8, device="cuda"); mask[1234] = 1
+        else:
+            mask = (torch.rand(rows, device="cuda", generator=g) < p_sel).to(torch.uint8)
+        n, (s_st, s_ac, s_lp, s_adv, s_ret, s_mask) = tr.select_rows(st, ac, lp, adv, ret, mask)
+        idx = torch.nonzero(mask).squeeze(1)
+        assert n == idx.numel(), (rows, n, idx.numel())
+        if n == 0:
+            continue
+        assert torch.equal(view(s_st, (n, 371)), st.index_select(0, idx))
+        assert torch.equal(view(s_ac, (n, 12)), ac.index_select(0, idx))
+        assert torch.equal(view(s_lp, (n, 12)), lp.index_select(0, idx))
+        assert torch.equal(view(s_adv, (n,)), adv.index_select(0, idx))
+        assert torch.equal(view(s_ret, (n,)), ret.index_select(0, idx))
+        assert bool((view(s_mask, (n,), torch.uint8) == 1).all())
+
+
 def test_an_empty_selection_is_a_no_op_that_says_so():
     """a rollout whose mask selects no transition must not move anything.  The count of selected transitions stays on
     the device (no host read in the update), so the no-op happens there: after one real update (the Adam moments are non-zero:
