@@ -77,7 +77,9 @@ class FusedPpoTrainer:
         self.grad_floats, self.critic_grad_offset = gn.value, go.value
         self._grads = None
         self.last_rows = 0
-        self.compact_rows = True  # train(): run the epochs on the selected rows only (False: all rows, the mask zeroes the rest)
+        # train(): run the epochs on the selected rows only (False, or EVM_PPO_COMPACT=0 for A/B runs: all rows, the mask zeroes the rest)
+        import os
+        self.compact_rows = os.environ.get("EVM_PPO_COMPACT", "1") != "0"
 
     def grad_buffer(self):
         """[grad_floats] device vector, actor gradients at 0, critic gradients at critic_grad_offset; owned by this object and
