@@ -1,6 +1,7 @@
 """Time evm_policy_forward at 4096 rows in its two tile forms (32 rows on v_mfma_f32_32x32x2_f32, 16 rows on
 v_mfma_f32_16x16x4_f32), both networks and actor only.  HIP events around 200 launches each; prints one JSON line.
-Usage (GPU box): python tools/policy_tiles.py [rows ...]"""
+Usage (GPU box): python tools/policy_tiles.py [rows ...]            inputs N(0,1)
+                 python tools/policy_tiles.py env [rows ...]        inputs = observations of a VecRobotWalk after reset() + 64 random steps"""
 import json
 import os
 import sys
@@ -14,15 +15,37 @@ FLOP_BOTH = 654848.0  # GEMM FLOP per row, actor + critic (bench.py)
 
 
 def main():
-    for n in ([int(a) for a in sys.argv[1:]] or [4096]):
+    args = sys.argv[1:]
+    global ENV_OBS
+    ENV_OBS = bool(args) and args[0] == "env"
+    if ENV_OBS:
+        args = args[1:]
+    for n in ([int(a) for a in args] or [4096]):
         one(n)
+
+
+ENV_OBS = False
+
+
+def inputs(n):
+    if not ENV_OBS:
+        return torch.randn(n, 371, device="cuda")
+    from evomotion_amd import VecRobotWalk
+    env = VecRobotWalk(n, seed=3)
+    st = env.reset()
+    g = torch.Generator(device="cuda"); g.manual_seed(1)
+    for _ in range(64):
+        st = env.step_autoreset(torch.rand(n, 12, device="cuda", generator=g) * 2 - 1)
+    x = st.state.clone()
+    env.close()
+    return x
 
 
 def one(n, reps=7, launches=100):
     actor, critic = ActorModule([371], [12], 256).cuda(), CriticModule([371], 256).cuda()
     f = FusedActorCritic(371, 12, 256, 0)
     f.load_modules(actor, critic)
-    x = torch.randn(n, 371, device="cuda")
+    x = inputs(n)
     flop_actor = 2.0 * (371 * 256 + 256 * 256 + 256 * 24)
     cfgs = [(rows, ao) for rows in (32, 16) for ao in (False, True)]
     times = {c: [] for c in cfgs}
@@ -36,7 +59,7 @@ def one(n, reps=7, launches=100):
                 f.forward(x, actor_only=ao)
             ms, k = f.timing_end()
             times[(rows, ao)].append(ms / k)
-    out = {"rows": n}
+    out = {"rows": n, "inputs": "env observations" if ENV_OBS else "N(0,1)"}
     for (rows, ao), ts in times.items():
         ts = sorted(ts)
         t = ts[len(ts) // 2]
