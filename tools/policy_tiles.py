@@ -1,7 +1,8 @@
 """Time evm_policy_forward at 4096 rows in its two tile forms (32 rows on v_mfma_f32_32x32x2_f32, 16 rows on
 v_mfma_f32_16x16x4_f32), both networks and actor only.  HIP events around 200 launches each; prints one JSON line.
 Usage (GPU box): python tools/policy_tiles.py [rows ...]            inputs N(0,1)
-                 python tools/policy_tiles.py env [rows ...]        inputs = observations of a VecRobotWalk after reset() + 64 random steps"""
+                 python tools/policy_tiles.py env [rows ...]        inputs = observations of a VecRobotWalk after reset() + 64 random steps
+                 python tools/policy_tiles.py one 16|32 both|actor [rows]   200 launches of that one form (for a rocprofv3 --pmc pass)"""
 import json
 import os
 import sys
@@ -16,6 +17,17 @@ FLOP_BOTH = 654848.0  # GEMM FLOP per row, actor + critic (bench.py)
 
 def main():
     args = sys.argv[1:]
+    if args and args[0] == "one":
+        tile, ao, n = int(args[1]), args[2] == "actor", int(args[3]) if len(args) > 3 else 4096
+        actor, critic = ActorModule([371], [12], 256).cuda(), CriticModule([371], 256).cuda()
+        f = FusedActorCritic(371, 12, 256, 0)
+        f.load_modules(actor, critic)
+        f.set_tile_rows(tile)
+        x = torch.randn(n, 371, device="cuda")
+        for _ in range(200):
+            f.forward(x, actor_only=ao)
+        torch.cuda.synchronize()
+        return
     global ENV_OBS
     ENV_OBS = bool(args) and args[0] == "env"
     if ENV_OBS:
