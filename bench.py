@@ -51,9 +51,13 @@ def policy_kernel_name(rows, nets, dev):
     tiles give the device at most one workgroup per CU."""
     import torch
     cus = torch.cuda.get_device_properties(dev).multi_processor_count
-    if -(-rows // 32) * nets <= cus:
+    split = os.environ.get("EVM_POLICY_SPLIT", "1") != "0"
+    wg32 = -(-rows // 32) * nets
+    if (wg32 < cus) if split else (wg32 <= cus):
         return "k_policy_forward16 (16-row tiles, v_mfma_f32_16x16x4_f32)"
-    return "k_policy_forward (32-row tiles, v_mfma_f32_32x32x2_f32)"
+    if split:
+        return "k_policy_forward<1> (32-row tiles, six v_mfma_f32_32x32x16_bf16 products per fp32 product)"
+    return "k_policy_forward<0> (32-row tiles, v_mfma_f32_32x32x2_f32)"
 
 
 def measured_traffic(n, self_collision=0):

@@ -98,6 +98,101 @@ __device__ __forceinline__ void dense_layer(const float *as, int ald, const floa
 }
 
 
+// ---- the same dense layer off the fp32 MFMA --------------------------------------------------------------------------------------
+// On gfx950 v_mfma_f32_32x32x2_f32 runs at the packed-fp32 VALU rate and shares the SIMD's time with the VALU
+// (tools/coexec_pad_probe.hip); v_mfma_f32_32x32x16_bf16 does 16 times the FLOP per clock.  An fp32 value is EXACTLY the sum of three
+// bf16 values (its 24-bit significand cut into 8-bit pieces by truncation, x = a0 + a1 + a2), and a product of two bf16 values is exact
+// in the fp32 accumulator, so
+//     a . b = a0 b0 + (a0 b1 + a1 b0) + (a0 b2 + a1 b1 + a2 b0) + [a1 b2 + a2 b1 + a2 b2 <= 3 x 2^-24 |a b|: dropped]
+// six bf16 MFMAs per 16 k-steps instead of eight fp32 ones per 16, at a quarter of the clocks each: 6/16 of the pipe time, with an error
+// at least as small as the fp32 chain's (tools/split_gemm_probe.hip: 1.3e-7 against 3.6e-7 of sum |a b|).
+// The weights are split once by the packers (NetDev::w1s / w2s); the activations stay fp32 in the k-split LDS tile and are split here,
+// per lane and block, between the loads and the MFMAs (~50 VALU operations against the ten fp32 MFMAs = 640 clocks they save).
+// Lane l = (row or column l & 31, k group g = l >> 5) supplies k = 16 b + 2 i + g, i = 0 .. 7: eight consecutive floats of half g
+// of the k-split tile; C/D layout as v_mfma_f32_32x32x2_f32.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+struct SplitA { bf16x8 p0, p1, p2; };
+__device__ __forceinline__ SplitA split8(const f32x4 &x0, const f32x4 &x1) {
+    unsigned h[8], m[8], l[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const float x = i < 4 ? x0[i] : x1[i - 4];
+        h[i] = __float_as_uint(x) & 0xffff0000u;
+        const float r1 = x - __uint_as_float(h[i]);
+        m[i] = __float_as_uint(r1) & 0xffff0000u;
+        const float r2 = r1 - __uint_as_float(m[i]);
+        l[i] = __float_as_uint(r2) & 0xffff0000u;
+    }
+    u32x4_ a, b, c;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        a[i] = (h[2 * i] >> 16) | h[2 * i + 1];
+        b[i] = (m[2 * i] >> 16) | m[2 * i + 1];
+        c[i] = (l[2 * i] >> 16) | l[2 * i + 1];
+    }
+    SplitA s;
+    s.p0 = __builtin_bit_cast(bf16x8, a); s.p1 = __builtin_bit_cast(bf16x8, b); s.p2 = __builtin_bit_cast(bf16x8, c);
+    return s;
+}
+template <int K>
+__device__ __forceinline__ void dense_layer_split(const float *as, int ald, const uint16_t *__restrict__ Ws, int wave, int lane,
+                                                  f32x16 (&acc)[1][2]) {
+    f32x16 c0[2], c1[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) { c0[j][r] = 0.f; c1[j][r] = 0.f; }
+    const int rc = lane & 31, g = lane >> 5;
+    constexpr int KH = K / 2;
+    const float *ap = as + rc * ald + g * KH;
+    // Ws[b][col][g][plane][8]: uint16 offset (((b * 256 + col) * 2 + g) * 3) * 8; as 16-byte units: ((b * 256 + col) * 2 + g) * 3
+    const u32x4_ *bp0 = reinterpret_cast<const u32x4_ *>(Ws) + ((size_t) (wave * 64 + rc) * 2 + g) * 3;
+    const u32x4_ *bp1 = bp0 + (size_t) 32 * 2 * 3;
+    constexpr int NB = K / 16, DEPTH = 4, BSTEP = 256 * 2 * 3;  // 16-byte units per block
+    static_assert(NB % DEPTH == 0, "K / 16 must be a multiple of the ring depth");
+    f32x4 a0[DEPTH], a1[DEPTH];
+    u32x4_ w[DEPTH][2][3];
+#define EVM_LOADS(q, s)                                                                    \
+    {                                                                                      \
+        a0[q] = *reinterpret_cast<const f32x4 *>(ap + 8 * (s));                            \
+        a1[q] = *reinterpret_cast<const f32x4 *>(ap + 8 * (s) + 4);                        \
+        _Pragma("unroll") for (int p = 0; p < 3; p++) {                                  \
+            w[q][0][p] = bp0[(size_t) (s) * BSTEP + p];                                    \
+            w[q][1][p] = bp1[(size_t) (s) * BSTEP + p];                                    \
+        }                                                                                  \
+    }
+#pragma unroll
+    for (int q = 0; q < DEPTH - 1; q++) EVM_LOADS(q, q)
+    __builtin_amdgcn_sched_barrier(0);
+    for (int s0 = 0; s0 < NB; s0 += DEPTH) {
+#pragma unroll
+        for (int q = 0; q < DEPTH; q++) {
+            const int sn = min(s0 + q + DEPTH - 1, NB - 1);
+            EVM_LOADS((q + DEPTH - 1) % DEPTH, sn)
+            __builtin_amdgcn_sched_barrier(0);
+            const SplitA a = split8(a0[q], a1[q]);
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const bf16x8 b0 = __builtin_bit_cast(bf16x8, w[q][j][0]), b1 = __builtin_bit_cast(bf16x8, w[q][j][1]),
+                             b2 = __builtin_bit_cast(bf16x8, w[q][j][2]);
+                c1[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p0, b2, c1[j], 0, 0, 0);
+                c1[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p1, b1, c1[j], 0, 0, 0);
+                c1[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p2, b0, c1[j], 0, 0, 0);
+                c1[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p0, b1, c1[j], 0, 0, 0);
+                c1[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p1, b0, c1[j], 0, 0, 0);
+                c0[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p0, b0, c0[j], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#undef EVM_LOADS
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[0][j][r] = c0[j][r] + c1[j][r];
+}
+
 // Workgroup barrier for LDS hand-overs only: waits for this wave's LDS operations, NOT for its global stores.
 // __syncthreads() carries a workgroup fence = s_waitcnt vmcnt(0): with activations streaming to HBM from the epilogues every
 // barrier then stalls until the wave's stores are acknowledged (~20 k cycles per layer in the training forward).

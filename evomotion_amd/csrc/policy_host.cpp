@@ -1,6 +1,7 @@
 // C ABI for the fused actor-critic forward (include/evomotion.h, evm_policy_*).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <utility>
@@ -30,7 +31,9 @@ int evm_policy_create(int state_dim, int action_dim, int hidden_size, int device
     p->S = state_dim; p->A = action_dim; p->H = hidden_size; p->device = device; p->counter = 0; p->timing = false; p->ev_used = 0; p->tile_rows = 0;
     p->K1pad = 384;  // K1 of policy_kernels.hip
     const size_t per_net = (size_t) p->K1pad * 256 + 3 * 256 + 256 * 256 + 3 * 256;
-    p->arena_floats = 2 * per_net + ((size_t) 2 * action_dim * 256 + 2 * action_dim) + (256 + 1) + 2 * 8192 + 4;
+    const size_t split_floats = ((size_t) p->K1pad + 256) * 256 * 3 / 2;  // three bf16 planes of both hidden layers' weights, as floats
+    p->arena_floats = 2 * per_net + ((size_t) 2 * action_dim * 256 + 2 * action_dim) + (256 + 1) + 2 * 8192 + 4 + 2 * split_floats + 8;
+    { const char *e = getenv("EVM_POLICY_SPLIT"); p->gemm = e ? (atoi(e) != 0) : 1; }  // EVM_POLICY_SPLIT=0: the fp32 MFMA layers (A/B runs)
     if (hipMalloc((void **) &p->arena, p->arena_floats * 4) != hipSuccess) { delete p; return pfail(EVM_E_HIP, "hipMalloc failed"); }
     if (hipMemset(p->arena, 0, p->arena_floats * 4) != hipSuccess) { hipFree(p->arena); delete p; return pfail(EVM_E_HIP, "hipMemset failed"); }
     float *b = p->arena;
@@ -41,7 +44,11 @@ int evm_policy_create(int state_dim, int action_dim, int hidden_size, int device
         n.b2 = b; b += 256; n.g2 = b; b += 256; n.be2 = b; b += 256;
         n.wh = b; b += head_w; n.bh = b; b += head_b;
     };
-    auto carve_packed = [&](evm::NetDev &n) { n.whp = b; b += 8192; };  // 16-byte aligned: behind everything else
+    auto carve_packed = [&](evm::NetDev &n) {  // 16-byte aligned: behind everything else
+        n.whp = b; b += 8192;
+        n.w1s = reinterpret_cast<const uint16_t *>(b); b += (size_t) p->K1pad * 256 * 3 / 2;
+        n.w2s = reinterpret_cast<const uint16_t *>(b); b += (size_t) 256 * 256 * 3 / 2;
+    };
     carve(p->dev.actor, (size_t) 2 * action_dim * 256, 2 * action_dim);
     carve(p->dev.critic, 256, 1);
     b = p->arena + ((b - p->arena + 3) / 4) * 4;
@@ -85,6 +92,8 @@ int evm_policy_set_weights(EvmPolicy *p, const float *h_actor, size_t n_actor, c
             for (int k = 0; k < S; k++) {
                 const int st = k >> 1, h = k & 1, s4 = st >> 2, t = st & 3;
                 w1t[(((size_t) s4 * 256 + o) * 2 + h) * 4 + t] = src[(size_t) o * S + k];
+                uint16_t *ws = reinterpret_cast<uint16_t *>(host.data() + (reinterpret_cast<const float *>(n.w1s) - p->arena)) + evm::split_index(o, k);
+                evm::bf16_split3(src[(size_t) o * S + k], ws[0], ws[8], ws[16]);
             }
         src += (size_t) 256 * S;
         memcpy(host.data() + (n.b1 - p->arena), src, 256 * 4); src += 256;
@@ -95,6 +104,8 @@ int evm_policy_set_weights(EvmPolicy *p, const float *h_actor, size_t n_actor, c
             for (int k = 0; k < 256; k++) {
                 const int st = k >> 1, h = k & 1, s4 = st >> 2, t = st & 3;
                 w2t[(((size_t) s4 * 256 + o) * 2 + h) * 4 + t] = src[(size_t) o * 256 + k];
+                uint16_t *ws = reinterpret_cast<uint16_t *>(host.data() + (reinterpret_cast<const float *>(n.w2s) - p->arena)) + evm::split_index(o, k);
+                evm::bf16_split3(src[(size_t) o * 256 + k], ws[0], ws[8], ws[16]);
             }
         src += 256 * 256;
         memcpy(host.data() + (n.b2 - p->arena), src, 256 * 4); src += 256;
@@ -149,7 +160,7 @@ int evm_policy_forward(EvmPolicy *p, int n, const float *d_obs, const float *d_u
         (void) hipEventRecord(p->ev_pairs[p->ev_used].first, s);
     }
     hipError_t e = evm::launch_policy_forward(p->dev, n, d_obs, d_uniform, seed, p->counter++, d_action, d_logp, d_value,
-                                              d_mu, d_sigma, s, p->tile_rows);
+                                              d_mu, d_sigma, s, p->tile_rows, p->gemm);
     if (e != hipSuccess) return pfail(EVM_E_HIP, std::string("policy forward: ") + hipGetErrorString(e));
     if (p->timing) { (void) hipEventRecord(p->ev_pairs[p->ev_used].second, s); p->ev_used++; }
     return EVM_OK;

@@ -38,6 +38,7 @@ __device__ __forceinline__ float rng_uniform(uint64_t seed, uint64_t counter, ui
     return (float) (uint32_t) (z >> 40) * (1.0f / 16777216.0f);
 }
 
+template <int SPLIT>  // 0: fp32 MFMA layers, 1: six bf16 products per fp32 product (dense_layer_split)
 __global__ __launch_bounds__(PT) void k_policy_forward(PolicyDev p, int n, const float *__restrict__ obs,
                                                        const float *__restrict__ uniform, uint64_t seed, uint64_t counter,
                                                        float *action, float *logp, float *value, float *mu_out,
@@ -64,11 +65,13 @@ __global__ __launch_bounds__(PT) void k_policy_forward(PolicyDev p, int n, const
     __syncthreads();
     PSTAMP(1)
     f32x16 acc[RT][2];
-    dense_layer<K1, RT>(xs, ALD1, N.w1t, wave, lane, acc);
+    if (SPLIT) dense_layer_split<K1>(xs, ALD1, N.w1s, wave, lane, acc);
+    else dense_layer<K1, RT>(xs, ALD1, N.w1t, wave, lane, acc);
     PSTAMP(2)
     mish_ln_epilogue(acc[0], N.b1, N.g1, N.be1, hb, red, wave, lane, row0, n, nullptr, nullptr, nullptr, 0, 0);
     PSTAMP(3)
-    dense_layer<256, RT>(hb, ALD2, N.w2t, wave, lane, acc);
+    if (SPLIT) dense_layer_split<256>(hb, ALD2, N.w2s, wave, lane, acc);
+    else dense_layer<256, RT>(hb, ALD2, N.w2t, wave, lane, acc);
     PSTAMP(4)
     mish_ln_epilogue(acc[0], N.b2, N.g2, N.be2, hb, red, wave, lane, row0, n, nullptr, nullptr, nullptr, 0, 0);
     PSTAMP(5)
@@ -270,11 +273,12 @@ static bool &evm_attr_done_for_current_device() {
 
 size_t policy_lds_bytes() { return (size_t) (POLICY_TILE_FLOATS + EVM_RED_FLOATS) * sizeof(float); }
 
-// Tile height of a launch: 16 rows while the 32-row grid has at most one workgroup per CU (measured at 4096 rows,
-// tools/policy_tiles.py: both networks 33.7 against 35.2 us, actor only 20.5 against 34.7 us; from two 32-row workgroups per
-// CU on the forms are level and the 32-row one reads each weight half as often); EVM_POLICY_TILE = 16 | 32 (read once)
-// forces one form, for measurements.
-static int policy_tile_rows(int n, int nets, int asked) {
+// Form of a launch.  32-row tiles run their layers as six bf16 MFMA products per fp32 product (dense_layer_split: 28.9 us for both
+// networks at 4096 rows against 35.2 us on the fp32 MFMA) unless gemm == 0; 16-row tiles (fp32 MFMA) take over while the 32-row grid
+// would leave CUs WITHOUT a workgroup (actor only at 4096 rows: 20.7 against 26.8 us; 2048 rows: 21 us) — with fp32 MFMA layers
+// (gemm == 0) already when it has no more than one per CU (33.0 against 35.2 us).  EVM_POLICY_TILE = 16 | 32 (read once) or
+// evm_policy_set_tile_rows force a tile height, for measurements and tests.
+static int policy_tile_rows(int n, int nets, int asked, int gemm) {
     static int forced = -1, cus[64] = {};
     if (asked == 16 || asked == 32) return asked;
     if (forced < 0) {
@@ -290,28 +294,36 @@ static int policy_tile_rows(int n, int nets, int asked) {
         if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c < 1) c = 256;
         cus[dev] = c;
     }
-    return ((n + TM - 1) / TM) * nets <= cus[dev] ? 16 : 32;
+    const int wg32 = ((n + TM - 1) / TM) * nets;
+    return (gemm == 1 ? wg32 < cus[dev] : wg32 <= cus[dev]) ? 16 : 32;
 }
 
 hipError_t launch_policy_forward(const PolicyDev &p, int n, const float *obs, const float *uniform, uint64_t seed,
                                  uint64_t counter, float *action, float *logp, float *value, float *mu, float *sigma,
-                                 hipStream_t s, int tile_rows) {
+                                 hipStream_t s, int tile_rows, int gemm) {
     bool &attr = evm_attr_done_for_current_device();
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_policy_forward),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_policy_forward<0>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int) policy_lds_bytes());
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_policy_forward<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int) policy_lds_bytes());
         if (e != hipSuccess) return e;
         attr = true;
     }
     const int nets = value ? 2 : 1;  // value == NULL: the critic network is not run (SAC's act)
-    if (policy_tile_rows(n, nets, tile_rows) == 16) {
+    if (policy_tile_rows(n, nets, tile_rows, gemm) == 16) {
         hipLaunchKernelGGL(k_policy_forward16, dim3((n + TM16 - 1) / TM16, nets), dim3(PT), policy_lds16_bytes(), s, p, n, obs,
                            uniform, seed, counter, action, logp, value, mu, sigma);
         return hipGetLastError();
     }
     dim3 grid((n + TM - 1) / TM, nets);
-    hipLaunchKernelGGL(k_policy_forward, grid, dim3(PT), policy_lds_bytes(), s, p, n, obs, uniform, seed, counter, action,
-                       logp, value, mu, sigma);
+    if (gemm == 1)
+        hipLaunchKernelGGL(k_policy_forward<1>, grid, dim3(PT), policy_lds_bytes(), s, p, n, obs, uniform, seed, counter, action,
+                           logp, value, mu, sigma);
+    else
+        hipLaunchKernelGGL(k_policy_forward<0>, grid, dim3(PT), policy_lds_bytes(), s, p, n, obs, uniform, seed, counter, action,
+                           logp, value, mu, sigma);
     return hipGetLastError();
 }
 

@@ -206,9 +206,10 @@ int evm_policy_set_weights_device(EvmPolicy *p, const float *d_actor, const floa
 int evm_policy_forward(EvmPolicy *p, int n, const float *d_obs, const float *d_uniform, uint64_t seed, float *d_action,
                        float *d_logp, float *d_value, float *d_mu, float *d_sigma, void *stream);
 
-/* Rows per workgroup tile of evm_policy_forward: 0 (default) = 16 rows on v_mfma_f32_16x16x4_f32 while 32-row tiles would give
- * the device at most one workgroup per CU (up to 4096 rows with both networks, 8192 actor only), 32 rows on
- * v_mfma_f32_32x32x2_f32 beyond;
+/* Rows per workgroup tile of evm_policy_forward: 0 (default) = 32 rows, the hidden layers as six bf16 MFMA products per fp32
+ * product (weights and activations cut exactly into three bf16 planes; error of the order of fp32 rounding — the fp32 matrix
+ * pipe of gfx950 is its vector pipe; EVM_POLICY_SPLIT=0 at creation: v_mfma_f32_32x32x2_f32 instead), except 16 rows on
+ * v_mfma_f32_16x16x4_f32 while 32-row tiles would leave CUs without a workgroup (below 4096 rows with both networks, 8192 actor only);
  * 16 / 32 force one form (measurements, tests).  The two forms agree to fp32 rounding (another k order), not bit for bit. */
 int evm_policy_set_tile_rows(EvmPolicy *p, int rows);
 
