@@ -25,6 +25,9 @@ __device__ unsigned long long g_fstamps[8192 * 4 * 8];
 #else
 #define FSTAMP
 #endif
+#ifndef EVM_PPO_FWD_SPLIT
+#define EVM_PPO_FWD_SPLIT 0   // 1: the training forward's hidden layers as six bf16 MFMA products per fp32 product (dense_layer_split)
+#endif
 template <int RT>
 __global__ __launch_bounds__(PT) void k_ppo_forward(PolicyDev p, PpoDev d, int n, const float *__restrict__ states) {
     constexpr int TM = 32 * RT, PARTS = PT / TM, RUN = 256 / PARTS;
@@ -45,11 +48,13 @@ __global__ __launch_bounds__(PT) void k_ppo_forward(PolicyDev p, PpoDev d, int n
     FSTAMP
     f32x16 acc[RT][2];
     float *red = sm + TM * ALD1;  // behind both tiles
-    dense_layer<K1, RT>(xs, ALD1, N.w1t, wave, lane, acc);
+    if constexpr (EVM_PPO_FWD_SPLIT && RT == 1) dense_layer_split<K1>(xs, ALD1, N.w1s, wave, lane, acc);
+    else dense_layer<K1, RT>(xs, ALD1, N.w1t, wave, lane, acc);
     FSTAMP
     train_epilogue<RT>(acc, N.b1, N.g1, N.be1, hb, red, wave, lane, row0, n, B.z1, B.a1, B.st, 0, 4);
     FSTAMP
-    dense_layer<256, RT>(hb, ALD2, N.w2t, wave, lane, acc);
+    if constexpr (EVM_PPO_FWD_SPLIT && RT == 1) dense_layer_split<256>(hb, ALD2, N.w2s, wave, lane, acc);
+    else dense_layer<256, RT>(hb, ALD2, N.w2t, wave, lane, acc);
     FSTAMP
     train_epilogue<RT>(acc, N.b2, N.g2, N.be2, hb, red, wave, lane, row0, n, B.z2, B.a2, B.st, 2, 4);
     FSTAMP

@@ -194,6 +194,51 @@ def test_16_row_tiles_equal_32_row_tiles_to_rounding(fused, gold):
         f.set_tile_rows(0)
 
 
+def test_bf16_split_layers_equal_fp32_mfma_layers_to_rounding(fused, gold, monkeypatch):
+    """The 32-row form runs its hidden layers as six bf16 MFMA products per fp32 product (exact three-way split of both operands);
+    EVM_POLICY_SPLIT=0 at creation keeps the fp32 MFMA.  Same weights (host packer and device repack), same inputs: outputs agree to
+    fp32 rounding, and the split form is held to the reference's golden vectors like the other."""
+    import torch
+    from evomotion_amd import ActorModule, CriticModule, FusedActorCritic
+    f, pa, pc = fused
+    monkeypatch.setenv("EVM_POLICY_SPLIT", "0")
+    f0 = FusedActorCritic(371, 12, 256, 0)
+    monkeypatch.delenv("EVM_POLICY_SPLIT")
+    f1 = FusedActorCritic(371, 12, 256, 0)
+    flat = lambda prm, shapes: np.concatenate([prm[n].ravel() for n, _ in shapes])
+    for g_ in (f0, f1):
+        g_.set_weights(flat(pa, ao.ACTOR_SHAPES), flat(pc, ao.CRITIC_SHAPES))
+        g_.set_tile_rows(32)
+    gen = torch.Generator(device="cpu").manual_seed(123)
+    for n in (1, 33, 4096):
+        x = ((torch.rand(n, 371, generator=gen) * 2 - 1) * 3).cuda()
+        u = torch.rand(n, 12, generator=gen).cuda()
+        r0 = f0.forward(x, uniform=u, want_dist=True)
+        r1 = f1.forward(x, uniform=u, want_dist=True)
+        for name, a, b, tol in zip(("action", "logp", "value", "mu", "sigma"), r0, r1, (2e-4, 2e-4, 2e-5, 5e-6, 5e-6)):
+            assert float((a - b).abs().max()) <= tol, (n, name, float((a - b).abs().max()))
+    x = torch.from_numpy(gold["X"]).cuda()
+    u = torch.full((8, 12), 0.5, device="cuda")
+    _, _, value, mu, sigma = f1.forward(x, uniform=u, want_dist=True)
+    np.testing.assert_allclose(mu.cpu().numpy(), gold["mu"], atol=2e-5)
+    np.testing.assert_allclose(sigma.cpu().numpy(), gold["sigma"], atol=2e-5, rtol=2e-5)
+    np.testing.assert_allclose(value.cpu().numpy()[:, None], gold["value"], atol=5e-5)
+    # the device-side repack writes the same planes as the host packer
+    a, c = ActorModule([371], [12], 256).cuda(), CriticModule([371], 256).cuda()
+    with torch.no_grad():
+        for n_, p_ in a.named_parameters():
+            p_.copy_(torch.from_numpy(pa[n_]))
+        for n_, p_ in c.named_parameters():
+            p_.copy_(torch.from_numpy(pc[n_]))
+    f2 = FusedActorCritic(371, 12, 256, 0)
+    f2.load_modules(a, c)
+    f2.set_tile_rows(32)
+    x = ((torch.rand(64, 371, generator=gen) * 2 - 1)).cuda()
+    u = torch.rand(64, 12, generator=gen).cuda()
+    for r, o in zip(f1.forward(x, uniform=u, want_dist=True), f2.forward(x, uniform=u, want_dist=True)):
+        assert torch.equal(r, o)
+
+
 def test_device_side_weight_repack_equals_host_packing(fused):
     import torch
     from evomotion_amd import ActorModule, CriticModule, FusedActorCritic
