@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run ON THE GPU BOX: GPU tests + the bench lines of every mode + kernel statistics of the training benches (tag r4u).
 set -u
-R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; TAG=r4u
+TAG=${1:-r4u}; R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out
 cd $R
 timeout -k 10 400 python -m pytest tests -m gpu -x -q > $O/${TAG}_gputests.log 2>&1; echo "gpu tests rc=$?"; tail -1 $O/${TAG}_gputests.log
 timeout -k 10 200 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/${TAG}_bench20.json 2> $O/${TAG}_bench20.err; echo "bench20 rc=$?"
