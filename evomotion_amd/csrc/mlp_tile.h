@@ -392,6 +392,64 @@ __device__ __forceinline__ void dense_layer16(const float *as, int ald, const fl
     }
 }
 
+// dense_layer16 off the fp32 MFMA (see dense_layer_split): v_mfma_f32_16x16x32_bf16, lane = (row or column c = l & 15, k group
+// kg = l >> 4: eight k).  The weight planes of NetDev::w1s / w2s serve as they are: 32-k block bb = their 16-k blocks 2 bb + (kg >> 1),
+// group kg & 1; the lane's eight A values are eight consecutive floats of half (kg & 1) of the k-split tile, from 16 bb + 8 (kg >> 1).
+template <int K>
+__device__ __forceinline__ void dense_layer16_split(const float *as, int ald, const uint16_t *__restrict__ Ws, int wave, int lane,
+                                                    f32x4c (&acc)[4]) {
+    f32x4c c0[4], c1[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) { c0[j][r] = 0.f; c1[j][r] = 0.f; }
+    const int c = lane & 15, kg = lane >> 4;
+    constexpr int KH = K / 2;
+    const float *ap = as + c * ald + (kg & 1) * KH + 8 * (kg >> 1);
+    // 16-byte units: ((b16 * 256 + col) * 2 + g) * 3 + plane, b16 = 2 bb + (kg >> 1)
+    const u32x4_ *bp = reinterpret_cast<const u32x4_ *>(Ws) + (((size_t) (kg >> 1) * 256 + wave * 64 + c) * 2 + (kg & 1)) * 3;
+    constexpr int NB = K / 32, DEPTH = 2, BSTEP = 2 * 256 * 2 * 3, JSTEP = 16 * 2 * 3;
+    static_assert(NB % DEPTH == 0, "K / 32 must be a multiple of the ring depth");
+    f32x4 a0[DEPTH], a1[DEPTH];
+    u32x4_ w[DEPTH][4][3];
+#define EVM_LOADS16(q, s)                                                                  \
+    {                                                                                      \
+        a0[q] = *reinterpret_cast<const f32x4 *>(ap + 16 * (s));                           \
+        a1[q] = *reinterpret_cast<const f32x4 *>(ap + 16 * (s) + 4);                       \
+        _Pragma("unroll") for (int j = 0; j < 4; j++)                                    \
+            _Pragma("unroll") for (int p = 0; p < 3; p++) w[q][j][p] = bp[(size_t) (s) * BSTEP + j * JSTEP + p]; \
+    }
+#pragma unroll
+    for (int q = 0; q < DEPTH - 1; q++) EVM_LOADS16(q, q)
+    __builtin_amdgcn_sched_barrier(0);
+    for (int s0 = 0; s0 < NB; s0 += DEPTH) {
+#pragma unroll
+        for (int q = 0; q < DEPTH; q++) {
+            const int sn = min(s0 + q + DEPTH - 1, NB - 1);
+            EVM_LOADS16((q + DEPTH - 1) % DEPTH, sn)
+            __builtin_amdgcn_sched_barrier(0);
+            const SplitA a = split8(a0[q], a1[q]);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const bf16x8 b0 = __builtin_bit_cast(bf16x8, w[q][j][0]), b1 = __builtin_bit_cast(bf16x8, w[q][j][1]),
+                             b2 = __builtin_bit_cast(bf16x8, w[q][j][2]);
+                c1[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.p0, b2, c1[j], 0, 0, 0);
+                c1[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.p1, b1, c1[j], 0, 0, 0);
+                c1[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.p2, b0, c1[j], 0, 0, 0);
+                c1[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.p0, b1, c1[j], 0, 0, 0);
+                c1[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.p1, b0, c1[j], 0, 0, 0);
+                c0[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.p0, b0, c0[j], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#undef EVM_LOADS16
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc[j][r] = c0[j][r] + c1[j][r];
+}
+
 // sum over the 16 lanes of each DPP row, result in every lane of the row
 __device__ __forceinline__ float row16_sum(float v) {
 #define EVM_DPP_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false));
